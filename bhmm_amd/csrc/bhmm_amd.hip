@@ -1,0 +1,709 @@
+// bhmm_amd.hip -- C ABI (include/bhmm_amd.h) over the gfx950 kernels: context management,
+// chunk planning, launches.  Host code only orchestrates; all arithmetic on trajectories is
+// in estep_kernels.hpp / path_kernels.hpp.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ctx.hpp"
+#include "estep_kernels.hpp"
+
+namespace bhmm {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? BHMM_ERR_NO_MEM : BHMM_ERR_HIP;
+}
+
+static int invalid(const std::string &msg)
+{
+    g_err = msg;
+    return BHMM_ERR_INVALID;
+}
+
+static int pad_states(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : 8); }
+
+// ---- model marshalling -----------------------------------------------------------------
+template <int N>
+static void fill_model(Model<N> &m, int n, int kind, int M, const double *A, const double *pi,
+                       const double *par0, const double *par1)
+{
+    memset(&m, 0, sizeof(m));
+    m.nreal = n;
+    m.M = M;
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j)
+            m.A[i * N + j] = (i < n && j < n) ? A[i * n + j] : (i == j ? 1.0 : 0.0);
+    for (int i = 0; i < n; ++i)
+        m.pi[i] = pi ? pi[i] : 0.0;
+    if (kind == EMIT_GAUSS)
+        for (int i = 0; i < n; ++i) {
+            m.e0[i] = par0[i];
+            m.e1[i] = 1.0 / par1[i];
+            m.e2[i] = 1.0 / (sqrt(2.0 * M_PI) * par1[i]); // _gaussian.c:18
+        }
+}
+
+static Chunks chunks_of(const bhmm_ctx *c)
+{
+    Chunks ch;
+    ch.traj = c->d_ctraj.p;
+    ch.t0 = c->d_ct0.p;
+    ch.len = c->d_clen.p;
+    ch.goff = c->d_cgoff.p;
+    ch.Lmax = c->Lmax;
+    return ch;
+}
+
+template <int N, int KIND>
+static size_t smem_fwdbwd(int M)
+{
+    return (size_t)(4 * StatLayout<N, KIND>::S + (KIND == EMIT_DISC ? 2 * M * N : 0)) *
+           sizeof(double);
+}
+
+// One E-step launch sequence for a fixed padded N.
+template <int N>
+struct Runner {
+    template <int KIND>
+    static int prescan_stitch(bhmm_ctx *c, const Model<N> &m)
+    {
+        const Chunks ch = chunks_of(c);
+        const int nblk = c->Gp / BLOCK;
+        const size_t sm0 = KIND == EMIT_DISC ? (size_t)c->M * N * sizeof(double) : 0;
+        BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
+        hipLaunchKernelGGL((k_prescan<N, KIND>), dim3(nblk), dim3(BLOCK), sm0, c->stream, m, ch,
+                           (const void *)c->d_obs_ci.p, (const double *)c->d_Bt.p, c->d_M.p);
+        BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
+        const int gp = 64 / N;
+        const int nb = (c->K + gp - 1) / gp;
+        hipLaunchKernelGGL((k_stitch<N>), dim3(2 * nb), dim3(64), 0, c->stream,
+                           (const int32_t *)c->d_traj_c0.p, c->K, nb, c->n,
+                           (const double *)c->d_M.p, c->d_aentry.p, c->d_bexit.p);
+        BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
+        return BHMM_OK;
+    }
+
+    template <int KIND, int MODE>
+    static int fwdbwd(bhmm_ctx *c, const Model<N> &m, bool store_gamma)
+    {
+        const Chunks ch = chunks_of(c);
+        const int nblk = c->Gp / BLOCK;
+        const size_t sm = smem_fwdbwd<N, KIND>(c->M);
+        if (sm > 64 * 1024)
+            BHMM_HIP(hipFuncSetAttribute((const void *)(k_fwdbwd<N, KIND, MODE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        hipLaunchKernelGGL((k_fwdbwd<N, KIND, MODE>), dim3(nblk), dim3(BLOCK), sm, c->stream, m, ch,
+                           (const void *)c->d_obs_ci.p, (const double *)c->d_Bt.p,
+                           (const double *)c->d_aentry.p, (const double *)c->d_bexit.p, c->d_ws.p,
+                           store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
+                           c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p);
+        BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
+        return BHMM_OK;
+    }
+
+    template <int KIND>
+    static int estep_kind(bhmm_ctx *c, const Model<N> &m, double *stats_dev, int flags)
+    {
+        int rc = prescan_stitch<KIND>(c, m);
+        if (rc)
+            return rc;
+        rc = fwdbwd<KIND, MODE_ESTEP>(c, m, (flags & BHMM_FLAG_STORE_GAMMA) != 0);
+        if (rc)
+            return rc;
+        hipLaunchKernelGGL(k_logl, dim3((c->K + 255) / 256), dim3(256), 0, c->stream,
+                           (const int32_t *)c->d_traj_c0.p, c->K, (const double *)c->d_logLc.p,
+                           c->d_logLk.p);
+        BHMM_HIP(hipGetLastError());
+        hipLaunchKernelGGL((k_finalize<N, KIND>), dim3(1), dim3(BLOCK), 0, c->stream, m, c->K,
+                           c->Gp / BLOCK, (const double *)c->d_partials.p,
+                           (const double *)c->d_dpartials.p, (const double *)c->d_logLk.p,
+                           (const double *)c->d_gamma0.p, stats_dev);
+        BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
+        c->ev_pending = true;
+        return BHMM_OK;
+    }
+
+    static int estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                     const double *par1, double *stats_dev, int flags)
+    {
+        Model<N> m;
+        fill_model<N>(m, c->n, c->kind, c->M, A, pi, par0, par1);
+        switch (c->kind) {
+        case EMIT_GAUSS:
+            return estep_kind<EMIT_GAUSS>(c, m, stats_dev, flags);
+        case EMIT_DISC:
+            return estep_kind<EMIT_DISC>(c, m, stats_dev, flags);
+        default:
+            return estep_kind<EMIT_EXPL>(c, m, stats_dev, flags);
+        }
+    }
+
+    // forward-only / backward-only passes on explicit pobs (hidden/api.py forward, backward)
+    template <int MODE>
+    static int sweep_explicit(bhmm_ctx *c, const double *A, const double *pi)
+    {
+        Model<N> m;
+        fill_model<N>(m, c->n, EMIT_EXPL, 0, A, pi, nullptr, nullptr);
+        int rc = prescan_stitch<EMIT_EXPL>(c, m);
+        if (rc)
+            return rc;
+        rc = fwdbwd<EMIT_EXPL, MODE>(c, m, false);
+        if (rc)
+            return rc;
+        if (MODE == MODE_FWD) {
+            hipLaunchKernelGGL(k_logl, dim3((c->K + 255) / 256), dim3(256), 0, c->stream,
+                               (const int32_t *)c->d_traj_c0.p, c->K,
+                               (const double *)c->d_logLc.p, c->d_logLk.p);
+            BHMM_HIP(hipGetLastError());
+        }
+        return BHMM_OK;
+    }
+
+    static int pack_rows(bhmm_ctx *c, const double *src_dev)
+    {
+        hipLaunchKernelGGL((k_pack_rows<N>), dim3(c->Gp / BLOCK), dim3(BLOCK), 0, c->stream,
+                           chunks_of(c), src_dev, c->n, reinterpret_cast<double *>(c->d_obs_ci.p));
+        BHMM_HIP(hipGetLastError());
+        return BHMM_OK;
+    }
+
+    static int unpack_rows(bhmm_ctx *c, const double *src_ci, double *dst_dev, int only_traj,
+                           int64_t shift)
+    {
+        hipLaunchKernelGGL((k_unpack_rows<N>), dim3(c->Gp / BLOCK), dim3(BLOCK), 0, c->stream,
+                           chunks_of(c), src_ci, c->n, dst_dev, only_traj, shift);
+        BHMM_HIP(hipGetLastError());
+        return BHMM_OK;
+    }
+};
+
+#define BHMM_DISPATCH_N(c, expr)            \
+    ((c)->N == 2 ? Runner<2>::expr          \
+     : (c)->N == 4 ? Runner<4>::expr        \
+                   : Runner<8>::expr)
+
+// ---- chunk planning ----------------------------------------------------------------------
+// Every trajectory is cut into ceil(T/L) chunks whose lengths differ by at most one.
+static int plan_chunks(bhmm_ctx *c, int chunk)
+{
+    const int K = c->K;
+    int L = chunk;
+    if (L <= 0) {
+        // aim for ~2 wavefronts per SIMD on 256 CUs: 2 * 1024 * 64 lanes
+        const int64_t target = 131072;
+        int64_t l = (c->total + target - 1) / target;
+        L = (int)std::min<int64_t>(std::max<int64_t>(l, 32), 4096);
+    }
+    c->L = L;
+    std::vector<int32_t> ctraj, clen;
+    std::vector<int64_t> ct0, cgoff;
+    c->traj_c0.assign(K + 1, 0);
+    int Lmax = 1;
+    for (int k = 0; k < K; ++k) {
+        const int64_t T = c->offsets[k + 1] - c->offsets[k];
+        c->traj_c0[k] = (int32_t)ctraj.size();
+        if (T <= 0)
+            continue;
+        const int64_t nck = (T + L - 1) / L;
+        const int64_t base = T / nck, rem = T % nck;
+        if ((int64_t)ctraj.size() + nck > (int64_t)1 << 30)
+            return invalid("too many chunks");
+        for (int64_t q = 0; q < nck; ++q) {
+            const int64_t len = base + (q < rem ? 1 : 0);
+            const int64_t t0 = q * base + std::min(q, rem);
+            ctraj.push_back(k);
+            clen.push_back((int32_t)len);
+            ct0.push_back(t0);
+            cgoff.push_back(c->offsets[k] + t0);
+            Lmax = std::max<int>(Lmax, (int)len);
+        }
+    }
+    c->traj_c0[K] = (int32_t)ctraj.size();
+    c->G = (int)ctraj.size();
+    c->Gp = std::max(BLOCK, (c->G + BLOCK - 1) / BLOCK * BLOCK);
+    c->Lmax = Lmax;
+    ctraj.resize(c->Gp, 0);
+    clen.resize(c->Gp, 0);
+    ct0.resize(c->Gp, 1);
+    cgoff.resize(c->Gp, 0);
+    int rc;
+    if ((rc = c->d_ctraj.ensure(c->Gp)) || (rc = c->d_clen.ensure(c->Gp)) ||
+        (rc = c->d_ct0.ensure(c->Gp)) || (rc = c->d_cgoff.ensure(c->Gp)) ||
+        (rc = c->d_traj_c0.ensure(K + 1)))
+        return rc;
+    BHMM_HIP(hipMemcpy(c->d_ctraj.p, ctraj.data(), c->Gp * sizeof(int32_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_clen.p, clen.data(), c->Gp * sizeof(int32_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_ct0.p, ct0.data(), c->Gp * sizeof(int64_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_cgoff.p, cgoff.data(), c->Gp * sizeof(int64_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_traj_c0.p, c->traj_c0.data(), (K + 1) * sizeof(int32_t),
+                       hipMemcpyHostToDevice));
+    return BHMM_OK;
+}
+
+static int64_t ci_records(const bhmm_ctx *c) { return (int64_t)(c->Gp / 64) * c->Lmax; }
+
+static int stats_size(const bhmm_ctx *c)
+{
+    const int n = c->n;
+    int s = 1 + n + n * n + n;
+    if (c->kind == EMIT_GAUSS)
+        s += 2 * n;
+    else if (c->kind == EMIT_DISC)
+        s += n * c->M;
+    return s;
+}
+
+static int alloc_work(bhmm_ctx *c)
+{
+    const int N = c->N;
+    int rc;
+    const int S = N * N + 3 * N;
+    if ((rc = c->d_M.ensure((size_t)c->Gp * (N * N + N))) ||
+        (rc = c->d_aentry.ensure((size_t)c->Gp * N)) || (rc = c->d_bexit.ensure((size_t)c->Gp * N)) ||
+        (rc = c->d_ws.ensure((size_t)ci_records(c) * N * 64)) ||
+        (rc = c->d_logLc.ensure(c->Gp)) || (rc = c->d_logLk.ensure(std::max(c->K, 1))) ||
+        (rc = c->d_gamma0.ensure((size_t)std::max(c->K, 1) * N)) ||
+        (rc = c->d_partials.ensure((size_t)(c->Gp / BLOCK) * S)) ||
+        (rc = c->d_stats.ensure(stats_size(c))))
+        return rc;
+    if (c->kind == EMIT_DISC) {
+        if ((rc = c->d_dpartials.ensure((size_t)(c->Gp / BLOCK) * c->M * N)) ||
+            (rc = c->d_Bt.ensure((size_t)c->M * N)))
+            return rc;
+    }
+    // chunks past G (padding) never write logL: clear once
+    BHMM_HIP(hipMemsetAsync(c->d_logLc.p, 0, c->Gp * sizeof(double), c->stream));
+    BHMM_HIP(hipMemsetAsync(c->d_gamma0.p, 0, (size_t)std::max(c->K, 1) * N * sizeof(double),
+                            c->stream));
+    const size_t need = (size_t)stats_size(c) + c->K;
+    if (need > c->h_pinned_n) {
+        if (c->h_pinned)
+            (void)hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr;
+        BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), need * sizeof(double),
+                               hipHostMallocDefault));
+        c->h_pinned_n = need;
+    }
+    return BHMM_OK;
+}
+
+static int upload_Bt(bhmm_ctx *c, const double *B)
+{
+    std::vector<double> bt((size_t)c->M * c->N, 0.0);
+    for (int i = 0; i < c->n; ++i)
+        for (int o = 0; o < c->M; ++o)
+            bt[(size_t)o * c->N + i] = B[(size_t)i * c->M + o];
+    BHMM_HIP(hipMemcpyAsync(c->d_Bt.p, bt.data(), bt.size() * sizeof(double),
+                            hipMemcpyHostToDevice, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream)); // bt is a temporary
+    return BHMM_OK;
+}
+
+static void collect_timing(bhmm_ctx *c)
+{
+    if (!c->ev_pending)
+        return;
+    c->ev_pending = false;
+    float ms = 0.f;
+    for (int i = 0; i < 4; ++i)
+        if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess)
+            c->last_ms[i] = ms;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess)
+        c->last_ms[4] = ms;
+    (void)hipGetLastError();
+}
+
+} // namespace bhmm
+
+using namespace bhmm;
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char *bhmm_last_error(void) { return g_err.c_str(); }
+
+const char *bhmm_version(void) { return "bhmm_amd 0.1 gfx950"; }
+
+int bhmm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int bhmm_ctx_create(bhmm_ctx **out, int device, void *stream)
+{
+    if (!out)
+        return invalid("out == NULL");
+    *out = nullptr;
+    int ndev = bhmm_device_count();
+    if (ndev <= 0) {
+        g_err = "no HIP device visible";
+        return BHMM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev)
+        return invalid("device ordinal out of range");
+    BHMM_HIP(hipSetDevice(device));
+    bhmm_ctx *c = new (std::nothrow) bhmm_ctx();
+    if (!c)
+        return BHMM_ERR_NO_MEM;
+    c->device = device;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return hip_fail(e, "hipStreamCreate");
+        }
+        c->own_stream = true;
+    }
+    for (auto &ev : c->ev) {
+        hipError_t e = hipEventCreate(&ev);
+        if (e != hipSuccess) {
+            bhmm_ctx_destroy(c);
+            return hip_fail(e, "hipEventCreate");
+        }
+    }
+    *out = c;
+    return BHMM_OK;
+}
+
+int bhmm_ctx_destroy(bhmm_ctx *c)
+{
+    if (!c)
+        return BHMM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    c->d_ctraj.release();
+    c->d_clen.release();
+    c->d_traj_c0.release();
+    c->d_ct0.release();
+    c->d_cgoff.release();
+    c->d_obs_ci.release();
+    c->d_obs_rm.release();
+    c->d_Bt.release();
+    c->d_M.release();
+    c->d_aentry.release();
+    c->d_bexit.release();
+    c->d_ws.release();
+    c->d_gamma_ci.release();
+    c->d_logLc.release();
+    c->d_logLk.release();
+    c->d_gamma0.release();
+    c->d_partials.release();
+    c->d_dpartials.release();
+    c->d_stats.release();
+    c->d_scratch.release();
+    c->d_scratch2.release();
+    if (c->h_pinned)
+        (void)hipHostFree(c->h_pinned);
+    for (auto &ev : c->ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (c->own_stream && c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+    return BHMM_OK;
+}
+
+int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int64_t *offsets, int K,
+                              int nstates, int nsymbols, int chunk, int obs_on_device)
+{
+    if (!c || !offsets || K < 1)
+        return invalid("bad context / offsets / K");
+    if (kind < 0 || kind > 2)
+        return invalid("unknown emission kind");
+    if (nstates < 1 || nstates > 8)
+        return invalid("this build handles 1..8 hidden states on the lane-per-chunk path");
+    if (kind == BHMM_EMIT_DISCRETE && nsymbols < 1)
+        return invalid("nsymbols must be >= 1 for discrete emissions");
+    BHMM_HIP(hipSetDevice(c->device));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    c->kind = kind;
+    c->n = nstates;
+    c->N = pad_states(nstates);
+    c->M = kind == BHMM_EMIT_DISCRETE ? nsymbols : 0;
+    c->K = K;
+    for (int k = 0; k < K; ++k)
+        if (offsets[k + 1] < offsets[k])
+            return invalid("offsets must be non-decreasing");
+    c->offsets.resize(K + 1);
+    for (int k = 0; k <= K; ++k) // positions relative to the first element handed over
+        c->offsets[k] = offsets[k] - offsets[0];
+    c->total = c->offsets[K];
+    if (c->total <= 0)
+        return invalid("no observations");
+    if (obs == nullptr)
+        return invalid("obs == NULL");
+    c->gamma_valid = false;
+    if (kind == BHMM_EMIT_DISCRETE) {
+        const size_t sm = smem_fwdbwd<8, EMIT_DISC>(c->M);
+        if (sm > 160 * 1024)
+            return invalid("discrete alphabet too large for the LDS-resident tables");
+    }
+    int rc = plan_chunks(c, chunk);
+    if (rc)
+        return rc;
+    if ((rc = alloc_work(c)))
+        return rc;
+
+    // bring the trajectory-major observations to the device, then re-lay them out CI
+    const size_t esz = kind == BHMM_EMIT_GAUSSIAN ? sizeof(double)
+                       : kind == BHMM_EMIT_DISCRETE ? sizeof(int32_t)
+                                                    : sizeof(double) * (size_t)c->n;
+    const size_t bytes = (size_t)c->total * esz;
+    const char *src_dev;
+    const char *base = static_cast<const char *>(obs) + (size_t)offsets[0] * esz;
+    if (obs_on_device) {
+        src_dev = base;
+    } else {
+        if ((rc = c->d_obs_rm.ensure(bytes)))
+            return rc;
+        BHMM_HIP(hipMemcpyAsync(c->d_obs_rm.p, base, bytes, hipMemcpyHostToDevice, c->stream));
+        src_dev = c->d_obs_rm.p;
+    }
+    const size_t ci_elems = (size_t)ci_records(c) * 64;
+    const Chunks ch = chunks_of(c);
+    const int nblk = c->Gp / BLOCK;
+    if (kind == BHMM_EMIT_GAUSSIAN) {
+        if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(double))))
+            return rc;
+        hipLaunchKernelGGL((k_pack_scalar<double>), dim3(nblk), dim3(BLOCK), 0, c->stream, ch,
+                           reinterpret_cast<const double *>(src_dev),
+                           reinterpret_cast<double *>(c->d_obs_ci.p));
+    } else if (kind == BHMM_EMIT_DISCRETE) {
+        if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(int32_t))))
+            return rc;
+        hipLaunchKernelGGL((k_pack_scalar<int32_t>), dim3(nblk), dim3(BLOCK), 0, c->stream, ch,
+                           reinterpret_cast<const int32_t *>(src_dev),
+                           reinterpret_cast<int32_t *>(c->d_obs_ci.p));
+    } else {
+        if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(double) * c->N)))
+            return rc;
+        rc = BHMM_DISPATCH_N(c, pack_rows(c, reinterpret_cast<const double *>(src_dev)));
+        if (rc)
+            return rc;
+    }
+    BHMM_HIP(hipGetLastError());
+    if (obs_on_device) {
+        // keep a trajectory-major copy for the path kernels
+        if ((rc = c->d_obs_rm.ensure(bytes)))
+            return rc;
+        BHMM_HIP(hipMemcpyAsync(c->d_obs_rm.p, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    return BHMM_OK;
+}
+
+int bhmm_ctx_stats_size(const bhmm_ctx *c) { return (c && c->kind >= 0) ? stats_size(c) : 0; }
+int64_t bhmm_ctx_total_steps(const bhmm_ctx *c) { return c ? c->total : 0; }
+int bhmm_ctx_num_chunks(const bhmm_ctx *c) { return c ? c->G : 0; }
+int bhmm_ctx_chunk_len(const bhmm_ctx *c) { return c ? c->Lmax : 0; }
+void *bhmm_ctx_stream(bhmm_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int bhmm_ctx_sync(bhmm_ctx *c)
+{
+    if (!c)
+        return invalid("ctx == NULL");
+    BHMM_HIP(hipSetDevice(c->device));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    return BHMM_OK;
+}
+
+double bhmm_ctx_last_kernel_ms(bhmm_ctx *c, int which)
+{
+    if (!c || which < 0 || which > 4)
+        return -1.0;
+    return c->last_ms[which];
+}
+
+int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+               const double *par1, double *stats_dev, int flags)
+{
+    if (!c || c->kind < 0)
+        return invalid("no observations loaded");
+    if (!A || !pi)
+        return invalid("A / pi == NULL");
+    if (c->kind == BHMM_EMIT_GAUSSIAN && (!par0 || !par1))
+        return invalid("gaussian emissions need means and sigmas");
+    if (c->kind == BHMM_EMIT_DISCRETE && !par0)
+        return invalid("discrete emissions need B");
+    BHMM_HIP(hipSetDevice(c->device));
+    int rc;
+    if (c->kind == BHMM_EMIT_DISCRETE && (rc = upload_Bt(c, par0)))
+        return rc;
+    if (flags & BHMM_FLAG_STORE_GAMMA) {
+        if ((rc = c->d_gamma_ci.ensure((size_t)ci_records(c) * c->N * 64)))
+            return rc;
+    }
+    c->gamma_valid = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
+    double *sd = stats_dev ? stats_dev : c->d_stats.p;
+    return BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
+}
+
+int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
+{
+    if (!c || c->kind < 0)
+        return invalid("no observations loaded");
+    BHMM_HIP(hipSetDevice(c->device));
+    const int S = stats_size(c);
+    BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->d_stats.p, S * sizeof(double), hipMemcpyDeviceToHost,
+                            c->stream));
+    BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, c->K * sizeof(double),
+                            hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    if (stats)
+        memcpy(stats, c->h_pinned, S * sizeof(double));
+    if (logL_k)
+        memcpy(logL_k, c->h_pinned + S, c->K * sizeof(double));
+    for (int k = 0; k < c->K; ++k)
+        if (!std::isfinite(c->h_pinned[S + k])) {
+            g_err = "log-likelihood of trajectory " + std::to_string(k) + " is not finite";
+            return BHMM_ERR_NONFINITE;
+        }
+    return BHMM_OK;
+}
+
+int bhmm_get_gamma(bhmm_ctx *c, int k, double *gamma)
+{
+    if (!c || c->kind < 0 || !gamma)
+        return invalid("bad arguments");
+    if (!c->gamma_valid)
+        return invalid("last E-step did not store gamma (BHMM_FLAG_STORE_GAMMA)");
+    if (k < 0 || k >= c->K)
+        return invalid("trajectory index out of range");
+    BHMM_HIP(hipSetDevice(c->device));
+    const int64_t T = c->offsets[k + 1] - c->offsets[k];
+    if (T == 0)
+        return BHMM_OK;
+    int rc = c->d_scratch.ensure((size_t)T * c->n * sizeof(double));
+    if (rc)
+        return rc;
+    rc = BHMM_DISPATCH_N(c, unpack_rows(c, c->d_gamma_ci.p, reinterpret_cast<double *>(c->d_scratch.p),
+                                        k, c->offsets[k]));
+    if (rc)
+        return rc;
+    BHMM_HIP(hipMemcpyAsync(gamma, c->d_scratch.p, (size_t)T * c->n * sizeof(double),
+                            hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    return BHMM_OK;
+}
+
+// ---- single-trajectory, reference-shaped entry points -------------------------------------
+namespace {
+struct TmpCtx {
+    bhmm_ctx *c = nullptr;
+    ~TmpCtx() { bhmm_ctx_destroy(c); }
+};
+
+int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        d = 0;
+    }
+    return d;
+}
+
+int explicit_ctx(TmpCtx &t, const double *pobs, int N, int64_t T)
+{
+    if (!pobs || N < 1 || T < 1)
+        return invalid("pobs == NULL or empty problem");
+    int rc = bhmm_ctx_create(&t.c, current_device(), nullptr);
+    if (rc)
+        return rc;
+    const int64_t off[2] = {0, T};
+    return bhmm_ctx_set_observations(t.c, BHMM_EMIT_EXPLICIT, pobs, off, 1, N, 0, 0, 0);
+}
+
+int download_rows(bhmm_ctx *c, const double *src_ci, double *dst_host)
+{
+    const size_t bytes = (size_t)c->total * c->n * sizeof(double);
+    int rc = c->d_scratch.ensure(bytes);
+    if (rc)
+        return rc;
+    rc = BHMM_DISPATCH_N(c, unpack_rows(c, src_ci, reinterpret_cast<double *>(c->d_scratch.p), -1, 0));
+    if (rc)
+        return rc;
+    BHMM_HIP(hipMemcpyAsync(dst_host, c->d_scratch.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    return BHMM_OK;
+}
+} // namespace
+
+int bhmm_forward(double *alpha, double *logprob, const double *A, const double *pobs,
+                 const double *pi, int N, int64_t T)
+{
+    if (!alpha || !A || !pi)
+        return invalid("NULL argument");
+    TmpCtx t;
+    int rc = explicit_ctx(t, pobs, N, T);
+    if (rc)
+        return rc;
+    bhmm_ctx *c = t.c;
+    rc = BHMM_DISPATCH_N(c, template sweep_explicit<MODE_FWD>(c, A, pi));
+    if (rc)
+        return rc;
+    rc = download_rows(c, c->d_ws.p, alpha);
+    if (rc)
+        return rc;
+    double ll = 0.0;
+    BHMM_HIP(hipMemcpy(&ll, c->d_logLk.p, sizeof(double), hipMemcpyDeviceToHost));
+    if (logprob)
+        *logprob = ll;
+    return BHMM_OK;
+}
+
+int bhmm_backward(double *beta, const double *A, const double *pobs, int N, int64_t T)
+{
+    if (!beta || !A)
+        return invalid("NULL argument");
+    TmpCtx t;
+    int rc = explicit_ctx(t, pobs, N, T);
+    if (rc)
+        return rc;
+    bhmm_ctx *c = t.c;
+    std::vector<double> pi(N, 1.0 / N); // the backward recursion does not involve pi
+    rc = BHMM_DISPATCH_N(c, template sweep_explicit<MODE_BWD>(c, A, pi.data()));
+    if (rc)
+        return rc;
+    return download_rows(c, c->d_ws.p, beta);
+}
+
+} // extern "C"
+
+// ---- TEMPORARY: entry points still to be implemented (filled in by path_kernels) ----------
+extern "C" {
+#define BHMM_TODO(name) { g_err = name ": not implemented yet"; return BHMM_ERR_INVALID; }
+int bhmm_state_probabilities(double *, const double *, const double *, int, int64_t) BHMM_TODO("state_probabilities")
+int bhmm_transition_counts(double *, const double *, const double *, const double *, const double *, int, int64_t) BHMM_TODO("transition_counts")
+int bhmm_viterbi(int32_t *, const double *, const double *, const double *, int, int64_t) BHMM_TODO("viterbi")
+int bhmm_sample_path(int32_t *, const double *, const double *, const double *, int, int64_t) BHMM_TODO("sample_path")
+int bhmm_pobs_gaussian(double *, const double *, const double *, const double *, int, int64_t, int) BHMM_TODO("pobs_gaussian")
+int bhmm_update_pout(double *, const int32_t *, const double *, int64_t, int, int) BHMM_TODO("update_pout")
+int bhmm_viterbi_batch(bhmm_ctx *, const double *, const double *, const double *, const double *, int32_t *) BHMM_TODO("viterbi_batch")
+int bhmm_sample_paths(bhmm_ctx *, const double *, const double *, const double *, const double *, const double *, uint64_t, int32_t *, int64_t *, int64_t *, double *) BHMM_TODO("sample_paths")
+}

@@ -1,0 +1,90 @@
+// ctx.hpp -- host-side state of the batched engine (opaque to C callers as bhmm_ctx).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/bhmm_amd.h"
+
+namespace bhmm {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+#define BHMM_HIP(call)                                  \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess)                           \
+            return ::bhmm::hip_fail(e_, #call);         \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n)
+            return BHMM_OK;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            set_error(std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) +
+                      " bytes failed: " + hipGetErrorString(e));
+            (void)hipGetLastError();
+            return BHMM_ERR_NO_MEM;
+        }
+        n = count;
+        return BHMM_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+} // namespace bhmm
+
+struct bhmm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // loaded problem
+    int kind = -1;
+    int n = 0;    // real number of states
+    int N = 0;    // padded (2, 4, 8)
+    int M = 0;    // symbols
+    int K = 0;    // trajectories
+    int64_t total = 0;
+    int L = 0, Lmax = 0, G = 0, Gp = 0;
+    std::vector<int64_t> offsets;  // [K+1]
+    std::vector<int32_t> traj_c0;  // [K+1] first chunk of each trajectory
+
+    // device buffers
+    bhmm::DevBuf<int32_t> d_ctraj, d_clen, d_traj_c0;
+    bhmm::DevBuf<int64_t> d_ct0, d_cgoff;
+    bhmm::DevBuf<char> d_obs_ci;     // CI observations (double / int32 / N doubles)
+    bhmm::DevBuf<char> d_obs_rm;     // trajectory-major observations (Viterbi / sampling)
+    bhmm::DevBuf<double> d_Bt;       // [M][N] transposed emission matrix
+    bhmm::DevBuf<double> d_M;        // chunk transfer matrices
+    bhmm::DevBuf<double> d_aentry, d_bexit, d_ws, d_gamma_ci;
+    bhmm::DevBuf<double> d_logLc, d_logLk, d_gamma0, d_partials, d_dpartials, d_stats;
+    bhmm::DevBuf<char> d_scratch;    // paths, uniforms, pointer tables ...
+    bhmm::DevBuf<char> d_scratch2;
+    double *h_pinned = nullptr;      // stats + logL_k landing zone
+    size_t h_pinned_n = 0;
+
+    bool gamma_valid = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_pending = false;
+    double last_ms[5] = {0, 0, 0, 0, 0};
+};

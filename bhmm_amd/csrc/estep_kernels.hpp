@@ -1,0 +1,724 @@
+// estep_kernels.hpp -- CDNA4 (gfx950) kernels of the batched E-step.
+//
+// Replaces the per-trajectory Python/C sequence of
+// bhmm/estimators/maximum_likelihood.py:221-282 (p_obs -> forward -> backward -> gamma ->
+// transition counts, then the host-side sums) by a parallel-in-time decomposition:
+//
+//   every trajectory is cut into time chunks; one LANE owns one chunk and keeps the whole
+//   N-state vector (N <= 8) in registers, so a 64-wide wavefront advances 64 chunks per
+//   instruction with no cross-lane traffic.  All per-step data (observations, alpha) live
+//   in HBM in a "chunk-interleaved" (CI) layout  [wave][step][component][lane]  so that
+//   every global load/store of a wavefront is one contiguous 512 B / 1 KiB segment.
+//
+//   k_prescan  : per chunk, the N x N transfer matrix  prod_t A*diag(p_t)  (rows kept
+//                exponent-normalised) -- makes the time recursion associative.
+//   k_stitch   : per trajectory, sequential over chunks (N lanes per trajectory): exact
+//                alpha at every chunk entry and beta at every chunk exit.
+//   k_fwdbwd   : per chunk, scaled forward sweep (alpha -> HBM, log-likelihood), then the
+//                backward sweep that consumes alpha and accumulates gamma / xi / emission
+//                sufficient statistics in registers.  beta and pobs never touch HBM.
+//   k_finalize : fixed-order reduction of the per-workgroup partials into the packed
+//                statistics vector (the quantity that is all-reduced across GPUs).
+//
+// Arithmetic follows SURVEY.md Appendix A up to re-association (fp64, results within 1e-6
+// relative of the reference; the bit-exact kernels -- Viterbi, path sampling -- live in
+// path_kernels.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bhmm {
+
+enum { EMIT_GAUSS = 0, EMIT_DISC = 1, EMIT_EXPL = 2 };
+enum { MODE_ESTEP = 0, MODE_FWD = 1, MODE_BWD = 2 };
+
+constexpr int BLOCK = 256;
+
+// Model parameters, passed by value as kernel arguments (uniform -> scalar registers).
+// N is the padded state count (2, 4 or 8); states >= nreal are inert (pi = 0, p = 0).
+template <int N>
+struct Model {
+    double A[N * N];
+    double pi[N];
+    double e0[N]; // gaussian: mean
+    double e1[N]; // gaussian: 1/sigma
+    double e2[N]; // gaussian: 1/(sqrt(2 pi) sigma)      (_gaussian.c:18)
+    int nreal;
+    int M; // number of symbols (discrete)
+};
+
+// Chunk table (device pointers), one entry per lane of the launch; padded entries have
+// len == 0.
+struct Chunks {
+    const int32_t *traj; // trajectory index of the chunk
+    const int64_t *t0;   // first time step of the chunk inside its trajectory
+    const int32_t *len;  // number of steps
+    const int64_t *goff; // t0 + offset of the trajectory in the concatenated arrays
+    int Lmax;            // record stride per wavefront (max chunk length)
+};
+
+// ---- CI addressing ------------------------------------------------------------------
+__device__ __forceinline__ int64_t ci_rec(int64_t g, int s, int Lmax)
+{
+    return (g >> 6) * (int64_t)Lmax + s;
+}
+
+template <int N>
+__device__ __forceinline__ void ci_load(const double *base, int64_t rec, int lane, double (&v)[N])
+{
+    const double2 *p = reinterpret_cast<const double2 *>(base + rec * (int64_t)(N * 64)) + lane;
+#pragma unroll
+    for (int q = 0; q < N / 2; ++q) {
+        const double2 x = p[q * 64];
+        v[2 * q] = x.x;
+        v[2 * q + 1] = x.y;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void ci_store(double *base, int64_t rec, int lane, const double (&v)[N])
+{
+    double2 *p = reinterpret_cast<double2 *>(base + rec * (int64_t)(N * 64)) + lane;
+#pragma unroll
+    for (int q = 0; q < N / 2; ++q)
+        p[q * 64] = make_double2(v[2 * q], v[2 * q + 1]);
+}
+
+// ---- emission probabilities, fused (never written to HBM) ------------------------------
+// gaussian: _gaussian.c:5-21 + the outlier rule of outputmodel.py:119-131
+// discrete: discrete.py:150-153 (column gather from B, staged transposed in LDS)
+// explicit: pobs rows supplied by the caller (hidden/api.py signatures)
+template <int N, int KIND>
+__device__ __forceinline__ void emit(const Model<N> &m, const void *obs_ci, const double *Bt,
+                                     int64_t rec, int lane, double (&p)[N], double &o, int &sym)
+{
+    if constexpr (KIND == EMIT_GAUSS) {
+        o = static_cast<const double *>(obs_ci)[rec * 64 + lane];
+        double mx = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double z = (o - m.e0[i]) * m.e1[i];
+            p[i] = m.e2[i] * exp(-0.5 * z * z);
+            mx = fmax(mx, p[i]);
+        }
+        if (mx == 0.0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                p[i] = (i < m.nreal) ? 1.0 : 0.0;
+        }
+    } else if constexpr (KIND == EMIT_DISC) {
+        sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + lane];
+        const double2 *row = reinterpret_cast<const double2 *>(Bt + (int64_t)sym * N);
+#pragma unroll
+        for (int q = 0; q < N / 2; ++q) {
+            const double2 x = row[q];
+            p[2 * q] = x.x;
+            p[2 * q + 1] = x.y;
+        }
+    } else {
+        ci_load<N>(static_cast<const double *>(obs_ci), rec, lane, p);
+    }
+}
+
+// exact power-of-two renormalisation of one row; returns the exponent removed
+template <int N>
+__device__ __forceinline__ int renorm_row(const double (&nr)[N], double (&dst)[N])
+{
+    double mx = nr[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j)
+        mx = fmax(mx, nr[j]);
+    int e;
+    (void)frexp(mx, &e);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        dst[j] = ldexp(nr[j], -e);
+    return e;
+}
+
+template <int N>
+__device__ __forceinline__ void stage_Bt(double *dst, const double *Bt_g, int M)
+{
+    for (int i = threadIdx.x; i < M * N; i += blockDim.x)
+        dst[i] = Bt_g[i];
+}
+
+// =========================================================================================
+// k_prescan: chunk transfer matrices.
+//   Mc = prod_{t in chunk} A diag(p_t)   (t = t0 .. t0+len-1; for the first chunk of a
+//   trajectory the product starts at t = 1 and every row is seeded with pi o p_0, so that
+//   e_0^T Mc is the unnormalised alpha at the chunk end).
+//   Row r is the forward recursion started from unit vector e_r (_hidden.c:42-63 without
+//   the division); rows are renormalised by a power of two every step (exact) and the
+//   exponent is carried separately:  true row r = 2^ex[r] * stored row r.
+//   Output per chunk: N*N doubles row-major + N exponents (as doubles).
+// =========================================================================================
+template <int N, int KIND>
+__global__ __launch_bounds__(BLOCK) void k_prescan(const Model<N> m, const Chunks ch,
+                                                   const void *obs_ci, const double *Bt_g,
+                                                   double *Mbuf)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if constexpr (KIND == EMIT_DISC) {
+        stage_Bt<N>(smem, Bt_g, m.M);
+        __syncthreads();
+    }
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int len = ch.len[g];
+    if (len == 0)
+        return;
+    const bool first = (ch.t0[g] == 0);
+
+    double Mx[N][N];
+    int ex[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        ex[r] = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            Mx[r][j] = (r == j) ? 1.0 : 0.0;
+    }
+
+    int s = 0;
+    if (first) {
+        double p[N], o;
+        int sym;
+        emit<N, KIND>(m, obs_ci, smem, ci_rec(g, 0, ch.Lmax), lane, p, o, sym);
+        double seed[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            seed[j] = m.pi[j] * p[j];
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+            ex[r] = renorm_row<N>(seed, Mx[r]);
+        s = 1;
+    }
+    for (; s < len; ++s) {
+        double p[N], o;
+        int sym;
+        emit<N, KIND>(m, obs_ci, smem, ci_rec(g, s, ch.Lmax), lane, p, o, sym);
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            double nr[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double acc = Mx[r][0] * m.A[j];
+#pragma unroll
+                for (int k = 1; k < N; ++k)
+                    acc = fma(Mx[r][k], m.A[k * N + j], acc);
+                nr[j] = acc * p[j];
+            }
+            ex[r] += renorm_row<N>(nr, Mx[r]);
+        }
+    }
+    double *out = Mbuf + g * (int64_t)(N * N + N);
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int j = 0; j < N; j += 2)
+            *reinterpret_cast<double2 *>(out + r * N + j) = make_double2(Mx[r][j], Mx[r][j + 1]);
+#pragma unroll
+    for (int r = 0; r < N; r += 2)
+        *reinterpret_cast<double2 *>(out + N * N + r) = make_double2((double)ex[r], (double)ex[r + 1]);
+}
+
+// =========================================================================================
+// k_stitch: exact chunk-boundary vectors.  N lanes cooperate on one (trajectory,
+// direction); lane r holds row r of the current transfer matrix.
+//   forward : alpha_entry[c] = normalised alpha at the step before chunk c
+//             (_hidden.c:42-63 collapsed over a chunk:  a <- normalise(a^T Mc))
+//   backward: beta_exit[c]   = normalised beta at the last step of chunk c
+//             (_hidden.c:91-109 collapsed:  b <- normalise(M_{c+1} b), b_{T-1} = 1/N)
+// Blocks [0, nb) run the forward direction, [nb, 2 nb) the backward one.
+// =========================================================================================
+template <int N>
+__device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int h = N / 2; h >= 1; h >>= 1)
+        v += __shfl_xor(v, h, N);
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ int group_max(int v)
+{
+#pragma unroll
+    for (int h = N / 2; h >= 1; h >>= 1)
+        v = max(v, __shfl_xor(v, h, N));
+    return v;
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_stitch(const int32_t *traj_c0, int K, int nb, int nreal,
+                                               const double *Mbuf, double *alpha_entry,
+                                               double *beta_exit)
+{
+    constexpr int GP = 64 / N; // trajectories per block
+    constexpr int MS = N * N + N;
+    const bool bwd = (int)blockIdx.x >= nb;
+    const int k = ((int)blockIdx.x % nb) * GP + (int)threadIdx.x / N;
+    const int r = threadIdx.x % N;
+    if (k >= K)
+        return;
+    const int c0 = traj_c0[k], c1 = traj_c0[k + 1];
+    constexpr int NEG = -(1 << 28);
+
+    if (!bwd) {
+        double a = (r == 0) ? 1.0 : 0.0; // selects row 0 of the seeded first chunk
+        double row[N], erow;
+        {
+            const double *src = Mbuf + (int64_t)c0 * MS;
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                row[j] = src[r * N + j];
+            erow = src[N * N + r];
+        }
+        for (int c = c0; c < c1; ++c) {
+            alpha_entry[(int64_t)c * N + r] = a;
+            double nrow[N], nerow = 0.0;
+            if (c + 1 < c1) { // prefetch the next matrix while this one is consumed
+                const double *src = Mbuf + (int64_t)(c + 1) * MS;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    nrow[j] = src[r * N + j];
+                nerow = src[N * N + r];
+            }
+            const int e = (int)erow;
+            const int E = group_max<N>(a > 0.0 ? e : NEG);
+            const double w = ldexp(a, e - E);
+            double buf[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                buf[j] = w * row[j];
+            // reduce-scatter over the N lanes: lane j ends with sum_r w_r M[r][j]
+#pragma unroll
+            for (int h = N / 2; h >= 1; h >>= 1) {
+                const bool up = (r & h) != 0;
+#pragma unroll
+                for (int i = 0; i < h; ++i) {
+                    const double keep = up ? buf[i + h] : buf[i];
+                    const double send = up ? buf[i] : buf[i + h];
+                    buf[i] = keep + __shfl_xor(send, h, N);
+                }
+            }
+            const double S = group_sum<N>(buf[0]);
+            a = buf[0] / S;
+            if (c + 1 < c1) {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    row[j] = nrow[j];
+                erow = nerow;
+            }
+        }
+    } else {
+        double b = (r < nreal) ? 1.0 / (double)nreal : 0.0; // _hidden.c:79-88
+        for (int c = c1 - 1; c >= c0; --c) {
+            beta_exit[(int64_t)c * N + r] = b;
+            if (c == c0)
+                break;
+            const double *src = Mbuf + (int64_t)c * MS;
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                s = fma(src[r * N + j], __shfl(b, j, N), s);
+            const int e = (int)src[N * N + r];
+            const int E = group_max<N>(s > 0.0 ? e : NEG);
+            const double u = ldexp(s, e - E);
+            const double S = group_sum<N>(u);
+            b = u / S;
+        }
+    }
+}
+
+// =========================================================================================
+// k_fwdbwd: the streaming kernel.  One lane = one chunk.
+// =========================================================================================
+template <int N, int KIND>
+struct StatLayout {
+    static constexpr int NC = N * N;                             // xi accumulators
+    static constexpr int NG = N;                                 // sum_t gamma
+    static constexpr int NE = (KIND == EMIT_GAUSS) ? 2 * N : 0;  // sum gamma d, sum gamma d^2
+    static constexpr int S = NC + NG + NE;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1)
+        v += __shfl_xor(v, h, 64);
+    return v;
+}
+
+template <int N, int KIND, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_fwdbwd(
+    const Model<N> m, const Chunks ch, const void *obs_ci, const double *Bt_g,
+    const double *alpha_entry, const double *beta_exit,
+    double *ws,            // CI workspace: alpha (ESTEP, FWD) or beta (BWD)
+    double *gamma_ci,      // CI gamma, or nullptr
+    double *logL_chunk,    // [G] log of the product of the chunk's scaling factors
+    double *gamma0,        // [K][N] gamma at t = 0 of every trajectory
+    double *partials,      // [gridDim.x][S] register statistics per workgroup
+    double *disc_partials) // [gridDim.x][M*N] discrete emission statistics per workgroup
+{
+    using SL = StatLayout<N, KIND>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *red = smem;                                     // [4][S]
+    double *Bt = smem + 4 * SL::S;                          // [M][N]
+    double *dstat = Bt + (KIND == EMIT_DISC ? m.M * N : 0); // [M][N]
+    if constexpr (KIND == EMIT_DISC) {
+        stage_Bt<N>(Bt, Bt_g, m.M);
+        if constexpr (MODE == MODE_ESTEP)
+            for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
+                dstat[i] = 0.0;
+        __syncthreads();
+    }
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int len = ch.len[g];
+    const int64_t t0 = ch.t0[g];
+    const bool first = (t0 == 0);
+
+    double Cacc[N][N], sg[N], sd[N], sdd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sg[i] = sd[i] = sdd[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            Cacc[i][j] = 0.0;
+    }
+
+    if (len > 0) {
+        double a[N];
+        // ---------------- forward sweep (_hidden.c:16-66) ------------------------------
+        if constexpr (MODE != MODE_BWD) {
+            double P = 1.0; // running product of the scaling factors c_t, mantissa part
+            int eP = 0;     // ... and its binary exponent: logL = log(P) + eP ln 2
+            int s = 0;
+            if (first) {
+                double p[N], o;
+                int sym;
+                emit<N, KIND>(m, obs_ci, Bt, ci_rec(g, 0, ch.Lmax), lane, p, o, sym);
+                double c = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    a[i] = m.pi[i] * p[i];
+                    c += a[i];
+                }
+                const double rc = 1.0 / c;
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    a[i] *= rc;
+                P = frexp(c, &eP);
+                ci_store<N>(ws, ci_rec(g, 0, ch.Lmax), lane, a);
+                s = 1;
+            } else {
+                const double2 *src = reinterpret_cast<const double2 *>(alpha_entry + g * N);
+#pragma unroll
+                for (int q = 0; q < N / 2; ++q) {
+                    const double2 x = src[q];
+                    a[2 * q] = x.x;
+                    a[2 * q + 1] = x.y;
+                }
+            }
+            for (; s < len; ++s) {
+                double p[N], o;
+                int sym;
+                const int64_t rec = ci_rec(g, s, ch.Lmax);
+                emit<N, KIND>(m, obs_ci, Bt, rec, lane, p, o, sym);
+                double n[N], c = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double acc = a[0] * m.A[j];
+#pragma unroll
+                    for (int i = 1; i < N; ++i)
+                        acc = fma(a[i], m.A[i * N + j], acc);
+                    n[j] = acc * p[j];
+                    c += n[j];
+                }
+                const double rc = 1.0 / c;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    a[j] = n[j] * rc;
+                int e;
+                P = frexp(P * c, &e);
+                eP += e;
+                ci_store<N>(ws, rec, lane, a);
+            }
+            logL_chunk[g] = log(P) + (double)eP * 0.693147180559945309417232121458;
+        }
+
+        // ---------------- backward sweep ------------------------------------------------
+        if constexpr (MODE == MODE_BWD) {
+            // plain scaled backward recursion with the reference normalisation
+            // (_hidden.c:69-110); beta rows go to the CI workspace.
+            double b[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                b[i] = beta_exit[g * N + i];
+            ci_store<N>(ws, ci_rec(g, len - 1, ch.Lmax), lane, b);
+            for (int s = len - 1; s >= 1; --s) {
+                double p[N], o;
+                int sym;
+                emit<N, KIND>(m, obs_ci, Bt, ci_rec(g, s, ch.Lmax), lane, p, o, sym);
+                double bb[N], br[N], c = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    bb[j] = p[j] * b[j];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double acc = m.A[i * N] * bb[0];
+#pragma unroll
+                    for (int j = 1; j < N; ++j)
+                        acc = fma(m.A[i * N + j], bb[j], acc);
+                    br[i] = acc;
+                    c += acc;
+                }
+                const double rc = 1.0 / c;
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    b[i] = br[i] * rc;
+                ci_store<N>(ws, ci_rec(g, s - 1, ch.Lmax), lane, b);
+            }
+        }
+        if constexpr (MODE == MODE_ESTEP) {
+            // b carries beta up to a power-of-two scale; gamma and xi are normalised by
+            // S_t = sum_i alpha_t[i] (A (p_{t+1} o beta_{t+1}))[i], which equals the
+            // reference's per-step normalisers (hidden/api.py:176-186, _hidden.c:168-179).
+            double b[N], gam[N];
+            {
+                double S = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    b[i] = beta_exit[g * N + i];
+                    gam[i] = a[i] * b[i];
+                    S += gam[i];
+                }
+                const double rS = 1.0 / S;
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    gam[i] *= rS;
+            }
+            const int k = ch.traj[g];
+            for (int s = len - 1; s >= 0; --s) {
+                double p[N], o = 0.0;
+                int sym = 0;
+                const int64_t rec = ci_rec(g, s, ch.Lmax);
+                emit<N, KIND>(m, obs_ci, Bt, rec, lane, p, o, sym);
+                // ---- consume gamma_s: state counts + emission statistics ---------------
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    sg[i] += gam[i];
+                    if constexpr (KIND == EMIT_GAUSS) {
+                        const double d = o - m.e0[i];
+                        const double gd = gam[i] * d;
+                        sd[i] += gd;
+                        sdd[i] = fma(gd, d, sdd[i]);
+                    }
+                    if constexpr (KIND == EMIT_DISC) // _discrete.c:22-30
+                        atomicAdd(&dstat[sym * N + i], gam[i]);
+                }
+                if (gamma_ci)
+                    ci_store<N>(gamma_ci, rec, lane, gam);
+                if (first && s == 0) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        gamma0[(int64_t)k * N + i] = gam[i];
+                    break;
+                }
+                // ---- pair (s-1, s): xi accumulation and beta_{s-1} ----------------------
+                double ap[N];
+                if (s > 0) {
+                    ci_load<N>(ws, rec - 1, lane, ap);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        ap[i] = alpha_entry[g * N + i];
+                }
+                double bb[N], br[N], q[N], Sx = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    bb[j] = p[j] * b[j];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double acc = m.A[i * N] * bb[0];
+#pragma unroll
+                    for (int j = 1; j < N; ++j)
+                        acc = fma(m.A[i * N + j], bb[j], acc);
+                    br[i] = acc;
+                    q[i] = ap[i] * acc;
+                    Sx += q[i];
+                }
+                const double rS = 1.0 / Sx;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    bb[j] *= rS;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    gam[i] = q[i] * rS;
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        Cacc[i][j] = fma(ap[i], bb[j], Cacc[i][j]);
+                }
+                (void)renorm_row<N>(br, b);
+            }
+        }
+    }
+
+    // ---------------- workgroup reduction of the register statistics ----------------------
+    if constexpr (MODE == MODE_ESTEP) {
+        const int wv = threadIdx.x >> 6;
+        double *mine = red + wv * SL::S;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double v = wave_sum(Cacc[i][j]);
+                if (lane == 0)
+                    mine[i * N + j] = v;
+            }
+            const double v = wave_sum(sg[i]);
+            if (lane == 0)
+                mine[SL::NC + i] = v;
+            if constexpr (KIND == EMIT_GAUSS) {
+                const double v1 = wave_sum(sd[i]);
+                const double v2 = wave_sum(sdd[i]);
+                if (lane == 0) {
+                    mine[SL::NC + N + i] = v1;
+                    mine[SL::NC + 2 * N + i] = v2;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < SL::S; i += blockDim.x)
+            partials[(int64_t)blockIdx.x * SL::S + i] =
+                ((red[i] + red[SL::S + i]) + red[2 * SL::S + i]) + red[3 * SL::S + i];
+        if constexpr (KIND == EMIT_DISC)
+            for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
+                disc_partials[(int64_t)blockIdx.x * (m.M * N) + i] = dstat[i];
+    }
+}
+
+// =========================================================================================
+// k_logl: per-trajectory log-likelihood = ordered sum of its chunks' logs.
+// k_finalize: one workgroup; fixed-order sums -> packed statistics (bhmm_amd.h layout).
+// =========================================================================================
+__global__ void k_logl(const int32_t *traj_c0, int K, const double *logL_chunk, double *logL_k)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K)
+        return;
+    double s = 0.0;
+    for (int c = traj_c0[k]; c < traj_c0[k + 1]; ++c)
+        s += logL_chunk[c];
+    logL_k[k] = s;
+}
+
+template <int N, int KIND>
+__global__ __launch_bounds__(BLOCK) void k_finalize(const Model<N> m, int K, int nblocks,
+                                                    const double *partials,
+                                                    const double *disc_partials,
+                                                    const double *logL_k, const double *gamma0,
+                                                    double *stats)
+{
+    using SL = StatLayout<N, KIND>;
+    const int n = m.nreal;
+    const int tid = threadIdx.x;
+    // packed offsets
+    const int oG0 = 1, oC = 1 + n, oSG = oC + n * n, oE = oSG + n;
+    for (int i = tid; i < SL::S; i += BLOCK) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b)
+            s += partials[(int64_t)b * SL::S + i];
+        if (i < SL::NC) {
+            const int r = i / N, c = i % N;
+            if (r < n && c < n)
+                stats[oC + r * n + c] = s * m.A[r * N + c]; // xi = A o (alpha (x) b / S)
+        } else if (i < SL::NC + N) {
+            const int r = i - SL::NC;
+            if (r < n)
+                stats[oSG + r] = s;
+        } else {
+            const int w = (i - SL::NC - N) / N, r = (i - SL::NC - N) % N;
+            if (r < n)
+                stats[oE + w * n + r] = s;
+        }
+    }
+    if constexpr (KIND == EMIT_DISC) {
+        const int MN = m.M * N;
+        for (int i = tid; i < MN; i += BLOCK) {
+            double s = 0.0;
+            for (int b = 0; b < nblocks; ++b)
+                s += disc_partials[(int64_t)b * MN + i];
+            const int sym = i / N, r = i % N;
+            if (r < n)
+                stats[oE + r * m.M + sym] = s;
+        }
+    }
+    if (tid < n) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k)
+            s += gamma0[(int64_t)k * N + tid];
+        stats[oG0 + tid] = s;
+    }
+    if (tid == BLOCK - 1) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) // trajectory order, maximum_likelihood.py:383-385
+            s += logL_k[k];
+        stats[0] = s;
+    }
+}
+
+// =========================================================================================
+// layout conversion kernels (one lane per chunk; CI side is coalesced)
+// =========================================================================================
+template <typename T>
+__global__ void k_pack_scalar(const Chunks ch, const T *src, T *dst_ci)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int len = ch.len[g];
+    const int64_t off = ch.goff[g];
+    for (int s = 0; s < len; ++s)
+        dst_ci[ci_rec(g, s, ch.Lmax) * 64 + lane] = src[off + s];
+}
+
+// rows of nreal doubles (row-major) -> CI records of N doubles (zero padded)
+template <int N>
+__global__ void k_pack_rows(const Chunks ch, const double *src, int nreal, double *dst_ci)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int len = ch.len[g];
+    const int64_t off = ch.goff[g];
+    for (int s = 0; s < len; ++s) {
+        double v[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            v[i] = (i < nreal) ? src[(off + s) * nreal + i] : 0.0;
+        ci_store<N>(dst_ci, ci_rec(g, s, ch.Lmax), lane, v);
+    }
+}
+
+template <int N>
+__global__ void k_unpack_rows(const Chunks ch, const double *src_ci, int nreal, double *dst,
+                              int only_traj, int64_t dst_shift)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int len = ch.len[g];
+    if (only_traj >= 0 && ch.traj[g] != only_traj)
+        return;
+    const int64_t off = ch.goff[g] - dst_shift;
+    for (int s = 0; s < len; ++s) {
+        double v[N];
+        ci_load<N>(src_ci, ci_rec(g, s, ch.Lmax), lane, v);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < nreal)
+                dst[(off + s) * nreal + i] = v[i];
+    }
+}
+
+} // namespace bhmm

@@ -1,0 +1,156 @@
+/*
+ * bhmm_amd.h -- C ABI of the MI355X (gfx950) forward-backward / Baum-Welch engine.
+ *
+ * This is the drop-in boundary for the hot path of bhmm: plain
+ * pointers and sizes, no torch / numpy types.  Two families of entry points:
+ *
+ *  (1) Single-trajectory, host-pointer kernels with the argument meaning of the
+ *      reference's native layer (bhmm/hidden/impl_c/_hidden.h:10-63,
+ *      bhmm/output_models/impl_c/_gaussian.h:5, discrete.pyx:25).  They are what
+ *      bhmm/hidden/impl_c/hidden.pyx binds today; a maintainer can bind these instead
+ *      (INTEGRATION.md shows the ctypes / Cython stubs).  Lengths are int64 here; the
+ *      reference uses 32-bit int T (T*N < 2^31).
+ *
+ *  (2) A batched, device-resident context: observations are uploaded once (they are
+ *      constant across EM iterations, maximum_likelihood.py:101) and every EM iteration /
+ *      Gibbs sweep is ONE call that processes all trajectories on the GPU and returns
+ *      only the reduced sufficient statistics.  It replaces the Python loops at
+ *      bhmm/estimators/maximum_likelihood.py:221-282,383-385 (E-step),
+ *      :332-352 (Viterbi) and bhmm/estimators/bayesian_sampling.py:283-331 (Gibbs
+ *      hidden-path step).
+ *
+ * All functions return an int status (never exit(), unlike _hidden.c:299-304):
+ */
+#ifndef BHMM_AMD_H_
+#define BHMM_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHMM_OK 0
+#define BHMM_ERR_NO_MEM 2      /* same value as _BHMM_ERR_NO_MEM, _hidden.h:5 */
+#define BHMM_ERR_INVALID 3     /* bad argument (shape, NULL, unsupported size) */
+#define BHMM_ERR_HIP 4         /* HIP runtime error; see bhmm_last_error() */
+#define BHMM_ERR_NONFINITE 5   /* log-likelihood not finite (maximum_likelihood.py:385) */
+#define BHMM_ERR_CHOICE 6      /* inverse-CDF draw found no state (_hidden.c:299-304) */
+#define BHMM_ERR_NO_DEVICE 7   /* no HIP device / library built without one visible */
+
+/* emission model kinds */
+#define BHMM_EMIT_GAUSSIAN 0 /* obs: double[T];  par0 = means[N], par1 = sigmas[N]            */
+#define BHMM_EMIT_DISCRETE 1 /* obs: int32[T];   par0 = B[N*M] row-major, par1 unused         */
+#define BHMM_EMIT_EXPLICIT 2 /* obs: double[T*N] = pobs rows (hidden/api.py signatures)       */
+
+/* flags for bhmm_estep */
+#define BHMM_FLAG_STORE_GAMMA 1 /* keep gamma (T,N) per trajectory on the device            */
+
+const char *bhmm_last_error(void);
+int bhmm_device_count(void);
+/* library version / build info: "bhmm_amd <ver> gfx950" */
+const char *bhmm_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * (1) reference-shaped single-trajectory kernels, host pointers, row-major (T,N) arrays.
+ *     Each runs on the current HIP device, synchronously.
+ * ---------------------------------------------------------------------------------- */
+
+/* replaces _forward (_hidden.h:10-15, _hidden.c:16-66): fills alpha[T*N], *logprob */
+int bhmm_forward(double *alpha, double *logprob, const double *A, const double *pobs,
+                 const double *pi, int N, int64_t T);
+/* replaces _backward (_hidden.h:17-21, _hidden.c:69-110): fills beta[T*N] */
+int bhmm_backward(double *beta, const double *A, const double *pobs, int N, int64_t T);
+/* replaces hidden/api.py:133-188 (numpy) / _computeGamma (_hidden.c:113-131) */
+int bhmm_state_probabilities(double *gamma, const double *alpha, const double *beta, int N,
+                             int64_t T);
+/* replaces _compute_transition_counts (_hidden.h:34-40, _hidden.c:148-183); C overwritten */
+int bhmm_transition_counts(double *C, const double *A, const double *pobs, const double *alpha,
+                           const double *beta, int N, int64_t T);
+/* replaces _compute_viterbi (_hidden.h:42-47, _hidden.c:203-281); path is int32[T] */
+int bhmm_viterbi(int32_t *path, const double *A, const double *pobs, const double *pi, int N,
+                 int64_t T);
+/* replaces _sample_path (_hidden.h:49-54, _hidden.c:330-378).  u[T] are the uniforms in
+ * [0,1), u[t] used for step t (the reference draws them from libc rand(), T-1 first). */
+int bhmm_sample_path(int32_t *path, const double *alpha, const double *A, const double *u,
+                     int N, int64_t T);
+/* replaces _p_obs (_gaussian.h:5, _gaussian.c:45-70) + outputmodel.py:119-131 */
+int bhmm_pobs_gaussian(double *pobs, const double *obs, const double *mu, const double *sigma,
+                       int N, int64_t T, int ignore_outliers);
+/* replaces _update_pout (discrete.pyx:25, _discrete.c:1-32): pout[N*M] += scatter */
+int bhmm_update_pout(double *pout, const int32_t *obs, const double *weights, int64_t T, int N,
+                     int M);
+
+/* ------------------------------------------------------------------------------------
+ * (2) batched device-resident context
+ * ---------------------------------------------------------------------------------- */
+typedef struct bhmm_ctx bhmm_ctx;
+
+/* device: HIP ordinal.  stream: a hipStream_t to launch on (NULL = the context creates
+ * its own).  The context owns every device buffer it allocates. */
+int bhmm_ctx_create(bhmm_ctx **out, int device, void *stream);
+int bhmm_ctx_destroy(bhmm_ctx *ctx);
+
+/* Upload K trajectories.  obs is the concatenation of all trajectories (element type per
+ * `kind`), offsets[K+1] the element offsets of each trajectory in time steps.
+ * nstates = N, nsymbols = M (discrete only).  chunk = time-chunk length used for the
+ * parallel-in-time decomposition (0 = choose automatically).  obs_on_device != 0 means
+ * `obs` is already a device pointer on the context's device (offsets stay on the host). */
+int bhmm_ctx_set_observations(bhmm_ctx *ctx, int kind, const void *obs, const int64_t *offsets,
+                              int K, int nstates, int nsymbols, int chunk, int obs_on_device);
+
+/* Number of doubles in the packed statistics vector produced by bhmm_estep for the loaded
+ * observations:  [0] sum_k logL_k | [1..N] sum_k gamma_k[0] | N*N transition counts C |
+ * N state counts sum_t gamma | emission block:
+ *   gaussian: N sum gamma*(o-mu_old), N sum gamma*(o-mu_old)^2     (2N)
+ *   discrete: N*M weighted symbol counts (row-major, unnormalised) (N*M)
+ *   explicit: none. */
+int bhmm_ctx_stats_size(const bhmm_ctx *ctx);
+
+/* One E-step over all loaded trajectories with the given model (host pointers):
+ * fused emission probabilities + scaled forward + backward + gamma/xi/emission statistics
+ * (maximum_likelihood.py:221-282).  Asynchronous on the context's stream.
+ *   stats_dev : device buffer of bhmm_ctx_stats_size() doubles, or NULL to use the
+ *               context's internal buffer (read back with bhmm_estep_fetch).  A caller
+ *               running several ranks all-reduces this buffer (RCCL) before fetching.
+ *   flags     : BHMM_FLAG_* */
+int bhmm_estep(bhmm_ctx *ctx, const double *A, const double *pi, const double *par0,
+               const double *par1, double *stats_dev, int flags);
+/* Wait for the last E-step and copy results to the host.  stats (packed vector) and/or
+ * logL_k[K] may be NULL.  Returns BHMM_ERR_NONFINITE if any logL_k is not finite. */
+int bhmm_estep_fetch(bhmm_ctx *ctx, double *stats, double *logL_k);
+/* After an E-step run with BHMM_FLAG_STORE_GAMMA: copy gamma of trajectory k, (T_k,N)
+ * row-major, to the host. */
+int bhmm_get_gamma(bhmm_ctx *ctx, int k, double *gamma);
+
+/* Viterbi paths of all trajectories (maximum_likelihood.py:332-352).  paths is a host
+ * buffer of sum_k T_k int32, trajectory-concatenated like obs. */
+int bhmm_viterbi_batch(bhmm_ctx *ctx, const double *A, const double *pi, const double *par0,
+                       const double *par1, int32_t *paths);
+
+/* Gibbs hidden-path step (bayesian_sampling.py:283-331): forward pass + backward sampling
+ * of every trajectory.  Uniforms come either from u (host, concatenated like obs; u[t]
+ * used at step t) or, when u == NULL, from a counter-based generator seeded with `seed`.
+ * Outputs (any may be NULL): paths (host, int32, concatenated), and the hidden-path
+ * statistics the sweep needs (generic_hmm.py:297-334,398-431):
+ *   counts[N*N] int64 transition counts, n0[N] int64 first-state counts,
+ *   emis: gaussian -> 3N doubles (n_i, sum o, sum o^2 per state); discrete -> N*M counts. */
+int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const double *par0,
+                      const double *par1, const double *u, uint64_t seed, int32_t *paths,
+                      int64_t *counts, int64_t *n0, double *emis);
+
+/* introspection (used by bench.py / tests) */
+int64_t bhmm_ctx_total_steps(const bhmm_ctx *ctx);
+int bhmm_ctx_num_chunks(const bhmm_ctx *ctx);
+int bhmm_ctx_chunk_len(const bhmm_ctx *ctx);
+/* time in milliseconds spent in the named kernel during the last bhmm_estep, measured with
+ * HIP events on the context's stream.  which: 0 prescan, 1 stitch, 2 forward-backward,
+ * 3 finalize, 4 whole E-step. Valid after bhmm_estep_fetch (or a stream sync). */
+double bhmm_ctx_last_kernel_ms(bhmm_ctx *ctx, int which);
+void *bhmm_ctx_stream(bhmm_ctx *ctx);
+int bhmm_ctx_sync(bhmm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHMM_AMD_H_ */
