@@ -48,6 +48,7 @@ SIGNATURES = {
                                     ctypes.c_int64]),
     "bhmm_sample_path": (ctypes.c_int, [c_int32_p, c_double_p, c_double_p, c_double_p,
                                         ctypes.c_int, ctypes.c_int64]),
+    "bhmm_libc_uniforms": (ctypes.c_int, [c_double_p, ctypes.c_int64, ctypes.c_int]),
     "bhmm_pobs_gaussian": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, c_double_p,
                                           ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
     "bhmm_update_pout": (ctypes.c_int, [c_double_p, c_int32_p, c_double_p, ctypes.c_int64,

@@ -9,8 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "ctx.hpp"
-#include "estep_kernels.hpp"
+#include "host_common.hpp"
 
 namespace bhmm {
 
@@ -28,31 +27,11 @@ static int invalid(const std::string &msg)
     g_err = msg;
     return BHMM_ERR_INVALID;
 }
+int invalid_arg(const std::string &msg) { return invalid(msg); }
 
-static int pad_states(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : 8); }
-
-// ---- model marshalling -----------------------------------------------------------------
-template <int N>
-static void fill_model(Model<N> &m, int n, int kind, int M, const double *A, const double *pi,
-                       const double *par0, const double *par1)
-{
-    memset(&m, 0, sizeof(m));
-    m.nreal = n;
-    m.M = M;
-    for (int i = 0; i < N; ++i)
-        for (int j = 0; j < N; ++j)
-            m.A[i * N + j] = (i < n && j < n) ? A[i * n + j] : (i == j ? 1.0 : 0.0);
-    for (int i = 0; i < n; ++i)
-        m.pi[i] = pi ? pi[i] : 0.0;
-    if (kind == EMIT_GAUSS)
-        for (int i = 0; i < n; ++i) {
-            m.e0[i] = par0[i];
-            m.e1[i] = 1.0 / par1[i];
-            m.e2[i] = 1.0 / (sqrt(2.0 * M_PI) * par1[i]); // _gaussian.c:18
-        }
-}
-
-static Chunks chunks_of(const bhmm_ctx *c)
+Chunks chunks_pub(const bhmm_ctx *c);
+static Chunks chunks_of(const bhmm_ctx *c) { return chunks_pub(c); }
+Chunks chunks_pub(const bhmm_ctx *c)
 {
     Chunks ch;
     ch.traj = c->d_ctraj.p;
@@ -172,6 +151,29 @@ struct Runner {
         return BHMM_OK;
     }
 
+    // forward pass only, alpha (normalised, _hidden.c:16-66) left in the CI workspace
+    static int forward_only(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                            const double *par1)
+    {
+        Model<N> m;
+        fill_model<N>(m, c->n, c->kind, c->M, A, pi, par0, par1);
+        int rc;
+        switch (c->kind) {
+        case EMIT_GAUSS:
+            if ((rc = prescan_stitch<EMIT_GAUSS>(c, m)))
+                return rc;
+            return fwdbwd<EMIT_GAUSS, MODE_FWD>(c, m, false);
+        case EMIT_DISC:
+            if ((rc = prescan_stitch<EMIT_DISC>(c, m)))
+                return rc;
+            return fwdbwd<EMIT_DISC, MODE_FWD>(c, m, false);
+        default:
+            if ((rc = prescan_stitch<EMIT_EXPL>(c, m)))
+                return rc;
+            return fwdbwd<EMIT_EXPL, MODE_FWD>(c, m, false);
+        }
+    }
+
     static int pack_rows(bhmm_ctx *c, const double *src_dev)
     {
         hipLaunchKernelGGL((k_pack_rows<N>), dim3(c->Gp / BLOCK), dim3(BLOCK), 0, c->stream,
@@ -250,8 +252,16 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
     BHMM_HIP(hipMemcpy(c->d_cgoff.p, cgoff.data(), c->Gp * sizeof(int64_t), hipMemcpyHostToDevice));
     BHMM_HIP(hipMemcpy(c->d_traj_c0.p, c->traj_c0.data(), (K + 1) * sizeof(int32_t),
                        hipMemcpyHostToDevice));
+    if ((rc = c->d_offsets.ensure(K + 1)))
+        return rc;
+    BHMM_HIP(hipMemcpy(c->d_offsets.p, c->offsets.data(), (K + 1) * sizeof(int64_t),
+                       hipMemcpyHostToDevice));
     return BHMM_OK;
 }
+
+int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+               const double *par1);
+int unpack_ws_rows(bhmm_ctx *c, double *dst_dev);
 
 static int64_t ci_records(const bhmm_ctx *c) { return (int64_t)(c->Gp / 64) * c->Lmax; }
 
@@ -310,6 +320,20 @@ static int upload_Bt(bhmm_ctx *c, const double *B)
                             hipMemcpyHostToDevice, c->stream));
     BHMM_HIP(hipStreamSynchronize(c->stream)); // bt is a temporary
     return BHMM_OK;
+}
+
+int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+               const double *par1)
+{
+    int rc;
+    if (c->kind == BHMM_EMIT_DISCRETE && (rc = upload_Bt(c, par0)))
+        return rc;
+    return BHMM_DISPATCH_N(c, forward_only(c, A, pi, par0, par1));
+}
+
+int unpack_ws_rows(bhmm_ctx *c, double *dst_dev)
+{
+    return BHMM_DISPATCH_N(c, unpack_rows(c, c->d_ws.p, dst_dev, -1, 0));
 }
 
 static void collect_timing(bhmm_ctx *c)
@@ -415,6 +439,9 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     c->d_stats.release();
     c->d_scratch.release();
     c->d_scratch2.release();
+    c->d_offsets.release();
+    c->d_Brm.release();
+    c->d_alpha_rm.release();
     if (c->h_pinned)
         (void)hipHostFree(c->h_pinned);
     for (auto &ev : c->ev)
@@ -695,15 +722,3 @@ int bhmm_backward(double *beta, const double *A, const double *pobs, int N, int6
 
 } // extern "C"
 
-// ---- TEMPORARY: entry points still to be implemented (filled in by path_kernels) ----------
-extern "C" {
-#define BHMM_TODO(name) { g_err = name ": not implemented yet"; return BHMM_ERR_INVALID; }
-int bhmm_state_probabilities(double *, const double *, const double *, int, int64_t) BHMM_TODO("state_probabilities")
-int bhmm_transition_counts(double *, const double *, const double *, const double *, const double *, int, int64_t) BHMM_TODO("transition_counts")
-int bhmm_viterbi(int32_t *, const double *, const double *, const double *, int, int64_t) BHMM_TODO("viterbi")
-int bhmm_sample_path(int32_t *, const double *, const double *, const double *, int, int64_t) BHMM_TODO("sample_path")
-int bhmm_pobs_gaussian(double *, const double *, const double *, const double *, int, int64_t, int) BHMM_TODO("pobs_gaussian")
-int bhmm_update_pout(double *, const int32_t *, const double *, int64_t, int, int) BHMM_TODO("update_pout")
-int bhmm_viterbi_batch(bhmm_ctx *, const double *, const double *, const double *, const double *, int32_t *) BHMM_TODO("viterbi_batch")
-int bhmm_sample_paths(bhmm_ctx *, const double *, const double *, const double *, const double *, const double *, uint64_t, int32_t *, int64_t *, int64_t *, double *) BHMM_TODO("sample_paths")
-}

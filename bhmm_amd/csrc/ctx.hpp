@@ -80,6 +80,9 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_logLc, d_logLk, d_gamma0, d_partials, d_dpartials, d_stats;
     bhmm::DevBuf<char> d_scratch;    // paths, uniforms, pointer tables ...
     bhmm::DevBuf<char> d_scratch2;
+    bhmm::DevBuf<int64_t> d_offsets; // [K+1] trajectory offsets (time steps)
+    bhmm::DevBuf<double> d_Brm;      // [n][M] emission matrix, row-major (path kernels)
+    bhmm::DevBuf<double> d_alpha_rm; // [total][n] alpha, trajectory-major (path sampling)
     double *h_pinned = nullptr;      // stats + logL_k landing zone
     size_t h_pinned_n = 0;
 

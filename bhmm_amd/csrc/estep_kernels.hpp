@@ -43,6 +43,7 @@ struct Model {
     double e0[N]; // gaussian: mean
     double e1[N]; // gaussian: 1/sigma
     double e2[N]; // gaussian: 1/(sqrt(2 pi) sigma)      (_gaussian.c:18)
+    double e3[N]; // gaussian: sigma (the bit-exact path kernels divide by it)
     int nreal;
     int M; // number of symbols (discrete)
 };
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwdbwd(
 // k_logl: per-trajectory log-likelihood = ordered sum of its chunks' logs.
 // k_finalize: one workgroup; fixed-order sums -> packed statistics (bhmm_amd.h layout).
 // =========================================================================================
-__global__ void k_logl(const int32_t *traj_c0, int K, const double *logL_chunk, double *logL_k)
+static __global__ void k_logl(const int32_t *traj_c0, int K, const double *logL_chunk, double *logL_k)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K)

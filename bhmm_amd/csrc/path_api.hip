@@ -1,0 +1,450 @@
+// path_api.hip -- C ABI entry points backed by the order-faithful kernels (Viterbi, path
+// sampling) and the small reference-shaped row-major kernels.  This translation unit is
+// compiled with -ffp-contract=off (see Makefile): no fused multiply-adds, so products and
+// sums round like the reference's scalar C.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "host_common.hpp"
+#include "path_kernels.hpp"
+
+namespace bhmm {
+int invalid_arg(const std::string &msg);
+int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+               const double *par1);
+int unpack_ws_rows(bhmm_ctx *c, double *dst_dev);
+Chunks chunks_pub(const bhmm_ctx *c);
+
+namespace {
+
+struct Tmp { // scoped raw device allocations for the context-free entry points
+    std::vector<void *> ptrs;
+    ~Tmp()
+    {
+        for (void *p : ptrs)
+            (void)hipFree(p);
+    }
+    template <typename T>
+    int alloc(T **out, size_t count)
+    {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("hipMalloc failed");
+            return BHMM_ERR_NO_MEM;
+        }
+        ptrs.push_back(p);
+        *out = static_cast<T *>(p);
+        return BHMM_OK;
+    }
+};
+
+template <int N>
+int viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                const double *par1, int32_t *paths_host)
+{
+    Model<N> m;
+    fill_model_pub<N>(m, c->n, c->kind, c->M, A, pi, par0, par1);
+    const int K = c->K;
+    const size_t words = (size_t)(c->total / VB + K) * N;
+    int rc;
+    if ((rc = c->d_scratch.ensure(words * sizeof(uint32_t))) ||
+        (rc = c->d_scratch2.ensure(((size_t)c->total + K) * sizeof(int32_t))))
+        return rc;
+    uint32_t *ptr = reinterpret_cast<uint32_t *>(c->d_scratch.p);
+    int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
+    int32_t *path = last + K;
+    const double *Bdev = nullptr;
+    if (c->kind == EMIT_DISC) {
+        if ((rc = c->d_Brm.ensure((size_t)c->n * c->M)))
+            return rc;
+        BHMM_HIP(hipMemcpyAsync(c->d_Brm.p, par0, (size_t)c->n * c->M * sizeof(double),
+                                hipMemcpyHostToDevice, c->stream));
+        Bdev = c->d_Brm.p;
+    }
+    constexpr int GP = 64 / N;
+    const dim3 grid((K + GP - 1) / GP), blk(64);
+    const void *obs = c->d_obs_rm.p;
+    switch (c->kind) {
+    case EMIT_GAUSS:
+        hipLaunchKernelGGL((k_viterbi_fwd<N, EMIT_GAUSS>), grid, blk, 0, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, K, obs, Bdev, ptr, last);
+        break;
+    case EMIT_DISC:
+        hipLaunchKernelGGL((k_viterbi_fwd<N, EMIT_DISC>), grid, blk, 0, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, K, obs, Bdev, ptr, last);
+        break;
+    default:
+        hipLaunchKernelGGL((k_viterbi_fwd<N, EMIT_EXPL>), grid, blk, 0, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, K, obs, Bdev, ptr, last);
+    }
+    BHMM_HIP(hipGetLastError());
+    hipLaunchKernelGGL((k_viterbi_trace<N>), dim3((K + 63) / 64), dim3(64), 0, c->stream,
+                       (const int64_t *)c->d_offsets.p, K, (const uint32_t *)ptr,
+                       (const int32_t *)last, path);
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipMemcpyAsync(paths_host, path, (size_t)c->total * sizeof(int32_t),
+                            hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    return BHMM_OK;
+}
+
+template <int N>
+int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+               const double *par1, const double *u, uint64_t seed, int32_t *paths, int64_t *counts,
+               int64_t *n0, double *emis)
+{
+    int rc = forward_ci(c, A, pi, par0, par1); // alpha -> CI workspace
+    if (rc)
+        return rc;
+    const int K = c->K, n = c->n;
+    if ((rc = c->d_alpha_rm.ensure((size_t)c->total * n)))
+        return rc;
+    if ((rc = unpack_ws_rows(c, c->d_alpha_rm.p)))
+        return rc;
+    const size_t nstat = (size_t)N * N + N;
+    const int nblk = c->Gp / BLOCK;
+    const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)N : (c->kind == EMIT_DISC ? (size_t)c->M * N : 0);
+    // scratch2: path | status ; scratch: counts | emission partials | reduced emission | u
+    if ((rc = c->d_scratch2.ensure(((size_t)c->total + 4) * sizeof(int32_t))))
+        return rc;
+    int32_t *path = reinterpret_cast<int32_t *>(c->d_scratch2.p);
+    int *status = reinterpret_cast<int *>(path + c->total);
+    const size_t dbl = nstat + (size_t)nblk * esz + esz + (u ? (size_t)c->total : 0) + 8;
+    if ((rc = c->d_scratch.ensure(dbl * sizeof(double))))
+        return rc;
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(c->d_scratch.p);
+    double *epart = reinterpret_cast<double *>(c->d_scratch.p) + nstat;
+    double *ered = epart + (size_t)nblk * esz;
+    double *udev = nullptr;
+    if (u) {
+        udev = ered + esz;
+        BHMM_HIP(hipMemcpyAsync(udev, u, (size_t)c->total * sizeof(double), hipMemcpyHostToDevice,
+                                c->stream));
+    }
+    BHMM_HIP(hipMemsetAsync(cnt, 0, nstat * sizeof(unsigned long long), c->stream));
+    BHMM_HIP(hipMemsetAsync(status, 0, sizeof(int), c->stream));
+    if (esz)
+        BHMM_HIP(hipMemsetAsync(ered, 0, esz * sizeof(double), c->stream));
+    Model<N> m;
+    fill_model_pub<N>(m, n, c->kind, c->M, A, pi, par0, par1);
+    constexpr int GP = 64 / N;
+    hipLaunchKernelGGL((k_sample_path<N>), dim3((K + GP - 1) / GP), dim3(64), 0, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, K, (const double *)c->d_alpha_rm.p,
+                       (const double *)udev, seed, path, status);
+    BHMM_HIP(hipGetLastError());
+    if (counts || n0 || emis) {
+        const Chunks ch = chunks_pub(c);
+        const void *obs = c->d_obs_rm.p;
+        if (c->kind == EMIT_GAUSS)
+            hipLaunchKernelGGL((k_path_stats<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream,
+                               m, ch, (const int64_t *)c->d_offsets.p, obs, (const int32_t *)path,
+                               cnt, epart);
+        else if (c->kind == EMIT_DISC)
+            hipLaunchKernelGGL((k_path_stats<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK),
+                               (size_t)c->M * N * sizeof(double), c->stream, m, ch,
+                               (const int64_t *)c->d_offsets.p, obs, (const int32_t *)path, cnt,
+                               epart);
+        else
+            hipLaunchKernelGGL((k_path_stats<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream,
+                               m, ch, (const int64_t *)c->d_offsets.p, obs, (const int32_t *)path,
+                               cnt, epart);
+        BHMM_HIP(hipGetLastError());
+        if (esz) {
+            hipLaunchKernelGGL(k_add_partials, dim3((unsigned)((esz + 255) / 256)), dim3(256), 0,
+                               c->stream, (const double *)epart, nblk, (int)esz, ered);
+            BHMM_HIP(hipGetLastError());
+        }
+    }
+    std::vector<unsigned long long> hc(nstat);
+    std::vector<double> he(esz);
+    int hstatus = 0;
+    BHMM_HIP(hipMemcpyAsync(hc.data(), cnt, nstat * sizeof(unsigned long long),
+                            hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (esz)
+        BHMM_HIP(hipMemcpyAsync(he.data(), ered, esz * sizeof(double), hipMemcpyDeviceToHost,
+                                c->stream));
+    if (paths)
+        BHMM_HIP(hipMemcpyAsync(paths, path, (size_t)c->total * sizeof(int32_t),
+                                hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    if (hstatus) {
+        set_error("random choice found no state: alpha/A not normalisable (_hidden.c:299-304)");
+        return hstatus;
+    }
+    if (counts)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                counts[i * n + j] = (int64_t)hc[i * N + j];
+    if (n0)
+        for (int i = 0; i < n; ++i)
+            n0[i] = (int64_t)hc[N * N + i];
+    if (emis) {
+        if (c->kind == EMIT_GAUSS)
+            for (int w = 0; w < 3; ++w)
+                for (int i = 0; i < n; ++i)
+                    emis[w * n + i] = he[w * N + i];
+        else if (c->kind == EMIT_DISC)
+            for (int i = 0; i < n; ++i)
+                for (int o = 0; o < c->M; ++o)
+                    emis[(size_t)i * c->M + o] = he[(size_t)o * N + i];
+    }
+    return BHMM_OK;
+}
+
+struct TmpCtx {
+    bhmm_ctx *c = nullptr;
+    ~TmpCtx() { bhmm_ctx_destroy(c); }
+};
+
+int cur_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        d = 0;
+    }
+    return d;
+}
+
+} // namespace
+} // namespace bhmm
+
+using namespace bhmm;
+
+extern "C" {
+
+int bhmm_viterbi_batch(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                       const double *par1, int32_t *paths)
+{
+    if (!c || c->kind < 0)
+        return invalid_arg("no observations loaded");
+    if (!A || !pi || !paths)
+        return invalid_arg("NULL argument");
+    if (c->kind == BHMM_EMIT_GAUSSIAN && (!par0 || !par1))
+        return invalid_arg("gaussian emissions need means and sigmas");
+    if (c->kind == BHMM_EMIT_DISCRETE && !par0)
+        return invalid_arg("discrete emissions need B");
+    BHMM_HIP(hipSetDevice(c->device));
+    switch (c->N) {
+    case 2:
+        return viterbi_run<2>(c, A, pi, par0, par1, paths);
+    case 4:
+        return viterbi_run<4>(c, A, pi, par0, par1, paths);
+    default:
+        return viterbi_run<8>(c, A, pi, par0, par1, paths);
+    }
+}
+
+int bhmm_sample_paths(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                      const double *par1, const double *u, uint64_t seed, int32_t *paths,
+                      int64_t *counts, int64_t *n0, double *emis)
+{
+    if (!c || c->kind < 0)
+        return invalid_arg("no observations loaded");
+    if (!A || !pi)
+        return invalid_arg("NULL argument");
+    BHMM_HIP(hipSetDevice(c->device));
+    switch (c->N) {
+    case 2:
+        return sample_run<2>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis);
+    case 4:
+        return sample_run<4>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis);
+    default:
+        return sample_run<8>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis);
+    }
+}
+
+int bhmm_viterbi(int32_t *path, const double *A, const double *pobs, const double *pi, int N,
+                 int64_t T)
+{
+    if (!path || !A || !pobs || !pi || N < 1 || T < 1)
+        return invalid_arg("NULL argument or empty problem");
+    TmpCtx t;
+    int rc = bhmm_ctx_create(&t.c, cur_device(), nullptr);
+    if (rc)
+        return rc;
+    const int64_t off[2] = {0, T};
+    rc = bhmm_ctx_set_observations(t.c, BHMM_EMIT_EXPLICIT, pobs, off, 1, N, 0, 0, 0);
+    if (rc)
+        return rc;
+    return bhmm_viterbi_batch(t.c, A, pi, nullptr, nullptr, path);
+}
+
+int bhmm_sample_path(int32_t *path, const double *alpha, const double *A, const double *u, int N,
+                     int64_t T)
+{
+    if (!path || !alpha || !A || !u || N < 1 || T < 1)
+        return invalid_arg("NULL argument or empty problem");
+    if (N > 8)
+        return invalid_arg("this build handles 1..8 hidden states");
+    Tmp tmp;
+    double *d_alpha, *d_u;
+    int64_t *d_off;
+    int32_t *d_path;
+    int *d_status;
+    int rc;
+    if ((rc = tmp.alloc(&d_alpha, (size_t)T * N)) || (rc = tmp.alloc(&d_u, (size_t)T)) ||
+        (rc = tmp.alloc(&d_off, 2)) || (rc = tmp.alloc(&d_path, (size_t)T)) ||
+        (rc = tmp.alloc(&d_status, 1)))
+        return rc;
+    const int64_t off[2] = {0, T};
+    BHMM_HIP(hipMemcpy(d_alpha, alpha, (size_t)T * N * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(d_u, u, (size_t)T * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(d_off, off, sizeof(off), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemset(d_status, 0, sizeof(int)));
+    const int NP = pad_states_pub(N);
+    std::vector<double> pi(N, 0.0);
+#define BHMM_SAMPLE_CASE(NN)                                                                    \
+    {                                                                                           \
+        Model<NN> m;                                                                            \
+        fill_model_pub<NN>(m, N, EMIT_EXPL, 0, A, pi.data(), nullptr, nullptr);                 \
+        hipLaunchKernelGGL((k_sample_path<NN>), dim3(1), dim3(64), 0, 0, m,                     \
+                           (const int64_t *)d_off, 1, (const double *)d_alpha,                  \
+                           (const double *)d_u, (uint64_t)0, d_path, d_status);                 \
+    }
+    if (NP == 2)
+        BHMM_SAMPLE_CASE(2)
+    else if (NP == 4)
+        BHMM_SAMPLE_CASE(4)
+    else
+        BHMM_SAMPLE_CASE(8)
+    BHMM_HIP(hipGetLastError());
+    int st = 0;
+    BHMM_HIP(hipMemcpy(path, d_path, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost));
+    BHMM_HIP(hipMemcpy(&st, d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        set_error("random choice found no state: p not normalised (_hidden.c:299-304)");
+        return st;
+    }
+    return BHMM_OK;
+}
+
+int bhmm_libc_uniforms(double *u, int64_t T, int seed)
+{
+    if (!u || T < 0)
+        return invalid_arg("NULL argument");
+    if (seed >= 0)
+        srand((unsigned)seed); // _hidden.c:321-327
+    for (int64_t t = T - 1; t >= 0; --t)
+        u[t] = (double)rand() / ((double)RAND_MAX + 1.0); // _hidden.c:285-287
+    return BHMM_OK;
+}
+
+int bhmm_state_probabilities(double *gamma, const double *alpha, const double *beta, int N,
+                             int64_t T)
+{
+    if (!gamma || !alpha || !beta || N < 1 || T < 1)
+        return invalid_arg("NULL argument or empty problem");
+    Tmp tmp;
+    double *da, *db, *dg;
+    int rc;
+    const size_t cnt = (size_t)T * N;
+    if ((rc = tmp.alloc(&da, cnt)) || (rc = tmp.alloc(&db, cnt)) || (rc = tmp.alloc(&dg, cnt)))
+        return rc;
+    BHMM_HIP(hipMemcpy(da, alpha, cnt * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(db, beta, cnt * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_gamma_rows, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, 0,
+                       (const double *)da, (const double *)db, dg, N, T);
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipMemcpy(gamma, dg, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    return BHMM_OK;
+}
+
+int bhmm_transition_counts(double *C, const double *A, const double *pobs, const double *alpha,
+                           const double *beta, int N, int64_t T)
+{
+    if (!C || !A || !pobs || !alpha || !beta || N < 1 || T < 1)
+        return invalid_arg("NULL argument or empty problem");
+    if (N > 8)
+        return invalid_arg("this build handles 1..8 hidden states");
+    Tmp tmp;
+    double *dA, *dp, *da, *db, *dpart, *dC;
+    int rc;
+    const size_t cnt = (size_t)T * N;
+    const int nblk = (int)std::min<int64_t>(1024, (T + 255) / 256);
+    const int NP = pad_states_pub(N);
+    if ((rc = tmp.alloc(&dA, (size_t)N * N)) || (rc = tmp.alloc(&dp, cnt)) ||
+        (rc = tmp.alloc(&da, cnt)) || (rc = tmp.alloc(&db, cnt)) ||
+        (rc = tmp.alloc(&dpart, (size_t)nblk * NP * NP)) || (rc = tmp.alloc(&dC, (size_t)N * N)))
+        return rc;
+    BHMM_HIP(hipMemcpy(dA, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(dp, pobs, cnt * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(da, alpha, cnt * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(db, beta, cnt * sizeof(double), hipMemcpyHostToDevice));
+#define BHMM_XI_CASE(NN)                                                                        \
+    {                                                                                           \
+        hipLaunchKernelGGL((k_xi_rows<NN>), dim3(nblk), dim3(256), 0, 0, (const double *)dA,    \
+                           (const double *)dp, (const double *)da, (const double *)db, N, T,    \
+                           dpart);                                                              \
+        hipLaunchKernelGGL((k_sum_partials<NN>), dim3(1), dim3(64), 0, 0,                       \
+                           (const double *)dpart, nblk, N, dC);                                 \
+    }
+    if (NP == 2)
+        BHMM_XI_CASE(2)
+    else if (NP == 4)
+        BHMM_XI_CASE(4)
+    else
+        BHMM_XI_CASE(8)
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipMemcpy(C, dC, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost));
+    return BHMM_OK;
+}
+
+int bhmm_pobs_gaussian(double *pobs, const double *obs, const double *mu, const double *sigma,
+                       int N, int64_t T, int ignore_outliers)
+{
+    if (!pobs || !obs || !mu || !sigma || N < 1 || T < 1)
+        return invalid_arg("NULL argument or empty problem");
+    Tmp tmp;
+    double *dobs, *dmu, *dsig, *dp;
+    int rc;
+    if ((rc = tmp.alloc(&dobs, (size_t)T)) || (rc = tmp.alloc(&dmu, (size_t)N)) ||
+        (rc = tmp.alloc(&dsig, (size_t)N)) || (rc = tmp.alloc(&dp, (size_t)T * N)))
+        return rc;
+    BHMM_HIP(hipMemcpy(dobs, obs, (size_t)T * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(dmu, mu, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(dsig, sigma, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pobs_gaussian, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, 0,
+                       (const double *)dobs, (const double *)dmu, (const double *)dsig, dp, N, T,
+                       ignore_outliers);
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipMemcpy(pobs, dp, (size_t)T * N * sizeof(double), hipMemcpyDeviceToHost));
+    return BHMM_OK;
+}
+
+int bhmm_update_pout(double *pout, const int32_t *obs, const double *weights, int64_t T, int N,
+                     int M)
+{
+    if (!pout || !obs || !weights || N < 1 || M < 1 || T < 1)
+        return invalid_arg("NULL argument or empty problem");
+    if ((size_t)N * M * sizeof(double) > 64 * 1024)
+        return invalid_arg("N*M too large for the LDS histogram");
+    Tmp tmp;
+    int32_t *dobs;
+    double *dw, *dpart, *dout;
+    int rc;
+    const int nblk = (int)std::min<int64_t>(512, (T + 255) / 256);
+    if ((rc = tmp.alloc(&dobs, (size_t)T)) || (rc = tmp.alloc(&dw, (size_t)T * N)) ||
+        (rc = tmp.alloc(&dpart, (size_t)nblk * N * M)) || (rc = tmp.alloc(&dout, (size_t)N * M)))
+        return rc;
+    BHMM_HIP(hipMemcpy(dobs, obs, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(dw, weights, (size_t)T * N * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(dout, pout, (size_t)N * M * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_update_pout, dim3(nblk), dim3(256), (size_t)N * M * sizeof(double), 0,
+                       (const int32_t *)dobs, (const double *)dw, T, N, M, dpart);
+    hipLaunchKernelGGL(k_add_partials, dim3((N * M + 255) / 256), dim3(256), 0, 0,
+                       (const double *)dpart, nblk, N * M, dout);
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipMemcpy(pout, dout, (size_t)N * M * sizeof(double), hipMemcpyDeviceToHost));
+    return BHMM_OK;
+}
+
+} // extern "C"

@@ -74,6 +74,11 @@ int bhmm_viterbi(int32_t *path, const double *A, const double *pobs, const doubl
  * [0,1), u[t] used for step t (the reference draws them from libc rand(), T-1 first). */
 int bhmm_sample_path(int32_t *path, const double *alpha, const double *A, const double *u,
                      int N, int64_t T);
+/* The uniforms the reference's _sample_path would consume after set_seed(seed)
+ * (_hidden.c:283-327: r = rand()/(RAND_MAX+1.0), first draw used for t = T-1).  Host-only
+ * helper on the C library generator; seed < 0 leaves the generator state untouched
+ * (hidden.pyx:181-182 seeds only when a seed is given). */
+int bhmm_libc_uniforms(double *u, int64_t T, int seed);
 /* replaces _p_obs (_gaussian.h:5, _gaussian.c:45-70) + outputmodel.py:119-131 */
 int bhmm_pobs_gaussian(double *pobs, const double *obs, const double *mu, const double *sigma,
                        int N, int64_t T, int ignore_outliers);
@@ -134,7 +139,8 @@ int bhmm_viterbi_batch(bhmm_ctx *ctx, const double *A, const double *pi, const d
  * Outputs (any may be NULL): paths (host, int32, concatenated), and the hidden-path
  * statistics the sweep needs (generic_hmm.py:297-334,398-431):
  *   counts[N*N] int64 transition counts, n0[N] int64 first-state counts,
- *   emis: gaussian -> 3N doubles (n_i, sum o, sum o^2 per state); discrete -> N*M counts. */
+ *   emis: gaussian -> 3N doubles: n_i, sum (o - mu_i), sum (o - mu_i)^2 over the steps
+ *         assigned to state i (mu = par0, the current means); discrete -> N*M counts. */
 int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const double *par0,
                       const double *par1, const double *u, uint64_t seed, int32_t *paths,
                       int64_t *counts, int64_t *n0, double *emis);
