@@ -105,7 +105,8 @@ def test_viterbi_bit_exact(hidden, golden):
     v = hidden.viterbi(g["A"], pobs, g["pi"])
     assert sha1(v) == str(g["viterbi_sha1"])
     g = golden("d3_zeros")
-    assert np.array_equal(hidden.viterbi(g["A"], g["pobs"], g["pi"]), g["viterbi"])
+    pobs = orc.pobs_discrete(g["obs"], g["B"])
+    assert np.array_equal(hidden.viterbi(g["A"], pobs, g["pi"]), g["viterbi"])
     g = golden("g8_outliers")
     pobs = orc.pobs_gaussian(g["obs"], g["mu"], g["sigma"])
     assert np.array_equal(hidden.viterbi(g["A"], pobs, g["pi"]), g["viterbi"])
