@@ -1,0 +1,71 @@
+"""Functional wrappers with the signatures of bhmm/api.py:309-372 (estimate_hmm) and
+:375-470 (bayesian_hmm), plus lag_observations (:70-94) and the model factories (:97-158)."""
+import numpy as np
+
+from .estimators.bayesian_sampling import BayesianHMMSampler
+from .estimators.maximum_likelihood import MaximumLikelihoodEstimator
+from .hmm import HMM
+from .output_models import DiscreteOutputModel, GaussianOutputModel
+
+
+def _guess_output_type(observations):
+    """bhmm/api.py:36-66."""
+    o1 = np.asarray(observations[0])
+    if np.issubdtype(o1.dtype, np.integer) and o1.ndim == 1:
+        return 'discrete'
+    if np.issubdtype(o1.dtype, np.floating) and o1.ndim == 1:
+        return 'gaussian'
+    raise TypeError('Observations is neither sequences of integers nor 1D-sequences of floats.')
+
+
+def lag_observations(observations, lag, stride=1):
+    """bhmm/api.py:70-94: shifted sub-sampled copies (views) of every trajectory."""
+    obsnew = []
+    for obs in observations:
+        for shift in range(0, lag, stride):
+            obs_lagged = obs[shift:][::lag]
+            if len(obs_lagged) > 1:
+                obsnew.append(obs_lagged)
+    return obsnew
+
+
+def gaussian_hmm(pi, P, means, sigmas):
+    """bhmm/api.py:97-126."""
+    nstates = len(means)
+    return HMM(pi, P, GaussianOutputModel(nstates, means, sigmas))
+
+
+def discrete_hmm(pi, P, pout):
+    """bhmm/api.py:129-158."""
+    return HMM(pi, P, DiscreteOutputModel(pout))
+
+
+def estimate_hmm(observations, nstates, lag=1, initial_model=None, output=None, reversible=True,
+                 stationary=False, p=None, accuracy=1e-3, maxit=1000, maxit_P=100000,
+                 mincount_connectivity=1e-2, **engine_kwargs):
+    """bhmm/api.py:309-372."""
+    if output is None:
+        output = _guess_output_type(observations)
+    if lag > 1:
+        observations = lag_observations(observations, lag)
+    est = MaximumLikelihoodEstimator(observations, nstates, initial_model=initial_model,
+                                     output=output, reversible=reversible, stationary=stationary,
+                                     p=p, accuracy=accuracy, maxit=maxit, maxit_P=maxit_P,
+                                     **engine_kwargs)
+    est.fit()
+    est.hmm._lag = lag
+    return est.hmm
+
+
+def bayesian_hmm(observations, estimated_hmm, nsample=100, reversible=True, stationary=False,
+                 p0_prior='mixed', transition_matrix_prior='mixed', store_hidden=False,
+                 call_back=None, **engine_kwargs):
+    """bhmm/api.py:375-470.  Returns the list of sampled HMMs (the reference wraps them in a
+    SampledHMM statistics container, which is outside the accelerated path)."""
+    sampler = BayesianHMMSampler(observations, estimated_hmm.nstates, initial_model=estimated_hmm,
+                                 reversible=reversible, stationary=stationary,
+                                 transition_matrix_sampling_steps=1000, p0_prior=p0_prior,
+                                 transition_matrix_prior=transition_matrix_prior,
+                                 output=estimated_hmm.output_model.model_type, **engine_kwargs)
+    return sampler.sample(nsamples=nsample, save_hidden_state_trajectory=store_hidden,
+                          call_back=call_back)

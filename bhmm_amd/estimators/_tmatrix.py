@@ -1,0 +1,242 @@
+"""Host-side transition-matrix estimation for the M-step: the O(N^2..N^3) work of
+bhmm/estimators/_tmatrix_disconnected.py, whose arithmetic the reference delegates to the
+(unvendored) msmtools package.
+
+What is pinned and what is not: the non-reversible branch is exactly
+row-normalisation with empty rows set to C_ii = 1 (_tmatrix_disconnected.py:107-115).  The
+reversible maximum-likelihood estimator is restated from the published fixed-point iteration
+(Bowman et al. 2009; Prinz et al. 2011, Eq. 29-31; Trendelkamp-Schroer et al. 2015, Alg. 1)
+and is "parity unpinned" against msmtools itself; it is checked by self-consistency
+(detailed balance, likelihood optimality) and the closed forms of
+bhmm/tests/test_mlhmm_patho.py.  The partially reversible iteration restates
+_tmatrix_disconnected.py:126-190.
+"""
+import numpy as np
+from scipy.sparse import csr_matrix
+from scipy.sparse.csgraph import connected_components
+
+
+def is_transition_matrix(T, tol=1e-10):
+    T = np.asarray(T)
+    if T.ndim != 2 or T.shape[0] != T.shape[1]:
+        return False
+    return bool(np.all(T >= -tol) and np.allclose(T.sum(axis=1), 1.0, atol=1e-8))
+
+
+def connected_sets(C, mincount_connectivity=0, strong=True):
+    """_tmatrix_disconnected.py:28-43: sets sorted by decreasing size."""
+    Cc = np.array(C, dtype=np.float64)
+    Cc[Cc <= mincount_connectivity] = 0
+    n, labels = connected_components(csr_matrix(Cc), directed=True,
+                                     connection='strong' if strong else 'weak')
+    sets = [np.where(labels == i)[0] for i in range(n)]
+    sets.sort(key=lambda s: (-len(s), s[0]))
+    return sets
+
+
+def is_connected(C, mincount_connectivity=0, strong=True):
+    return len(connected_sets(C, mincount_connectivity=mincount_connectivity, strong=strong)) == 1
+
+
+def stationary_vector(P):
+    """Stationary distribution of an irreducible stochastic matrix (dense eigen-solve with a
+    linear-system fallback)."""
+    P = np.asarray(P, dtype=np.float64)
+    n = P.shape[0]
+    if n == 1:
+        return np.ones(1)
+    A = np.vstack([P.T - np.eye(n), np.ones((1, n))])
+    b = np.zeros(n + 1)
+    b[-1] = 1.0
+    pi = np.linalg.lstsq(A, b, rcond=None)[0]
+    pi = np.maximum(pi, 0.0)
+    return pi / pi.sum()
+
+
+def mle_reversible(C, maxiter=1000000, maxerr=1e-8):
+    """Reversible maximum-likelihood transition matrix of a strongly connected count matrix.
+    Fixed point  x_ij <- (c_ij + c_ji) / (c_i / x_i + c_j / x_j),  P_ij = x_ij / x_i."""
+    C = np.asarray(C, dtype=np.float64)
+    C2 = C + C.T
+    csum = C.sum(axis=1)
+    X = C2 / C2.sum()
+    xsum = X.sum(axis=1)
+    it, err = 0, 1.0
+    while err > maxerr and it < maxiter:
+        q = csum / xsum
+        with np.errstate(divide='ignore', invalid='ignore'):
+            X = C2 / (q[:, None] + q[None, :])
+        X[C2 == 0] = 0.0
+        X /= X.sum()
+        xnew = X.sum(axis=1)
+        err = np.max(np.abs(xnew - xsum))
+        xsum = xnew
+        it += 1
+    return X / X.sum(axis=1)[:, None]
+
+
+def mle_reversible_fixed_pi(C, pi, maxiter=1000000, maxerr=1e-8):
+    """Reversible MLE with a given stationary vector (Trendelkamp-Schroer & Noe 2013):
+    Lagrange-multiplier fixed point."""
+    C = np.asarray(C, dtype=np.float64)
+    pi = np.asarray(pi, dtype=np.float64)
+    n = C.shape[0]
+    C2 = C + C.T
+    lam = 0.5 * C2.sum(axis=1)
+    lam[lam == 0] = 1.0
+    it, err = 0, 1.0
+    while err > maxerr and it < maxiter:
+        D = lam[:, None] * pi[None, :] + lam[None, :] * pi[:, None]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            F = np.where(C2 > 0, C2 * pi[None, :] * lam[:, None] / D, 0.0)
+        lam_new = F.sum(axis=1)
+        lam_new[lam_new == 0] = lam[lam_new == 0]
+        err = np.max(np.abs(lam_new - lam) / np.maximum(lam, 1e-300))
+        lam = lam_new
+        it += 1
+    D = lam[:, None] * pi[None, :] + lam[None, :] * pi[:, None]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        P = np.where(C2 > 0, C2 * pi[None, :] / D, 0.0)
+    P[np.arange(n), np.arange(n)] = 0.0
+    P[np.arange(n), np.arange(n)] = 1.0 - P.sum(axis=1)
+    return P
+
+
+def transition_matrix_partial_rev(C, P, S, maxiter=1000000, maxerr=1e-8):
+    """_tmatrix_disconnected.py:126-190: rows S reversible among themselves, with outgoing
+    counts to the rest.  Writes rows S of P."""
+    S = np.asarray(S, dtype=bool)
+    Css = C[S][:, S]
+    Cso = C[S][:, ~S]
+    sym = Css + Css.T
+    rowcounts = C[S].sum(axis=1)
+    X = 0.5 * sym
+    Y = Cso.copy()
+    tot = X.sum() + Y.sum()
+    X, Y = X / tot, Y / tot
+    rows = X.sum(axis=1) + Y.sum(axis=1)
+    it, err = 0, 1.0
+    while err > maxerr and it < maxiter:
+        d = rowcounts / rows
+        X = sym / (d[:, None] + d)
+        Y = Cso / d[:, None]
+        tot = X.sum() + Y.sum()
+        X, Y = X / tot, Y / tot
+        new_rows = X.sum(axis=1) + Y.sum(axis=1)
+        err = np.max(np.abs(new_rows - rows))
+        rows = new_rows
+        it += 1
+    P[np.ix_(S, S)] = X
+    P[np.ix_(S, ~S)] = Y
+    P[S] /= P[S].sum(axis=1)[:, None]
+
+
+def estimate_P(C, reversible=True, fixed_statdist=None, maxiter=1000000, maxerr=1e-8,
+               mincount_connectivity=0):
+    """_tmatrix_disconnected.py:68-123."""
+    C = np.asarray(C, dtype=np.float64)
+    n = C.shape[0]
+    P = np.eye(n)
+    if reversible and fixed_statdist is None:
+        for s in connected_sets(C, mincount_connectivity=mincount_connectivity, strong=True):
+            mask = np.zeros(n, dtype=bool)
+            mask[s] = True
+            if C[np.ix_(mask, ~mask)].sum() > np.finfo(C.dtype).eps:
+                transition_matrix_partial_rev(C, P, mask, maxiter=maxiter, maxerr=maxerr)
+            elif s.size > 1:
+                I = np.ix_(mask, mask)
+                P[I] = mle_reversible(C[I], maxiter=maxiter, maxerr=maxerr)
+    else:
+        for s in connected_sets(C, mincount_connectivity=mincount_connectivity, strong=False):
+            I = np.ix_(s, s)
+            if not reversible:
+                Csub = C[I].copy()
+                zero_rows = np.where(Csub.sum(axis=1) == 0)[0]
+                Csub[zero_rows, zero_rows] = 1.0
+                P[I] = Csub / Csub.sum(axis=1)[:, None]
+            elif fixed_statdist is not None:
+                pi_s = np.asarray(fixed_statdist)[s]
+                P[I] = mle_reversible_fixed_pi(C[I], pi_s / pi_s.sum(), maxiter=maxiter,
+                                               maxerr=maxerr)
+            else:
+                raise NotImplementedError('Transition estimation for the case reversible='
+                                          + str(reversible) + ' not implemented.')
+    return P
+
+
+def stationary_distribution(P, C=None, mincount_connectivity=0):
+    """_tmatrix_disconnected.py:229-251."""
+    if C is None:
+        if is_connected(P, strong=True):
+            return stationary_vector(P)
+        raise ValueError('Computing stationary distribution for disconnected matrix. '
+                         'Need count matrix.')
+    C = np.asarray(C, dtype=np.float64)
+    pi = np.zeros(C.shape[0])
+    ctot = C.sum()
+    for s in connected_sets(C, mincount_connectivity=mincount_connectivity, strong=False):
+        w = C[s, :].sum() / ctot
+        pi[s] = w * stationary_vector(P[s, :][:, s])
+    return pi / pi.sum()
+
+
+def is_reversible(P):
+    """_tmatrix_disconnected.py:213-226."""
+    P = np.asarray(P, dtype=np.float64)
+    for s in connected_sets(P, strong=False):
+        Ps = P[s, :][:, s]
+        if not is_transition_matrix(Ps):
+            return False
+        pi = stationary_vector(Ps)
+        X = pi[:, None] * Ps
+        if not np.allclose(X, X.T):
+            return False
+    return True
+
+
+def sample_nonreversible(C, rng=np.random):
+    """Non-reversible posterior draw: independent Dirichlet rows,
+    P_i ~ Dir(c_i + 1) restricted to positive entries (msmtools sample_tmatrix,
+    reversible=False: prior counts -1 ... here the counts already include the prior)."""
+    C = np.asarray(C, dtype=np.float64)
+    n = C.shape[0]
+    P = np.zeros((n, n))
+    for i in range(n):
+        pos = C[i] > 0
+        if np.any(pos):
+            P[i, pos] = rng.dirichlet(C[i, pos])
+        else:
+            P[i, i] = 1.0
+    return P
+
+
+def sample_reversible(C, nsteps=1000, P0=None, rng=np.random):
+    """Reversible posterior draw by the Gibbs/Metropolis element sampler of
+    Noe, J. Chem. Phys. 128, 244103 (2008) on the symmetric flux matrix X (x_ij = pi_i p_ij):
+    each step rescales one row+column pair (detailed balance preserved by construction).
+    PARITY UNPINNED with respect to msmtools' sampler (statistical agreement only)."""
+    C = np.asarray(C, dtype=np.float64)
+    n = C.shape[0]
+    if P0 is None:
+        P0 = mle_reversible(C + 1e-12)
+    pi = stationary_vector(P0)
+    X = pi[:, None] * P0
+    X = 0.5 * (X + X.T)
+    X /= X.sum()
+    logpost = lambda X_: np.sum(np.where(C > 0, C * np.log(
+        np.maximum(X_ / X_.sum(axis=1)[:, None], 1e-300)), 0.0))
+    cur = logpost(X)
+    idx = [(i, j) for i in range(n) for j in range(i, n) if (C[i, j] + C[j, i]) > 0]
+    for _ in range(int(nsteps)):
+        i, j = idx[rng.randint(len(idx))]
+        f = np.exp(rng.normal(0.0, 0.5))
+        Xn = X.copy()
+        Xn[i, j] *= f
+        if i != j:
+            Xn[j, i] = Xn[i, j]
+        Xn /= Xn.sum()
+        new = logpost(Xn)
+        # log-normal proposal on a positive element: Jacobian factor f
+        if np.log(rng.random_sample()) < new - cur + np.log(f):
+            X, cur = Xn, new
+    return X / X.sum(axis=1)[:, None]

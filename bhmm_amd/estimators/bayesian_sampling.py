@@ -1,0 +1,186 @@
+"""Gibbs sampler driver with the interface of bhmm/estimators/bayesian_sampling.py:31-373.
+
+The hot step of every sweep -- sampling all hidden paths (forward pass + backward sampling per
+trajectory, :283-331) and collecting their statistics (generic_hmm.py:297-334,398-431) -- is
+one call into the device engine, which returns the integer transition / start counts and the
+per-state emission statistics.  The parameter updates that follow (emission parameters, p0,
+transition matrix; :333-373) are tiny host-side draws; the reversible transition-matrix
+sampler lives in msmtools in the reference and is restated from the literature here
+("parity unpinned", see _tmatrix.sample_reversible).
+"""
+import copy
+
+import numpy as np
+
+from .. import hidden
+from ..sharding import Comm, lpt_partition
+from ..util import config
+from . import _tmatrix
+
+
+def _default_engine_factory(device):
+    from ..engine import Engine
+    return Engine(device)
+
+
+class BayesianHMMSampler(object):
+    def __init__(self, observations, nstates, initial_model=None, reversible=True,
+                 stationary=False, transition_matrix_sampling_steps=1000, p0_prior='mixed',
+                 transition_matrix_prior='mixed', output='gaussian', device=None,
+                 process_group=None, engine_factory=None):
+        if len(observations) == 0:
+            raise Exception("No observations were provided.")
+        self.reversible = reversible
+        self.stationary = stationary
+        self.nstates = nstates
+        self.observations = copy.deepcopy(observations)
+        self.nobs = len(observations)
+        self.Ts = [len(o) for o in observations]
+        self.maxT = np.max(self.Ts)
+        if not initial_model:
+            raise NotImplementedError('bhmm_amd needs an initial_model (e.g. the result of '
+                                      'MaximumLikelihoodEstimator.fit())')
+        self.model = copy.deepcopy(initial_model)
+        self._output = self.model.output_model.model_type
+
+        # priors, bayesian_sampling.py:158-184
+        if p0_prior is None or (isinstance(p0_prior, str) and p0_prior == 'sparse'):
+            self.prior_n0 = np.zeros(self.nstates)
+        elif isinstance(p0_prior, np.ndarray):
+            if p0_prior.ndim == 1 and p0_prior.shape[0] == self.nstates:
+                self.prior_n0 = np.array(p0_prior)
+            else:
+                raise ValueError('initial distribution prior must have dimension ' + str(nstates))
+        elif p0_prior == 'mixed':
+            self.prior_n0 = np.array(self.model.initial_distribution)
+        elif p0_prior == 'uniform':
+            self.prior_n0 = np.ones(nstates)
+        else:
+            raise ValueError('initial distribution prior mode undefined: ' + str(p0_prior))
+        if transition_matrix_prior is None or (isinstance(p0_prior, str) and p0_prior == 'sparse'):
+            self.prior_C = np.zeros((self.nstates, self.nstates))
+        elif isinstance(transition_matrix_prior, np.ndarray):
+            if np.array_equal(transition_matrix_prior.shape, (self.nstates, self.nstates)):
+                self.prior_C = np.array(transition_matrix_prior)
+            else:
+                raise ValueError('transition matrix prior must have shape (n, n)')
+        elif transition_matrix_prior == 'mixed':
+            self.prior_C = np.array(self.model.transition_matrix)
+        elif transition_matrix_prior == 'uniform':
+            self.prior_C = np.ones((nstates, nstates))
+        else:
+            raise ValueError('transition matrix prior mode undefined: '
+                             + str(transition_matrix_prior))
+        if reversible:
+            if not _tmatrix.is_connected(self.model.transition_matrix + self.prior_C, strong=True):
+                raise NotImplementedError('Trying to sample disconnected HMM with option '
+                                          'reversible:\n ' + str(self.model.transition_matrix)
+                                          + '\nUse prior to connect, select connected subset, '
+                                          'or use reversible=False.')
+        self.transition_matrix_sampling_steps = transition_matrix_sampling_steps
+        hidden.set_implementation(config.kernel)
+        self.model.output_model.set_implementation(config.kernel)
+
+        self._comm = Comm(process_group)
+        self._parts = lpt_partition(self.Ts, self._comm.world)
+        self._mine = self._parts[self._comm.rank]
+        if device is None:
+            device = self._comm.rank if self._comm.active else 0
+        factory = engine_factory or _default_engine_factory
+        self._engine = factory(device)
+        M = self.model.output_model.nsymbols if self._output == 'discrete' else 0
+        self._engine.set_observations(self._output, [self.observations[k] for k in self._mine],
+                                      nstates, nsymbols=M)
+        self._sweep = 0
+        self._rng = np.random
+
+    def sample(self, nsamples, nburn=0, nthin=1, save_hidden_state_trajectory=False,
+               call_back=None, seed=None):
+        """bayesian_sampling.py:206-267."""
+        first = True
+        for _ in range(nburn):
+            self._update(seed=seed if first else None, keep_paths=False)
+            first = False
+        models = list()
+        for _ in range(nsamples):
+            for _thin in range(nthin):
+                self._update(seed=seed if first else None,
+                             keep_paths=save_hidden_state_trajectory)
+                first = False
+            model_copy = copy.deepcopy(self.model)
+            if not save_hidden_state_trajectory:
+                model_copy.hidden_state_trajectories = None
+            models.append(model_copy)
+            if call_back is not None:
+                call_back()
+        return models
+
+    def _update(self, seed=None, keep_paths=False):
+        """One Gibbs sweep, bayesian_sampling.py:269-281."""
+        C, n0, emis = self._updateHiddenStateTrajectories(seed=seed, keep_paths=keep_paths)
+        self._updateEmissionProbabilities(emis)
+        self._updateTransitionMatrix(C, n0)
+
+    def _updateHiddenStateTrajectories(self, seed=None, keep_paths=False):
+        """bayesian_sampling.py:283-331 for all trajectories at once, plus the hidden-path
+        statistics the two parameter updates need."""
+        if seed is not None:
+            self._seed_base = int(seed)
+        base = getattr(self, '_seed_base', 0x5EED)
+        sweep_seed = (base * 1000003 + self._sweep * 7919 + self._comm.rank) & 0xFFFFFFFFFFFF
+        self._sweep += 1
+        om = self.model.output_model
+        par0, par1 = om.parameters()
+        paths, C, n0, emis = self._engine.sample_paths(
+            self.model.transition_matrix, self.model.initial_distribution, par0, par1,
+            seed=sweep_seed, want_paths=keep_paths)
+        if self._comm.active:
+            C = self._comm.allreduce_sum_numpy(C)
+            n0 = self._comm.allreduce_sum_numpy(n0)
+            emis = self._comm.allreduce_sum_numpy(emis)
+        if keep_paths:
+            full = [None] * self.nobs
+            if self._comm.active:
+                for part, plist in zip(self._parts, self._comm.gather_objects(paths)):
+                    for k, pth in zip(part, plist):
+                        full[k] = pth
+            else:
+                for k, pth in zip(self._mine, paths):
+                    full[k] = pth
+            self.model.hidden_state_trajectories = full
+        else:
+            self.model.hidden_state_trajectories = None
+        return C, n0, emis
+
+    def _updateEmissionProbabilities(self, emis):
+        """bayesian_sampling.py:333-339 from per-state statistics instead of gathered arrays."""
+        om = self.model.output_model
+        if self._output == 'gaussian':
+            om.sample_from_statistics(emis[0], emis[1], emis[2], rng=self._rng)
+        else:
+            om.sample_from_statistics(emis, rng=self._rng)
+
+    def _updateTransitionMatrix(self, Cint, n0int):
+        """bayesian_sampling.py:341-373."""
+        C = Cint.astype(np.float64) + self.prior_C
+        if self.reversible and not _tmatrix.is_connected(C, strong=True):
+            raise NotImplementedError('Encountered disconnected count matrix with sampling '
+                                      'option reversible:\n ' + str(C) + '\nUse prior to ensure '
+                                      'connectivity or use reversible=False.')
+        if self.reversible:
+            P0 = _tmatrix.mle_reversible(C, maxiter=10000)
+            C = C.copy()
+            C[np.where(P0 + P0.T == 0)] = 0
+            Tij = _tmatrix.sample_reversible(C, nsteps=self.transition_matrix_sampling_steps,
+                                             P0=P0, rng=self._rng)
+        else:
+            Tij = _tmatrix.sample_nonreversible(C, rng=self._rng)
+        if self.stationary:
+            p0 = _tmatrix.stationary_distribution(Tij, C=C)
+        else:
+            n0 = n0int.astype(float)
+            w = n0 + self.prior_n0
+            positive = w > 0
+            p0 = np.zeros_like(n0)
+            p0[positive] = self._rng.dirichlet(w[positive])
+        self.model.update(p0, Tij)

@@ -1,0 +1,239 @@
+"""Baum-Welch EM driver with the interface of bhmm/estimators/maximum_likelihood.py:36-446.
+
+Same constructor, `fit()`, properties, convergence rule and final Viterbi pass as the
+reference; what changes is where the loop over trajectories runs.  The reference walks the
+trajectories in Python and calls five kernels per trajectory (:221-269, :383-385); here the
+whole E-step is one call into the device-resident engine (bhmm_amd/engine.py), which returns
+only the reduced sufficient statistics.  With torch.distributed initialised, trajectories are
+sharded over ranks and the statistics are all-reduced (bhmm_amd/sharding.py); every rank then
+performs the identical O(N^2) M-step.
+"""
+import copy
+import time
+
+import numpy as np
+
+from .. import hidden
+from ..sharding import Comm, lpt_partition
+from ..util import config
+from . import _tmatrix
+
+
+def _default_engine_factory(device):
+    from ..engine import Engine
+    return Engine(device)
+
+
+class MaximumLikelihoodEstimator(object):
+    def __init__(self, observations, nstates, initial_model=None, output='gaussian',
+                 reversible=True, stationary=False, p=None, accuracy=1e-3, maxit=1000,
+                 maxit_P=100000, device=None, process_group=None, store_gamma=False,
+                 engine_factory=None):
+        # maximum_likelihood.py:101-104
+        self._observations = copy.deepcopy(observations)
+        self._nobs = len(observations)
+        self._Ts = [len(o) for o in observations]
+        self._maxT = np.max(self._Ts)
+        self._nstates = nstates
+        self._reversible = reversible
+        self._stationary = stationary
+        if initial_model is None:
+            # the reference builds one with bhmm.init_hmm (GMM / PCCA heuristics, needs
+            # msmtools); model initialisation is outside the accelerated path.
+            raise NotImplementedError('bhmm_amd needs an initial_model (HMM); the heuristic '
+                                      'initialisers of bhmm.init are out of scope')
+        self._hmm = copy.deepcopy(initial_model)
+        if self._hmm.nstates != nstates:
+            raise ValueError('initial_model has %d states, nstates=%d' % (self._hmm.nstates, nstates))
+        self._output = self._hmm.output_model.model_type
+        self._fixed_stationary_distribution = None
+        self._fixed_initial_distribution = None
+        if p is not None:
+            if stationary:
+                self._fixed_stationary_distribution = np.array(p)
+            else:
+                self._fixed_initial_distribution = np.array(p)
+        self._accuracy = accuracy
+        self._maxit = maxit
+        self._maxit_P = maxit_P
+        self._likelihoods = None
+        self._store_gamma = store_gamma
+        self._gammas = None
+        self._last = None
+        hidden.set_implementation(config.kernel)
+        self._hmm.output_model.set_implementation(config.kernel)
+
+        # ---- device-resident batch (replaces the shared alpha/beta/pobs buffers, :128-133) ----
+        self._comm = Comm(process_group)
+        self._parts = lpt_partition(self._Ts, self._comm.world)
+        self._mine = self._parts[self._comm.rank]
+        if device is None:
+            device = self._comm.rank if self._comm.active else 0
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    device = device % max(torch.cuda.device_count(), 1)
+            except ImportError:
+                pass
+        self._device = device
+        factory = engine_factory or _default_engine_factory
+        self._engine = factory(device)
+        M = self._hmm.output_model.nsymbols if self._output == 'discrete' else 0
+        self._engine.set_observations(self._output, [self._observations[k] for k in self._mine],
+                                      nstates, nsymbols=M)
+
+    # ---- properties (maximum_likelihood.py:145-219) -------------------------------------
+    @property
+    def observations(self):
+        return self._observations
+
+    @property
+    def nobservations(self):
+        return self._nobs
+
+    @property
+    def observation_lengths(self):
+        return self._Ts
+
+    @property
+    def is_reversible(self):
+        return self._reversible
+
+    @property
+    def nstates(self):
+        return self._nstates
+
+    @property
+    def accuracy(self):
+        return self._accuracy
+
+    @property
+    def maxit(self):
+        return self._maxit
+
+    @property
+    def likelihood(self):
+        return self._likelihoods[-1]
+
+    @property
+    def likelihoods(self):
+        return self._likelihoods
+
+    @property
+    def hidden_state_probabilities(self):
+        """gamma per trajectory (T_k, N), fetched from the device on demand (construct the
+        estimator with store_gamma=True).  With several ranks only the local trajectories are
+        filled, the others are None."""
+        if not self._store_gamma:
+            raise RuntimeError('construct the estimator with store_gamma=True to keep gamma')
+        out = [None] * self._nobs
+        for j, k in enumerate(self._mine):
+            out[k] = self._engine.gamma(j)
+        return out
+
+    @property
+    def hmm(self):
+        return self._hmm
+
+    @property
+    def output_model(self):
+        return self._hmm.output_model
+
+    @property
+    def transition_matrix(self):
+        return self._hmm.transition_matrix
+
+    @property
+    def initial_probability(self):
+        return self._hmm.initial_distribution
+
+    @property
+    def stationary_probability(self):
+        assert self._stationary, 'Estimator is not stationary'
+        return self._hmm.initial_distribution
+
+    # ---- E-step --------------------------------------------------------------------------
+    def _estep(self):
+        """All trajectories of this rank on the GPU, then the cross-rank reduction
+        (maximum_likelihood.py:221-282, 383-385).  Returns an EStepResult."""
+        om = self._hmm.output_model
+        par0, par1 = om.parameters()
+        res = self._engine.estep(self._hmm.transition_matrix, self._hmm.initial_distribution,
+                                 par0, par1, store_gamma=self._store_gamma)
+        if self._comm.active:
+            packed = self._comm.allreduce_sum_numpy(res.packed)
+            res = self._engine.unpack(packed, res.logL_k)
+        assert np.isfinite(res.loglik)       # maximum_likelihood.py:385
+        return res
+
+    # ---- M-step --------------------------------------------------------------------------
+    def _update_model(self, res, maxiter=10000000):
+        """maximum_likelihood.py:284-330 on the reduced statistics."""
+        gamma0_sum, C = res.gamma0_sum, res.C
+        T = _tmatrix.estimate_P(C, reversible=self._hmm.is_reversible,
+                                fixed_statdist=self._fixed_stationary_distribution,
+                                maxiter=maxiter, maxerr=1e-12, mincount_connectivity=1e-16)
+        if self._stationary:
+            if self._fixed_stationary_distribution is None:
+                pi = _tmatrix.stationary_distribution(T, C=C, mincount_connectivity=1e-16)
+            else:
+                pi = self._fixed_stationary_distribution
+        else:
+            if self._fixed_initial_distribution is None:
+                pi = gamma0_sum / np.sum(gamma0_sum)
+            else:
+                pi = self._fixed_initial_distribution
+        self._hmm.update(pi, T)
+        om = self._hmm.output_model
+        if self._output == 'gaussian':
+            om.estimate_from_statistics(res.state_counts, res.sum_gd, res.sum_gdd)
+        else:
+            om.estimate_from_statistics(res.symbol_counts)
+
+    def compute_viterbi_paths(self):
+        """maximum_likelihood.py:332-352.  Paths of the local trajectories; with several
+        ranks they are gathered so that every rank returns the full list."""
+        om = self._hmm.output_model
+        par0, par1 = om.parameters()
+        local = self._engine.viterbi(self._hmm.transition_matrix, self._hmm.initial_distribution,
+                                     par0, par1)
+        paths = np.empty(self._nobs, dtype=object)
+        if self._comm.active:
+            for part, plist in zip(self._parts, self._comm.gather_objects(local)):
+                for k, pth in zip(part, plist):
+                    paths[k] = pth
+        else:
+            for k, pth in zip(self._mine, local):
+                paths[k] = pth
+        return paths
+
+    def fit(self):
+        """maximum_likelihood.py:354-446."""
+        it = 0
+        self._likelihoods = np.zeros(self.maxit)
+        loglik = 0.0
+        tmatrix_nonzeros = self.hmm.transition_matrix.nonzero()
+        converged = False
+        res = None
+        while not converged and it < self.maxit:
+            res = self._estep()
+            loglik = res.loglik
+            if it > 0:
+                dL = loglik - self._likelihoods[it - 1]
+                if dL < self._accuracy:          # signed, as in the reference (:389-394)
+                    converged = True
+            self._update_model(res, maxiter=self._maxit_P)
+            tmatrix_nonzeros_new = self.hmm.transition_matrix.nonzero()
+            if not np.array_equal(tmatrix_nonzeros, tmatrix_nonzeros_new):
+                converged = False                # likelihood is discontinuous here (:401-404)
+                tmatrix_nonzeros = tmatrix_nonzeros_new
+            self._likelihoods[it] = loglik
+            it += 1
+        self._likelihoods = self._likelihoods[:it]
+        self._hmm.likelihood = loglik            # of the model before the last M-step (:423)
+        if res is not None:
+            self.count_matrix = res.C.copy()
+            self.initial_count = res.gamma0_sum.copy()
+        self._last = res
+        self._hmm.hidden_state_trajectories = self.compute_viterbi_paths()
+        return self._hmm

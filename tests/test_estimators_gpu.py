@@ -1,0 +1,66 @@
+"""End-to-end estimators on the HIP engine: the same EM run as the oracle-backed CPU double
+must give the same likelihood history, parameters and Viterbi paths."""
+import numpy as np
+import pytest
+
+import bhmm_amd
+from oracle_engine import OracleEngine
+from test_host_logic import _gauss_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mle_fit_matches_oracle_driven_fit():
+    obs, init = _gauss_problem(seed=1, K=6, T=700)
+    ref = bhmm_amd.MaximumLikelihoodEstimator(obs, 3, initial_model=init, reversible=True,
+                                              accuracy=1e-5, maxit=25, engine_factory=OracleEngine)
+    href = ref.fit()
+    est = bhmm_amd.MaximumLikelihoodEstimator(obs, 3, initial_model=init, reversible=True,
+                                              accuracy=1e-5, maxit=25, store_gamma=True)
+    hmm = est.fit()
+    assert len(est.likelihoods) == len(ref.likelihoods)
+    np.testing.assert_allclose(est.likelihoods, ref.likelihoods, rtol=1e-10)
+    np.testing.assert_allclose(hmm.transition_matrix, href.transition_matrix, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(hmm.output_model.means, href.output_model.means, rtol=1e-8)
+    np.testing.assert_allclose(hmm.output_model.sigmas, href.output_model.sigmas, rtol=1e-7)
+    for a, b in zip(hmm.hidden_state_trajectories, href.hidden_state_trajectories):
+        assert np.array_equal(a, b)
+    g = est.hidden_state_probabilities
+    assert np.allclose(g[0].sum(axis=1), 1.0) and g[0].shape == (len(obs[0]), 3)
+
+
+def test_discrete_patho_on_gpu():
+    obs = np.array([0, 0, 0, 0, 0, 1, 1, 1, 1], dtype=int)
+    init = bhmm_amd.discrete_hmm([0.5, 0.5], [[0.7, 0.3], [0.2, 0.8]], [[0.8, 0.2], [0.3, 0.7]])
+    hmm = bhmm_amd.estimate_hmm([obs], nstates=2, accuracy=1e-6, initial_model=init)
+    assert np.allclose(hmm.transition_matrix, [[0.8, 0.2], [0.0, 1.0]], atol=1e-5)
+    assert np.allclose(hmm.output_model.output_probabilities, np.eye(2), atol=1e-5)
+
+
+def test_bayesian_sampler_on_gpu():
+    obs, init = _gauss_problem(seed=2, K=4, T=500)
+    mle = bhmm_amd.estimate_hmm(obs, 3, initial_model=init, reversible=False, maxit=15)
+    np.random.seed(1)
+    models = bhmm_amd.bayesian_hmm(obs, mle, nsample=10, reversible=False, store_hidden=True)
+    means = np.array([m.output_model.means for m in models])
+    assert means.std(axis=0).min() > 0
+    assert np.allclose(means.mean(axis=0), mle.output_model.means, atol=0.3)
+    assert all(p.shape == (len(o),) for p, o in zip(models[-1].hidden_state_trajectories, obs))
+
+
+def test_output_models_on_gpu(golden):
+    g = golden("pobs_gauss3")
+    om = bhmm_amd.GaussianOutputModel(3, means=g["mu"], sigmas=g["sigma"])
+    np.testing.assert_allclose(om.p_obs(g["obs"]), g["pobs"], rtol=1e-13)
+    out = np.zeros((len(g["obs"]) + 3, 3))
+    om.p_obs(g["obs"], out=out)
+    np.testing.assert_allclose(out[:-3], g["pobs"], rtol=1e-13)
+    assert np.all(out[-3:] == 1.0)      # stale zero rows are "outliers" too (gaussian.py:194-195)
+    gd = golden("d8_ragged")
+    from conftest import split
+    obs = split(gd["obs"].astype(np.int32), gd["lengths"])
+    dm = bhmm_amd.DiscreteOutputModel(gd["B"])
+    from oracle import oracle as orc
+    r = orc.estep("discrete", obs, gd["A"], gd["pi"], gd["B"], want_gamma=True)
+    dm.estimate(obs, r["gammas"])
+    np.testing.assert_allclose(dm.output_probabilities, gd["B_new"], rtol=1e-10, atol=1e-15)
