@@ -45,7 +45,7 @@ Chunks chunks_pub(const bhmm_ctx *c)
 template <int N, int KIND>
 static size_t smem_fwdbwd(int M)
 {
-    return (size_t)(4 * StatLayout<N, KIND>::S + (KIND == EMIT_DISC ? 2 * M * N : 0)) *
+    return (size_t)(4 * StatLayout<N, KIND>::S + 2 * N * N + (KIND == EMIT_DISC ? 2 * M * N : 0)) *
            sizeof(double);
 }
 
@@ -56,10 +56,13 @@ struct Runner {
     static int prescan_stitch(bhmm_ctx *c, const Model<N> &m)
     {
         const Chunks ch = chunks_of(c);
-        const int nblk = c->Gp / BLOCK;
-        const size_t sm0 = KIND == EMIT_DISC ? (size_t)c->M * N * sizeof(double) : 0;
+        const size_t sm0 = (size_t)(N * N + 64 * N + (KIND == EMIT_DISC ? c->M * N : 0)) *
+                           sizeof(double);
+        if (sm0 > 64 * 1024)
+            BHMM_HIP(hipFuncSetAttribute((const void *)(k_prescan<N, KIND>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm0));
         BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
-        hipLaunchKernelGGL((k_prescan<N, KIND>), dim3(nblk), dim3(BLOCK), sm0, c->stream, m, ch,
+        hipLaunchKernelGGL((k_prescan<N, KIND>), dim3(c->Gp / 64), dim3(64 * N), sm0, c->stream, m, ch,
                            (const void *)c->d_obs_ci.p, (const double *)c->d_Bt.p, c->d_M.p);
         BHMM_HIP(hipGetLastError());
         BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
@@ -101,11 +104,12 @@ struct Runner {
         rc = fwdbwd<KIND, MODE_ESTEP>(c, m, (flags & BHMM_FLAG_STORE_GAMMA) != 0);
         if (rc)
             return rc;
-        hipLaunchKernelGGL(k_logl, dim3((c->K + 255) / 256), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_logl, dim3(c->K), dim3(64), 0, c->stream,
                            (const int32_t *)c->d_traj_c0.p, c->K, (const double *)c->d_logLc.p,
                            c->d_logLk.p);
         BHMM_HIP(hipGetLastError());
-        hipLaunchKernelGGL((k_finalize<N, KIND>), dim3(1), dim3(BLOCK), 0, c->stream, m, c->K,
+        const int nfin = StatLayout<N, KIND>::S + (KIND == EMIT_DISC ? c->M * N : 0) + N + 1;
+        hipLaunchKernelGGL((k_finalize<N, KIND>), dim3(nfin), dim3(64), 0, c->stream, m, c->K,
                            c->Gp / BLOCK, (const double *)c->d_partials.p,
                            (const double *)c->d_dpartials.p, (const double *)c->d_logLk.p,
                            (const double *)c->d_gamma0.p, stats_dev);
@@ -143,7 +147,7 @@ struct Runner {
         if (rc)
             return rc;
         if (MODE == MODE_FWD) {
-            hipLaunchKernelGGL(k_logl, dim3((c->K + 255) / 256), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(k_logl, dim3(c->K), dim3(64), 0, c->stream,
                                (const int32_t *)c->d_traj_c0.p, c->K,
                                (const double *)c->d_logLc.p, c->d_logLk.p);
             BHMM_HIP(hipGetLastError());

@@ -144,113 +144,163 @@ __device__ __forceinline__ void stage_Bt(double *dst, const double *Bt_g, int M)
         dst[i] = Bt_g[i];
 }
 
+// ---- cross-lane helpers on DPP (no LDS round trip): exchanges inside aligned groups of
+// 2, 4 or 8 lanes.  xor1/xor2 are quad permutes; xor4 is row_half_mirror followed by a quad
+// reversal (lane i -> 7-i -> i^4).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int H>
+__device__ __forceinline__ int xchg_i32(int v)
+{
+    if constexpr (H == 1)
+        return dpp_i32<0xB1>(v); // quad_perm [1,0,3,2]
+    else if constexpr (H == 2)
+        return dpp_i32<0x4E>(v); // quad_perm [2,3,0,1]
+    else
+        return dpp_i32<0x1B>(dpp_i32<0x141>(v)); // row_half_mirror, quad_perm [3,2,1,0]
+}
+template <int H>
+__device__ __forceinline__ double xchg_f64(double x)
+{
+    const int lo = xchg_i32<H>(__double2loint(x));
+    const int hi = xchg_i32<H>(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ int group_max(int v)
+{
+    v = max(v, xchg_i32<1>(v));
+    if constexpr (N >= 4)
+        v = max(v, xchg_i32<2>(v));
+    if constexpr (N >= 8)
+        v = max(v, xchg_i32<4>(v));
+    return v;
+}
+__device__ __forceinline__ int exponent_of(double x)
+{
+    int e;
+    (void)frexp(x, &e);
+    return e;
+}
+
 // =========================================================================================
 // k_prescan: chunk transfer matrices.
 //   Mc = prod_{t in chunk} A diag(p_t)   (t = t0 .. t0+len-1; for the first chunk of a
 //   trajectory the product starts at t = 1 and every row is seeded with pi o p_0, so that
 //   e_0^T Mc is the unnormalised alpha at the chunk end).
 //   Row r is the forward recursion started from unit vector e_r (_hidden.c:42-63 without
-//   the division); rows are renormalised by a power of two every step (exact) and the
-//   exponent is carried separately:  true row r = 2^ex[r] * stored row r.
+//   the division).  Mapping: N lanes per chunk, lane r owns row r (N doubles) and a private
+//   register copy of A; the step's emission vector is computed one state per lane and
+//   exchanged through a 64-byte LDS slot per chunk.  A workgroup of 64*N threads covers the
+//   same 64 chunks as one wavefront of k_fwdbwd (one CI record group), so observation loads
+//   stay inside one 512 B segment.  Rows are renormalised by a power of two every step
+//   (exact); the exponent is carried separately:  true row r = 2^ex[r] * stored row r.
 //   Output per chunk: N*N doubles row-major + N exponents (as doubles).
 // =========================================================================================
 template <int N, int KIND>
-__global__ __launch_bounds__(BLOCK) void k_prescan(const Model<N> m, const Chunks ch,
-                                                   const void *obs_ci, const double *Bt_g,
-                                                   double *Mbuf)
+__global__ __launch_bounds__(64 * N) void k_prescan(const Model<N> m, const Chunks ch,
+                                                    const void *obs_ci, const double *Bt_g,
+                                                    double *Mbuf)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if constexpr (KIND == EMIT_DISC) {
-        stage_Bt<N>(smem, Bt_g, m.M);
-        __syncthreads();
-    }
-    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    double *sA = smem;             // [N][N]
+    double *sP = smem + N * N;     // [64 chunks][N] emission exchange
+    double *sBt = sP + 64 * N;     // [M][N] (discrete)
+    for (int i = threadIdx.x; i < N * N; i += blockDim.x)
+        sA[i] = m.A[i];
+    if constexpr (KIND == EMIT_DISC)
+        stage_Bt<N>(sBt, Bt_g, m.M);
+    __syncthreads();
+    const int cl = threadIdx.x / N; // chunk within the record group == CI lane
+    const int r = threadIdx.x % N;
+    const int64_t g = (int64_t)blockIdx.x * 64 + cl;
     const int len = ch.len[g];
     if (len == 0)
         return;
     const bool first = (ch.t0[g] == 0);
+    double A[N][N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int j = 0; j < N; j += 2) {
+            const double2 x = *reinterpret_cast<const double2 *>(sA + k * N + j);
+            A[k][j] = x.x;
+            A[k][j + 1] = x.y;
+        }
+    const double mu_r = m.e0[r], is_r = m.e1[r], cn_r = m.e2[r];
+    const bool real = r < m.nreal;
+    double *slot = sP + cl * N;
+    const unsigned long long gmask = ((N == 64) ? ~0ull : ((1ull << N) - 1))
+                                     << ((threadIdx.x & 63) / N * N);
 
-    double Mx[N][N];
-    int ex[N];
+    double row[N];
 #pragma unroll
-    for (int r = 0; r < N; ++r) {
-        ex[r] = 0;
+    for (int j = 0; j < N; ++j)
+        row[j] = (r == j) ? 1.0 : 0.0;
+    int ex = 0;
+    for (int s = 0; s < len; ++s) {
+        const int64_t rec = ci_rec(g, s, ch.Lmax);
+        double pr;
+        if constexpr (KIND == EMIT_GAUSS) {
+            const double o = static_cast<const double *>(obs_ci)[rec * 64 + cl];
+            const double z = (o - mu_r) * is_r;
+            pr = cn_r * exp(-0.5 * z * z);
+            if ((__ballot(pr != 0.0) & gmask) == 0ull) // outlier row, outputmodel.py:126-130
+                pr = real ? 1.0 : 0.0;
+        } else if constexpr (KIND == EMIT_DISC) {
+            const int sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + cl];
+            pr = sBt[sym * N + r];
+        } else {
+            pr = static_cast<const double *>(obs_ci)[rec * (int64_t)(N * 64) + (r >> 1) * 128 +
+                                                     cl * 2 + (r & 1)];
+        }
+        slot[r] = pr;
+        double p[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j)
-            Mx[r][j] = (r == j) ? 1.0 : 0.0;
-    }
-
-    int s = 0;
-    if (first) {
-        double p[N], o;
-        int sym;
-        emit<N, KIND>(m, obs_ci, smem, ci_rec(g, 0, ch.Lmax), lane, p, o, sym);
-        double seed[N];
+        for (int j = 0; j < N; j += 2) {
+            const double2 x = *reinterpret_cast<const double2 *>(slot + j);
+            p[j] = x.x;
+            p[j + 1] = x.y;
+        }
+        double nr[N];
+        if (first && s == 0) {
 #pragma unroll
-        for (int j = 0; j < N; ++j)
-            seed[j] = m.pi[j] * p[j];
-#pragma unroll
-        for (int r = 0; r < N; ++r)
-            ex[r] = renorm_row<N>(seed, Mx[r]);
-        s = 1;
-    }
-    for (; s < len; ++s) {
-        double p[N], o;
-        int sym;
-        emit<N, KIND>(m, obs_ci, smem, ci_rec(g, s, ch.Lmax), lane, p, o, sym);
-#pragma unroll
-        for (int r = 0; r < N; ++r) {
-            double nr[N];
+            for (int j = 0; j < N; ++j)
+                nr[j] = m.pi[j] * p[j];
+        } else {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                double acc = Mx[r][0] * m.A[j];
+                double acc = row[0] * A[0][j];
 #pragma unroll
                 for (int k = 1; k < N; ++k)
-                    acc = fma(Mx[r][k], m.A[k * N + j], acc);
+                    acc = fma(row[k], A[k][j], acc);
                 nr[j] = acc * p[j];
             }
-            ex[r] += renorm_row<N>(nr, Mx[r]);
         }
+        ex += renorm_row<N>(nr, row);
     }
     double *out = Mbuf + g * (int64_t)(N * N + N);
 #pragma unroll
-    for (int r = 0; r < N; ++r)
-#pragma unroll
-        for (int j = 0; j < N; j += 2)
-            *reinterpret_cast<double2 *>(out + r * N + j) = make_double2(Mx[r][j], Mx[r][j + 1]);
-#pragma unroll
-    for (int r = 0; r < N; r += 2)
-        *reinterpret_cast<double2 *>(out + N * N + r) = make_double2((double)ex[r], (double)ex[r + 1]);
+    for (int j = 0; j < N; j += 2)
+        *reinterpret_cast<double2 *>(out + r * N + j) = make_double2(row[j], row[j + 1]);
+    out[N * N + r] = (double)ex;
 }
 
 // =========================================================================================
 // k_stitch: exact chunk-boundary vectors.  N lanes cooperate on one (trajectory,
 // direction); lane r holds row r of the current transfer matrix.
-//   forward : alpha_entry[c] = normalised alpha at the step before chunk c
-//             (_hidden.c:42-63 collapsed over a chunk:  a <- normalise(a^T Mc))
-//   backward: beta_exit[c]   = normalised beta at the last step of chunk c
-//             (_hidden.c:91-109 collapsed:  b <- normalise(M_{c+1} b), b_{T-1} = 1/N)
+//   forward : alpha_entry[c] ~ alpha at the step before chunk c
+//             (_hidden.c:42-63 collapsed over a chunk:  a <- a^T Mc)
+//   backward: beta_exit[c]   ~ beta at the last step of chunk c
+//             (_hidden.c:91-109 collapsed:  b <- M_{c+1} b,  b_{T-1} = 1/N)
+// Both vectors are kept up to a power-of-two scale (largest entry in [0.25, 8)); k_fwdbwd
+// normalises them where the reference's normalisation matters.  Cross-lane traffic is DPP
+// only; the next PD matrices are prefetched into registers because the chain is latency bound.
 // Blocks [0, nb) run the forward direction, [nb, 2 nb) the backward one.
 // =========================================================================================
-template <int N>
-__device__ __forceinline__ double group_sum(double v)
-{
-#pragma unroll
-    for (int h = N / 2; h >= 1; h >>= 1)
-        v += __shfl_xor(v, h, N);
-    return v;
-}
-
-template <int N>
-__device__ __forceinline__ int group_max(int v)
-{
-#pragma unroll
-    for (int h = N / 2; h >= 1; h >>= 1)
-        v = max(v, __shfl_xor(v, h, N));
-    return v;
-}
-
 template <int N>
 __global__ __launch_bounds__(64) void k_stitch(const int32_t *traj_c0, int K, int nb, int nreal,
                                                const double *Mbuf, double *alpha_entry,
@@ -258,77 +308,127 @@ __global__ __launch_bounds__(64) void k_stitch(const int32_t *traj_c0, int K, in
 {
     constexpr int GP = 64 / N; // trajectories per block
     constexpr int MS = N * N + N;
+    constexpr int PD = 4;      // prefetch depth (chunks)
+    constexpr int NEG = -(1 << 28);
     const bool bwd = (int)blockIdx.x >= nb;
     const int k = ((int)blockIdx.x % nb) * GP + (int)threadIdx.x / N;
     const int r = threadIdx.x % N;
     if (k >= K)
         return;
     const int c0 = traj_c0[k], c1 = traj_c0[k + 1];
-    constexpr int NEG = -(1 << 28);
+    const int nc = c1 - c0;
+
+    double rows[PD][N], er[PD];
+    // forward: row r in natural column order; backward: in xor order (entry q = M[r][r^q]),
+    // matching the order the DPP all-gather delivers b in
+    auto fetch = [&](int u, int c) {
+        const double *src = Mbuf + (int64_t)c * MS + r * N;
+        if (!bwd) {
+#pragma unroll
+            for (int j = 0; j < N; j += 2) {
+                const double2 x = *reinterpret_cast<const double2 *>(src + j);
+                rows[u][j] = x.x;
+                rows[u][j + 1] = x.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < N; ++q)
+                rows[u][q] = src[r ^ q];
+        }
+        er[u] = Mbuf[(int64_t)c * MS + N * N + r];
+    };
 
     if (!bwd) {
         double a = (r == 0) ? 1.0 : 0.0; // selects row 0 of the seeded first chunk
-        double row[N], erow;
-        {
-            const double *src = Mbuf + (int64_t)c0 * MS;
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                row[j] = src[r * N + j];
-            erow = src[N * N + r];
-        }
-        for (int c = c0; c < c1; ++c) {
-            alpha_entry[(int64_t)c * N + r] = a;
-            double nrow[N], nerow = 0.0;
-            if (c + 1 < c1) { // prefetch the next matrix while this one is consumed
-                const double *src = Mbuf + (int64_t)(c + 1) * MS;
+        for (int u = 0; u < PD; ++u)
+            if (u < nc)
+                fetch(u, c0 + u);
+        for (int cb = 0; cb < nc; cb += PD) {
 #pragma unroll
-                for (int j = 0; j < N; ++j)
-                    nrow[j] = src[r * N + j];
-                nerow = src[N * N + r];
-            }
-            const int e = (int)erow;
-            const int E = group_max<N>(a > 0.0 ? e : NEG);
-            const double w = ldexp(a, e - E);
-            double buf[N];
+            for (int u = 0; u < PD; ++u) {
+                const int ci = cb + u;
+                if (ci < nc) {
+                    alpha_entry[(int64_t)(c0 + ci) * N + r] = a;
+                    const int e = (int)er[u];
+                    const int E = group_max<N>(a > 0.0 ? e + exponent_of(a) : NEG);
+                    const double w = ldexp(a, e - E);
+                    double buf[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                buf[j] = w * row[j];
-            // reduce-scatter over the N lanes: lane j ends with sum_r w_r M[r][j]
+                    for (int j = 0; j < N; ++j)
+                        buf[j] = w * rows[u][j];
+                    if (ci + PD < nc)
+                        fetch(u, c0 + ci + PD);
+                    // reduce-scatter over the N lanes: lane j ends with sum_r w_r M[r][j]
+                    if constexpr (N >= 8) {
+                        const bool up = (r & 4) != 0;
 #pragma unroll
-            for (int h = N / 2; h >= 1; h >>= 1) {
-                const bool up = (r & h) != 0;
+                        for (int i = 0; i < 4; ++i) {
+                            const double keep = up ? buf[i + 4] : buf[i];
+                            const double send = up ? buf[i] : buf[i + 4];
+                            buf[i] = keep + xchg_f64<4>(send);
+                        }
+                    }
+                    if constexpr (N >= 4) {
+                        const bool up = (r & 2) != 0;
 #pragma unroll
-                for (int i = 0; i < h; ++i) {
-                    const double keep = up ? buf[i + h] : buf[i];
-                    const double send = up ? buf[i] : buf[i + h];
-                    buf[i] = keep + __shfl_xor(send, h, N);
+                        for (int i = 0; i < 2; ++i) {
+                            const double keep = up ? buf[i + 2] : buf[i];
+                            const double send = up ? buf[i] : buf[i + 2];
+                            buf[i] = keep + xchg_f64<2>(send);
+                        }
+                    }
+                    {
+                        const bool up = (r & 1) != 0;
+                        const double keep = up ? buf[1] : buf[0];
+                        const double send = up ? buf[0] : buf[1];
+                        buf[0] = keep + xchg_f64<1>(send);
+                    }
+                    a = buf[0]; // largest entry of the group is in [0.25, N)
                 }
-            }
-            const double S = group_sum<N>(buf[0]);
-            a = buf[0] / S;
-            if (c + 1 < c1) {
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    row[j] = nrow[j];
-                erow = nerow;
             }
         }
     } else {
         double b = (r < nreal) ? 1.0 / (double)nreal : 0.0; // _hidden.c:79-88
-        for (int c = c1 - 1; c >= c0; --c) {
-            beta_exit[(int64_t)c * N + r] = b;
-            if (c == c0)
-                break;
-            const double *src = Mbuf + (int64_t)c * MS;
-            double s = 0.0;
+        // chunk c (> c0) is consumed when producing the exit vector of chunk c-1
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                s = fma(src[r * N + j], __shfl(b, j, N), s);
-            const int e = (int)src[N * N + r];
-            const int E = group_max<N>(s > 0.0 ? e : NEG);
-            const double u = ldexp(s, e - E);
-            const double S = group_sum<N>(u);
-            b = u / S;
+        for (int u = 0; u < PD; ++u)
+            if (u < nc - 1)
+                fetch(u, c1 - 1 - u);
+        for (int cb = 0; cb < nc; cb += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int ci = cb + u; // counts chunks from the end
+                if (ci < nc) {
+                    const int c = c1 - 1 - ci;
+                    beta_exit[(int64_t)c * N + r] = b;
+                    if (c > c0) {
+                        // all-gather b over the group in xor order: bx[q] = b of lane r^q
+                        double bx[N];
+                        bx[0] = b;
+                        bx[1] = xchg_f64<1>(b);
+                        if constexpr (N >= 4) {
+                            bx[2] = xchg_f64<2>(bx[0]);
+                            bx[3] = xchg_f64<2>(bx[1]);
+                        }
+                        if constexpr (N >= 8) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                bx[4 + q] = xchg_f64<4>(bx[q]);
+                        }
+                        // s = sum_j M[r][j] b_j, summed in xor order j = r ^ q
+                        double s = 0.0;
+#pragma unroll
+                        for (int q = 0; q < N; ++q)
+                            s = fma(rows[u][q], bx[q], s);
+                        const int e = (int)er[u];
+                        if (ci + PD < nc - 1)
+                            fetch(u, c - PD);
+                        const int E = group_max<N>(s > 0.0 ? e + exponent_of(s) : NEG);
+                        b = ldexp(s, e - E); // largest entry of the group in [0.5, 1)
+                    }
+                }
+            }
         }
     }
 }
@@ -336,6 +436,32 @@ __global__ __launch_bounds__(64) void k_stitch(const int32_t *traj_c0, int K, in
 // =========================================================================================
 // k_fwdbwd: the streaming kernel.  One lane = one chunk.
 // =========================================================================================
+// out[j] = sum_i x[i] * Mlds[i][j] with Mlds an N x N row-major matrix in LDS.  The offset
+// is laundered through an empty asm so the (loop-invariant) LDS reads are re-issued every
+// step instead of being hoisted into 2*N*N vector registers.
+template <int N>
+__device__ __forceinline__ void matvec_lds(const double *Mlds, const double (&x)[N],
+                                           double (&out)[N])
+{
+    int off = 0;
+    asm volatile("" : "+v"(off));
+    const double *base = Mlds + off;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; j += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(base + i * N + j);
+            if (i == 0) {
+                out[j] = x[0] * v.x;
+                out[j + 1] = x[0] * v.y;
+            } else {
+                out[j] = fma(x[i], v.x, out[j]);
+                out[j + 1] = fma(x[i], v.y, out[j + 1]);
+            }
+        }
+    }
+}
+
 template <int N, int KIND>
 struct StatLayout {
     static constexpr int NC = N * N;                             // xi accumulators
@@ -366,15 +492,24 @@ __global__ __launch_bounds__(BLOCK) void k_fwdbwd(
     using SL = StatLayout<N, KIND>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *red = smem;                                     // [4][S]
-    double *Bt = smem + 4 * SL::S;                          // [M][N]
+    double *sA = smem + 4 * SL::S;                          // [N][N]  A
+    double *sAt = sA + N * N;                               // [N][N]  A transposed
+    double *Bt = sAt + N * N;                               // [M][N]
     double *dstat = Bt + (KIND == EMIT_DISC ? m.M * N : 0); // [M][N]
+    // The transition matrix is uniform across lanes but too large for the scalar register
+    // file (N*N doubles = 128 SGPRs at N = 8): it is staged in LDS and re-read every step
+    // with wave-uniform (broadcast) ds_read_b128.
+    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
+        sA[i] = m.A[i];
+        sAt[(i % N) * N + i / N] = m.A[i];
+    }
     if constexpr (KIND == EMIT_DISC) {
         stage_Bt<N>(Bt, Bt_g, m.M);
         if constexpr (MODE == MODE_ESTEP)
             for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
                 dstat[i] = 0.0;
-        __syncthreads();
     }
+    __syncthreads();
     const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int len = ch.len[g];
@@ -415,13 +550,20 @@ __global__ __launch_bounds__(BLOCK) void k_fwdbwd(
                 ci_store<N>(ws, ci_rec(g, 0, ch.Lmax), lane, a);
                 s = 1;
             } else {
+                // entry vector from k_stitch (power-of-two scaled): normalise, _hidden.c:57-59
                 const double2 *src = reinterpret_cast<const double2 *>(alpha_entry + g * N);
+                double S = 0.0;
 #pragma unroll
                 for (int q = 0; q < N / 2; ++q) {
                     const double2 x = src[q];
                     a[2 * q] = x.x;
                     a[2 * q + 1] = x.y;
+                    S += x.x + x.y;
                 }
+                const double rS = 1.0 / S;
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    a[i] *= rS;
             }
             for (; s < len; ++s) {
                 double p[N], o;
@@ -429,13 +571,10 @@ __global__ __launch_bounds__(BLOCK) void k_fwdbwd(
                 const int64_t rec = ci_rec(g, s, ch.Lmax);
                 emit<N, KIND>(m, obs_ci, Bt, rec, lane, p, o, sym);
                 double n[N], c = 0.0;
+                matvec_lds<N>(sA, a, n); // n[j] = sum_i a[i] A[i][j]
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    double acc = a[0] * m.A[j];
-#pragma unroll
-                    for (int i = 1; i < N; ++i)
-                        acc = fma(a[i], m.A[i * N + j], acc);
-                    n[j] = acc * p[j];
+                    n[j] *= p[j];
                     c += n[j];
                 }
                 const double rc = 1.0 / c;
@@ -455,9 +594,18 @@ __global__ __launch_bounds__(BLOCK) void k_fwdbwd(
             // plain scaled backward recursion with the reference normalisation
             // (_hidden.c:69-110); beta rows go to the CI workspace.
             double b[N];
+            {
+                double S = 0.0;
 #pragma unroll
-            for (int i = 0; i < N; ++i)
-                b[i] = beta_exit[g * N + i];
+                for (int i = 0; i < N; ++i) {
+                    b[i] = beta_exit[g * N + i];
+                    S += b[i];
+                }
+                const double rS = 1.0 / S;
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    b[i] *= rS;
+            }
             ci_store<N>(ws, ci_rec(g, len - 1, ch.Lmax), lane, b);
             for (int s = len - 1; s >= 1; --s) {
                 double p[N], o;
@@ -467,15 +615,10 @@ __global__ __launch_bounds__(BLOCK) void k_fwdbwd(
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                     bb[j] = p[j] * b[j];
+                matvec_lds<N>(sAt, bb, br); // br[i] = sum_j A[i][j] bb[j]
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    double acc = m.A[i * N] * bb[0];
-#pragma unroll
-                    for (int j = 1; j < N; ++j)
-                        acc = fma(m.A[i * N + j], bb[j], acc);
-                    br[i] = acc;
-                    c += acc;
-                }
+                for (int i = 0; i < N; ++i)
+                    c += br[i];
                 const double rc = 1.0 / c;
 #pragma unroll
                 for (int i = 0; i < N; ++i)
@@ -541,14 +684,10 @@ __global__ __launch_bounds__(BLOCK) void k_fwdbwd(
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                     bb[j] = p[j] * b[j];
+                matvec_lds<N>(sAt, bb, br); // br[i] = sum_j A[i][j] bb[j]
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    double acc = m.A[i * N] * bb[0];
-#pragma unroll
-                    for (int j = 1; j < N; ++j)
-                        acc = fma(m.A[i * N + j], bb[j], acc);
-                    br[i] = acc;
-                    q[i] = ap[i] * acc;
+                    q[i] = ap[i] * br[i];
                     Sx += q[i];
                 }
                 const double rS = 1.0 / Sx;
@@ -602,73 +741,84 @@ __global__ __launch_bounds__(BLOCK) void k_fwdbwd(
 }
 
 // =========================================================================================
-// k_logl: per-trajectory log-likelihood = ordered sum of its chunks' logs.
-// k_finalize: one workgroup; fixed-order sums -> packed statistics (bhmm_amd.h layout).
+// k_logl: per-trajectory log-likelihood = sum of its chunks' logs (one wavefront per
+// trajectory, fixed summation tree -> run-to-run identical).
+// k_finalize: one wavefront per output entry; fixed-order sums of the per-workgroup partials
+// -> packed statistics (bhmm_amd.h layout).
 // =========================================================================================
-static __global__ void k_logl(const int32_t *traj_c0, int K, const double *logL_chunk, double *logL_k)
+static __global__ __launch_bounds__(64) void k_logl(const int32_t *traj_c0, int K,
+                                                    const double *logL_chunk, double *logL_k)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K)
-        return;
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x;
     double s = 0.0;
-    for (int c = traj_c0[k]; c < traj_c0[k + 1]; ++c)
+    for (int c = traj_c0[k] + lane; c < traj_c0[k + 1]; c += 64)
         s += logL_chunk[c];
-    logL_k[k] = s;
+    s = wave_sum(s);
+    if (lane == 0)
+        logL_k[k] = s;
 }
 
 template <int N, int KIND>
-__global__ __launch_bounds__(BLOCK) void k_finalize(const Model<N> m, int K, int nblocks,
-                                                    const double *partials,
-                                                    const double *disc_partials,
-                                                    const double *logL_k, const double *gamma0,
-                                                    double *stats)
+__global__ __launch_bounds__(64) void k_finalize(const Model<N> m, int K, int nblocks,
+                                                 const double *partials,
+                                                 const double *disc_partials,
+                                                 const double *logL_k, const double *gamma0,
+                                                 double *stats)
 {
     using SL = StatLayout<N, KIND>;
     const int n = m.nreal;
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
+    const int MN = (KIND == EMIT_DISC) ? m.M * N : 0;
     // packed offsets
     const int oG0 = 1, oC = 1 + n, oSG = oC + n * n, oE = oSG + n;
-    for (int i = tid; i < SL::S; i += BLOCK) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b)
-            s += partials[(int64_t)b * SL::S + i];
-        if (i < SL::NC) {
-            const int r = i / N, c = i % N;
+    int e = blockIdx.x;
+    double s = 0.0;
+    if (e < SL::S) {
+        for (int b = lane; b < nblocks; b += 64)
+            s += partials[(int64_t)b * SL::S + e];
+        s = wave_sum(s);
+        if (lane != 0)
+            return;
+        if (e < SL::NC) {
+            const int r = e / N, c = e % N;
             if (r < n && c < n)
                 stats[oC + r * n + c] = s * m.A[r * N + c]; // xi = A o (alpha (x) b / S)
-        } else if (i < SL::NC + N) {
-            const int r = i - SL::NC;
+        } else if (e < SL::NC + N) {
+            const int r = e - SL::NC;
             if (r < n)
                 stats[oSG + r] = s;
         } else {
-            const int w = (i - SL::NC - N) / N, r = (i - SL::NC - N) % N;
+            const int w = (e - SL::NC - N) / N, r = (e - SL::NC - N) % N;
             if (r < n)
                 stats[oE + w * n + r] = s;
         }
+        return;
     }
-    if constexpr (KIND == EMIT_DISC) {
-        const int MN = m.M * N;
-        for (int i = tid; i < MN; i += BLOCK) {
-            double s = 0.0;
-            for (int b = 0; b < nblocks; ++b)
-                s += disc_partials[(int64_t)b * MN + i];
-            const int sym = i / N, r = i % N;
-            if (r < n)
-                stats[oE + r * m.M + sym] = s;
-        }
+    e -= SL::S;
+    if (e < MN) {
+        for (int b = lane; b < nblocks; b += 64)
+            s += disc_partials[(int64_t)b * MN + e];
+        s = wave_sum(s);
+        const int sym = e / N, r = e % N;
+        if (lane == 0 && r < n)
+            stats[oE + r * m.M + sym] = s;
+        return;
     }
-    if (tid < n) {
-        double s = 0.0;
-        for (int k = 0; k < K; ++k)
-            s += gamma0[(int64_t)k * N + tid];
-        stats[oG0 + tid] = s;
+    e -= MN;
+    if (e < N) {
+        for (int k = lane; k < K; k += 64)
+            s += gamma0[(int64_t)k * N + e];
+        s = wave_sum(s);
+        if (lane == 0 && e < n)
+            stats[oG0 + e] = s;
+        return;
     }
-    if (tid == BLOCK - 1) {
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) // trajectory order, maximum_likelihood.py:383-385
-            s += logL_k[k];
+    for (int k = lane; k < K; k += 64)
+        s += logL_k[k];
+    s = wave_sum(s);
+    if (lane == 0)
         stats[0] = s;
-    }
 }
 
 // =========================================================================================
