@@ -45,7 +45,9 @@ Chunks chunks_pub(const bhmm_ctx *c)
 template <int N, int KIND>
 static size_t smem_fwdbwd(int M)
 {
-    return (size_t)(4 * StatLayout<N, KIND>::S + 2 * N * N + (KIND == EMIT_DISC ? 2 * M * N : 0)) *
+    // [wavefronts per workgroup][S] reduction scratch + (discrete) B^T and the count table
+    return (size_t)(((N / 2 * 64 + 63) / 64) * StatLayout<N, KIND>::S +
+                    (KIND == EMIT_DISC ? 2 * M * N : 0)) *
            sizeof(double);
 }
 
@@ -80,12 +82,12 @@ struct Runner {
     static int fwdbwd(bhmm_ctx *c, const Model<N> &m, bool store_gamma)
     {
         const Chunks ch = chunks_of(c);
-        const int nblk = c->Gp / BLOCK;
+        const int nblk = c->Gp / 64; // one workgroup per CI record group (64 chunks)
         const size_t sm = smem_fwdbwd<N, KIND>(c->M);
         if (sm > 64 * 1024)
             BHMM_HIP(hipFuncSetAttribute((const void *)(k_fwdbwd<N, KIND, MODE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        hipLaunchKernelGGL((k_fwdbwd<N, KIND, MODE>), dim3(nblk), dim3(BLOCK), sm, c->stream, m, ch,
+        hipLaunchKernelGGL((k_fwdbwd<N, KIND, MODE>), dim3(nblk), dim3(32 * N), sm, c->stream, m, ch,
                            (const void *)c->d_obs_ci.p, (const double *)c->d_Bt.p,
                            (const double *)c->d_aentry.p, (const double *)c->d_bexit.p, c->d_ws.p,
                            store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
@@ -110,7 +112,7 @@ struct Runner {
         BHMM_HIP(hipGetLastError());
         const int nfin = StatLayout<N, KIND>::S + (KIND == EMIT_DISC ? c->M * N : 0) + N + 1;
         hipLaunchKernelGGL((k_finalize<N, KIND>), dim3(nfin), dim3(64), 0, c->stream, m, c->K,
-                           c->Gp / BLOCK, (const double *)c->d_partials.p,
+                           c->Gp / 64, (const double *)c->d_partials.p,
                            (const double *)c->d_dpartials.p, (const double *)c->d_logLk.p,
                            (const double *)c->d_gamma0.p, stats_dev);
         BHMM_HIP(hipGetLastError());
@@ -290,11 +292,11 @@ static int alloc_work(bhmm_ctx *c)
         (rc = c->d_ws.ensure((size_t)ci_records(c) * N * 64)) ||
         (rc = c->d_logLc.ensure(c->Gp)) || (rc = c->d_logLk.ensure(std::max(c->K, 1))) ||
         (rc = c->d_gamma0.ensure((size_t)std::max(c->K, 1) * N)) ||
-        (rc = c->d_partials.ensure((size_t)(c->Gp / BLOCK) * S)) ||
+        (rc = c->d_partials.ensure((size_t)(c->Gp / 64) * S)) ||
         (rc = c->d_stats.ensure(stats_size(c))))
         return rc;
     if (c->kind == EMIT_DISC) {
-        if ((rc = c->d_dpartials.ensure((size_t)(c->Gp / BLOCK) * c->M * N)) ||
+        if ((rc = c->d_dpartials.ensure((size_t)(c->Gp / 64) * c->M * N)) ||
             (rc = c->d_Bt.ensure((size_t)c->M * N)))
             return rc;
     }

@@ -434,34 +434,18 @@ __global__ __launch_bounds__(64) void k_stitch(const int32_t *traj_c0, int K, in
 }
 
 // =========================================================================================
-// k_fwdbwd: the streaming kernel.  One lane = one chunk.
+// k_fwdbwd: the streaming kernel.
+//
+// Mapping: H = N/2 lanes cooperate on one chunk; lane q owns the state pair (2q, 2q+1), i.e.
+// exactly one 16-byte element of every CI record, the two columns / rows of A that touch its
+// states, and the two rows of the xi accumulator.  A workgroup of 64*H threads covers one CI
+// record group (64 chunks).  Per step the only cross-lane traffic is one all-gather of an
+// N-vector (alpha in the forward sweep, p o beta in the backward sweep) and two scalar
+// reductions, all on DPP quad permutes (H <= 4 lanes sit inside one quad).  Compared with
+// one lane per chunk this cuts the per-lane register state by H (the 2*N*N-register xi
+// accumulator was what limited occupancy to one wavefront per SIMD), keeps A in registers,
+// and leaves the instruction count per chunk-step about equal.
 // =========================================================================================
-// out[j] = sum_i x[i] * Mlds[i][j] with Mlds an N x N row-major matrix in LDS.  The offset
-// is laundered through an empty asm so the (loop-invariant) LDS reads are re-issued every
-// step instead of being hoisted into 2*N*N vector registers.
-template <int N>
-__device__ __forceinline__ void matvec_lds(const double *Mlds, const double (&x)[N],
-                                           double (&out)[N])
-{
-    int off = 0;
-    asm volatile("" : "+v"(off));
-    const double *base = Mlds + off;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-#pragma unroll
-        for (int j = 0; j < N; j += 2) {
-            const double2 v = *reinterpret_cast<const double2 *>(base + i * N + j);
-            if (i == 0) {
-                out[j] = x[0] * v.x;
-                out[j + 1] = x[0] * v.y;
-            } else {
-                out[j] = fma(x[i], v.x, out[j]);
-                out[j + 1] = fma(x[i], v.y, out[j + 1]);
-            }
-        }
-    }
-}
-
 template <int N, int KIND>
 struct StatLayout {
     static constexpr int NC = N * N;                             // xi accumulators
@@ -478,8 +462,97 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// value of lane K (0..H-1) of my H-lane group, H in {1,2,4}: one quad permute per dword
+template <int H, int K>
+__device__ __forceinline__ double grp_bcast(double x)
+{
+    if constexpr (H == 1) {
+        return x;
+    } else {
+        constexpr int CTRL = (H == 4) ? (K | (K << 2) | (K << 4) | (K << 6))
+                                      : (K | (K << 2) | ((2 + K) << 4) | ((2 + K) << 6));
+        const int lo = dpp_i32<CTRL>(__double2loint(x));
+        const int hi = dpp_i32<CTRL>(__double2hiint(x));
+        return __hiloint2double(hi, lo);
+    }
+}
+template <int H>
+__device__ __forceinline__ double grp_sum(double x)
+{
+    if constexpr (H >= 2)
+        x += xchg_f64<1>(x);
+    if constexpr (H >= 4)
+        x += xchg_f64<2>(x);
+    return x;
+}
+template <int H>
+__device__ __forceinline__ int grp_max_i32(int v)
+{
+    if constexpr (H >= 2)
+        v = max(v, xchg_i32<1>(v));
+    if constexpr (H >= 4)
+        v = max(v, xchg_i32<2>(v));
+    return v;
+}
+// all-gather: full[2k + b] = pair[b] of lane k
+template <int N>
+__device__ __forceinline__ void grp_gather(const double (&pair)[2], double (&full)[N])
+{
+    constexpr int H = N / 2;
+    full[0] = grp_bcast<H, 0>(pair[0]);
+    full[1] = grp_bcast<H, 0>(pair[1]);
+    if constexpr (H >= 2) {
+        full[2] = grp_bcast<H, 1>(pair[0]);
+        full[3] = grp_bcast<H, 1>(pair[1]);
+    }
+    if constexpr (H >= 4) {
+        full[4] = grp_bcast<H, 2>(pair[0]);
+        full[5] = grp_bcast<H, 2>(pair[1]);
+        full[6] = grp_bcast<H, 3>(pair[0]);
+        full[7] = grp_bcast<H, 3>(pair[1]);
+    }
+}
+
+// emission probabilities of MY two states at CI record `rec` (+ the outlier rule)
+template <int N, int KIND>
+__device__ __forceinline__ void emit_pair(const Model<N> &m, const void *obs_ci, const double *Bt,
+                                          int64_t rec, int cl, int q, const double (&mu)[2],
+                                          const double (&is)[2], const double (&cn)[2],
+                                          unsigned long long gmask, double (&p)[2], double &o,
+                                          int &sym)
+{
+    if constexpr (KIND == EMIT_GAUSS) {
+        o = static_cast<const double *>(obs_ci)[rec * 64 + cl];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const double z = (o - mu[b]) * is[b];
+            p[b] = cn[b] * exp(-0.5 * z * z);
+        }
+        if ((__ballot(p[0] != 0.0 || p[1] != 0.0) & gmask) == 0ull) {
+            p[0] = (2 * q < m.nreal) ? 1.0 : 0.0; // outlier row, outputmodel.py:126-130
+            p[1] = (2 * q + 1 < m.nreal) ? 1.0 : 0.0;
+        }
+    } else if constexpr (KIND == EMIT_DISC) {
+        sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + cl];
+        const double2 x = *reinterpret_cast<const double2 *>(Bt + (int64_t)sym * N + 2 * q);
+        p[0] = x.x;
+        p[1] = x.y;
+    } else {
+        const double2 x = *(reinterpret_cast<const double2 *>(
+                                static_cast<const double *>(obs_ci) + rec * (int64_t)(N * 64)) +
+                            q * 64 + cl);
+        p[0] = x.x;
+        p[1] = x.y;
+    }
+}
+
+__device__ __forceinline__ double2 *ci_pair(double *base, int64_t rec, int N_, int q, int cl)
+{
+    return reinterpret_cast<double2 *>(base + rec * (int64_t)(N_ * 64)) + q * 64 + cl;
+}
+
 template <int N, int KIND, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_fwdbwd(
+__global__ __launch_bounds__(32 * N) void k_fwdbwd(
     const Model<N> m, const Chunks ch, const void *obs_ci, const double *Bt_g,
     const double *alpha_entry, const double *beta_exit,
     double *ws,            // CI workspace: alpha (ESTEP, FWD) or beta (BWD)
@@ -490,250 +563,257 @@ __global__ __launch_bounds__(BLOCK) void k_fwdbwd(
     double *disc_partials) // [gridDim.x][M*N] discrete emission statistics per workgroup
 {
     using SL = StatLayout<N, KIND>;
+    constexpr int H = N / 2;
+    constexpr int NW = (64 * H + 63) / 64; // wavefronts per workgroup
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *red = smem;                                     // [4][S]
-    double *sA = smem + 4 * SL::S;                          // [N][N]  A
-    double *sAt = sA + N * N;                               // [N][N]  A transposed
-    double *Bt = sAt + N * N;                               // [M][N]
+    double *red = smem;                                     // [NW][S]
+    double *Bt = smem + NW * SL::S;                         // [M][N]
     double *dstat = Bt + (KIND == EMIT_DISC ? m.M * N : 0); // [M][N]
-    // The transition matrix is uniform across lanes but too large for the scalar register
-    // file (N*N doubles = 128 SGPRs at N = 8): it is staged in LDS and re-read every step
-    // with wave-uniform (broadcast) ds_read_b128.
-    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
-        sA[i] = m.A[i];
-        sAt[(i % N) * N + i / N] = m.A[i];
-    }
     if constexpr (KIND == EMIT_DISC) {
         stage_Bt<N>(Bt, Bt_g, m.M);
         if constexpr (MODE == MODE_ESTEP)
             for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
                 dstat[i] = 0.0;
+        __syncthreads();
     }
-    __syncthreads();
-    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int cl = threadIdx.x / H; // chunk within the record group == CI lane
+    const int q = threadIdx.x % H;  // my state pair
+    const int64_t g = (int64_t)blockIdx.x * 64 + cl;
     const int len = ch.len[g];
     const int64_t t0 = ch.t0[g];
     const bool first = (t0 == 0);
+    const unsigned long long gmask = ((1ull << H) - 1) << ((threadIdx.x & 63) / H * H);
 
-    double Cacc[N][N], sg[N], sd[N], sdd[N];
+    // my slices of the model (vector registers; loaded once)
+    double Ac[N][2], Ar[2][N], mu[2], is[2], cn[2], pi2[2];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        sg[i] = sd[i] = sdd[i] = 0.0;
+        Ac[i][0] = m.A[i * N + 2 * q];
+        Ac[i][1] = m.A[i * N + 2 * q + 1];
+        Ar[0][i] = m.A[(2 * q) * N + i];
+        Ar[1][i] = m.A[(2 * q + 1) * N + i];
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        mu[b] = m.e0[2 * q + b];
+        is[b] = m.e1[2 * q + b];
+        cn[b] = m.e2[2 * q + b];
+        pi2[b] = m.pi[2 * q + b];
+    }
+
+    double Cacc[2][N], sg[2], sd[2], sdd[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        sg[b] = sd[b] = sdd[b] = 0.0;
 #pragma unroll
         for (int j = 0; j < N; ++j)
-            Cacc[i][j] = 0.0;
+            Cacc[b][j] = 0.0;
     }
 
     if (len > 0) {
-        double a[N];
+        double a[2];
         // ---------------- forward sweep (_hidden.c:16-66) ------------------------------
         if constexpr (MODE != MODE_BWD) {
             double P = 1.0; // running product of the scaling factors c_t, mantissa part
             int eP = 0;     // ... and its binary exponent: logL = log(P) + eP ln 2
             int s = 0;
             if (first) {
-                double p[N], o;
+                double p[2], o;
                 int sym;
-                emit<N, KIND>(m, obs_ci, Bt, ci_rec(g, 0, ch.Lmax), lane, p, o, sym);
-                double c = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    a[i] = m.pi[i] * p[i];
-                    c += a[i];
-                }
+                emit_pair<N, KIND>(m, obs_ci, Bt, ci_rec(g, 0, ch.Lmax), cl, q, mu, is, cn, gmask,
+                                   p, o, sym);
+                a[0] = pi2[0] * p[0];
+                a[1] = pi2[1] * p[1];
+                const double c = grp_sum<H>(a[0] + a[1]);
                 const double rc = 1.0 / c;
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-                    a[i] *= rc;
+                a[0] *= rc;
+                a[1] *= rc;
                 P = frexp(c, &eP);
-                ci_store<N>(ws, ci_rec(g, 0, ch.Lmax), lane, a);
+                *ci_pair(ws, ci_rec(g, 0, ch.Lmax), N, q, cl) = make_double2(a[0], a[1]);
                 s = 1;
             } else {
                 // entry vector from k_stitch (power-of-two scaled): normalise, _hidden.c:57-59
-                const double2 *src = reinterpret_cast<const double2 *>(alpha_entry + g * N);
-                double S = 0.0;
-#pragma unroll
-                for (int q = 0; q < N / 2; ++q) {
-                    const double2 x = src[q];
-                    a[2 * q] = x.x;
-                    a[2 * q + 1] = x.y;
-                    S += x.x + x.y;
-                }
-                const double rS = 1.0 / S;
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-                    a[i] *= rS;
+                const double2 x = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
+                const double rS = 1.0 / grp_sum<H>(x.x + x.y);
+                a[0] = x.x * rS;
+                a[1] = x.y * rS;
             }
             for (; s < len; ++s) {
-                double p[N], o;
+                double p[2], o;
                 int sym;
                 const int64_t rec = ci_rec(g, s, ch.Lmax);
-                emit<N, KIND>(m, obs_ci, Bt, rec, lane, p, o, sym);
-                double n[N], c = 0.0;
-                matvec_lds<N>(sA, a, n); // n[j] = sum_i a[i] A[i][j]
+                emit_pair<N, KIND>(m, obs_ci, Bt, rec, cl, q, mu, is, cn, gmask, p, o, sym);
+                double af[N];
+                grp_gather<N>(a, af);
+                double n0 = af[0] * Ac[0][0], n1 = af[0] * Ac[0][1];
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    n[j] *= p[j];
-                    c += n[j];
+                for (int i = 1; i < N; ++i) {
+                    n0 = fma(af[i], Ac[i][0], n0);
+                    n1 = fma(af[i], Ac[i][1], n1);
                 }
+                n0 *= p[0];
+                n1 *= p[1];
+                const double c = grp_sum<H>(n0 + n1);
                 const double rc = 1.0 / c;
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    a[j] = n[j] * rc;
+                a[0] = n0 * rc;
+                a[1] = n1 * rc;
                 int e;
                 P = frexp(P * c, &e);
                 eP += e;
-                ci_store<N>(ws, rec, lane, a);
+                *ci_pair(ws, rec, N, q, cl) = make_double2(a[0], a[1]);
             }
-            logL_chunk[g] = log(P) + (double)eP * 0.693147180559945309417232121458;
+            if (q == 0)
+                logL_chunk[g] = log(P) + (double)eP * 0.693147180559945309417232121458;
         }
 
         // ---------------- backward sweep ------------------------------------------------
         if constexpr (MODE == MODE_BWD) {
             // plain scaled backward recursion with the reference normalisation
             // (_hidden.c:69-110); beta rows go to the CI workspace.
-            double b[N];
+            double b2[2];
             {
-                double S = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    b[i] = beta_exit[g * N + i];
-                    S += b[i];
-                }
-                const double rS = 1.0 / S;
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-                    b[i] *= rS;
+                const double2 x = *reinterpret_cast<const double2 *>(beta_exit + g * N + 2 * q);
+                const double rS = 1.0 / grp_sum<H>(x.x + x.y);
+                b2[0] = x.x * rS;
+                b2[1] = x.y * rS;
             }
-            ci_store<N>(ws, ci_rec(g, len - 1, ch.Lmax), lane, b);
+            *ci_pair(ws, ci_rec(g, len - 1, ch.Lmax), N, q, cl) = make_double2(b2[0], b2[1]);
             for (int s = len - 1; s >= 1; --s) {
-                double p[N], o;
+                double p[2], o;
                 int sym;
-                emit<N, KIND>(m, obs_ci, Bt, ci_rec(g, s, ch.Lmax), lane, p, o, sym);
-                double bb[N], br[N], c = 0.0;
+                emit_pair<N, KIND>(m, obs_ci, Bt, ci_rec(g, s, ch.Lmax), cl, q, mu, is, cn, gmask,
+                                   p, o, sym);
+                const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
+                double bf[N];
+                grp_gather<N>(bb2, bf);
+                double r0 = Ar[0][0] * bf[0], r1 = Ar[1][0] * bf[0];
 #pragma unroll
-                for (int j = 0; j < N; ++j)
-                    bb[j] = p[j] * b[j];
-                matvec_lds<N>(sAt, bb, br); // br[i] = sum_j A[i][j] bb[j]
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-                    c += br[i];
-                const double rc = 1.0 / c;
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-                    b[i] = br[i] * rc;
-                ci_store<N>(ws, ci_rec(g, s - 1, ch.Lmax), lane, b);
+                for (int j = 1; j < N; ++j) {
+                    r0 = fma(Ar[0][j], bf[j], r0);
+                    r1 = fma(Ar[1][j], bf[j], r1);
+                }
+                const double rc = 1.0 / grp_sum<H>(r0 + r1);
+                b2[0] = r0 * rc;
+                b2[1] = r1 * rc;
+                *ci_pair(ws, ci_rec(g, s - 1, ch.Lmax), N, q, cl) = make_double2(b2[0], b2[1]);
             }
         }
         if constexpr (MODE == MODE_ESTEP) {
             // b carries beta up to a power-of-two scale; gamma and xi are normalised by
             // S_t = sum_i alpha_t[i] (A (p_{t+1} o beta_{t+1}))[i], which equals the
             // reference's per-step normalisers (hidden/api.py:176-186, _hidden.c:168-179).
-            double b[N], gam[N];
+            double b2[2], gam[2];
             {
-                double S = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    b[i] = beta_exit[g * N + i];
-                    gam[i] = a[i] * b[i];
-                    S += gam[i];
-                }
-                const double rS = 1.0 / S;
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-                    gam[i] *= rS;
+                const double2 x = *reinterpret_cast<const double2 *>(beta_exit + g * N + 2 * q);
+                b2[0] = x.x;
+                b2[1] = x.y;
+                gam[0] = a[0] * b2[0];
+                gam[1] = a[1] * b2[1];
+                const double rS = 1.0 / grp_sum<H>(gam[0] + gam[1]);
+                gam[0] *= rS;
+                gam[1] *= rS;
             }
             const int k = ch.traj[g];
             for (int s = len - 1; s >= 0; --s) {
-                double p[N], o = 0.0;
+                double p[2], o = 0.0;
                 int sym = 0;
                 const int64_t rec = ci_rec(g, s, ch.Lmax);
-                emit<N, KIND>(m, obs_ci, Bt, rec, lane, p, o, sym);
+                emit_pair<N, KIND>(m, obs_ci, Bt, rec, cl, q, mu, is, cn, gmask, p, o, sym);
                 // ---- consume gamma_s: state counts + emission statistics ---------------
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    sg[i] += gam[i];
+                for (int b = 0; b < 2; ++b) {
+                    sg[b] += gam[b];
                     if constexpr (KIND == EMIT_GAUSS) {
-                        const double d = o - m.e0[i];
-                        const double gd = gam[i] * d;
-                        sd[i] += gd;
-                        sdd[i] = fma(gd, d, sdd[i]);
+                        const double d = o - mu[b];
+                        const double gd = gam[b] * d;
+                        sd[b] += gd;
+                        sdd[b] = fma(gd, d, sdd[b]);
                     }
                     if constexpr (KIND == EMIT_DISC) // _discrete.c:22-30
-                        atomicAdd(&dstat[sym * N + i], gam[i]);
+                        atomicAdd(&dstat[sym * N + 2 * q + b], gam[b]);
                 }
                 if (gamma_ci)
-                    ci_store<N>(gamma_ci, rec, lane, gam);
+                    *ci_pair(gamma_ci, rec, N, q, cl) = make_double2(gam[0], gam[1]);
                 if (first && s == 0) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        gamma0[(int64_t)k * N + i] = gam[i];
+                    *reinterpret_cast<double2 *>(gamma0 + (int64_t)k * N + 2 * q) =
+                        make_double2(gam[0], gam[1]);
                     break;
                 }
                 // ---- pair (s-1, s): xi accumulation and beta_{s-1} ----------------------
-                double ap[N];
-                if (s > 0) {
-                    ci_load<N>(ws, rec - 1, lane, ap);
-                } else {
+                double2 apv;
+                if (s > 0)
+                    apv = *ci_pair(ws, rec - 1, N, q, cl);
+                else
+                    apv = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
+                const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
+                double bf[N];
+                grp_gather<N>(bb2, bf);
+                double r0 = Ar[0][0] * bf[0], r1 = Ar[1][0] * bf[0];
 #pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        ap[i] = alpha_entry[g * N + i];
+                for (int j = 1; j < N; ++j) {
+                    r0 = fma(Ar[0][j], bf[j], r0);
+                    r1 = fma(Ar[1][j], bf[j], r1);
                 }
-                double bb[N], br[N], q[N], Sx = 0.0;
+                const double q0 = apv.x * r0, q1 = apv.y * r1;
+                const double rS = 1.0 / grp_sum<H>(q0 + q1);
+                gam[0] = q0 * rS;
+                gam[1] = q1 * rS;
+                const double w0 = apv.x * rS, w1 = apv.y * rS;
 #pragma unroll
-                for (int j = 0; j < N; ++j)
-                    bb[j] = p[j] * b[j];
-                matvec_lds<N>(sAt, bb, br); // br[i] = sum_j A[i][j] bb[j]
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    q[i] = ap[i] * br[i];
-                    Sx += q[i];
+                for (int j = 0; j < N; ++j) {
+                    Cacc[0][j] = fma(w0, bf[j], Cacc[0][j]);
+                    Cacc[1][j] = fma(w1, bf[j], Cacc[1][j]);
                 }
-                const double rS = 1.0 / Sx;
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    bb[j] *= rS;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    gam[i] = q[i] * rS;
-#pragma unroll
-                    for (int j = 0; j < N; ++j)
-                        Cacc[i][j] = fma(ap[i], bb[j], Cacc[i][j]);
-                }
-                (void)renorm_row<N>(br, b);
+                // beta_{s-1} up to a power of two (exact scaling)
+                const int E = grp_max_i32<H>(max(exponent_of(r0), exponent_of(r1)));
+                b2[0] = ldexp(r0, -E);
+                b2[1] = ldexp(r1, -E);
             }
         }
     }
 
     // ---------------- workgroup reduction of the register statistics ----------------------
     if constexpr (MODE == MODE_ESTEP) {
+        // entry e of the statistics vector is owned by lane q = (state of e) / 2; sum over
+        // the chunks of the wavefront (lanes with equal q), then over wavefronts through LDS
+        const int lane = threadIdx.x & 63;
         const int wv = threadIdx.x >> 6;
         double *mine = red + wv * SL::S;
+        auto chunk_sum = [&](double v) {
+            // sum over lanes with the same (lane % H): strides H, 2H, ... 32
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
+            for (int h = 32; h >= H; h >>= 1)
+                v += __shfl_xor(v, h, 64);
+            return v;
+        };
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                const double v = wave_sum(Cacc[i][j]);
-                if (lane == 0)
-                    mine[i * N + j] = v;
+                const double v = chunk_sum(Cacc[b][j]);
+                if (lane < H)
+                    mine[(2 * q + b) * N + j] = v;
             }
-            const double v = wave_sum(sg[i]);
-            if (lane == 0)
-                mine[SL::NC + i] = v;
+            const double v = chunk_sum(sg[b]);
+            if (lane < H)
+                mine[SL::NC + 2 * q + b] = v;
             if constexpr (KIND == EMIT_GAUSS) {
-                const double v1 = wave_sum(sd[i]);
-                const double v2 = wave_sum(sdd[i]);
-                if (lane == 0) {
-                    mine[SL::NC + N + i] = v1;
-                    mine[SL::NC + 2 * N + i] = v2;
+                const double v1 = chunk_sum(sd[b]);
+                const double v2 = chunk_sum(sdd[b]);
+                if (lane < H) {
+                    mine[SL::NC + N + 2 * q + b] = v1;
+                    mine[SL::NC + 2 * N + 2 * q + b] = v2;
                 }
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < SL::S; i += blockDim.x)
-            partials[(int64_t)blockIdx.x * SL::S + i] =
-                ((red[i] + red[SL::S + i]) + red[2 * SL::S + i]) + red[3 * SL::S + i];
+        for (int i = threadIdx.x; i < SL::S; i += blockDim.x) {
+            double v = red[i];
+#pragma unroll
+            for (int w = 1; w < NW; ++w)
+                v += red[w * SL::S + i];
+            partials[(int64_t)blockIdx.x * SL::S + i] = v;
+        }
         if constexpr (KIND == EMIT_DISC)
             for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
                 disc_partials[(int64_t)blockIdx.x * (m.M * N) + i] = dstat[i];
