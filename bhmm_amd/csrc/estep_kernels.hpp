@@ -179,6 +179,15 @@ __device__ __forceinline__ int group_max(int v)
         v = max(v, xchg_i32<4>(v));
     return v;
 }
+// 1/x to ~1 ulp: hardware seed + two Newton steps (the full IEEE division sequence is only
+// needed by the bit-exact path kernels)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
 __device__ __forceinline__ int exponent_of(double x)
 {
     int e;
@@ -241,21 +250,36 @@ __global__ __launch_bounds__(64 * N) void k_prescan(const Model<N> m, const Chun
     for (int j = 0; j < N; ++j)
         row[j] = (r == j) ? 1.0 : 0.0;
     int ex = 0;
+    // raw input of the next step, loaded one iteration ahead (the recursion is serial; the
+    // load latency would otherwise sit on the critical path of every step)
+    auto load_in = [&](int64_t rec, double &o, int &sym, double &pv) {
+        if constexpr (KIND == EMIT_GAUSS)
+            o = static_cast<const double *>(obs_ci)[rec * 64 + cl];
+        else if constexpr (KIND == EMIT_DISC)
+            sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + cl];
+        else
+            pv = static_cast<const double *>(obs_ci)[rec * (int64_t)(N * 64) + (r >> 1) * 128 +
+                                                     cl * 2 + (r & 1)];
+    };
+    double o_n = 0.0, pv_n = 0.0;
+    int sym_n = 0;
+    load_in(ci_rec(g, 0, ch.Lmax), o_n, sym_n, pv_n);
     for (int s = 0; s < len; ++s) {
         const int64_t rec = ci_rec(g, s, ch.Lmax);
+        const double o = o_n, pv = pv_n;
+        const int sym = sym_n;
+        if (s + 1 < len)
+            load_in(rec + 1, o_n, sym_n, pv_n);
         double pr;
         if constexpr (KIND == EMIT_GAUSS) {
-            const double o = static_cast<const double *>(obs_ci)[rec * 64 + cl];
             const double z = (o - mu_r) * is_r;
             pr = cn_r * exp(-0.5 * z * z);
             if ((__ballot(pr != 0.0) & gmask) == 0ull) // outlier row, outputmodel.py:126-130
                 pr = real ? 1.0 : 0.0;
         } else if constexpr (KIND == EMIT_DISC) {
-            const int sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + cl];
             pr = sBt[sym * N + r];
         } else {
-            pr = static_cast<const double *>(obs_ci)[rec * (int64_t)(N * 64) + (r >> 1) * 128 +
-                                                     cl * 2 + (r & 1)];
+            pr = pv;
         }
         slot[r] = pr;
         double p[N];
@@ -513,19 +537,41 @@ __device__ __forceinline__ void grp_gather(const double (&pair)[2], double (&ful
     }
 }
 
-// emission probabilities of MY two states at CI record `rec` (+ the outlier rule)
+// Raw per-step input of one lane: the observation (gaussian / discrete) or my pobs pair.
+struct ObsIn {
+    double o;
+    int sym;
+    double2 pp;
+};
 template <int N, int KIND>
-__device__ __forceinline__ void emit_pair(const Model<N> &m, const void *obs_ci, const double *Bt,
-                                          int64_t rec, int cl, int q, const double (&mu)[2],
-                                          const double (&is)[2], const double (&cn)[2],
-                                          unsigned long long gmask, double (&p)[2], double &o,
-                                          int &sym)
+__device__ __forceinline__ ObsIn load_obs(const void *obs_ci, int64_t rec, int cl, int q)
+{
+    ObsIn in;
+    in.o = 0.0;
+    in.sym = 0;
+    in.pp = make_double2(0.0, 0.0);
+    if constexpr (KIND == EMIT_GAUSS)
+        in.o = static_cast<const double *>(obs_ci)[rec * 64 + cl];
+    else if constexpr (KIND == EMIT_DISC)
+        in.sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + cl];
+    else
+        in.pp = *(reinterpret_cast<const double2 *>(static_cast<const double *>(obs_ci) +
+                                                    rec * (int64_t)(N * 64)) +
+                  q * 64 + cl);
+    return in;
+}
+
+// emission probabilities of MY two states (+ the outlier rule)
+template <int N, int KIND>
+__device__ __forceinline__ void emit_pair(const Model<N> &m, const ObsIn &in, const double *Bt,
+                                          int q, const double (&mu)[2], const double (&is)[2],
+                                          const double (&cn)[2], unsigned long long gmask,
+                                          double (&p)[2])
 {
     if constexpr (KIND == EMIT_GAUSS) {
-        o = static_cast<const double *>(obs_ci)[rec * 64 + cl];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const double z = (o - mu[b]) * is[b];
+            const double z = (in.o - mu[b]) * is[b];
             p[b] = cn[b] * exp(-0.5 * z * z);
         }
         if ((__ballot(p[0] != 0.0 || p[1] != 0.0) & gmask) == 0ull) {
@@ -533,16 +579,12 @@ __device__ __forceinline__ void emit_pair(const Model<N> &m, const void *obs_ci,
             p[1] = (2 * q + 1 < m.nreal) ? 1.0 : 0.0;
         }
     } else if constexpr (KIND == EMIT_DISC) {
-        sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + cl];
-        const double2 x = *reinterpret_cast<const double2 *>(Bt + (int64_t)sym * N + 2 * q);
+        const double2 x = *reinterpret_cast<const double2 *>(Bt + (int64_t)in.sym * N + 2 * q);
         p[0] = x.x;
         p[1] = x.y;
     } else {
-        const double2 x = *(reinterpret_cast<const double2 *>(
-                                static_cast<const double *>(obs_ci) + rec * (int64_t)(N * 64)) +
-                            q * 64 + cl);
-        p[0] = x.x;
-        p[1] = x.y;
+        p[0] = in.pp.x;
+        p[1] = in.pp.y;
     }
 }
 
@@ -617,15 +659,16 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
             double P = 1.0; // running product of the scaling factors c_t, mantissa part
             int eP = 0;     // ... and its binary exponent: logL = log(P) + eP ln 2
             int s = 0;
+            ObsIn nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, 0, ch.Lmax), cl, q);
             if (first) {
-                double p[2], o;
-                int sym;
-                emit_pair<N, KIND>(m, obs_ci, Bt, ci_rec(g, 0, ch.Lmax), cl, q, mu, is, cn, gmask,
-                                   p, o, sym);
+                double p[2];
+                emit_pair<N, KIND>(m, nxt, Bt, q, mu, is, cn, gmask, p);
+                if (len > 1)
+                    nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, 1, ch.Lmax), cl, q);
                 a[0] = pi2[0] * p[0];
                 a[1] = pi2[1] * p[1];
                 const double c = grp_sum<H>(a[0] + a[1]);
-                const double rc = 1.0 / c;
+                const double rc = fast_rcp(c);
                 a[0] *= rc;
                 a[1] *= rc;
                 P = frexp(c, &eP);
@@ -634,15 +677,17 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
             } else {
                 // entry vector from k_stitch (power-of-two scaled): normalise, _hidden.c:57-59
                 const double2 x = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
-                const double rS = 1.0 / grp_sum<H>(x.x + x.y);
+                const double rS = fast_rcp(grp_sum<H>(x.x + x.y));
                 a[0] = x.x * rS;
                 a[1] = x.y * rS;
             }
             for (; s < len; ++s) {
-                double p[2], o;
-                int sym;
+                double p[2];
                 const int64_t rec = ci_rec(g, s, ch.Lmax);
-                emit_pair<N, KIND>(m, obs_ci, Bt, rec, cl, q, mu, is, cn, gmask, p, o, sym);
+                const ObsIn cur = nxt;
+                if (s + 1 < len) // issue the next step's load before this step's arithmetic
+                    nxt = load_obs<N, KIND>(obs_ci, rec + 1, cl, q);
+                emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
                 double af[N];
                 grp_gather<N>(a, af);
                 double n0 = af[0] * Ac[0][0], n1 = af[0] * Ac[0][1];
@@ -654,7 +699,7 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
                 n0 *= p[0];
                 n1 *= p[1];
                 const double c = grp_sum<H>(n0 + n1);
-                const double rc = 1.0 / c;
+                const double rc = fast_rcp(c);
                 a[0] = n0 * rc;
                 a[1] = n1 * rc;
                 int e;
@@ -679,10 +724,9 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
             }
             *ci_pair(ws, ci_rec(g, len - 1, ch.Lmax), N, q, cl) = make_double2(b2[0], b2[1]);
             for (int s = len - 1; s >= 1; --s) {
-                double p[2], o;
-                int sym;
-                emit_pair<N, KIND>(m, obs_ci, Bt, ci_rec(g, s, ch.Lmax), cl, q, mu, is, cn, gmask,
-                                   p, o, sym);
+                double p[2];
+                const ObsIn cur = load_obs<N, KIND>(obs_ci, ci_rec(g, s, ch.Lmax), cl, q);
+                emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
                 const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
                 double bf[N];
                 grp_gather<N>(bb2, bf);
@@ -709,16 +753,30 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
                 b2[1] = x.y;
                 gam[0] = a[0] * b2[0];
                 gam[1] = a[1] * b2[1];
-                const double rS = 1.0 / grp_sum<H>(gam[0] + gam[1]);
+                const double rS = fast_rcp(grp_sum<H>(gam[0] + gam[1]));
                 gam[0] *= rS;
                 gam[1] *= rS;
             }
             const int k = ch.traj[g];
+            // one-step-ahead prefetch of the inputs of the NEXT iteration (obs_{s-1},
+            // alpha_{s-2}): with a few wavefronts per SIMD the HBM latency of a load issued
+            // at its point of use is not covered by the other waves
+            ObsIn nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, len - 1, ch.Lmax), cl, q);
+            double2 apn = make_double2(0.0, 0.0);
+            if (len > 1)
+                apn = *ci_pair(ws, ci_rec(g, len - 2, ch.Lmax), N, q, cl);
             for (int s = len - 1; s >= 0; --s) {
-                double p[2], o = 0.0;
-                int sym = 0;
+                double p[2];
                 const int64_t rec = ci_rec(g, s, ch.Lmax);
-                emit_pair<N, KIND>(m, obs_ci, Bt, rec, cl, q, mu, is, cn, gmask, p, o, sym);
+                const ObsIn cur = nxt;
+                double2 apv = apn;
+                if (s > 0)
+                    nxt = load_obs<N, KIND>(obs_ci, rec - 1, cl, q);
+                if (s > 1)
+                    apn = *ci_pair(ws, rec - 2, N, q, cl);
+                emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
+                const double o = cur.o;
+                const int sym = cur.sym;
                 // ---- consume gamma_s: state counts + emission statistics ---------------
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
@@ -740,10 +798,7 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
                     break;
                 }
                 // ---- pair (s-1, s): xi accumulation and beta_{s-1} ----------------------
-                double2 apv;
-                if (s > 0)
-                    apv = *ci_pair(ws, rec - 1, N, q, cl);
-                else
+                if (s == 0)
                     apv = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
                 const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
                 double bf[N];
@@ -755,7 +810,7 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
                     r1 = fma(Ar[1][j], bf[j], r1);
                 }
                 const double q0 = apv.x * r0, q1 = apv.y * r1;
-                const double rS = 1.0 / grp_sum<H>(q0 + q1);
+                const double rS = fast_rcp(grp_sum<H>(q0 + q1));
                 gam[0] = q0 * rS;
                 gam[1] = q1 * rS;
                 const double w0 = apv.x * rS, w1 = apv.y * rS;
