@@ -33,6 +33,9 @@ enum { EMIT_GAUSS = 0, EMIT_DISC = 1, EMIT_EXPL = 2 };
 enum { MODE_ESTEP = 0, MODE_FWD = 1, MODE_BWD = 2 };
 
 constexpr int BLOCK = 256;
+#ifndef FB_MINW
+#define FB_MINW 1
+#endif
 
 // Model parameters, passed by value as kernel arguments (uniform -> scalar registers).
 // N is the padded state count (2, 4 or 8); states >= nreal are inert (pi = 0, p = 0).
@@ -594,7 +597,7 @@ __device__ __forceinline__ double2 *ci_pair(double *base, int64_t rec, int N_, i
 }
 
 template <int N, int KIND, int MODE>
-__global__ __launch_bounds__(32 * N) void k_fwdbwd(
+__global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
     const Model<N> m, const Chunks ch, const void *obs_ci, const double *Bt_g,
     const double *alpha_entry, const double *beta_exit,
     double *ws,            // CI workspace: alpha (ESTEP, FWD) or beta (BWD)
@@ -626,15 +629,10 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
     const bool first = (t0 == 0);
     const unsigned long long gmask = ((1ull << H) - 1) << ((threadIdx.x & 63) / H * H);
 
-    // my slices of the model (vector registers; loaded once)
-    double Ac[N][2], Ar[2][N], mu[2], is[2], cn[2], pi2[2];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        Ac[i][0] = m.A[i * N + 2 * q];
-        Ac[i][1] = m.A[i * N + 2 * q + 1];
-        Ar[0][i] = m.A[(2 * q) * N + i];
-        Ar[1][i] = m.A[(2 * q + 1) * N + i];
-    }
+    // my slices of the model (vector registers): the two columns of A for the forward sweep,
+    // the two rows for the backward sweep -- each loaded where its sweep starts so that they
+    // are not live together
+    double mu[2], is[2], cn[2], pi2[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         mu[b] = m.e0[2 * q + b];
@@ -656,6 +654,12 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
         double a[2];
         // ---------------- forward sweep (_hidden.c:16-66) ------------------------------
         if constexpr (MODE != MODE_BWD) {
+            double Ac[N][2];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                Ac[i][0] = m.A[i * N + 2 * q];
+                Ac[i][1] = m.A[i * N + 2 * q + 1];
+            }
             double P = 1.0; // running product of the scaling factors c_t, mantissa part
             int eP = 0;     // ... and its binary exponent: logL = log(P) + eP ln 2
             int s = 0;
@@ -712,6 +716,14 @@ __global__ __launch_bounds__(32 * N) void k_fwdbwd(
         }
 
         // ---------------- backward sweep ------------------------------------------------
+        double Ar[2][N];
+        if constexpr (MODE != MODE_FWD) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                Ar[0][i] = m.A[(2 * q) * N + i];
+                Ar[1][i] = m.A[(2 * q + 1) * N + i];
+            }
+        }
         if constexpr (MODE == MODE_BWD) {
             // plain scaled backward recursion with the reference normalisation
             // (_hidden.c:69-110); beta rows go to the CI workspace.
