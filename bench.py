@@ -227,6 +227,12 @@ def main():
         # kernel k_fwdbwd carries all of them (obs twice, alpha written once and read once).
         alg_bytes_launch = B_ALG_GAUSS * K * T
         achieved = alg_bytes_launch / (kern_ms[2] * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01", "r01c_traffic.json")
+        if os.path.exists(tj) and (K, T) == (256, 100000):
+            # HBM bytes of one k_fwdbwd launch from the PMC counters (collected offline with
+            # rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)
+            traffic = json.load(open(tj))["traffic_bytes_per_launch"]
         out = {
             "metric": "timesteps/sec forward-backward (whole node), N=8 states",
             "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
@@ -241,7 +247,9 @@ def main():
                                       "%d statistics" % (world, S)},
             "roofline": {"bound": "hbm", "kernel": "k_fwdbwd<8,gauss,estep>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC, profiles/r01/r01c_traffic.json)",
+                         "alg_bytes_per_launch": alg_bytes_launch,
                          "alg_bytes_per_timestep": B_ALG_GAUSS,
                          "whole_estep_frac": B_ALG_GAUSS * value / world / 1e9 / HBM_PEAK_GBS},
             "kernel_ms": {names[i]: float(kern_ms[i]) for i in range(5)},
