@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--ntraj", type=int, default=256)
     ap.add_argument("--length", type=int, default=100000)
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--cpu-traj", type=int, default=48, help="trajectories in the CPU baseline")
+    ap.add_argument("--cpu-traj", type=int, default=200, help="trajectories in the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

@@ -210,8 +210,10 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
     const int K = c->K;
     int L = chunk;
     if (L <= 0) {
-        // aim for ~2 wavefronts per SIMD on 256 CUs: 2 * 1024 * 64 lanes
-        const int64_t target = 131072;
+        // k_fwdbwd uses N/2 lanes and k_prescan N lanes per chunk: 65536 chunks put 4 (8)
+        // wavefronts on every SIMD of the 256 CUs, and halve the serial depth of k_stitch
+        // compared with one chunk per lane (measured optimum on configs[1], profiles/r01)
+        const int64_t target = 65536;
         int64_t l = (c->total + target - 1) / target;
         L = (int)std::min<int64_t>(std::max<int64_t>(l, 32), 4096);
     }
