@@ -270,6 +270,13 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
 int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1);
 int unpack_ws_rows(bhmm_ctx *c, double *dst_dev);
+// wide_api.hip (9..64 states)
+int wide_alloc(bhmm_ctx *c);
+int wide_forward(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                 const double *par1);
+int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+               const double *par1, double *stats_dev, int flags);
+int wide_backward(bhmm_ctx *c, const double *A);
 
 static int64_t ci_records(const bhmm_ctx *c) { return (int64_t)(c->Gp / 64) * c->Lmax; }
 
@@ -450,6 +457,7 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     c->d_offsets.release();
     c->d_Brm.release();
     c->d_alpha_rm.release();
+    c->d_wmodel.release();
     if (c->h_pinned)
         (void)hipHostFree(c->h_pinned);
     for (auto &ev : c->ev)
@@ -468,14 +476,15 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         return invalid("bad context / offsets / K");
     if (kind < 0 || kind > 2)
         return invalid("unknown emission kind");
-    if (nstates < 1 || nstates > 8)
-        return invalid("this build handles 1..8 hidden states on the lane-per-chunk path");
+    if (nstates < 1 || nstates > 64)
+        return invalid("1..64 hidden states are supported");
     if (kind == BHMM_EMIT_DISCRETE && nsymbols < 1)
         return invalid("nsymbols must be >= 1 for discrete emissions");
     BHMM_HIP(hipSetDevice(c->device));
     BHMM_HIP(hipStreamSynchronize(c->stream));
     c->kind = kind;
     c->n = nstates;
+    c->wide = nstates > 8;
     c->N = pad_states(nstates);
     c->M = kind == BHMM_EMIT_DISCRETE ? nsymbols : 0;
     c->K = K;
@@ -496,7 +505,38 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         if (sm > 160 * 1024)
             return invalid("discrete alphabet too large for the LDS-resident tables");
     }
-    int rc = plan_chunks(c, chunk);
+    int rc;
+    if (c->wide) {
+        // 9..64 states: trajectory-parallel kernels on trajectory-major data, no chunk plan
+        const size_t esz_w = kind == BHMM_EMIT_GAUSSIAN ? sizeof(double)
+                             : kind == BHMM_EMIT_DISCRETE ? sizeof(int32_t)
+                                                          : sizeof(double) * (size_t)c->n;
+        const size_t bytes_w = (size_t)c->total * esz_w;
+        const char *base_w = static_cast<const char *>(obs) + (size_t)offsets[0] * esz_w;
+        if ((rc = c->d_obs_rm.ensure(bytes_w)) || (rc = c->d_offsets.ensure(K + 1)))
+            return rc;
+        BHMM_HIP(hipMemcpyAsync(c->d_obs_rm.p, base_w, bytes_w,
+                                obs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                c->stream));
+        BHMM_HIP(hipMemcpyAsync(c->d_offsets.p, c->offsets.data(), (K + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, c->stream));
+        c->G = c->Gp = 0;
+        c->Lmax = 0;
+        if ((rc = wide_alloc(c)))
+            return rc;
+        const size_t need = (size_t)stats_size(c) + c->K;
+        if (need > c->h_pinned_n) {
+            if (c->h_pinned)
+                (void)hipHostFree(c->h_pinned);
+            c->h_pinned = nullptr;
+            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), need * sizeof(double),
+                                   hipHostMallocDefault));
+            c->h_pinned_n = need;
+        }
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        return BHMM_OK;
+    }
+    rc = plan_chunks(c, chunk);
     if (rc)
         return rc;
     if ((rc = alloc_work(c)))
@@ -586,14 +626,16 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         return invalid("discrete emissions need B");
     BHMM_HIP(hipSetDevice(c->device));
     int rc;
-    if (c->kind == BHMM_EMIT_DISCRETE && (rc = upload_Bt(c, par0)))
+    if (!c->wide && c->kind == BHMM_EMIT_DISCRETE && (rc = upload_Bt(c, par0)))
         return rc;
-    if (flags & BHMM_FLAG_STORE_GAMMA) {
+    if (!c->wide && (flags & BHMM_FLAG_STORE_GAMMA)) {
         if ((rc = c->d_gamma_ci.ensure((size_t)ci_records(c) * c->N * 64)))
             return rc;
     }
     c->gamma_valid = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
     double *sd = stats_dev ? stats_dev : c->d_stats.p;
+    if (c->wide)
+        return wide_estep(c, A, pi, par0, par1, sd, flags);
     return BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
 }
 
@@ -633,6 +675,13 @@ int bhmm_get_gamma(bhmm_ctx *c, int k, double *gamma)
     const int64_t T = c->offsets[k + 1] - c->offsets[k];
     if (T == 0)
         return BHMM_OK;
+    if (c->wide) { // already trajectory-major
+        BHMM_HIP(hipMemcpyAsync(gamma, c->d_gamma_ci.p + c->offsets[k] * c->n,
+                                (size_t)T * c->n * sizeof(double), hipMemcpyDeviceToHost,
+                                c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        return BHMM_OK;
+    }
     int rc = c->d_scratch.ensure((size_t)T * c->n * sizeof(double));
     if (rc)
         return rc;
@@ -699,12 +748,20 @@ int bhmm_forward(double *alpha, double *logprob, const double *A, const double *
     if (rc)
         return rc;
     bhmm_ctx *c = t.c;
-    rc = BHMM_DISPATCH_N(c, template sweep_explicit<MODE_FWD>(c, A, pi));
-    if (rc)
-        return rc;
-    rc = download_rows(c, c->d_ws.p, alpha);
-    if (rc)
-        return rc;
+    if (c->wide) {
+        if ((rc = wide_forward(c, A, pi, nullptr, nullptr)))
+            return rc;
+        BHMM_HIP(hipMemcpyAsync(alpha, c->d_alpha_rm.p, (size_t)T * N * sizeof(double),
+                                hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        rc = BHMM_DISPATCH_N(c, template sweep_explicit<MODE_FWD>(c, A, pi));
+        if (rc)
+            return rc;
+        rc = download_rows(c, c->d_ws.p, alpha);
+        if (rc)
+            return rc;
+    }
     double ll = 0.0;
     BHMM_HIP(hipMemcpy(&ll, c->d_logLk.p, sizeof(double), hipMemcpyDeviceToHost));
     if (logprob)
@@ -721,6 +778,14 @@ int bhmm_backward(double *beta, const double *A, const double *pobs, int N, int6
     if (rc)
         return rc;
     bhmm_ctx *c = t.c;
+    if (c->wide) {
+        if ((rc = wide_backward(c, A)))
+            return rc;
+        BHMM_HIP(hipMemcpyAsync(beta, c->d_alpha_rm.p, (size_t)T * N * sizeof(double),
+                                hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        return BHMM_OK;
+    }
     std::vector<double> pi(N, 1.0 / N); // the backward recursion does not involve pi
     rc = BHMM_DISPATCH_N(c, template sweep_explicit<MODE_BWD>(c, A, pi.data()));
     if (rc)

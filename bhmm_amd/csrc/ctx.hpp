@@ -83,6 +83,8 @@ struct bhmm_ctx {
     bhmm::DevBuf<int64_t> d_offsets; // [K+1] trajectory offsets (time steps)
     bhmm::DevBuf<double> d_Brm;      // [n][M] emission matrix, row-major (path kernels)
     bhmm::DevBuf<double> d_alpha_rm; // [total][n] alpha, trajectory-major (path sampling)
+    bhmm::DevBuf<double> d_wmodel;   // model parameters of the 9..64-state family
+    bool wide = false;               // nstates > 8: wide_kernels.hpp family
     double *h_pinned = nullptr;      // stats + logL_k landing zone
     size_t h_pinned_n = 0;
 

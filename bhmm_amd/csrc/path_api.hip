@@ -15,6 +15,8 @@
 
 namespace bhmm {
 int invalid_arg(const std::string &msg);
+int wide_transition_counts(double *C, const double *A, const double *pobs, const double *alpha,
+                           const double *beta, int n, int64_t T);
 int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1);
 int unpack_ws_rows(bhmm_ctx *c, double *dst_dev);
@@ -232,6 +234,8 @@ int bhmm_viterbi_batch(bhmm_ctx *c, const double *A, const double *pi, const dou
         return invalid_arg("gaussian emissions need means and sigmas");
     if (c->kind == BHMM_EMIT_DISCRETE && !par0)
         return invalid_arg("discrete emissions need B");
+    if (c->wide)
+        return invalid_arg("Viterbi for more than 8 states is not implemented yet");
     BHMM_HIP(hipSetDevice(c->device));
     switch (c->N) {
     case 2:
@@ -251,6 +255,8 @@ int bhmm_sample_paths(bhmm_ctx *c, const double *A, const double *pi, const doub
         return invalid_arg("no observations loaded");
     if (!A || !pi)
         return invalid_arg("NULL argument");
+    if (c->wide)
+        return invalid_arg("path sampling for more than 8 states is not implemented yet");
     BHMM_HIP(hipSetDevice(c->device));
     switch (c->N) {
     case 2:
@@ -363,8 +369,10 @@ int bhmm_transition_counts(double *C, const double *A, const double *pobs, const
 {
     if (!C || !A || !pobs || !alpha || !beta || N < 1 || T < 1)
         return invalid_arg("NULL argument or empty problem");
+    if (N > 64)
+        return invalid_arg("1..64 hidden states are supported");
     if (N > 8)
-        return invalid_arg("this build handles 1..8 hidden states");
+        return wide_transition_counts(C, A, pobs, alpha, beta, N, T);
     Tmp tmp;
     double *dA, *dp, *da, *db, *dpart, *dC;
     int rc;

@@ -1,0 +1,246 @@
+// wide_api.hip -- host side of the 9..64-state kernel family (wide_kernels.hpp).
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "host_common.hpp"
+#include "wide_kernels.hpp"
+
+namespace bhmm {
+int invalid_arg(const std::string &msg);
+
+static int wide_np(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
+
+// upload the model into ctx->d_wmodel and describe it
+static int wide_model(bhmm_ctx *c, int kind, const double *A, const double *pi, const double *par0,
+                      const double *par1, WideModel &m)
+{
+    const int n = c->n;
+    std::vector<double> h((size_t)n * n + 5 * n, 0.0);
+    memcpy(h.data(), A, sizeof(double) * n * n);
+    double *hp = h.data() + (size_t)n * n;
+    for (int i = 0; i < n; ++i) {
+        hp[i] = pi ? pi[i] : 0.0;
+        if (kind == EMIT_GAUSS) {
+            hp[n + i] = par0[i];
+            hp[2 * n + i] = 1.0 / par1[i];
+            hp[3 * n + i] = 1.0 / (sqrt(2.0 * M_PI) * par1[i]);
+            hp[4 * n + i] = par1[i];
+        }
+    }
+    int rc = c->d_wmodel.ensure(h.size());
+    if (rc)
+        return rc;
+    BHMM_HIP(hipMemcpyAsync(c->d_wmodel.p, h.data(), h.size() * sizeof(double),
+                            hipMemcpyHostToDevice, c->stream));
+    m.A = c->d_wmodel.p;
+    m.pi = m.A + (size_t)n * n;
+    m.mu = m.pi + n;
+    m.isig = m.mu + n;
+    m.cnorm = m.isig + n;
+    m.sigma = m.cnorm + n;
+    m.n = n;
+    m.M = c->M;
+    m.B = nullptr;
+    if (kind == EMIT_DISC) {
+        if ((rc = c->d_Brm.ensure((size_t)n * c->M)))
+            return rc;
+        BHMM_HIP(hipMemcpyAsync(c->d_Brm.p, par0, (size_t)n * c->M * sizeof(double),
+                                hipMemcpyHostToDevice, c->stream));
+        m.B = c->d_Brm.p;
+    }
+    BHMM_HIP(hipStreamSynchronize(c->stream)); // h is a temporary
+    return BHMM_OK;
+}
+
+template <int NP, int KIND>
+static int wide_launch_fwd(bhmm_ctx *c, const WideModel &m)
+{
+    constexpr int GP = 64 / NP;
+    hipLaunchKernelGGL((k_wide_fwd<NP, KIND>), dim3((c->K + GP - 1) / GP), dim3(64), 0, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, c->K, (const void *)c->d_obs_rm.p,
+                       c->d_alpha_rm.p, c->d_logLk.p);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+template <int NP, int KIND>
+static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, bool store_gamma, double *stats_dev)
+{
+    constexpr int GP = 64 / NP;
+    const size_t sm = (size_t)(NP * (NP + 1) + GP * NP) * sizeof(double);
+    hipLaunchKernelGGL((k_wide_bwd<NP, KIND>), dim3((c->K + GP - 1) / GP), dim3(64), sm, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, c->K, (const void *)c->d_obs_rm.p,
+                       (const double *)c->d_alpha_rm.p,
+                       store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_gamma0.p,
+                       c->d_partials.p, c->d_dpartials.p);
+    BHMM_HIP(hipGetLastError());
+    const int n = c->n;
+    const int nfin = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0) + (KIND == EMIT_DISC ? n * c->M : 0) +
+                     n + 1;
+    hipLaunchKernelGGL((k_wide_finalize<KIND>), dim3(nfin), dim3(64), 0, c->stream, m, c->K,
+                       (const double *)c->d_partials.p, (const double *)c->d_dpartials.p,
+                       (const double *)c->d_logLk.p, (const double *)c->d_gamma0.p, stats_dev);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+#define WIDE_DISPATCH(c, KIND, fn, ...)                               \
+    ((c)->N == 16 ? fn<16, KIND>(__VA_ARGS__)                         \
+     : (c)->N == 32 ? fn<32, KIND>(__VA_ARGS__)                       \
+                    : fn<64, KIND>(__VA_ARGS__))
+
+int wide_alloc(bhmm_ctx *c)
+{
+    const int n = c->n;
+    c->N = wide_np(n);
+    const int S = n * n + 3 * n;
+    int rc;
+    if ((rc = c->d_alpha_rm.ensure((size_t)c->total * n)) ||
+        (rc = c->d_logLk.ensure(std::max(c->K, 1))) ||
+        (rc = c->d_gamma0.ensure((size_t)std::max(c->K, 1) * n)) ||
+        (rc = c->d_partials.ensure((size_t)c->K * S)) || (rc = c->d_stats.ensure(1 + n + n * n + n + std::max(2 * n, n * c->M))))
+        return rc;
+    if (c->kind == EMIT_DISC && (rc = c->d_dpartials.ensure((size_t)c->K * n * c->M)))
+        return rc;
+    BHMM_HIP(hipMemsetAsync(c->d_gamma0.p, 0, (size_t)std::max(c->K, 1) * n * sizeof(double),
+                            c->stream));
+    return BHMM_OK;
+}
+
+int wide_forward(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                 const double *par1)
+{
+    WideModel m;
+    int rc = wide_model(c, c->kind, A, pi, par0, par1, m);
+    if (rc)
+        return rc;
+    switch (c->kind) {
+    case EMIT_GAUSS:
+        return WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m);
+    case EMIT_DISC:
+        return WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m);
+    default:
+        return WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m);
+    }
+}
+
+int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+               const double *par1, double *stats_dev, int flags)
+{
+    WideModel m;
+    int rc = wide_model(c, c->kind, A, pi, par0, par1, m);
+    if (rc)
+        return rc;
+    const bool sg = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
+    if (sg && (rc = c->d_gamma_ci.ensure((size_t)c->total * c->n)))
+        return rc;
+    BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
+    BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
+    BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
+    switch (c->kind) {
+    case EMIT_GAUSS:
+        if ((rc = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m)))
+            return rc;
+        rc = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_bwd, c, m, sg, stats_dev);
+        break;
+    case EMIT_DISC:
+        if ((rc = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m)))
+            return rc;
+        rc = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_bwd, c, m, sg, stats_dev);
+        break;
+    default:
+        if ((rc = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m)))
+            return rc;
+        rc = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_bwd, c, m, sg, stats_dev);
+    }
+    if (rc)
+        return rc;
+    BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
+    BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
+    c->ev_pending = true;
+    return BHMM_OK;
+}
+
+// beta (row-major) for explicit pobs into ctx->d_alpha_rm (reused as the output buffer)
+int wide_backward(bhmm_ctx *c, const double *A)
+{
+    WideModel m;
+    int rc = wide_model(c, EMIT_EXPL, A, nullptr, nullptr, nullptr, m);
+    if (rc)
+        return rc;
+    const int NP = c->N, GP = 64 / NP;
+    const size_t sm = (size_t)(NP * (NP + 1) + GP * NP) * sizeof(double);
+    const dim3 grid((c->K + GP - 1) / GP), blk(64);
+    const double *pobs = reinterpret_cast<const double *>(c->d_obs_rm.p);
+    if (NP == 16)
+        hipLaunchKernelGGL((k_wide_beta<16>), grid, blk, sm, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, c->K, pobs, c->d_alpha_rm.p);
+    else if (NP == 32)
+        hipLaunchKernelGGL((k_wide_beta<32>), grid, blk, sm, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, c->K, pobs, c->d_alpha_rm.p);
+    else
+        hipLaunchKernelGGL((k_wide_beta<64>), grid, blk, sm, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, c->K, pobs, c->d_alpha_rm.p);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+// xi-counts from host alpha / beta / pobs (hidden API), 9..64 states
+int wide_transition_counts(double *C, const double *A, const double *pobs, const double *alpha,
+                           const double *beta, int n, int64_t T)
+{
+    const int NP = wide_np(n), GP = 64 / NP;
+    const int nslab = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (T - 1 + 63) / 64));
+    double *dA, *dp, *da, *db, *dpart, *dC;
+    const size_t cnt = (size_t)T * n;
+    std::vector<void *> ptrs;
+    auto alloc = [&](double **p, size_t count) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(double));
+        if (e == hipSuccess)
+            ptrs.push_back(*p);
+        return e;
+    };
+    auto cleanup = [&]() {
+        for (void *p : ptrs)
+            (void)hipFree(p);
+    };
+    if (alloc(&dA, (size_t)n * n) || alloc(&dp, cnt) || alloc(&da, cnt) || alloc(&db, cnt) ||
+        alloc(&dpart, (size_t)nslab * n * n) || alloc(&dC, (size_t)n * n)) {
+        cleanup();
+        (void)hipGetLastError();
+        set_error("hipMalloc failed");
+        return BHMM_ERR_NO_MEM;
+    }
+    hipError_t e = hipMemcpy(dA, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dp, pobs, cnt * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(da, alpha, cnt * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, beta, cnt * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dpart, 0, (size_t)nslab * n * n * sizeof(double));
+    if (e == hipSuccess) {
+        const size_t sm = (size_t)(NP * (NP + 1) + GP * NP) * sizeof(double);
+        const dim3 grid((nslab + GP - 1) / GP), blk(64);
+        if (NP == 16)
+            hipLaunchKernelGGL((k_wide_xi<16>), grid, blk, sm, 0, (const double *)dA, (const double *)dp,
+                               (const double *)da, (const double *)db, n, T, nslab, dpart);
+        else if (NP == 32)
+            hipLaunchKernelGGL((k_wide_xi<32>), grid, blk, sm, 0, (const double *)dA, (const double *)dp,
+                               (const double *)da, (const double *)db, n, T, nslab, dpart);
+        else
+            hipLaunchKernelGGL((k_wide_xi<64>), grid, blk, sm, 0, (const double *)dA, (const double *)dp,
+                               (const double *)da, (const double *)db, n, T, nslab, dpart);
+        hipLaunchKernelGGL(k_wide_xi_sum, dim3(n * n), dim3(64), 0, 0, (const double *)dA,
+                           (const double *)dpart, n, nslab, dC);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(C, dC, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess)
+        return hip_fail(e, "wide_transition_counts");
+    return BHMM_OK;
+}
+
+} // namespace bhmm
