@@ -15,6 +15,10 @@
 
 namespace bhmm {
 int invalid_arg(const std::string &msg);
+int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, const double *par0,
+                   const double *par1, WideModel &m);
+int wide_forward(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                 const double *par1);
 int wide_transition_counts(double *C, const double *A, const double *pobs, const double *alpha,
                            const double *beta, int n, int64_t T);
 int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
@@ -201,6 +205,145 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     return BHMM_OK;
 }
 
+// ---- 9..64 states ---------------------------------------------------------------------
+int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                     const double *par1, int32_t *paths_host)
+{
+    WideModel m;
+    int rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m);
+    if (rc)
+        return rc;
+    const int K = c->K, n = c->n, NP = c->N, GP = 64 / NP;
+    if ((rc = c->d_scratch.ensure((size_t)c->total * n)) ||
+        (rc = c->d_scratch2.ensure(((size_t)c->total + K) * sizeof(int32_t))))
+        return rc;
+    uint8_t *ptr = reinterpret_cast<uint8_t *>(c->d_scratch.p);
+    int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
+    int32_t *path = last + K;
+    const dim3 grid((K + GP - 1) / GP), blk(64);
+    const void *obs = c->d_obs_rm.p;
+    const int64_t *off = c->d_offsets.p;
+#define BHMM_WV(NPV, KINDV)                                                                     \
+    hipLaunchKernelGGL((k_wide_viterbi_fwd<NPV, KINDV>), grid, blk, 0, c->stream, m, off, K, obs, \
+                       ptr, last)
+#define BHMM_WV_KIND(NPV)                                 \
+    do {                                                  \
+        if (c->kind == EMIT_GAUSS)                        \
+            BHMM_WV(NPV, EMIT_GAUSS);                     \
+        else if (c->kind == EMIT_DISC)                    \
+            BHMM_WV(NPV, EMIT_DISC);                      \
+        else                                              \
+            BHMM_WV(NPV, EMIT_EXPL);                      \
+    } while (0)
+    if (NP == 16)
+        BHMM_WV_KIND(16);
+    else if (NP == 32)
+        BHMM_WV_KIND(32);
+    else
+        BHMM_WV_KIND(64);
+    BHMM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_wide_viterbi_trace, dim3(K), dim3(64), 0, c->stream, off, K, n,
+                       (const uint8_t *)ptr, (const int32_t *)last, path);
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipMemcpyAsync(paths_host, path, (size_t)c->total * sizeof(int32_t),
+                            hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    return BHMM_OK;
+}
+
+int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                    const double *par1, const double *u, uint64_t seed, int32_t *paths,
+                    int64_t *counts, int64_t *n0, double *emis)
+{
+    int rc = wide_forward(c, A, pi, par0, par1); // alpha (row-major) in d_alpha_rm
+    if (rc)
+        return rc;
+    WideModel m;
+    if ((rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m)))
+        return rc;
+    const int K = c->K, n = c->n, NP = c->N, GP = 64 / NP;
+    const size_t nstat = (size_t)n * n + n;
+    const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)n
+                                             : (c->kind == EMIT_DISC ? (size_t)n * c->M : 0);
+    if ((rc = c->d_scratch2.ensure(((size_t)c->total + 4) * sizeof(int32_t))))
+        return rc;
+    int32_t *path = reinterpret_cast<int32_t *>(c->d_scratch2.p);
+    int *status = reinterpret_cast<int *>(path + c->total);
+    const size_t dbl = nstat + (size_t)K * esz + esz + (u ? (size_t)c->total : 0) + 8;
+    if ((rc = c->d_scratch.ensure(dbl * sizeof(double))))
+        return rc;
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(c->d_scratch.p);
+    double *epart = reinterpret_cast<double *>(c->d_scratch.p) + nstat;
+    double *ered = epart + (size_t)K * esz;
+    double *udev = nullptr;
+    if (u) {
+        udev = ered + esz;
+        BHMM_HIP(hipMemcpyAsync(udev, u, (size_t)c->total * sizeof(double), hipMemcpyHostToDevice,
+                                c->stream));
+    }
+    BHMM_HIP(hipMemsetAsync(cnt, 0, nstat * sizeof(unsigned long long), c->stream));
+    BHMM_HIP(hipMemsetAsync(status, 0, sizeof(int), c->stream));
+    if (esz)
+        BHMM_HIP(hipMemsetAsync(ered, 0, esz * sizeof(double), c->stream));
+    const dim3 grid((K + GP - 1) / GP), blk(64);
+    const int64_t *off = c->d_offsets.p;
+    if (NP == 16)
+        hipLaunchKernelGGL((k_wide_sample_path<16>), grid, blk, 0, c->stream, m, off, K,
+                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status);
+    else if (NP == 32)
+        hipLaunchKernelGGL((k_wide_sample_path<32>), grid, blk, 0, c->stream, m, off, K,
+                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status);
+    else
+        hipLaunchKernelGGL((k_wide_sample_path<64>), grid, blk, 0, c->stream, m, off, K,
+                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status);
+    BHMM_HIP(hipGetLastError());
+    if (counts || n0 || emis) {
+        const size_t sm = esz * sizeof(double) + nstat * sizeof(unsigned int);
+        const void *obs = c->d_obs_rm.p;
+        if (c->kind == EMIT_GAUSS)
+            hipLaunchKernelGGL((k_wide_path_stats<EMIT_GAUSS>), dim3(K), dim3(256), sm, c->stream, m,
+                               off, obs, (const int32_t *)path, cnt, epart);
+        else if (c->kind == EMIT_DISC)
+            hipLaunchKernelGGL((k_wide_path_stats<EMIT_DISC>), dim3(K), dim3(256), sm, c->stream, m,
+                               off, obs, (const int32_t *)path, cnt, epart);
+        else
+            hipLaunchKernelGGL((k_wide_path_stats<EMIT_EXPL>), dim3(K), dim3(256), sm, c->stream, m,
+                               off, obs, (const int32_t *)path, cnt, epart);
+        BHMM_HIP(hipGetLastError());
+        if (esz) {
+            hipLaunchKernelGGL(k_add_partials, dim3((unsigned)((esz + 255) / 256)), dim3(256), 0,
+                               c->stream, (const double *)epart, K, (int)esz, ered);
+            BHMM_HIP(hipGetLastError());
+        }
+    }
+    std::vector<unsigned long long> hc(nstat);
+    std::vector<double> he(esz);
+    int hstatus = 0;
+    BHMM_HIP(hipMemcpyAsync(hc.data(), cnt, nstat * sizeof(unsigned long long),
+                            hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (esz)
+        BHMM_HIP(hipMemcpyAsync(he.data(), ered, esz * sizeof(double), hipMemcpyDeviceToHost,
+                                c->stream));
+    if (paths)
+        BHMM_HIP(hipMemcpyAsync(paths, path, (size_t)c->total * sizeof(int32_t),
+                                hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    if (hstatus) {
+        set_error("random choice found no state: alpha/A not normalisable (_hidden.c:299-304)");
+        return hstatus;
+    }
+    if (counts)
+        for (size_t e = 0; e < (size_t)n * n; ++e)
+            counts[e] = (int64_t)hc[e];
+    if (n0)
+        for (int i = 0; i < n; ++i)
+            n0[i] = (int64_t)hc[(size_t)n * n + i];
+    if (emis && esz)
+        memcpy(emis, he.data(), esz * sizeof(double)); // gaussian [3][n]; discrete [n][M]
+    return BHMM_OK;
+}
+
 struct TmpCtx {
     bhmm_ctx *c = nullptr;
     ~TmpCtx() { bhmm_ctx_destroy(c); }
@@ -234,9 +377,9 @@ int bhmm_viterbi_batch(bhmm_ctx *c, const double *A, const double *pi, const dou
         return invalid_arg("gaussian emissions need means and sigmas");
     if (c->kind == BHMM_EMIT_DISCRETE && !par0)
         return invalid_arg("discrete emissions need B");
-    if (c->wide)
-        return invalid_arg("Viterbi for more than 8 states is not implemented yet");
     BHMM_HIP(hipSetDevice(c->device));
+    if (c->wide)
+        return wide_viterbi_run(c, A, pi, par0, par1, paths);
     switch (c->N) {
     case 2:
         return viterbi_run<2>(c, A, pi, par0, par1, paths);
@@ -255,9 +398,9 @@ int bhmm_sample_paths(bhmm_ctx *c, const double *A, const double *pi, const doub
         return invalid_arg("no observations loaded");
     if (!A || !pi)
         return invalid_arg("NULL argument");
-    if (c->wide)
-        return invalid_arg("path sampling for more than 8 states is not implemented yet");
     BHMM_HIP(hipSetDevice(c->device));
+    if (c->wide)
+        return wide_sample_run(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis);
     switch (c->N) {
     case 2:
         return sample_run<2>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis);
@@ -289,8 +432,8 @@ int bhmm_sample_path(int32_t *path, const double *alpha, const double *A, const 
 {
     if (!path || !alpha || !A || !u || N < 1 || T < 1)
         return invalid_arg("NULL argument or empty problem");
-    if (N > 8)
-        return invalid_arg("this build handles 1..8 hidden states");
+    if (N > 64)
+        return invalid_arg("1..64 hidden states are supported");
     Tmp tmp;
     double *d_alpha, *d_u;
     int64_t *d_off;
@@ -306,6 +449,37 @@ int bhmm_sample_path(int32_t *path, const double *alpha, const double *A, const 
     BHMM_HIP(hipMemcpy(d_u, u, (size_t)T * sizeof(double), hipMemcpyHostToDevice));
     BHMM_HIP(hipMemcpy(d_off, off, sizeof(off), hipMemcpyHostToDevice));
     BHMM_HIP(hipMemset(d_status, 0, sizeof(int)));
+    if (N > 8) {
+        double *d_A;
+        if ((rc = tmp.alloc(&d_A, (size_t)N * N)))
+            return rc;
+        BHMM_HIP(hipMemcpy(d_A, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice));
+        WideModel m;
+        memset(&m, 0, sizeof(m));
+        m.A = d_A;
+        m.n = N;
+        if (N <= 16)
+            hipLaunchKernelGGL((k_wide_sample_path<16>), dim3(1), dim3(64), 0, 0, m,
+                               (const int64_t *)d_off, 1, (const double *)d_alpha,
+                               (const double *)d_u, (uint64_t)0, d_path, d_status);
+        else if (N <= 32)
+            hipLaunchKernelGGL((k_wide_sample_path<32>), dim3(1), dim3(64), 0, 0, m,
+                               (const int64_t *)d_off, 1, (const double *)d_alpha,
+                               (const double *)d_u, (uint64_t)0, d_path, d_status);
+        else
+            hipLaunchKernelGGL((k_wide_sample_path<64>), dim3(1), dim3(64), 0, 0, m,
+                               (const int64_t *)d_off, 1, (const double *)d_alpha,
+                               (const double *)d_u, (uint64_t)0, d_path, d_status);
+        BHMM_HIP(hipGetLastError());
+        int stw = 0;
+        BHMM_HIP(hipMemcpy(path, d_path, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost));
+        BHMM_HIP(hipMemcpy(&stw, d_status, sizeof(int), hipMemcpyDeviceToHost));
+        if (stw) {
+            set_error("random choice found no state: p not normalised (_hidden.c:299-304)");
+            return stw;
+        }
+        return BHMM_OK;
+    }
     const int NP = pad_states_pub(N);
     std::vector<double> pi(N, 0.0);
 #define BHMM_SAMPLE_CASE(NN)                                                                    \

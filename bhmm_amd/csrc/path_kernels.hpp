@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "estep_kernels.hpp"
+#include "wide_kernels.hpp"
 
 namespace bhmm {
 
@@ -453,6 +454,231 @@ __global__ __launch_bounds__(256) void k_path_stats(const Model<N> m, const Chun
     if constexpr (KIND == EMIT_DISC)
         for (int e = threadIdx.x; e < m.M * N; e += blockDim.x)
             epartials[(int64_t)blockIdx.x * m.M * N + e] = lds[e];
+}
+
+// =========================================================================================
+// 9..64 states: same order-faithful recursions, NP lanes per trajectory, vectors exchanged
+// through LDS so that every lane can take the index-ordered sums the reference takes.
+// Back-pointers: one byte per (t, j), trajectory-major [T][n].
+// =========================================================================================
+template <int NP, int KIND>
+__global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, const int64_t *off,
+                                                         int K, const void *obs_rm,
+                                                         uint8_t *ptr, int32_t *last_state)
+{
+    constexpr int GP = 64 / NP;
+    __shared__ __attribute__((aligned(16))) double xv[GP][NP];
+    __shared__ __attribute__((aligned(16))) double xn[GP][NP];
+    const int lane = threadIdx.x;
+    const int gi = lane / NP, j = lane % NP;
+    const int k = blockIdx.x * GP + gi;
+    if (k >= K)
+        return;
+    const int n = m.n;
+    const bool real = j < n;
+    const int64_t o0 = off[k];
+    const int64_t T = off[k + 1] - o0;
+    if (T <= 0)
+        return;
+    const unsigned long long gmask = wgroup_mask<NP>(lane);
+    double Acol[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        Acol[i] = (real && i < n) ? m.A[(int64_t)i * n + j] : 0.0;
+    const double mu_j = (KIND == EMIT_GAUSS && real) ? m.mu[j] : 0.0;
+    const double sg_j = (KIND == EMIT_GAUSS && real) ? m.sigma[j] : 1.0;
+    const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
+    const double pi_j = real ? m.pi[j] : 0.0;
+    double v = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+        double p;
+        if constexpr (KIND == EMIT_GAUSS) {
+            const double o = static_cast<const double *>(obs_rm)[o0 + t];
+            const double d = (o - mu_j) / sg_j;
+            p = real ? cn_j * exp(-0.5 * d * d) : 0.0; // _gaussian.c:18-20
+            if ((__ballot(p != 0.0) & gmask) == 0ull)
+                p = real ? 1.0 : 0.0;
+        } else if constexpr (KIND == EMIT_DISC) {
+            const int sym = static_cast<const int32_t *>(obs_rm)[o0 + t];
+            p = real ? m.B[(int64_t)j * m.M + sym] : 0.0;
+        } else {
+            p = real ? static_cast<const double *>(obs_rm)[(o0 + t) * n + j] : 0.0;
+        }
+        double vn;
+        if (t == 0) {
+            vn = p * pi_j; // _hidden.c:232
+        } else {
+            xv[gi][j] = v;
+            double bh = xv[gi][0] * Acol[0], bv = xv[gi][0], bA = Acol[0];
+            int bi = 0;
+#pragma unroll
+            for (int i = 1; i < NP; ++i) {
+                const double vi = xv[gi][i];
+                const double h = vi * Acol[i]; // _hidden.c:249
+                if (h > bh) {                  // strict: first maximum wins
+                    bh = h;
+                    bv = vi;
+                    bA = Acol[i];
+                    bi = i;
+                }
+            }
+            if (real)
+                ptr[(o0 + t) * n + j] = (uint8_t)bi;
+            vn = p * bv * bA; // _hidden.c:253
+        }
+        xn[gi][j] = vn;
+        double S = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            S += xn[gi][i]; // ascending order; padded states add exact zeros
+        v = vn / S;
+    }
+    xv[gi][j] = v;
+    if (j == 0) {
+        double bm = xv[gi][0];
+        int bi = 0;
+        for (int i = 1; i < n; ++i)
+            if (xv[gi][i] > bm) {
+                bm = xv[gi][i];
+                bi = i;
+            }
+        last_state[k] = bi;
+    }
+}
+
+// back-trace: one wavefront per trajectory stages 64 steps of back-pointers in LDS
+// (coalesced), lane 0 chases them (_hidden.c:269-272)
+__global__ __launch_bounds__(64) void k_wide_viterbi_trace(const int64_t *off, int K, int n,
+                                                           const uint8_t *ptr,
+                                                           const int32_t *last_state,
+                                                           int32_t *path)
+{
+    __shared__ uint8_t tile[64 * 64];
+    __shared__ int32_t outp[64];
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t o0 = off[k];
+    const int64_t T = off[k + 1] - o0;
+    if (T <= 0)
+        return;
+    int cur = last_state[k];
+    if (lane == 0)
+        path[o0 + T - 1] = cur;
+    // steps t = hi .. lo (descending) use ptr[t] to produce path[t-1]
+    for (int64_t hi = T - 1; hi >= 1; hi -= 64) {
+        const int64_t lo = (hi - 63 > 1) ? hi - 63 : 1;
+        const int cnt = (int)(hi - lo + 1);
+        const int64_t base = (o0 + lo) * n;
+        for (int e = lane; e < cnt * n; e += 64)
+            tile[e] = ptr[base + e];
+        __syncthreads();
+        if (lane == 0) {
+            for (int q = cnt - 1; q >= 0; --q) {
+                cur = tile[q * n + cur];
+                outp[q] = cur; // path[lo + q - 1]
+            }
+        }
+        __syncthreads();
+        if (lane < cnt)
+            path[o0 + lo + lane - 1] = outp[lane];
+        cur = outp[0];
+        __syncthreads();
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(64) void k_wide_sample_path(const WideModel m, const int64_t *off,
+                                                         int K, const double *alpha_rm,
+                                                         const double *u, uint64_t seed,
+                                                         int32_t *path, int *status)
+{
+    constexpr int GP = 64 / NP;
+    __shared__ __attribute__((aligned(16))) double xs[GP][NP];
+    const int lane = threadIdx.x;
+    const int gi = lane / NP, i = lane % NP;
+    const int k = blockIdx.x * GP + gi;
+    if (k >= K)
+        return;
+    const int n = m.n;
+    const bool real = i < n;
+    const int64_t o0 = off[k];
+    const int64_t T = off[k + 1] - o0;
+    if (T <= 0)
+        return;
+    int nxt = 0;
+    for (int64_t t = T - 1; t >= 0; --t) {
+        const double a = real ? alpha_rm[(o0 + t) * n + i] : 0.0;
+        double ps = a;
+        if (t != T - 1)
+            ps = real ? a * m.A[(int64_t)i * n + nxt] : 0.0; // _hidden.c:365
+        xs[gi][i] = ps;
+        double S = 0.0;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            S += xs[gi][q]; // _normalize, ascending
+        const double pn = ps / S;
+        xs[gi][i] = pn;
+        const double r = u ? u[o0 + t] : uniform01(seed, (uint64_t)(o0 + t));
+        double acc = 0.0;
+        int pick = -1;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            acc += xs[gi][q];
+            if (pick < 0 && q < n && acc >= r)
+                pick = q;
+        }
+        if (pick < 0) {
+            if (i == 0)
+                status[0] = BHMM_ERR_CHOICE;
+            pick = n - 1;
+        }
+        nxt = pick;
+        if (i == 0)
+            path[o0 + t] = pick;
+    }
+}
+
+// hidden-path statistics for 9..64 states: one workgroup per trajectory; integer counts in
+// LDS (exact), per-state emission sums through LDS fp64 atomics.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_wide_path_stats(const WideModel m, const int64_t *off,
+                                                         const void *obs_rm, const int32_t *path,
+                                                         unsigned long long *counts, // [n*n+n]
+                                                         double *epart)             // [K][esz]
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = m.n;
+    const int esz = (KIND == EMIT_GAUSS) ? 3 * n : (KIND == EMIT_DISC ? n * m.M : 0);
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(lds + esz);
+    for (int e = threadIdx.x; e < esz; e += blockDim.x)
+        lds[e] = 0.0;
+    for (int e = threadIdx.x; e < n * n + n; e += blockDim.x)
+        cnt[e] = 0u;
+    __syncthreads();
+    const int k = blockIdx.x;
+    const int64_t o0 = off[k];
+    const int64_t T = off[k + 1] - o0;
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+        const int st = path[o0 + t];
+        if (t == 0)
+            atomicAdd(&cnt[n * n + st], 1u);
+        if (t + 1 < T)
+            atomicAdd(&cnt[st * n + path[o0 + t + 1]], 1u);
+        if constexpr (KIND == EMIT_GAUSS) {
+            const double d = static_cast<const double *>(obs_rm)[o0 + t] - m.mu[st];
+            atomicAdd(&lds[st], 1.0);
+            atomicAdd(&lds[n + st], d);
+            atomicAdd(&lds[2 * n + st], d * d);
+        }
+        if constexpr (KIND == EMIT_DISC)
+            atomicAdd(&lds[(int64_t)st * m.M + static_cast<const int32_t *>(obs_rm)[o0 + t]], 1.0);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * n + n; e += blockDim.x)
+        if (cnt[e])
+            atomicAdd(&counts[e], (unsigned long long)cnt[e]);
+    for (int e = threadIdx.x; e < esz; e += blockDim.x)
+        epart[(int64_t)k * esz + e] = lds[e];
 }
 
 } // namespace bhmm

@@ -93,6 +93,12 @@ static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, bool store_gamma, do
      : (c)->N == 32 ? fn<32, KIND>(__VA_ARGS__)                       \
                     : fn<64, KIND>(__VA_ARGS__))
 
+int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, const double *par0,
+                   const double *par1, WideModel &m)
+{
+    return wide_model(c, kind, A, pi, par0, par1, m);
+}
+
 int wide_alloc(bhmm_ctx *c)
 {
     const int n = c->n;

@@ -92,3 +92,82 @@ def test_hidden_api_wide(n):
                                rtol=1e-9, atol=1e-300)
     np.testing.assert_allclose(hidden.transition_counts(alpha, beta, A, pobs),
                                orc.transition_counts(a_ref, b_ref, A, pobs), rtol=1e-9, atol=1e-12)
+
+
+def test_wide_viterbi_bit_exact(golden):
+    import bhmm_amd.hidden as hidden
+    from bhmm_amd.engine import Engine
+    g = golden("g64")
+    pobs = orc.pobs_gaussian(g["obs"], g["mu"], g["sigma"])
+    assert np.array_equal(hidden.viterbi(g["A"], pobs, g["pi"]), g["viterbi"])
+    rng = np.random.default_rng(77)
+    for n in (9, 16, 20, 33, 64):
+        A, pi, B, _ = _random_model(n, rng, "discrete", 25)
+        for T in (1, 2, 63, 64, 65, 129, 1000):
+            o = rng.integers(0, 25, T).astype(np.int32)
+            pobs = orc.pobs_discrete(o, B)
+            assert np.array_equal(hidden.viterbi(A, pobs, pi), orc.viterbi(A, pobs, pi)), (n, T)
+    # ties: first maximum wins
+    A = np.full((12, 12), 1.0 / 12)
+    assert np.array_equal(hidden.viterbi(A, np.full((200, 12), 0.5), np.full(12, 1.0 / 12)),
+                          orc.viterbi(A, np.full((200, 12), 0.5), np.full(12, 1.0 / 12)))
+    # batched, fused emissions
+    n, M = 24, 25
+    A, pi, B, _ = _random_model(n, rng, "discrete", M)
+    obs = [rng.integers(0, M, T).astype(np.int32) for T in (500, 1, 130)]
+    eng = Engine(0)
+    eng.set_observations("discrete", obs, n, nsymbols=M)
+    for p, o in zip(eng.viterbi(A, pi, B), obs):
+        assert np.array_equal(p, orc.viterbi(A, orc.pobs_discrete(o, B), pi))
+    eng.close()
+    A, pi, mu, sig = _random_model(64, rng, "gaussian")
+    obs = [rng.normal(0, 4, T) for T in (800, 70)]
+    eng = Engine(0)
+    eng.set_observations("gaussian", obs, 64)
+    for p, o in zip(eng.viterbi(A, pi, mu, sig), obs):
+        assert np.array_equal(p, orc.viterbi(A, orc.pobs_gaussian(o, mu, sig), pi))
+    eng.close()
+
+
+def test_wide_path_sampling():
+    import bhmm_amd.hidden as hidden
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(5)
+    for n in (10, 32, 50):
+        A = rng.dirichlet(np.ones(n), n)
+        alpha = rng.dirichlet(np.ones(n), 700)
+        u = rng.random(700)
+        assert np.array_equal(hidden.sample_path(alpha, A, np.ones((700, n)), u=u),
+                              orc.sample_path(alpha, A, u=u))
+    n, M = 20, 15
+    A, pi, B, _ = _random_model(n, rng, "discrete", M)
+    obs = [rng.integers(0, M, T).astype(np.int32) for T in (600, 1, 77)]
+    u = [rng.random(len(o)) for o in obs]
+    eng = Engine(0)
+    eng.set_observations("discrete", obs, n, nsymbols=M)
+    paths, C, n0, emis = eng.sample_paths(A, pi, B, u=u)
+    ref = []
+    for o, uu in zip(obs, u):
+        _, al = orc.forward(A, orc.pobs_discrete(o, B), pi)
+        ref.append(orc.sample_path(al, A, u=uu))
+    assert sum(int((p != r).sum()) for p, r in zip(paths, ref)) == 0
+    Cr, n0r = orc.path_counts(ref, n)
+    assert np.array_equal(C, Cr) and np.array_equal(n0, n0r)
+    cnt = np.zeros((n, M))
+    np.add.at(cnt, (np.concatenate(ref), np.concatenate(obs)), 1.0)
+    assert np.array_equal(emis, cnt)
+    eng.close()
+    A, pi, mu, sig = _random_model(12, rng, "gaussian")
+    obs = [rng.normal(0, 4, T) for T in (400, 90)]
+    eng = Engine(0)
+    eng.set_observations("gaussian", obs, 12)
+    paths, C, n0, emis = eng.sample_paths(A, pi, mu, sig, seed=3)
+    allp, allo = np.concatenate(paths), np.concatenate(obs)
+    Cr, n0r = orc.path_counts(paths, 12)
+    assert np.array_equal(C, Cr) and np.array_equal(n0, n0r)
+    for i in range(12):
+        sel = allo[allp == i]
+        assert emis[0, i] == len(sel)
+        np.testing.assert_allclose(emis[1, i], (sel - mu[i]).sum(), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(emis[2, i], ((sel - mu[i]) ** 2).sum(), rtol=1e-9, atol=1e-9)
+    eng.close()
