@@ -161,12 +161,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # launched by torch.distributed.run (even with one rank): bring up RCCL
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if distributed:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     K, T = args.ntraj, args.length
@@ -185,7 +188,7 @@ def main():
     def one_step():
         eng.estep_launch(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"],
                          stats_dev=stats.data_ptr())
-        if world > 1:
+        if distributed:
             dist.all_reduce(stats)                      # RCCL sum of the packed statistics
         host_stats.copy_(stats, non_blocking=True)
         stream.synchronize()                            # statistics are on the host
@@ -193,7 +196,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -208,7 +211,7 @@ def main():
         kern_ms += [eng.kernel_ms(i) for i in range(5)]
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -270,7 +273,7 @@ def main():
             out["cpu_baseline"] = cb
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 
