@@ -110,18 +110,17 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     if (rc)
         return rc;
     const int K = c->K, n = c->n;
-    if ((rc = c->d_alpha_rm.ensure((size_t)c->total * n)))
-        return rc;
-    if ((rc = unpack_ws_rows(c, c->d_alpha_rm.p)))
-        return rc;
     const size_t nstat = (size_t)N * N + N;
     const int nblk = c->Gp / BLOCK;
     const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)N : (c->kind == EMIT_DISC ? (size_t)c->M * N : 0);
-    // scratch2: path | status ; scratch: counts | emission partials | reduced emission | u
-    if ((rc = c->d_scratch2.ensure(((size_t)c->total + 4) * sizeof(int32_t))))
+    // scratch2: path | status | chunk maps | next-chunk states
+    if ((rc = c->d_scratch2.ensure(((size_t)c->total + 4 + 2 * (size_t)c->Gp) * sizeof(int32_t))))
         return rc;
     int32_t *path = reinterpret_cast<int32_t *>(c->d_scratch2.p);
     int *status = reinterpret_cast<int *>(path + c->total);
+    uint32_t *fmap = reinterpret_cast<uint32_t *>(status + 4);
+    int32_t *nstate = reinterpret_cast<int32_t *>(fmap + c->Gp);
+    // scratch: counts | emission partials | reduced emission | u
     const size_t dbl = nstat + (size_t)nblk * esz + esz + (u ? (size_t)c->total : 0) + 8;
     if ((rc = c->d_scratch.ensure(dbl * sizeof(double))))
         return rc;
@@ -140,11 +139,21 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipMemsetAsync(ered, 0, esz * sizeof(double), c->stream));
     Model<N> m;
     fill_model_pub<N>(m, n, c->kind, c->M, A, pi, par0, par1);
-    constexpr int GP = 64 / N;
-    hipLaunchKernelGGL((k_sample_path<N>), dim3((K + GP - 1) / GP), dim3(64), 0, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, K, (const double *)c->d_alpha_rm.p,
-                       (const double *)udev, seed, path, status);
-    BHMM_HIP(hipGetLastError());
+    {
+        // exact chunk-parallel sampling: maps per chunk, stitch, apply (path_kernels.hpp)
+        const Chunks chs = chunks_pub(c);
+        const int64_t *offd = c->d_offsets.p;
+        hipLaunchKernelGGL((k_smp_maps<N>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd,
+                           (const double *)c->d_ws.p, (const double *)udev, seed, fmap, status);
+        BHMM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_smp_stitch, dim3((K + 255) / 256), dim3(256), 0, c->stream,
+                           (const int32_t *)c->d_traj_c0.p, K, (const uint32_t *)fmap, nstate);
+        BHMM_HIP(hipGetLastError());
+        hipLaunchKernelGGL((k_smp_apply<N>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd,
+                           (const double *)c->d_ws.p, (const double *)udev, seed,
+                           (const int32_t *)nstate, path, status);
+        BHMM_HIP(hipGetLastError());
+    }
     if (counts || n0 || emis) {
         const Chunks ch = chunks_pub(c);
         const void *obs = c->d_obs_rm.p;
@@ -213,7 +222,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     int rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m);
     if (rc)
         return rc;
-    const int K = c->K, n = c->n, NP = c->N, GP = 64 / NP;
+    const int K = c->K, n = c->n, NP = c->wide ? c->N : 8, GP = 64 / NP;
     if ((rc = c->d_scratch.ensure((size_t)c->total * n)) ||
         (rc = c->d_scratch2.ensure(((size_t)c->total + K) * sizeof(int32_t))))
         return rc;
@@ -235,7 +244,9 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         else                                              \
             BHMM_WV(NPV, EMIT_EXPL);                      \
     } while (0)
-    if (NP == 16)
+    if (NP == 8)
+        BHMM_WV_KIND(8);
+    else if (NP == 16)
         BHMM_WV_KIND(16);
     else if (NP == 32)
         BHMM_WV_KIND(32);
@@ -378,8 +389,9 @@ int bhmm_viterbi_batch(bhmm_ctx *c, const double *A, const double *pi, const dou
     if (c->kind == BHMM_EMIT_DISCRETE && !par0)
         return invalid_arg("discrete emissions need B");
     BHMM_HIP(hipSetDevice(c->device));
-    if (c->wide)
-        return wide_viterbi_run(c, A, pi, par0, par1, paths);
+    // all state counts use the LDS-exchange kernels (k_wide_viterbi_*): for N <= 8 they are
+    // ~3x faster than the shuffle-based k_viterbi_fwd (serial chain, latency bound)
+    return wide_viterbi_run(c, A, pi, par0, par1, paths);
     switch (c->N) {
     case 2:
         return viterbi_run<2>(c, A, pi, par0, par1, paths);

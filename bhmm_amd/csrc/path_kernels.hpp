@@ -238,6 +238,157 @@ __global__ __launch_bounds__(64) void k_sample_path(const Model<N> m, const int6
     }
 }
 
+// =========================================================================================
+// Chunk-parallel backward path sampling (batched Gibbs step), exact given the uniforms.
+//
+// For fixed uniforms the reference's draw at step t is a map of the next state,
+//   g_t(j) = first i with  cumsum_i( alpha_t[.] A[., j] / sum ) >= u_t      (_hidden.c:359-372)
+// (a constant map at t = T-1, :347-355).  Maps compose exactly, so the chunks of the E-step
+// decomposition are processed independently:
+//   k_smp_maps   : per chunk, F_c = g_{t0} o ... o g_{t1-1} as 8 nibbles (state at the first
+//                  step of the NEXT chunk -> state at t0).  All 8 images are tracked until they
+//                  coalesce (they usually do within a few steps), then a single image.
+//   k_smp_stitch : per trajectory, backwards over chunks: the state each chunk starts from.
+//   k_smp_apply  : per chunk, re-walk with the known start state and emit the path.
+// One draw is decided on the unnormalised partial sums (c_i >= u*S) when the margin exceeds
+// 1e-13*S -- 50x the worst-case rounding difference to the reference's normalise-then-cumsum
+// arithmetic -- and falls back to exactly that arithmetic (IEEE division, ascending sums)
+// otherwise, so the sampled path is identical to the reference's for the same uniforms.
+// =========================================================================================
+template <int N>
+__device__ __forceinline__ int pick_state(const double (&a)[N], const double *col, double r, int n,
+                                          int *status)
+{
+    double ps[N], c[N], S = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ps[i] = col ? a[i] * col[i] : a[i]; // _hidden.c:349 / :365
+        S += ps[i];                         // ascending: S is bit-identical to _normalize's sum
+        c[i] = S;
+    }
+    const double t = r * S, tol = 1e-13 * S;
+    int pick = -1;
+    bool amb = !(S > 0.0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double d = c[i] - t;
+        const bool in = i < n;
+        amb |= in && (fabs(d) <= tol);
+        if (pick < 0 && in && d >= 0.0)
+            pick = i;
+    }
+    if (amb) { // the reference's own arithmetic (_normalize + _random_choice)
+        double acc = 0.0;
+        pick = -1;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            acc += ps[i] / S;
+            if (pick < 0 && i < n && acc >= r)
+                pick = i;
+        }
+    }
+    if (pick < 0) {
+        *status = BHMM_ERR_CHOICE;
+        pick = n - 1;
+    }
+    return pick;
+}
+
+template <int N>
+__device__ __forceinline__ void stage_At(double *sAt, const Model<N> &m)
+{
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x)
+        sAt[(e % N) * N + e / N] = m.A[e]; // sAt[j][i] = A[i][j]
+    __syncthreads();
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks ch,
+                                                  const int64_t *off, const double *alpha_ci,
+                                                  const double *u, uint64_t seed, uint32_t *Fmap,
+                                                  int *status)
+{
+    __shared__ __attribute__((aligned(16))) double sAt[N * N];
+    stage_At<N>(sAt, m);
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int len = ch.len[g];
+    if (len == 0)
+        return;
+    const int k = ch.traj[g];
+    const int64_t t0 = ch.t0[g], base = ch.goff[g];
+    const int64_t Tk = off[k + 1] - off[k];
+    const int n = m.nreal;
+    uint32_t cur = 0x76543210u; // nibble j = image of next-chunk state j (identity)
+    for (int s = len - 1; s >= 0; --s) {
+        double a[N];
+        ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
+        const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
+        const bool last = (t0 + s == Tk - 1);
+        const uint32_t c0 = cur & 7u;
+        if (cur == c0 * 0x11111111u || last) { // coalesced (or constant map): one image
+            const int x = pick_state<N>(a, last ? nullptr : sAt + c0 * N, r, n, status);
+            cur = (uint32_t)x * 0x11111111u;
+        } else {
+            uint32_t G = 0;
+#pragma unroll
+            for (int x = 0; x < N; ++x)
+                if (x < n) // padded (inert) states are never a next state
+                    G |= (uint32_t)pick_state<N>(a, sAt + x * N, r, n, status) << (4 * x);
+            uint32_t nw = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                nw |= ((G >> (4 * ((cur >> (4 * j)) & 7u))) & 7u) << (4 * j);
+            cur = nw;
+        }
+    }
+    Fmap[g] = cur;
+}
+
+// state at the first step of the NEXT chunk, for every chunk (0 for a trajectory's last chunk,
+// whose map is constant)
+static __global__ void k_smp_stitch(const int32_t *traj_c0, int K, const uint32_t *Fmap,
+                                    int32_t *next_state)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K)
+        return;
+    uint32_t x = 0;
+    for (int c = traj_c0[k + 1] - 1; c >= traj_c0[k]; --c) {
+        next_state[c] = (int32_t)x;
+        x = (Fmap[c] >> (4 * x)) & 7u;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunks ch,
+                                                   const int64_t *off, const double *alpha_ci,
+                                                   const double *u, uint64_t seed,
+                                                   const int32_t *next_state, int32_t *path,
+                                                   int *status)
+{
+    __shared__ __attribute__((aligned(16))) double sAt[N * N];
+    stage_At<N>(sAt, m);
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int len = ch.len[g];
+    if (len == 0)
+        return;
+    const int k = ch.traj[g];
+    const int64_t t0 = ch.t0[g], base = ch.goff[g];
+    const int64_t Tk = off[k + 1] - off[k];
+    const int n = m.nreal;
+    int nxt = next_state[g];
+    for (int s = len - 1; s >= 0; --s) {
+        double a[N];
+        ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
+        const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
+        const bool last = (t0 + s == Tk - 1);
+        nxt = pick_state<N>(a, last ? nullptr : sAt + nxt * N, r, n, status);
+        path[base + s] = nxt;
+    }
+}
+
 // ---- small reference-shaped kernels on row-major arrays ------------------------------------
 // gamma_t = alpha_t o beta_t / sum (hidden/api.py:176-186); one thread per time step.
 __global__ void k_gamma_rows(const double *alpha, const double *beta, double *gamma, int n,

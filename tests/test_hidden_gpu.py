@@ -248,3 +248,31 @@ def test_output_model_kernels(golden):
     pout = np.zeros((8, 64))
     _lib.check(L.bhmm_update_pout(_lib.dp(pout), _lib.ip(obs), _lib.dp(w), 5000, 8, 64))
     np.testing.assert_allclose(pout, orc.update_pout(obs, w, np.zeros((8, 64))), rtol=1e-11)
+
+
+def test_batched_sampling_exact_on_ties():
+    """Uniforms that hit CDF steps exactly (margin 0): the chunk-parallel sampler must take the
+    reference's normalise-then-cumsum fallback and reproduce its choice."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(12)
+    for n in (2, 4, 8):
+        A = np.full((n, n), 1.0 / n)                       # dyadic everywhere
+        B = np.full((n, 4), 0.25)
+        pi = np.full(n, 1.0 / n)
+        obs = [rng.integers(0, 4, T).astype(np.int32) for T in (257, 31, 1)]
+        u = [rng.integers(0, 2 * n, len(o)) / (2.0 * n) for o in obs]   # exact multiples of 1/(2n)
+        eng = Engine(0)
+        eng.set_observations("discrete", obs, n, nsymbols=4, chunk=16)
+        paths, C, n0, _ = eng.sample_paths(A, pi, B, u=u)
+        for p, o, uu in zip(paths, obs, u):
+            _, alpha = orc.forward(A, orc.pobs_discrete(o, B), pi)
+            assert np.array_equal(p, orc.sample_path(alpha, A, u=uu))
+        eng.close()
+    # impossible draw (u >= 1 can never be reached): reported, not fatal (_hidden.c:299-304)
+    eng = Engine(0)
+    eng.set_observations("discrete", [obs[0]], 8, nsymbols=4)
+    from bhmm_amd import _lib
+    with pytest.raises(_lib.BhmmAmdError):
+        eng.sample_paths(np.full((8, 8), 0.125), np.full(8, 0.125), np.full((8, 4), 0.25),
+                         u=[np.full(len(obs[0]), 1.5)])
+    eng.close()
