@@ -69,11 +69,34 @@ struct Runner {
         BHMM_HIP(hipGetLastError());
         BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
         const int gp = 64 / N;
-        const int nb = (c->K + gp - 1) / gp;
-        hipLaunchKernelGGL((k_stitch<N>), dim3(2 * nb), dim3(64), 0, c->stream,
-                           (const int32_t *)c->d_traj_c0.p, c->K, nb, c->n,
-                           (const double *)c->d_M.p, c->d_aentry.p, c->d_bexit.p);
-        BHMM_HIP(hipGetLastError());
+        if (c->nG == 0) {
+            // one level: every trajectory stitched serially over its chunks
+            const int nb = (c->K + gp - 1) / gp;
+            hipLaunchKernelGGL((k_stitch<N>), dim3(2 * nb), dim3(64), 0, c->stream,
+                               (const int32_t *)c->d_traj_c0.p, (const int32_t *)c->d_traj_c0.p + 1,
+                               c->K, nb, c->n, (const double *)c->d_M.p, (const double *)nullptr,
+                               (const double *)nullptr, c->d_aentry.p, c->d_bexit.p);
+            BHMM_HIP(hipGetLastError());
+        } else {
+            // two levels: group products, stitch over groups, stitch inside all groups
+            const int ngb = (c->nG + gp - 1) / gp;
+            hipLaunchKernelGGL((k_compose<N>), dim3(ngb), dim3(64), 0, c->stream,
+                               (const int32_t *)c->d_grp_c0.p, (const int32_t *)c->d_grp_c1.p, c->nG,
+                               (const double *)c->d_M.p, c->d_P.p);
+            BHMM_HIP(hipGetLastError());
+            const int nb = (c->K + gp - 1) / gp;
+            hipLaunchKernelGGL((k_stitch<N>), dim3(2 * nb), dim3(64), 0, c->stream,
+                               (const int32_t *)c->d_grp_traj0.p,
+                               (const int32_t *)c->d_grp_traj0.p + 1, c->K, nb, c->n,
+                               (const double *)c->d_P.p, (const double *)nullptr,
+                               (const double *)nullptr, c->d_agrp.p, c->d_bgrp.p);
+            BHMM_HIP(hipGetLastError());
+            hipLaunchKernelGGL((k_stitch<N>), dim3(2 * ngb), dim3(64), 0, c->stream,
+                               (const int32_t *)c->d_grp_c0.p, (const int32_t *)c->d_grp_c1.p, c->nG,
+                               ngb, c->n, (const double *)c->d_M.p, (const double *)c->d_agrp.p,
+                               (const double *)c->d_bgrp.p, c->d_aentry.p, c->d_bexit.p);
+            BHMM_HIP(hipGetLastError());
+        }
         BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
         return BHMM_OK;
     }
@@ -264,6 +287,34 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
         return rc;
     BHMM_HIP(hipMemcpy(c->d_offsets.p, c->offsets.data(), (K + 1) * sizeof(int64_t),
                        hipMemcpyHostToDevice));
+    // two-level stitch: groups of R consecutive chunks; serial depth 2R + n/R instead of n
+    int nmax = 0;
+    for (int k = 0; k < K; ++k)
+        nmax = std::max(nmax, c->traj_c0[k + 1] - c->traj_c0[k]);
+    c->nG = 0;
+    if (nmax > 48) {
+        const int R = std::max(4, std::min(256, (int)lround(sqrt(0.5 * nmax))));
+        std::vector<int32_t> g0, g1, gt(K + 1, 0);
+        for (int k = 0; k < K; ++k) {
+            gt[k] = (int32_t)g0.size();
+            for (int cc = c->traj_c0[k]; cc < c->traj_c0[k + 1]; cc += R) {
+                g0.push_back(cc);
+                g1.push_back(std::min(cc + R, c->traj_c0[k + 1]));
+            }
+        }
+        gt[K] = (int32_t)g0.size();
+        c->nG = (int)g0.size();
+        const size_t MSz = (size_t)c->N * c->N + c->N;
+        if ((rc = c->d_grp_c0.ensure(c->nG)) || (rc = c->d_grp_c1.ensure(c->nG)) ||
+            (rc = c->d_grp_traj0.ensure(K + 1)) || (rc = c->d_P.ensure((size_t)c->nG * MSz)) ||
+            (rc = c->d_agrp.ensure((size_t)c->nG * c->N)) ||
+            (rc = c->d_bgrp.ensure((size_t)c->nG * c->N)))
+            return rc;
+        BHMM_HIP(hipMemcpy(c->d_grp_c0.p, g0.data(), c->nG * sizeof(int32_t), hipMemcpyHostToDevice));
+        BHMM_HIP(hipMemcpy(c->d_grp_c1.p, g1.data(), c->nG * sizeof(int32_t), hipMemcpyHostToDevice));
+        BHMM_HIP(hipMemcpy(c->d_grp_traj0.p, gt.data(), (K + 1) * sizeof(int32_t),
+                           hipMemcpyHostToDevice));
+    }
     return BHMM_OK;
 }
 
@@ -458,6 +509,12 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     c->d_Brm.release();
     c->d_alpha_rm.release();
     c->d_wmodel.release();
+    c->d_grp_c0.release();
+    c->d_grp_c1.release();
+    c->d_grp_traj0.release();
+    c->d_P.release();
+    c->d_agrp.release();
+    c->d_bgrp.release();
     if (c->h_pinned)
         (void)hipHostFree(c->h_pinned);
     for (auto &ev : c->ev)

@@ -84,6 +84,10 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_Brm;      // [n][M] emission matrix, row-major (path kernels)
     bhmm::DevBuf<double> d_alpha_rm; // [total][n] alpha, trajectory-major (path sampling)
     bhmm::DevBuf<double> d_wmodel;   // model parameters of the 9..64-state family
+    // two-level stitch: groups of consecutive chunks (empty when every trajectory is short)
+    int nG = 0;
+    bhmm::DevBuf<int32_t> d_grp_c0, d_grp_c1, d_grp_traj0; // [nG], [nG], [K+1]
+    bhmm::DevBuf<double> d_P, d_agrp, d_bgrp;              // group products / boundary vectors
     bool wide = false;               // nstates > 8: wide_kernels.hpp family
     double *h_pinned = nullptr;      // stats + logL_k landing zone
     size_t h_pinned_n = 0;

@@ -317,6 +317,66 @@ __global__ __launch_bounds__(64 * N) void k_prescan(const Model<N> m, const Chun
 }
 
 // =========================================================================================
+// k_compose: product of the transfer matrices of one group of consecutive chunks,
+//   P_g = M_{c0} M_{c0+1} ... M_{c1-1},  same storage format as M (rows power-of-two
+// normalised, exponents separate).  N lanes per group, lane r carries row r of the running
+// product.  It makes k_stitch two-level: groups are stitched first (serial depth n/R), then
+// the chunks inside every group in parallel (depth R) -- instead of depth n.
+// =========================================================================================
+template <int N>
+__global__ __launch_bounds__(64) void k_compose(const int32_t *grp_c0, const int32_t *grp_c1,
+                                                int nG, const double *Mbuf, double *Pbuf)
+{
+    constexpr int GP = 64 / N;
+    constexpr int MS = N * N + N;
+    constexpr int NEG = -(1 << 28);
+    const int gidx = (int)blockIdx.x * GP + (int)threadIdx.x / N;
+    const int r = threadIdx.x % N;
+    if (gidx >= nG)
+        return;
+    const int c0 = grp_c0[gidx], c1 = grp_c1[gidx];
+    double row[N];
+    int ex = 0;
+    {
+        const double *src = Mbuf + (int64_t)c0 * MS;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            row[j] = src[r * N + j];
+        ex = (int)src[N * N + r];
+    }
+    for (int c = c0 + 1; c < c1; ++c) {
+        const double *src = Mbuf + (int64_t)c * MS;
+        // weights w_k = row[k] * 2^(e_c[k] - E): align the exponents of the rows of M_c
+        int ek[N], E = NEG;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            ek[k] = (int)src[N * N + k];
+            if (row[k] > 0.0)
+                E = max(E, ek[k] + exponent_of(row[k]));
+        }
+        double w[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            w[k] = ldexp(row[k], ek[k] - E);
+        double nr[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double acc = w[0] * src[j];
+#pragma unroll
+            for (int k = 1; k < N; ++k)
+                acc = fma(w[k], src[k * N + j], acc);
+            nr[j] = acc;
+        }
+        ex += (E == NEG ? 0 : E) + renorm_row<N>(nr, row);
+    }
+    double *out = Pbuf + (int64_t)gidx * MS;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        out[r * N + j] = row[j];
+    out[N * N + r] = (double)ex;
+}
+
+// =========================================================================================
 // k_stitch: exact chunk-boundary vectors.  N lanes cooperate on one (trajectory,
 // direction); lane r holds row r of the current transfer matrix.
 //   forward : alpha_entry[c] ~ alpha at the step before chunk c
@@ -329,9 +389,10 @@ __global__ __launch_bounds__(64 * N) void k_prescan(const Model<N> m, const Chun
 // Blocks [0, nb) run the forward direction, [nb, 2 nb) the backward one.
 // =========================================================================================
 template <int N>
-__global__ __launch_bounds__(64) void k_stitch(const int32_t *traj_c0, int K, int nb, int nreal,
-                                               const double *Mbuf, double *alpha_entry,
-                                               double *beta_exit)
+__global__ __launch_bounds__(64) void k_stitch(const int32_t *seg_c0, const int32_t *seg_c1, int K,
+                                               int nb, int nreal, const double *Mbuf,
+                                               const double *a_init, const double *b_init,
+                                               double *alpha_entry, double *beta_exit)
 {
     constexpr int GP = 64 / N; // trajectories per block
     constexpr int MS = N * N + N;
@@ -342,7 +403,10 @@ __global__ __launch_bounds__(64) void k_stitch(const int32_t *traj_c0, int K, in
     const int r = threadIdx.x % N;
     if (k >= K)
         return;
-    const int c0 = traj_c0[k], c1 = traj_c0[k + 1];
+    // a segment is a run of consecutive chunks of one trajectory: the whole trajectory
+    // (a_init == nullptr), or one group of the two-level scheme (vectors at the group
+    // boundaries come from the group-level pass)
+    const int c0 = seg_c0[k], c1 = seg_c1[k];
     const int nc = c1 - c0;
 
     double rows[PD][N], er[PD];
@@ -366,7 +430,8 @@ __global__ __launch_bounds__(64) void k_stitch(const int32_t *traj_c0, int K, in
     };
 
     if (!bwd) {
-        double a = (r == 0) ? 1.0 : 0.0; // selects row 0 of the seeded first chunk
+        double a = a_init ? a_init[(int64_t)k * N + r]
+                          : ((r == 0) ? 1.0 : 0.0); // e_0 selects row 0 of the seeded first chunk
 #pragma unroll
         for (int u = 0; u < PD; ++u)
             if (u < nc)
@@ -416,7 +481,8 @@ __global__ __launch_bounds__(64) void k_stitch(const int32_t *traj_c0, int K, in
             }
         }
     } else {
-        double b = (r < nreal) ? 1.0 / (double)nreal : 0.0; // _hidden.c:79-88
+        double b = b_init ? b_init[(int64_t)k * N + r]
+                          : ((r < nreal) ? 1.0 / (double)nreal : 0.0); // _hidden.c:79-88
         // chunk c (> c0) is consumed when producing the exit vector of chunk c-1
 #pragma unroll
         for (int u = 0; u < PD; ++u)
