@@ -229,12 +229,17 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     uint8_t *ptr = reinterpret_cast<uint8_t *>(c->d_scratch.p);
     int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
     int32_t *path = last + K;
-    const dim3 grid((K + GP - 1) / GP), blk(64);
+    // U trajectories per lane group.  Measured on configs[1] (256 trajectories): the kernel is
+    // bound by the instruction stream of each wavefront, not by latency, and SIMDs are plentiful
+    // (32 of 1024 busy), so U = 1 is fastest (U = 4 was 3.5x slower); the parameter stays for
+    // batches with more trajectories than SIMD slots.
+    const int U = 1;
+    const dim3 grid((K + GP * U - 1) / (GP * U)), blk(64);
     const void *obs = c->d_obs_rm.p;
     const int64_t *off = c->d_offsets.p;
 #define BHMM_WV(NPV, KINDV)                                                                     \
-    hipLaunchKernelGGL((k_wide_viterbi_fwd<NPV, KINDV>), grid, blk, 0, c->stream, m, off, K, obs, \
-                       ptr, last)
+    hipLaunchKernelGGL((k_wide_viterbi_fwd<NPV, KINDV, 1>), grid,                                  \
+                       blk, 0, c->stream, m, off, K, obs, ptr, last)
 #define BHMM_WV_KIND(NPV)                                 \
     do {                                                  \
         if (c->kind == EMIT_GAUSS)                        \

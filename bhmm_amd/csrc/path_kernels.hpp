@@ -612,25 +612,26 @@ __global__ __launch_bounds__(256) void k_path_stats(const Model<N> m, const Chun
 // through LDS so that every lane can take the index-ordered sums the reference takes.
 // Back-pointers: one byte per (t, j), trajectory-major [T][n].
 // =========================================================================================
-template <int NP, int KIND>
+// U trajectories are advanced in lock-step by one lane group: the recursion of a single
+// trajectory is one long dependency chain (LDS exchange -> argmax -> LDS exchange -> ordered
+// sum -> IEEE division), so a wavefront alone on its SIMD is latency bound; U independent chains
+// interleave in the same instruction stream and hide each other's latencies.
+template <int NP, int KIND, int U>
 __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, const int64_t *off,
                                                          int K, const void *obs_rm,
                                                          uint8_t *ptr, int32_t *last_state)
 {
     constexpr int GP = 64 / NP;
-    __shared__ __attribute__((aligned(16))) double xv[GP][NP];
-    __shared__ __attribute__((aligned(16))) double xn[GP][NP];
+    constexpr int TL = NP < 16 ? NP : 16; // argmax tile
+    __shared__ __attribute__((aligned(16))) double xv[GP][U][NP];
+    __shared__ __attribute__((aligned(16))) double xn[GP][U][NP];
     const int lane = threadIdx.x;
     const int gi = lane / NP, j = lane % NP;
-    const int k = blockIdx.x * GP + gi;
-    if (k >= K)
+    const int kbase = (blockIdx.x * GP + gi) * U;
+    if (kbase >= K)
         return;
     const int n = m.n;
     const bool real = j < n;
-    const int64_t o0 = off[k];
-    const int64_t T = off[k + 1] - o0;
-    if (T <= 0)
-        return;
     const unsigned long long gmask = wgroup_mask<NP>(lane);
     double Acol[NP];
 #pragma unroll
@@ -640,60 +641,141 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
     const double sg_j = (KIND == EMIT_GAUSS && real) ? m.sigma[j] : 1.0;
     const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
     const double pi_j = real ? m.pi[j] : 0.0;
-    double v = 0.0;
-    for (int64_t t = 0; t < T; ++t) {
+    int64_t o0[U], T[U], Tmax = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = kbase + u;
+        o0[u] = (k < K) ? off[k] : 0;
+        T[u] = (k < K) ? off[k + 1] - off[k] : 0;
+        Tmax = T[u] > Tmax ? T[u] : Tmax;
+    }
+    // emission probability of my state at global step gt (+ outlier rule over the group)
+    auto emis = [&](int64_t gt) {
         double p;
         if constexpr (KIND == EMIT_GAUSS) {
-            const double o = static_cast<const double *>(obs_rm)[o0 + t];
+            const double o = static_cast<const double *>(obs_rm)[gt];
             const double d = (o - mu_j) / sg_j;
             p = real ? cn_j * exp(-0.5 * d * d) : 0.0; // _gaussian.c:18-20
             if ((__ballot(p != 0.0) & gmask) == 0ull)
                 p = real ? 1.0 : 0.0;
         } else if constexpr (KIND == EMIT_DISC) {
-            const int sym = static_cast<const int32_t *>(obs_rm)[o0 + t];
+            const int sym = static_cast<const int32_t *>(obs_rm)[gt];
             p = real ? m.B[(int64_t)j * m.M + sym] : 0.0;
         } else {
-            p = real ? static_cast<const double *>(obs_rm)[(o0 + t) * n + j] : 0.0;
+            p = real ? static_cast<const double *>(obs_rm)[gt * n + j] : 0.0;
         }
-        double vn;
-        if (t == 0) {
-            vn = p * pi_j; // _hidden.c:232
-        } else {
-            xv[gi][j] = v;
-            double bh = xv[gi][0] * Acol[0], bv = xv[gi][0], bA = Acol[0];
-            int bi = 0;
+        return p;
+    };
+    double v[U], p_next[U];
 #pragma unroll
-            for (int i = 1; i < NP; ++i) {
-                const double vi = xv[gi][i];
-                const double h = vi * Acol[i]; // _hidden.c:249
-                if (h > bh) {                  // strict: first maximum wins
-                    bh = h;
-                    bv = vi;
-                    bA = Acol[i];
-                    bi = i;
-                }
-            }
-            if (real)
-                ptr[(o0 + t) * n + j] = (uint8_t)bi;
-            vn = p * bv * bA; // _hidden.c:253
-        }
-        xn[gi][j] = vn;
-        double S = 0.0;
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-            S += xn[gi][i]; // ascending order; padded states add exact zeros
-        v = vn / S;
+    for (int u = 0; u < U; ++u) {
+        v[u] = 0.0;
+        p_next[u] = (T[u] > 0) ? emis(o0[u]) : 0.0;
     }
-    xv[gi][j] = v;
-    if (j == 0) {
-        double bm = xv[gi][0];
-        int bi = 0;
-        for (int i = 1; i < n; ++i)
-            if (xv[gi][i] > bm) {
-                bm = xv[gi][i];
-                bi = i;
+    for (int64_t t = 0; t < Tmax; ++t) {
+        double p[U], vn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            p[u] = p_next[u];
+            if (t + 1 < T[u])
+                p_next[u] = emis(o0[u] + t + 1); // independent of the recursion
+        }
+        if (t > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                xv[gi][u][j] = v[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (t == 0) {
+                vn[u] = p[u] * pi_j; // _hidden.c:232
+            } else {
+                // first-maximum argmax (_hidden.c:186-200) as a select tree per tile of <= 16
+                // states: the later candidate wins only if strictly greater, which is exactly
+                // the linear scan's result; tiles are folded in index order with the same rule
+                double bh = 0.0, bv = 0.0, bA = 0.0;
+                int bi = 0;
+#pragma unroll
+                for (int tl = 0; tl < NP; tl += TL) {
+                    double vv[TL], hh[TL], aa[TL];
+                    int ii[TL];
+#pragma unroll
+                    for (int i = 0; i < TL; i += 2) {
+                        const double2 x = *reinterpret_cast<const double2 *>(&xv[gi][u][tl + i]);
+                        vv[i] = x.x;
+                        vv[i + 1] = x.y;
+                    }
+#pragma unroll
+                    for (int i = 0; i < TL; ++i) {
+                        aa[i] = Acol[tl + i];
+                        hh[i] = vv[i] * aa[i]; // _hidden.c:249
+                        ii[i] = tl + i;
+                    }
+#define BHMM_ARGMAX_LEVEL(W)                                           \
+    if constexpr (TL > W) {                                            \
+        _Pragma("unroll") for (int i = 0; i + W < TL; i += 2 * W)      \
+        {                                                              \
+            const bool take = hh[i + W] > hh[i];                       \
+            hh[i] = take ? hh[i + W] : hh[i];                          \
+            vv[i] = take ? vv[i + W] : vv[i];                          \
+            aa[i] = take ? aa[i + W] : aa[i];                          \
+            ii[i] = take ? ii[i + W] : ii[i];                          \
+        }                                                              \
+    }
+                    BHMM_ARGMAX_LEVEL(1)
+                    BHMM_ARGMAX_LEVEL(2)
+                    BHMM_ARGMAX_LEVEL(4)
+                    BHMM_ARGMAX_LEVEL(8)
+#undef BHMM_ARGMAX_LEVEL
+                    const bool take = (tl == 0) || (hh[0] > bh);
+                    bh = take ? hh[0] : bh;
+                    bv = take ? vv[0] : bv;
+                    bA = take ? aa[0] : bA;
+                    bi = take ? ii[0] : bi;
+                }
+                if (real && t < T[u])
+                    ptr[(o0[u] + t) * n + j] = (uint8_t)bi;
+                vn[u] = p[u] * bv * bA; // _hidden.c:253
             }
-        last_state[k] = bi;
+            xn[gi][u][j] = vn[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double S = 0.0;
+#pragma unroll
+            for (int tl = 0; tl < NP; tl += TL) {
+                double xs[TL];
+#pragma unroll
+                for (int i = 0; i < TL; i += 2) {
+                    const double2 x = *reinterpret_cast<const double2 *>(&xn[gi][u][tl + i]);
+                    xs[i] = x.x;
+                    xs[i + 1] = x.y;
+                }
+#pragma unroll
+                for (int i = 0; i < TL; ++i)
+                    S += xs[i]; // ascending order; padded states add exact zeros
+            }
+            if (t < T[u]) // a finished trajectory keeps its final v
+                v[u] = vn[u] / S;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        xv[gi][u][j] = v[u];
+    if (j == 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kbase + u < K && T[u] > 0) {
+                double bm = xv[gi][u][0];
+                int bi = 0;
+                for (int i = 1; i < n; ++i)
+                    if (xv[gi][u][i] > bm) {
+                        bm = xv[gi][u][i];
+                        bi = i;
+                    }
+                last_state[kbase + u] = bi;
+            }
+        }
     }
 }
 
