@@ -237,14 +237,36 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     const dim3 grid((K + GP * U - 1) / (GP * U)), blk(64);
     const void *obs = c->d_obs_rm.p;
     const int64_t *off = c->d_offsets.p;
+    // emission probabilities in a separate, fully parallel pass when the (total, n) matrix
+    // fits (it is what the reference materialises anyway, maximum_likelihood.py:345-347)
+    int vkind = c->kind;
+    if (c->kind != EMIT_EXPL) {
+        size_t freeb = 0, totb = 0;
+        const size_t need = (size_t)c->total * n * sizeof(double);
+        if (hipMemGetInfo(&freeb, &totb) == hipSuccess && need + ((size_t)1 << 30) < freeb + c->d_alpha_rm.n * sizeof(double) &&
+            c->d_alpha_rm.ensure((size_t)c->total * n) == BHMM_OK) {
+            const dim3 pg((unsigned)((c->total + 255) / 256)), pb(256);
+            if (c->kind == EMIT_GAUSS)
+                hipLaunchKernelGGL((k_pobs_all<EMIT_GAUSS>), pg, pb, 0, c->stream, m, obs, c->total,
+                                   c->d_alpha_rm.p);
+            else
+                hipLaunchKernelGGL((k_pobs_all<EMIT_DISC>), pg, pb, 0, c->stream, m, obs, c->total,
+                                   c->d_alpha_rm.p);
+            BHMM_HIP(hipGetLastError());
+            obs = c->d_alpha_rm.p;
+            vkind = EMIT_EXPL;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
 #define BHMM_WV(NPV, KINDV)                                                                     \
     hipLaunchKernelGGL((k_wide_viterbi_fwd<NPV, KINDV, 1>), grid,                                  \
                        blk, 0, c->stream, m, off, K, obs, ptr, last)
 #define BHMM_WV_KIND(NPV)                                 \
     do {                                                  \
-        if (c->kind == EMIT_GAUSS)                        \
+        if (vkind == EMIT_GAUSS)                          \
             BHMM_WV(NPV, EMIT_GAUSS);                     \
-        else if (c->kind == EMIT_DISC)                    \
+        else if (vkind == EMIT_DISC)                      \
             BHMM_WV(NPV, EMIT_DISC);                      \
         else                                              \
             BHMM_WV(NPV, EMIT_EXPL);                      \

@@ -779,6 +779,36 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
     }
 }
 
+// Emission probabilities of all steps, row-major (total, n), fully parallel (one thread per
+// step): takes exp / division / table gathers out of the serial Viterbi recursion, whose time
+// is set by the length of its per-step instruction stream.  Same arithmetic as the fused form
+// (_gaussian.c:18-20 with true division, outputmodel.py:126-130).
+template <int KIND>
+__global__ void k_pobs_all(const WideModel m, const void *obs_rm, int64_t total, double *pobs)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total)
+        return;
+    const int n = m.n;
+    if constexpr (KIND == EMIT_GAUSS) {
+        const double o = static_cast<const double *>(obs_rm)[t];
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double d = (o - m.mu[j]) / m.sigma[j];
+            const double p = m.cnorm[j] * exp(-0.5 * d * d);
+            pobs[t * n + j] = p;
+            s = (p != 0.0) ? 1.0 : s;
+        }
+        if (s == 0.0)
+            for (int j = 0; j < n; ++j)
+                pobs[t * n + j] = 1.0;
+    } else {
+        const int sym = static_cast<const int32_t *>(obs_rm)[t];
+        for (int j = 0; j < n; ++j)
+            pobs[t * n + j] = m.B[(int64_t)j * m.M + sym];
+    }
+}
+
 // back-trace: one wavefront per trajectory stages 64 steps of back-pointers in LDS
 // (coalesced), lane 0 chases them (_hidden.c:269-272)
 __global__ __launch_bounds__(64) void k_wide_viterbi_trace(const int64_t *off, int K, int n,
