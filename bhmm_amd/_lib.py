@@ -68,6 +68,8 @@ SIGNATURES = {
     "bhmm_sample_paths": (ctypes.c_int, [c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                          c_double_p, ctypes.c_uint64, c_int32_p, c_int64_p,
                                          c_int64_p, c_double_p]),
+    "bhmm_ctx_set_option": (ctypes.c_int, [c_void_p, ctypes.c_char_p, ctypes.c_double]),
+    "bhmm_ctx_get_option": (ctypes.c_int, [c_void_p, ctypes.c_char_p, c_double_p]),
     "bhmm_ctx_total_steps": (ctypes.c_int64, [c_void_p]),
     "bhmm_ctx_num_chunks": (ctypes.c_int, [c_void_p]),
     "bhmm_ctx_chunk_len": (ctypes.c_int, [c_void_p]),

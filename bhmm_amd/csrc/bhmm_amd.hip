@@ -2,6 +2,7 @@
 // chunk planning, launches.  Host code only orchestrates; all arithmetic on trajectories is
 // in estep_kernels.hpp / path_kernels.hpp.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -101,18 +102,19 @@ struct Runner {
         return BHMM_OK;
     }
 
-    template <int KIND, int MODE>
+    template <int KIND, int MODE, bool SPEC = false>
     static int fwdbwd(bhmm_ctx *c, const Model<N> &m, bool store_gamma)
     {
         const Chunks ch = chunks_of(c);
         const int nblk = c->Gp / 64; // one workgroup per CI record group (64 chunks)
         const size_t sm = smem_fwdbwd<N, KIND>(c->M);
         if (sm > 64 * 1024)
-            BHMM_HIP(hipFuncSetAttribute((const void *)(k_fwdbwd<N, KIND, MODE>),
+            BHMM_HIP(hipFuncSetAttribute((const void *)(k_fwdbwd<N, KIND, MODE, SPEC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        hipLaunchKernelGGL((k_fwdbwd<N, KIND, MODE>), dim3(nblk), dim3(32 * N), sm, c->stream, m, ch,
-                           (const void *)c->d_obs_ci.p, (const double *)c->d_Bt.p,
-                           (const double *)c->d_aentry.p, (const double *)c->d_bexit.p, c->d_ws.p,
+        hipLaunchKernelGGL((k_fwdbwd<N, KIND, MODE, SPEC>), dim3(nblk), dim3(32 * N), sm, c->stream, m,
+                           ch, (const void *)c->d_obs_ci.p, (const double *)c->d_Bt.p,
+                           c->d_aentry.p, c->d_bexit.p, c->d_aexit.p, c->d_bentry.p, c->spec_W,
+                           c->d_ws.p,
                            store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
                            c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p);
         BHMM_HIP(hipGetLastError());
@@ -121,9 +123,84 @@ struct Runner {
     }
 
     template <int KIND>
+    static int finish(bhmm_ctx *c, const Model<N> &m, double *stats_dev)
+    {
+        hipLaunchKernelGGL(k_logl, dim3(c->K), dim3(64), 0, c->stream,
+                           (const int32_t *)c->d_traj_c0.p, c->K, (const double *)c->d_logLc.p,
+                           c->d_logLk.p);
+        BHMM_HIP(hipGetLastError());
+        const int nfin = StatLayout<N, KIND>::S + (KIND == EMIT_DISC ? c->M * N : 0) + N + 1;
+        hipLaunchKernelGGL((k_finalize<N, KIND>), dim3(nfin), dim3(64), 0, c->stream, m, c->K,
+                           c->Gp / 64, (const double *)c->d_partials.p,
+                           (const double *)c->d_dpartials.p, (const double *)c->d_logLk.p,
+                           (const double *)c->d_gamma0.p, stats_dev);
+        BHMM_HIP(hipGetLastError());
+        return BHMM_OK;
+    }
+
+    // Speculative E-step: no prescan / stitch; chunk boundaries from warm-ups, verified.
+    // Returns BHMM_OK with *verified = false when the caller has to run the exact pipeline.
+    template <int KIND>
+    static int estep_spec(bhmm_ctx *c, const Model<N> &m, double *stats_dev, int flags,
+                          bool *verified)
+    {
+        *verified = false;
+        int rc;
+        if ((rc = c->d_aexit.ensure((size_t)c->Gp * N)) || (rc = c->d_bentry.ensure((size_t)c->Gp * N)) ||
+            (rc = c->d_specres.ensure(2)))
+            return rc;
+        if (!c->h_specres)
+            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 2 * sizeof(unsigned int),
+                                   hipHostMallocDefault));
+        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 2 * sizeof(unsigned int), c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
+        rc = fwdbwd<KIND, MODE_ESTEP, true>(c, m, (flags & BHMM_FLAG_STORE_GAMMA) != 0);
+        if (rc)
+            return rc;
+        hipLaunchKernelGGL((k_spec_check<N>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
+                           chunks_of(c), c->G, (const double *)c->d_aentry.p,
+                           (const double *)c->d_aexit.p, (const double *)c->d_bexit.p,
+                           (const double *)c->d_bentry.p, 1e-11, c->d_specres.p);
+        BHMM_HIP(hipGetLastError());
+        if ((rc = finish<KIND>(c, m, stats_dev)))
+            return rc;
+        BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
+        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 2 * sizeof(unsigned int),
+                                hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream)); // the verdict decides what runs next
+        float dev;
+        memcpy(&dev, &c->h_specres[1], sizeof(float));
+        c->spec_last_dev = dev;
+        if (c->h_specres[0] == 0) {
+            *verified = true;
+            c->spec_ok++;
+            c->ev_pending = true;
+            return BHMM_OK;
+        }
+        // some boundary disagreed: lengthen the warm-up for the next call; give up after the
+        // chunk length is exceeded a few times (slowly mixing model / uninformative data)
+        c->spec_fail++;
+        if (c->spec_W >= 4096 || c->spec_W >= 4 * c->Lmax)
+            c->spec_enabled = false;
+        else
+            c->spec_W *= 2;
+        return BHMM_OK;
+    }
+
+    template <int KIND>
     static int estep_kind(bhmm_ctx *c, const Model<N> &m, double *stats_dev, int flags)
     {
-        int rc = prescan_stitch<KIND>(c, m);
+        int rc;
+        if (c->spec_enabled) {
+            bool ok = false;
+            if ((rc = estep_spec<KIND>(c, m, stats_dev, flags, &ok)))
+                return rc;
+            if (ok)
+                return BHMM_OK;
+        }
+        rc = prescan_stitch<KIND>(c, m);
         if (rc)
             return rc;
         rc = fwdbwd<KIND, MODE_ESTEP>(c, m, (flags & BHMM_FLAG_STORE_GAMMA) != 0);
@@ -456,6 +533,10 @@ int bhmm_ctx_create(bhmm_ctx **out, int device, void *stream)
     if (!c)
         return BHMM_ERR_NO_MEM;
     c->device = device;
+    if (const char *e = getenv("BHMM_AMD_SPEC"))
+        c->spec_enabled = atoi(e) != 0;
+    if (const char *e = getenv("BHMM_AMD_SPEC_W"))
+        c->spec_W = std::max(1, atoi(e));
     if (stream) {
         c->stream = static_cast<hipStream_t>(stream);
     } else {
@@ -515,6 +596,11 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     c->d_P.release();
     c->d_agrp.release();
     c->d_bgrp.release();
+    c->d_aexit.release();
+    c->d_bentry.release();
+    c->d_specres.release();
+    if (c->h_specres)
+        (void)hipHostFree(c->h_specres);
     if (c->h_pinned)
         (void)hipHostFree(c->h_pinned);
     for (auto &ev : c->ev)
@@ -644,6 +730,40 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         BHMM_HIP(hipMemcpyAsync(c->d_obs_rm.p, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
     }
     BHMM_HIP(hipStreamSynchronize(c->stream));
+    return BHMM_OK;
+}
+
+int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
+{
+    if (!c || !name)
+        return invalid("NULL argument");
+    const std::string n(name);
+    if (n == "spec_enabled")
+        c->spec_enabled = value != 0.0;
+    else if (n == "spec_W")
+        c->spec_W = std::max(1, (int)value);
+    else
+        return invalid("unknown or read-only option: " + n);
+    return BHMM_OK;
+}
+
+int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
+{
+    if (!c || !name || !value)
+        return invalid("NULL argument");
+    const std::string n(name);
+    if (n == "spec_enabled")
+        *value = c->spec_enabled ? 1.0 : 0.0;
+    else if (n == "spec_W")
+        *value = c->spec_W;
+    else if (n == "spec_ok")
+        *value = c->spec_ok;
+    else if (n == "spec_fail")
+        *value = c->spec_fail;
+    else if (n == "spec_last_dev")
+        *value = c->spec_last_dev;
+    else
+        return invalid("unknown option: " + n);
     return BHMM_OK;
 }
 

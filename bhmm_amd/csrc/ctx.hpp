@@ -84,6 +84,14 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_Brm;      // [n][M] emission matrix, row-major (path kernels)
     bhmm::DevBuf<double> d_alpha_rm; // [total][n] alpha, trajectory-major (path sampling)
     bhmm::DevBuf<double> d_wmodel;   // model parameters of the 9..64-state family
+    // speculative (verified) chunk boundaries, see k_fwdbwd<..., SPEC> / k_spec_check
+    bool spec_enabled = true;
+    int spec_W = 256;             // warm-up length (doubles after a failed verification)
+    int spec_fail = 0, spec_ok = 0;
+    float spec_last_dev = 0.f;
+    bhmm::DevBuf<double> d_aexit, d_bentry;
+    bhmm::DevBuf<unsigned int> d_specres;
+    unsigned int *h_specres = nullptr; // pinned
     // two-level stitch: groups of consecutive chunks (empty when every trajectory is short)
     int nG = 0;
     bhmm::DevBuf<int32_t> d_grp_c0, d_grp_c1, d_grp_traj0; // [nG], [nG], [K+1]

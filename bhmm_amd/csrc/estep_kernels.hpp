@@ -662,10 +662,23 @@ __device__ __forceinline__ double2 *ci_pair(double *base, int64_t rec, int N_, i
     return reinterpret_cast<double2 *>(base + rec * (int64_t)(N_ * 64)) + q * 64 + cl;
 }
 
-template <int N, int KIND, int MODE>
+// SPEC (speculative boundaries, verified afterwards by k_spec_check): instead of reading the
+// exact chunk-boundary vectors from k_stitch, every chunk derives them itself by warming the
+// recursion up over the W steps before (alpha) / after (beta) the chunk from a uniform vector.
+// A hidden Markov filter forgets its initial condition, so after enough steps the result no
+// longer depends on that vector; k_spec_check then compares, at every chunk boundary, the
+// vector one chunk assumed with the vector its neighbour actually computed (componentwise
+// relative tolerance).  If all boundaries agree the whole chain is exact to that tolerance
+// (chunk 0 starts from the true initial condition; the normalised recursion is non-expansive
+// in Hilbert's projective metric, so deviations add at most linearly); otherwise the host
+// re-runs the E-step with the prescan/stitch kernels, which are exact unconditionally.
+template <int N, int KIND, int MODE, bool SPEC>
 __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
     const Model<N> m, const Chunks ch, const void *obs_ci, const double *Bt_g,
-    const double *alpha_entry, const double *beta_exit,
+    double *alpha_entry, double *beta_exit,
+    double *a_exit,        // SPEC: [G][N] normalised alpha at each chunk's last step
+    double *b_entry,       // SPEC: [G][N] beta one step before each chunk, as the chunk derived it
+    int W,                 // SPEC: warm-up length
     double *ws,            // CI workspace: alpha (ESTEP, FWD) or beta (BWD)
     double *gamma_ci,      // CI gamma, or nullptr
     double *logL_chunk,    // [G] log of the product of the chunk's scaling factors
@@ -718,6 +731,7 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
 
     if (len > 0) {
         double a[2];
+        double2 aent = make_double2(0.0, 0.0); // SPEC: the entry vector this chunk derived
         // ---------------- forward sweep (_hidden.c:16-66) ------------------------------
         if constexpr (MODE != MODE_BWD) {
             double Ac[N][2];
@@ -744,6 +758,60 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
                 P = frexp(c, &eP);
                 *ci_pair(ws, ci_rec(g, 0, ch.Lmax), N, q, cl) = make_double2(a[0], a[1]);
                 s = 1;
+            } else if constexpr (SPEC) {
+                // warm-up: position a cursor W steps back (or at the trajectory start, where
+                // the recursion is exact), then run forward to my first step
+                int64_t gg = g;
+                int ss = 0, rem = W;
+                bool exact0 = false;
+                while (rem > 0) {
+                    if (ss == 0) {
+                        if (ch.t0[gg] == 0) {
+                            exact0 = true;
+                            break;
+                        }
+                        --gg;
+                        ss = ch.len[gg];
+                    }
+                    const int take = rem < ss ? rem : ss;
+                    ss -= take;
+                    rem -= take;
+                }
+                a[0] = (2 * q < m.nreal) ? 1.0 / (double)m.nreal : 0.0;
+                a[1] = (2 * q + 1 < m.nreal) ? 1.0 / (double)m.nreal : 0.0;
+                while (gg != g) {
+                    double p[2];
+                    const ObsIn in = load_obs<N, KIND>(obs_ci, ci_rec(gg, ss, ch.Lmax),
+                                                       (int)(gg & 63), q);
+                    emit_pair<N, KIND>(m, in, Bt, q, mu, is, cn, gmask, p);
+                    double n0, n1;
+                    if (exact0) { // first step of the trajectory, _hidden.c:28-39
+                        n0 = pi2[0] * p[0];
+                        n1 = pi2[1] * p[1];
+                        exact0 = false;
+                    } else {
+                        double af[N];
+                        grp_gather<N>(a, af);
+                        n0 = af[0] * Ac[0][0];
+                        n1 = af[0] * Ac[0][1];
+#pragma unroll
+                        for (int i = 1; i < N; ++i) {
+                            n0 = fma(af[i], Ac[i][0], n0);
+                            n1 = fma(af[i], Ac[i][1], n1);
+                        }
+                        n0 *= p[0];
+                        n1 *= p[1];
+                    }
+                    const double rc = fast_rcp(grp_sum<H>(n0 + n1));
+                    a[0] = n0 * rc;
+                    a[1] = n1 * rc;
+                    if (++ss == ch.len[gg]) {
+                        ++gg;
+                        ss = 0;
+                    }
+                }
+                aent = make_double2(a[0], a[1]);
+                *reinterpret_cast<double2 *>(alpha_entry + g * N + 2 * q) = aent;
             } else {
                 // entry vector from k_stitch (power-of-two scaled): normalise, _hidden.c:57-59
                 const double2 x = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
@@ -779,6 +847,8 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
             }
             if (q == 0)
                 logL_chunk[g] = log(P) + (double)eP * 0.693147180559945309417232121458;
+            if constexpr (SPEC)
+                *reinterpret_cast<double2 *>(a_exit + g * N + 2 * q) = make_double2(a[0], a[1]);
         }
 
         // ---------------- backward sweep ------------------------------------------------
@@ -825,10 +895,66 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
             // S_t = sum_i alpha_t[i] (A (p_{t+1} o beta_{t+1}))[i], which equals the
             // reference's per-step normalisers (hidden/api.py:176-186, _hidden.c:168-179).
             double b2[2], gam[2];
-            {
+            if constexpr (SPEC) {
+                // beta at my last step: 1/N at the trajectory end (_hidden.c:79-88), otherwise
+                // warmed up backwards over the W steps after the chunk from the same vector
+                b2[0] = (2 * q < m.nreal) ? 1.0 / (double)m.nreal : 0.0;
+                b2[1] = (2 * q + 1 < m.nreal) ? 1.0 / (double)m.nreal : 0.0;
+                const bool last_chunk = (g + 1 >= (int64_t)gridDim.x * 64) || ch.len[g + 1] == 0 ||
+                                        ch.t0[g + 1] == 0;
+                if (!last_chunk) {
+                    int64_t gg = g + 1;
+                    int ss = 0, rem = W - 1;
+                    while (rem > 0) { // cursor -> last warm-up step (clamped to the trajectory end)
+                        const int avail = ch.len[gg] - 1 - ss;
+                        if (rem <= avail) {
+                            ss += rem;
+                            break;
+                        }
+                        const bool more = (gg + 1 < (int64_t)gridDim.x * 64) && ch.len[gg + 1] > 0 &&
+                                          ch.t0[gg + 1] != 0;
+                        if (!more) {
+                            ss = ch.len[gg] - 1;
+                            break;
+                        }
+                        rem -= avail + 1;
+                        ++gg;
+                        ss = 0;
+                    }
+                    for (;;) {
+                        double p[2];
+                        const ObsIn in = load_obs<N, KIND>(obs_ci, ci_rec(gg, ss, ch.Lmax),
+                                                           (int)(gg & 63), q);
+                        emit_pair<N, KIND>(m, in, Bt, q, mu, is, cn, gmask, p);
+                        const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
+                        double bf[N];
+                        grp_gather<N>(bb2, bf);
+                        double r0 = Ar[0][0] * bf[0], r1 = Ar[1][0] * bf[0];
+#pragma unroll
+                        for (int j = 1; j < N; ++j) {
+                            r0 = fma(Ar[0][j], bf[j], r0);
+                            r1 = fma(Ar[1][j], bf[j], r1);
+                        }
+                        const int E = grp_max_i32<H>(max(exponent_of(r0), exponent_of(r1)));
+                        b2[0] = ldexp(r0, -E);
+                        b2[1] = ldexp(r1, -E);
+                        if (gg == g + 1 && ss == 0)
+                            break;
+                        if (ss == 0) {
+                            --gg;
+                            ss = ch.len[gg] - 1;
+                        } else {
+                            --ss;
+                        }
+                    }
+                }
+                *reinterpret_cast<double2 *>(beta_exit + g * N + 2 * q) = make_double2(b2[0], b2[1]);
+            } else {
                 const double2 x = *reinterpret_cast<const double2 *>(beta_exit + g * N + 2 * q);
                 b2[0] = x.x;
                 b2[1] = x.y;
+            }
+            {
                 gam[0] = a[0] * b2[0];
                 gam[1] = a[1] * b2[1];
                 const double rS = fast_rcp(grp_sum<H>(gam[0] + gam[1]));
@@ -876,8 +1002,12 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
                     break;
                 }
                 // ---- pair (s-1, s): xi accumulation and beta_{s-1} ----------------------
-                if (s == 0)
-                    apv = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
+                if (s == 0) {
+                    if constexpr (SPEC)
+                        apv = aent;
+                    else
+                        apv = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
+                }
                 const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
                 double bf[N];
                 grp_gather<N>(bb2, bf);
@@ -901,6 +1031,10 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
                 const int E = grp_max_i32<H>(max(exponent_of(r0), exponent_of(r1)));
                 b2[0] = ldexp(r0, -E);
                 b2[1] = ldexp(r1, -E);
+                if constexpr (SPEC)
+                    if (s == 0) // beta one step before this chunk: what the previous chunk assumed
+                        *reinterpret_cast<double2 *>(b_entry + g * N + 2 * q) =
+                            make_double2(b2[0], b2[1]);
             }
         }
     }
@@ -951,6 +1085,49 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
             for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
                 disc_partials[(int64_t)blockIdx.x * (m.M * N) + i] = dstat[i];
     }
+}
+
+// =========================================================================================
+// k_spec_check: boundary consistency of a speculative E-step.  For every chunk g that is not the
+// first of its trajectory: the alpha vector g started from (warm-up) against the alpha its
+// predecessor ended with, and the beta vector the predecessor started its backward sweep from
+// (warm-up) against the beta that g derived for that step.  Vectors are compared after
+// normalisation, componentwise relative.  result[0] counts violations, result[1] holds the bit
+// pattern of the largest relative deviation seen (float), for adapting the warm-up length.
+// =========================================================================================
+template <int N>
+__global__ void k_spec_check(const Chunks ch, int G, const double *alpha_entry, const double *a_exit,
+                             const double *beta_exit, const double *b_entry, double tol,
+                             unsigned int *result)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G || ch.len[g] == 0 || ch.t0[g] == 0)
+        return;
+    double dev = 0.0;
+    auto cmp = [&](const double *x, const double *y) { // y: reference side
+        double sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            sx += x[j];
+            sy += y[j];
+        }
+        if (!(sx > 0.0) || !(sy > 0.0)) {
+            dev = 1.0;
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double xs = x[j] / sx, ys = y[j] / sy;
+            const double d = fabs(xs - ys);
+            const double r = (ys > 1e-280) ? d / ys : (d > 1e-280 ? 1.0 : 0.0);
+            dev = fmax(dev, r);
+        }
+    };
+    cmp(alpha_entry + g * N, a_exit + (g - 1) * N);
+    cmp(beta_exit + (g - 1) * N, b_entry + g * N);
+    if (!(dev <= tol))
+        atomicAdd(&result[0], 1u);
+    atomicMax(&result[1], __float_as_uint((float)fmin(dev, 1.0)));
 }
 
 // =========================================================================================

@@ -121,6 +121,14 @@ class Engine(object):
     def stream(self):
         return self._L.bhmm_ctx_stream(self._h)
 
+    def set_option(self, name, value):
+        _lib.check(self._L.bhmm_ctx_set_option(self._h, name.encode(), float(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_double(0.0)
+        _lib.check(self._L.bhmm_ctx_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
     def sync(self):
         _lib.check(self._L.bhmm_ctx_sync(self._h))
 
