@@ -246,6 +246,9 @@ def main():
                                    "timesteps per GPU, one full E-step" % (K, T),
                        "trajectories_per_gpu": K, "timesteps_per_trajectory": T,
                        "chunk_len": eng.chunk_len, "chunks": eng.num_chunks,
+                       "speculative_boundaries": {k: eng.get_option(k) for k in
+                                                  ("spec_enabled", "spec_W", "spec_ok", "spec_fail",
+                                                   "spec_last_dev")},
                        "parallelism": "trajectories sharded over %d GPU(s), RCCL all-reduce of "
                                       "%d statistics" % (world, S)},
             "roofline": {"bound": "hbm", "kernel": "k_fwdbwd<8,gauss,estep>",

@@ -182,10 +182,10 @@ struct Runner {
         // some boundary disagreed: lengthen the warm-up for the next call; give up after the
         // chunk length is exceeded a few times (slowly mixing model / uninformative data)
         c->spec_fail++;
-        if (c->spec_W >= 4096 || c->spec_W >= 4 * c->Lmax)
-            c->spec_enabled = false;
+        if (c->spec_W >= 8192 || c->spec_W >= 2 * c->Lmax)
+            c->spec_enabled = false; // the warm-up would cost more than the prescan
         else
-            c->spec_W *= 2;
+            c->spec_W += std::max(64, c->spec_W / 2);
         return BHMM_OK;
     }
 
@@ -310,12 +310,13 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
     const int K = c->K;
     int L = chunk;
     if (L <= 0) {
-        // k_fwdbwd uses N/2 lanes and k_prescan N lanes per chunk: 65536 chunks put 4 (8)
-        // wavefronts on every SIMD of the 256 CUs, and halve the serial depth of k_stitch
-        // compared with one chunk per lane (measured optimum on configs[1], profiles/r01)
-        const int64_t target = 65536;
+        // k_fwdbwd uses N/2 lanes per chunk: 32768 chunks put two 64-lane wavefronts on every
+        // SIMD of the 256 CUs.  Fewer, longer chunks amortise the warm-up of the speculative
+        // boundaries (W / L extra steps); more chunks only help occupancy (measured optimum on
+        // configs[1]: profiles/r01).
+        const int64_t target = 32768;
         int64_t l = (c->total + target - 1) / target;
-        L = (int)std::min<int64_t>(std::max<int64_t>(l, 32), 4096);
+        L = (int)std::min<int64_t>(std::max<int64_t>(l, 32), (int64_t)1 << 20);
     }
     c->L = L;
     std::vector<int32_t> ctraj, clen;

@@ -86,7 +86,7 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_wmodel;   // model parameters of the 9..64-state family
     // speculative (verified) chunk boundaries, see k_fwdbwd<..., SPEC> / k_spec_check
     bool spec_enabled = true;
-    int spec_W = 256;             // warm-up length (doubles after a failed verification)
+    int spec_W = 288;             // warm-up length (grows by half after a failed verification)
     int spec_fail = 0, spec_ok = 0;
     float spec_last_dev = 0.f;
     bhmm::DevBuf<double> d_aexit, d_bentry;

@@ -148,7 +148,7 @@ int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const do
 /* Tuning / introspection knobs by name (returns BHMM_ERR_INVALID for an unknown name):
  *   "spec_enabled"  1/0  use speculative, verified chunk boundaries in bhmm_estep (default 1;
  *                        switched off automatically when verification keeps failing)
- *   "spec_W"        warm-up length in time steps (default 256, doubled after a failed check)
+ *   "spec_W"        warm-up length in time steps (default 288, +50 % after a failed check)
  *   "spec_ok", "spec_fail"  (read-only) E-steps whose boundaries verified / fell back
  *   "spec_last_dev" (read-only) largest relative boundary deviation of the last check */
 int bhmm_ctx_set_option(bhmm_ctx *ctx, const char *name, double value);

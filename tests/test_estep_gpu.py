@@ -209,3 +209,52 @@ def test_full_size_properties():
     eng2.close()
     del obs_dev, sub
     torch.cuda.empty_cache()
+
+
+def test_speculative_boundaries_verify_or_fall_back(golden):
+    """The E-step first tries chunk boundaries obtained by warm-up (no prescan / stitch) and
+    verifies them; a warm-up that is too short must be detected and the exact pipeline used."""
+    g = golden("g8_ragged")
+    obs = split(g["obs"], g["lengths"])
+    ref = orc.estep("gaussian", obs, g["A"], g["pi"], g["mu"], g["sigma"])
+    # (1) far too short a warm-up: every boundary is wrong -> detected, exact fallback
+    eng = _engine()
+    eng.set_observations("gaussian", obs, 8, chunk=16)
+    eng.set_option("spec_W", 2)
+    res = eng.estep(g["A"], g["pi"], g["mu"], g["sigma"])
+    assert eng.get_option("spec_fail") == 1 and eng.get_option("spec_ok") == 0
+    assert eng.get_option("spec_last_dev") > 1e-6
+    _cmp(res, ref, 8)
+    assert eng.get_option("spec_W") > 2                  # lengthened for the next call
+    for _ in range(4):
+        res = eng.estep(g["A"], g["pi"], g["mu"], g["sigma"])
+        _cmp(res, ref, 8)
+    # the warm-up grows until it verifies (or speculation is switched off); either way exact
+    assert eng.get_option("spec_ok") >= 1 or eng.get_option("spec_enabled") == 0
+    eng.close()
+    # (2) normal case: verified at once, and identical to the exact pipeline within 1e-10
+    eng = _engine()
+    eng.set_observations("gaussian", obs, 8, chunk=500)
+    r_spec = eng.estep(g["A"], g["pi"], g["mu"], g["sigma"])
+    assert eng.get_option("spec_ok") == 1 and eng.get_option("spec_last_dev") <= 1e-11
+    eng.set_option("spec_enabled", 0)
+    r_exact = eng.estep(g["A"], g["pi"], g["mu"], g["sigma"])
+    np.testing.assert_allclose(r_spec.packed, r_exact.packed, rtol=1e-10, atol=1e-12)
+    _cmp(r_spec, ref, 8)
+    eng.close()
+    # (3) a chain that does not forget (near-identity A, uninformative emissions): speculation
+    # cannot verify, is abandoned, results stay exact
+    A = np.full((4, 4), 1e-7)
+    np.fill_diagonal(A, 1.0 - 3e-7)
+    pi = np.array([0.4, 0.3, 0.2, 0.1])
+    mu, sig = np.array([0.0, 0.01, 0.02, 0.03]), np.ones(4)
+    rng = np.random.default_rng(0)
+    o = [rng.normal(0, 1, 6000)]
+    ref = orc.estep("gaussian", o, A, pi, mu, sig)
+    eng = _engine()
+    eng.set_observations("gaussian", o, 4, chunk=50)
+    for _ in range(6):
+        res = eng.estep(A, pi, mu, sig)
+        _cmp(res, ref, 4)
+    assert eng.get_option("spec_fail") >= 1
+    eng.close()
