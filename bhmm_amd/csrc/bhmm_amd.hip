@@ -145,47 +145,22 @@ struct Runner {
                           bool *verified)
     {
         *verified = false;
-        int rc;
-        if ((rc = c->d_aexit.ensure((size_t)c->Gp * N)) || (rc = c->d_bentry.ensure((size_t)c->Gp * N)) ||
-            (rc = c->d_specres.ensure(2)))
+        int rc = spec_prepare(c);
+        if (rc)
             return rc;
-        if (!c->h_specres)
-            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 2 * sizeof(unsigned int),
-                                   hipHostMallocDefault));
-        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 2 * sizeof(unsigned int), c->stream));
         BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
         BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
         BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
         rc = fwdbwd<KIND, MODE_ESTEP, true>(c, m, (flags & BHMM_FLAG_STORE_GAMMA) != 0);
         if (rc)
             return rc;
-        hipLaunchKernelGGL((k_spec_check<N>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
-                           chunks_of(c), c->G, (const double *)c->d_aentry.p,
-                           (const double *)c->d_aexit.p, (const double *)c->d_bexit.p,
-                           (const double *)c->d_bentry.p, 1e-11, c->d_specres.p);
-        BHMM_HIP(hipGetLastError());
         if ((rc = finish<KIND>(c, m, stats_dev)))
             return rc;
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
-        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 2 * sizeof(unsigned int),
-                                hipMemcpyDeviceToHost, c->stream));
-        BHMM_HIP(hipStreamSynchronize(c->stream)); // the verdict decides what runs next
-        float dev;
-        memcpy(&dev, &c->h_specres[1], sizeof(float));
-        c->spec_last_dev = dev;
-        if (c->h_specres[0] == 0) {
-            *verified = true;
-            c->spec_ok++;
+        if ((rc = spec_verdict(c, true, verified)))
+            return rc;
+        if (*verified)
             c->ev_pending = true;
-            return BHMM_OK;
-        }
-        // some boundary disagreed: lengthen the warm-up for the next call; give up after the
-        // chunk length is exceeded a few times (slowly mixing model / uninformative data)
-        c->spec_fail++;
-        if (c->spec_W >= 8192 || c->spec_W >= 2 * c->Lmax)
-            c->spec_enabled = false; // the warm-up would cost more than the prescan
-        else
-            c->spec_W += std::max(64, c->spec_W / 2);
         return BHMM_OK;
     }
 
@@ -257,26 +232,79 @@ struct Runner {
         return BHMM_OK;
     }
 
+    // verdict of a speculative pass (synchronises the stream)
+    static int spec_verdict(bhmm_ctx *c, bool with_beta, bool *verified)
+    {
+        hipLaunchKernelGGL((k_spec_check<N>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
+                           chunks_of(c), c->G, (const double *)c->d_aentry.p,
+                           (const double *)c->d_aexit.p,
+                           with_beta ? (const double *)c->d_bexit.p : (const double *)nullptr,
+                           (const double *)c->d_bentry.p, 1e-11, c->d_specres.p);
+        BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 2 * sizeof(unsigned int),
+                                hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        float dev;
+        memcpy(&dev, &c->h_specres[1], sizeof(float));
+        c->spec_last_dev = dev;
+        *verified = c->h_specres[0] == 0;
+        if (*verified) {
+            c->spec_ok++;
+        } else {
+            // lengthen the warm-up for the next call; give up once it would cost more than the
+            // prescan (slowly mixing model / uninformative data)
+            c->spec_fail++;
+            if (c->spec_W >= 8192 || c->spec_W >= 2 * c->Lmax)
+                c->spec_enabled = false;
+            else
+                c->spec_W += std::max(64, c->spec_W / 2);
+        }
+        return BHMM_OK;
+    }
+
+    static int spec_prepare(bhmm_ctx *c)
+    {
+        int rc;
+        if ((rc = c->d_aexit.ensure((size_t)c->Gp * N)) || (rc = c->d_bentry.ensure((size_t)c->Gp * N)) ||
+            (rc = c->d_specres.ensure(2)))
+            return rc;
+        if (!c->h_specres)
+            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 2 * sizeof(unsigned int),
+                                   hipHostMallocDefault));
+        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 2 * sizeof(unsigned int), c->stream));
+        return BHMM_OK;
+    }
+
+    template <int KIND>
+    static int forward_kind(bhmm_ctx *c, const Model<N> &m)
+    {
+        int rc;
+        if (c->spec_enabled) {
+            bool ok = false;
+            if ((rc = spec_prepare(c)) || (rc = fwdbwd<KIND, MODE_FWD, true>(c, m, false)) ||
+                (rc = spec_verdict(c, false, &ok)))
+                return rc;
+            if (ok)
+                return BHMM_OK;
+        }
+        if ((rc = prescan_stitch<KIND>(c, m)))
+            return rc;
+        return fwdbwd<KIND, MODE_FWD>(c, m, false);
+    }
+
     // forward pass only, alpha (normalised, _hidden.c:16-66) left in the CI workspace
     static int forward_only(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                             const double *par1)
     {
         Model<N> m;
         fill_model<N>(m, c->n, c->kind, c->M, A, pi, par0, par1);
-        int rc;
         switch (c->kind) {
         case EMIT_GAUSS:
-            if ((rc = prescan_stitch<EMIT_GAUSS>(c, m)))
-                return rc;
-            return fwdbwd<EMIT_GAUSS, MODE_FWD>(c, m, false);
+            return forward_kind<EMIT_GAUSS>(c, m);
         case EMIT_DISC:
-            if ((rc = prescan_stitch<EMIT_DISC>(c, m)))
-                return rc;
-            return fwdbwd<EMIT_DISC, MODE_FWD>(c, m, false);
+            return forward_kind<EMIT_DISC>(c, m);
         default:
-            if ((rc = prescan_stitch<EMIT_EXPL>(c, m)))
-                return rc;
-            return fwdbwd<EMIT_EXPL, MODE_FWD>(c, m, false);
+            return forward_kind<EMIT_EXPL>(c, m);
         }
     }
 

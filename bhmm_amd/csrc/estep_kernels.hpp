@@ -1124,7 +1124,8 @@ __global__ void k_spec_check(const Chunks ch, int G, const double *alpha_entry, 
         }
     };
     cmp(alpha_entry + g * N, a_exit + (g - 1) * N);
-    cmp(beta_exit + (g - 1) * N, b_entry + g * N);
+    if (beta_exit) // forward-only passes verify alpha alone
+        cmp(beta_exit + (g - 1) * N, b_entry + g * N);
     if (!(dev <= tol))
         atomicAdd(&result[0], 1u);
     atomicMax(&result[1], __float_as_uint((float)fmin(dev, 1.0)));

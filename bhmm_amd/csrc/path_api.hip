@@ -111,15 +111,17 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         return rc;
     const int K = c->K, n = c->n;
     const size_t nstat = (size_t)N * N + N;
-    const int nblk = c->Gp / BLOCK;
+    const int P = c->Lmax >= 256 ? 4 : 1;       // parts per chunk for the map kernels
+    const int nblk = (c->Gp / BLOCK) * P;
     const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)N : (c->kind == EMIT_DISC ? (size_t)c->M * N : 0);
-    // scratch2: path | status | chunk maps | next-chunk states
-    if ((rc = c->d_scratch2.ensure(((size_t)c->total + 4 + 2 * (size_t)c->Gp) * sizeof(int32_t))))
+    // scratch2: [path] | status | part maps | next-part states
+    const size_t npath = paths ? (size_t)c->total : 0;
+    if ((rc = c->d_scratch2.ensure((npath + 4 + 2 * (size_t)c->Gp * P) * sizeof(int32_t))))
         return rc;
-    int32_t *path = reinterpret_cast<int32_t *>(c->d_scratch2.p);
-    int *status = reinterpret_cast<int *>(path + c->total);
+    int32_t *path = paths ? reinterpret_cast<int32_t *>(c->d_scratch2.p) : nullptr;
+    int *status = reinterpret_cast<int *>(reinterpret_cast<int32_t *>(c->d_scratch2.p) + npath);
     uint32_t *fmap = reinterpret_cast<uint32_t *>(status + 4);
-    int32_t *nstate = reinterpret_cast<int32_t *>(fmap + c->Gp);
+    int32_t *nstate = reinterpret_cast<int32_t *>(fmap + (size_t)c->Gp * P);
     // scratch: counts | emission partials | reduced emission | u
     const size_t dbl = nstat + (size_t)nblk * esz + esz + (u ? (size_t)c->total : 0) + 8;
     if ((rc = c->d_scratch.ensure(dbl * sizeof(double))))
@@ -140,36 +142,29 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     Model<N> m;
     fill_model_pub<N>(m, n, c->kind, c->M, A, pi, par0, par1);
     {
-        // exact chunk-parallel sampling: maps per chunk, stitch, apply (path_kernels.hpp)
+        // exact chunk-parallel sampling: maps per part, stitch, apply + statistics
         const Chunks chs = chunks_pub(c);
         const int64_t *offd = c->d_offsets.p;
+        const void *obs_ci = c->d_obs_ci.p;
         hipLaunchKernelGGL((k_smp_maps<N>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd,
-                           (const double *)c->d_ws.p, (const double *)udev, seed, fmap, status);
+                           (const double *)c->d_ws.p, (const double *)udev, seed, P, fmap, status);
         BHMM_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_smp_stitch, dim3((K + 255) / 256), dim3(256), 0, c->stream,
-                           (const int32_t *)c->d_traj_c0.p, K, (const uint32_t *)fmap, nstate);
+                           (const int32_t *)c->d_traj_c0.p, K, P, (const uint32_t *)fmap, nstate);
         BHMM_HIP(hipGetLastError());
-        hipLaunchKernelGGL((k_smp_apply<N>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd,
-                           (const double *)c->d_ws.p, (const double *)udev, seed,
-                           (const int32_t *)nstate, path, status);
-        BHMM_HIP(hipGetLastError());
-    }
-    if (counts || n0 || emis) {
-        const Chunks ch = chunks_pub(c);
-        const void *obs = c->d_obs_rm.p;
         if (c->kind == EMIT_GAUSS)
-            hipLaunchKernelGGL((k_path_stats<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream,
-                               m, ch, (const int64_t *)c->d_offsets.p, obs, (const int32_t *)path,
-                               cnt, epart);
+            hipLaunchKernelGGL((k_smp_apply<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
+                               chs, offd, (const double *)c->d_ws.p, obs_ci, (const double *)udev,
+                               seed, P, (const int32_t *)nstate, path, cnt, epart, status);
         else if (c->kind == EMIT_DISC)
-            hipLaunchKernelGGL((k_path_stats<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK),
-                               (size_t)c->M * N * sizeof(double), c->stream, m, ch,
-                               (const int64_t *)c->d_offsets.p, obs, (const int32_t *)path, cnt,
-                               epart);
+            hipLaunchKernelGGL((k_smp_apply<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK),
+                               (size_t)c->M * N * sizeof(double), c->stream, m, chs, offd,
+                               (const double *)c->d_ws.p, obs_ci, (const double *)udev, seed, P,
+                               (const int32_t *)nstate, path, cnt, epart, status);
         else
-            hipLaunchKernelGGL((k_path_stats<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream,
-                               m, ch, (const int64_t *)c->d_offsets.p, obs, (const int32_t *)path,
-                               cnt, epart);
+            hipLaunchKernelGGL((k_smp_apply<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
+                               chs, offd, (const double *)c->d_ws.p, obs_ci, (const double *)udev,
+                               seed, P, (const int32_t *)nstate, path, cnt, epart, status);
         BHMM_HIP(hipGetLastError());
         if (esz) {
             hipLaunchKernelGGL(k_add_partials, dim3((unsigned)((esz + 255) / 256)), dim3(256), 0,

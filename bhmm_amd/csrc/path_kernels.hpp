@@ -302,15 +302,19 @@ __device__ __forceinline__ void stage_At(double *sAt, const Model<N> &m)
     __syncthreads();
 }
 
+// The maps are built on a partition finer than the E-step chunks (every chunk is cut into P
+// parts, P workgroups walk the same 256 chunks): these kernels keep one lane per (chunk, part),
+// so more parts = more wavefronts in flight; composition does not care where the cuts are.
 template <int N>
 __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks ch,
                                                   const int64_t *off, const double *alpha_ci,
-                                                  const double *u, uint64_t seed, uint32_t *Fmap,
-                                                  int *status)
+                                                  const double *u, uint64_t seed, int P,
+                                                  uint32_t *Fmap, int *status)
 {
     __shared__ __attribute__((aligned(16))) double sAt[N * N];
     stage_At<N>(sAt, m);
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int part = blockIdx.x % P;
+    const int64_t g = (int64_t)(blockIdx.x / P) * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int len = ch.len[g];
     if (len == 0)
@@ -319,8 +323,9 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
     const int64_t t0 = ch.t0[g], base = ch.goff[g];
     const int64_t Tk = off[k + 1] - off[k];
     const int n = m.nreal;
-    uint32_t cur = 0x76543210u; // nibble j = image of next-chunk state j (identity)
-    for (int s = len - 1; s >= 0; --s) {
+    const int s_lo = (int)((int64_t)len * part / P), s_hi = (int)((int64_t)len * (part + 1) / P);
+    uint32_t cur = 0x76543210u; // nibble j = image of next-part state j (identity)
+    for (int s = s_hi - 1; s >= s_lo; --s) {
         double a[N];
         ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
         const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
@@ -342,51 +347,116 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
             cur = nw;
         }
     }
-    Fmap[g] = cur;
+    Fmap[g * P + part] = cur;
 }
 
-// state at the first step of the NEXT chunk, for every chunk (0 for a trajectory's last chunk,
-// whose map is constant)
-static __global__ void k_smp_stitch(const int32_t *traj_c0, int K, const uint32_t *Fmap,
+// state at the first step of the NEXT part, for every (chunk, part) (0 behind a trajectory's
+// last part, whose map is constant)
+static __global__ void k_smp_stitch(const int32_t *traj_c0, int K, int P, const uint32_t *Fmap,
                                     int32_t *next_state)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K)
         return;
     uint32_t x = 0;
-    for (int c = traj_c0[k + 1] - 1; c >= traj_c0[k]; --c) {
-        next_state[c] = (int32_t)x;
-        x = (Fmap[c] >> (4 * x)) & 7u;
+    for (int64_t e = (int64_t)traj_c0[k + 1] * P - 1; e >= (int64_t)traj_c0[k] * P; --e) {
+        next_state[e] = (int32_t)x;
+        x = (Fmap[e] >> (4 * x)) & 7u;
     }
 }
 
-template <int N>
+// re-walk every part from its known start state: the sampled path (optional output) and the
+// hidden-path statistics of the Gibbs sweep (generic_hmm.py:297-334,398-431): integer
+// transition / start counts (exact) and per-state emission sums, fused so that neither the path
+// nor the observations are read again.
+template <int N, int KIND>
 __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunks ch,
                                                    const int64_t *off, const double *alpha_ci,
-                                                   const double *u, uint64_t seed,
-                                                   const int32_t *next_state, int32_t *path,
-                                                   int *status)
+                                                   const void *obs_ci, const double *u,
+                                                   uint64_t seed, int P, const int32_t *next_state,
+                                                   int32_t *path, unsigned long long *counts,
+                                                   double *epartials, int *status)
 {
+    extern __shared__ __attribute__((aligned(16))) double lds[]; // discrete: [M][N] counts
     __shared__ __attribute__((aligned(16))) double sAt[N * N];
+    __shared__ unsigned int cnt[N * N + N];
+    __shared__ double red[4][3 * N];
     stage_At<N>(sAt, m);
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int e = threadIdx.x; e < N * N + N; e += blockDim.x)
+        cnt[e] = 0u;
+    if constexpr (KIND == EMIT_DISC)
+        for (int e = threadIdx.x; e < m.M * N; e += blockDim.x)
+            lds[e] = 0.0;
+    __syncthreads();
+    const int part = blockIdx.x % P;
+    const int64_t g = (int64_t)(blockIdx.x / P) * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int len = ch.len[g];
-    if (len == 0)
-        return;
-    const int k = ch.traj[g];
-    const int64_t t0 = ch.t0[g], base = ch.goff[g];
-    const int64_t Tk = off[k + 1] - off[k];
-    const int n = m.nreal;
-    int nxt = next_state[g];
-    for (int s = len - 1; s >= 0; --s) {
-        double a[N];
-        ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
-        const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
-        const bool last = (t0 + s == Tk - 1);
-        nxt = pick_state<N>(a, last ? nullptr : sAt + nxt * N, r, n, status);
-        path[base + s] = nxt;
+    double s0[N], s1[N], s2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        s0[i] = s1[i] = s2[i] = 0.0;
+    if (len > 0) {
+        const int k = ch.traj[g];
+        const int64_t t0 = ch.t0[g], base = ch.goff[g];
+        const int64_t Tk = off[k + 1] - off[k];
+        const int n = m.nreal;
+        const int s_lo = (int)((int64_t)len * part / P), s_hi = (int)((int64_t)len * (part + 1) / P);
+        int nxt = next_state[g * P + part];
+        for (int s = s_hi - 1; s >= s_lo; --s) {
+            double a[N];
+            const int64_t rec = ci_rec(g, s, ch.Lmax);
+            ci_load<N>(alpha_ci, rec, lane, a);
+            const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
+            const bool last = (t0 + s == Tk - 1);
+            const int st = pick_state<N>(a, last ? nullptr : sAt + nxt * N, r, n, status);
+            if (path)
+                path[base + s] = st;
+            if (!last)
+                atomicAdd(&cnt[st * N + nxt], 1u);
+            if (t0 + s == 0)
+                atomicAdd(&cnt[N * N + st], 1u);
+            if constexpr (KIND == EMIT_GAUSS) {
+                const double o = static_cast<const double *>(obs_ci)[rec * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double d = o - m.e0[i];
+                    const bool hit = (st == i);
+                    s0[i] += hit ? 1.0 : 0.0;
+                    s1[i] += hit ? d : 0.0;
+                    s2[i] += hit ? d * d : 0.0;
+                }
+            }
+            if constexpr (KIND == EMIT_DISC) {
+                const int sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + lane];
+                atomicAdd(&lds[sym * N + st], 1.0); // integer-valued: exact, order-independent
+            }
+            nxt = st;
+        }
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * N + N; e += blockDim.x)
+        if (cnt[e])
+            atomicAdd(&counts[e], (unsigned long long)cnt[e]);
+    if constexpr (KIND == EMIT_GAUSS) {
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double a = wave_sum(s0[i]), b = wave_sum(s1[i]), c = wave_sum(s2[i]);
+            if (lane == 0) {
+                red[wv][i] = a;
+                red[wv][N + i] = b;
+                red[wv][2 * N + i] = c;
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x)
+            epartials[(int64_t)blockIdx.x * 3 * N + e] =
+                ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    }
+    if constexpr (KIND == EMIT_DISC)
+        for (int e = threadIdx.x; e < m.M * N; e += blockDim.x)
+            epartials[(int64_t)blockIdx.x * m.M * N + e] = lds[e];
 }
 
 // ---- small reference-shaped kernels on row-major arrays ------------------------------------
