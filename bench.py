@@ -231,11 +231,12 @@ def main():
         alg_bytes_launch = B_ALG_GAUSS * K * T
         achieved = alg_bytes_launch / (kern_ms[2] * 1e-3) / 1e9
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01", "r01c_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r01", "r01f_traffic.json")
         if os.path.exists(tj) and (K, T) == (256, 100000):
             # HBM bytes of one k_fwdbwd launch from the PMC counters (collected offline with
             # rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)
-            traffic = json.load(open(tj))["traffic_bytes_per_launch"]
+            if eng.get_option("spec_ok") > 0 and eng.get_option("spec_fail") == 0:
+                traffic = json.load(open(tj))["traffic_bytes_per_launch"]
         out = {
             "metric": "timesteps/sec forward-backward (whole node), N=8 states",
             "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
@@ -251,10 +252,10 @@ def main():
                                                    "spec_last_dev")},
                        "parallelism": "trajectories sharded over %d GPU(s), RCCL all-reduce of "
                                       "%d statistics" % (world, S)},
-            "roofline": {"bound": "hbm", "kernel": "k_fwdbwd<8,gauss,estep>",
+            "roofline": {"bound": "hbm", "kernel": "k_fwdbwd<8,gauss,estep,spec>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, profiles/r01/r01c_traffic.json)",
+                         "traffic_unit": "bytes per launch (PMC, profiles/r01/r01f_traffic.json)",
                          "alg_bytes_per_launch": alg_bytes_launch,
                          "alg_bytes_per_timestep": B_ALG_GAUSS,
                          "whole_estep_frac": B_ALG_GAUSS * value / world / 1e9 / HBM_PEAK_GBS},
