@@ -627,6 +627,17 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     c->d_bgrp.release();
     c->d_aexit.release();
     c->d_bentry.release();
+    for (int w = 0; w < 2; ++w) {
+        c->d_wseg_traj[w].release();
+        c->d_wseg_len[w].release();
+        c->d_wseg_traj0[w].release();
+        c->d_wseg_t0[w].release();
+    }
+    c->d_wlogLseg.release();
+    c->d_waentry.release();
+    c->d_waexit.release();
+    c->d_wbexit.release();
+    c->d_wbentry.release();
     c->d_specres.release();
     if (c->h_specres)
         (void)hipHostFree(c->h_specres);
@@ -771,6 +782,10 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
         c->spec_enabled = value != 0.0;
     else if (n == "spec_W")
         c->spec_W = std::max(1, (int)value);
+    else if (n == "wide_segments")
+        c->wseg_enabled = value != 0.0;
+    else if (n == "wide_segment_len")
+        c->wseg_len = std::max(0, (int)value); // takes effect at the next set_observations
     else
         return invalid("unknown or read-only option: " + n);
     return BHMM_OK;
@@ -791,6 +806,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->spec_fail;
     else if (n == "spec_last_dev")
         *value = c->spec_last_dev;
+    else if (n == "wide_segments")
+        *value = (c->wseg_enabled && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
     else
         return invalid("unknown option: " + n);
     return BHMM_OK;

@@ -97,6 +97,14 @@ struct bhmm_ctx {
     bhmm::DevBuf<int32_t> d_grp_c0, d_grp_c1, d_grp_traj0; // [nG], [nG], [K+1]
     bhmm::DevBuf<double> d_P, d_agrp, d_bgrp;              // group products / boundary vectors
     bool wide = false;               // nstates > 8: wide_kernels.hpp family
+    // wide family: segment tables.  [0] = one segment per trajectory (exact serial recursion),
+    // [1] = time-segmented plan with verified warm-up boundaries (optional)
+    int w_nseg[2] = {0, 0};
+    bhmm::DevBuf<int32_t> d_wseg_traj[2], d_wseg_len[2], d_wseg_traj0[2];
+    bhmm::DevBuf<int64_t> d_wseg_t0[2];
+    bhmm::DevBuf<double> d_wlogLseg, d_waentry, d_waexit, d_wbexit, d_wbentry;
+    bool wseg_enabled = true;
+    int wseg_len = 0;                // 0 = automatic
     double *h_pinned = nullptr;      // stats + logL_k landing zone
     size_t h_pinned_n = 0;
 

@@ -56,32 +56,50 @@ static int wide_model(bhmm_ctx *c, int kind, const double *A, const double *pi, 
     return BHMM_OK;
 }
 
+static Segs segs_of(bhmm_ctx *c, int which)
+{
+    Segs sg;
+    sg.traj = c->d_wseg_traj[which].p;
+    sg.t0 = c->d_wseg_t0[which].p;
+    sg.len = c->d_wseg_len[which].p;
+    sg.nseg = c->w_nseg[which];
+    sg.W = c->spec_W;
+    return sg;
+}
+
 template <int NP, int KIND>
-static int wide_launch_fwd(bhmm_ctx *c, const WideModel &m)
+static int wide_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
 {
     constexpr int GP = 64 / NP;
-    hipLaunchKernelGGL((k_wide_fwd<NP, KIND>), dim3((c->K + GP - 1) / GP), dim3(64), 0, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, c->K, (const void *)c->d_obs_rm.p,
-                       c->d_alpha_rm.p, c->d_logLk.p);
+    const Segs sg = segs_of(c, which);
+    hipLaunchKernelGGL((k_wide_fwd<NP, KIND>), dim3((sg.nseg + GP - 1) / GP), dim3(64), 0, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, sg, (const void *)c->d_obs_rm.p,
+                       c->d_alpha_rm.p, c->d_wlogLseg.p, c->d_waentry.p, c->d_waexit.p);
+    BHMM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_logl, dim3(c->K), dim3(64), 0, c->stream,
+                       (const int32_t *)c->d_wseg_traj0[which].p, c->K,
+                       (const double *)c->d_wlogLseg.p, c->d_logLk.p);
     BHMM_HIP(hipGetLastError());
     return BHMM_OK;
 }
 
 template <int NP, int KIND>
-static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, bool store_gamma, double *stats_dev)
+static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool store_gamma,
+                           double *stats_dev)
 {
     constexpr int GP = 64 / NP;
+    const Segs sg = segs_of(c, which);
     const size_t sm = (size_t)(NP * (NP + 1) + GP * NP) * sizeof(double);
-    hipLaunchKernelGGL((k_wide_bwd<NP, KIND>), dim3((c->K + GP - 1) / GP), dim3(64), sm, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, c->K, (const void *)c->d_obs_rm.p,
+    hipLaunchKernelGGL((k_wide_bwd<NP, KIND>), dim3((sg.nseg + GP - 1) / GP), dim3(64), sm, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, sg, (const void *)c->d_obs_rm.p,
                        (const double *)c->d_alpha_rm.p,
                        store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_gamma0.p,
-                       c->d_partials.p, c->d_dpartials.p);
+                       c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p);
     BHMM_HIP(hipGetLastError());
     const int n = c->n;
     const int nfin = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0) + (KIND == EMIT_DISC ? n * c->M : 0) +
                      n + 1;
-    hipLaunchKernelGGL((k_wide_finalize<KIND>), dim3(nfin), dim3(64), 0, c->stream, m, c->K,
+    hipLaunchKernelGGL((k_wide_finalize<KIND>), dim3(nfin), dim3(64), 0, c->stream, m, c->K, sg.nseg,
                        (const double *)c->d_partials.p, (const double *)c->d_dpartials.p,
                        (const double *)c->d_logLk.p, (const double *)c->d_gamma0.p, stats_dev);
     BHMM_HIP(hipGetLastError());
@@ -92,6 +110,41 @@ static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, bool store_gamma, do
     ((c)->N == 16 ? fn<16, KIND>(__VA_ARGS__)                         \
      : (c)->N == 32 ? fn<32, KIND>(__VA_ARGS__)                       \
                     : fn<64, KIND>(__VA_ARGS__))
+
+// segment plan `which` with segments of at most seglen steps (seglen <= 0: one per trajectory)
+static int wide_plan(bhmm_ctx *c, int which, int64_t seglen)
+{
+    std::vector<int32_t> st, sl, s0(c->K + 1, 0);
+    std::vector<int64_t> stt;
+    for (int k = 0; k < c->K; ++k) {
+        s0[k] = (int32_t)st.size();
+        const int64_t T = c->offsets[k + 1] - c->offsets[k];
+        if (T <= 0)
+            continue;
+        const int64_t ns = seglen > 0 ? (T + seglen - 1) / seglen : 1;
+        const int64_t base = T / ns, rem = T % ns;
+        for (int64_t q = 0; q < ns; ++q) {
+            st.push_back(k);
+            sl.push_back((int32_t)(base + (q < rem ? 1 : 0)));
+            stt.push_back(q * base + std::min(q, rem));
+        }
+    }
+    s0[c->K] = (int32_t)st.size();
+    const int ns = (int)st.size();
+    c->w_nseg[which] = ns;
+    int rc;
+    if ((rc = c->d_wseg_traj[which].ensure(std::max(ns, 1))) ||
+        (rc = c->d_wseg_len[which].ensure(std::max(ns, 1))) ||
+        (rc = c->d_wseg_t0[which].ensure(std::max(ns, 1))) ||
+        (rc = c->d_wseg_traj0[which].ensure(c->K + 1)))
+        return rc;
+    BHMM_HIP(hipMemcpy(c->d_wseg_traj[which].p, st.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_wseg_len[which].p, sl.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_wseg_t0[which].p, stt.data(), ns * sizeof(int64_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_wseg_traj0[which].p, s0.data(), (c->K + 1) * sizeof(int32_t),
+                       hipMemcpyHostToDevice));
+    return BHMM_OK;
+}
 
 int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, const double *par0,
                    const double *par1, WideModel &m)
@@ -105,13 +158,38 @@ int wide_alloc(bhmm_ctx *c)
     c->N = wide_np(n);
     const int S = n * n + 3 * n;
     int rc;
+    if ((rc = wide_plan(c, 0, 0)))
+        return rc;
+    // time-segmented plan: ~4 lane groups per SIMD, but segments long against the warm-up
+    c->w_nseg[1] = 0;
+    {
+        int64_t seglen = c->wseg_len;
+        if (seglen <= 0) {
+            const int64_t groups_per_wave = 64 / c->N;
+            seglen = std::max<int64_t>((c->total + 4096 * groups_per_wave - 1) / (4096 * groups_per_wave),
+                                       8 * (int64_t)c->spec_W);
+        }
+        int64_t maxT = 0;
+        for (int k = 0; k < c->K; ++k)
+            maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+        if (c->wseg_enabled && maxT > seglen && (rc = wide_plan(c, 1, seglen)))
+            return rc;
+    }
+    const int nsmax = std::max(std::max(c->w_nseg[0], c->w_nseg[1]), 1);
     if ((rc = c->d_alpha_rm.ensure((size_t)c->total * n)) ||
-        (rc = c->d_logLk.ensure(std::max(c->K, 1))) ||
+        (rc = c->d_logLk.ensure(std::max(c->K, 1))) || (rc = c->d_wlogLseg.ensure(nsmax)) ||
         (rc = c->d_gamma0.ensure((size_t)std::max(c->K, 1) * n)) ||
-        (rc = c->d_partials.ensure((size_t)c->K * S)) || (rc = c->d_stats.ensure(1 + n + n * n + n + std::max(2 * n, n * c->M))))
+        (rc = c->d_partials.ensure((size_t)nsmax * S)) ||
+        (rc = c->d_waentry.ensure((size_t)nsmax * n)) || (rc = c->d_waexit.ensure((size_t)nsmax * n)) ||
+        (rc = c->d_wbexit.ensure((size_t)nsmax * n)) || (rc = c->d_wbentry.ensure((size_t)nsmax * n)) ||
+        (rc = c->d_specres.ensure(2)) ||
+        (rc = c->d_stats.ensure(1 + n + n * n + n + std::max(2 * n, n * c->M))))
         return rc;
-    if (c->kind == EMIT_DISC && (rc = c->d_dpartials.ensure((size_t)c->K * n * c->M)))
+    if (c->kind == EMIT_DISC && (rc = c->d_dpartials.ensure((size_t)nsmax * n * c->M)))
         return rc;
+    if (!c->h_specres)
+        BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 2 * sizeof(unsigned int),
+                               hipHostMallocDefault));
     BHMM_HIP(hipMemsetAsync(c->d_gamma0.p, 0, (size_t)std::max(c->K, 1) * n * sizeof(double),
                             c->stream));
     return BHMM_OK;
@@ -124,13 +202,13 @@ int wide_forward(bhmm_ctx *c, const double *A, const double *pi, const double *p
     int rc = wide_model(c, c->kind, A, pi, par0, par1, m);
     if (rc)
         return rc;
-    switch (c->kind) {
+    switch (c->kind) { // plan 0: one segment per trajectory, the exact serial recursion
     case EMIT_GAUSS:
-        return WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m);
+        return WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m, 0);
     case EMIT_DISC:
-        return WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m);
+        return WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m, 0);
     default:
-        return WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m);
+        return WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m, 0);
     }
 }
 
@@ -144,29 +222,63 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     const bool sg = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
     if (sg && (rc = c->d_gamma_ci.ensure((size_t)c->total * c->n)))
         return rc;
-    BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
-    BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
-    BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
-    switch (c->kind) {
-    case EMIT_GAUSS:
-        if ((rc = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m)))
+    auto run = [&](int which) -> int {
+        int r;
+        BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
+        switch (c->kind) {
+        case EMIT_GAUSS:
+            if ((r = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m, which)))
+                return r;
+            r = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_bwd, c, m, which, sg, stats_dev);
+            break;
+        case EMIT_DISC:
+            if ((r = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m, which)))
+                return r;
+            r = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_bwd, c, m, which, sg, stats_dev);
+            break;
+        default:
+            if ((r = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m, which)))
+                return r;
+            r = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_bwd, c, m, which, sg, stats_dev);
+        }
+        if (r)
+            return r;
+        BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
+        return BHMM_OK;
+    };
+    if (c->wseg_enabled && c->w_nseg[1] > c->w_nseg[0]) {
+        // time-segmented run with warm-up boundaries, verified afterwards
+        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 2 * sizeof(unsigned int), c->stream));
+        if ((rc = run(1)))
             return rc;
-        rc = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_bwd, c, m, sg, stats_dev);
-        break;
-    case EMIT_DISC:
-        if ((rc = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m)))
-            return rc;
-        rc = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_bwd, c, m, sg, stats_dev);
-        break;
-    default:
-        if ((rc = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m)))
-            return rc;
-        rc = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_bwd, c, m, sg, stats_dev);
+        const Segs sgs = segs_of(c, 1);
+        hipLaunchKernelGGL(k_wide_check, dim3((sgs.nseg + 255) / 256), dim3(256), 0, c->stream, sgs,
+                           c->n, (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
+                           (const double *)c->d_wbexit.p, (const double *)c->d_wbentry.p, 1e-11,
+                           c->d_specres.p);
+        BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 2 * sizeof(unsigned int),
+                                hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        float dev;
+        memcpy(&dev, &c->h_specres[1], sizeof(float));
+        c->spec_last_dev = dev;
+        if (c->h_specres[0] == 0) {
+            c->spec_ok++;
+            c->ev_pending = true;
+            return BHMM_OK;
+        }
+        c->spec_fail++;
+        if (c->spec_fail >= 2)
+            c->wseg_enabled = false; // keeps failing: stay on the serial plan
+        else
+            c->spec_W += std::max(64, c->spec_W / 2);
     }
-    if (rc)
+    if ((rc = run(0)))
         return rc;
-    BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
-    BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
     c->ev_pending = true;
     return BHMM_OK;
 }

@@ -94,25 +94,39 @@ __device__ __forceinline__ double wide_emit(const WideModel &m, int j, bool real
     return p;
 }
 
+// Segments: a trajectory may be cut into time segments that are processed by different lane
+// groups (one segment per trajectory = the plain serial recursion).  With several segments the
+// boundary vectors come from warm-ups over the W steps before / after the segment and are
+// verified afterwards by k_wide_check (same scheme as k_fwdbwd<..., SPEC>, see there); alpha of
+// the step before a segment is read from the previous segment's output by the backward pass.
+struct Segs {
+    const int32_t *traj; // trajectory of the segment
+    const int64_t *t0;   // first step inside the trajectory
+    const int32_t *len;
+    int nseg;
+    int W;
+};
+
 template <int NP, int KIND>
-__global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_t *off, int K,
+__global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_t *off, const Segs sg,
                                                  const void *obs_rm, double *alpha_rm,
-                                                 double *logL_k)
+                                                 double *logL_seg, double *a_entry, double *a_exit)
 {
     constexpr int GP = 64 / NP;
     __shared__ __attribute__((aligned(16))) double xch[GP][NP];
     const int lane = threadIdx.x;
     const int gi = lane / NP, j = lane % NP;
-    const int k = blockIdx.x * GP + gi;
-    if (k >= K)
+    const int s = blockIdx.x * GP + gi;
+    if (s >= sg.nseg)
         return;
     const int n = m.n;
     const bool real = j < n;
+    const int k = sg.traj[s];
     const int64_t o0 = off[k];
-    const int64_t T = off[k + 1] - o0;
-    if (T <= 0) {
+    const int64_t t0 = sg.t0[s], t1 = t0 + sg.len[s];
+    if (t1 <= t0) {
         if (j == 0)
-            logL_k[k] = 0.0;
+            logL_seg[s] = 0.0;
         return;
     }
     const unsigned long long gmask = wgroup_mask<NP>(lane);
@@ -125,9 +139,10 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
     const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
     const double pi_j = real ? m.pi[j] : 0.0;
 
-    double a = 0.0, P = 1.0;
+    const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0; // warm-up start (0: exact start)
+    double a = real ? 1.0 / (double)n : 0.0, P = 1.0;
     int eP = 0;
-    for (int64_t t = 0; t < T; ++t) {
+    for (int64_t t = tw; t < t1; ++t) {
         double o;
         int sym;
         const double p = wide_emit<NP, KIND>(m, j, real, o0 + t, obs_rm, mu_j, is_j, cn_j, gmask,
@@ -148,23 +163,29 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
         }
         const double c = wgroup_sum<NP>(nj);
         a = nj * fast_rcp(c);
-        int e;
-        P = frexp(P * c, &e);
-        eP += e;
-        if (real)
-            alpha_rm[(o0 + t) * n + j] = a;
+        if (t >= t0) {
+            int e;
+            P = frexp(P * c, &e);
+            eP += e;
+            if (real)
+                alpha_rm[(o0 + t) * n + j] = a;
+        } else if (t == t0 - 1 && real) {
+            a_entry[(int64_t)s * n + j] = a; // the entry vector this segment derived
+        }
     }
+    if (real)
+        a_exit[(int64_t)s * n + j] = a;
     if (j == 0)
-        logL_k[k] = log(P) + (double)eP * 0.693147180559945309417232121458;
+        logL_seg[s] = log(P) + (double)eP * 0.693147180559945309417232121458;
 }
 
-// statistics per trajectory: [n*n C' rows | n sum gamma | (gauss) n sum gamma d | n sum gamma d^2]
-// discrete symbol table: [K][n][M] (dstat)
+// statistics per segment: [n*n C' rows | n sum gamma | (gauss) n sum gamma d | n sum gamma d^2]
+// discrete symbol table: [nseg][n][M] (dstat)
 template <int NP, int KIND>
-__global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_t *off, int K,
+__global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_t *off, const Segs sg,
                                                  const void *obs_rm, const double *alpha_rm,
                                                  double *gamma_rm, double *gamma0, double *part,
-                                                 double *dstat)
+                                                 double *dstat, double *b_exit, double *b_entry)
 {
     constexpr int GP = 64 / NP;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -178,45 +199,75 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         sA[r * (NP + 1) + c] = (r < n && c < n) ? m.A[(int64_t)r * n + c] : 0.0;
     }
     __syncthreads();
-    const int k = blockIdx.x * GP + gi;
-    if (k >= K)
+    const int s = blockIdx.x * GP + gi;
+    if (s >= sg.nseg)
         return;
     const bool real = i < n;
+    const int k = sg.traj[s];
     const int64_t o0 = off[k];
     const int64_t T = off[k + 1] - o0;
+    const int64_t t0 = sg.t0[s], t1 = t0 + sg.len[s];
     const int S = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0);
-    double *mypart = part + (int64_t)k * S;
-    double *mytab = (KIND == EMIT_DISC) ? dstat + (int64_t)k * n * m.M : nullptr;
+    double *mypart = part + (int64_t)s * S;
+    double *mytab = (KIND == EMIT_DISC) ? dstat + (int64_t)s * n * m.M : nullptr;
     if (KIND == EMIT_DISC && real)
-        for (int s = 0; s < m.M; ++s)
-            mytab[(int64_t)i * m.M + s] = 0.0;
+        for (int q = 0; q < m.M; ++q)
+            mytab[(int64_t)i * m.M + q] = 0.0;
     double Crow[NP];
 #pragma unroll
     for (int c = 0; c < NP; ++c)
         Crow[c] = 0.0;
-    double sg = 0.0, sd = 0.0, sdd = 0.0;
-    if (T > 0) {
+    double sgm = 0.0, sd = 0.0, sdd = 0.0;
+    if (t1 > t0) {
         const unsigned long long gmask = wgroup_mask<NP>(lane);
         const double mu_i = (KIND == EMIT_GAUSS && real) ? m.mu[i] : 0.0;
         const double is_i = (KIND == EMIT_GAUSS && real) ? m.isig[i] : 0.0;
         const double cn_i = (KIND == EMIT_GAUSS && real) ? m.cnorm[i] : 0.0;
         const double *arow = sA + i * (NP + 1);
         double *xg = xb + gi * NP;
+        // one backward step: b <- A (p o b), rescaled by a power of two; returns A (p o b)[i]
+        auto back = [&](double p, double b) {
+            xg[i] = p * b;
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < NP; c += 2) {
+                const double2 x = *reinterpret_cast<const double2 *>(&xg[c]);
+                acc[(c / 2) & 3] = fma(arow[c], x.x, acc[(c / 2) & 3]);
+                acc[(c / 2) & 3] = fma(arow[c + 1], x.y, acc[(c / 2) & 3]);
+            }
+            return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        };
+        auto rescale = [&](double br) {
+            const int E = wgroup_max<NP>(br > 0.0 ? exponent_of(br) : -(1 << 28));
+            return ldexp(br, -E);
+        };
 
         double b = real ? 1.0 / (double)n : 0.0; // _hidden.c:79-88
-        double a = real ? alpha_rm[(o0 + T - 1) * n + i] : 0.0;
+        if (t1 < T) { // warm-up from te down to t1: beta at t1 - 1
+            const int64_t te = (t1 - 1 + sg.W < T - 1) ? t1 - 1 + sg.W : T - 1;
+            for (int64_t t = te; t >= t1; --t) {
+                double o;
+                int sym;
+                const double p = wide_emit<NP, KIND>(m, i, real, o0 + t, obs_rm, mu_i, is_i, cn_i,
+                                                     gmask, o, sym);
+                b = rescale(back(p, b));
+            }
+            if (real)
+                b_exit[(int64_t)s * n + i] = b;
+        }
+        double a = real ? alpha_rm[(o0 + t1 - 1) * n + i] : 0.0;
         double gam;
         {
             const double g = a * b;
             gam = g * fast_rcp(wgroup_sum<NP>(g));
         }
-        for (int64_t t = T - 1; t >= 0; --t) {
+        for (int64_t t = t1 - 1; t >= t0; --t) {
             double o = 0.0;
             int sym = 0;
             const double p = wide_emit<NP, KIND>(m, i, real, o0 + t, obs_rm, mu_i, is_i, cn_i,
                                                  gmask, o, sym);
             // consume gamma_t
-            sg += gam;
+            sgm += gam;
             if constexpr (KIND == EMIT_GAUSS) {
                 const double d = o - mu_i;
                 const double gd = gam * d;
@@ -234,15 +285,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                 break;
             }
             const double ap = real ? alpha_rm[(o0 + t - 1) * n + i] : 0.0;
-            xg[i] = p * b;
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int c = 0; c < NP; c += 2) {
-                const double2 x = *reinterpret_cast<const double2 *>(&xg[c]);
-                acc[(c / 2) & 3] = fma(arow[c], x.x, acc[(c / 2) & 3]);
-                acc[(c / 2) & 3] = fma(arow[c + 1], x.y, acc[(c / 2) & 3]);
-            }
-            const double br = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            const double br = back(p, b);
             const double q = ap * br;
             const double rS = fast_rcp(wgroup_sum<NP>(q));
             gam = q * rS;
@@ -253,8 +296,9 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                 Crow[c] = fma(w, x.x, Crow[c]);
                 Crow[c + 1] = fma(w, x.y, Crow[c + 1]);
             }
-            const int E = wgroup_max<NP>(br > 0.0 ? exponent_of(br) : -(1 << 28));
-            b = ldexp(br, -E);
+            b = rescale(br);
+            if (t == t0 && real) // beta one step before this segment, as derived here
+                b_entry[(int64_t)s * n + i] = b;
         }
     }
     if (real) {
@@ -262,7 +306,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         for (int c = 0; c < NP; ++c)
             if (c < n)
                 mypart[(int64_t)i * n + c] = Crow[c];
-        mypart[n * n + i] = sg;
+        mypart[n * n + i] = sgm;
         if constexpr (KIND == EMIT_GAUSS) {
             mypart[n * n + n + i] = sd;
             mypart[n * n + 2 * n + i] = sdd;
@@ -270,12 +314,46 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
     }
 }
 
+// boundary consistency of a segmented run (see k_spec_check): one thread per segment
+static __global__ void k_wide_check(const Segs sg, int n, const double *a_entry,
+                                    const double *a_exit, const double *b_exit,
+                                    const double *b_entry, double tol, unsigned int *result)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= sg.nseg || sg.len[s] == 0 || sg.t0[s] == 0)
+        return;
+    double dev = 0.0;
+    auto cmp = [&](const double *x, const double *y) {
+        double sx = 0.0, sy = 0.0;
+        for (int j = 0; j < n; ++j) {
+            sx += x[j];
+            sy += y[j];
+        }
+        if (!(sx > 0.0) || !(sy > 0.0)) {
+            dev = 1.0;
+            return;
+        }
+        for (int j = 0; j < n; ++j) {
+            const double xs = x[j] / sx, ys = y[j] / sy;
+            const double d = fabs(xs - ys);
+            const double r = (ys > 1e-280) ? d / ys : (d > 1e-280 ? 1.0 : 0.0);
+            dev = fmax(dev, r);
+        }
+    };
+    cmp(a_entry + (int64_t)s * n, a_exit + (int64_t)(s - 1) * n);
+    cmp(b_exit + (int64_t)(s - 1) * n, b_entry + (int64_t)s * n);
+    if (!(dev <= tol))
+        atomicAdd(&result[0], 1u);
+    atomicMax(&result[1], __float_as_uint((float)fmin(dev, 1.0)));
+}
+
 // packed statistics (bhmm_amd.h layout) from the per-trajectory partials; one wavefront per
 // output entry, trajectory-strided partial sums + fixed shuffle tree.
 template <int KIND>
-__global__ __launch_bounds__(64) void k_wide_finalize(const WideModel m, int K, const double *part,
-                                                      const double *dstat, const double *logL_k,
-                                                      const double *gamma0, double *stats)
+__global__ __launch_bounds__(64) void k_wide_finalize(const WideModel m, int K, int nseg,
+                                                      const double *part, const double *dstat,
+                                                      const double *logL_k, const double *gamma0,
+                                                      double *stats)
 {
     const int n = m.n;
     const int S = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0);
@@ -285,7 +363,7 @@ __global__ __launch_bounds__(64) void k_wide_finalize(const WideModel m, int K, 
     int e = blockIdx.x;
     double s = 0.0;
     if (e < S) {
-        for (int k = lane; k < K; k += 64)
+        for (int k = lane; k < nseg; k += 64)
             s += part[(int64_t)k * S + e];
         s = wave_sum(s);
         if (lane == 0) {
@@ -300,7 +378,7 @@ __global__ __launch_bounds__(64) void k_wide_finalize(const WideModel m, int K, 
     }
     e -= S;
     if (e < MN) {
-        for (int k = lane; k < K; k += 64)
+        for (int k = lane; k < nseg; k += 64)
             s += dstat[(int64_t)k * MN + e];
         s = wave_sum(s);
         if (lane == 0)

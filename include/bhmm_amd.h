@@ -149,6 +149,9 @@ int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const do
  *   "spec_enabled"  1/0  use speculative, verified chunk boundaries in bhmm_estep (default 1;
  *                        switched off automatically when verification keeps failing)
  *   "spec_W"        warm-up length in time steps (default 288, +50 % after a failed check)
+ *   "wide_segments" 1/0  (9..64 states) cut trajectories into time segments with the same
+ *                        verified warm-up boundaries; reading it returns the segment count in use
+ *   "wide_segment_len"   segment length for the next bhmm_ctx_set_observations (0 = automatic)
  *   "spec_ok", "spec_fail"  (read-only) E-steps whose boundaries verified / fell back
  *   "spec_last_dev" (read-only) largest relative boundary deviation of the last check */
 int bhmm_ctx_set_option(bhmm_ctx *ctx, const char *name, double value);

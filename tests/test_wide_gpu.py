@@ -171,3 +171,46 @@ def test_wide_path_sampling():
         np.testing.assert_allclose(emis[1, i], (sel - mu[i]).sum(), rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(emis[2, i], ((sel - mu[i]) ** 2).sum(), rtol=1e-9, atol=1e-9)
     eng.close()
+
+
+def test_wide_time_segments_verified_or_fallback():
+    """9..64 states: trajectories cut into time segments with warm-up boundaries; the result
+    must equal the serial recursion, and a too-short warm-up must be caught."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(21)
+    n = 20
+    A, pi, mu, sig = _random_model(n, rng, "gaussian")
+    obs = [rng.normal(0, 4, T) for T in (5000, 700, 1, 2600)]
+    ref = orc.estep("gaussian", obs, A, pi, mu, sig, want_gamma=True)
+    eng = Engine(0)
+    eng.set_option("wide_segment_len", 400)
+    eng.set_option("spec_W", 150)
+    eng.set_observations("gaussian", obs, n)
+    assert eng.get_option("wide_segments") > len(obs)
+    res = eng.estep(A, pi, mu, sig, store_gamma=True)
+    assert eng.get_option("spec_ok") == 1 and eng.get_option("spec_fail") == 0
+    _check(res, ref)
+    np.testing.assert_allclose(eng.gamma(0), ref["gammas"][0], rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(eng.gamma(3), ref["gammas"][3], rtol=1e-8, atol=1e-13)
+    eng.close()
+    eng = Engine(0)
+    eng.set_option("wide_segment_len", 400)
+    eng.set_option("spec_W", 1)                     # hopeless warm-up: detected, serial fallback
+    eng.set_observations("gaussian", obs, n)
+    res = eng.estep(A, pi, mu, sig)
+    assert eng.get_option("spec_fail") == 1
+    _check(res, ref)
+    res = eng.estep(A, pi, mu, sig)
+    _check(res, ref)
+    eng.close()
+    # discrete, 40 states
+    n, M = 40, 30
+    A, pi, B, _ = _random_model(n, rng, "discrete", M)
+    obs = [rng.integers(0, M, T).astype(np.int32) for T in (3000, 1200)]
+    ref = orc.estep("discrete", obs, A, pi, B)
+    eng = Engine(0)
+    eng.set_option("wide_segment_len", 500)
+    eng.set_observations("discrete", obs, n, nsymbols=M)
+    res = eng.estep(A, pi, B)
+    _check(res, ref)
+    eng.close()

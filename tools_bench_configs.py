@@ -85,7 +85,10 @@ def main():
         r = eng.estep(*args)
         assert abs(r.state_counts.sum() - K * T) < 1e-6 * K * T
         res.append(dict(config="configs[3] E-step, 64-state Gaussian 128 x 1e5 (wide family)",
-                        seconds=dt, timesteps_per_s=K * T / dt))
+                        seconds=dt, timesteps_per_s=K * T / dt,
+                        segments=eng.get_option("wide_segments"),
+                        spec={k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail",
+                                                             "spec_last_dev")}))
         eng.close()
         del obs, s
     if "c3" in which:
