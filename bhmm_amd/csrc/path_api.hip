@@ -52,56 +52,6 @@ struct Tmp { // scoped raw device allocations for the context-free entry points
 };
 
 template <int N>
-int viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
-                const double *par1, int32_t *paths_host)
-{
-    Model<N> m;
-    fill_model_pub<N>(m, c->n, c->kind, c->M, A, pi, par0, par1);
-    const int K = c->K;
-    const size_t words = (size_t)(c->total / VB + K) * N;
-    int rc;
-    if ((rc = c->d_scratch.ensure(words * sizeof(uint32_t))) ||
-        (rc = c->d_scratch2.ensure(((size_t)c->total + K) * sizeof(int32_t))))
-        return rc;
-    uint32_t *ptr = reinterpret_cast<uint32_t *>(c->d_scratch.p);
-    int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
-    int32_t *path = last + K;
-    const double *Bdev = nullptr;
-    if (c->kind == EMIT_DISC) {
-        if ((rc = c->d_Brm.ensure((size_t)c->n * c->M)))
-            return rc;
-        BHMM_HIP(hipMemcpyAsync(c->d_Brm.p, par0, (size_t)c->n * c->M * sizeof(double),
-                                hipMemcpyHostToDevice, c->stream));
-        Bdev = c->d_Brm.p;
-    }
-    constexpr int GP = 64 / N;
-    const dim3 grid((K + GP - 1) / GP), blk(64);
-    const void *obs = c->d_obs_rm.p;
-    switch (c->kind) {
-    case EMIT_GAUSS:
-        hipLaunchKernelGGL((k_viterbi_fwd<N, EMIT_GAUSS>), grid, blk, 0, c->stream, m,
-                           (const int64_t *)c->d_offsets.p, K, obs, Bdev, ptr, last);
-        break;
-    case EMIT_DISC:
-        hipLaunchKernelGGL((k_viterbi_fwd<N, EMIT_DISC>), grid, blk, 0, c->stream, m,
-                           (const int64_t *)c->d_offsets.p, K, obs, Bdev, ptr, last);
-        break;
-    default:
-        hipLaunchKernelGGL((k_viterbi_fwd<N, EMIT_EXPL>), grid, blk, 0, c->stream, m,
-                           (const int64_t *)c->d_offsets.p, K, obs, Bdev, ptr, last);
-    }
-    BHMM_HIP(hipGetLastError());
-    hipLaunchKernelGGL((k_viterbi_trace<N>), dim3((K + 63) / 64), dim3(64), 0, c->stream,
-                       (const int64_t *)c->d_offsets.p, K, (const uint32_t *)ptr,
-                       (const int32_t *)last, path);
-    BHMM_HIP(hipGetLastError());
-    BHMM_HIP(hipMemcpyAsync(paths_host, path, (size_t)c->total * sizeof(int32_t),
-                            hipMemcpyDeviceToHost, c->stream));
-    BHMM_HIP(hipStreamSynchronize(c->stream));
-    return BHMM_OK;
-}
-
-template <int N>
 int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1, const double *u, uint64_t seed, int32_t *paths, int64_t *counts,
                int64_t *n0, double *emis)
@@ -411,17 +361,8 @@ int bhmm_viterbi_batch(bhmm_ctx *c, const double *A, const double *pi, const dou
     if (c->kind == BHMM_EMIT_DISCRETE && !par0)
         return invalid_arg("discrete emissions need B");
     BHMM_HIP(hipSetDevice(c->device));
-    // all state counts use the LDS-exchange kernels (k_wide_viterbi_*): for N <= 8 they are
-    // ~3x faster than the shuffle-based k_viterbi_fwd (serial chain, latency bound)
+    // all state counts use the LDS-exchange kernels (k_wide_viterbi_*)
     return wide_viterbi_run(c, A, pi, par0, par1, paths);
-    switch (c->N) {
-    case 2:
-        return viterbi_run<2>(c, A, pi, par0, par1, paths);
-    case 4:
-        return viterbi_run<4>(c, A, pi, par0, par1, paths);
-    default:
-        return viterbi_run<8>(c, A, pi, par0, par1, paths);
-    }
 }
 
 int bhmm_sample_paths(bhmm_ctx *c, const double *A, const double *pi, const double *par0,

@@ -4,10 +4,13 @@
 // bit-identical to bhmm/hidden/impl_c/_hidden.c:203-281 and :330-378 given the same pobs /
 // alpha / uniforms.
 //
-// Both recursions are strictly serial in t (a chunked max-product would round differently),
-// so parallelism is: N lanes per trajectory (lane j owns state j), 64/N trajectories per
-// wavefront, trajectories across the grid.  Per-step all-gathers inside the N-lane group use
-// wavefront shuffles; normalising sums are taken in ascending state order in every lane.
+// Viterbi is strictly serial in t (a chunked max-product would round differently), so its
+// parallelism is: NP lanes per trajectory (lane j owns state j), 64/NP trajectories per
+// wavefront, trajectories across the grid; vectors are exchanged through LDS and normalising
+// sums are taken in ascending state order in every lane (k_wide_viterbi_*, all state counts).
+// Path sampling is exact AND parallel in time: for fixed uniforms the draws are maps of the
+// next state and maps compose exactly (k_smp_*); k_sample_path is the serial form behind the
+// single-trajectory entry point.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,159 +19,6 @@
 #include "wide_kernels.hpp"
 
 namespace bhmm {
-
-constexpr int VB = 8; // time steps per back-pointer word (4 bits each)
-
-// emission probability of MY state (lane j) at one step, plus the outlier rule
-template <int N, int KIND>
-__device__ __forceinline__ double emit_lane(const Model<N> &m, int j, int64_t gt,
-                                            const void *obs_rm, const double *B_g,
-                                            double mu_j, double sigma_j)
-{
-    double p;
-    if constexpr (KIND == EMIT_GAUSS) {
-        // _gaussian.c:18-20 with the reference's association
-        const double o = static_cast<const double *>(obs_rm)[gt];
-        const double d = (o - mu_j) / sigma_j;
-        p = (j < m.nreal) ? exp(-0.5 * d * d) : 0.0;
-    } else if constexpr (KIND == EMIT_DISC) {
-        const int sym = static_cast<const int32_t *>(obs_rm)[gt];
-        p = (j < m.nreal) ? B_g[(int64_t)j * m.M + sym] : 0.0;
-    } else {
-        p = (j < m.nreal) ? static_cast<const double *>(obs_rm)[gt * m.nreal + j] : 0.0;
-    }
-    return p;
-}
-
-// Forward (max-product) pass: back-pointers packed 4 bits per (t, j), final state per
-// trajectory.   ptr word index: (wbase[k] + t / 8) * N + j,  nibble t % 8.
-template <int N, int KIND>
-__global__ __launch_bounds__(64) void k_viterbi_fwd(const Model<N> m, const int64_t *off, int K,
-                                                    const void *obs_rm, const double *B_g,
-                                                    uint32_t *ptr, int32_t *last_state)
-{
-    constexpr int GP = 64 / N;
-    const int k = blockIdx.x * GP + threadIdx.x / N;
-    const int j = threadIdx.x % N;
-    if (k >= K)
-        return;
-    const int grp = (threadIdx.x & 63) / N;
-    const int64_t o0 = off[k];
-    const int64_t T = off[k + 1] - o0;
-    if (T <= 0)
-        return;
-    const int64_t wbase = o0 / VB + k;
-    double Acol[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-        Acol[i] = m.A[i * N + j];
-    const double mu_j = m.e0[j];
-    const double sg_j = (KIND == EMIT_GAUSS && j < m.nreal) ? m.e3[j] : 1.0;
-    const double cn_j = m.e2[j];
-
-    double v = 0.0;
-    for (int64_t tb = 0; tb < T; tb += VB) {
-        const int nb = (int)((T - tb) < VB ? (T - tb) : VB);
-        double p[VB];
-#pragma unroll
-        for (int q = 0; q < VB; ++q) {
-            p[q] = 0.0;
-            if (q < nb) {
-                p[q] = emit_lane<N, KIND>(m, j, o0 + tb + q, obs_rm, B_g, mu_j, sg_j);
-                if constexpr (KIND == EMIT_GAUSS) {
-                    p[q] = cn_j * p[q]; // C * exp(...), _gaussian.c:20
-                    // outlier rows (all states exactly 0) become all ones, outputmodel.py:126-130
-                    const unsigned long long nz = __ballot(p[q] != 0.0);
-                    const unsigned long long gm = ((N == 64) ? ~0ull : ((1ull << N) - 1)) << (grp * N);
-                    if ((nz & gm) == 0ull)
-                        p[q] = (j < m.nreal) ? 1.0 : 0.0;
-                }
-            }
-        }
-        uint32_t word = 0;
-#pragma unroll
-        for (int q = 0; q < VB; ++q) {
-            if (q < nb) {
-                double vn;
-                if (tb + q == 0) {
-                    vn = p[q] * m.pi[j]; // _hidden.c:232
-                } else {
-                    double vv[N];
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        vv[i] = __shfl(v, i, N);
-                    double bh = vv[0] * Acol[0], bv = vv[0], bA = Acol[0];
-                    int bi = 0;
-#pragma unroll
-                    for (int i = 1; i < N; ++i) {
-                        const double h = vv[i] * Acol[i]; // _hidden.c:249
-                        if (h > bh) {                     // strict: first maximum wins (:193)
-                            bh = h;
-                            bv = vv[i];
-                            bA = Acol[i];
-                            bi = i;
-                        }
-                    }
-                    word |= (uint32_t)bi << (4 * q);
-                    vn = p[q] * bv * bA; // (pobs * v[maxi]) * A[maxi][j], _hidden.c:253
-                }
-                double S = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-                    S += __shfl(vn, i, N); // ascending order, _hidden.c:254
-                v = vn / S;
-            }
-        }
-        ptr[(wbase + tb / VB) * N + j] = word;
-    }
-    // final state: first maximum of v (_hidden.c:268)
-    double bm = __shfl(v, 0, N);
-    int bi = 0;
-#pragma unroll
-    for (int i = 1; i < N; ++i) {
-        const double x = __shfl(v, i, N);
-        if (x > bm) {
-            bm = x;
-            bi = i;
-        }
-    }
-    if (j == 0)
-        last_state[k] = bi;
-}
-
-// Back-trace: path[t] = ptr[t+1][path[t+1]] (_hidden.c:269-272).  One lane per trajectory;
-// the N words of an 8-step block are fetched together and chased in registers.
-template <int N>
-__global__ void k_viterbi_trace(const int64_t *off, int K, const uint32_t *ptr,
-                                const int32_t *last_state, int32_t *path)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K)
-        return;
-    const int64_t o0 = off[k];
-    const int64_t T = off[k + 1] - o0;
-    if (T <= 0)
-        return;
-    const int64_t wbase = o0 / VB + k;
-    int cur = last_state[k];
-    int32_t *out = path + o0;
-    out[T - 1] = cur;
-    for (int64_t blk = (T - 1) / VB; blk >= 0; --blk) {
-        uint32_t w[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            w[i] = ptr[(wbase + blk) * N + i];
-        const int64_t thi = (blk * VB + VB - 1 < T - 1) ? blk * VB + VB - 1 : T - 1;
-        for (int64_t t = thi; t >= blk * VB && t >= 1; --t) {
-            uint32_t word = w[0];
-#pragma unroll
-            for (int i = 1; i < N; ++i)
-                word = (cur == i) ? w[i] : word;
-            cur = (word >> (4 * (int)(t - blk * VB))) & 0xF;
-            out[t - 1] = cur;
-        }
-    }
-}
 
 // splitmix64-based uniform in [0,1) for global step index x (device-generated stream)
 __device__ __forceinline__ double uniform01(uint64_t seed, uint64_t x)
@@ -600,81 +450,6 @@ __global__ void k_add_partials(const double *partials, int nblocks, int count, d
     for (int b = 0; b < nblocks; ++b)
         s += partials[(int64_t)b * count + e];
     dst[e] = s;
-}
-
-// ---- hidden-path statistics for the Gibbs sweep (generic_hmm.py:297-334,398-431) ----------
-// one lane per chunk: integer transition / start counts (exact), per-state emission sums.
-template <int N, int KIND>
-__global__ __launch_bounds__(256) void k_path_stats(const Model<N> m, const Chunks ch,
-                                                    const int64_t *off, const void *obs_rm,
-                                                    const int32_t *path,
-                                                    unsigned long long *counts, // [N*N + N]
-                                                    double *epartials)         // [grid][3N] / LDS
-{
-    extern __shared__ double lds[];
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int len = ch.len[g];
-    const int k = ch.traj[g];
-    const int64_t t0 = ch.t0[g];
-    const int64_t base = ch.goff[g];
-    const int64_t Tk = len > 0 ? off[k + 1] - off[k] : 0;
-    __shared__ unsigned int cnt[N * N + N];
-    for (int e = threadIdx.x; e < N * N + N; e += blockDim.x)
-        cnt[e] = 0u;
-    if constexpr (KIND == EMIT_DISC)
-        for (int e = threadIdx.x; e < m.M * N; e += blockDim.x)
-            lds[e] = 0.0;
-    __syncthreads();
-    double s0[N], s1[N], s2[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-        s0[i] = s1[i] = s2[i] = 0.0;
-    for (int s = 0; s < len; ++s) {
-        const int st = path[base + s];
-        if (t0 + s == 0)
-            atomicAdd(&cnt[N * N + st], 1u);
-        if (t0 + s + 1 < Tk)
-            atomicAdd(&cnt[st * N + path[base + s + 1]], 1u);
-        if constexpr (KIND == EMIT_GAUSS) {
-            const double o = static_cast<const double *>(obs_rm)[base + s];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const double d = o - m.e0[i];
-                const bool hit = (st == i);
-                s0[i] += hit ? 1.0 : 0.0;
-                s1[i] += hit ? d : 0.0;
-                s2[i] += hit ? d * d : 0.0;
-            }
-        }
-        if constexpr (KIND == EMIT_DISC) {
-            const int sym = static_cast<const int32_t *>(obs_rm)[base + s];
-            atomicAdd(&lds[sym * N + st], 1.0); // integer-valued: exact, order-independent
-        }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < N * N + N; e += blockDim.x)
-        if (cnt[e])
-            atomicAdd(&counts[e], (unsigned long long)cnt[e]);
-    if constexpr (KIND == EMIT_GAUSS) {
-        __shared__ double red[4][3 * N];
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const double a = wave_sum(s0[i]), b = wave_sum(s1[i]), c = wave_sum(s2[i]);
-            if (lane == 0) {
-                red[wv][i] = a;
-                red[wv][N + i] = b;
-                red[wv][2 * N + i] = c;
-            }
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x)
-            epartials[(int64_t)blockIdx.x * 3 * N + e] =
-                ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
-    }
-    if constexpr (KIND == EMIT_DISC)
-        for (int e = threadIdx.x; e < m.M * N; e += blockDim.x)
-            epartials[(int64_t)blockIdx.x * m.M * N + e] = lds[e];
 }
 
 // =========================================================================================
