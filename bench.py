@@ -186,10 +186,14 @@ def main():
     host_stats = torch.zeros(S, dtype=torch.float64).pin_memory()
 
     def one_step():
+        if not distributed:
+            # single GPU: the library lands the statistics in pinned host memory itself
+            eng.estep_launch(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
+            host_stats.copy_(torch.from_numpy(eng.estep_fetch().packed))
+            return host_stats
         eng.estep_launch(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"],
                          stats_dev=stats.data_ptr())
-        if distributed:
-            dist.all_reduce(stats)                      # RCCL sum of the packed statistics
+        dist.all_reduce(stats)                          # RCCL sum of the packed statistics
         host_stats.copy_(stats, non_blocking=True)
         stream.synchronize()                            # statistics are on the host
         return host_stats

@@ -52,6 +52,8 @@ static size_t smem_fwdbwd(int M)
            sizeof(double);
 }
 
+static int stats_size(const bhmm_ctx *c);
+
 // One E-step launch sequence for a fixed padded N.
 template <int N>
 struct Runner {
@@ -157,7 +159,7 @@ struct Runner {
         if ((rc = finish<KIND>(c, m, stats_dev)))
             return rc;
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
-        if ((rc = spec_verdict(c, true, verified)))
+        if ((rc = spec_verdict(c, true, verified, stats_dev)))
             return rc;
         if (*verified)
             c->ev_pending = true;
@@ -233,7 +235,8 @@ struct Runner {
     }
 
     // verdict of a speculative pass (synchronises the stream)
-    static int spec_verdict(bhmm_ctx *c, bool with_beta, bool *verified)
+    static int spec_verdict(bhmm_ctx *c, bool with_beta, bool *verified,
+                            const double *stats_src = nullptr)
     {
         hipLaunchKernelGGL((k_spec_check<N>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
                            chunks_of(c), c->G, (const double *)c->d_aentry.p,
@@ -243,12 +246,21 @@ struct Runner {
         BHMM_HIP(hipGetLastError());
         BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 2 * sizeof(unsigned int),
                                 hipMemcpyDeviceToHost, c->stream));
+        c->prefetched = false;
+        if (stats_src) { // the results ride on the same synchronisation as the verdict
+            const int S = stats_size(c);
+            BHMM_HIP(hipMemcpyAsync(c->h_pinned, stats_src, S * sizeof(double),
+                                    hipMemcpyDeviceToHost, c->stream));
+            BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, c->K * sizeof(double),
+                                    hipMemcpyDeviceToHost, c->stream));
+        }
         BHMM_HIP(hipStreamSynchronize(c->stream));
         float dev;
         memcpy(&dev, &c->h_specres[1], sizeof(float));
         c->spec_last_dev = dev;
         *verified = c->h_specres[0] == 0;
         if (*verified) {
+            c->prefetched = stats_src != nullptr;
             c->spec_ok++;
         } else {
             // lengthen the warm-up for the next call; give up once it would cost more than the
@@ -857,6 +869,8 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     }
     c->gamma_valid = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
     double *sd = stats_dev ? stats_dev : c->d_stats.p;
+    c->last_stats_internal = (stats_dev == nullptr);
+    c->prefetched = false;
     if (c->wide)
         return wide_estep(c, A, pi, par0, par1, sd, flags);
     return BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
@@ -868,11 +882,14 @@ int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
         return invalid("no observations loaded");
     BHMM_HIP(hipSetDevice(c->device));
     const int S = stats_size(c);
-    BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->d_stats.p, S * sizeof(double), hipMemcpyDeviceToHost,
-                            c->stream));
-    BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, c->K * sizeof(double),
-                            hipMemcpyDeviceToHost, c->stream));
-    BHMM_HIP(hipStreamSynchronize(c->stream));
+    if (!(c->prefetched && c->last_stats_internal)) {
+        BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->d_stats.p, S * sizeof(double), hipMemcpyDeviceToHost,
+                                c->stream));
+        BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, c->K * sizeof(double),
+                                hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->prefetched = false;
     collect_timing(c);
     if (stats)
         memcpy(stats, c->h_pinned, S * sizeof(double));
