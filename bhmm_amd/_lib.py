@@ -76,6 +76,7 @@ SIGNATURES = {
     "bhmm_ctx_last_kernel_ms": (ctypes.c_double, [c_void_p, ctypes.c_int]),
     "bhmm_ctx_stream": (c_void_p, [c_void_p]),
     "bhmm_ctx_sync": (ctypes.c_int, [c_void_p]),
+    "bhmm_diag_exp_nonpos": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int64]),
 }
 
 _lib = None

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "host_common.hpp"
+#include "estep_sweep.hpp"
 
 namespace bhmm {
 
@@ -110,15 +111,27 @@ struct Runner {
         const Chunks ch = chunks_of(c);
         const int nblk = c->Gp / 64; // one workgroup per CI record group (64 chunks)
         const size_t sm = smem_fwdbwd<N, KIND>(c->M);
-        if (sm > 64 * 1024)
-            BHMM_HIP(hipFuncSetAttribute((const void *)(k_fwdbwd<N, KIND, MODE, SPEC>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        hipLaunchKernelGGL((k_fwdbwd<N, KIND, MODE, SPEC>), dim3(nblk), dim3(32 * N), sm, c->stream, m,
-                           ch, (const void *)c->d_obs_ci.p, (const double *)c->d_Bt.p,
-                           c->d_aentry.p, c->d_bexit.p, c->d_aexit.p, c->d_bentry.p, c->spec_W,
-                           c->d_ws.p,
-                           store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
-                           c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p);
+        if constexpr (MODE == MODE_ESTEP) {
+            if (sm > 64 * 1024)
+                BHMM_HIP(hipFuncSetAttribute((const void *)(k_estep<N, KIND, SPEC>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+            hipLaunchKernelGGL((k_estep<N, KIND, SPEC>), dim3(nblk), dim3(32 * N), sm, c->stream, m,
+                               ch, (const void *)c->d_obs_ci.p, (const void *)c->d_obs_rm.p,
+                               (const int64_t *)c->d_offsets.p, (const double *)c->d_Bt.p,
+                               c->d_aentry.p, c->d_bexit.p, c->d_aexit.p, c->d_bentry.p, c->spec_W,
+                               c->d_ws.p, store_gamma ? c->d_gamma_ci.p : (double *)nullptr,
+                               c->d_logLc.p, c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p);
+        } else {
+            if (sm > 64 * 1024)
+                BHMM_HIP(hipFuncSetAttribute((const void *)(k_fwdbwd<N, KIND, MODE, SPEC>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+            hipLaunchKernelGGL((k_fwdbwd<N, KIND, MODE, SPEC>), dim3(nblk), dim3(32 * N), sm,
+                               c->stream, m, ch, (const void *)c->d_obs_ci.p,
+                               (const double *)c->d_Bt.p, c->d_aentry.p, c->d_bexit.p, c->d_aexit.p,
+                               c->d_bentry.p, c->spec_W, c->d_ws.p,
+                               store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
+                               c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p);
+        }
         BHMM_HIP(hipGetLastError());
         BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
         return BHMM_OK;
@@ -783,6 +796,29 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     }
     BHMM_HIP(hipStreamSynchronize(c->stream));
     return BHMM_OK;
+}
+
+int bhmm_diag_exp_nonpos(double *y, const double *x, int64_t n)
+{
+    if (!y || !x || n < 1)
+        return invalid("NULL argument or empty problem");
+    double *dx = nullptr, *dy = nullptr;
+    BHMM_HIP(hipMalloc(reinterpret_cast<void **>(&dx), (size_t)n * sizeof(double)));
+    if (hipMalloc(reinterpret_cast<void **>(&dy), (size_t)n * sizeof(double)) != hipSuccess) {
+        (void)hipFree(dx);
+        return hip_fail(hipErrorOutOfMemory, "hipMalloc");
+    }
+    hipError_t e = hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_exp_nonpos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0,
+                           (const double *)dx, dy, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(y, dy, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    return e == hipSuccess ? BHMM_OK : hip_fail(e, "bhmm_diag_exp_nonpos");
 }
 
 int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)

@@ -1,0 +1,605 @@
+// estep_sweep.hpp -- k_estep: the fused forward/backward sweep of the E-step (2, 4, 8 states).
+//
+// Same lane mapping as k_fwdbwd (estep_kernels.hpp): H = N/2 lanes per chunk, lane q owns the
+// state pair (2q, 2q+1).  What this kernel changes is the instruction stream of the four
+// loops, which bound the E-step (fp64 VALU):
+//   * alpha is carried up to a power of two (the group's largest entry in [0.5, 1)); gamma and
+//     xi are normalised by S_t = sum_i alpha_{t-1}[i] (A (p_t o beta_t))[i] in the backward
+//     sweep (hidden/api.py:176-186), where the scale of alpha cancels, and the log-likelihood
+//     (_hidden.c:57-66) is the exponent sum plus one log per chunk.  This removes the sum /
+//     reciprocal / multiply chain from every forward step.
+//   * the outlier rule of the gaussian model (outputmodel.py:119-131) is evaluated lazily: an
+//     all-zero emission row makes the new vector exactly zero, which the exponent extraction
+//     sees for free; the rule itself runs in a branch that is taken only then.
+//   * exp() of the gaussian density is a branch-free kernel for non-positive arguments.
+//   * every load is issued two steps (main sweeps) or four steps (warm-ups) ahead of its use;
+//     the warm-ups of the speculative boundaries read the trajectory-major copy of the
+//     observations, which needs no walk over the chunk table.
+#pragma once
+
+#include "estep_kernels.hpp"
+
+namespace bhmm {
+
+// exp(x) for x <= 0 to about 1 ulp: x = k ln2 + r, |r| <= ln2/2, exp(r) = 1 + r + r^2 q(r) with
+// q the degree-9 minimax polynomial of tools/gen_exp_poly.py (approximation error 7.5e-18).
+// Arguments below -750 (including -inf) give 0 like exp(); a NaN argument also gives 0 -- the
+// caller restores NaN propagation in its outlier branch (fix_outlier).
+__device__ __forceinline__ double exp_nonpos(double x)
+{
+    x = fmax(x, -750.0);
+    const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma(k, -0x1.62e42fefa39efp-1, x);
+    r = fma(k, -0x1.abc9e3b39803fp-56, r);
+    double q = 0x1.ad7e38e167506p-26;
+    q = fma(q, r, 0x1.28ae7908135d8p-22);
+    q = fma(q, r, 0x1.71df27c33abefp-19);
+    q = fma(q, r, 0x1.a01998fd42e01p-16);
+    q = fma(q, r, 0x1.a01a012882c92p-13);
+    q = fma(q, r, 0x1.6c16c184889e3p-10);
+    q = fma(q, r, 0x1.111111112836cp-7);
+    q = fma(q, r, 0x1.55555555506eap-5);
+    q = fma(q, r, 0x1.55555555554f7p-3);
+    q = fma(q, r, 0x1.000000000000ap-1);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(q, (int)k);
+}
+
+static __global__ void k_exp_nonpos(const double *x, double *y, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        y[i] = exp_nonpos(x[i]);
+}
+
+// my two states' slice of the emission model
+struct EmisPair {
+    double mu[2]; // gaussian: mean
+    double nh[2]; // gaussian: -1/(2 sigma^2)
+    double cn[2]; // gaussian: 1/(sqrt(2 pi) sigma)
+};
+
+// observation at position pos of the trajectory-major copy (same concatenation as the input)
+template <int N, int KIND>
+__device__ __forceinline__ ObsIn load_obs_rm(const void *obs_rm, int64_t pos, int q, int nreal)
+{
+    ObsIn in;
+    in.o = 0.0;
+    in.sym = 0;
+    in.pp = make_double2(0.0, 0.0);
+    if constexpr (KIND == EMIT_GAUSS) {
+        in.o = static_cast<const double *>(obs_rm)[pos];
+    } else if constexpr (KIND == EMIT_DISC) {
+        in.sym = static_cast<const int32_t *>(obs_rm)[pos];
+    } else {
+        const double *row = static_cast<const double *>(obs_rm) + pos * nreal;
+        in.pp.x = (2 * q < nreal) ? row[2 * q] : 0.0;
+        in.pp.y = (2 * q + 1 < nreal) ? row[2 * q + 1] : 0.0;
+    }
+    return in;
+}
+
+// emission probabilities of my two states WITHOUT the outlier rule; d = o - mu (gaussian)
+template <int N, int KIND>
+__device__ __forceinline__ void emit_raw(const ObsIn &in, const double *Bt, int q,
+                                         const EmisPair &em, double (&p)[2], double (&d)[2])
+{
+    if constexpr (KIND == EMIT_GAUSS) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            d[b] = in.o - em.mu[b];
+            p[b] = em.cn[b] * exp_nonpos(d[b] * d[b] * em.nh[b]);
+        }
+    } else if constexpr (KIND == EMIT_DISC) {
+        const double2 x = *reinterpret_cast<const double2 *>(Bt + (int64_t)in.sym * N + 2 * q);
+        p[0] = x.x;
+        p[1] = x.y;
+        d[0] = d[1] = 0.0;
+    } else {
+        p[0] = in.pp.x;
+        p[1] = in.pp.y;
+        d[0] = d[1] = 0.0;
+    }
+}
+
+// The outlier rule, outputmodel.py:126-130: a row of pobs that is zero for every state becomes a
+// row of ones.  Called only after a zero/denormal product was seen; returns true if p changed.
+// A NaN observation (emit_raw turned it into p = 0) is turned back into NaN here.
+template <int N, int KIND>
+__device__ __forceinline__ bool fix_outlier(const ObsIn &in, int q, int nreal,
+                                            unsigned long long gmask, double (&p)[2])
+{
+    if constexpr (KIND != EMIT_GAUSS) {
+        return false;
+    } else {
+        const bool nz = (p[0] != 0.0) || (p[1] != 0.0);
+        if ((__ballot(nz) & gmask) != 0ull)
+            return false;
+        const double one = (in.o != in.o) ? in.o : 1.0;
+        p[0] = (2 * q < nreal) ? one : 0.0;
+        p[1] = (2 * q + 1 < nreal) ? one : 0.0;
+        return true;
+    }
+}
+
+// high dword of a non-negative double orders like the value; its top bits are the exponent
+__device__ __forceinline__ bool tiny_hi(int hm) { return hm < 0x00100000; }
+
+// a <- 2^ne (s o p), the group's largest entry brought into [0.5, 1); returns the exponent
+// removed (-ne).  Zero / denormal results take the slow branch: outlier rule, then frexp.
+template <int N, int KIND>
+__device__ __forceinline__ int scaled_emit(const ObsIn &in, int q, int nreal,
+                                           unsigned long long gmask, const double (&s)[2],
+                                           double (&p)[2], double (&a)[2])
+{
+    constexpr int H = N / 2;
+    double n0 = s[0] * p[0], n1 = s[1] * p[1];
+    const int hm = grp_max_i32<H>(max(__double2hiint(n0), __double2hiint(n1)));
+    int ne;
+    if (__builtin_expect(__ballot(tiny_hi(hm)) != 0ull, 0)) {
+        if (fix_outlier<N, KIND>(in, q, nreal, gmask, p)) {
+            n0 = s[0] * p[0];
+            n1 = s[1] * p[1];
+        }
+        ne = -grp_max_i32<H>(max(exponent_of(n0), exponent_of(n1)));
+    } else {
+        ne = 1022 - (hm >> 20);
+    }
+    a[0] = ldexp(n0, ne);
+    a[1] = ldexp(n1, ne);
+    return -ne;
+}
+
+// s = (a^T A)[my two states]:  all-gather of a over the group, my two columns of A
+template <int N>
+__device__ __forceinline__ void fwd_matvec(const double (&a)[2], const double (&Ac)[N][2],
+                                           double (&s)[2])
+{
+    double af[N];
+    grp_gather<N>(a, af);
+    s[0] = af[0] * Ac[0][0];
+    s[1] = af[0] * Ac[0][1];
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        s[0] = fma(af[i], Ac[i][0], s[0]);
+        s[1] = fma(af[i], Ac[i][1], s[1]);
+    }
+}
+
+// r = (A bb)[my two states], bf = all-gather of bb
+template <int N>
+__device__ __forceinline__ void bwd_matvec(const double (&bb)[2], const double (&Ar)[2][N],
+                                           double (&bf)[N], double (&r)[2])
+{
+    grp_gather<N>(bb, bf);
+    r[0] = Ar[0][0] * bf[0];
+    r[1] = Ar[1][0] * bf[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) {
+        r[0] = fma(Ar[0][j], bf[j], r[0]);
+        r[1] = fma(Ar[1][j], bf[j], r[1]);
+    }
+}
+
+// One backward step without statistics: b <- 2^ne A (p o b); p may be replaced by the outlier
+// row.  bf (the gathered p o b) is returned for the xi accumulation of the caller.
+template <int N, int KIND>
+__device__ __forceinline__ void beta_step(const ObsIn &in, int q, int nreal,
+                                          unsigned long long gmask, const double (&Ar)[2][N],
+                                          double (&p)[2], const double (&b)[2], double (&bf)[N],
+                                          double (&r)[2], int &ne)
+{
+    constexpr int H = N / 2;
+    double bb[2] = {p[0] * b[0], p[1] * b[1]};
+    bwd_matvec<N>(bb, Ar, bf, r);
+    const int hm = grp_max_i32<H>(max(__double2hiint(r[0]), __double2hiint(r[1])));
+    if (__builtin_expect(__ballot(tiny_hi(hm)) != 0ull, 0)) {
+        if (fix_outlier<N, KIND>(in, q, nreal, gmask, p)) {
+            bb[0] = p[0] * b[0];
+            bb[1] = p[1] * b[1];
+            bwd_matvec<N>(bb, Ar, bf, r);
+        }
+        ne = -grp_max_i32<H>(max(exponent_of(r[0]), exponent_of(r[1])));
+    } else {
+        ne = 1022 - (hm >> 20);
+    }
+}
+
+// =========================================================================================
+// k_estep<N, KIND, SPEC>: forward sweep (alpha -> CI workspace, chunk log-likelihood), then
+// backward sweep with gamma / xi / emission statistics in registers.
+//   SPEC: chunk-boundary vectors by warm-up over W steps, verified afterwards by k_spec_check
+//   (see k_fwdbwd); otherwise they are read from k_stitch.
+// Workgroup = one CI record group (64 chunks) = 32*N threads.
+// =========================================================================================
+template <int N, int KIND, bool SPEC>
+__global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
+    const Model<N> m, const Chunks ch, const void *obs_ci, const void *obs_rm,
+    const int64_t *toff,   // [K+1] trajectory offsets (time steps)
+    const double *Bt_g, double *alpha_entry, double *beta_exit,
+    double *a_exit,        // SPEC: [G][N] alpha at each chunk's last step (any scale)
+    double *b_entry,       // SPEC: [G][N] beta one step before each chunk, as the chunk derived it
+    int W,                 // SPEC: warm-up length
+    double *ws,            // CI workspace: alpha up to a power of two per step
+    double *gamma_ci,      // CI gamma, or nullptr
+    double *logL_chunk,    // [G] log of the product of the chunk's scaling factors
+    double *gamma0,        // [K][N] gamma at t = 0 of every trajectory
+    double *partials,      // [gridDim.x][S] register statistics per workgroup
+    double *disc_partials) // [gridDim.x][M*N] discrete emission statistics per workgroup
+{
+    using SL = StatLayout<N, KIND>;
+    constexpr int H = N / 2;
+    constexpr int NW = (64 * H + 63) / 64; // wavefronts per workgroup
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *red = smem;                                     // [NW][S]
+    double *Bt = smem + NW * SL::S;                         // [M][N]
+    double *dstat = Bt + (KIND == EMIT_DISC ? m.M * N : 0); // [M][N]
+    if constexpr (KIND == EMIT_DISC) {
+        stage_Bt<N>(Bt, Bt_g, m.M);
+        for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
+            dstat[i] = 0.0;
+        __syncthreads();
+    }
+    const int cl = threadIdx.x / H; // chunk within the record group == CI lane
+    const int q = threadIdx.x % H;  // my state pair
+    const int64_t g = (int64_t)blockIdx.x * 64 + cl;
+    const int len = ch.len[g];
+    const int64_t t0 = ch.t0[g];
+    const int64_t goff = ch.goff[g];
+    const bool first = (t0 == 0);
+    const int nreal = m.nreal;
+    const unsigned long long gmask = ((1ull << H) - 1) << ((threadIdx.x & 63) / H * H);
+    const int64_t rec0 = ci_rec(g, 0, ch.Lmax);
+
+    EmisPair em;
+    double pi2[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        em.mu[b] = m.e0[2 * q + b];
+        em.nh[b] = -0.5 * m.e1[2 * q + b] * m.e1[2 * q + b];
+        em.cn[b] = m.e2[2 * q + b];
+        pi2[b] = m.pi[2 * q + b];
+    }
+    const double u0 = (2 * q < nreal) ? 1.0 / (double)nreal : 0.0;
+    const double u1 = (2 * q + 1 < nreal) ? 1.0 / (double)nreal : 0.0;
+
+    double Cacc[2][N], sg[2], sd[2], sdd[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        sg[b] = sd[b] = sdd[b] = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            Cacc[b][j] = 0.0;
+    }
+
+    if (len > 0) {
+        double a[2];
+        double2 aent = make_double2(0.0, 0.0); // the vector this chunk was entered with
+        // ---------------- forward sweep (_hidden.c:16-66) ------------------------------
+        {
+            double Ac[N][2];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                Ac[i][0] = m.A[i * N + 2 * q];
+                Ac[i][1] = m.A[i * N + 2 * q + 1];
+            }
+            int eP = 0;       // sum of the exponents removed
+            double Sin = 1.0; // sum of the entry vector
+            int s = 0;
+            if (first) {
+                // alpha_0 = pi o p_0, _hidden.c:28-39
+                const ObsIn in = load_obs<N, KIND>(obs_ci, rec0, cl, q);
+                double p[2], d[2];
+                emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                eP = scaled_emit<N, KIND>(in, q, nreal, gmask, pi2, p, a);
+                *ci_pair(ws, rec0, N, q, cl) = make_double2(a[0], a[1]);
+                s = 1;
+            } else {
+                if constexpr (SPEC) {
+                    // warm-up over the nw steps before the chunk, from the uniform vector or
+                    // -- where that reaches the start of the trajectory -- exactly from pi
+                    int nw = (int)(t0 < (int64_t)W ? t0 : (int64_t)W);
+                    int64_t pos = goff - nw;
+                    auto wstep = [&](const ObsIn &in) {
+                        double p[2], d[2], sv[2];
+                        emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                        fwd_matvec<N>(a, Ac, sv);
+                        (void)scaled_emit<N, KIND>(in, q, nreal, gmask, sv, p, a);
+                    };
+                    if ((int64_t)nw == t0) {
+                        const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
+                        double p[2], d[2];
+                        emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                        (void)scaled_emit<N, KIND>(in, q, nreal, gmask, pi2, p, a);
+                        ++pos;
+                        --nw;
+                    } else {
+                        a[0] = u0;
+                        a[1] = u1;
+                    }
+                    for (int i = nw & 3; i > 0; --i) {
+                        const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
+                        wstep(in);
+                        ++pos;
+                    }
+                    nw &= ~3;
+                    if (nw > 0) {
+                        ObsIn c[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            c[j] = load_obs_rm<N, KIND>(obs_rm, pos + j, q, nreal);
+                        for (; nw > 0; nw -= 4) {
+                            pos += 4;
+                            ObsIn nx[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                nx[j] = c[j];
+                            if (nw > 4) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    nx[j] = load_obs_rm<N, KIND>(obs_rm, pos + j, q, nreal);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                wstep(c[j]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                c[j] = nx[j];
+                        }
+                    }
+                    aent = make_double2(a[0], a[1]);
+                    *reinterpret_cast<double2 *>(alpha_entry + g * N + 2 * q) = aent;
+                } else {
+                    // entry vector from k_stitch (power-of-two scaled)
+                    aent = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
+                    a[0] = aent.x;
+                    a[1] = aent.y;
+                }
+                Sin = grp_sum<H>(a[0] + a[1]);
+            }
+            auto fstep = [&](const ObsIn &in, int64_t rec) {
+                double p[2], d[2], sv[2];
+                emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                fwd_matvec<N>(a, Ac, sv);
+                eP += scaled_emit<N, KIND>(in, q, nreal, gmask, sv, p, a);
+                *ci_pair(ws, rec, N, q, cl) = make_double2(a[0], a[1]);
+            };
+            int64_t rec = rec0 + s;
+            int rem = len - s;
+            if (rem & 1) {
+                const ObsIn in = load_obs<N, KIND>(obs_ci, rec, cl, q);
+                fstep(in, rec);
+                ++rec;
+                --rem;
+            }
+            if (rem > 0) {
+                ObsIn c0 = load_obs<N, KIND>(obs_ci, rec, cl, q);
+                ObsIn c1 = load_obs<N, KIND>(obs_ci, rec + 1, cl, q);
+                for (; rem > 0; rem -= 2) {
+                    ObsIn n0 = c0, n1 = c1;
+                    if (rem > 2) {
+                        n0 = load_obs<N, KIND>(obs_ci, rec + 2, cl, q);
+                        n1 = load_obs<N, KIND>(obs_ci, rec + 3, cl, q);
+                    }
+                    fstep(c0, rec);
+                    fstep(c1, rec + 1);
+                    rec += 2;
+                    c0 = n0;
+                    c1 = n1;
+                }
+            }
+            const double Sfin = grp_sum<H>(a[0] + a[1]);
+            if (q == 0)
+                logL_chunk[g] = log(Sfin / Sin) + (double)eP * 0.693147180559945309417232121458;
+            if constexpr (SPEC)
+                *reinterpret_cast<double2 *>(a_exit + g * N + 2 * q) = make_double2(a[0], a[1]);
+        }
+
+        // ---------------- backward sweep (_hidden.c:69-110, hidden/api.py:176-186) ----------
+        double Ar[2][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            Ar[0][i] = m.A[(2 * q) * N + i];
+            Ar[1][i] = m.A[(2 * q + 1) * N + i];
+        }
+        const int k = ch.traj[g];
+        double b2[2], gam[2];
+        if constexpr (SPEC) {
+            // beta at my last step: constant at the end of the trajectory (_hidden.c:79-88),
+            // otherwise warmed up backwards over the nw steps after the chunk -- which is the
+            // same start vector where the warm-up reaches the end of the trajectory
+            const int64_t after = (toff[k + 1] - toff[k]) - (t0 + len);
+            int nw = (int)(after < (int64_t)W ? after : (int64_t)W);
+            int64_t pos = goff + len + nw - 1;
+            b2[0] = u0;
+            b2[1] = u1;
+            auto wstep = [&](const ObsIn &in) {
+                double p[2], d[2], bf[N], r[2];
+                int ne;
+                emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                beta_step<N, KIND>(in, q, nreal, gmask, Ar, p, b2, bf, r, ne);
+                b2[0] = ldexp(r[0], ne);
+                b2[1] = ldexp(r[1], ne);
+            };
+            for (int i = nw & 3; i > 0; --i) {
+                const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
+                wstep(in);
+                --pos;
+            }
+            nw &= ~3;
+            if (nw > 0) {
+                ObsIn c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    c[j] = load_obs_rm<N, KIND>(obs_rm, pos - j, q, nreal);
+                for (; nw > 0; nw -= 4) {
+                    pos -= 4;
+                    ObsIn nx[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        nx[j] = c[j];
+                    if (nw > 4) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            nx[j] = load_obs_rm<N, KIND>(obs_rm, pos - j, q, nreal);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        wstep(c[j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        c[j] = nx[j];
+                }
+            }
+            *reinterpret_cast<double2 *>(beta_exit + g * N + 2 * q) = make_double2(b2[0], b2[1]);
+        } else {
+            const double2 x = *reinterpret_cast<const double2 *>(beta_exit + g * N + 2 * q);
+            b2[0] = x.x;
+            b2[1] = x.y;
+        }
+        {
+            gam[0] = a[0] * b2[0];
+            gam[1] = a[1] * b2[1];
+            const double rS = fast_rcp(grp_sum<H>(gam[0] + gam[1]));
+            gam[0] *= rS;
+            gam[1] *= rS;
+        }
+        // consume gamma_s: state counts, emission statistics, optional gamma row
+        auto consume = [&](const ObsIn &in, const double (&d)[2], int64_t rec) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                sg[b] += gam[b];
+                if constexpr (KIND == EMIT_GAUSS) {
+                    const double gd = gam[b] * d[b];
+                    sd[b] += gd;
+                    sdd[b] = fma(gd, d[b], sdd[b]);
+                }
+                if constexpr (KIND == EMIT_DISC) // _discrete.c:22-30
+                    atomicAdd(&dstat[in.sym * N + 2 * q + b], gam[b]);
+            }
+            if (gamma_ci)
+                *ci_pair(gamma_ci, rec, N, q, cl) = make_double2(gam[0], gam[1]);
+        };
+        // step s with apv = alpha_{s-1}: consume gamma_s, then the pair (s-1, s) gives the xi
+        // contribution, gamma_{s-1} and beta_{s-1}
+        auto bstep = [&](const ObsIn &in, const double2 &apv, int64_t rec) {
+            double p[2], d[2], bf[N], r[2];
+            int ne;
+            emit_raw<N, KIND>(in, Bt, q, em, p, d);
+            consume(in, d, rec);
+            beta_step<N, KIND>(in, q, nreal, gmask, Ar, p, b2, bf, r, ne);
+            const double q0 = apv.x * r[0], q1 = apv.y * r[1];
+            const double rS = fast_rcp(grp_sum<H>(q0 + q1));
+            gam[0] = q0 * rS;
+            gam[1] = q1 * rS;
+            const double w0 = apv.x * rS, w1 = apv.y * rS;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                Cacc[0][j] = fma(w0, bf[j], Cacc[0][j]);
+                Cacc[1][j] = fma(w1, bf[j], Cacc[1][j]);
+            }
+            b2[0] = ldexp(r[0], ne);
+            b2[1] = ldexp(r[1], ne);
+        };
+        // the observation of step 0 is needed last: fetch it now
+        const ObsIn in0 = load_obs<N, KIND>(obs_ci, rec0, cl, q);
+        {
+            int64_t rec = rec0 + len - 1; // steps len-1 .. 1
+            int rem = len - 1;
+            if (rem & 1) {
+                const ObsIn in = load_obs<N, KIND>(obs_ci, rec, cl, q);
+                const double2 apv = *ci_pair(ws, rec - 1, N, q, cl);
+                bstep(in, apv, rec);
+                --rec;
+                --rem;
+            }
+            if (rem > 0) {
+                ObsIn c0 = load_obs<N, KIND>(obs_ci, rec, cl, q);
+                ObsIn c1 = load_obs<N, KIND>(obs_ci, rec - 1, cl, q);
+                double2 a0 = *ci_pair(ws, rec - 1, N, q, cl);
+                double2 a1 = *ci_pair(ws, rec - 2, N, q, cl);
+                for (; rem > 0; rem -= 2) {
+                    ObsIn n0 = c0, n1 = c1;
+                    double2 na0 = a0, na1 = a1;
+                    if (rem > 2) {
+                        n0 = load_obs<N, KIND>(obs_ci, rec - 2, cl, q);
+                        n1 = load_obs<N, KIND>(obs_ci, rec - 3, cl, q);
+                        na0 = *ci_pair(ws, rec - 3, N, q, cl);
+                        na1 = *ci_pair(ws, rec - 4, N, q, cl);
+                    }
+                    bstep(c0, a0, rec);
+                    bstep(c1, a1, rec - 1);
+                    rec -= 2;
+                    c0 = n0;
+                    c1 = n1;
+                    a0 = na0;
+                    a1 = na1;
+                }
+            }
+        }
+        // step 0
+        if (first) {
+            double d[2] = {0.0, 0.0};
+            if constexpr (KIND == EMIT_GAUSS) {
+                d[0] = in0.o - em.mu[0];
+                d[1] = in0.o - em.mu[1];
+            }
+            consume(in0, d, rec0);
+            *reinterpret_cast<double2 *>(gamma0 + (int64_t)k * N + 2 * q) =
+                make_double2(gam[0], gam[1]);
+        } else {
+            bstep(in0, aent, rec0);
+            if constexpr (SPEC) // beta one step before this chunk: what the previous chunk assumed
+                *reinterpret_cast<double2 *>(b_entry + g * N + 2 * q) = make_double2(b2[0], b2[1]);
+        }
+    }
+
+    // ---------------- workgroup reduction of the register statistics ----------------------
+    // entry e of the statistics vector is owned by lane q = (state of e) / 2; sum over the
+    // chunks of the wavefront (lanes with equal q), then over wavefronts through LDS
+    {
+        const int lane = threadIdx.x & 63;
+        const int wv = threadIdx.x >> 6;
+        double *mine = red + wv * SL::S;
+        auto chunk_sum = [&](double v) {
+#pragma unroll
+            for (int h = 32; h >= H; h >>= 1)
+                v += __shfl_xor(v, h, 64);
+            return v;
+        };
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double v = chunk_sum(Cacc[b][j]);
+                if (lane < H)
+                    mine[(2 * q + b) * N + j] = v;
+            }
+            const double v = chunk_sum(sg[b]);
+            if (lane < H)
+                mine[SL::NC + 2 * q + b] = v;
+            if constexpr (KIND == EMIT_GAUSS) {
+                const double v1 = chunk_sum(sd[b]);
+                const double v2 = chunk_sum(sdd[b]);
+                if (lane < H) {
+                    mine[SL::NC + N + 2 * q + b] = v1;
+                    mine[SL::NC + 2 * N + 2 * q + b] = v2;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < SL::S; i += blockDim.x) {
+            double v = red[i];
+#pragma unroll
+            for (int w = 1; w < NW; ++w)
+                v += red[w * SL::S + i];
+            partials[(int64_t)blockIdx.x * SL::S + i] = v;
+        }
+        if constexpr (KIND == EMIT_DISC)
+            for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
+                disc_partials[(int64_t)blockIdx.x * (m.M * N) + i] = dstat[i];
+    }
+}
+
+} // namespace bhmm

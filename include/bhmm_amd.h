@@ -167,6 +167,9 @@ int bhmm_ctx_chunk_len(const bhmm_ctx *ctx);
 double bhmm_ctx_last_kernel_ms(bhmm_ctx *ctx, int which);
 void *bhmm_ctx_stream(bhmm_ctx *ctx);
 int bhmm_ctx_sync(bhmm_ctx *ctx);
+/* diagnostics: y[i] = the E-step kernels' exp() for non-positive arguments (the exponential
+ * of the gaussian density, _gaussian.c:18), so that tests can bound its error in ulps */
+int bhmm_diag_exp_nonpos(double *y, const double *x, int64_t n);
 
 #ifdef __cplusplus
 }

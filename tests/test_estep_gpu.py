@@ -258,3 +258,28 @@ def test_speculative_boundaries_verify_or_fall_back(golden):
         _cmp(res, ref, 4)
     assert eng.get_option("spec_fail") >= 1
     eng.close()
+
+
+def test_exp_of_gaussian_density_is_ulp_accurate():
+    """The E-step evaluates exp(-z^2/2) (_gaussian.c:18) with its own branch-free kernel for
+    non-positive arguments: bound its error against libm over the whole range, including the
+    gradual underflow and the clamp."""
+    import ctypes
+    from bhmm_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        -rng.uniform(0.0, 50.0, 200000), -rng.uniform(0.0, 1e-3, 20000),
+        -rng.uniform(50.0, 745.0, 100000), -np.exp(rng.uniform(-40, 0, 20000)),
+        np.array([0.0, -0.0, -1e-300, -708.3, -745.13, -745.2, -750.0, -1e4, -1e300, -np.inf]),
+        -np.log(2.0) * (np.arange(2000) + 0.5)])  # reduction boundaries
+    y = np.empty_like(x)
+    _lib.check(L.bhmm_diag_exp_nonpos(_lib.dp(y), _lib.dp(x), x.size))
+    ref = np.exp(x)
+    normal = ref > 2.3e-308
+    ulp = np.abs(y[normal] - ref[normal]) / np.spacing(ref[normal])
+    assert ulp.max() <= 1.0, ulp.max()
+    # gradual underflow: absolute error of one denormal spacing, exact zero below the range
+    assert np.all(np.abs(y[~normal] - ref[~normal]) <= 4.95e-324 * 1.5)
+    assert np.all(y[x < -746.0] == 0.0)
+    assert y[0 + np.flatnonzero(x == 0.0)[0]] == 1.0
