@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbhmm_amd.so")
+# BHMM_AMD_LIB selects another build of the same library (kernel experiments, tools/build_variant.sh)
+LIB_PATH = os.environ.get("BHMM_AMD_LIB") or os.path.join(_HERE, "lib", "libbhmm_amd.so")
 
 OK = 0
 ERR_NO_MEM = 2

@@ -47,9 +47,10 @@ Chunks chunks_pub(const bhmm_ctx *c)
 template <int N, int KIND>
 static size_t smem_fwdbwd(int M)
 {
-    // [wavefronts per workgroup][S] reduction scratch + (discrete) B^T and the count table
+    // [wavefronts per workgroup][S] reduction scratch + (discrete) B^T and the count table +
+    // the gather exchange area of k_estep (one 16-byte slot per thread)
     return (size_t)(((N / 2 * 64 + 63) / 64) * StatLayout<N, KIND>::S +
-                    (KIND == EMIT_DISC ? 2 * M * N : 0)) *
+                    (KIND == EMIT_DISC ? 2 * M * N : 0) + 2 * 32 * N) *
            sizeof(double);
 }
 
@@ -112,15 +113,31 @@ struct Runner {
         const int nblk = c->Gp / 64; // one workgroup per CI record group (64 chunks)
         const size_t sm = smem_fwdbwd<N, KIND>(c->M);
         if constexpr (MODE == MODE_ESTEP) {
-            if (sm > 64 * 1024)
-                BHMM_HIP(hipFuncSetAttribute((const void *)(k_estep<N, KIND, SPEC>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-            hipLaunchKernelGGL((k_estep<N, KIND, SPEC>), dim3(nblk), dim3(32 * N), sm, c->stream, m,
-                               ch, (const void *)c->d_obs_ci.p, (const void *)c->d_obs_rm.p,
-                               (const int64_t *)c->d_offsets.p, (const double *)c->d_Bt.p,
-                               c->d_aentry.p, c->d_bexit.p, c->d_aexit.p, c->d_bentry.p, c->spec_W,
-                               c->d_ws.p, store_gamma ? c->d_gamma_ci.p : (double *)nullptr,
-                               c->d_logLc.p, c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p);
+            // the exact fallback always uses the gamma-capable, careful instantiation
+            auto launch = [&](auto kern) -> int {
+                if (sm > 64 * 1024)
+                    BHMM_HIP(hipFuncSetAttribute((const void *)kern,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)sm));
+                hipLaunchKernelGGL(kern, dim3(nblk), dim3(32 * N), sm, c->stream, m, ch,
+                                   (const void *)c->d_obs_ci.p, (const void *)c->d_obs_rm.p,
+                                   (const int64_t *)c->d_offsets.p, (const double *)c->d_Bt.p,
+                                   c->d_aentry.p, c->d_bexit.p, c->d_aexit.p, c->d_bentry.p,
+                                   c->spec_W, c->d_ws.p,
+                                   store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
+                                   c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p,
+                                   c->d_specres.p);
+                return BHMM_OK;
+            };
+            // the branch-free instantiation needs the verdict round trip of the speculative
+            // path to report zero / denormal vectors; everything else runs the careful one
+            int rc;
+            if (SPEC && !store_gamma && !c->careful)
+                rc = launch(k_estep<N, KIND, SPEC, false, false>);
+            else
+                rc = launch(k_estep<N, KIND, SPEC, true, true>);
+            if (rc)
+                return rc;
         } else {
             if (sm > 64 * 1024)
                 BHMM_HIP(hipFuncSetAttribute((const void *)(k_fwdbwd<N, KIND, MODE, SPEC>),
@@ -184,11 +201,16 @@ struct Runner {
     {
         int rc;
         if (c->spec_enabled) {
-            bool ok = false;
-            if ((rc = estep_spec<KIND>(c, m, stats_dev, flags, &ok)))
-                return rc;
-            if (ok)
-                return BHMM_OK;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                bool ok = false;
+                if ((rc = estep_spec<KIND>(c, m, stats_dev, flags, &ok)))
+                    return rc;
+                if (ok)
+                    return BHMM_OK;
+                if (!c->careful_retry)
+                    break; // boundaries did not verify: exact pipeline
+                c->careful_retry = false; // zero / denormal vectors: same path, careful kernel
+            }
         }
         rc = prescan_stitch<KIND>(c, m);
         if (rc)
@@ -257,7 +279,7 @@ struct Runner {
                            with_beta ? (const double *)c->d_bexit.p : (const double *)nullptr,
                            (const double *)c->d_bentry.p, 1e-11, c->d_specres.p);
         BHMM_HIP(hipGetLastError());
-        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 2 * sizeof(unsigned int),
+        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
                                 hipMemcpyDeviceToHost, c->stream));
         c->prefetched = false;
         if (stats_src) { // the results ride on the same synchronisation as the verdict
@@ -268,10 +290,47 @@ struct Runner {
                                     hipMemcpyDeviceToHost, c->stream));
         }
         BHMM_HIP(hipStreamSynchronize(c->stream));
+#ifdef ESTEP_CLOCKPROBE
+        {
+            const int nb = c->Gp / 64;
+            std::vector<unsigned long long> pr(4 * (size_t)nb);
+            BHMM_HIP(hipMemcpy(pr.data(), c->d_specres.p + 4, pr.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long r0 = ~0ull, r1 = 0;
+            double sumd = 0, mind = 1e30, maxd = 0, sumf = 0;
+            for (int b = 0; b < nb; ++b) {
+                r0 = std::min(r0, pr[4 * b + 2]);
+                r1 = std::max(r1, pr[4 * b + 3]);
+            }
+            std::vector<int> hist(20, 0);
+            for (int b = 0; b < nb; ++b) {
+                const double d = (double)(pr[4 * b + 3] - pr[4 * b + 2]);
+                sumd += d;
+                mind = std::min(mind, d);
+                maxd = std::max(maxd, d);
+                sumf += (double)(pr[4 * b + 1] - pr[4 * b]) / d;
+                hist[std::min(19, (int)(20.0 * (pr[4 * b + 3] - r0) / (double)(r1 - r0)))]++;
+            }
+            fprintf(stderr, "[probe] blocks %d span %.1f us; block dur mean %.1f min %.1f max %.1f us; "
+                            "cyclecounter/realtime %.3f; start spread: first end hist:",
+                    nb, (r1 - r0) * 0.01, sumd / nb * 0.01, mind * 0.01, maxd * 0.01, sumf / nb);
+            for (int h : hist)
+                fprintf(stderr, " %d", h);
+            fprintf(stderr, "\n");
+        }
+#endif
         float dev;
         memcpy(&dev, &c->h_specres[1], sizeof(float));
         c->spec_last_dev = dev;
         *verified = c->h_specres[0] == 0;
+        if (c->h_specres[2] != 0) {
+            // the branch-free sweep met a zero / denormal vector (an all-zero emission row,
+            // outputmodel.py:126-130): its statistics are void, repeat with the careful kernel
+            // and keep using that one for this set of observations
+            *verified = false;
+            c->careful = true;
+            c->careful_retry = true;
+            return BHMM_OK;
+        }
         if (*verified) {
             c->prefetched = stats_src != nullptr;
             c->spec_ok++;
@@ -291,12 +350,16 @@ struct Runner {
     {
         int rc;
         if ((rc = c->d_aexit.ensure((size_t)c->Gp * N)) || (rc = c->d_bentry.ensure((size_t)c->Gp * N)) ||
-            (rc = c->d_specres.ensure(2)))
+#ifdef ESTEP_CLOCKPROBE
+            (rc = c->d_specres.ensure(4 + 8 * (size_t)(c->Gp / 64))))
+#else
+            (rc = c->d_specres.ensure(4)))
+#endif
             return rc;
         if (!c->h_specres)
-            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 2 * sizeof(unsigned int),
+            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
                                    hipHostMallocDefault));
-        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 2 * sizeof(unsigned int), c->stream));
+        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
         return BHMM_OK;
     }
 
@@ -708,6 +771,7 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     if (obs == nullptr)
         return invalid("obs == NULL");
     c->gamma_valid = false;
+    c->careful = c->careful_retry = false;
     if (kind == BHMM_EMIT_DISCRETE) {
         const size_t sm = smem_fwdbwd<8, EMIT_DISC>(c->M);
         if (sm > 160 * 1024)
@@ -854,6 +918,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->spec_fail;
     else if (n == "spec_last_dev")
         *value = c->spec_last_dev;
+    else if (n == "careful")
+        *value = c->careful ? 1.0 : 0.0;
     else if (n == "wide_segments")
         *value = (c->wseg_enabled && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
     else

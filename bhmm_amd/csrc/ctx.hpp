@@ -109,6 +109,8 @@ struct bhmm_ctx {
     size_t h_pinned_n = 0;
 
     bool gamma_valid = false;
+    bool careful = false;       // E-steps use the kernel with the per-step outlier branch
+    bool careful_retry = false; // the last verdict asked for a repeat with that kernel
     bool prefetched = false;          // stats + logL_k of the last E-step already sit in h_pinned
     bool last_stats_internal = true;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -4,11 +4,12 @@
 // bhmm/estimators/maximum_likelihood.py:221-282 (p_obs -> forward -> backward -> gamma ->
 // transition counts, then the host-side sums) by a parallel-in-time decomposition:
 //
-//   every trajectory is cut into time chunks; one LANE owns one chunk and keeps the whole
-//   N-state vector (N <= 8) in registers, so a 64-wide wavefront advances 64 chunks per
-//   instruction with no cross-lane traffic.  All per-step data (observations, alpha) live
-//   in HBM in a "chunk-interleaved" (CI) layout  [wave][step][component][lane]  so that
-//   every global load/store of a wavefront is one contiguous 512 B / 1 KiB segment.
+//   every trajectory is cut into time chunks; N/2 lanes own one chunk (a state pair each;
+//   k_prescan: N lanes), so that a 64-wide wavefront advances 64 / (N/2) chunks per
+//   instruction.  All per-step data (observations, alpha, gamma) live in HBM in a
+//   "chunk-interleaved" (CI) layout  [group of 64 chunks][step][chunk][state]: the rows that
+//   the chunks of one group touch at the same step are one contiguous record, and the 16-byte
+//   elements of a wavefront's lanes (chunk-major, then state pair) are consecutive in it.
 //
 //   k_prescan  : per chunk, the N x N transfer matrix  prod_t A*diag(p_t)  (rows kept
 //                exponent-normalised) -- makes the time recursion associative.
@@ -70,10 +71,11 @@ __device__ __forceinline__ int64_t ci_rec(int64_t g, int s, int Lmax)
 template <int N>
 __device__ __forceinline__ void ci_load(const double *base, int64_t rec, int lane, double (&v)[N])
 {
-    const double2 *p = reinterpret_cast<const double2 *>(base + rec * (int64_t)(N * 64)) + lane;
+    const double2 *p =
+        reinterpret_cast<const double2 *>(base + rec * (int64_t)(N * 64)) + lane * (N / 2);
 #pragma unroll
     for (int q = 0; q < N / 2; ++q) {
-        const double2 x = p[q * 64];
+        const double2 x = p[q];
         v[2 * q] = x.x;
         v[2 * q + 1] = x.y;
     }
@@ -82,10 +84,10 @@ __device__ __forceinline__ void ci_load(const double *base, int64_t rec, int lan
 template <int N>
 __device__ __forceinline__ void ci_store(double *base, int64_t rec, int lane, const double (&v)[N])
 {
-    double2 *p = reinterpret_cast<double2 *>(base + rec * (int64_t)(N * 64)) + lane;
+    double2 *p = reinterpret_cast<double2 *>(base + rec * (int64_t)(N * 64)) + lane * (N / 2);
 #pragma unroll
     for (int q = 0; q < N / 2; ++q)
-        p[q * 64] = make_double2(v[2 * q], v[2 * q + 1]);
+        p[q] = make_double2(v[2 * q], v[2 * q + 1]);
 }
 
 // ---- emission probabilities, fused (never written to HBM) ------------------------------
@@ -261,8 +263,7 @@ __global__ __launch_bounds__(64 * N) void k_prescan(const Model<N> m, const Chun
         else if constexpr (KIND == EMIT_DISC)
             sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + cl];
         else
-            pv = static_cast<const double *>(obs_ci)[rec * (int64_t)(N * 64) + (r >> 1) * 128 +
-                                                     cl * 2 + (r & 1)];
+            pv = static_cast<const double *>(obs_ci)[rec * (int64_t)(N * 64) + cl * N + r];
     };
     double o_n = 0.0, pv_n = 0.0;
     int sym_n = 0;
@@ -626,7 +627,7 @@ __device__ __forceinline__ ObsIn load_obs(const void *obs_ci, int64_t rec, int c
     else
         in.pp = *(reinterpret_cast<const double2 *>(static_cast<const double *>(obs_ci) +
                                                     rec * (int64_t)(N * 64)) +
-                  q * 64 + cl);
+                  cl * (N / 2) + q);
     return in;
 }
 
@@ -659,7 +660,7 @@ __device__ __forceinline__ void emit_pair(const Model<N> &m, const ObsIn &in, co
 
 __device__ __forceinline__ double2 *ci_pair(double *base, int64_t rec, int N_, int q, int cl)
 {
-    return reinterpret_cast<double2 *>(base + rec * (int64_t)(N_ * 64)) + q * 64 + cl;
+    return reinterpret_cast<double2 *>(base + rec * (int64_t)(N_ * 64)) + cl * (N_ / 2) + q;
 }
 
 // SPEC (speculative boundaries, verified afterwards by k_spec_check): instead of reading the

@@ -17,6 +17,8 @@
 //     observations, which needs no walk over the chunk table.
 #pragma once
 
+#include <type_traits>
+
 #include "estep_kernels.hpp"
 
 namespace bhmm {
@@ -80,6 +82,35 @@ __device__ __forceinline__ ObsIn load_obs_rm(const void *obs_rm, int64_t pos, in
     return in;
 }
 
+// Per-lane cursor into the CI observations: one pointer that moves by whole records, so that the
+// loads of neighbouring steps differ only in their immediate offset.
+template <int N, int KIND>
+struct ObsCursor {
+    using T = typename std::conditional<KIND == EMIT_GAUSS, double,
+              typename std::conditional<KIND == EMIT_DISC, int32_t, double2>::type>::type;
+    static constexpr int STRIDE = (KIND == EMIT_EXPL) ? (N / 2) * 64 : 64; // elements per record
+    const T *p;
+    __device__ __forceinline__ ObsCursor(const void *obs_ci, int64_t rec, int cl, int q)
+    {
+        p = static_cast<const T *>(obs_ci) + rec * STRIDE + (KIND == EMIT_EXPL ? cl * (N / 2) + q : cl);
+    }
+    __device__ __forceinline__ ObsIn at(int drec) const
+    {
+        ObsIn in;
+        in.o = 0.0;
+        in.sym = 0;
+        in.pp = make_double2(0.0, 0.0);
+        if constexpr (KIND == EMIT_GAUSS)
+            in.o = p[drec * STRIDE];
+        else if constexpr (KIND == EMIT_DISC)
+            in.sym = p[drec * STRIDE];
+        else
+            in.pp = p[drec * STRIDE];
+        return in;
+    }
+    __device__ __forceinline__ void move(int drec) { p += drec * STRIDE; }
+};
+
 // emission probabilities of my two states WITHOUT the outlier rule; d = o - mu (gaussian)
 template <int N, int KIND>
 __device__ __forceinline__ void emit_raw(const ObsIn &in, const double *Bt, int q,
@@ -116,7 +147,9 @@ __device__ __forceinline__ bool fix_outlier(const ObsIn &in, int q, int nreal,
         const bool nz = (p[0] != 0.0) || (p[1] != 0.0);
         if ((__ballot(nz) & gmask) != 0ull)
             return false;
-        const double one = (in.o != in.o) ? in.o : 1.0;
+        double o = in.o, one = 1.0;
+        asm volatile("" : "+v"(o), "+v"(one)); // keeps this arithmetic inside the rare branch
+        one = (o != o) ? o : one;
         p[0] = (2 * q < nreal) ? one : 0.0;
         p[1] = (2 * q + 1 < nreal) ? one : 0.0;
         return true;
@@ -127,37 +160,89 @@ __device__ __forceinline__ bool fix_outlier(const ObsIn &in, int q, int nreal,
 __device__ __forceinline__ bool tiny_hi(int hm) { return hm < 0x00100000; }
 
 // a <- 2^ne (s o p), the group's largest entry brought into [0.5, 1); returns the exponent
-// removed (-ne).  Zero / denormal results take the slow branch: outlier rule, then frexp.
-template <int N, int KIND>
+// removed (-ne).  CAREFUL (gaussian): a zero / denormal result takes the slow branch with the
+// outlier rule.  Otherwise the step is branch-free and only records the smallest maximum seen
+// (hmin); the kernel reports chunks where that was zero / denormal and the host repeats the
+// E-step with the CAREFUL instantiation (only the gaussian model has such a rule; for the other
+// emission kinds both variants are the same arithmetic).
+template <int N, int KIND, bool CAREFUL>
 __device__ __forceinline__ int scaled_emit(const ObsIn &in, int q, int nreal,
                                            unsigned long long gmask, const double (&s)[2],
-                                           double (&p)[2], double (&a)[2])
+                                           double (&p)[2], double (&a)[2], int &hmin)
 {
     constexpr int H = N / 2;
-    double n0 = s[0] * p[0], n1 = s[1] * p[1];
-    const int hm = grp_max_i32<H>(max(__double2hiint(n0), __double2hiint(n1)));
-    int ne;
-    if (__builtin_expect(__ballot(tiny_hi(hm)) != 0ull, 0)) {
-        if (fix_outlier<N, KIND>(in, q, nreal, gmask, p)) {
+    double n0, n1;
+    int hm;
+    if constexpr (CAREFUL && KIND == EMIT_GAUSS) {
+        for (;;) { // runs once; a second time only after the outlier rule replaced p
             n0 = s[0] * p[0];
             n1 = s[1] * p[1];
+            hm = grp_max_i32<H>(max(__double2hiint(n0), __double2hiint(n1)));
+            if (__builtin_expect(__ballot(tiny_hi(hm)) == 0ull, 1))
+                break;
+            if (__ballot(fix_outlier<N, KIND>(in, q, nreal, gmask, p)) == 0ull)
+                break;
         }
-        ne = -grp_max_i32<H>(max(exponent_of(n0), exponent_of(n1)));
     } else {
-        ne = 1022 - (hm >> 20);
+        n0 = s[0] * p[0];
+        n1 = s[1] * p[1];
+        hm = grp_max_i32<H>(max(__double2hiint(n0), __double2hiint(n1)));
+        hmin = min(hmin, hm);
     }
+    // a zero or denormal maximum (exponent field 0) is scaled by 2^1022 -- the bookkeeping stays
+    // exact, the next steps finish the normalisation
+    const int ne = 1022 - (hm >> 20);
     a[0] = ldexp(n0, ne);
     a[1] = ldexp(n1, ne);
     return -ne;
 }
 
+// All-gather of a state-pair over the H lanes of a chunk.  ESTEP_LDS_GATHER: through a
+// per-wavefront LDS exchange area (one 16-byte write, H 16-byte broadcast reads: LDS
+// instructions, which leave the VALU to the arithmetic); otherwise on DPP quad permutes (2 VALU
+// moves per double).  LDS operations of one wavefront execute in order, so the reads see the
+// writes of the same step and no barrier is needed -- only the compiler has to keep the order.
+#ifndef ESTEP_LDS_GATHER
+#define ESTEP_LDS_GATHER 1
+#endif
+template <int N>
+struct Gather {
+    static constexpr int H = N / 2;
+    static constexpr bool LDS = ESTEP_LDS_GATHER && H > 1;
+    double2 *w;       // my slot
+    const double2 *r; // slot of lane 0 of my group; lane k is k * (64 / H) further
+    __device__ __forceinline__ Gather(double *area)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        double2 *base = reinterpret_cast<double2 *>(area) + wv * 64;
+        w = base + (lane % H) * (64 / H) + lane / H;
+        r = base + lane / H;
+    }
+    __device__ __forceinline__ void operator()(const double (&pair)[2], double (&full)[N]) const
+    {
+        if constexpr (LDS) {
+            *w = make_double2(pair[0], pair[1]);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                const double2 v = r[k * (64 / H)];
+                full[2 * k] = v.x;
+                full[2 * k + 1] = v.y;
+            }
+            asm volatile("" ::: "memory");
+        } else {
+            grp_gather<N>(pair, full);
+        }
+    }
+};
+
 // s = (a^T A)[my two states]:  all-gather of a over the group, my two columns of A
 template <int N>
-__device__ __forceinline__ void fwd_matvec(const double (&a)[2], const double (&Ac)[N][2],
-                                           double (&s)[2])
+__device__ __forceinline__ void fwd_matvec(const Gather<N> &gather, const double (&a)[2],
+                                           const double (&Ac)[N][2], double (&s)[2])
 {
     double af[N];
-    grp_gather<N>(a, af);
+    gather(a, af);
     s[0] = af[0] * Ac[0][0];
     s[1] = af[0] * Ac[0][1];
 #pragma unroll
@@ -169,10 +254,11 @@ __device__ __forceinline__ void fwd_matvec(const double (&a)[2], const double (&
 
 // r = (A bb)[my two states], bf = all-gather of bb
 template <int N>
-__device__ __forceinline__ void bwd_matvec(const double (&bb)[2], const double (&Ar)[2][N],
-                                           double (&bf)[N], double (&r)[2])
+__device__ __forceinline__ void bwd_matvec(const Gather<N> &gather, const double (&bb)[2],
+                                           const double (&Ar)[2][N], double (&bf)[N],
+                                           double (&r)[2])
 {
-    grp_gather<N>(bb, bf);
+    gather(bb, bf);
     r[0] = Ar[0][0] * bf[0];
     r[1] = Ar[1][0] * bf[0];
 #pragma unroll
@@ -184,37 +270,53 @@ __device__ __forceinline__ void bwd_matvec(const double (&bb)[2], const double (
 
 // One backward step without statistics: b <- 2^ne A (p o b); p may be replaced by the outlier
 // row.  bf (the gathered p o b) is returned for the xi accumulation of the caller.
-template <int N, int KIND>
-__device__ __forceinline__ void beta_step(const ObsIn &in, int q, int nreal,
-                                          unsigned long long gmask, const double (&Ar)[2][N],
+template <int N, int KIND, bool CAREFUL>
+__device__ __forceinline__ void beta_step(const Gather<N> &gather, const ObsIn &in, int q,
+                                          int nreal, unsigned long long gmask,
+                                          const double (&Ar)[2][N],
                                           double (&p)[2], const double (&b)[2], double (&bf)[N],
-                                          double (&r)[2], int &ne)
+                                          double (&r)[2], int &ne, int &hmin)
 {
     constexpr int H = N / 2;
-    double bb[2] = {p[0] * b[0], p[1] * b[1]};
-    bwd_matvec<N>(bb, Ar, bf, r);
-    const int hm = grp_max_i32<H>(max(__double2hiint(r[0]), __double2hiint(r[1])));
-    if (__builtin_expect(__ballot(tiny_hi(hm)) != 0ull, 0)) {
-        if (fix_outlier<N, KIND>(in, q, nreal, gmask, p)) {
-            bb[0] = p[0] * b[0];
-            bb[1] = p[1] * b[1];
-            bwd_matvec<N>(bb, Ar, bf, r);
+    int hm;
+    if constexpr (CAREFUL && KIND == EMIT_GAUSS) {
+        for (;;) { // runs once; a second time only after the outlier rule replaced p
+            const double bb[2] = {p[0] * b[0], p[1] * b[1]};
+            bwd_matvec<N>(gather, bb, Ar, bf, r);
+            hm = grp_max_i32<H>(max(__double2hiint(r[0]), __double2hiint(r[1])));
+            if (__builtin_expect(__ballot(tiny_hi(hm)) == 0ull, 1))
+                break;
+            if (__ballot(fix_outlier<N, KIND>(in, q, nreal, gmask, p)) == 0ull)
+                break;
         }
-        ne = -grp_max_i32<H>(max(exponent_of(r[0]), exponent_of(r[1])));
     } else {
-        ne = 1022 - (hm >> 20);
+        const double bb[2] = {p[0] * b[0], p[1] * b[1]};
+        bwd_matvec<N>(gather, bb, Ar, bf, r);
+        hm = grp_max_i32<H>(max(__double2hiint(r[0]), __double2hiint(r[1])));
+        hmin = min(hmin, hm);
     }
+    ne = 1022 - (hm >> 20); // see scaled_emit
 }
 
 // =========================================================================================
-// k_estep<N, KIND, SPEC>: forward sweep (alpha -> CI workspace, chunk log-likelihood), then
+// k_estep<N, KIND, SPEC, GAMMA, CAREFUL>: forward sweep (alpha -> CI workspace, chunk log-likelihood), then
 // backward sweep with gamma / xi / emission statistics in registers.
 //   SPEC: chunk-boundary vectors by warm-up over W steps, verified afterwards by k_spec_check
 //   (see k_fwdbwd); otherwise they are read from k_stitch.
+//   GAMMA: the instantiation that can store the gamma rows (gamma_ci may still be null).
 // Workgroup = one CI record group (64 chunks) = 32*N threads.
 // =========================================================================================
-template <int N, int KIND, bool SPEC>
-__global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
+#ifndef ESTEP_PF_F
+#define ESTEP_PF_F 4 // steps per prefetch register set, forward sweep (observations)
+#endif
+#ifndef ESTEP_PF_B
+#define ESTEP_PF_B 2 // ... backward sweep (observations + alpha)
+#endif
+#ifndef ESTEP_WAVES
+#define ESTEP_WAVES 2
+#endif
+template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL>
+__global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WAVES, ESTEP_WAVES))) void k_estep(
     const Model<N> m, const Chunks ch, const void *obs_ci, const void *obs_rm,
     const int64_t *toff,   // [K+1] trajectory offsets (time steps)
     const double *Bt_g, double *alpha_entry, double *beta_exit,
@@ -226,7 +328,8 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
     double *logL_chunk,    // [G] log of the product of the chunk's scaling factors
     double *gamma0,        // [K][N] gamma at t = 0 of every trajectory
     double *partials,      // [gridDim.x][S] register statistics per workgroup
-    double *disc_partials) // [gridDim.x][M*N] discrete emission statistics per workgroup
+    double *disc_partials, // [gridDim.x][M*N] discrete emission statistics per workgroup
+    unsigned int *flags)   // !CAREFUL: flags[2] counts chunks that met a zero / denormal vector
 {
     using SL = StatLayout<N, KIND>;
     constexpr int H = N / 2;
@@ -235,6 +338,11 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
     double *red = smem;                                     // [NW][S]
     double *Bt = smem + NW * SL::S;                         // [M][N]
     double *dstat = Bt + (KIND == EMIT_DISC ? m.M * N : 0); // [M][N]
+    const Gather<N> gather(dstat + (KIND == EMIT_DISC ? m.M * N : 0)); // [32 * N] pairs
+    int hmin = 0x7fffffff;
+#ifdef ESTEP_CLOCKPROBE
+    const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = wall_clock64();
+#endif
     if constexpr (KIND == EMIT_DISC) {
         stage_Bt<N>(Bt, Bt_g, m.M);
         for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
@@ -292,7 +400,7 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
                 const ObsIn in = load_obs<N, KIND>(obs_ci, rec0, cl, q);
                 double p[2], d[2];
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                eP = scaled_emit<N, KIND>(in, q, nreal, gmask, pi2, p, a);
+                eP = scaled_emit<N, KIND, CAREFUL>(in, q, nreal, gmask, pi2, p, a, hmin);
                 *ci_pair(ws, rec0, N, q, cl) = make_double2(a[0], a[1]);
                 s = 1;
             } else {
@@ -304,14 +412,14 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
                     auto wstep = [&](const ObsIn &in) {
                         double p[2], d[2], sv[2];
                         emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                        fwd_matvec<N>(a, Ac, sv);
-                        (void)scaled_emit<N, KIND>(in, q, nreal, gmask, sv, p, a);
+                        fwd_matvec<N>(gather, a, Ac, sv);
+                        (void)scaled_emit<N, KIND, CAREFUL>(in, q, nreal, gmask, sv, p, a, hmin);
                     };
                     if ((int64_t)nw == t0) {
                         const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
                         double p[2], d[2];
                         emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                        (void)scaled_emit<N, KIND>(in, q, nreal, gmask, pi2, p, a);
+                        (void)scaled_emit<N, KIND, CAREFUL>(in, q, nreal, gmask, pi2, p, a, hmin);
                         ++pos;
                         --nw;
                     } else {
@@ -358,35 +466,48 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
                 }
                 Sin = grp_sum<H>(a[0] + a[1]);
             }
-            auto fstep = [&](const ObsIn &in, int64_t rec) {
+            constexpr int RS = (N / 2) * 64; // double2 elements per CI record of N doubles
+            auto fstep = [&](const ObsIn &in, double2 *dst) {
                 double p[2], d[2], sv[2];
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                fwd_matvec<N>(a, Ac, sv);
-                eP += scaled_emit<N, KIND>(in, q, nreal, gmask, sv, p, a);
-                *ci_pair(ws, rec, N, q, cl) = make_double2(a[0], a[1]);
+                fwd_matvec<N>(gather, a, Ac, sv);
+                eP += scaled_emit<N, KIND, CAREFUL>(in, q, nreal, gmask, sv, p, a, hmin);
+                *dst = make_double2(a[0], a[1]);
             };
-            int64_t rec = rec0 + s;
+            ObsCursor<N, KIND> po(obs_ci, rec0 + s, cl, q);
+            double2 *pw = ci_pair(ws, rec0 + s, N, q, cl);
             int rem = len - s;
-            if (rem & 1) {
-                const ObsIn in = load_obs<N, KIND>(obs_ci, rec, cl, q);
-                fstep(in, rec);
-                ++rec;
-                --rem;
+            constexpr int PF = ESTEP_PF_F;
+            // single steps until the rest is a multiple of 2 PF, then two register sets of PF
+            // steps, each loaded PF..2PF-1 steps before its use
+            for (int i = rem % (2 * PF); i > 0; --i) {
+                fstep(po.at(0), pw);
+                po.move(1);
+                pw += RS;
             }
+            rem -= rem % (2 * PF);
             if (rem > 0) {
-                ObsIn c0 = load_obs<N, KIND>(obs_ci, rec, cl, q);
-                ObsIn c1 = load_obs<N, KIND>(obs_ci, rec + 1, cl, q);
-                for (; rem > 0; rem -= 2) {
-                    ObsIn n0 = c0, n1 = c1;
-                    if (rem > 2) {
-                        n0 = load_obs<N, KIND>(obs_ci, rec + 2, cl, q);
-                        n1 = load_obs<N, KIND>(obs_ci, rec + 3, cl, q);
+                ObsIn x[PF], y[PF];
+#pragma unroll
+                for (int j = 0; j < PF; ++j)
+                    x[j] = po.at(j);
+                for (; rem > 0; rem -= 2 * PF) {
+#pragma unroll
+                    for (int j = 0; j < PF; ++j)
+                        y[j] = po.at(PF + j);
+#pragma unroll
+                    for (int j = 0; j < PF; ++j)
+                        fstep(x[j], pw + j * RS);
+                    if (rem > 2 * PF) {
+#pragma unroll
+                        for (int j = 0; j < PF; ++j)
+                            x[j] = po.at(2 * PF + j);
                     }
-                    fstep(c0, rec);
-                    fstep(c1, rec + 1);
-                    rec += 2;
-                    c0 = n0;
-                    c1 = n1;
+#pragma unroll
+                    for (int j = 0; j < PF; ++j)
+                        fstep(y[j], pw + (PF + j) * RS);
+                    po.move(2 * PF);
+                    pw += 2 * PF * RS;
                 }
             }
             const double Sfin = grp_sum<H>(a[0] + a[1]);
@@ -418,7 +539,7 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
                 double p[2], d[2], bf[N], r[2];
                 int ne;
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                beta_step<N, KIND>(in, q, nreal, gmask, Ar, p, b2, bf, r, ne);
+                beta_step<N, KIND, CAREFUL>(gather, in, q, nreal, gmask, Ar, p, b2, bf, r, ne, hmin);
                 b2[0] = ldexp(r[0], ne);
                 b2[1] = ldexp(r[1], ne);
             };
@@ -466,7 +587,8 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
             gam[1] *= rS;
         }
         // consume gamma_s: state counts, emission statistics, optional gamma row
-        auto consume = [&](const ObsIn &in, const double (&d)[2], int64_t rec) {
+        constexpr int RS = (N / 2) * 64; // double2 elements per CI record of N doubles
+        auto consume = [&](const ObsIn &in, const double (&d)[2], double2 *gdst) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 sg[b] += gam[b];
@@ -478,17 +600,18 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
                 if constexpr (KIND == EMIT_DISC) // _discrete.c:22-30
                     atomicAdd(&dstat[in.sym * N + 2 * q + b], gam[b]);
             }
-            if (gamma_ci)
-                *ci_pair(gamma_ci, rec, N, q, cl) = make_double2(gam[0], gam[1]);
+            if constexpr (GAMMA)
+                if (gamma_ci)
+                    *gdst = make_double2(gam[0], gam[1]);
         };
         // step s with apv = alpha_{s-1}: consume gamma_s, then the pair (s-1, s) gives the xi
         // contribution, gamma_{s-1} and beta_{s-1}
-        auto bstep = [&](const ObsIn &in, const double2 &apv, int64_t rec) {
+        auto bstep = [&](const ObsIn &in, const double2 &apv, double2 *gdst) {
             double p[2], d[2], bf[N], r[2];
             int ne;
             emit_raw<N, KIND>(in, Bt, q, em, p, d);
-            consume(in, d, rec);
-            beta_step<N, KIND>(in, q, nreal, gmask, Ar, p, b2, bf, r, ne);
+            consume(in, d, gdst);
+            beta_step<N, KIND, CAREFUL>(gather, in, q, nreal, gmask, Ar, p, b2, bf, r, ne, hmin);
             const double q0 = apv.x * r[0], q1 = apv.y * r[1];
             const double rS = fast_rcp(grp_sum<H>(q0 + q1));
             gam[0] = q0 * rS;
@@ -503,38 +626,52 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
             b2[1] = ldexp(r[1], ne);
         };
         // the observation of step 0 is needed last: fetch it now
-        const ObsIn in0 = load_obs<N, KIND>(obs_ci, rec0, cl, q);
+        const ObsIn in0 = ObsCursor<N, KIND>(obs_ci, rec0, cl, q).at(0);
+        double2 *const pg0 = GAMMA && gamma_ci ? ci_pair(gamma_ci, rec0, N, q, cl) : nullptr;
         {
-            int64_t rec = rec0 + len - 1; // steps len-1 .. 1
+            // steps len-1 .. 1; po / pa / pg point at the records of the step about to be done
+            ObsCursor<N, KIND> po(obs_ci, rec0 + len - 1, cl, q);
+            const double2 *pa = ci_pair(ws, rec0 + len - 1, N, q, cl);
+            double2 *pg = pg0 + (int64_t)(len - 1) * RS;
             int rem = len - 1;
-            if (rem & 1) {
-                const ObsIn in = load_obs<N, KIND>(obs_ci, rec, cl, q);
-                const double2 apv = *ci_pair(ws, rec - 1, N, q, cl);
-                bstep(in, apv, rec);
-                --rec;
-                --rem;
+            constexpr int PF = ESTEP_PF_B;
+            for (int i = rem % (2 * PF); i > 0; --i) { // as in the forward sweep
+                bstep(po.at(0), pa[-RS], pg);
+                po.move(-1);
+                pa -= RS;
+                pg -= RS;
             }
+            rem -= rem % (2 * PF);
             if (rem > 0) {
-                ObsIn c0 = load_obs<N, KIND>(obs_ci, rec, cl, q);
-                ObsIn c1 = load_obs<N, KIND>(obs_ci, rec - 1, cl, q);
-                double2 a0 = *ci_pair(ws, rec - 1, N, q, cl);
-                double2 a1 = *ci_pair(ws, rec - 2, N, q, cl);
-                for (; rem > 0; rem -= 2) {
-                    ObsIn n0 = c0, n1 = c1;
-                    double2 na0 = a0, na1 = a1;
-                    if (rem > 2) {
-                        n0 = load_obs<N, KIND>(obs_ci, rec - 2, cl, q);
-                        n1 = load_obs<N, KIND>(obs_ci, rec - 3, cl, q);
-                        na0 = *ci_pair(ws, rec - 3, N, q, cl);
-                        na1 = *ci_pair(ws, rec - 4, N, q, cl);
+                ObsIn x[PF], y[PF];
+                double2 u[PF], v[PF];
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    x[j] = po.at(-j);
+                    u[j] = pa[-(j + 1) * RS];
+                }
+                for (; rem > 0; rem -= 2 * PF) {
+#pragma unroll
+                    for (int j = 0; j < PF; ++j) {
+                        y[j] = po.at(-(PF + j));
+                        v[j] = pa[-(PF + j + 1) * RS];
                     }
-                    bstep(c0, a0, rec);
-                    bstep(c1, a1, rec - 1);
-                    rec -= 2;
-                    c0 = n0;
-                    c1 = n1;
-                    a0 = na0;
-                    a1 = na1;
+#pragma unroll
+                    for (int j = 0; j < PF; ++j)
+                        bstep(x[j], u[j], pg - j * RS);
+                    if (rem > 2 * PF) {
+#pragma unroll
+                        for (int j = 0; j < PF; ++j) {
+                            x[j] = po.at(-(2 * PF + j));
+                            u[j] = pa[-(2 * PF + j + 1) * RS];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < PF; ++j)
+                        bstep(y[j], v[j], pg - (PF + j) * RS);
+                    po.move(-2 * PF);
+                    pa -= 2 * PF * RS;
+                    pg -= 2 * PF * RS;
                 }
             }
         }
@@ -545,15 +682,29 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_estep(
                 d[0] = in0.o - em.mu[0];
                 d[1] = in0.o - em.mu[1];
             }
-            consume(in0, d, rec0);
+            consume(in0, d, pg0);
             *reinterpret_cast<double2 *>(gamma0 + (int64_t)k * N + 2 * q) =
                 make_double2(gam[0], gam[1]);
         } else {
-            bstep(in0, aent, rec0);
+            bstep(in0, aent, pg0);
             if constexpr (SPEC) // beta one step before this chunk: what the previous chunk assumed
                 *reinterpret_cast<double2 *>(b_entry + g * N + 2 * q) = make_double2(b2[0], b2[1]);
         }
     }
+
+    if constexpr (!CAREFUL && KIND == EMIT_GAUSS) {
+        if (__ballot(tiny_hi(hmin)) != 0ull && (threadIdx.x & 63) == 0)
+            atomicAdd(&flags[2], 1u);
+    }
+#ifdef ESTEP_CLOCKPROBE
+    if (threadIdx.x == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(flags + 4) + 4 * (size_t)blockIdx.x;
+        o[0] = pc0;
+        o[1] = __builtin_readcyclecounter();
+        o[2] = pr0;
+        o[3] = wall_clock64();
+    }
+#endif
 
     // ---------------- workgroup reduction of the register statistics ----------------------
     // entry e of the statistics vector is owned by lane q = (state of e) / 2; sum over the

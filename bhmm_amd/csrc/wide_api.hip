@@ -182,13 +182,13 @@ int wide_alloc(bhmm_ctx *c)
         (rc = c->d_partials.ensure((size_t)nsmax * S)) ||
         (rc = c->d_waentry.ensure((size_t)nsmax * n)) || (rc = c->d_waexit.ensure((size_t)nsmax * n)) ||
         (rc = c->d_wbexit.ensure((size_t)nsmax * n)) || (rc = c->d_wbentry.ensure((size_t)nsmax * n)) ||
-        (rc = c->d_specres.ensure(2)) ||
+        (rc = c->d_specres.ensure(4)) ||
         (rc = c->d_stats.ensure(1 + n + n * n + n + std::max(2 * n, n * c->M))))
         return rc;
     if (c->kind == EMIT_DISC && (rc = c->d_dpartials.ensure((size_t)nsmax * n * c->M)))
         return rc;
     if (!c->h_specres)
-        BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 2 * sizeof(unsigned int),
+        BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
                                hipHostMallocDefault));
     BHMM_HIP(hipMemsetAsync(c->d_gamma0.p, 0, (size_t)std::max(c->K, 1) * n * sizeof(double),
                             c->stream));

@@ -153,7 +153,10 @@ int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const do
  *                        verified warm-up boundaries; reading it returns the segment count in use
  *   "wide_segment_len"   segment length for the next bhmm_ctx_set_observations (0 = automatic)
  *   "spec_ok", "spec_fail"  (read-only) E-steps whose boundaries verified / fell back
- *   "spec_last_dev" (read-only) largest relative boundary deviation of the last check */
+ *   "spec_last_dev" (read-only) largest relative boundary deviation of the last check
+ *   "careful"       (read-only) 1 after an E-step met an all-zero emission row (gaussian
+ *                   outlier rule, outputmodel.py:126-130) and switched to the kernel that
+ *                   applies the rule per step */
 int bhmm_ctx_set_option(bhmm_ctx *ctx, const char *name, double value);
 int bhmm_ctx_get_option(bhmm_ctx *ctx, const char *name, double *value);
 
