@@ -131,8 +131,14 @@ struct Runner {
             };
             // the branch-free instantiation needs the verdict round trip of the speculative
             // path to report zero / denormal vectors; everything else runs the careful one
+            // (it rescales only every few steps: emission values must stay far from the
+            // exponent range -- caller-supplied pobs and very narrow gaussians do not qualify)
+            bool fast = SPEC && !store_gamma && !c->careful && KIND != EMIT_EXPL;
+            if (KIND == EMIT_GAUSS)
+                for (int i = 0; i < c->n; ++i)
+                    fast = fast && m.e2[i] < 1048576.0;
             int rc;
-            if (SPEC && !store_gamma && !c->careful)
+            if (fast)
                 rc = launch(k_estep<N, KIND, SPEC, false, false>);
             else
                 rc = launch(k_estep<N, KIND, SPEC, true, true>);
@@ -293,29 +299,35 @@ struct Runner {
 #ifdef ESTEP_CLOCKPROBE
         {
             const int nb = c->Gp / 64;
-            std::vector<unsigned long long> pr(4 * (size_t)nb);
+            std::vector<unsigned long long> pr(8 * (size_t)nb);
             BHMM_HIP(hipMemcpy(pr.data(), c->d_specres.p + 4, pr.size() * 8, hipMemcpyDeviceToHost));
             unsigned long long r0 = ~0ull, r1 = 0;
-            double sumd = 0, mind = 1e30, maxd = 0, sumf = 0;
             for (int b = 0; b < nb; ++b) {
-                r0 = std::min(r0, pr[4 * b + 2]);
-                r1 = std::max(r1, pr[4 * b + 3]);
+                r0 = std::min(r0, pr[8 * b + 2]);
+                r1 = std::max(r1, pr[8 * b + 3]);
             }
-            std::vector<int> hist(20, 0);
+            // early finishers (first half by end time) and late finishers separately
+            std::vector<double> ends(nb);
+            for (int b = 0; b < nb; ++b)
+                ends[b] = (double)(pr[8 * b + 3] - r0);
+            std::vector<double> se = ends;
+            std::sort(se.begin(), se.end());
+            const double med = se[nb / 2];
+            double ph[2][4] = {{0}}, cnt[2] = {0, 0}, fr = 0;
             for (int b = 0; b < nb; ++b) {
-                const double d = (double)(pr[4 * b + 3] - pr[4 * b + 2]);
-                sumd += d;
-                mind = std::min(mind, d);
-                maxd = std::max(maxd, d);
-                sumf += (double)(pr[4 * b + 1] - pr[4 * b]) / d;
-                hist[std::min(19, (int)(20.0 * (pr[4 * b + 3] - r0) / (double)(r1 - r0)))]++;
+                const int cls = ends[b] < med ? 0 : 1;
+                const unsigned long long t[5] = {pr[8 * b + 2], pr[8 * b + 4], pr[8 * b + 5],
+                                                 pr[8 * b + 6], pr[8 * b + 3]};
+                for (int k = 0; k < 4; ++k)
+                    ph[cls][k] += (double)(t[k + 1] - t[k]) * 0.01;
+                cnt[cls] += 1;
+                fr += (double)(pr[8 * b + 1] - pr[8 * b]) / (double)(t[4] - t[0]);
             }
-            fprintf(stderr, "[probe] blocks %d span %.1f us; block dur mean %.1f min %.1f max %.1f us; "
-                            "cyclecounter/realtime %.3f; start spread: first end hist:",
-                    nb, (r1 - r0) * 0.01, sumd / nb * 0.01, mind * 0.01, maxd * 0.01, sumf / nb);
-            for (int h : hist)
-                fprintf(stderr, " %d", h);
-            fprintf(stderr, "\n");
+            fprintf(stderr, "[probe] span %.0f us, counter/realtime %.2f | early blocks (wave 0): warmF %.0f "
+                            "mainF %.0f warmB %.0f mainB %.0f us | late: %.0f %.0f %.0f %.0f us\n",
+                    (r1 - r0) * 0.01, fr / nb, ph[0][0] / cnt[0], ph[0][1] / cnt[0], ph[0][2] / cnt[0],
+                    ph[0][3] / cnt[0], ph[1][0] / cnt[1], ph[1][1] / cnt[1], ph[1][2] / cnt[1],
+                    ph[1][3] / cnt[1]);
         }
 #endif
         float dev;
@@ -351,7 +363,7 @@ struct Runner {
         int rc;
         if ((rc = c->d_aexit.ensure((size_t)c->Gp * N)) || (rc = c->d_bentry.ensure((size_t)c->Gp * N)) ||
 #ifdef ESTEP_CLOCKPROBE
-            (rc = c->d_specres.ensure(4 + 8 * (size_t)(c->Gp / 64))))
+            (rc = c->d_specres.ensure(4 + 16 * (size_t)(c->Gp / 64))))
 #else
             (rc = c->d_specres.ensure(4)))
 #endif

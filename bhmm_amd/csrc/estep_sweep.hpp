@@ -21,6 +21,10 @@
 
 #include "estep_kernels.hpp"
 
+#ifndef ESTEP_SCALE_EVERY
+#define ESTEP_SCALE_EVERY 4 // branch-free sweeps rescale every so many steps
+#endif
+
 namespace bhmm {
 
 // exp(x) for x <= 0 to about 1 ulp: x = k ln2 + r, |r| <= ln2/2, exp(r) = 1 + r + r^2 q(r) with
@@ -54,6 +58,20 @@ static __global__ void k_exp_nonpos(const double *x, double *y, int64_t n)
     if (i < n)
         y[i] = exp_nonpos(x[i]);
 }
+
+// compile-time loop index helpers: unrolled<K>(f) calls f(integral_constant<int, 0..K-1>);
+// sc_at<J> says whether step J of an unrolled group rescales (the last one of every
+// ESTEP_SCALE_EVERY)
+template <int K, typename F, int J = 0>
+__device__ __forceinline__ void unrolled(F &&f)
+{
+    if constexpr (J < K) {
+        f(std::integral_constant<int, J>());
+        unrolled<K, F, J + 1>(static_cast<F &&>(f));
+    }
+}
+template <int J>
+using sc_at = std::integral_constant<bool, (J % ESTEP_SCALE_EVERY) == ESTEP_SCALE_EVERY - 1>;
 
 // my two states' slice of the emission model
 struct EmisPair {
@@ -158,14 +176,19 @@ __device__ __forceinline__ bool fix_outlier(const ObsIn &in, int q, int nreal,
 
 // high dword of a non-negative double orders like the value; its top bits are the exponent
 __device__ __forceinline__ bool tiny_hi(int hm) { return hm < 0x00100000; }
+// ... below 2^-800: what the branch-free sweeps (rescaling every ESTEP_SCALE_EVERY steps) report
+__device__ __forceinline__ bool small_hi(int hm) { return hm < ((1023 - 800) << 20); }
 
 // a <- 2^ne (s o p), the group's largest entry brought into [0.5, 1); returns the exponent
-// removed (-ne).  CAREFUL (gaussian): a zero / denormal result takes the slow branch with the
-// outlier rule.  Otherwise the step is branch-free and only records the smallest maximum seen
-// (hmin); the kernel reports chunks where that was zero / denormal and the host repeats the
-// E-step with the CAREFUL instantiation (only the gaussian model has such a rule; for the other
-// emission kinds both variants are the same arithmetic).
-template <int N, int KIND, bool CAREFUL>
+// removed (-ne).
+//   CAREFUL: every step is rescaled; for the gaussian model a zero / denormal result takes the
+//   slow branch with the outlier rule.
+//   otherwise the step is branch-free, rescales only where SCALE is set (every
+//   ESTEP_SCALE_EVERY-th step of the unrolled loops -- powers of two, so the results do not
+//   depend on the schedule) and records the smallest maximum seen at those points (hmin); the
+//   kernel reports chunks where that fell below 2^-800 and the host repeats the E-step with the
+//   CAREFUL instantiation.
+template <int N, int KIND, bool CAREFUL, bool SCALE>
 __device__ __forceinline__ int scaled_emit(const ObsIn &in, int q, int nreal,
                                            unsigned long long gmask, const double (&s)[2],
                                            double (&p)[2], double (&a)[2], int &hmin)
@@ -186,6 +209,11 @@ __device__ __forceinline__ int scaled_emit(const ObsIn &in, int q, int nreal,
     } else {
         n0 = s[0] * p[0];
         n1 = s[1] * p[1];
+        if constexpr (!CAREFUL && !SCALE) {
+            a[0] = n0;
+            a[1] = n1;
+            return 0;
+        }
         hm = grp_max_i32<H>(max(__double2hiint(n0), __double2hiint(n1)));
         hmin = min(hmin, hm);
     }
@@ -268,14 +296,15 @@ __device__ __forceinline__ void bwd_matvec(const Gather<N> &gather, const double
     }
 }
 
-// One backward step without statistics: b <- 2^ne A (p o b); p may be replaced by the outlier
-// row.  bf (the gathered p o b) is returned for the xi accumulation of the caller.
-template <int N, int KIND, bool CAREFUL>
+// One backward step without statistics: bnew <- 2^ne A (p o b) (rescaled as in scaled_emit); p
+// may be replaced by the outlier row.  bf (the gathered p o b) and r (the unscaled product) are
+// returned for the xi accumulation of the caller.
+template <int N, int KIND, bool CAREFUL, bool SCALE>
 __device__ __forceinline__ void beta_step(const Gather<N> &gather, const ObsIn &in, int q,
                                           int nreal, unsigned long long gmask,
-                                          const double (&Ar)[2][N],
-                                          double (&p)[2], const double (&b)[2], double (&bf)[N],
-                                          double (&r)[2], int &ne, int &hmin)
+                                          const double (&Ar)[2][N], double (&p)[2],
+                                          const double (&b)[2], double (&bf)[N], double (&r)[2],
+                                          double (&bnew)[2], int &hmin)
 {
     constexpr int H = N / 2;
     int hm;
@@ -292,10 +321,17 @@ __device__ __forceinline__ void beta_step(const Gather<N> &gather, const ObsIn &
     } else {
         const double bb[2] = {p[0] * b[0], p[1] * b[1]};
         bwd_matvec<N>(gather, bb, Ar, bf, r);
+        if constexpr (!CAREFUL && !SCALE) {
+            bnew[0] = r[0];
+            bnew[1] = r[1];
+            return;
+        }
         hm = grp_max_i32<H>(max(__double2hiint(r[0]), __double2hiint(r[1])));
         hmin = min(hmin, hm);
     }
-    ne = 1022 - (hm >> 20); // see scaled_emit
+    const int ne = 1022 - (hm >> 20); // see scaled_emit
+    bnew[0] = ldexp(r[0], ne);
+    bnew[1] = ldexp(r[1], ne);
 }
 
 // =========================================================================================
@@ -342,6 +378,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
     int hmin = 0x7fffffff;
 #ifdef ESTEP_CLOCKPROBE
     const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = wall_clock64();
+    unsigned long long pr1 = pr0, pr2 = pr0, pr3 = pr0;
 #endif
     if constexpr (KIND == EMIT_DISC) {
         stage_Bt<N>(Bt, Bt_g, m.M);
@@ -400,7 +437,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                 const ObsIn in = load_obs<N, KIND>(obs_ci, rec0, cl, q);
                 double p[2], d[2];
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                eP = scaled_emit<N, KIND, CAREFUL>(in, q, nreal, gmask, pi2, p, a, hmin);
+                eP = scaled_emit<N, KIND, CAREFUL, true>(in, q, nreal, gmask, pi2, p, a, hmin);
                 *ci_pair(ws, rec0, N, q, cl) = make_double2(a[0], a[1]);
                 s = 1;
             } else {
@@ -409,17 +446,18 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                     // -- where that reaches the start of the trajectory -- exactly from pi
                     int nw = (int)(t0 < (int64_t)W ? t0 : (int64_t)W);
                     int64_t pos = goff - nw;
-                    auto wstep = [&](const ObsIn &in) {
+                    auto wstep = [&](const ObsIn &in, auto sc) {
                         double p[2], d[2], sv[2];
                         emit_raw<N, KIND>(in, Bt, q, em, p, d);
                         fwd_matvec<N>(gather, a, Ac, sv);
-                        (void)scaled_emit<N, KIND, CAREFUL>(in, q, nreal, gmask, sv, p, a, hmin);
+                        (void)scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask,
+                                                                                 sv, p, a, hmin);
                     };
                     if ((int64_t)nw == t0) {
                         const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
                         double p[2], d[2];
                         emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                        (void)scaled_emit<N, KIND, CAREFUL>(in, q, nreal, gmask, pi2, p, a, hmin);
+                        (void)scaled_emit<N, KIND, CAREFUL, true>(in, q, nreal, gmask, pi2, p, a, hmin);
                         ++pos;
                         --nw;
                     } else {
@@ -428,7 +466,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                     }
                     for (int i = nw & 3; i > 0; --i) {
                         const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
-                        wstep(in);
+                        wstep(in, std::true_type());
                         ++pos;
                     }
                     nw &= ~3;
@@ -448,9 +486,10 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                                 for (int j = 0; j < 4; ++j)
                                     nx[j] = load_obs_rm<N, KIND>(obs_rm, pos + j, q, nreal);
                             }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                wstep(c[j]);
+                            wstep(c[0], sc_at<0>());
+                            wstep(c[1], sc_at<1>());
+                            wstep(c[2], sc_at<2>());
+                            wstep(c[3], sc_at<3>());
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 c[j] = nx[j];
@@ -466,13 +505,24 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                 }
                 Sin = grp_sum<H>(a[0] + a[1]);
             }
+#ifdef ESTEP_CLOCKPROBE
+            pr1 = wall_clock64();
+#endif
             constexpr int RS = (N / 2) * 64; // double2 elements per CI record of N doubles
-            auto fstep = [&](const ObsIn &in, double2 *dst) {
+            auto fstep = [&](const ObsIn &in, double2 *dst, auto sc) {
                 double p[2], d[2], sv[2];
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
                 fwd_matvec<N>(gather, a, Ac, sv);
-                eP += scaled_emit<N, KIND, CAREFUL>(in, q, nreal, gmask, sv, p, a, hmin);
+                eP += scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask, sv, p,
+                                                                        a, hmin);
+#if defined(ESTEP_ABLATE_STORE) // timing experiments only
+                if (a[0] == 12345.678)
+                    *dst = make_double2(a[0], a[1]);
+#elif defined(ESTEP_ABLATE_HALFSTORE)
+                *(reinterpret_cast<double *>(dst) - (threadIdx.x & 63)) = a[0];
+#else
                 *dst = make_double2(a[0], a[1]);
+#endif
             };
             ObsCursor<N, KIND> po(obs_ci, rec0 + s, cl, q);
             double2 *pw = ci_pair(ws, rec0 + s, N, q, cl);
@@ -481,7 +531,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             // single steps until the rest is a multiple of 2 PF, then two register sets of PF
             // steps, each loaded PF..2PF-1 steps before its use
             for (int i = rem % (2 * PF); i > 0; --i) {
-                fstep(po.at(0), pw);
+                fstep(po.at(0), pw, std::true_type());
                 po.move(1);
                 pw += RS;
             }
@@ -495,21 +545,20 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
 #pragma unroll
                     for (int j = 0; j < PF; ++j)
                         y[j] = po.at(PF + j);
-#pragma unroll
-                    for (int j = 0; j < PF; ++j)
-                        fstep(x[j], pw + j * RS);
+                    unrolled<PF>([&](auto j) { fstep(x[j], pw + j * RS, sc_at<j>()); });
                     if (rem > 2 * PF) {
 #pragma unroll
                         for (int j = 0; j < PF; ++j)
                             x[j] = po.at(2 * PF + j);
                     }
-#pragma unroll
-                    for (int j = 0; j < PF; ++j)
-                        fstep(y[j], pw + (PF + j) * RS);
+                    unrolled<PF>([&](auto j) { fstep(y[j], pw + (PF + j) * RS, sc_at<PF + j>()); });
                     po.move(2 * PF);
                     pw += 2 * PF * RS;
                 }
             }
+#ifdef ESTEP_CLOCKPROBE
+            pr2 = wall_clock64();
+#endif
             const double Sfin = grp_sum<H>(a[0] + a[1]);
             if (q == 0)
                 logL_chunk[g] = log(Sfin / Sin) + (double)eP * 0.693147180559945309417232121458;
@@ -535,17 +584,17 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             int64_t pos = goff + len + nw - 1;
             b2[0] = u0;
             b2[1] = u1;
-            auto wstep = [&](const ObsIn &in) {
-                double p[2], d[2], bf[N], r[2];
-                int ne;
+            auto wstep = [&](const ObsIn &in, auto sc) {
+                double p[2], d[2], bf[N], r[2], bn[2];
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                beta_step<N, KIND, CAREFUL>(gather, in, q, nreal, gmask, Ar, p, b2, bf, r, ne, hmin);
-                b2[0] = ldexp(r[0], ne);
-                b2[1] = ldexp(r[1], ne);
+                beta_step<N, KIND, CAREFUL, decltype(sc)::value>(gather, in, q, nreal, gmask, Ar, p,
+                                                                 b2, bf, r, bn, hmin);
+                b2[0] = bn[0];
+                b2[1] = bn[1];
             };
             for (int i = nw & 3; i > 0; --i) {
                 const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
-                wstep(in);
+                wstep(in, std::true_type());
                 --pos;
             }
             nw &= ~3;
@@ -565,9 +614,10 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                         for (int j = 0; j < 4; ++j)
                             nx[j] = load_obs_rm<N, KIND>(obs_rm, pos - j, q, nreal);
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        wstep(c[j]);
+                    wstep(c[0], sc_at<0>());
+                    wstep(c[1], sc_at<1>());
+                    wstep(c[2], sc_at<2>());
+                    wstep(c[3], sc_at<3>());
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         c[j] = nx[j];
@@ -580,6 +630,9 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             b2[1] = x.y;
         }
         {
+#ifdef ESTEP_CLOCKPROBE
+            pr3 = wall_clock64();
+#endif
             gam[0] = a[0] * b2[0];
             gam[1] = a[1] * b2[1];
             const double rS = fast_rcp(grp_sum<H>(gam[0] + gam[1]));
@@ -606,12 +659,12 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
         };
         // step s with apv = alpha_{s-1}: consume gamma_s, then the pair (s-1, s) gives the xi
         // contribution, gamma_{s-1} and beta_{s-1}
-        auto bstep = [&](const ObsIn &in, const double2 &apv, double2 *gdst) {
-            double p[2], d[2], bf[N], r[2];
-            int ne;
+        auto bstep = [&](const ObsIn &in, const double2 &apv, double2 *gdst, auto sc) {
+            double p[2], d[2], bf[N], r[2], bn[2];
             emit_raw<N, KIND>(in, Bt, q, em, p, d);
             consume(in, d, gdst);
-            beta_step<N, KIND, CAREFUL>(gather, in, q, nreal, gmask, Ar, p, b2, bf, r, ne, hmin);
+            beta_step<N, KIND, CAREFUL, decltype(sc)::value>(gather, in, q, nreal, gmask, Ar, p, b2,
+                                                             bf, r, bn, hmin);
             const double q0 = apv.x * r[0], q1 = apv.y * r[1];
             const double rS = fast_rcp(grp_sum<H>(q0 + q1));
             gam[0] = q0 * rS;
@@ -622,8 +675,8 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                 Cacc[0][j] = fma(w0, bf[j], Cacc[0][j]);
                 Cacc[1][j] = fma(w1, bf[j], Cacc[1][j]);
             }
-            b2[0] = ldexp(r[0], ne);
-            b2[1] = ldexp(r[1], ne);
+            b2[0] = bn[0];
+            b2[1] = bn[1];
         };
         // the observation of step 0 is needed last: fetch it now
         const ObsIn in0 = ObsCursor<N, KIND>(obs_ci, rec0, cl, q).at(0);
@@ -636,7 +689,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             int rem = len - 1;
             constexpr int PF = ESTEP_PF_B;
             for (int i = rem % (2 * PF); i > 0; --i) { // as in the forward sweep
-                bstep(po.at(0), pa[-RS], pg);
+                bstep(po.at(0), pa[-RS], pg, std::true_type());
                 po.move(-1);
                 pa -= RS;
                 pg -= RS;
@@ -656,9 +709,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                         y[j] = po.at(-(PF + j));
                         v[j] = pa[-(PF + j + 1) * RS];
                     }
-#pragma unroll
-                    for (int j = 0; j < PF; ++j)
-                        bstep(x[j], u[j], pg - j * RS);
+                    unrolled<PF>([&](auto j) { bstep(x[j], u[j], pg - j * RS, sc_at<j>()); });
                     if (rem > 2 * PF) {
 #pragma unroll
                         for (int j = 0; j < PF; ++j) {
@@ -666,9 +717,8 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                             u[j] = pa[-(2 * PF + j + 1) * RS];
                         }
                     }
-#pragma unroll
-                    for (int j = 0; j < PF; ++j)
-                        bstep(y[j], v[j], pg - (PF + j) * RS);
+                    unrolled<PF>(
+                        [&](auto j) { bstep(y[j], v[j], pg - (PF + j) * RS, sc_at<PF + j>()); });
                     po.move(-2 * PF);
                     pa -= 2 * PF * RS;
                     pg -= 2 * PF * RS;
@@ -686,23 +736,26 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             *reinterpret_cast<double2 *>(gamma0 + (int64_t)k * N + 2 * q) =
                 make_double2(gam[0], gam[1]);
         } else {
-            bstep(in0, aent, pg0);
+            bstep(in0, aent, pg0, std::true_type());
             if constexpr (SPEC) // beta one step before this chunk: what the previous chunk assumed
                 *reinterpret_cast<double2 *>(b_entry + g * N + 2 * q) = make_double2(b2[0], b2[1]);
         }
     }
 
-    if constexpr (!CAREFUL && KIND == EMIT_GAUSS) {
-        if (__ballot(tiny_hi(hmin)) != 0ull && (threadIdx.x & 63) == 0)
+    if constexpr (!CAREFUL) {
+        if (__ballot(small_hi(hmin)) != 0ull && (threadIdx.x & 63) == 0)
             atomicAdd(&flags[2], 1u);
     }
 #ifdef ESTEP_CLOCKPROBE
     if (threadIdx.x == 0) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(flags + 4) + 4 * (size_t)blockIdx.x;
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(flags + 4) + 8 * (size_t)blockIdx.x;
         o[0] = pc0;
         o[1] = __builtin_readcyclecounter();
         o[2] = pr0;
         o[3] = wall_clock64();
+        o[4] = pr1;
+        o[5] = pr2;
+        o[6] = pr3;
     }
 #endif
 
