@@ -348,6 +348,9 @@ __device__ __forceinline__ void beta_step(const Gather<N> &gather, const ObsIn &
 #ifndef ESTEP_PF_B
 #define ESTEP_PF_B 2 // ... backward sweep (observations + alpha)
 #endif
+#ifndef ESTEP_CKPT
+#define ESTEP_CKPT 1 // keep every second alpha row in HBM, rebuild the others
+#endif
 #ifndef ESTEP_WAVES
 #define ESTEP_WAVES 2
 #endif
@@ -421,14 +424,15 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
     if (len > 0) {
         double a[2];
         double2 aent = make_double2(0.0, 0.0); // the vector this chunk was entered with
+        // my two columns of A (forward products; with ESTEP_CKPT also the backward sweep)
+        double Ac[N][2];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            Ac[i][0] = m.A[i * N + 2 * q];
+            Ac[i][1] = m.A[i * N + 2 * q + 1];
+        }
         // ---------------- forward sweep (_hidden.c:16-66) ------------------------------
         {
-            double Ac[N][2];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                Ac[i][0] = m.A[i * N + 2 * q];
-                Ac[i][1] = m.A[i * N + 2 * q + 1];
-            }
             int eP = 0;       // sum of the exponents removed
             double Sin = 1.0; // sum of the entry vector
             int s = 0;
@@ -509,35 +513,41 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             pr1 = wall_clock64();
 #endif
             constexpr int RS = (N / 2) * 64; // double2 elements per CI record of N doubles
-            auto fstep = [&](const ObsIn &in, double2 *dst, auto sc) {
+            // Which alpha rows reach HBM.  The forward main sweep is bound by HBM write bandwidth
+            // when every row is stored, so with ESTEP_CKPT only the rows of
+            // even steps are, plus the last rows of the chunk that the single steps of the
+            // backward sweep read; the backward sweep rebuilds alpha_{s-1} from alpha_{s-2} and
+            // the emission of step s-1, which it needs anyway.
+            auto fstep = [&](const ObsIn &in, double2 &out, auto sc) {
                 double p[2], d[2], sv[2];
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
                 fwd_matvec<N>(gather, a, Ac, sv);
                 eP += scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask, sv, p,
                                                                         a, hmin);
-#if defined(ESTEP_ABLATE_STORE) // timing experiments only
-                if (a[0] == 12345.678)
-                    *dst = make_double2(a[0], a[1]);
-#elif defined(ESTEP_ABLATE_HALFSTORE)
-                *(reinterpret_cast<double *>(dst) - (threadIdx.x & 63)) = a[0];
-#else
-                *dst = make_double2(a[0], a[1]);
-#endif
+                out = make_double2(a[0], a[1]);
+            };
+            auto single = [&](ObsCursor<N, KIND> &po, double2 *&pw) {
+                double2 o;
+                fstep(po.at(0), o, std::true_type());
+                *pw = o;
+                po.move(1);
+                pw += RS;
             };
             ObsCursor<N, KIND> po(obs_ci, rec0 + s, cl, q);
             double2 *pw = ci_pair(ws, rec0 + s, N, q, cl);
-            int rem = len - s;
             constexpr int PF = ESTEP_PF_F;
-            // single steps until the rest is a multiple of 2 PF, then two register sets of PF
-            // steps, each loaded PF..2PF-1 steps before its use
-            for (int i = rem % (2 * PF); i > 0; --i) {
-                fstep(po.at(0), pw, std::true_type());
-                po.move(1);
-                pw += RS;
+            static_assert(PF % 2 == 0, "row parity inside the unrolled groups");
+            if ((s & 1) && s < len) { // first chunk of a trajectory: bring the group base to an even step
+                single(po, pw);
+                ++s;
             }
-            rem -= rem % (2 * PF);
+            // groups of 2 PF steps (two register sets, each loaded PF..2PF-1 steps before its
+            // use), then the remaining 0 .. 2PF-1 steps one by one
+            const int tail = (len - s) % (2 * PF);
+            int rem = len - s - tail;
             if (rem > 0) {
                 ObsIn x[PF], y[PF];
+                double2 ox[PF], oy[PF];
 #pragma unroll
                 for (int j = 0; j < PF; ++j)
                     x[j] = po.at(j);
@@ -545,17 +555,38 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
 #pragma unroll
                     for (int j = 0; j < PF; ++j)
                         y[j] = po.at(PF + j);
-                    unrolled<PF>([&](auto j) { fstep(x[j], pw + j * RS, sc_at<j>()); });
+                    unrolled<PF>([&](auto j) {
+                        fstep(x[j], ox[j], sc_at<j>());
+                        if constexpr (!ESTEP_CKPT || j % 2 == 0)
+                            pw[j * RS] = ox[j];
+                    });
                     if (rem > 2 * PF) {
 #pragma unroll
                         for (int j = 0; j < PF; ++j)
                             x[j] = po.at(2 * PF + j);
                     }
-                    unrolled<PF>([&](auto j) { fstep(y[j], pw + (PF + j) * RS, sc_at<PF + j>()); });
+                    unrolled<PF>([&](auto j) {
+                        fstep(y[j], oy[j], sc_at<PF + j>());
+                        if constexpr (!ESTEP_CKPT || j % 2 == 0)
+                            pw[(PF + j) * RS] = oy[j];
+                    });
+                    if constexpr (ESTEP_CKPT != 0) {
+                        // the backward sweep reads the last (len-1) % 4 + 1 rows directly: if the
+                        // single steps below do not cover them, the odd rows of the last group do
+                        if (rem == 2 * PF && tail < 4) {
+#pragma unroll
+                            for (int j = 1; j < PF; j += 2) {
+                                pw[j * RS] = ox[j];
+                                pw[(PF + j) * RS] = oy[j];
+                            }
+                        }
+                    }
                     po.move(2 * PF);
                     pw += 2 * PF * RS;
                 }
             }
+            for (int i = tail; i > 0; --i)
+                single(po, pw);
 #ifdef ESTEP_CLOCKPROBE
             pr2 = wall_clock64();
 #endif
@@ -657,11 +688,11 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                 if (gamma_ci)
                     *gdst = make_double2(gam[0], gam[1]);
         };
-        // step s with apv = alpha_{s-1}: consume gamma_s, then the pair (s-1, s) gives the xi
-        // contribution, gamma_{s-1} and beta_{s-1}
-        auto bstep = [&](const ObsIn &in, const double2 &apv, double2 *gdst, auto sc) {
-            double p[2], d[2], bf[N], r[2], bn[2];
-            emit_raw<N, KIND>(in, Bt, q, em, p, d);
+        // step s with apv = alpha_{s-1} and the emission row p of step s: consume gamma_s, then
+        // the pair (s-1, s) gives the xi contribution, gamma_{s-1} and beta_{s-1}
+        auto bcore = [&](const ObsIn &in, double (&p)[2], const double (&d)[2], const double2 &apv,
+                         double2 *gdst, auto sc) {
+            double bf[N], r[2], bn[2];
             consume(in, d, gdst);
             beta_step<N, KIND, CAREFUL, decltype(sc)::value>(gather, in, q, nreal, gmask, Ar, p, b2,
                                                              bf, r, bn, hmin);
@@ -678,6 +709,25 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             b2[0] = bn[0];
             b2[1] = bn[1];
         };
+        auto bstep = [&](const ObsIn &in, const double2 &apv, double2 *gdst, auto sc) {
+            double p[2], d[2];
+            emit_raw<N, KIND>(in, Bt, q, em, p, d);
+            bcore(in, p, d, apv, gdst, sc);
+        };
+        // steps s and s-1 from the stored row alpha_{s-2}: alpha_{s-1} = (alpha_{s-2} A) o p_{s-1}
+        // up to a scale, which gamma and xi do not see
+        auto bpair = [&](const ObsIn &hi, const ObsIn &lo, const double2 &alo, double2 *gdst,
+                         auto sc_hi, auto sc_lo) {
+            double p_hi[2], d_hi[2], p_lo[2], d_lo[2], sv[2], ah[2];
+            emit_raw<N, KIND>(hi, Bt, q, em, p_hi, d_hi);
+            emit_raw<N, KIND>(lo, Bt, q, em, p_lo, d_lo);
+            const double al[2] = {alo.x, alo.y};
+            fwd_matvec<N>(gather, al, Ac, sv);
+            int unused = 0x7fffffff;
+            (void)scaled_emit<N, KIND, CAREFUL, false>(lo, q, nreal, gmask, sv, p_lo, ah, unused);
+            bcore(hi, p_hi, d_hi, make_double2(ah[0], ah[1]), gdst, sc_hi);
+            bcore(lo, p_lo, d_lo, alo, gdst - RS, sc_lo);
+        };
         // the observation of step 0 is needed last: fetch it now
         const ObsIn in0 = ObsCursor<N, KIND>(obs_ci, rec0, cl, q).at(0);
         double2 *const pg0 = GAMMA && gamma_ci ? ci_pair(gamma_ci, rec0, N, q, cl) : nullptr;
@@ -687,41 +737,73 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             const double2 *pa = ci_pair(ws, rec0 + len - 1, N, q, cl);
             double2 *pg = pg0 + (int64_t)(len - 1) * RS;
             int rem = len - 1;
-            constexpr int PF = ESTEP_PF_B;
-            for (int i = rem % (2 * PF); i > 0; --i) { // as in the forward sweep
-                bstep(po.at(0), pa[-RS], pg, std::true_type());
-                po.move(-1);
-                pa -= RS;
-                pg -= RS;
-            }
-            rem -= rem % (2 * PF);
-            if (rem > 0) {
-                ObsIn x[PF], y[PF];
-                double2 u[PF], v[PF];
-#pragma unroll
-                for (int j = 0; j < PF; ++j) {
-                    x[j] = po.at(-j);
-                    u[j] = pa[-(j + 1) * RS];
+            if constexpr (ESTEP_CKPT != 0) {
+                // (len-1) % 4 single steps on stored rows, then groups of two pairs: two register
+                // sets {obs_s, obs_{s-1}, alpha_{s-2}}, each loaded 2..3 steps before its use
+                for (int i = rem % 4; i > 0; --i) {
+                    bstep(po.at(0), pa[-RS], pg, std::true_type());
+                    po.move(-1);
+                    pa -= RS;
+                    pg -= RS;
                 }
-                for (; rem > 0; rem -= 2 * PF) {
+                rem -= rem % 4;
+                if (rem > 0) {
+                    ObsIn xh = po.at(0), xl = po.at(-1), yh, yl;
+                    double2 xa = pa[-2 * RS], ya;
+                    for (; rem > 0; rem -= 4) {
+                        yh = po.at(-2);
+                        yl = po.at(-3);
+                        ya = pa[-4 * RS];
+                        bpair(xh, xl, xa, pg, sc_at<0>(), sc_at<1>());
+                        if (rem > 4) {
+                            xh = po.at(-4);
+                            xl = po.at(-5);
+                            xa = pa[-6 * RS];
+                        }
+                        bpair(yh, yl, ya, pg - 2 * RS, sc_at<2>(), sc_at<3>());
+                        po.move(-4);
+                        pa -= 4 * RS;
+                        pg -= 4 * RS;
+                    }
+                }
+            } else {
+                constexpr int PF = ESTEP_PF_B;
+                for (int i = rem % (2 * PF); i > 0; --i) { // as in the forward sweep
+                    bstep(po.at(0), pa[-RS], pg, std::true_type());
+                    po.move(-1);
+                    pa -= RS;
+                    pg -= RS;
+                }
+                rem -= rem % (2 * PF);
+                if (rem > 0) {
+                    ObsIn x[PF], y[PF];
+                    double2 u[PF], v[PF];
 #pragma unroll
                     for (int j = 0; j < PF; ++j) {
-                        y[j] = po.at(-(PF + j));
-                        v[j] = pa[-(PF + j + 1) * RS];
+                        x[j] = po.at(-j);
+                        u[j] = pa[-(j + 1) * RS];
                     }
-                    unrolled<PF>([&](auto j) { bstep(x[j], u[j], pg - j * RS, sc_at<j>()); });
-                    if (rem > 2 * PF) {
+                    for (; rem > 0; rem -= 2 * PF) {
 #pragma unroll
                         for (int j = 0; j < PF; ++j) {
-                            x[j] = po.at(-(2 * PF + j));
-                            u[j] = pa[-(2 * PF + j + 1) * RS];
+                            y[j] = po.at(-(PF + j));
+                            v[j] = pa[-(PF + j + 1) * RS];
                         }
+                        unrolled<PF>([&](auto j) { bstep(x[j], u[j], pg - j * RS, sc_at<j>()); });
+                        if (rem > 2 * PF) {
+#pragma unroll
+                            for (int j = 0; j < PF; ++j) {
+                                x[j] = po.at(-(2 * PF + j));
+                                u[j] = pa[-(2 * PF + j + 1) * RS];
+                            }
+                        }
+                        unrolled<PF>([&](auto j) {
+                            bstep(y[j], v[j], pg - (PF + j) * RS, sc_at<PF + j>());
+                        });
+                        po.move(-2 * PF);
+                        pa -= 2 * PF * RS;
+                        pg -= 2 * PF * RS;
                     }
-                    unrolled<PF>(
-                        [&](auto j) { bstep(y[j], v[j], pg - (PF + j) * RS, sc_at<PF + j>()); });
-                    po.move(-2 * PF);
-                    pa -= 2 * PF * RS;
-                    pg -= 2 * PF * RS;
                 }
             }
         }
