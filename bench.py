@@ -231,13 +231,13 @@ def main():
         names = ["prescan", "stitch", "fwdbwd", "finalize", "estep_total"]
         dom = int(np.argmax(kern_ms[:4]))
         # algorithmic bytes of the canonical two-pass algorithm: the streaming
-        # kernel k_fwdbwd carries all of them (obs twice, alpha written once and read once).
+        # kernel k_estep carries them (obs twice, alpha written once and read once).
         alg_bytes_launch = B_ALG_GAUSS * K * T
         achieved = alg_bytes_launch / (kern_ms[2] * 1e-3) / 1e9
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01", "r01f_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r01", "r01k_traffic.json")
         if os.path.exists(tj) and (K, T) == (256, 100000):
-            # HBM bytes of one k_fwdbwd launch from the PMC counters (collected offline with
+            # HBM bytes of one k_estep launch from the PMC counters (collected offline with
             # rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)
             if eng.get_option("spec_ok") > 0 and eng.get_option("spec_fail") == 0:
                 traffic = json.load(open(tj))["traffic_bytes_per_launch"]
@@ -256,10 +256,10 @@ def main():
                                                    "spec_last_dev")},
                        "parallelism": "trajectories sharded over %d GPU(s), RCCL all-reduce of "
                                       "%d statistics" % (world, S)},
-            "roofline": {"bound": "hbm", "kernel": "k_fwdbwd<8,gauss,estep,spec>",
+            "roofline": {"bound": "hbm", "kernel": "k_estep<8,gauss,spec>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, profiles/r01/r01f_traffic.json)",
+                         "traffic_unit": "bytes per launch (PMC, profiles/r01/r01k_traffic.json)",
                          "alg_bytes_per_launch": alg_bytes_launch,
                          "alg_bytes_per_timestep": B_ALG_GAUSS,
                          "whole_estep_frac": B_ALG_GAUSS * value / world / 1e9 / HBM_PEAK_GBS},

@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import make_c2_model, metastable_matrix, stationary  # noqa: E402
 from bhmm_amd.engine import Engine  # noqa: E402

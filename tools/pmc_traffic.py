@@ -1,7 +1,7 @@
 """Run a few E-steps plus a calibration copy of known size (for the FETCH_SIZE / WRITE_SIZE
 counter calibration prescribed by MI355X_MICROARCH.md, section HBM)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bench import make_c2_model, synth_gaussian
 from bhmm_amd.engine import Engine
