@@ -264,13 +264,24 @@ struct Gather {
     }
 };
 
-// s = (a^T A)[my two states]:  all-gather of a over the group, my two columns of A
-template <int N>
-__device__ __forceinline__ void fwd_matvec(const Gather<N> &gather, const double (&a)[2],
-                                           const double (&Ac)[N][2], double (&s)[2])
+// Scheduling fence: the exchange above has a latency of a few hundred cycles; independent
+// arithmetic (the exp of the emission density) is placed between issuing it and using its result,
+// and the compiler is kept from moving it back (ESTEP_SHADOW=0: leave the order to the compiler).
+#ifndef ESTEP_SHADOW
+#define ESTEP_SHADOW 1
+#endif
+__device__ __forceinline__ void sched_fence()
 {
-    double af[N];
-    gather(a, af);
+#if ESTEP_SHADOW
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// s = (a^T A)[my two states] from the gathered vector and my two columns of A
+template <int N>
+__device__ __forceinline__ void fwd_dot(const double (&af)[N], const double (&Ac)[N][2],
+                                        double (&s)[2])
+{
     s[0] = af[0] * Ac[0][0];
     s[1] = af[0] * Ac[0][1];
 #pragma unroll
@@ -278,6 +289,14 @@ __device__ __forceinline__ void fwd_matvec(const Gather<N> &gather, const double
         s[0] = fma(af[i], Ac[i][0], s[0]);
         s[1] = fma(af[i], Ac[i][1], s[1]);
     }
+}
+template <int N>
+__device__ __forceinline__ void fwd_matvec(const Gather<N> &gather, const double (&a)[2],
+                                           const double (&Ac)[N][2], double (&s)[2])
+{
+    double af[N];
+    gather(a, af);
+    fwd_dot<N>(af, Ac, s);
 }
 
 // r = (A bb)[my two states], bf = all-gather of bb
@@ -451,9 +470,12 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                     int nw = (int)(t0 < (int64_t)W ? t0 : (int64_t)W);
                     int64_t pos = goff - nw;
                     auto wstep = [&](const ObsIn &in, auto sc) {
-                        double p[2], d[2], sv[2];
+                        double p[2], d[2], sv[2], af[N];
+                        gather(a, af);
+                        sched_fence();
                         emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                        fwd_matvec<N>(gather, a, Ac, sv);
+                        sched_fence();
+                        fwd_dot<N>(af, Ac, sv);
                         (void)scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask,
                                                                                  sv, p, a, hmin);
                     };
@@ -519,9 +541,12 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             // backward sweep read; the backward sweep rebuilds alpha_{s-1} from alpha_{s-2} and
             // the emission of step s-1, which it needs anyway.
             auto fstep = [&](const ObsIn &in, double2 &out, auto sc) {
-                double p[2], d[2], sv[2];
+                double p[2], d[2], sv[2], af[N];
+                gather(a, af);
+                sched_fence();
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
-                fwd_matvec<N>(gather, a, Ac, sv);
+                sched_fence();
+                fwd_dot<N>(af, Ac, sv);
                 eP += scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask, sv, p,
                                                                         a, hmin);
                 out = make_double2(a[0], a[1]);
