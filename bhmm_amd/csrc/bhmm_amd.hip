@@ -107,8 +107,11 @@ struct Runner {
     }
 
     template <int KIND, int MODE, bool SPEC = false>
-    static int fwdbwd(bhmm_ctx *c, const Model<N> &m, bool store_gamma)
+    static int fwdbwd(bhmm_ctx *c, const Model<N> &m, bool store_gamma,
+                      unsigned int *flag_words = nullptr)
     {
+        if (!flag_words)
+            flag_words = c->d_specres.p;
         const Chunks ch = chunks_of(c);
         const int nblk = c->Gp / 64; // one workgroup per CI record group (64 chunks)
         const size_t sm = smem_fwdbwd<N, KIND>(c->M);
@@ -125,8 +128,7 @@ struct Runner {
                                    c->d_aentry.p, c->d_bexit.p, c->d_aexit.p, c->d_bentry.p,
                                    c->spec_W, c->d_ws.p,
                                    store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
-                                   c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p,
-                                   c->d_specres.p);
+                                   c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p, flag_words);
                 return BHMM_OK;
             };
             // the branch-free instantiation needs the verdict round trip of the speculative
@@ -183,9 +185,15 @@ struct Runner {
                           bool *verified)
     {
         *verified = false;
+#ifdef ESTEP_CLOCKPROBE
         int rc = spec_prepare(c);
+#else
+        int rc = spec_prepare(c, false); // the tail kernel clears the verdict words itself
+#endif
         if (rc)
             return rc;
+#ifdef ESTEP_CLOCKPROBE
+        // instrumented build: separate tail kernels, probe records behind the verdict words
         BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
         BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
         BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
@@ -195,8 +203,48 @@ struct Runner {
         if ((rc = finish<KIND>(c, m, stats_dev)))
             return rc;
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
+        c->ev_lean = false;
         if ((rc = spec_verdict(c, true, verified, stats_dev)))
             return rc;
+#else
+        // sweep kernel, one tail kernel (statistics, log-likelihoods, boundary check), one
+        // device-to-host copy of [verdict words | statistics | logL_k], one synchronisation
+        const int S = stats_size(c);
+        const size_t ntail = 4 + (size_t)S + std::max(c->K, 1);
+        if (!c->tail_ready) {
+            if ((rc = c->d_tail.ensure(ntail)))
+                return rc;
+            BHMM_HIP(hipMemsetAsync(c->d_tail.p, 0, 4 * sizeof(double), c->stream));
+            c->tail_slot = 0;
+            c->tail_ready = true;
+        }
+        const int slot = c->tail_slot;
+        c->tail_slot ^= 1;
+        unsigned int *words = reinterpret_cast<unsigned int *>(c->d_tail.p) + 4 * slot;
+        unsigned int *words_next = reinterpret_cast<unsigned int *>(c->d_tail.p) + 4 * (slot ^ 1);
+        BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
+        rc = fwdbwd<KIND, MODE_ESTEP, true>(c, m, (flags & BHMM_FLAG_STORE_GAMMA) != 0, words);
+        if (rc)
+            return rc;
+        const int nfin = StatLayout<N, KIND>::S + (KIND == EMIT_DISC ? c->M * N : 0) + N + 1;
+        hipLaunchKernelGGL((k_tail<N, KIND>), dim3(nfin + c->K + (c->G + 63) / 64), dim3(64), 0,
+                           c->stream, m, chunks_of(c), c->K, c->G, c->Gp / 64, nfin,
+                           (const int32_t *)c->d_traj_c0.p, (const double *)c->d_partials.p,
+                           (const double *)c->d_dpartials.p, (const double *)c->d_logLc.p,
+                           (const double *)c->d_gamma0.p, (const double *)c->d_aentry.p,
+                           (const double *)c->d_aexit.p, (const double *)c->d_bexit.p,
+                           (const double *)c->d_bentry.p, 1e-11, stats_dev, c->d_logLk.p,
+                           c->d_tail.p + 4, S, words, words_next);
+        BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
+        c->ev_lean = true;
+        BHMM_HIP(hipMemcpyAsync(c->h_raw, c->d_tail.p, ntail * sizeof(double), hipMemcpyDeviceToHost,
+                                c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        if ((rc = apply_verdict(c, reinterpret_cast<const unsigned int *>(c->h_raw) + 4 * slot,
+                                verified, true)))
+            return rc;
+#endif
         if (*verified)
             c->ev_pending = true;
         return BHMM_OK;
@@ -330,11 +378,19 @@ struct Runner {
                     ph[1][3] / cnt[1]);
         }
 #endif
+        return apply_verdict(c, c->h_specres, verified, stats_src != nullptr);
+    }
+
+    // words: [0] boundaries out of tolerance, [1] largest deviation (float bits), [2] chunks of
+    // the branch-free sweep that met a zero / tiny vector
+    static int apply_verdict(bhmm_ctx *c, const unsigned int *words, bool *verified,
+                             bool results_on_host)
+    {
         float dev;
-        memcpy(&dev, &c->h_specres[1], sizeof(float));
+        memcpy(&dev, &words[1], sizeof(float));
         c->spec_last_dev = dev;
-        *verified = c->h_specres[0] == 0;
-        if (c->h_specres[2] != 0) {
+        *verified = words[0] == 0;
+        if (words[2] != 0) {
             // the branch-free sweep met a zero / denormal vector (an all-zero emission row,
             // outputmodel.py:126-130): its statistics are void, repeat with the careful kernel
             // and keep using that one for this set of observations
@@ -344,7 +400,7 @@ struct Runner {
             return BHMM_OK;
         }
         if (*verified) {
-            c->prefetched = stats_src != nullptr;
+            c->prefetched = results_on_host;
             c->spec_ok++;
         } else {
             // lengthen the warm-up for the next call; give up once it would cost more than the
@@ -358,7 +414,7 @@ struct Runner {
         return BHMM_OK;
     }
 
-    static int spec_prepare(bhmm_ctx *c)
+    static int spec_prepare(bhmm_ctx *c, bool clear_words = true)
     {
         int rc;
         if ((rc = c->d_aexit.ensure((size_t)c->Gp * N)) || (rc = c->d_bentry.ensure((size_t)c->Gp * N)) ||
@@ -371,7 +427,8 @@ struct Runner {
         if (!c->h_specres)
             BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
                                    hipHostMallocDefault));
-        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+        if (clear_words)
+            BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
         return BHMM_OK;
     }
 
@@ -548,6 +605,21 @@ static int stats_size(const bhmm_ctx *c)
     return s;
 }
 
+// pinned landing zone: 4 doubles of verdict words in front of [stats | logL_k]
+static int ensure_pinned(bhmm_ctx *c, size_t need)
+{
+    if (need > c->h_pinned_n) {
+        if (c->h_raw)
+            (void)hipHostFree(c->h_raw);
+        c->h_raw = c->h_pinned = nullptr;
+        BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_raw), (need + 4) * sizeof(double),
+                               hipHostMallocDefault));
+        c->h_pinned = c->h_raw + 4;
+        c->h_pinned_n = need;
+    }
+    return BHMM_OK;
+}
+
 static int alloc_work(bhmm_ctx *c)
 {
     const int N = c->N;
@@ -570,16 +642,8 @@ static int alloc_work(bhmm_ctx *c)
     BHMM_HIP(hipMemsetAsync(c->d_logLc.p, 0, c->Gp * sizeof(double), c->stream));
     BHMM_HIP(hipMemsetAsync(c->d_gamma0.p, 0, (size_t)std::max(c->K, 1) * N * sizeof(double),
                             c->stream));
-    const size_t need = (size_t)stats_size(c) + c->K;
-    if (need > c->h_pinned_n) {
-        if (c->h_pinned)
-            (void)hipHostFree(c->h_pinned);
-        c->h_pinned = nullptr;
-        BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), need * sizeof(double),
-                               hipHostMallocDefault));
-        c->h_pinned_n = need;
-    }
-    return BHMM_OK;
+    c->tail_ready = false;
+    return ensure_pinned(c, (size_t)stats_size(c) + c->K);
 }
 
 static int upload_Bt(bhmm_ctx *c, const double *B)
@@ -614,6 +678,17 @@ static void collect_timing(bhmm_ctx *c)
         return;
     c->ev_pending = false;
     float ms = 0.f;
+    if (c->ev_lean) { // sweep kernel, tail kernel; no prescan / stitch
+        c->last_ms[0] = c->last_ms[1] = 0.0;
+        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess)
+            c->last_ms[2] = ms;
+        if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess)
+            c->last_ms[3] = ms;
+        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[4]) == hipSuccess)
+            c->last_ms[4] = ms;
+        (void)hipGetLastError();
+        return;
+    }
     for (int i = 0; i < 4; ++i)
         if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess)
             c->last_ms[i] = ms;
@@ -741,8 +816,9 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     c->d_specres.release();
     if (c->h_specres)
         (void)hipHostFree(c->h_specres);
-    if (c->h_pinned)
-        (void)hipHostFree(c->h_pinned);
+    if (c->h_raw)
+        (void)hipHostFree(c->h_raw);
+    c->d_tail.release();
     for (auto &ev : c->ev)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -808,15 +884,8 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         c->Lmax = 0;
         if ((rc = wide_alloc(c)))
             return rc;
-        const size_t need = (size_t)stats_size(c) + c->K;
-        if (need > c->h_pinned_n) {
-            if (c->h_pinned)
-                (void)hipHostFree(c->h_pinned);
-            c->h_pinned = nullptr;
-            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), need * sizeof(double),
-                                   hipHostMallocDefault));
-            c->h_pinned_n = need;
-        }
+        if ((rc = ensure_pinned(c, (size_t)stats_size(c) + c->K)))
+            return rc;
         BHMM_HIP(hipStreamSynchronize(c->stream));
         return BHMM_OK;
     }
@@ -985,6 +1054,7 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     double *sd = stats_dev ? stats_dev : c->d_stats.p;
     c->last_stats_internal = (stats_dev == nullptr);
     c->prefetched = false;
+    c->ev_lean = false;
     if (c->wide)
         return wide_estep(c, A, pi, par0, par1, sd, flags);
     return BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));

@@ -91,6 +91,10 @@ struct bhmm_ctx {
     float spec_last_dev = 0.f;
     bhmm::DevBuf<double> d_aexit, d_bentry;
     bhmm::DevBuf<unsigned int> d_specres;
+    bhmm::DevBuf<double> d_tail;      // same layout as h_raw, written by k_tail (one D2H copy)
+    int tail_slot = 0;                // verdict word set of the next E-step
+    bool tail_ready = false;          // d_tail allocated and its verdict words cleared
+    bool ev_lean = false;             // last E-step recorded only ev[2..4]
     unsigned int *h_specres = nullptr; // pinned
     // two-level stitch: groups of consecutive chunks (empty when every trajectory is short)
     int nG = 0;
@@ -105,7 +109,8 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_wlogLseg, d_waentry, d_waexit, d_wbexit, d_wbentry;
     bool wseg_enabled = true;
     int wseg_len = 0;                // 0 = automatic
-    double *h_pinned = nullptr;      // stats + logL_k landing zone
+    double *h_raw = nullptr;         // pinned: [verdict words, 2 sets (4 doubles) | stats | logL_k]
+    double *h_pinned = nullptr;      // = h_raw + 4: stats + logL_k landing zone
     size_t h_pinned_n = 0;
 
     bool gamma_valid = false;

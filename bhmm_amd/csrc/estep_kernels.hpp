@@ -1096,14 +1096,14 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
 // normalisation, componentwise relative.  result[0] counts violations, result[1] holds the bit
 // pattern of the largest relative deviation seen (float), for adapting the warm-up length.
 // =========================================================================================
+// deviation at the boundary in front of chunk g (0 where there is none)
 template <int N>
-__global__ void k_spec_check(const Chunks ch, int G, const double *alpha_entry, const double *a_exit,
-                             const double *beta_exit, const double *b_entry, double tol,
-                             unsigned int *result)
+__device__ __forceinline__ double spec_dev_one(const Chunks &ch, int G, int64_t g,
+                                               const double *alpha_entry, const double *a_exit,
+                                               const double *beta_exit, const double *b_entry)
 {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G || ch.len[g] == 0 || ch.t0[g] == 0)
-        return;
+        return 0.0;
     double dev = 0.0;
     auto cmp = [&](const double *x, const double *y) { // y: reference side
         double sx = 0.0, sy = 0.0;
@@ -1127,9 +1127,40 @@ __global__ void k_spec_check(const Chunks ch, int G, const double *alpha_entry, 
     cmp(alpha_entry + g * N, a_exit + (g - 1) * N);
     if (beta_exit) // forward-only passes verify alpha alone
         cmp(beta_exit + (g - 1) * N, b_entry + g * N);
-    if (!(dev <= tol))
-        atomicAdd(&result[0], 1u);
-    atomicMax(&result[1], __float_as_uint((float)fmin(dev, 1.0)));
+    return dev == dev ? dev : 1.0;
+}
+
+// one pair of atomics per wavefront: count of boundaries out of tolerance, largest deviation
+__device__ __forceinline__ void spec_commit(double dev, double tol, unsigned int *result)
+{
+    const unsigned long long bad = __ballot(!(dev <= tol));
+    float m = (float)fmin(dev, 1.0);
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1)
+        m = fmaxf(m, __shfl_xor(m, h, 64));
+    if ((threadIdx.x & 63) == 0) {
+        if (bad)
+            atomicAdd(&result[0], (unsigned int)__popcll(bad));
+        atomicMax(&result[1], __float_as_uint(m));
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void spec_check_one(const Chunks &ch, int G, int64_t g,
+                                               const double *alpha_entry, const double *a_exit,
+                                               const double *beta_exit, const double *b_entry,
+                                               double tol, unsigned int *result)
+{
+    spec_commit(spec_dev_one<N>(ch, G, g, alpha_entry, a_exit, beta_exit, b_entry), tol, result);
+}
+
+template <int N>
+__global__ void k_spec_check(const Chunks ch, int G, const double *alpha_entry, const double *a_exit,
+                             const double *beta_exit, const double *b_entry, double tol,
+                             unsigned int *result)
+{
+    spec_check_one<N>(ch, G, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, alpha_entry, a_exit,
+                      beta_exit, b_entry, tol, result);
 }
 
 // =========================================================================================
@@ -1138,33 +1169,49 @@ __global__ void k_spec_check(const Chunks ch, int G, const double *alpha_entry, 
 // k_finalize: one wavefront per output entry; fixed-order sums of the per-workgroup partials
 // -> packed statistics (bhmm_amd.h layout).
 // =========================================================================================
-static __global__ __launch_bounds__(64) void k_logl(const int32_t *traj_c0, int K,
-                                                    const double *logL_chunk, double *logL_k)
+__device__ __forceinline__ void logl_one(int k, const int32_t *traj_c0, const double *logL_chunk,
+                                         double *logL_k, double *mirror = nullptr)
 {
-    const int k = blockIdx.x;
     const int lane = threadIdx.x;
     double s = 0.0;
     for (int c = traj_c0[k] + lane; c < traj_c0[k + 1]; c += 64)
         s += logL_chunk[c];
     s = wave_sum(s);
-    if (lane == 0)
+    if (lane == 0) {
         logL_k[k] = s;
+        if (mirror)
+            mirror[k] = s;
+    }
 }
 
+static __global__ __launch_bounds__(64) void k_logl(const int32_t *traj_c0, int K,
+                                                    const double *logL_chunk, double *logL_k)
+{
+    logl_one(blockIdx.x, traj_c0, logL_chunk, logL_k);
+}
+
+// Entry e of the finalisation (one wavefront): e < S register statistics, then the discrete
+// count table, then gamma_0, then the total log-likelihood -- the sum of logL_k[0..K) or, if
+// logL_k is null, left to the caller (the fused tail kernel, where the per-trajectory sums are
+// produced by other workgroups of the same launch).
 template <int N, int KIND>
-__global__ __launch_bounds__(64) void k_finalize(const Model<N> m, int K, int nblocks,
-                                                 const double *partials,
-                                                 const double *disc_partials,
-                                                 const double *logL_k, const double *gamma0,
-                                                 double *stats)
+__device__ __forceinline__ void finalize_one(int e, const Model<N> &m, int K, int nblocks,
+                                             const double *partials, const double *disc_partials,
+                                             const double *logL_k, const double *logL_chunk, int G,
+                                             const double *gamma0, double *stats,
+                                             double *mirror = nullptr)
 {
     using SL = StatLayout<N, KIND>;
+    auto put = [&](int idx, double v) { // mirror: contiguous copy for the single D2H transfer
+        stats[idx] = v;
+        if (mirror)
+            mirror[idx] = v;
+    };
     const int n = m.nreal;
     const int lane = threadIdx.x;
     const int MN = (KIND == EMIT_DISC) ? m.M * N : 0;
     // packed offsets
     const int oG0 = 1, oC = 1 + n, oSG = oC + n * n, oE = oSG + n;
-    int e = blockIdx.x;
     double s = 0.0;
     if (e < SL::S) {
         for (int b = lane; b < nblocks; b += 64)
@@ -1175,15 +1222,15 @@ __global__ __launch_bounds__(64) void k_finalize(const Model<N> m, int K, int nb
         if (e < SL::NC) {
             const int r = e / N, c = e % N;
             if (r < n && c < n)
-                stats[oC + r * n + c] = s * m.A[r * N + c]; // xi = A o (alpha (x) b / S)
+                put(oC + r * n + c, s * m.A[r * N + c]); // xi = A o (alpha (x) b / S)
         } else if (e < SL::NC + N) {
             const int r = e - SL::NC;
             if (r < n)
-                stats[oSG + r] = s;
+                put(oSG + r, s);
         } else {
             const int w = (e - SL::NC - N) / N, r = (e - SL::NC - N) % N;
             if (r < n)
-                stats[oE + w * n + r] = s;
+                put(oE + w * n + r, s);
         }
         return;
     }
@@ -1194,7 +1241,7 @@ __global__ __launch_bounds__(64) void k_finalize(const Model<N> m, int K, int nb
         s = wave_sum(s);
         const int sym = e / N, r = e % N;
         if (lane == 0 && r < n)
-            stats[oE + r * m.M + sym] = s;
+            put(oE + r * m.M + sym, s);
         return;
     }
     e -= MN;
@@ -1203,14 +1250,75 @@ __global__ __launch_bounds__(64) void k_finalize(const Model<N> m, int K, int nb
             s += gamma0[(int64_t)k * N + e];
         s = wave_sum(s);
         if (lane == 0 && e < n)
-            stats[oG0 + e] = s;
+            put(oG0 + e, s);
         return;
     }
+    if (!logL_k)
+        return; // fused tail: the total is formed by the last trajectory workgroup (k_tail)
     for (int k = lane; k < K; k += 64)
         s += logL_k[k];
     s = wave_sum(s);
     if (lane == 0)
-        stats[0] = s;
+        put(0, s);
+}
+
+template <int N, int KIND>
+__global__ __launch_bounds__(64) void k_finalize(const Model<N> m, int K, int nblocks,
+                                                 const double *partials,
+                                                 const double *disc_partials,
+                                                 const double *logL_k, const double *gamma0,
+                                                 double *stats)
+{
+    finalize_one<N, KIND>(blockIdx.x, m, K, nblocks, partials, disc_partials, logL_k, nullptr, 0,
+                          gamma0, stats);
+}
+
+// k_tail: everything after the sweep of a speculative E-step in one launch of 64-thread
+// workgroups -- [0, nfin) finalisation entries, [nfin, nfin + K) per-trajectory log-likelihoods,
+// then one thread per chunk boundary of the check.  The workgroups are independent of each other.
+// flags_next: the verdict words of the NEXT E-step (the two sets alternate), cleared here so
+// that no memset sits between E-steps.
+template <int N, int KIND>
+__global__ __launch_bounds__(64) void k_tail(const Model<N> m, const Chunks ch, int K, int G,
+                                             int nblocks, int nfin, const int32_t *traj_c0,
+                                             const double *partials, const double *disc_partials,
+                                             const double *logL_chunk, const double *gamma0,
+                                             const double *alpha_entry, const double *a_exit,
+                                             const double *beta_exit, const double *b_entry,
+                                             double tol, double *stats, double *logL_k,
+                                             double *mirror, // [S stats | K logL_k], contiguous
+                                             int S, unsigned int *flags, unsigned int *flags_next)
+{
+    const int b = blockIdx.x;
+    if (b < nfin) {
+        finalize_one<N, KIND>(b, m, K, nblocks, partials, disc_partials, nullptr, logL_chunk, G,
+                              gamma0, stats, mirror);
+        if (b == 0 && threadIdx.x < 4)
+            flags_next[threadIdx.x] = 0u;
+    } else if (b < nfin + K) {
+        logl_one(b - nfin, traj_c0, logL_chunk, logL_k, mirror + S);
+        // the workgroup that finishes last adds up all trajectories in index order (word 3 of
+        // the verdict set counts finished workgroups; it is cleared with the set)
+        __threadfence();
+        unsigned int ticket = 0;
+        if (threadIdx.x == 0)
+            ticket = atomicAdd(&flags[3], 1u);
+        ticket = __shfl(ticket, 0, 64);
+        if (ticket == (unsigned int)(K - 1)) {
+            __threadfence();
+            double s = 0.0;
+            for (int k = threadIdx.x; k < K; k += 64)
+                s += __hip_atomic_load(logL_k + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s = wave_sum(s);
+            if (threadIdx.x == 0) {
+                stats[0] = s;
+                mirror[0] = s;
+            }
+        }
+    } else {
+        spec_check_one<N>(ch, G, (int64_t)(b - nfin - K) * 64 + threadIdx.x, alpha_entry, a_exit,
+                          beta_exit, b_entry, tol, flags);
+    }
 }
 
 // =========================================================================================
