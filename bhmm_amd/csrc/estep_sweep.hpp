@@ -176,8 +176,11 @@ __device__ __forceinline__ bool fix_outlier(const ObsIn &in, int q, int nreal,
 
 // high dword of a non-negative double orders like the value; its top bits are the exponent
 __device__ __forceinline__ bool tiny_hi(int hm) { return hm < 0x00100000; }
-// ... below 2^-800: what the branch-free sweeps (rescaling every ESTEP_SCALE_EVERY steps) report
-__device__ __forceinline__ bool small_hi(int hm) { return hm < ((1023 - 800) << 20); }
+// ... below 2^-400: what the branch-free sweeps (rescaling every ESTEP_SCALE_EVERY steps) report.
+// gamma and xi multiply an alpha row by a beta row, so each may use up only half of the exponent
+// range; entries more than 2^-600 below the largest one of their vector may then be denormal,
+// which is far below anything that reaches the statistics.
+__device__ __forceinline__ bool small_hi(int hm) { return hm < ((1023 - 400) << 20); }
 
 // a <- 2^ne (s o p), the group's largest entry brought into [0.5, 1); returns the exponent
 // removed (-ne).
@@ -186,7 +189,7 @@ __device__ __forceinline__ bool small_hi(int hm) { return hm < ((1023 - 800) << 
 //   otherwise the step is branch-free, rescales only where SCALE is set (every
 //   ESTEP_SCALE_EVERY-th step of the unrolled loops -- powers of two, so the results do not
 //   depend on the schedule) and records the smallest maximum seen at those points (hmin); the
-//   kernel reports chunks where that fell below 2^-800 and the host repeats the E-step with the
+//   kernel reports chunks where that fell below 2^-400 and the host repeats the E-step with the
 //   CAREFUL instantiation.
 template <int N, int KIND, bool CAREFUL, bool SCALE>
 __device__ __forceinline__ int scaled_emit(const ObsIn &in, int q, int nreal,

@@ -283,3 +283,102 @@ def test_exp_of_gaussian_density_is_ulp_accurate():
     assert np.all(np.abs(y[~normal] - ref[~normal]) <= 4.95e-324 * 1.5)
     assert np.all(y[x < -746.0] == 0.0)
     assert y[0 + np.flatnonzero(x == 0.0)[0]] == 1.0
+
+
+# ---------------------------------------------------------------------------------------------
+# The statistics-only E-step (no gamma rows) runs the branch-free instantiation of k_estep: every
+# second alpha row in HBM, rescaling every 4th step, zero / tiny vectors only reported.  The tests
+# above ask for gamma and therefore run the careful instantiation; these cover the other one over
+# every alignment of chunk length, unroll group and trajectory end.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("spec", [1, 0])
+@pytest.mark.parametrize("chunk", [0, 1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 16, 17, 23, 33, 64])
+def test_statistics_only_estep_all_alignments(golden, chunk, spec):
+    g = golden("g8_ragged")
+    obs = split(g["obs"], g["lengths"])
+    ref = orc.estep("gaussian", obs, g["A"], g["pi"], g["mu"], g["sigma"], want_gamma=True)
+    eng = _engine()
+    eng.set_option("spec_enabled", spec)
+    eng.set_observations("gaussian", obs, 8, chunk=chunk)
+    res = eng.estep(g["A"], g["pi"], g["mu"], g["sigma"])
+    assert eng.get_option("careful") == 0.0
+    np.testing.assert_allclose(res.logL_k, g["logL"], rtol=RTOL)
+    _cmp(res, ref, 8)
+    sd, sdd = _gauss_stats(obs, ref["gammas"], g["mu"])
+    np.testing.assert_allclose(res.sum_gd, sd, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(res.sum_gdd, sdd, rtol=1e-8)
+    # same numbers as the careful instantiation up to rounding
+    res2 = eng.estep(g["A"], g["pi"], g["mu"], g["sigma"], store_gamma=True)
+    np.testing.assert_allclose(res.packed, res2.packed, rtol=1e-11, atol=1e-13)
+    eng.close()
+
+
+@pytest.mark.parametrize("chunk", [0, 2, 5, 8, 13, 33])
+def test_statistics_only_estep_discrete_and_explicit(golden, chunk):
+    g = golden("d8_ragged")
+    obs = split(g["obs"], g["lengths"])
+    M = g["B"].shape[1]
+    ref = orc.estep("discrete", obs, g["A"], g["pi"], g["B"], want_gamma=True)
+    eng = _engine()
+    eng.set_observations("discrete", obs, 8, nsymbols=M, chunk=chunk)
+    res = eng.estep(g["A"], g["pi"], g["B"])
+    np.testing.assert_allclose(res.logL_k, g["logL"], rtol=RTOL)
+    _cmp(res, ref, 8)
+    cnt = np.zeros_like(g["B"])
+    for o, gm in zip(obs, ref["gammas"]):
+        for s in range(M):
+            cnt[:, s] += gm[o == s].sum(axis=0)
+    np.testing.assert_allclose(res.symbol_counts, cnt, rtol=1e-9, atol=1e-12)
+    eng.close()
+    # caller-supplied pobs rows (hidden/api.py signatures)
+    pobs = [np.ascontiguousarray(g["B"][:, o].T) for o in obs]
+    eng = _engine()
+    eng.set_observations("explicit", pobs, 8, chunk=chunk)
+    res = eng.estep(g["A"], g["pi"])
+    np.testing.assert_allclose(res.logL_k, g["logL"], rtol=RTOL)
+    _cmp(res, ref, 8)
+    eng.close()
+
+
+@pytest.mark.parametrize("chunk", [0, 4, 9])
+def test_outlier_rows_switch_to_the_careful_kernel(golden, chunk):
+    """An all-zero emission row (outputmodel.py:126-130) is only *reported* by the branch-free
+    kernel; the library must repeat the E-step with the kernel that applies the rule, give the
+    reference's numbers, and stay on that kernel for the data set."""
+    g = golden("g8_outliers")
+    eng = _engine()
+    eng.set_observations("gaussian", [g["obs"]], 8, chunk=chunk)
+    assert eng.get_option("careful") == 0.0
+    for _ in range(2):
+        res = eng.estep(g["A"], g["pi"], g["mu"], g["sigma"])
+        assert eng.get_option("careful") == 1.0
+        np.testing.assert_allclose(res.loglik, float(g["logL"]), rtol=RTOL)
+        np.testing.assert_allclose(res.C, g["C"], rtol=RTOL, atol=1e-12)
+    # new observations start on the fast kernel again
+    g2 = golden("g8_ragged")
+    eng.set_observations("gaussian", split(g2["obs"], g2["lengths"]), 8, chunk=chunk)
+    eng.estep(g2["A"], g2["pi"], g2["mu"], g2["sigma"])
+    assert eng.get_option("careful") == 0.0
+    eng.close()
+
+
+def test_tiny_emissions_are_rescaled_in_time():
+    """Emission densities around 1e-150 per step: four unscaled steps would underflow.  The
+    branch-free kernel has to notice (its running maximum falls below 2^-800) and hand over to the
+    kernel that rescales every step; the result must match the oracle."""
+    rng = np.random.default_rng(11)
+    n, T = 4, 600
+    A = rng.random((n, n)) + np.eye(n) * 3
+    A /= A.sum(axis=1, keepdims=True)
+    pi = np.full(n, 1.0 / n)
+    mu = np.array([-1.0, 0.0, 1.0, 2.0])
+    sigma = np.full(n, 0.02)          # observations up to 25 sigma from the nearest mean:
+    obs = [rng.uniform(-1.5, 2.5, T) for _ in range(3)]  # densities down to 1e-136, no denormals
+    ref = orc.estep("gaussian", obs, A, pi, mu, sigma)
+    eng = _engine()
+    eng.set_observations("gaussian", obs, n, chunk=64)
+    res = eng.estep(A, pi, mu, sigma)
+    assert eng.get_option("careful") == 1.0
+    np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=RTOL)
+    np.testing.assert_allclose(res.C, ref["C"], rtol=1e-8, atol=1e-12)
+    eng.close()
