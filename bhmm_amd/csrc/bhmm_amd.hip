@@ -860,6 +860,8 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         return invalid("obs == NULL");
     c->gamma_valid = false;
     c->careful = c->careful_retry = false;
+    c->wide_replans = 0;
+    c->wseg_given_up = false;
     if (kind == BHMM_EMIT_DISCRETE) {
         const size_t sm = smem_fwdbwd<8, EMIT_DISC>(c->M);
         if (sm > 160 * 1024)
@@ -1002,7 +1004,7 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
     else if (n == "careful")
         *value = c->careful ? 1.0 : 0.0;
     else if (n == "wide_segments")
-        *value = (c->wseg_enabled && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
+        *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
     else
         return invalid("unknown option: " + n);
     return BHMM_OK;

@@ -249,7 +249,7 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
         return BHMM_OK;
     };
-    if (c->wseg_enabled && c->w_nseg[1] > c->w_nseg[0]) {
+    if (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) {
         // time-segmented run with warm-up boundaries, verified afterwards
         BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 2 * sizeof(unsigned int), c->stream));
         if ((rc = run(1)))
@@ -272,10 +272,32 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
             return BHMM_OK;
         }
         c->spec_fail++;
-        if (c->spec_fail >= 2)
-            c->wseg_enabled = false; // keeps failing: stay on the serial plan
-        else
-            c->spec_W += std::max(64, c->spec_W / 2);
+        // The deviation decays geometrically with the warm-up length (the filter forgets its start
+        // vector): extrapolate to where it reaches a tenth of the tolerance, lengthen the
+        // segments to at least four warm-ups and try again at the next call; give up (serial
+        // plan) after three re-plans or when the segments would no longer split a trajectory.
+        int64_t maxT = 0;
+        for (int k = 0; k < c->K; ++k)
+            maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+        const double d = std::min(std::max((double)dev, 1e-300), 0.5);
+        double f = log(1e-12) / log(d);
+        f = std::min(std::max(f, 1.25), 8.0);
+        const int64_t Wn = ((int64_t)ceil(c->spec_W * f) + 7) / 8 * 8;
+        int64_t seglen = c->wseg_len > 0 ? (int64_t)c->wseg_len : 4 * Wn;
+        if (c->wseg_len <= 0) {
+            const int64_t groups_per_wave = 64 / c->N;
+            seglen = std::max(seglen, (c->total + 4096 * groups_per_wave - 1) / (4096 * groups_per_wave));
+        }
+        if (c->wide_replans >= 3 || seglen >= maxT || Wn >= maxT / 2) {
+            c->wseg_given_up = true;
+        } else {
+            ++c->wide_replans;
+            c->spec_W = (int)Wn;
+            if ((rc = wide_plan(c, 1, seglen)))
+                return rc;
+            if (c->w_nseg[1] <= c->w_nseg[0])
+                c->wseg_given_up = true;
+        }
     }
     if ((rc = run(0)))
         return rc;
