@@ -56,6 +56,9 @@ static size_t smem_fwdbwd(int M)
 
 static int stats_size(const bhmm_ctx *c);
 
+// componentwise relative tolerance of the boundary check (k_spec_check / k_tail)
+constexpr double SPEC_TOL = 1e-11;
+
 // One E-step launch sequence for a fixed padded N.
 template <int N>
 struct Runner {
@@ -233,7 +236,7 @@ struct Runner {
                            (const double *)c->d_dpartials.p, (const double *)c->d_logLc.p,
                            (const double *)c->d_gamma0.p, (const double *)c->d_aentry.p,
                            (const double *)c->d_aexit.p, (const double *)c->d_bexit.p,
-                           (const double *)c->d_bentry.p, 1e-11, stats_dev, c->d_logLk.p,
+                           (const double *)c->d_bentry.p, SPEC_TOL, stats_dev, c->d_logLk.p,
                            c->d_tail.p + 4, S, words, words_next);
         BHMM_HIP(hipGetLastError());
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
@@ -331,7 +334,7 @@ struct Runner {
                            chunks_of(c), c->G, (const double *)c->d_aentry.p,
                            (const double *)c->d_aexit.p,
                            with_beta ? (const double *)c->d_bexit.p : (const double *)nullptr,
-                           (const double *)c->d_bentry.p, 1e-11, c->d_specres.p);
+                           (const double *)c->d_bentry.p, SPEC_TOL, c->d_specres.p);
         BHMM_HIP(hipGetLastError());
         BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
                                 hipMemcpyDeviceToHost, c->stream));
@@ -406,10 +409,15 @@ struct Runner {
             // lengthen the warm-up for the next call; give up once it would cost more than the
             // prescan (slowly mixing model / uninformative data)
             c->spec_fail++;
-            if (c->spec_W >= 8192 || c->spec_W >= 2 * c->Lmax)
+            if (c->spec_W >= 8192 || c->spec_W >= 2 * c->Lmax) {
                 c->spec_enabled = false;
-            else
-                c->spec_W += std::max(64, c->spec_W / 2);
+            } else {
+                // the deviation decays geometrically with the warm-up length: extrapolate to a
+                // tenth of the tolerance (at least +25 %, at most x8 per failure)
+                const double d = std::min(std::max((double)c->spec_last_dev, 1e-300), 0.5);
+                const double f = std::min(std::max(log(0.1 * SPEC_TOL) / log(d), 1.25), 8.0);
+                c->spec_W = std::max(c->spec_W + 4, ((int)ceil(c->spec_W * f) + 3) / 4 * 4);
+            }
         }
         return BHMM_OK;
     }

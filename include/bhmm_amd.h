@@ -148,7 +148,7 @@ int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const do
 /* Tuning / introspection knobs by name (returns BHMM_ERR_INVALID for an unknown name):
  *   "spec_enabled"  1/0  use speculative, verified chunk boundaries in bhmm_estep (default 1;
  *                        switched off automatically when verification keeps failing)
- *   "spec_W"        warm-up length in time steps (default 288, +50 % after a failed check)
+ *   "spec_W"        warm-up length in time steps (default 288; after a failed check extrapolated from the measured deviation, x1.25 .. x8)
  *   "wide_segments" 1/0  (9..64 states) cut trajectories into time segments with the same
  *                        verified warm-up boundaries; reading it returns the segment count in use
  *   "wide_segment_len"   segment length for the next bhmm_ctx_set_observations (0 = automatic)
