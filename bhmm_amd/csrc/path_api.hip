@@ -99,7 +99,8 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         hipLaunchKernelGGL((k_smp_maps<N>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd,
                            (const double *)c->d_ws.p, (const double *)udev, seed, P, fmap, status);
         BHMM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_smp_stitch, dim3((K + 255) / 256), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_smp_stitch, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB), dim3(64), 0,
+                           c->stream,
                            (const int32_t *)c->d_traj_c0.p, K, P, (const uint32_t *)fmap, nstate);
         BHMM_HIP(hipGetLastError());
         if (c->kind == EMIT_GAUSS)
@@ -117,7 +118,7 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
                                seed, P, (const int32_t *)nstate, path, cnt, epart, status);
         BHMM_HIP(hipGetLastError());
         if (esz) {
-            hipLaunchKernelGGL(k_add_partials, dim3((unsigned)((esz + 255) / 256)), dim3(256), 0,
+            hipLaunchKernelGGL(k_add_partials, dim3((unsigned)esz), dim3(64), 0,
                                c->stream, (const double *)epart, nblk, (int)esz, ered);
             BHMM_HIP(hipGetLastError());
         }
@@ -294,7 +295,7 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
                                off, obs, (const int32_t *)path, cnt, epart);
         BHMM_HIP(hipGetLastError());
         if (esz) {
-            hipLaunchKernelGGL(k_add_partials, dim3((unsigned)((esz + 255) / 256)), dim3(256), 0,
+            hipLaunchKernelGGL(k_add_partials, dim3((unsigned)esz), dim3(64), 0,
                                c->stream, (const double *)epart, K, (int)esz, ered);
             BHMM_HIP(hipGetLastError());
         }
@@ -597,7 +598,7 @@ int bhmm_update_pout(double *pout, const int32_t *obs, const double *weights, in
     BHMM_HIP(hipMemcpy(dout, pout, (size_t)N * M * sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_update_pout, dim3(nblk), dim3(256), (size_t)N * M * sizeof(double), 0,
                        (const int32_t *)dobs, (const double *)dw, T, N, M, dpart);
-    hipLaunchKernelGGL(k_add_partials, dim3((N * M + 255) / 256), dim3(256), 0, 0,
+    hipLaunchKernelGGL(k_add_partials, dim3(N * M), dim3(64), 0, 0,
                        (const double *)dpart, nblk, N * M, dout);
     BHMM_HIP(hipGetLastError());
     BHMM_HIP(hipMemcpy(pout, dout, (size_t)N * M * sizeof(double), hipMemcpyDeviceToHost));

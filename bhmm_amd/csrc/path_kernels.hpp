@@ -202,16 +202,34 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
 
 // state at the first step of the NEXT part, for every (chunk, part) (0 behind a trajectory's
 // last part, whose map is constant)
-static __global__ void k_smp_stitch(const int32_t *traj_c0, int K, int P, const uint32_t *Fmap,
+constexpr int SMP_STITCH_TPB = 8;
+static __global__ __launch_bounds__(64) void k_smp_stitch(const int32_t *traj_c0, int K, int P, const uint32_t *Fmap,
                                     int32_t *next_state)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K)
+    // every lane walks its own trajectory, so each wavefront-wide load / store touches one cache
+    // line per active lane: few lanes per workgroup, many workgroups
+    const int k = blockIdx.x * SMP_STITCH_TPB + threadIdx.x;
+    if (threadIdx.x >= SMP_STITCH_TPB || k >= K)
         return;
     uint32_t x = 0;
-    for (int64_t e = (int64_t)traj_c0[k + 1] * P - 1; e >= (int64_t)traj_c0[k] * P; --e) {
-        next_state[e] = (int32_t)x;
-        x = (Fmap[e] >> (4 * x)) & 7u;
+    // the maps are loaded 16 at a time (their addresses do not depend on the walk), the walk itself
+    // is register arithmetic
+    int64_t hi = (int64_t)traj_c0[k + 1] * P - 1;
+    const int64_t lo = (int64_t)traj_c0[k] * P;
+    while (hi >= lo) {
+        const int cnt = (int)((hi - lo + 1) < 16 ? (hi - lo + 1) : 16);
+        uint32_t f[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) // clamped, unconditional: all 16 loads go out together
+            f[j] = Fmap[hi - j > lo ? hi - j : lo];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < cnt) {
+                next_state[hi - j] = (int32_t)x;
+                x = (f[j] >> (4 * x)) & 7u;
+            }
+        }
+        hi -= cnt;
     }
 }
 
@@ -441,15 +459,20 @@ __global__ void k_update_pout(const int32_t *obs, const double *w, int64_t T, in
         pout_partials[(int64_t)blockIdx.x * n * M + e] = hist[e];
 }
 
-__global__ void k_add_partials(const double *partials, int nblocks, int count, double *dst)
+// dst[e] += sum_b partials[b][e]: one wavefront per entry (a single thread walking all blocks
+// is bound by the latency of its dependent loads), fixed summation tree
+__global__ __launch_bounds__(64) void k_add_partials(const double *partials, int nblocks, int count,
+                                                     double *dst)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x;
     if (e >= count)
         return;
-    double s = dst[e];
-    for (int b = 0; b < nblocks; ++b)
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64)
         s += partials[(int64_t)b * count + e];
-    dst[e] = s;
+    s = wave_sum(s);
+    if (threadIdx.x == 0)
+        dst[e] += s;
 }
 
 // =========================================================================================

@@ -2,7 +2,7 @@
 # tools/ktrace.sh SCRIPT.py: per-kernel durations (rocprofv3 --kernel-trace --stats) of a python script
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pk
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- python3 $GRAFT_REPO_ROOT/$1 > /tmp/pk.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- python3 $GRAFT_REPO_ROOT/"$@" > /tmp/pk.log 2>&1
 tail -2 /tmp/pk.log
 f=$(find /tmp/pk -name "*kernel_stats.csv" 2>/dev/null | head -1)
 [ -n "$f" ] && python3 -c "
