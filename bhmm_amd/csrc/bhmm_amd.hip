@@ -440,24 +440,55 @@ struct Runner {
         return BHMM_OK;
     }
 
+    // forward sweep only with k_estep<..., FWDONLY> (alpha rows up to a power of two)
+    template <int KIND, bool CAREFUL>
+    static int forward_launch(bhmm_ctx *c, const Model<N> &m)
+    {
+        const Chunks ch = chunks_of(c);
+        const size_t sm = smem_fwdbwd<N, KIND>(c->M);
+        auto kern = k_estep<N, KIND, true, false, CAREFUL, true>;
+        if (sm > 64 * 1024)
+            BHMM_HIP(hipFuncSetAttribute((const void *)kern,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        hipLaunchKernelGGL(kern, dim3(c->Gp / 64), dim3(32 * N), sm, c->stream, m, ch,
+                           (const void *)c->d_obs_ci.p, (const void *)c->d_obs_rm.p,
+                           (const int64_t *)c->d_offsets.p, (const double *)c->d_Bt.p, c->d_aentry.p,
+                           c->d_bexit.p, c->d_aexit.p, c->d_bentry.p, c->spec_W, c->d_ws.p,
+                           (double *)nullptr, c->d_logLc.p, c->d_gamma0.p, c->d_partials.p,
+                           c->d_dpartials.p, c->d_specres.p);
+        BHMM_HIP(hipGetLastError());
+        return BHMM_OK;
+    }
+
     template <int KIND>
     static int forward_kind(bhmm_ctx *c, const Model<N> &m)
     {
         int rc;
         if (c->spec_enabled) {
-            bool ok = false;
-            if ((rc = spec_prepare(c)) || (rc = fwdbwd<KIND, MODE_FWD, true>(c, m, false)) ||
-                (rc = spec_verdict(c, false, &ok)))
-                return rc;
-            if (ok)
-                return BHMM_OK;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                bool ok = false;
+                bool fast = !c->careful && KIND != EMIT_EXPL;
+                if (KIND == EMIT_GAUSS)
+                    for (int i = 0; i < c->n; ++i)
+                        fast = fast && m.e2[i] < 1048576.0;
+                if ((rc = spec_prepare(c)))
+                    return rc;
+                rc = fast ? forward_launch<KIND, false>(c, m) : forward_launch<KIND, true>(c, m);
+                if (rc || (rc = spec_verdict(c, false, &ok)))
+                    return rc;
+                if (ok)
+                    return BHMM_OK;
+                if (!c->careful_retry)
+                    break;
+                c->careful_retry = false;
+            }
         }
         if ((rc = prescan_stitch<KIND>(c, m)))
             return rc;
         return fwdbwd<KIND, MODE_FWD>(c, m, false);
     }
 
-    // forward pass only, alpha (normalised, _hidden.c:16-66) left in the CI workspace
+    // forward pass only, alpha (any scale per row; _hidden.c:16-66 up to that) left in the CI workspace
     static int forward_only(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                             const double *par1)
     {

@@ -362,6 +362,8 @@ __device__ __forceinline__ void beta_step(const Gather<N> &gather, const ObsIn &
 //   SPEC: chunk-boundary vectors by warm-up over W steps, verified afterwards by k_spec_check
 //   (see k_fwdbwd); otherwise they are read from k_stitch.
 //   GAMMA: the instantiation that can store the gamma rows (gamma_ci may still be null).
+//   FWDONLY: forward sweep only, every alpha row stored (any power-of-two scale): the Gibbs
+//   hidden-path step samples from alpha and is indifferent to its scale (_hidden.c:330-378).
 // Workgroup = one CI record group (64 chunks) = 32*N threads.
 // =========================================================================================
 #ifndef ESTEP_PF_F
@@ -376,7 +378,7 @@ __device__ __forceinline__ void beta_step(const Gather<N> &gather, const ObsIn &
 #ifndef ESTEP_WAVES
 #define ESTEP_WAVES 2
 #endif
-template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL>
+template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, bool FWDONLY = false>
 __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WAVES, ESTEP_WAVES))) void k_estep(
     const Model<N> m, const Chunks ch, const void *obs_ci, const void *obs_rm,
     const int64_t *toff,   // [K+1] trajectory offsets (time steps)
@@ -564,6 +566,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             ObsCursor<N, KIND> po(obs_ci, rec0 + s, cl, q);
             double2 *pw = ci_pair(ws, rec0 + s, N, q, cl);
             constexpr int PF = ESTEP_PF_F;
+            constexpr bool CKPT = ESTEP_CKPT && !FWDONLY; // a forward-only pass keeps every row
             static_assert(PF % 2 == 0, "row parity inside the unrolled groups");
             if ((s & 1) && s < len) { // first chunk of a trajectory: bring the group base to an even step
                 single(po, pw);
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                         y[j] = po.at(PF + j);
                     unrolled<PF>([&](auto j) {
                         fstep(x[j], ox[j], sc_at<j>());
-                        if constexpr (!ESTEP_CKPT || j % 2 == 0)
+                        if constexpr (!CKPT || j % 2 == 0)
                             pw[j * RS] = ox[j];
                     });
                     if (rem > 2 * PF) {
@@ -595,10 +598,10 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                     }
                     unrolled<PF>([&](auto j) {
                         fstep(y[j], oy[j], sc_at<PF + j>());
-                        if constexpr (!ESTEP_CKPT || j % 2 == 0)
+                        if constexpr (!CKPT || j % 2 == 0)
                             pw[(PF + j) * RS] = oy[j];
                     });
-                    if constexpr (ESTEP_CKPT != 0) {
+                    if constexpr (CKPT) {
                         // the backward sweep reads the last (len-1) % 4 + 1 rows directly: if the
                         // single steps below do not cover them, the odd rows of the last group do
                         if (rem == 2 * PF && tail < 4) {
@@ -625,6 +628,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
                 *reinterpret_cast<double2 *>(a_exit + g * N + 2 * q) = make_double2(a[0], a[1]);
         }
 
+        if constexpr (!FWDONLY) {
         // ---------------- backward sweep (_hidden.c:69-110, hidden/api.py:176-186) ----------
         double Ar[2][N];
 #pragma unroll
@@ -850,6 +854,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             if constexpr (SPEC) // beta one step before this chunk: what the previous chunk assumed
                 *reinterpret_cast<double2 *>(b_entry + g * N + 2 * q) = make_double2(b2[0], b2[1]);
         }
+        } // !FWDONLY
     }
 
     if constexpr (!CAREFUL) {
@@ -872,7 +877,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
     // ---------------- workgroup reduction of the register statistics ----------------------
     // entry e of the statistics vector is owned by lane q = (state of e) / 2; sum over the
     // chunks of the wavefront (lanes with equal q), then over wavefronts through LDS
-    {
+    if constexpr (!FWDONLY) {
         const int lane = threadIdx.x & 63;
         const int wv = threadIdx.x >> 6;
         double *mine = red + wv * SL::S;
