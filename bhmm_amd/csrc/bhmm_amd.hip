@@ -1042,6 +1042,10 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->spec_last_dev;
     else if (n == "careful")
         *value = c->careful ? 1.0 : 0.0;
+    else if (n == "viterbi_chunked")
+        *value = c->viterbi_chunked ? 1.0 : 0.0;
+    else if (n == "viterbi_close")
+        *value = c->viterbi_close;
     else if (n == "wide_segments")
         *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
     else

@@ -93,6 +93,8 @@ struct bhmm_ctx {
     bhmm::DevBuf<unsigned int> d_specres;
     bhmm::DevBuf<double> d_tail;      // same layout as h_raw, written by k_tail (one D2H copy)
     int tail_slot = 0;                // verdict word set of the next E-step
+    unsigned int viterbi_close = 0;   // ... number of lanes that met a close decision
+    bool viterbi_chunked = false;     // last bhmm_viterbi_batch ran chunk-parallel (verified)
     int wide_replans = 0;             // 9..64 states: segment plans re-made after failed checks
     bool wseg_given_up = false;       // ... and segmentation abandoned for this data set
     bool tail_ready = false;          // d_tail allocated and its verdict words cleared

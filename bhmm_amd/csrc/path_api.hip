@@ -169,6 +169,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     if (rc)
         return rc;
     const int K = c->K, n = c->n, NP = c->wide ? c->N : 8, GP = 64 / NP;
+    c->viterbi_chunked = false;
     if ((rc = c->d_scratch.ensure((size_t)c->total * n)) ||
         (rc = c->d_scratch2.ensure(((size_t)c->total + K) * sizeof(int32_t))))
         return rc;
@@ -217,7 +218,45 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         else                                              \
             BHMM_WV(NPV, EMIT_EXPL);                      \
     } while (0)
-    if (NP == 8)
+    // n <= 8 with a chunk plan: the chunk-parallel run first; its back-pointers are accepted only
+    // if every chunk boundary verifies and no decision was close (k_viterbi_chunks)
+    bool done = false;
+    if (!c->wide && vkind == EMIT_EXPL && c->spec_enabled && c->G > K) {
+        int maxchunks = 1;
+        for (int k = 0; k < K; ++k)
+            maxchunks = std::max(maxchunks, c->traj_c0[k + 1] - c->traj_c0[k]);
+        const double tol = 1e-11, margin = std::max(1e-7, 16.0 * tol * maxchunks);
+        if ((rc = c->d_aentry.ensure((size_t)c->Gp * 8)) || (rc = c->d_aexit.ensure((size_t)c->Gp * 8)) ||
+            (rc = c->d_specres.ensure(4)))
+            return rc;
+        if (!c->h_specres)
+            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
+                                   hipHostMallocDefault));
+        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+        const Chunks chs = chunks_pub(c);
+        hipLaunchKernelGGL((k_viterbi_chunks<8>), dim3((c->G + 7) / 8), dim3(64), 0, c->stream, m, chs,
+                           c->G, off, static_cast<const double *>(obs), c->spec_W, margin, ptr, last,
+                           c->d_aentry.p, c->d_aexit.p, c->d_specres.p);
+        BHMM_HIP(hipGetLastError());
+        hipLaunchKernelGGL((k_viterbi_check<8>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
+                           chs, c->G, (const double *)c->d_aentry.p, (const double *)c->d_aexit.p, tol,
+                           c->d_specres.p);
+        BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
+                                hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        // all boundaries bit-identical: it is the serial run; else within tolerance and no
+        // close decision
+        done = c->h_specres[3] == 0 || (c->h_specres[0] == 0 && c->h_specres[2] == 0);
+        c->viterbi_chunked = done;
+        float dev;
+        memcpy(&dev, &c->h_specres[1], sizeof(float));
+        c->spec_last_dev = dev;
+        c->viterbi_close = c->h_specres[2];
+    }
+    if (done)
+        ;
+    else if (NP == 8)
         BHMM_WV_KIND(8);
     else if (NP == 16)
         BHMM_WV_KIND(16);

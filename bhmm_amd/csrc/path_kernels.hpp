@@ -647,6 +647,175 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
     }
 }
 
+// =========================================================================================
+// k_viterbi_chunks: the same order-faithful recursion, parallel over the time chunks of the
+// E-step plan, and still bit-identical to the serial run -- verified, not assumed:
+//   * every chunk starts W steps early from a uniform vector (or exactly from pi where that
+//     reaches the start of the trajectory); the max-product recursion forgets its start like the
+//     filter does, and it is non-expansive in Hilbert's projective metric, so if at every chunk
+//     boundary the vector a chunk assumed agrees with the one its predecessor computed to
+//     tol (k_spec_check, componentwise relative), every vector of the run is within
+//     (#chunks of the trajectory) x 2 tol of the serial run's;
+//   * a back-pointer equals the serial run's if it is decided by more than that: the kernel
+//     counts decisions whose runner-up is within `margin` (relative) of the winner -- exact
+//     ties, the all-zero case and NaNs included.
+// If no boundary is out of tolerance and no decision is that close, the back-pointers are the
+// serial ones.  In practice the survivors coalesce and the boundary vectors come out
+// BIT-IDENTICAL (k_viterbi_check); then the run is the serial run outright and close decisions
+// are irrelevant.  Otherwise the host runs k_wide_viterbi_fwd.  Emission rows: k_pobs_all.
+// =========================================================================================
+template <int NP>
+__global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const Chunks ch, int G,
+                                                       const int64_t *toff, const double *pobs,
+                                                       int W, double margin, uint8_t *ptr,
+                                                       int32_t *last_state, double *v_entry,
+                                                       double *v_exit, unsigned int *flags)
+{
+    constexpr int GP = 64 / NP;
+    static_assert(NP <= 16, "one argmax tile");
+    __shared__ __attribute__((aligned(16))) double xv[GP][NP];
+    __shared__ __attribute__((aligned(16))) double xn[GP][NP];
+    const int lane = threadIdx.x;
+    const int gi = lane / NP, j = lane % NP;
+    const int64_t g = (int64_t)blockIdx.x * GP + gi;
+    const int len = g < G ? ch.len[g] : 0;
+    bool low = false;
+    if (len > 0) {
+        const int n = m.n;
+        const bool real = j < n;
+        double Acol[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            Acol[i] = (real && i < n) ? m.A[(int64_t)i * n + j] : 0.0;
+        const double pi_j = real ? m.pi[j] : 0.0;
+        const int64_t t0 = ch.t0[g], goff = ch.goff[g];
+        const int k = ch.traj[g];
+        const int nw = (int)(t0 < (int64_t)W ? t0 : (int64_t)W);
+        const bool exact = (int64_t)nw == t0; // the warm-up reaches the start of the trajectory
+        const int64_t gs = goff - nw;
+        const int steps = nw + len;
+        double v = real ? 1.0 / (double)n : 0.0;
+        double p_next = real ? pobs[gs * n + j] : 0.0;
+        for (int s = 0; s < steps; ++s) {
+            const double p = p_next;
+            if (s + 1 < steps)
+                p_next = real ? pobs[(gs + s + 1) * n + j] : 0.0; // independent of the recursion
+            double vn;
+            if (exact && s == 0) {
+                vn = p * pi_j; // _hidden.c:232
+            } else {
+                xv[gi][j] = v;
+                // first-maximum argmax (_hidden.c:186-200) as a select tree, see
+                // k_wide_viterbi_fwd
+                double vv[NP], hh[NP], h0[NP], aa[NP];
+                int ii[NP];
+#pragma unroll
+                for (int i = 0; i < NP; i += 2) {
+                    const double2 x = *reinterpret_cast<const double2 *>(&xv[gi][i]);
+                    vv[i] = x.x;
+                    vv[i + 1] = x.y;
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    aa[i] = Acol[i];
+                    hh[i] = vv[i] * aa[i]; // _hidden.c:249
+                    h0[i] = hh[i];
+                    ii[i] = i;
+                }
+#define BHMM_ARGMAX_LEVEL(Wd)                                          \
+    if constexpr (NP > Wd) {                                           \
+        _Pragma("unroll") for (int i = 0; i + Wd < NP; i += 2 * Wd)    \
+        {                                                              \
+            const bool take = hh[i + Wd] > hh[i];                      \
+            hh[i] = take ? hh[i + Wd] : hh[i];                         \
+            vv[i] = take ? vv[i + Wd] : vv[i];                         \
+            aa[i] = take ? aa[i + Wd] : aa[i];                         \
+            ii[i] = take ? ii[i + Wd] : ii[i];                         \
+        }                                                              \
+    }
+                BHMM_ARGMAX_LEVEL(1)
+                BHMM_ARGMAX_LEVEL(2)
+                BHMM_ARGMAX_LEVEL(4)
+                BHMM_ARGMAX_LEVEL(8)
+#undef BHMM_ARGMAX_LEVEL
+                if (s >= nw) {
+                    if (real)
+                        ptr[(gs + s) * n + j] = (uint8_t)ii[0];
+                    // candidates within `margin` of the winner: must be the winner alone
+                    const double thr = hh[0] - margin * hh[0];
+                    int cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        cnt += (h0[i] >= thr) ? 1 : 0;
+                    low |= real && cnt != 1;
+                }
+                vn = p * vv[0] * aa[0]; // _hidden.c:253
+            }
+            xn[gi][j] = vn;
+            double S = 0.0;
+            {
+                double xs[NP];
+#pragma unroll
+                for (int i = 0; i < NP; i += 2) {
+                    const double2 x = *reinterpret_cast<const double2 *>(&xn[gi][i]);
+                    xs[i] = x.x;
+                    xs[i + 1] = x.y;
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    S += xs[i]; // ascending order; padded states add exact zeros
+            }
+            v = vn / S;
+            if (s == nw - 1)
+                v_entry[g * NP + j] = v; // the vector this chunk starts from
+        }
+        v_exit[g * NP + j] = v;
+        if (t0 + len == toff[k + 1] - toff[k]) { // last chunk of the trajectory: final state
+            xv[gi][j] = v;
+            if (j == 0) {
+                double bm = xv[gi][0];
+                int bi = 0;
+                for (int i = 1; i < n; ++i)
+                    if (xv[gi][i] > bm) {
+                        bm = xv[gi][i];
+                        bi = i;
+                    }
+                int cnt = 0;
+                for (int i = 0; i < n; ++i)
+                    cnt += (xv[gi][i] >= bm - margin * bm) ? 1 : 0;
+                low |= cnt != 1;
+                last_state[k] = bi;
+            }
+        }
+    }
+    const unsigned long long lows = __ballot(low);
+    if (lane == 0 && lows)
+        atomicAdd(&flags[2], (unsigned int)__popcll(lows));
+}
+
+// boundary check of k_viterbi_chunks: result[0] boundaries out of tolerance, [1] largest
+// deviation (float bits), [3] boundaries whose two vectors are not bit-identical.  When all are
+// bit-identical the chunked run IS the serial run (by induction from the exact first chunk), and
+// close decisions do not matter.
+template <int NP>
+__global__ void k_viterbi_check(const Chunks ch, int G, const double *v_entry, const double *v_exit,
+                                double tol, unsigned int *result)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double dev = spec_dev_one<NP>(ch, G, g, v_entry, v_exit, nullptr, nullptr);
+    spec_commit(dev, tol, result);
+    bool differs = false;
+    if (g < G && ch.len[g] > 0 && ch.t0[g] != 0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            differs |= __double_as_longlong(v_entry[g * NP + j]) !=
+                       __double_as_longlong(v_exit[(g - 1) * NP + j]);
+    }
+    const unsigned long long d = __ballot(differs);
+    if ((threadIdx.x & 63) == 0 && d)
+        atomicAdd(&result[3], (unsigned int)__popcll(d));
+}
+
 // Emission probabilities of all steps, row-major (total, n), fully parallel (one thread per
 // step): takes exp / division / table gathers out of the serial Viterbi recursion, whose time
 // is set by the length of its per-step instruction stream.  Same arithmetic as the fused form

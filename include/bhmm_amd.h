@@ -156,7 +156,9 @@ int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const do
  *   "spec_last_dev" (read-only) largest relative boundary deviation of the last check
  *   "careful"       (read-only) 1 after an E-step met an all-zero emission row (gaussian
  *                   outlier rule, outputmodel.py:126-130) and switched to the kernel that
- *                   applies the rule per step */
+ *                   applies the rule per step
+ *   "viterbi_chunked" (read-only) 1 if the last bhmm_viterbi_batch ran parallel over time
+ *                   chunks (boundaries verified, no close decision), 0 if it ran serially */
 int bhmm_ctx_set_option(bhmm_ctx *ctx, const char *name, double value);
 int bhmm_ctx_get_option(bhmm_ctx *ctx, const char *name, double *value);
 

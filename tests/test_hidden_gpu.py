@@ -276,3 +276,52 @@ def test_batched_sampling_exact_on_ties():
         eng.sample_paths(np.full((8, 8), 0.125), np.full(8, 0.125), np.full((8, 4), 0.25),
                          u=[np.full(len(obs[0]), 1.5)])
     eng.close()
+
+
+@pytest.mark.parametrize("chunk", [0, 5, 16, 40, 200])
+def test_chunk_parallel_viterbi_is_bit_exact_or_falls_back(golden, chunk):
+    """bhmm_viterbi_batch first runs parallel over time chunks (warm-up boundaries, verified;
+    decisions must not be close) and otherwise serially; either way the path is the reference's
+    (_hidden.c:203-281), bit for bit."""
+    from bhmm_amd.engine import Engine
+    g = golden("g8_ragged")
+    obs = split(g["obs"], g["lengths"])
+    ref = split(g["viterbi"], g["lengths"])
+    eng = Engine(0)
+    eng.set_observations("gaussian", obs, 8, chunk=chunk)
+    for W in (288, 24, 2):
+        eng.set_option("spec_W", W)
+        paths = eng.viterbi(g["A"], g["pi"], g["mu"], g["sigma"])
+        for p, r in zip(paths, ref):
+            assert np.array_equal(p, r)
+        ran_chunked = eng.get_option("viterbi_chunked")
+        if W == 2 and 0 < chunk < 100:
+            assert ran_chunked == 0.0        # two warm-up steps cannot verify -> serial run
+    eng.close()
+    # a longer problem where the chunked run must be the one that is used
+    rng = np.random.default_rng(4)
+    n, T, K = 5, 20000, 6
+    A = rng.random((n, n)) + 4 * np.eye(n)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = np.full(n, 1.0 / n)
+    mu, sig = np.linspace(-3, 3, n), np.full(n, 0.8)
+    s = np.zeros((K, T), dtype=int)
+    for t in range(1, T):
+        s[:, t] = [rng.choice(n, p=A[i]) for i in s[:, t - 1]]
+    obs = [mu[s[k]] + sig[s[k]] * rng.standard_normal(T) for k in range(K)]
+    eng = Engine(0)
+    eng.set_observations("gaussian", obs, n, chunk=500)
+    paths = eng.viterbi(A, pi, mu, sig)
+    assert eng.get_option("viterbi_chunked") == 1.0
+    for k in range(K):
+        pobs = orc.pobs_gaussian(obs[k], mu, sig)
+        assert np.array_equal(paths[k], orc.viterbi(A, pobs, pi))
+    # exact ties everywhere (uniform model): every decision is "close", but the boundary vectors
+    # are bit-identical, so the chunked run is the serial run and the first maximum wins as in the
+    # reference
+    Au = np.full((n, n), 1.0 / n)
+    eng.set_observations("explicit", [np.full((3000, n), 0.3)], n, chunk=100)
+    p = eng.viterbi(Au, pi)
+    assert eng.get_option("viterbi_close") > 0
+    assert np.array_equal(p[0], orc.viterbi(Au, np.full((3000, n), 0.3), pi))
+    eng.close()

@@ -61,7 +61,10 @@ def main():
         if "c2v" in which:
             dt = timeit(lambda: eng.viterbi(*args), 3)
             res.append(dict(config="configs[1] Viterbi, 8-state Gaussian 256 x 1e5", seconds=dt,
-                            timesteps_per_s=K * T / dt, note="includes copying 102 MB of paths to the host"))
+                            timesteps_per_s=K * T / dt, note="includes copying 102 MB of paths to the host",
+                            chunked=eng.get_option("viterbi_chunked"),
+                            close_decisions=eng.get_option("viterbi_close"),
+                            boundary_dev=eng.get_option("spec_last_dev")))
         if "c5" in which:
             dt = timeit(lambda: eng.sample_paths(*args, seed=1, want_paths=False), 5)
             res.append(dict(config="configs[4] Gibbs hidden-path sweep (forward + backward sampling + "
