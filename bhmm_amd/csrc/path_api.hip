@@ -170,12 +170,15 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         return rc;
     const int K = c->K, n = c->n, NP = c->wide ? c->N : 8, GP = 64 / NP;
     c->viterbi_chunked = false;
+    const size_t gpad = c->wide ? 0 : (size_t)c->Gp;
     if ((rc = c->d_scratch.ensure((size_t)c->total * n)) ||
-        (rc = c->d_scratch2.ensure(((size_t)c->total + K) * sizeof(int32_t))))
+        (rc = c->d_scratch2.ensure(((size_t)c->total + K + 2 * gpad) * sizeof(int32_t))))
         return rc;
     uint8_t *ptr = reinterpret_cast<uint8_t *>(c->d_scratch.p);
     int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
     int32_t *path = last + K;
+    uint32_t *vmaps = reinterpret_cast<uint32_t *>(path + c->total); // chunked run: chunk maps,
+    int32_t *vend = reinterpret_cast<int32_t *>(vmaps + gpad);       // state at each chunk's end
     // U trajectories per lane group.  Measured on configs[1] (256 trajectories): the kernel is
     // bound by the instruction stream of each wavefront, not by latency, and SIMDs are plentiful
     // (32 of 1024 busy), so U = 1 is fastest (U = 4 was 3.5x slower); the parameter stays for
@@ -265,8 +268,20 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     else
         BHMM_WV_KIND(64);
     BHMM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_wide_viterbi_trace, dim3(K), dim3(64), 0, c->stream, off, K, n,
-                       (const uint8_t *)ptr, (const int32_t *)last, path);
+    if (done) {
+        const Chunks chs = chunks_pub(c);
+        const dim3 wg((c->G + 7) / 8);
+        hipLaunchKernelGGL((k_vit_walk<8, false>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                           (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, (int32_t *)nullptr);
+        hipLaunchKernelGGL(k_smp_stitch, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB), dim3(64), 0,
+                           c->stream, (const int32_t *)c->d_traj_c0.p, K, 1, (const uint32_t *)vmaps,
+                           vend, (const int32_t *)last);
+        hipLaunchKernelGGL((k_vit_walk<8, true>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                           (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path);
+    } else {
+        hipLaunchKernelGGL(k_wide_viterbi_trace, dim3(K), dim3(64), 0, c->stream, off, K, n,
+                           (const uint8_t *)ptr, (const int32_t *)last, path);
+    }
     BHMM_HIP(hipGetLastError());
     BHMM_HIP(hipMemcpyAsync(paths_host, path, (size_t)c->total * sizeof(int32_t),
                             hipMemcpyDeviceToHost, c->stream));

@@ -203,15 +203,16 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
 // state at the first step of the NEXT part, for every (chunk, part) (0 behind a trajectory's
 // last part, whose map is constant)
 constexpr int SMP_STITCH_TPB = 8;
-static __global__ __launch_bounds__(64) void k_smp_stitch(const int32_t *traj_c0, int K, int P, const uint32_t *Fmap,
-                                    int32_t *next_state)
+static __global__ __launch_bounds__(64) void k_smp_stitch(const int32_t *traj_c0, int K, int P,
+                                                          const uint32_t *Fmap, int32_t *next_state,
+                                                          const int32_t *start = nullptr)
 {
     // every lane walks its own trajectory, so each wavefront-wide load / store touches one cache
     // line per active lane: few lanes per workgroup, many workgroups
     const int k = blockIdx.x * SMP_STITCH_TPB + threadIdx.x;
     if (threadIdx.x >= SMP_STITCH_TPB || k >= K)
         return;
-    uint32_t x = 0;
+    uint32_t x = start ? (uint32_t)start[k] : 0u; // Viterbi: the final state of the trajectory
     // the maps are loaded 16 at a time (their addresses do not depend on the walk), the walk itself
     // is register arithmetic
     int64_t hi = (int64_t)traj_c0[k + 1] * P - 1;
@@ -814,6 +815,60 @@ __global__ void k_viterbi_check(const Chunks ch, int G, const double *v_entry, c
     const unsigned long long d = __ballot(differs);
     if ((threadIdx.x & 63) == 0 && d)
         atomicAdd(&result[3], (unsigned int)__popcll(d));
+}
+
+// Back-trace of the chunked run, parallel over chunks like the path sampler: k_vit_walk<false>
+// gives every chunk its map "state at my last step -> state at the last step of the previous
+// chunk" (8 candidates walked by 8 lanes, packed as nibbles), k_smp_stitch chains the maps per
+// trajectory from its final state, k_vit_walk<true> re-walks every chunk from its known last state
+// and writes the path (_hidden.c:269-272).  Back-pointer rows are staged through LDS 64 steps at
+// a time; a dependent chain of global byte loads would be latency bound.
+template <int NP, bool APPLY>
+__global__ __launch_bounds__(64) void k_vit_walk(const Chunks ch, int G, int n, const uint8_t *ptr,
+                                                 const int32_t *end_state, uint32_t *maps,
+                                                 int32_t *path)
+{
+    constexpr int GP = 64 / NP;
+    __shared__ uint8_t tile[GP][64 * NP];
+    __shared__ int32_t outp[GP][64];
+    const int lane = threadIdx.x;
+    const int gi = lane / NP, e = lane % NP;
+    const int64_t g = (int64_t)blockIdx.x * GP + gi;
+    const int len = g < G ? ch.len[g] : 0;
+    unsigned int packed = 0;
+    if (len > 0) {
+        const int64_t goff = ch.goff[g];
+        const bool first = ch.t0[g] == 0;
+        // row s of the chunk leads from the state at step s to the state at step s-1; row 0 of a
+        // chunk that does not start its trajectory leads into the previous chunk (maps only)
+        const int s_lo = (APPLY || first) ? 1 : 0;
+        int cur = APPLY ? end_state[g] : e;
+        if (APPLY && e == 0)
+            path[goff + len - 1] = cur;
+        for (int hi = len - 1; hi >= s_lo; hi -= 64) {
+            const int lo = hi - 63 > s_lo ? hi - 63 : s_lo;
+            const int cnt = hi - lo + 1;
+            const int64_t base = (goff + lo) * n;
+            for (int b = e; b < cnt * n; b += NP)
+                tile[gi][b] = ptr[base + b];
+            for (int q = cnt - 1; q >= 0; --q) {
+                cur = tile[gi][q * n + cur];
+                if (APPLY && e == 0)
+                    outp[gi][q] = cur; // path at step lo + q - 1
+            }
+            if constexpr (APPLY)
+                for (int q = e; q < cnt; q += NP)
+                    path[goff + lo - 1 + q] = outp[gi][q];
+        }
+        packed = (unsigned int)cur << (4 * e);
+    }
+    if constexpr (!APPLY) {
+#pragma unroll
+        for (int h = 1; h < NP; h <<= 1)
+            packed |= __shfl_xor(packed, h, 64);
+        if (e == 0 && len > 0)
+            maps[g] = packed;
+    }
 }
 
 // Emission probabilities of all steps, row-major (total, n), fully parallel (one thread per
