@@ -283,9 +283,19 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                            (const uint8_t *)ptr, (const int32_t *)last, path);
     }
     BHMM_HIP(hipGetLastError());
-    BHMM_HIP(hipMemcpyAsync(paths_host, path, (size_t)c->total * sizeof(int32_t),
-                            hipMemcpyDeviceToHost, c->stream));
-    BHMM_HIP(hipStreamSynchronize(c->stream));
+    // large results: pin the caller's buffer for the transfer (a pageable destination goes
+    // through the runtime's staging buffers at a fraction of the link rate)
+    const size_t pbytes = (size_t)c->total * sizeof(int32_t);
+    const bool pinned = pbytes >= ((size_t)8 << 20) &&
+                        hipHostRegister(paths_host, pbytes, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned)
+        (void)hipGetLastError();
+    hipError_t ce = hipMemcpyAsync(paths_host, path, pbytes, hipMemcpyDeviceToHost, c->stream);
+    if (ce == hipSuccess)
+        ce = hipStreamSynchronize(c->stream);
+    if (pinned)
+        (void)hipHostUnregister(paths_host);
+    BHMM_HIP(ce);
     return BHMM_OK;
 }
 
