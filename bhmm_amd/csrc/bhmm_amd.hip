@@ -150,15 +150,15 @@ struct Runner {
             if (rc)
                 return rc;
         } else {
-            if (sm > 64 * 1024)
-                BHMM_HIP(hipFuncSetAttribute((const void *)(k_fwdbwd<N, KIND, MODE, SPEC>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-            hipLaunchKernelGGL((k_fwdbwd<N, KIND, MODE, SPEC>), dim3(nblk), dim3(32 * N), sm,
-                               c->stream, m, ch, (const void *)c->d_obs_ci.p,
-                               (const double *)c->d_Bt.p, c->d_aentry.p, c->d_bexit.p, c->d_aexit.p,
-                               c->d_bentry.p, c->spec_W, c->d_ws.p,
-                               store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
-                               c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p);
+            static_assert(MODE == MODE_ESTEP || !SPEC, "row passes take exact boundaries");
+            const size_t smr = (size_t)(KIND == EMIT_DISC ? c->M * N : 0) * sizeof(double);
+            if (smr > 64 * 1024)
+                BHMM_HIP(hipFuncSetAttribute((const void *)(k_rows<N, KIND, MODE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr));
+            hipLaunchKernelGGL((k_rows<N, KIND, MODE>), dim3(nblk), dim3(32 * N), smr, c->stream, m,
+                               ch, (const void *)c->d_obs_ci.p, (const double *)c->d_Bt.p,
+                               (const double *)c->d_aentry.p, (const double *)c->d_bexit.p, c->d_ws.p,
+                               c->d_logLc.p);
         }
         BHMM_HIP(hipGetLastError());
         BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
@@ -534,7 +534,7 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
     const int K = c->K;
     int L = chunk;
     if (L <= 0) {
-        // k_fwdbwd uses N/2 lanes per chunk: 32768 chunks put two 64-lane wavefronts on every
+        // k_estep uses N/2 lanes per chunk: 32768 chunks put two 64-lane wavefronts on every
         // SIMD of the 256 CUs.  Fewer, longer chunks amortise the warm-up of the speculative
         // boundaries (W / L extra steps); more chunks only help occupancy (measured optimum on
         // configs[1]: profiles/r01).

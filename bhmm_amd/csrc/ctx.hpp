@@ -84,7 +84,7 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_Brm;      // [n][M] emission matrix, row-major (path kernels)
     bhmm::DevBuf<double> d_alpha_rm; // [total][n] alpha, trajectory-major (path sampling)
     bhmm::DevBuf<double> d_wmodel;   // model parameters of the 9..64-state family
-    // speculative (verified) chunk boundaries, see k_fwdbwd<..., SPEC> / k_spec_check
+    // speculative (verified) chunk boundaries, see k_estep<..., SPEC> (estep_sweep.hpp) / k_spec_check
     bool spec_enabled = true;
     int spec_W = 288;             // warm-up length (grows by half after a failed verification)
     int spec_fail = 0, spec_ok = 0;

@@ -15,9 +15,11 @@
 //                exponent-normalised) -- makes the time recursion associative.
 //   k_stitch   : per trajectory, sequential over chunks (N lanes per trajectory): exact
 //                alpha at every chunk entry and beta at every chunk exit.
-//   k_fwdbwd   : per chunk, scaled forward sweep (alpha -> HBM, log-likelihood), then the
-//                backward sweep that consumes alpha and accumulates gamma / xi / emission
-//                sufficient statistics in registers.  beta and pobs never touch HBM.
+//   k_estep    : (estep_sweep.hpp) per chunk, forward sweep (alpha -> HBM, log-likelihood),
+//                then the backward sweep that consumes alpha and accumulates gamma / xi /
+//                emission sufficient statistics in registers.  beta and pobs never touch HBM.
+//   k_rows     : forward-only / backward-only rows with the reference's normalisation (the
+//                `hidden` API).
 //   k_finalize : fixed-order reduction of the per-workgroup partials into the packed
 //                statistics vector (the quantity that is all-reduced across GPUs).
 //
@@ -209,7 +211,7 @@ __device__ __forceinline__ int exponent_of(double x)
 //   the division).  Mapping: N lanes per chunk, lane r owns row r (N doubles) and a private
 //   register copy of A; the step's emission vector is computed one state per lane and
 //   exchanged through a 64-byte LDS slot per chunk.  A workgroup of 64*N threads covers the
-//   same 64 chunks as one wavefront of k_fwdbwd (one CI record group), so observation loads
+//   same 64 chunks as one wavefront of k_estep (one CI record group), so observation loads
 //   stay inside one 512 B segment.  Rows are renormalised by a power of two every step
 //   (exact); the exponent is carried separately:  true row r = 2^ex[r] * stored row r.
 //   Output per chunk: N*N doubles row-major + N exponents (as doubles).
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(64) void k_compose(const int32_t *grp_c0, const int
 //             (_hidden.c:42-63 collapsed over a chunk:  a <- a^T Mc)
 //   backward: beta_exit[c]   ~ beta at the last step of chunk c
 //             (_hidden.c:91-109 collapsed:  b <- M_{c+1} b,  b_{T-1} = 1/N)
-// Both vectors are kept up to a power-of-two scale (largest entry in [0.25, 8)); k_fwdbwd
+// Both vectors are kept up to a power-of-two scale (largest entry in [0.25, 8)); k_estep / k_rows
 // normalises them where the reference's normalisation matters.  Cross-lane traffic is DPP
 // only; the next PD matrices are prefetched into registers because the chain is latency bound.
 // Blocks [0, nb) run the forward direction, [nb, 2 nb) the backward one.
@@ -528,17 +530,13 @@ __global__ __launch_bounds__(64) void k_stitch(const int32_t *seg_c0, const int3
 }
 
 // =========================================================================================
-// k_fwdbwd: the streaming kernel.
-//
-// Mapping: H = N/2 lanes cooperate on one chunk; lane q owns the state pair (2q, 2q+1), i.e.
-// exactly one 16-byte element of every CI record, the two columns / rows of A that touch its
-// states, and the two rows of the xi accumulator.  A workgroup of 64*H threads covers one CI
-// record group (64 chunks).  Per step the only cross-lane traffic is one all-gather of an
-// N-vector (alpha in the forward sweep, p o beta in the backward sweep) and two scalar
-// reductions, all on DPP quad permutes (H <= 4 lanes sit inside one quad).  Compared with
-// one lane per chunk this cuts the per-lane register state by H (the 2*N*N-register xi
-// accumulator was what limited occupancy to one wavefront per SIMD), keeps A in registers,
-// and leaves the instruction count per chunk-step about equal.
+// Lane mapping of the streaming kernels (k_estep in estep_sweep.hpp, k_rows below):
+// H = N/2 lanes cooperate on one chunk; lane q owns the state pair (2q, 2q+1), i.e. exactly one
+// 16-byte element of every CI record, the two columns / rows of A that touch its states, and
+// (k_estep) the two rows of the xi accumulator.  A workgroup of 64*H threads covers one CI
+// record group (64 chunks).  Compared with one lane per chunk this cuts the per-lane register
+// state by H (the 2*N*N-register xi accumulator was what limited occupancy to one wavefront per
+// SIMD), keeps A in registers, and leaves the instruction count per chunk-step about equal.
 // =========================================================================================
 template <int N, int KIND>
 struct StatLayout {
@@ -663,55 +661,37 @@ __device__ __forceinline__ double2 *ci_pair(double *base, int64_t rec, int N_, i
     return reinterpret_cast<double2 *>(base + rec * (int64_t)(N_ * 64)) + cl * (N_ / 2) + q;
 }
 
-// SPEC (speculative boundaries, verified afterwards by k_spec_check): instead of reading the
-// exact chunk-boundary vectors from k_stitch, every chunk derives them itself by warming the
-// recursion up over the W steps before (alpha) / after (beta) the chunk from a uniform vector.
-// A hidden Markov filter forgets its initial condition, so after enough steps the result no
-// longer depends on that vector; k_spec_check then compares, at every chunk boundary, the
-// vector one chunk assumed with the vector its neighbour actually computed (componentwise
-// relative tolerance).  If all boundaries agree the whole chain is exact to that tolerance
-// (chunk 0 starts from the true initial condition; the normalised recursion is non-expansive
-// in Hilbert's projective metric, so deviations add at most linearly); otherwise the host
-// re-runs the E-step with the prescan/stitch kernels, which are exact unconditionally.
-template <int N, int KIND, int MODE, bool SPEC>
-__global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
-    const Model<N> m, const Chunks ch, const void *obs_ci, const double *Bt_g,
-    double *alpha_entry, double *beta_exit,
-    double *a_exit,        // SPEC: [G][N] normalised alpha at each chunk's last step
-    double *b_entry,       // SPEC: [G][N] beta one step before each chunk, as the chunk derived it
-    int W,                 // SPEC: warm-up length
-    double *ws,            // CI workspace: alpha (ESTEP, FWD) or beta (BWD)
-    double *gamma_ci,      // CI gamma, or nullptr
-    double *logL_chunk,    // [G] log of the product of the chunk's scaling factors
-    double *gamma0,        // [K][N] gamma at t = 0 of every trajectory
-    double *partials,      // [gridDim.x][S] register statistics per workgroup
-    double *disc_partials) // [gridDim.x][M*N] discrete emission statistics per workgroup
+// =========================================================================================
+// k_rows<N, KIND, MODE>: forward (MODE_FWD) or backward (MODE_BWD) rows with the reference's own
+// per-step normalisation (_hidden.c:16-66, :69-110), into the CI workspace -- the forward-only /
+// backward-only passes of the `hidden` API, which must return the reference's normalised rows.
+// Chunk-boundary vectors come from k_stitch (exact).  The E-step itself runs k_estep
+// (estep_sweep.hpp), which carries alpha and beta up to powers of two instead.
+// =========================================================================================
+template <int N, int KIND, int MODE>
+__global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks ch,
+                                                 const void *obs_ci, const double *Bt_g,
+                                                 const double *alpha_entry,
+                                                 const double *beta_exit,
+                                                 double *ws,         // CI rows: alpha or beta
+                                                 double *logL_chunk) // [G] (MODE_FWD)
 {
-    using SL = StatLayout<N, KIND>;
+    static_assert(MODE == MODE_FWD || MODE == MODE_BWD, "row passes only");
     constexpr int H = N / 2;
-    constexpr int NW = (64 * H + 63) / 64; // wavefronts per workgroup
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *red = smem;                                     // [NW][S]
-    double *Bt = smem + NW * SL::S;                         // [M][N]
-    double *dstat = Bt + (KIND == EMIT_DISC ? m.M * N : 0); // [M][N]
+    double *Bt = smem; // [M][N]
     if constexpr (KIND == EMIT_DISC) {
         stage_Bt<N>(Bt, Bt_g, m.M);
-        if constexpr (MODE == MODE_ESTEP)
-            for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
-                dstat[i] = 0.0;
         __syncthreads();
     }
     const int cl = threadIdx.x / H; // chunk within the record group == CI lane
     const int q = threadIdx.x % H;  // my state pair
     const int64_t g = (int64_t)blockIdx.x * 64 + cl;
     const int len = ch.len[g];
-    const int64_t t0 = ch.t0[g];
-    const bool first = (t0 == 0);
+    if (len <= 0)
+        return;
+    const bool first = (ch.t0[g] == 0);
     const unsigned long long gmask = ((1ull << H) - 1) << ((threadIdx.x & 63) / H * H);
-
-    // my slices of the model (vector registers): the two columns of A for the forward sweep,
-    // the two rows for the backward sweep -- each loaded where its sweep starts so that they
-    // are not live together
     double mu[2], is[2], cn[2], pi2[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -720,371 +700,98 @@ __global__ __launch_bounds__(32 * N, FB_MINW) void k_fwdbwd(
         cn[b] = m.e2[2 * q + b];
         pi2[b] = m.pi[2 * q + b];
     }
-
-    double Cacc[2][N], sg[2], sd[2], sdd[2];
+    if constexpr (MODE == MODE_FWD) {
+        double Ac[N][2], a[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        sg[b] = sd[b] = sdd[b] = 0.0;
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            Cacc[b][j] = 0.0;
-    }
-
-    if (len > 0) {
-        double a[2];
-        double2 aent = make_double2(0.0, 0.0); // SPEC: the entry vector this chunk derived
-        // ---------------- forward sweep (_hidden.c:16-66) ------------------------------
-        if constexpr (MODE != MODE_BWD) {
-            double Ac[N][2];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                Ac[i][0] = m.A[i * N + 2 * q];
-                Ac[i][1] = m.A[i * N + 2 * q + 1];
-            }
-            double P = 1.0; // running product of the scaling factors c_t, mantissa part
-            int eP = 0;     // ... and its binary exponent: logL = log(P) + eP ln 2
-            int s = 0;
-            ObsIn nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, 0, ch.Lmax), cl, q);
-            if (first) {
-                double p[2];
-                emit_pair<N, KIND>(m, nxt, Bt, q, mu, is, cn, gmask, p);
-                if (len > 1)
-                    nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, 1, ch.Lmax), cl, q);
-                a[0] = pi2[0] * p[0];
-                a[1] = pi2[1] * p[1];
-                const double c = grp_sum<H>(a[0] + a[1]);
-                const double rc = fast_rcp(c);
-                a[0] *= rc;
-                a[1] *= rc;
-                P = frexp(c, &eP);
-                *ci_pair(ws, ci_rec(g, 0, ch.Lmax), N, q, cl) = make_double2(a[0], a[1]);
-                s = 1;
-            } else if constexpr (SPEC) {
-                // warm-up: position a cursor W steps back (or at the trajectory start, where
-                // the recursion is exact), then run forward to my first step
-                int64_t gg = g;
-                int ss = 0, rem = W;
-                bool exact0 = false;
-                while (rem > 0) {
-                    if (ss == 0) {
-                        if (ch.t0[gg] == 0) {
-                            exact0 = true;
-                            break;
-                        }
-                        --gg;
-                        ss = ch.len[gg];
-                    }
-                    const int take = rem < ss ? rem : ss;
-                    ss -= take;
-                    rem -= take;
-                }
-                a[0] = (2 * q < m.nreal) ? 1.0 / (double)m.nreal : 0.0;
-                a[1] = (2 * q + 1 < m.nreal) ? 1.0 / (double)m.nreal : 0.0;
-                while (gg != g) {
-                    double p[2];
-                    const ObsIn in = load_obs<N, KIND>(obs_ci, ci_rec(gg, ss, ch.Lmax),
-                                                       (int)(gg & 63), q);
-                    emit_pair<N, KIND>(m, in, Bt, q, mu, is, cn, gmask, p);
-                    double n0, n1;
-                    if (exact0) { // first step of the trajectory, _hidden.c:28-39
-                        n0 = pi2[0] * p[0];
-                        n1 = pi2[1] * p[1];
-                        exact0 = false;
-                    } else {
-                        double af[N];
-                        grp_gather<N>(a, af);
-                        n0 = af[0] * Ac[0][0];
-                        n1 = af[0] * Ac[0][1];
-#pragma unroll
-                        for (int i = 1; i < N; ++i) {
-                            n0 = fma(af[i], Ac[i][0], n0);
-                            n1 = fma(af[i], Ac[i][1], n1);
-                        }
-                        n0 *= p[0];
-                        n1 *= p[1];
-                    }
-                    const double rc = fast_rcp(grp_sum<H>(n0 + n1));
-                    a[0] = n0 * rc;
-                    a[1] = n1 * rc;
-                    if (++ss == ch.len[gg]) {
-                        ++gg;
-                        ss = 0;
-                    }
-                }
-                aent = make_double2(a[0], a[1]);
-                *reinterpret_cast<double2 *>(alpha_entry + g * N + 2 * q) = aent;
-            } else {
-                // entry vector from k_stitch (power-of-two scaled): normalise, _hidden.c:57-59
-                const double2 x = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
-                const double rS = fast_rcp(grp_sum<H>(x.x + x.y));
-                a[0] = x.x * rS;
-                a[1] = x.y * rS;
-            }
-            for (; s < len; ++s) {
-                double p[2];
-                const int64_t rec = ci_rec(g, s, ch.Lmax);
-                const ObsIn cur = nxt;
-                if (s + 1 < len) // issue the next step's load before this step's arithmetic
-                    nxt = load_obs<N, KIND>(obs_ci, rec + 1, cl, q);
-                emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
-                double af[N];
-                grp_gather<N>(a, af);
-                double n0 = af[0] * Ac[0][0], n1 = af[0] * Ac[0][1];
-#pragma unroll
-                for (int i = 1; i < N; ++i) {
-                    n0 = fma(af[i], Ac[i][0], n0);
-                    n1 = fma(af[i], Ac[i][1], n1);
-                }
-                n0 *= p[0];
-                n1 *= p[1];
-                const double c = grp_sum<H>(n0 + n1);
-                const double rc = fast_rcp(c);
-                a[0] = n0 * rc;
-                a[1] = n1 * rc;
-                int e;
-                P = frexp(P * c, &e);
-                eP += e;
-                *ci_pair(ws, rec, N, q, cl) = make_double2(a[0], a[1]);
-            }
-            if (q == 0)
-                logL_chunk[g] = log(P) + (double)eP * 0.693147180559945309417232121458;
-            if constexpr (SPEC)
-                *reinterpret_cast<double2 *>(a_exit + g * N + 2 * q) = make_double2(a[0], a[1]);
+        for (int i = 0; i < N; ++i) {
+            Ac[i][0] = m.A[i * N + 2 * q];
+            Ac[i][1] = m.A[i * N + 2 * q + 1];
         }
-
-        // ---------------- backward sweep ------------------------------------------------
-        double Ar[2][N];
-        if constexpr (MODE != MODE_FWD) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                Ar[0][i] = m.A[(2 * q) * N + i];
-                Ar[1][i] = m.A[(2 * q + 1) * N + i];
-            }
-        }
-        if constexpr (MODE == MODE_BWD) {
-            // plain scaled backward recursion with the reference normalisation
-            // (_hidden.c:69-110); beta rows go to the CI workspace.
-            double b2[2];
-            {
-                const double2 x = *reinterpret_cast<const double2 *>(beta_exit + g * N + 2 * q);
-                const double rS = 1.0 / grp_sum<H>(x.x + x.y);
-                b2[0] = x.x * rS;
-                b2[1] = x.y * rS;
-            }
-            *ci_pair(ws, ci_rec(g, len - 1, ch.Lmax), N, q, cl) = make_double2(b2[0], b2[1]);
-            for (int s = len - 1; s >= 1; --s) {
-                double p[2];
-                const ObsIn cur = load_obs<N, KIND>(obs_ci, ci_rec(g, s, ch.Lmax), cl, q);
-                emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
-                const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
-                double bf[N];
-                grp_gather<N>(bb2, bf);
-                double r0 = Ar[0][0] * bf[0], r1 = Ar[1][0] * bf[0];
-#pragma unroll
-                for (int j = 1; j < N; ++j) {
-                    r0 = fma(Ar[0][j], bf[j], r0);
-                    r1 = fma(Ar[1][j], bf[j], r1);
-                }
-                const double rc = 1.0 / grp_sum<H>(r0 + r1);
-                b2[0] = r0 * rc;
-                b2[1] = r1 * rc;
-                *ci_pair(ws, ci_rec(g, s - 1, ch.Lmax), N, q, cl) = make_double2(b2[0], b2[1]);
-            }
-        }
-        if constexpr (MODE == MODE_ESTEP) {
-            // b carries beta up to a power-of-two scale; gamma and xi are normalised by
-            // S_t = sum_i alpha_t[i] (A (p_{t+1} o beta_{t+1}))[i], which equals the
-            // reference's per-step normalisers (hidden/api.py:176-186, _hidden.c:168-179).
-            double b2[2], gam[2];
-            if constexpr (SPEC) {
-                // beta at my last step: 1/N at the trajectory end (_hidden.c:79-88), otherwise
-                // warmed up backwards over the W steps after the chunk from the same vector
-                b2[0] = (2 * q < m.nreal) ? 1.0 / (double)m.nreal : 0.0;
-                b2[1] = (2 * q + 1 < m.nreal) ? 1.0 / (double)m.nreal : 0.0;
-                const bool last_chunk = (g + 1 >= (int64_t)gridDim.x * 64) || ch.len[g + 1] == 0 ||
-                                        ch.t0[g + 1] == 0;
-                if (!last_chunk) {
-                    int64_t gg = g + 1;
-                    int ss = 0, rem = W - 1;
-                    while (rem > 0) { // cursor -> last warm-up step (clamped to the trajectory end)
-                        const int avail = ch.len[gg] - 1 - ss;
-                        if (rem <= avail) {
-                            ss += rem;
-                            break;
-                        }
-                        const bool more = (gg + 1 < (int64_t)gridDim.x * 64) && ch.len[gg + 1] > 0 &&
-                                          ch.t0[gg + 1] != 0;
-                        if (!more) {
-                            ss = ch.len[gg] - 1;
-                            break;
-                        }
-                        rem -= avail + 1;
-                        ++gg;
-                        ss = 0;
-                    }
-                    for (;;) {
-                        double p[2];
-                        const ObsIn in = load_obs<N, KIND>(obs_ci, ci_rec(gg, ss, ch.Lmax),
-                                                           (int)(gg & 63), q);
-                        emit_pair<N, KIND>(m, in, Bt, q, mu, is, cn, gmask, p);
-                        const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
-                        double bf[N];
-                        grp_gather<N>(bb2, bf);
-                        double r0 = Ar[0][0] * bf[0], r1 = Ar[1][0] * bf[0];
-#pragma unroll
-                        for (int j = 1; j < N; ++j) {
-                            r0 = fma(Ar[0][j], bf[j], r0);
-                            r1 = fma(Ar[1][j], bf[j], r1);
-                        }
-                        const int E = grp_max_i32<H>(max(exponent_of(r0), exponent_of(r1)));
-                        b2[0] = ldexp(r0, -E);
-                        b2[1] = ldexp(r1, -E);
-                        if (gg == g + 1 && ss == 0)
-                            break;
-                        if (ss == 0) {
-                            --gg;
-                            ss = ch.len[gg] - 1;
-                        } else {
-                            --ss;
-                        }
-                    }
-                }
-                *reinterpret_cast<double2 *>(beta_exit + g * N + 2 * q) = make_double2(b2[0], b2[1]);
-            } else {
-                const double2 x = *reinterpret_cast<const double2 *>(beta_exit + g * N + 2 * q);
-                b2[0] = x.x;
-                b2[1] = x.y;
-            }
-            {
-                gam[0] = a[0] * b2[0];
-                gam[1] = a[1] * b2[1];
-                const double rS = fast_rcp(grp_sum<H>(gam[0] + gam[1]));
-                gam[0] *= rS;
-                gam[1] *= rS;
-            }
-            const int k = ch.traj[g];
-            // one-step-ahead prefetch of the inputs of the NEXT iteration (obs_{s-1},
-            // alpha_{s-2}): with a few wavefronts per SIMD the HBM latency of a load issued
-            // at its point of use is not covered by the other waves
-            ObsIn nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, len - 1, ch.Lmax), cl, q);
-            double2 apn = make_double2(0.0, 0.0);
+        double P = 1.0; // running product of the scaling factors c_t, mantissa part
+        int eP = 0;     // ... and its binary exponent: logL = log(P) + eP ln 2
+        int s = 0;
+        ObsIn nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, 0, ch.Lmax), cl, q);
+        if (first) {
+            double p[2];
+            emit_pair<N, KIND>(m, nxt, Bt, q, mu, is, cn, gmask, p);
             if (len > 1)
-                apn = *ci_pair(ws, ci_rec(g, len - 2, ch.Lmax), N, q, cl);
-            for (int s = len - 1; s >= 0; --s) {
-                double p[2];
-                const int64_t rec = ci_rec(g, s, ch.Lmax);
-                const ObsIn cur = nxt;
-                double2 apv = apn;
-                if (s > 0)
-                    nxt = load_obs<N, KIND>(obs_ci, rec - 1, cl, q);
-                if (s > 1)
-                    apn = *ci_pair(ws, rec - 2, N, q, cl);
-                emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
-                const double o = cur.o;
-                const int sym = cur.sym;
-                // ---- consume gamma_s: state counts + emission statistics ---------------
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    sg[b] += gam[b];
-                    if constexpr (KIND == EMIT_GAUSS) {
-                        const double d = o - mu[b];
-                        const double gd = gam[b] * d;
-                        sd[b] += gd;
-                        sdd[b] = fma(gd, d, sdd[b]);
-                    }
-                    if constexpr (KIND == EMIT_DISC) // _discrete.c:22-30
-                        atomicAdd(&dstat[sym * N + 2 * q + b], gam[b]);
-                }
-                if (gamma_ci)
-                    *ci_pair(gamma_ci, rec, N, q, cl) = make_double2(gam[0], gam[1]);
-                if (first && s == 0) {
-                    *reinterpret_cast<double2 *>(gamma0 + (int64_t)k * N + 2 * q) =
-                        make_double2(gam[0], gam[1]);
-                    break;
-                }
-                // ---- pair (s-1, s): xi accumulation and beta_{s-1} ----------------------
-                if (s == 0) {
-                    if constexpr (SPEC)
-                        apv = aent;
-                    else
-                        apv = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
-                }
-                const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
-                double bf[N];
-                grp_gather<N>(bb2, bf);
-                double r0 = Ar[0][0] * bf[0], r1 = Ar[1][0] * bf[0];
-#pragma unroll
-                for (int j = 1; j < N; ++j) {
-                    r0 = fma(Ar[0][j], bf[j], r0);
-                    r1 = fma(Ar[1][j], bf[j], r1);
-                }
-                const double q0 = apv.x * r0, q1 = apv.y * r1;
-                const double rS = fast_rcp(grp_sum<H>(q0 + q1));
-                gam[0] = q0 * rS;
-                gam[1] = q1 * rS;
-                const double w0 = apv.x * rS, w1 = apv.y * rS;
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    Cacc[0][j] = fma(w0, bf[j], Cacc[0][j]);
-                    Cacc[1][j] = fma(w1, bf[j], Cacc[1][j]);
-                }
-                // beta_{s-1} up to a power of two (exact scaling)
-                const int E = grp_max_i32<H>(max(exponent_of(r0), exponent_of(r1)));
-                b2[0] = ldexp(r0, -E);
-                b2[1] = ldexp(r1, -E);
-                if constexpr (SPEC)
-                    if (s == 0) // beta one step before this chunk: what the previous chunk assumed
-                        *reinterpret_cast<double2 *>(b_entry + g * N + 2 * q) =
-                            make_double2(b2[0], b2[1]);
-            }
+                nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, 1, ch.Lmax), cl, q);
+            a[0] = pi2[0] * p[0];
+            a[1] = pi2[1] * p[1];
+            const double c = grp_sum<H>(a[0] + a[1]);
+            const double rc = fast_rcp(c);
+            a[0] *= rc;
+            a[1] *= rc;
+            P = frexp(c, &eP);
+            *ci_pair(ws, ci_rec(g, 0, ch.Lmax), N, q, cl) = make_double2(a[0], a[1]);
+            s = 1;
+        } else {
+            // entry vector from k_stitch (power-of-two scaled): normalise, _hidden.c:57-59
+            const double2 x = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
+            const double rS = fast_rcp(grp_sum<H>(x.x + x.y));
+            a[0] = x.x * rS;
+            a[1] = x.y * rS;
         }
-    }
-
-    // ---------------- workgroup reduction of the register statistics ----------------------
-    if constexpr (MODE == MODE_ESTEP) {
-        // entry e of the statistics vector is owned by lane q = (state of e) / 2; sum over
-        // the chunks of the wavefront (lanes with equal q), then over wavefronts through LDS
-        const int lane = threadIdx.x & 63;
-        const int wv = threadIdx.x >> 6;
-        double *mine = red + wv * SL::S;
-        auto chunk_sum = [&](double v) {
-            // sum over lanes with the same (lane % H): strides H, 2H, ... 32
+        for (; s < len; ++s) {
+            double p[2];
+            const int64_t rec = ci_rec(g, s, ch.Lmax);
+            const ObsIn cur = nxt;
+            if (s + 1 < len) // issue the next step's load before this step's arithmetic
+                nxt = load_obs<N, KIND>(obs_ci, rec + 1, cl, q);
+            emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
+            double af[N];
+            grp_gather<N>(a, af);
+            double n0 = af[0] * Ac[0][0], n1 = af[0] * Ac[0][1];
 #pragma unroll
-            for (int h = 32; h >= H; h >>= 1)
-                v += __shfl_xor(v, h, 64);
-            return v;
-        };
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const double v = chunk_sum(Cacc[b][j]);
-                if (lane < H)
-                    mine[(2 * q + b) * N + j] = v;
+            for (int i = 1; i < N; ++i) {
+                n0 = fma(af[i], Ac[i][0], n0);
+                n1 = fma(af[i], Ac[i][1], n1);
             }
-            const double v = chunk_sum(sg[b]);
-            if (lane < H)
-                mine[SL::NC + 2 * q + b] = v;
-            if constexpr (KIND == EMIT_GAUSS) {
-                const double v1 = chunk_sum(sd[b]);
-                const double v2 = chunk_sum(sdd[b]);
-                if (lane < H) {
-                    mine[SL::NC + N + 2 * q + b] = v1;
-                    mine[SL::NC + 2 * N + 2 * q + b] = v2;
-                }
-            }
+            n0 *= p[0];
+            n1 *= p[1];
+            const double c = grp_sum<H>(n0 + n1);
+            const double rc = fast_rcp(c);
+            a[0] = n0 * rc;
+            a[1] = n1 * rc;
+            int e;
+            P = frexp(P * c, &e);
+            eP += e;
+            *ci_pair(ws, rec, N, q, cl) = make_double2(a[0], a[1]);
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < SL::S; i += blockDim.x) {
-            double v = red[i];
+        if (q == 0)
+            logL_chunk[g] = log(P) + (double)eP * 0.693147180559945309417232121458;
+    } else {
+        double Ar[2][N], b2[2];
 #pragma unroll
-            for (int w = 1; w < NW; ++w)
-                v += red[w * SL::S + i];
-            partials[(int64_t)blockIdx.x * SL::S + i] = v;
+        for (int i = 0; i < N; ++i) {
+            Ar[0][i] = m.A[(2 * q) * N + i];
+            Ar[1][i] = m.A[(2 * q + 1) * N + i];
         }
-        if constexpr (KIND == EMIT_DISC)
-            for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
-                disc_partials[(int64_t)blockIdx.x * (m.M * N) + i] = dstat[i];
+        {
+            const double2 x = *reinterpret_cast<const double2 *>(beta_exit + g * N + 2 * q);
+            const double rS = 1.0 / grp_sum<H>(x.x + x.y);
+            b2[0] = x.x * rS;
+            b2[1] = x.y * rS;
+        }
+        *ci_pair(ws, ci_rec(g, len - 1, ch.Lmax), N, q, cl) = make_double2(b2[0], b2[1]);
+        for (int s = len - 1; s >= 1; --s) {
+            double p[2];
+            const ObsIn cur = load_obs<N, KIND>(obs_ci, ci_rec(g, s, ch.Lmax), cl, q);
+            emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
+            const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
+            double bf[N];
+            grp_gather<N>(bb2, bf);
+            double r0 = Ar[0][0] * bf[0], r1 = Ar[1][0] * bf[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) {
+                r0 = fma(Ar[0][j], bf[j], r0);
+                r1 = fma(Ar[1][j], bf[j], r1);
+            }
+            const double rc = 1.0 / grp_sum<H>(r0 + r1);
+            b2[0] = r0 * rc;
+            b2[1] = r1 * rc;
+            *ci_pair(ws, ci_rec(g, s - 1, ch.Lmax), N, q, cl) = make_double2(b2[0], b2[1]);
+        }
     }
 }
 

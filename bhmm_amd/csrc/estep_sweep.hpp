@@ -1,6 +1,6 @@
 // estep_sweep.hpp -- k_estep: the fused forward/backward sweep of the E-step (2, 4, 8 states).
 //
-// Same lane mapping as k_fwdbwd (estep_kernels.hpp): H = N/2 lanes per chunk, lane q owns the
+// Lane mapping (estep_kernels.hpp): H = N/2 lanes per chunk, lane q owns the
 // state pair (2q, 2q+1).  What this kernel changes is the instruction stream of the four
 // loops, which bound the E-step (fp64 VALU):
 //   * alpha is carried up to a power of two (the group's largest entry in [0.5, 1)); gamma and
@@ -360,7 +360,15 @@ __device__ __forceinline__ void beta_step(const Gather<N> &gather, const ObsIn &
 // k_estep<N, KIND, SPEC, GAMMA, CAREFUL>: forward sweep (alpha -> CI workspace, chunk log-likelihood), then
 // backward sweep with gamma / xi / emission statistics in registers.
 //   SPEC: chunk-boundary vectors by warm-up over W steps, verified afterwards by k_spec_check
-//   (see k_fwdbwd); otherwise they are read from k_stitch.
+//   (below); otherwise they are read from k_stitch.
+//   A hidden Markov filter forgets its initial condition, so after enough steps the warm-up
+//   result no longer depends on the uniform start vector.  k_spec_check (k_tail) compares, at
+//   every chunk boundary, the vector one chunk assumed with the vector its neighbour actually
+//   computed (componentwise relative tolerance).  If all boundaries agree the whole chain is
+//   exact to that tolerance: chunk 0 starts from the true initial condition and the normalised
+//   recursion is non-expansive in Hilbert's projective metric, so deviations add at most
+//   linearly.  Otherwise the host re-runs the E-step with the prescan / stitch kernels, which
+//   are exact unconditionally.
 //   GAMMA: the instantiation that can store the gamma rows (gamma_ci may still be null).
 //   FWDONLY: forward sweep only, every alpha row stored (any power-of-two scale): the Gibbs
 //   hidden-path step samples from alpha and is indifferent to its scale (_hidden.c:330-378).

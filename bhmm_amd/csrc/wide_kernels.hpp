@@ -97,7 +97,7 @@ __device__ __forceinline__ double wide_emit(const WideModel &m, int j, bool real
 // Segments: a trajectory may be cut into time segments that are processed by different lane
 // groups (one segment per trajectory = the plain serial recursion).  With several segments the
 // boundary vectors come from warm-ups over the W steps before / after the segment and are
-// verified afterwards by k_wide_check (same scheme as k_fwdbwd<..., SPEC>, see there); alpha of
+// verified afterwards by k_wide_check (same scheme as k_estep<..., SPEC>, see estep_sweep.hpp); alpha of
 // the step before a segment is read from the previous segment's output by the backward pass.
 struct Segs {
     const int32_t *traj; // trajectory of the segment
