@@ -253,19 +253,94 @@ struct Runner {
         return BHMM_OK;
     }
 
+    // Warm-up length from the measured forgetting curve (k_forget_probe): the smallest length
+    // after which two differently started chains agree to 1e-13 on every sampled stretch, in
+    // both directions, plus 15 %.  The boundary check of every E-step remains the judge.
+    template <int KIND>
+    static int probe_warmup(bhmm_ctx *c, const Model<N> &m, int *W_out)
+    {
+        *W_out = 0;
+        int64_t maxT = 0;
+        for (int k = 0; k < c->K; ++k)
+            maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+        const int Wmax = (int)std::min<int64_t>(1024, maxT / 2) / 4 * 4;
+        if (Wmax < 32)
+            return BHMM_OK;
+        std::vector<int> longk;
+        for (int k = 0; k < c->K; ++k)
+            if (c->offsets[k + 1] - c->offsets[k] >= Wmax)
+                longk.push_back(k);
+        const int S = 256;
+        std::vector<int64_t> starts(S);
+        for (int i = 0; i < S; ++i) {
+            const int k = longk[i % longk.size()];
+            const int64_t room = c->offsets[k + 1] - c->offsets[k] - Wmax + 1;
+            const int64_t rep = i / (int64_t)longk.size(), reps = (S + longk.size() - 1) / longk.size();
+            starts[i] = c->offsets[k] + (room - 1) * rep / std::max<int64_t>(reps - 1, 1);
+        }
+        const size_t bytes = S * sizeof(int64_t) + 2 * (size_t)Wmax * sizeof(unsigned int);
+        int rc;
+        if ((rc = c->d_probe.ensure(bytes)))
+            return rc;
+        int64_t *d_starts = reinterpret_cast<int64_t *>(c->d_probe.p);
+        unsigned int *d_curve = reinterpret_cast<unsigned int *>(d_starts + S);
+        BHMM_HIP(hipMemcpyAsync(d_starts, starts.data(), S * sizeof(int64_t), hipMemcpyHostToDevice,
+                                c->stream));
+        BHMM_HIP(hipMemsetAsync(d_curve, 0, 2 * (size_t)Wmax * sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL((k_forget_probe<N, KIND>), dim3((2 * S + 63) / 64), dim3(64), 0, c->stream,
+                           m, (const void *)c->d_obs_rm.p, (const double *)c->d_Bt.p,
+                           (const int64_t *)d_starts, S, Wmax, d_curve);
+        BHMM_HIP(hipGetLastError());
+        std::vector<float> curve(2 * (size_t)Wmax);
+        BHMM_HIP(hipMemcpyAsync(curve.data(), d_curve, curve.size() * sizeof(float),
+                                hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream)); // starts / curve are temporaries
+        int last = -1;
+        for (int w = 0; w < Wmax; ++w)
+            if (std::max(curve[w], curve[Wmax + w]) >= 1e-13f)
+                last = w;
+        int W = last + 2; // steps needed to get below the target and stay there
+        W = (int)std::ceil(1.15 * W);
+        W = std::max(16, (W + 3) / 4 * 4);
+        *W_out = std::min(W, Wmax);
+        return BHMM_OK;
+    }
+
     template <int KIND>
     static int estep_kind(bhmm_ctx *c, const Model<N> &m, double *stats_dev, int flags)
     {
         int rc;
+        if (c->spec_enabled && !c->spec_calibrated) {
+            // first E-step on these observations: measure how fast this model forgets
+            c->spec_calibrated = true;
+            c->spec_probes_left = 2;
+            int W = 0;
+            if ((rc = probe_warmup<KIND>(c, m, &W)))
+                return rc;
+            if (W > 0)
+                c->spec_W = W;
+        }
         if (c->spec_enabled) {
             for (int attempt = 0; attempt < 2; ++attempt) {
                 bool ok = false;
+                const int W_tried = c->spec_W;
                 if ((rc = estep_spec<KIND>(c, m, stats_dev, flags, &ok)))
                     return rc;
                 if (ok)
                     return BHMM_OK;
-                if (!c->careful_retry)
-                    break; // boundaries did not verify: exact pipeline
+                if (!c->careful_retry) {
+                    // boundaries did not verify: exact pipeline now; for the next call measure
+                    // the curve again (the model has moved), never below +25 %
+                    if (c->spec_enabled && !c->spec_W_fixed && c->spec_probes_left > 0) {
+                        --c->spec_probes_left;
+                        int W = 0;
+                        if ((rc = probe_warmup<KIND>(c, m, &W)))
+                            return rc;
+                        if (W > 0)
+                            c->spec_W = std::max(W, (W_tried * 5 / 4 + 3) / 4 * 4);
+                    }
+                    break;
+                }
                 c->careful_retry = false; // zero / denormal vectors: same path, careful kernel
             }
         }
@@ -778,8 +853,10 @@ int bhmm_ctx_create(bhmm_ctx **out, int device, void *stream)
     c->device = device;
     if (const char *e = getenv("BHMM_AMD_SPEC"))
         c->spec_enabled = atoi(e) != 0;
-    if (const char *e = getenv("BHMM_AMD_SPEC_W"))
+    if (const char *e = getenv("BHMM_AMD_SPEC_W")) {
         c->spec_W = std::max(1, atoi(e));
+        c->spec_W_fixed = true;
+    }
     if (stream) {
         c->stream = static_cast<hipStream_t>(stream);
     } else {
@@ -858,6 +935,7 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     if (c->h_raw)
         (void)hipHostFree(c->h_raw);
     c->d_tail.release();
+    c->d_probe.release();
     for (auto &ev : c->ev)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -899,6 +977,9 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         return invalid("obs == NULL");
     c->gamma_valid = false;
     c->careful = c->careful_retry = false;
+    c->spec_calibrated = c->spec_W_fixed;
+    if (!c->spec_W_fixed)
+        c->spec_W = 288;
     c->wide_replans = 0;
     c->wseg_given_up = false;
     if (kind == BHMM_EMIT_DISCRETE) {
@@ -1014,8 +1095,10 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
     const std::string n(name);
     if (n == "spec_enabled")
         c->spec_enabled = value != 0.0;
-    else if (n == "spec_W")
+    else if (n == "spec_W") {
         c->spec_W = std::max(1, (int)value);
+        c->spec_W_fixed = c->spec_calibrated = true; // the caller's choice: no probe
+    }
     else if (n == "wide_segments")
         c->wseg_enabled = value != 0.0;
     else if (n == "wide_segment_len")

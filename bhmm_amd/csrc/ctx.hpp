@@ -86,7 +86,13 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_wmodel;   // model parameters of the 9..64-state family
     // speculative (verified) chunk boundaries, see k_estep<..., SPEC> (estep_sweep.hpp) / k_spec_check
     bool spec_enabled = true;
-    int spec_W = 288;             // warm-up length (grows by half after a failed verification)
+    int spec_W = 288;             // warm-up length: read off the measured forgetting curve at the
+                                  // first E-step on new data (probe_warmup), lengthened after a
+                                  // failed verification
+    bool spec_W_fixed = false;    // given by the caller (option / BHMM_AMD_SPEC_W): never probed
+    bool spec_calibrated = false; // probe done for this set of observations
+    int spec_probes_left = 0;     // re-probes allowed after failed checks
+    bhmm::DevBuf<char> d_probe;   // probe: sample positions + forgetting curve
     int spec_fail = 0, spec_ok = 0;
     float spec_last_dev = 0.f;
     bhmm::DevBuf<double> d_aexit, d_bentry;

@@ -1029,6 +1029,106 @@ __global__ __launch_bounds__(64) void k_tail(const Model<N> m, const Chunks ch, 
 }
 
 // =========================================================================================
+// k_forget_probe: how fast does the filter forget under THIS model on THIS data?  For a sample
+// of positions the forward (dir 0) and backward (dir 1) recursions are run over the same stretch
+// of observations from two different start vectors (uniform / all mass on one state), and
+// curve[dir][w] receives the largest componentwise relative deviation between the two normalised
+// vectors after w + 1 steps (float bits; maximum over the samples).  The host reads the warm-up
+// length of the speculative boundaries off this curve (calibrate_warmup in bhmm_amd.hip) instead
+// of guessing it; the boundary check still verifies every E-step.  One thread per (sample, dir),
+// plain per-thread arithmetic -- this runs once per data set, not per E-step.
+// =========================================================================================
+template <int N, int KIND>
+__global__ __launch_bounds__(64) void k_forget_probe(const Model<N> m, const void *obs_rm,
+                                                     const double *Bt_g, const int64_t *starts,
+                                                     int S, int Wmax, unsigned int *curve)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = id < 2 * S;
+    const int dir = act ? id / S : 0, idx = act ? id % S : 0;
+    const int n = m.nreal;
+    const int64_t pos0 = starts[idx];
+    double x[N], y[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        x[j] = j < n ? 1.0 / (double)n : 0.0;
+        y[j] = (j == idx % n) ? 1.0 : 0.0;
+    }
+    for (int w = 0; w < Wmax; ++w) {
+        const int64_t t = dir == 0 ? pos0 + w : pos0 + Wmax - 1 - w;
+        double p[N];
+        if constexpr (KIND == EMIT_GAUSS) {
+            const double o = static_cast<const double *>(obs_rm)[t];
+            double mx = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double z = (o - m.e0[j]) * m.e1[j];
+                p[j] = j < n ? m.e2[j] * exp(-0.5 * z * z) : 0.0;
+                mx = fmax(mx, p[j]);
+            }
+            if (mx == 0.0) {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    p[j] = j < n ? 1.0 : 0.0;
+            }
+        } else if constexpr (KIND == EMIT_DISC) {
+            const int sym = static_cast<const int32_t *>(obs_rm)[t];
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                p[j] = Bt_g[(int64_t)sym * N + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                p[j] = j < n ? static_cast<const double *>(obs_rm)[t * n + j] : 0.0;
+        }
+        auto step = [&](double (&v)[N]) {
+            double r[N], sum = 0.0;
+            if (dir == 0) { // (v A) o p
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        a = fma(v[i], m.A[i * N + j], a);
+                    r[j] = a * p[j];
+                }
+            } else { // A (p o v)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        a = fma(m.A[i * N + j], p[j] * v[j], a);
+                    r[i] = i < n ? a : 0.0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                sum += r[j];
+            const double rs = 1.0 / sum;
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                v[j] = r[j] * rs;
+        };
+        step(x);
+        step(y);
+        double dev = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double d = fabs(x[j] - y[j]), lo = fmin(x[j], y[j]);
+            dev = fmax(dev, lo > 1e-280 ? d / lo : (d > 1e-280 ? 1.0 : 0.0));
+        }
+        if (!(dev == dev))
+            dev = 1.0;
+        dev = fmin(dev, 1.0);
+        if (act)
+            atomicMax(&curve[dir * Wmax + w], __float_as_uint((float)dev));
+        if (__all(dev < 1e-15)) // the wavefront's chains have all merged to rounding noise
+            break;
+    }
+}
+
+// =========================================================================================
 // layout conversion kernels (one lane per chunk; CI side is coalesced)
 // =========================================================================================
 template <typename T>

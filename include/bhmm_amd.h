@@ -148,7 +148,11 @@ int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const do
 /* Tuning / introspection knobs by name (returns BHMM_ERR_INVALID for an unknown name):
  *   "spec_enabled"  1/0  use speculative, verified chunk boundaries in bhmm_estep (default 1;
  *                        switched off automatically when verification keeps failing)
- *   "spec_W"        warm-up length in time steps (default 288; after a failed check extrapolated from the measured deviation, x1.25 .. x8)
+ *   "spec_W"        warm-up length in time steps.  By default it is read off the forgetting
+ *                   curve that the first E-step on new observations measures for the model at
+ *                   hand (two differently started chains on 256 sampled stretches, both
+ *                   directions; +15 %); a failed check re-measures and lengthens it.  Setting
+ *                   it (or BHMM_AMD_SPEC_W) fixes it
  *   "wide_segments" 1/0  (9..64 states) cut trajectories into time segments with the same
  *                        verified warm-up boundaries; reading it returns the segment count in use
  *   "wide_segment_len"   segment length for the next bhmm_ctx_set_observations (0 = automatic)

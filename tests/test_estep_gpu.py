@@ -382,3 +382,38 @@ def test_tiny_emissions_are_rescaled_in_time():
     np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=RTOL)
     np.testing.assert_allclose(res.C, ref["C"], rtol=1e-8, atol=1e-12)
     eng.close()
+
+
+def test_warmup_length_is_measured_not_guessed():
+    """The first E-step on new observations measures the forgetting curve of the model at hand
+    and takes the warm-up length from it; the boundary check must then pass at once, with a
+    deviation below the tolerance but not absurdly far below it (i.e. the warm-up is not
+    wastefully long).  A caller-supplied length is left alone."""
+    rng = np.random.default_rng(21)
+    n, K, T = 6, 4, 30000
+    mu, sig = np.linspace(-4, 4, n), np.full(n, 1.0)
+    pi = np.full(n, 1.0 / n)
+    res = {}
+    for stay in (0.7, 0.97):           # fast / slowly mixing chain
+        A = np.full((n, n), (1 - stay) / (n - 1))
+        np.fill_diagonal(A, stay)
+        s = np.zeros((K, T), dtype=int)
+        u = rng.random((K, T))
+        for t in range(1, T):
+            s[:, t] = np.where(u[:, t] < stay, s[:, t - 1], rng.integers(0, n, K))
+        obs = [mu[s[k]] + sig[s[k]] * rng.standard_normal(T) for k in range(K)]
+        eng = _engine()
+        eng.set_observations("gaussian", obs, n, chunk=2000)
+        r = eng.estep(A, pi, mu, sig)
+        assert eng.get_option("spec_ok") == 1 and eng.get_option("spec_fail") == 0
+        assert 1e-16 < eng.get_option("spec_last_dev") <= 1e-11
+        res[stay] = eng.get_option("spec_W")
+        ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+        np.testing.assert_allclose(r.logL_k, ref["logL"], rtol=RTOL)
+        # a fixed length is respected
+        eng.set_option("spec_W", 400)
+        eng.set_observations("gaussian", obs, n, chunk=2000)
+        eng.estep(A, pi, mu, sig)
+        assert eng.get_option("spec_W") == 400
+        eng.close()
+    assert res[0.97] > res[0.7]        # the slower chain needs the longer warm-up
