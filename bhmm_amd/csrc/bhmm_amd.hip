@@ -539,6 +539,15 @@ struct Runner {
     static int forward_kind(bhmm_ctx *c, const Model<N> &m)
     {
         int rc;
+        if (c->spec_enabled && !c->spec_calibrated) {
+            c->spec_calibrated = true;
+            c->spec_probes_left = 2;
+            int W = 0;
+            if ((rc = probe_warmup<KIND>(c, m, &W)))
+                return rc;
+            if (W > 0)
+                c->spec_W = W;
+        }
         if (c->spec_enabled) {
             for (int attempt = 0; attempt < 2; ++attempt) {
                 bool ok = false;
