@@ -38,10 +38,15 @@ class MaximumLikelihoodEstimator(object):
         self._reversible = reversible
         self._stationary = stationary
         if initial_model is None:
-            # the reference builds one with bhmm.init_hmm (GMM / PCCA heuristics, needs
-            # msmtools); model initialisation is outside the accelerated path.
-            raise NotImplementedError('bhmm_amd needs an initial_model (HMM); the heuristic '
-                                      'initialisers of bhmm.init are out of scope')
+            # maximum_likelihood.py:112-118 -> bhmm.init_hmm.  Gaussian: mixture fit +
+            # fractional counts (bhmm_amd/init/gaussian.py); the discrete initialiser of the
+            # reference (lagged count matrix + PCCA+, init/discrete.py:167-338) is not part of
+            # this package.
+            if output != 'gaussian':
+                raise NotImplementedError('bhmm_amd needs an initial_model (HMM) for discrete '
+                                          'output; only the gaussian initialiser is provided')
+            from ..init import init_model_gaussian1d
+            initial_model = init_model_gaussian1d(observations, nstates, reversible=reversible)
         self._hmm = copy.deepcopy(initial_model)
         if self._hmm.nstates != nstates:
             raise ValueError('initial_model has %d states, nstates=%d' % (self._hmm.nstates, nstates))

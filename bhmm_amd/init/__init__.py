@@ -1,0 +1,3 @@
+"""Initial-model heuristics: only what `estimate_hmm` needs to
+start from raw data.  Host-side numpy; the E-step that follows is the accelerated path."""
+from .gaussian import init_model_gaussian1d, fit_gmm1d  # noqa: F401

@@ -1,0 +1,79 @@
+"""Initial HMM with 1-D Gaussian emissions -- the role of bhmm/init/gaussian.py:26-92.
+
+The reference fits a Gaussian mixture to the pooled observations (its vendored sklearn GMM with a
+random k-means start), takes the mixture weights / means / variances as emission model, turns the
+per-step posterior memberships into fractional transition counts `N += outer(w_t, w_{t+1})` and
+estimates the transition matrix from them.  Same construction here, written from scratch: the
+mixture is fitted by plain EM from a deterministic quantile start (so that the initial model --
+and with it the whole estimation -- is reproducible), the counts are one matrix product per
+trajectory, the transition matrix comes from bhmm_amd.estimators._tmatrix.
+"""
+import numpy as np
+
+from ..estimators import _tmatrix
+from ..hmm import HMM
+from ..output_models import GaussianOutputModel
+
+
+def _log_pdf(x, means, sigmas):
+    z = (x[:, None] - means[None, :]) / sigmas[None, :]
+    return -0.5 * z * z - np.log(sigmas)[None, :] - 0.5 * np.log(2.0 * np.pi)
+
+
+def fit_gmm1d(x, ncomp, maxit=200, tol=1e-6, min_sigma=None, max_points=2000000, seed=0):
+    """EM for a 1-D Gaussian mixture.  Returns (weights, means, sigmas), components sorted by
+    mean.  Start: means at the (i + 1/2)/ncomp quantiles, common sigma, equal weights.  Data sets
+    above `max_points` are subsampled (seeded) for the fit."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    if x.size > max_points:
+        x = np.random.RandomState(seed).choice(x, max_points, replace=False)
+    if x.size < ncomp:
+        raise ValueError('fewer observations than mixture components')
+    spread = x.std()
+    if min_sigma is None:
+        min_sigma = max(1e-3 * spread, 1e-12)
+    means = np.quantile(x, (np.arange(ncomp) + 0.5) / ncomp)
+    sigmas = np.full(ncomp, max(spread / ncomp, min_sigma))
+    weights = np.full(ncomp, 1.0 / ncomp)
+    last = -np.inf
+    for _ in range(maxit):
+        lp = _log_pdf(x, means, sigmas) + np.log(weights)[None, :]
+        m = lp.max(axis=1, keepdims=True)
+        norm = m[:, 0] + np.log(np.exp(lp - m).sum(axis=1))
+        resp = np.exp(lp - norm[:, None])
+        ll = norm.mean()
+        nk = resp.sum(axis=0) + 1e-300
+        weights = nk / nk.sum()
+        means = (resp * x[:, None]).sum(axis=0) / nk
+        var = (resp * (x[:, None] - means[None, :]) ** 2).sum(axis=0) / nk
+        sigmas = np.sqrt(np.maximum(var, min_sigma ** 2))
+        if ll - last < tol * max(1.0, abs(ll)):
+            break
+        last = ll
+    order = np.argsort(means)
+    return weights[order], means[order], sigmas[order]
+
+
+def fractional_counts(observations, means, sigmas):
+    """N[i, j] = sum over trajectories and t of w_t[i] * w_{t+1}[j] with w_t the normalised
+    emission densities of step t (init/gaussian.py:66-78)."""
+    n = len(means)
+    N = np.zeros((n, n))
+    for o in observations:
+        o = np.asarray(o, dtype=np.float64)
+        if o.size < 2:
+            continue
+        lp = _log_pdf(o, means, sigmas)
+        w = np.exp(lp - lp.max(axis=1, keepdims=True))
+        w /= w.sum(axis=1, keepdims=True)
+        N += w[:-1].T @ w[1:]
+    return N
+
+
+def init_model_gaussian1d(observations, nstates, reversible=True):
+    pooled = np.concatenate([np.asarray(o, dtype=np.float64).ravel() for o in observations])
+    weights, means, sigmas = fit_gmm1d(pooled, nstates)
+    N = fractional_counts(observations, means, sigmas)
+    P = _tmatrix.estimate_P(N, reversible=reversible)
+    pi = _tmatrix.stationary_distribution(P, C=N)
+    return HMM(pi, P, GaussianOutputModel(nstates, means=means, sigmas=sigmas))

@@ -64,3 +64,24 @@ def test_output_models_on_gpu(golden):
     r = orc.estep("discrete", obs, gd["A"], gd["pi"], gd["B"], want_gamma=True)
     dm.estimate(obs, r["gammas"])
     np.testing.assert_allclose(dm.output_probabilities, gd["B_new"], rtol=1e-10, atol=1e-15)
+
+
+def test_estimate_hmm_from_raw_gaussian_data():
+    """estimate_hmm(observations, nstates) without an initial model (bhmm/api.py:309-372 with the
+    initialiser of bhmm/init/gaussian.py): the heuristic start + Baum-Welch on the GPU recover
+    the generating model."""
+    import bhmm_amd
+    rng = np.random.default_rng(9)
+    mu, sg = np.array([-2.0, 1.0, 5.0]), np.array([0.6, 0.8, 0.7])
+    P = np.array([[0.95, 0.05, 0.0], [0.03, 0.94, 0.03], [0.0, 0.06, 0.94]])
+    obs = []
+    for T in (6000, 5000, 3000):
+        s = np.zeros(T, dtype=int)
+        for t in range(1, T):
+            s[t] = rng.choice(3, p=P[s[t - 1]])
+        obs.append(mu[s] + sg[s] * rng.standard_normal(T))
+    hmm = bhmm_amd.estimate_hmm(obs, 3, reversible=False, accuracy=1e-4, maxit=200)
+    order = np.argsort(hmm.output_model.means)
+    np.testing.assert_allclose(hmm.output_model.means[order], mu, atol=0.1)
+    np.testing.assert_allclose(hmm.output_model.sigmas[order], sg, atol=0.1)
+    np.testing.assert_allclose(hmm.transition_matrix[np.ix_(order, order)], P, atol=0.03)

@@ -140,8 +140,12 @@ def test_em_loop_semantics_and_monotone_likelihood():
 
 def test_estimator_argument_handling():
     obs, init = _gauss_problem(K=2, T=50)
+    # no initial model: gaussian data get the heuristic start, discrete data must bring one
+    est = bhmm_amd.MaximumLikelihoodEstimator(obs, 3, engine_factory=OracleEngine)
+    assert est.hmm.nstates == 3 and est.hmm.output_model.model_type == 'gaussian'
     with pytest.raises(NotImplementedError):
-        bhmm_amd.MaximumLikelihoodEstimator(obs, 3, engine_factory=OracleEngine)
+        bhmm_amd.MaximumLikelihoodEstimator([np.array([0, 1, 1, 0, 2])], 2, output='discrete',
+                                            engine_factory=OracleEngine)
     with pytest.raises(ValueError):
         bhmm_amd.MaximumLikelihoodEstimator(obs, 2, initial_model=init, engine_factory=OracleEngine)
     # fixed initial distribution (p with stationary=False), maximum_likelihood.py:118-126
@@ -183,3 +187,41 @@ def test_bayesian_sampler_sweeps():
     with pytest.raises(NotImplementedError):                 # bayesian_sampling.py:187-191
         bhmm_amd.BayesianHMMSampler(obs, 2, initial_model=dis, reversible=True,
                                     transition_matrix_prior=None, engine_factory=OracleEngine)
+
+
+def test_gaussian_initial_model_heuristic():
+    """bhmm_amd.init (the role of bhmm/init/gaussian.py:26-92): mixture fit from a deterministic
+    start, fractional transition counts as one matrix product (checked against the reference's
+    per-step outer-product loop), a proper HMM out."""
+    from bhmm_amd.init.gaussian import fit_gmm1d, fractional_counts, init_model_gaussian1d
+    rng = np.random.default_rng(5)
+    mu, sg = np.array([-3.0, 0.0, 4.0]), np.array([0.5, 1.0, 0.7])
+    P = np.array([[0.9, 0.1, 0.0], [0.05, 0.9, 0.05], [0.0, 0.1, 0.9]])
+    obs = []
+    for T in (4000, 2500):
+        s = np.zeros(T, dtype=int)
+        for t in range(1, T):
+            s[t] = rng.choice(3, p=P[s[t - 1]])
+        obs.append(mu[s] + sg[s] * rng.standard_normal(T))
+    w, m, s_ = fit_gmm1d(np.concatenate(obs), 3)
+    np.testing.assert_allclose(m, mu, atol=0.15)
+    np.testing.assert_allclose(s_, sg, atol=0.15)
+    assert abs(w.sum() - 1) < 1e-12 and np.all(np.diff(m) > 0)
+    assert np.array_equal(fit_gmm1d(np.concatenate(obs), 3)[1], m)       # reproducible
+    # fractional counts: the reference's loop, init/gaussian.py:66-78
+    N = fractional_counts(obs, m, s_)
+    Nref = np.zeros((3, 3))
+    for o in obs:
+        p = np.exp(-0.5 * ((o[:, None] - m[None, :]) / s_[None, :]) ** 2) / (np.sqrt(2 * np.pi) * s_)
+        p /= p.sum(axis=1)[:, None]
+        for t in range(len(o) - 1):
+            Nref += np.outer(p[t], p[t + 1])
+    np.testing.assert_allclose(N, Nref, rtol=1e-9)
+    assert abs(N.sum() - sum(len(o) - 1 for o in obs)) < 1e-6
+    for rev in (True, False):
+        hmm = init_model_gaussian1d(obs, 3, reversible=rev)
+        T = hmm.transition_matrix
+        np.testing.assert_allclose(T.sum(axis=1), 1.0, atol=1e-12)
+        np.testing.assert_allclose(hmm.initial_distribution @ T, hmm.initial_distribution, atol=1e-8)
+        np.testing.assert_allclose(np.diag(T), np.diag(P), atol=0.12)   # metastable as generated (a start, not a fit)
+        assert hmm.output_model.model_type == 'gaussian'
