@@ -45,13 +45,21 @@ Chunks chunks_pub(const bhmm_ctx *c)
 }
 
 template <int N, int KIND>
-static size_t smem_fwdbwd(int M)
+static size_t smem_fwdbwd(int M, int dcopies = 1)
 {
     // [wavefronts per workgroup][S] reduction scratch + (discrete) B^T and the count table +
     // the gather exchange area of k_estep (one 16-byte slot per thread)
     return (size_t)(((N / 2 * 64 + 63) / 64) * StatLayout<N, KIND>::S +
-                    (KIND == EMIT_DISC ? 2 * M * N : 0) + 2 * 32 * N) *
+                    (KIND == EMIT_DISC ? (1 + dcopies) * M * N : 0) + 2 * 32 * N) *
            sizeof(double);
+}
+
+// discrete count tables per workgroup: one per wavefront if that fits the LDS, else one
+template <int N>
+static int disc_copies(int M)
+{
+    const int NW = (N / 2 * 64 + 63) / 64;
+    return smem_fwdbwd<N, EMIT_DISC>(M, NW) <= 150 * 1024 ? NW : 1;
 }
 
 static int stats_size(const bhmm_ctx *c);
@@ -117,7 +125,7 @@ struct Runner {
             flag_words = c->d_specres.p;
         const Chunks ch = chunks_of(c);
         const int nblk = c->Gp / 64; // one workgroup per CI record group (64 chunks)
-        const size_t sm = smem_fwdbwd<N, KIND>(c->M);
+        const size_t sm = smem_fwdbwd<N, KIND>(c->M, KIND == EMIT_DISC ? m.dcopies : 1);
         if constexpr (MODE == MODE_ESTEP) {
             // the exact fallback always uses the gamma-capable, careful instantiation
             auto launch = [&](auto kern) -> int {
@@ -370,6 +378,8 @@ struct Runner {
     {
         Model<N> m;
         fill_model<N>(m, c->n, c->kind, c->M, A, pi, par0, par1);
+        if (c->kind == EMIT_DISC)
+            m.dcopies = disc_copies<N>(c->M);
         switch (c->kind) {
         case EMIT_GAUSS:
             return estep_kind<EMIT_GAUSS>(c, m, stats_dev, flags);
@@ -520,7 +530,7 @@ struct Runner {
     static int forward_launch(bhmm_ctx *c, const Model<N> &m)
     {
         const Chunks ch = chunks_of(c);
-        const size_t sm = smem_fwdbwd<N, KIND>(c->M);
+        const size_t sm = smem_fwdbwd<N, KIND>(c->M, KIND == EMIT_DISC ? m.dcopies : 1);
         auto kern = k_estep<N, KIND, true, false, CAREFUL, true>;
         if (sm > 64 * 1024)
             BHMM_HIP(hipFuncSetAttribute((const void *)kern,
@@ -578,6 +588,8 @@ struct Runner {
     {
         Model<N> m;
         fill_model<N>(m, c->n, c->kind, c->M, A, pi, par0, par1);
+        if (c->kind == EMIT_DISC)
+            m.dcopies = disc_copies<N>(c->M);
         switch (c->kind) {
         case EMIT_GAUSS:
             return forward_kind<EMIT_GAUSS>(c, m);

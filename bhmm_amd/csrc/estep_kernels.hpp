@@ -52,6 +52,7 @@ struct Model {
     double e3[N]; // gaussian: sigma (the bit-exact path kernels divide by it)
     int nreal;
     int M; // number of symbols (discrete)
+    int dcopies; // k_estep, discrete: LDS count tables per workgroup (one per wavefront, or 1)
 };
 
 // Chunk table (device pointers), one entry per lane of the launch; padded entries have

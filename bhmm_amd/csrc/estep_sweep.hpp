@@ -408,8 +408,13 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *red = smem;                                     // [NW][S]
     double *Bt = smem + NW * SL::S;                         // [M][N]
-    double *dstat = Bt + (KIND == EMIT_DISC ? m.M * N : 0); // [M][N]
-    const Gather<N> gather(dstat + (KIND == EMIT_DISC ? m.M * N : 0)); // [32 * N] pairs
+    // discrete emission counts (_discrete.c:22-30) by LDS atomics: one table per wavefront where
+    // LDS allows (m.dcopies == NW), so that the order of the additions -- hence the last bits of
+    // the result -- does not depend on how the wavefronts of a workgroup interleave
+    double *dstat0 = Bt + (KIND == EMIT_DISC ? m.M * N : 0); // [dcopies][M][N]
+    const int dcopies = KIND == EMIT_DISC ? m.dcopies : 0;
+    double *dstat = dstat0 + (dcopies > 1 ? (threadIdx.x >> 6) * (m.M * N) : 0);
+    const Gather<N> gather(dstat0 + dcopies * m.M * N); // [32 * N] pairs
     int hmin = 0x7fffffff;
 #ifdef ESTEP_CLOCKPROBE
     const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = wall_clock64();
@@ -417,8 +422,8 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
 #endif
     if constexpr (KIND == EMIT_DISC) {
         stage_Bt<N>(Bt, Bt_g, m.M);
-        for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
-            dstat[i] = 0.0;
+        for (int i = threadIdx.x; i < dcopies * m.M * N; i += blockDim.x)
+            dstat0[i] = 0.0;
         __syncthreads();
     }
     const int cl = threadIdx.x / H; // chunk within the record group == CI lane
@@ -925,7 +930,12 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
         }
         if constexpr (KIND == EMIT_DISC)
             for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
-                disc_partials[(int64_t)blockIdx.x * (m.M * N) + i] = dstat[i];
+            {
+                double v = dstat0[i];
+                for (int w = 1; w < dcopies; ++w)
+                    v += dstat0[w * (m.M * N) + i];
+                disc_partials[(int64_t)blockIdx.x * (m.M * N) + i] = v;
+            }
     }
 }
 

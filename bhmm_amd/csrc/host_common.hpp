@@ -18,6 +18,7 @@ inline void fill_model(Model<N> &m, int n, int kind, int M, const double *A, con
     memset(&m, 0, sizeof(m));
     m.nreal = n;
     m.M = M;
+    m.dcopies = 1;
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j)
             m.A[i * N + j] = (i < n && j < n) ? A[i * n + j] : (i == j ? 1.0 : 0.0);

@@ -417,3 +417,48 @@ def test_warmup_length_is_measured_not_guessed():
         assert eng.get_option("spec_W") == 400
         eng.close()
     assert res[0.97] > res[0.7]        # the slower chain needs the longer warm-up
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_models_and_shapes(seed):
+    """Random state counts (incl. the padded ones), trajectory counts, ragged lengths, chunk
+    lengths and emission kinds, default settings (probe, speculative boundaries, branch-free
+    kernel): statistics against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([2, 3, 4, 5, 7, 8]))
+    K = int(rng.integers(1, 9))
+    lengths = rng.integers(1, 2500, K)
+    if seed % 4 == 0:
+        lengths[0] = 1                                  # T = 1 trajectory
+    A = rng.random((n, n)) + np.eye(n) * rng.uniform(0, 6)
+    if seed % 3 == 0:
+        A[rng.integers(0, n), rng.integers(0, n)] = 0.0  # a structural zero
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    chunk = int(rng.choice([0, 0, 3, 10, 37, 128, 1000]))
+    kind = ["gaussian", "discrete", "explicit"][seed % 3]
+    eng = _engine()
+    if kind == "gaussian":
+        mu, sig = np.sort(rng.normal(0, 3, n)), rng.uniform(0.3, 2.0, n)
+        obs = [rng.normal(0, 4, T) for T in lengths]
+        ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+        eng.set_observations("gaussian", obs, n, chunk=chunk)
+        res = eng.estep(A, pi, mu, sig)
+    else:
+        M = int(rng.integers(2, 12))
+        B = rng.dirichlet(np.ones(M), size=n)
+        sym = [rng.integers(0, M, T).astype(np.int32) for T in lengths]
+        ref = orc.estep("discrete", sym, A, pi, B)
+        if kind == "discrete":
+            eng.set_observations("discrete", sym, n, nsymbols=M, chunk=chunk)
+            res = eng.estep(A, pi, B)
+        else:
+            eng.set_observations("explicit", [np.ascontiguousarray(B[:, o].T) for o in sym], n,
+                                 chunk=chunk)
+            res = eng.estep(A, pi)
+    _cmp(res, ref, n)
+    # and the same numbers when called again (run-to-run identical)
+    again = eng.estep(*((A, pi, mu, sig) if kind == "gaussian" else
+                        ((A, pi, B) if kind == "discrete" else (A, pi))))
+    assert np.array_equal(res.packed, again.packed)
+    eng.close()
