@@ -325,3 +325,42 @@ def test_chunk_parallel_viterbi_is_bit_exact_or_falls_back(golden, chunk):
     assert eng.get_option("viterbi_close") > 0
     assert np.array_equal(p[0], orc.viterbi(Au, np.full((3000, n), 0.3), pi))
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_viterbi_and_sampling(seed):
+    """Random shapes / chunk lengths / kinds: batched Viterbi (chunk-parallel or serial, whichever
+    the library picks) and batched path sampling against the oracle, bit for bit."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.choice([2, 3, 5, 8]))
+    K = int(rng.integers(1, 7))
+    lengths = rng.integers(1, 3000, K)
+    A = rng.random((n, n)) + np.eye(n) * rng.uniform(0, 5)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    chunk = int(rng.choice([0, 7, 64, 300, 1000]))
+    eng = Engine(0)
+    if seed % 2 == 0:
+        mu, sig = np.sort(rng.normal(0, 3, n)), rng.uniform(0.4, 1.5, n)
+        obs = [rng.normal(0, 3, T) for T in lengths]
+        pobs = [orc.pobs_gaussian(o, mu, sig) for o in obs]
+        eng.set_observations("gaussian", obs, n, chunk=chunk)
+        args = (A, pi, mu, sig)
+    else:
+        M = int(rng.integers(2, 9))
+        B = rng.dirichlet(np.ones(M), size=n)
+        obs = [rng.integers(0, M, T).astype(np.int32) for T in lengths]
+        pobs = [orc.pobs_discrete(o, B) for o in obs]
+        eng.set_observations("discrete", obs, n, nsymbols=M, chunk=chunk)
+        args = (A, pi, B)
+    paths = eng.viterbi(*args)
+    for p, pb in zip(paths, pobs):
+        assert np.array_equal(p, orc.viterbi(A, pb, pi))
+    u = [rng.random(T) for T in lengths]
+    sp, C, n0, _ = eng.sample_paths(*args, u=u)
+    ref = [orc.sample_path(orc.forward(A, pb, pi)[1], A, u=uu) for pb, uu in zip(pobs, u)]
+    assert sum(int((p != r).sum()) for p, r in zip(sp, ref)) == 0
+    Cr, n0r = orc.path_counts(ref, n)
+    assert np.array_equal(C, Cr) and np.array_equal(n0, n0r)
+    eng.close()
