@@ -761,17 +761,79 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
         };
         // steps s and s-1 from the stored row alpha_{s-2}: alpha_{s-1} = (alpha_{s-2} A) o p_{s-1}
         // up to a scale, which gamma and xi do not see
+        // second half of a backward step, from the gathered p o beta: beta_{s-1}, gamma_{s-1}, xi
+        auto bfinish = [&](const double (&bf)[N], const double2 &apv, auto sc) {
+            double r[2];
+            r[0] = Ar[0][0] * bf[0];
+            r[1] = Ar[1][0] * bf[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) {
+                r[0] = fma(Ar[0][j], bf[j], r[0]);
+                r[1] = fma(Ar[1][j], bf[j], r[1]);
+            }
+            const double q0 = apv.x * r[0], q1 = apv.y * r[1];
+            const double rS = fast_rcp(grp_sum<H>(q0 + q1));
+            gam[0] = q0 * rS;
+            gam[1] = q1 * rS;
+            const double w0 = apv.x * rS, w1 = apv.y * rS;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                Cacc[0][j] = fma(w0, bf[j], Cacc[0][j]);
+                Cacc[1][j] = fma(w1, bf[j], Cacc[1][j]);
+            }
+            if constexpr (decltype(sc)::value) {
+                const int hm = grp_max_i32<H>(max(__double2hiint(r[0]), __double2hiint(r[1])));
+                hmin = min(hmin, hm);
+                const int ne = 1022 - (hm >> 20);
+                b2[0] = ldexp(r[0], ne);
+                b2[1] = ldexp(r[1], ne);
+            } else {
+                b2[0] = r[0];
+                b2[1] = r[1];
+            }
+        };
+        // steps s and s-1 from the stored row alpha_{s-2}: alpha_{s-1} = (alpha_{s-2} A) o p_{s-1}
+        // up to a scale, which gamma and xi do not see.  Branch-free variant: the three LDS
+        // exchanges of the pair are issued as early as their inputs allow and the two exp
+        // evaluations sit in their shadows.
         auto bpair = [&](const ObsIn &hi, const ObsIn &lo, const double2 &alo, double2 *gdst,
                          auto sc_hi, auto sc_lo) {
             double p_hi[2], d_hi[2], p_lo[2], d_lo[2], sv[2], ah[2];
-            emit_raw<N, KIND>(hi, Bt, q, em, p_hi, d_hi);
-            emit_raw<N, KIND>(lo, Bt, q, em, p_lo, d_lo);
             const double al[2] = {alo.x, alo.y};
-            fwd_matvec<N>(gather, al, Ac, sv);
-            int unused = 0x7fffffff;
-            (void)scaled_emit<N, KIND, CAREFUL, false>(lo, q, nreal, gmask, sv, p_lo, ah, unused);
-            bcore(hi, p_hi, d_hi, make_double2(ah[0], ah[1]), gdst, sc_hi);
-            bcore(lo, p_lo, d_lo, alo, gdst - RS, sc_lo);
+            if constexpr (CAREFUL && KIND == EMIT_GAUSS) {
+                emit_raw<N, KIND>(hi, Bt, q, em, p_hi, d_hi);
+                emit_raw<N, KIND>(lo, Bt, q, em, p_lo, d_lo);
+                fwd_matvec<N>(gather, al, Ac, sv);
+                int unused = 0x7fffffff;
+                (void)scaled_emit<N, KIND, CAREFUL, false>(lo, q, nreal, gmask, sv, p_lo, ah,
+                                                           unused);
+                bcore(hi, p_hi, d_hi, make_double2(ah[0], ah[1]), gdst, sc_hi);
+                bcore(lo, p_lo, d_lo, alo, gdst - RS, sc_lo);
+            } else {
+                double afl[N], bf[N];
+                gather(al, afl); // (1) alpha_{s-2}, for the rebuild
+                sched_fence();
+                emit_raw<N, KIND>(hi, Bt, q, em, p_hi, d_hi);
+                sched_fence();
+                fwd_dot<N>(afl, Ac, sv);
+                consume(hi, d_hi, gdst);
+                {
+                    const double bb[2] = {p_hi[0] * b2[0], p_hi[1] * b2[1]};
+                    gather(bb, bf); // (2) p o beta of step s
+                }
+                sched_fence();
+                emit_raw<N, KIND>(lo, Bt, q, em, p_lo, d_lo);
+                sched_fence();
+                ah[0] = sv[0] * p_lo[0];
+                ah[1] = sv[1] * p_lo[1];
+                bfinish(bf, make_double2(ah[0], ah[1]), sc_hi);
+                consume(lo, d_lo, gdst - RS);
+                {
+                    const double bb[2] = {p_lo[0] * b2[0], p_lo[1] * b2[1]};
+                    gather(bb, bf); // (3) p o beta of step s-1
+                }
+                bfinish(bf, alo, sc_lo);
+            }
         };
         // the observation of step 0 is needed last: fetch it now
         const ObsIn in0 = ObsCursor<N, KIND>(obs_ci, rec0, cl, q).at(0);
