@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(64) void k_forget_probe(const Model<N> m, const voi
         dev = fmin(dev, 1.0);
         if (act)
             atomicMax(&curve[dir * Wmax + w], __float_as_uint((float)dev));
-        if (__all(dev < 1e-15)) // the wavefront's chains have all merged to rounding noise
+        if (__all(dev < 1e-14)) // all chains of the wavefront have merged (target: 1e-13)
             break;
     }
 }
