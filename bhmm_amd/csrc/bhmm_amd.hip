@@ -64,6 +64,10 @@ static int disc_copies(int M)
 
 static int stats_size(const bhmm_ctx *c);
 
+#ifndef ESTEP_SPLIT
+#define ESTEP_SPLIT 1 // statistics-only speculative E-step in two launches (PH_P1, PH_P2)
+#endif
+
 // componentwise relative tolerance of the boundary check (k_spec_check / k_tail)
 constexpr double SPEC_TOL = 1e-11;
 
@@ -151,10 +155,34 @@ struct Runner {
                 for (int i = 0; i < c->n; ++i)
                     fast = fast && m.e2[i] < 1048576.0;
             int rc;
-            if (fast)
-                rc = launch(k_estep<N, KIND, SPEC, false, false>);
-            else
+            if (fast) {
+                if constexpr (SPEC && ESTEP_SPLIT) {
+                    // two launches: forward sweeps + backward warm-ups side by side (four
+                    // wavefronts per SIMD), then the backward sweeps
+                    auto launch2 = [&](auto kern, int grid) -> int {
+                        if (sm > 64 * 1024)
+                            BHMM_HIP(hipFuncSetAttribute((const void *)kern,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)sm));
+                        hipLaunchKernelGGL(kern, dim3(grid), dim3(32 * N), sm, c->stream, m, ch,
+                                           (const void *)c->d_obs_ci.p, (const void *)c->d_obs_rm.p,
+                                           (const int64_t *)c->d_offsets.p,
+                                           (const double *)c->d_Bt.p, c->d_aentry.p, c->d_bexit.p,
+                                           c->d_aexit.p, c->d_bentry.p, c->spec_W, c->d_ws.p,
+                                           (double *)nullptr, c->d_logLc.p, c->d_gamma0.p,
+                                           c->d_partials.p, c->d_dpartials.p, flag_words);
+                        return BHMM_OK;
+                    };
+                    if ((rc = launch2(k_estep_light<N, KIND, SPEC, false, false, PH_P1>, 2 * nblk)))
+                        return rc;
+                    BHMM_HIP(hipGetLastError());
+                    rc = launch2(k_estep<N, KIND, SPEC, false, false, PH_P2>, nblk);
+                } else {
+                    rc = launch(k_estep<N, KIND, SPEC, false, false>);
+                }
+            } else {
                 rc = launch(k_estep<N, KIND, SPEC, true, true>);
+            }
             if (rc)
                 return rc;
         } else {
@@ -531,7 +559,7 @@ struct Runner {
     {
         const Chunks ch = chunks_of(c);
         const size_t sm = smem_fwdbwd<N, KIND>(c->M, KIND == EMIT_DISC ? m.dcopies : 1);
-        auto kern = k_estep<N, KIND, true, false, CAREFUL, true>;
+        auto kern = k_estep_light<N, KIND, true, false, CAREFUL, PH_FWDROWS>;
         if (sm > 64 * 1024)
             BHMM_HIP(hipFuncSetAttribute((const void *)kern,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));

@@ -370,8 +370,14 @@ __device__ __forceinline__ void beta_step(const Gather<N> &gather, const ObsIn &
 //   linearly.  Otherwise the host re-runs the E-step with the prescan / stitch kernels, which
 //   are exact unconditionally.
 //   GAMMA: the instantiation that can store the gamma rows (gamma_ci may still be null).
-//   FWDONLY: forward sweep only, every alpha row stored (any power-of-two scale): the Gibbs
-//   hidden-path step samples from alpha and is indifferent to its scale (_hidden.c:330-378).
+//   PHASE: PH_ALL -- everything in one launch.  PH_FWDROWS -- forward sweep only, every alpha
+//   row stored (any power-of-two scale): the Gibbs hidden-path step samples from alpha and is
+//   indifferent to its scale (_hidden.c:330-378).  PH_P1 / PH_P2 -- the E-step in two launches:
+//   P1 has twice the workgroups, the first half run the forward sweep of their record group, the
+//   second half only the backward warm-up (beta at the chunk's last step); neither needs the xi
+//   accumulators, so four wavefronts fit a SIMD where PH_ALL has two, and the two halves hide
+//   each other's latencies.  P2 is the backward sweep, started from the vectors P1 left in
+//   a_exit / alpha_entry / beta_exit.
 // Workgroup = one CI record group (64 chunks) = 32*N threads.
 // =========================================================================================
 #ifndef ESTEP_PF_F
@@ -386,8 +392,10 @@ __device__ __forceinline__ void beta_step(const Gather<N> &gather, const ObsIn &
 #ifndef ESTEP_WAVES
 #define ESTEP_WAVES 2
 #endif
-template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, bool FWDONLY = false>
-__global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WAVES, ESTEP_WAVES))) void k_estep(
+enum { PH_ALL = 0, PH_FWDROWS = 1, PH_P1 = 2, PH_P2 = 3 };
+
+template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE>
+__device__ __forceinline__ void estep_body(
     const Model<N> m, const Chunks ch, const void *obs_ci, const void *obs_rm,
     const int64_t *toff,   // [K+1] trajectory offsets (time steps)
     const double *Bt_g, double *alpha_entry, double *beta_exit,
@@ -405,6 +413,13 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
     using SL = StatLayout<N, KIND>;
     constexpr int H = N / 2;
     constexpr int NW = (64 * H + 63) / 64; // wavefronts per workgroup
+    constexpr bool FWDONLY = PHASE == PH_FWDROWS;
+    constexpr bool HAS_BWD = PHASE == PH_ALL || PHASE == PH_P2;
+    static_assert(SPEC || PHASE == PH_ALL, "the split phases are speculative-only");
+    // PH_P1: workgroup b and b + gridDim/2 share record group b (forward / backward warm-up)
+    const int bidx = PHASE == PH_P1 ? (int)(blockIdx.x % (gridDim.x / 2)) : (int)blockIdx.x;
+    const bool role_f = PHASE != PH_P1 || blockIdx.x < gridDim.x / 2;
+    const bool role_b = PHASE != PH_P1 || blockIdx.x >= gridDim.x / 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *red = smem;                                     // [NW][S]
     double *Bt = smem + NW * SL::S;                         // [M][N]
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
     }
     const int cl = threadIdx.x / H; // chunk within the record group == CI lane
     const int q = threadIdx.x % H;  // my state pair
-    const int64_t g = (int64_t)blockIdx.x * 64 + cl;
+    const int64_t g = (int64_t)bidx * 64 + cl;
     const int len = ch.len[g];
     const int64_t t0 = ch.t0[g];
     const int64_t goff = ch.goff[g];
@@ -469,7 +484,13 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             Ac[i][1] = m.A[i * N + 2 * q + 1];
         }
         // ---------------- forward sweep (_hidden.c:16-66) ------------------------------
-        {
+        if constexpr (PHASE == PH_P2) {
+            // the forward sweep ran in PH_P1: its last vector and the entry vector
+            const double2 x = *reinterpret_cast<const double2 *>(a_exit + g * N + 2 * q);
+            a[0] = x.x;
+            a[1] = x.y;
+            aent = *reinterpret_cast<const double2 *>(alpha_entry + g * N + 2 * q);
+        } else if (role_f) {
             int eP = 0;       // sum of the exponents removed
             double Sin = 1.0; // sum of the entry vector
             int s = 0;
@@ -642,6 +663,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
         }
 
         if constexpr (!FWDONLY) {
+        if (role_b) {
         // ---------------- backward sweep (_hidden.c:69-110, hidden/api.py:176-186) ----------
         double Ar[2][N];
 #pragma unroll
@@ -651,7 +673,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
         }
         const int k = ch.traj[g];
         double b2[2], gam[2];
-        if constexpr (SPEC) {
+        if constexpr (SPEC && PHASE != PH_P2) {
             // beta at my last step: constant at the end of the trajectory (_hidden.c:79-88),
             // otherwise warmed up backwards over the nw steps after the chunk -- which is the
             // same start vector where the warm-up reaches the end of the trajectory
@@ -705,6 +727,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             b2[0] = x.x;
             b2[1] = x.y;
         }
+        if constexpr (HAS_BWD) {
         {
 #ifdef ESTEP_CLOCKPROBE
             pr3 = wall_clock64();
@@ -929,6 +952,8 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             if constexpr (SPEC) // beta one step before this chunk: what the previous chunk assumed
                 *reinterpret_cast<double2 *>(b_entry + g * N + 2 * q) = make_double2(b2[0], b2[1]);
         }
+        } // HAS_BWD
+        } // role_b
         } // !FWDONLY
     }
 
@@ -952,7 +977,7 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
     // ---------------- workgroup reduction of the register statistics ----------------------
     // entry e of the statistics vector is owned by lane q = (state of e) / 2; sum over the
     // chunks of the wavefront (lanes with equal q), then over wavefronts through LDS
-    if constexpr (!FWDONLY) {
+    if constexpr (HAS_BWD) {
         const int lane = threadIdx.x & 63;
         const int wv = threadIdx.x >> 6;
         double *mine = red + wv * SL::S;
@@ -1000,5 +1025,34 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(ESTEP_WA
             }
     }
 }
+
+#define ESTEP_ARGS                                                                               \
+    const Model<N> m, const Chunks ch, const void *obs_ci, const void *obs_rm, const int64_t *toff, \
+        const double *Bt_g, double *alpha_entry, double *beta_exit, double *a_exit,              \
+        double *b_entry, int W, double *ws, double *gamma_ci, double *logL_chunk, double *gamma0, \
+        double *partials, double *disc_partials, unsigned int *flags
+#define ESTEP_PASS                                                                               \
+    m, ch, obs_ci, obs_rm, toff, Bt_g, alpha_entry, beta_exit, a_exit, b_entry, W, ws, gamma_ci,   \
+        logL_chunk, gamma0, partials, disc_partials, flags
+
+// the sweeps that carry the xi accumulators: two wavefronts per SIMD, up to 256 VGPRs
+template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE = PH_ALL>
+__global__ __launch_bounds__(32 * N)
+    __attribute__((amdgpu_waves_per_eu(ESTEP_WAVES, ESTEP_WAVES))) void k_estep(ESTEP_ARGS)
+{
+    static_assert(PHASE == PH_ALL || PHASE == PH_P2, "use k_estep_light");
+    estep_body<N, KIND, SPEC, GAMMA, CAREFUL, PHASE>(ESTEP_PASS);
+}
+
+// forward sweeps / warm-ups only (PH_P1, PH_FWDROWS): four wavefronts per SIMD
+template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE>
+__global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(4))) void k_estep_light(
+    ESTEP_ARGS)
+{
+    static_assert(PHASE == PH_P1 || PHASE == PH_FWDROWS, "use k_estep");
+    estep_body<N, KIND, SPEC, GAMMA, CAREFUL, PHASE>(ESTEP_PASS);
+}
+#undef ESTEP_ARGS
+#undef ESTEP_PASS
 
 } // namespace bhmm
