@@ -14,8 +14,10 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
 import csv,sys,collections
 d=collections.defaultdict(list)
 for r in csv.DictReader(open('$f')):
-    if 'k_estep' in r['Kernel_Name']: d[r['Counter_Name']].append(float(r['Counter_Value']))
-for k,v in d.items(): print(k, len(v), sum(v)/len(v))
+    kn = r['Kernel_Name']
+    tag = 'P1' if 'k_estep_light' in kn else ('P2' if 'k_estep' in kn else None)
+    if tag: d[(tag, r['Counter_Name'])].append(float(r['Counter_Value']))
+for (t,k),v in sorted(d.items()): print(t, k, len(v), sum(v)/len(v))
 " > $R/gpurun_out/pmc_set$i.txt; else tail -5 /tmp/pmc$i.log > $R/gpurun_out/pmc_set$i.err; fi
 done
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ[C]*_[A-Z_0-9]*" | sort -u > $R/gpurun_out/sq_counters.txt

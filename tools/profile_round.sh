@@ -18,7 +18,8 @@ import csv, sys, collections
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     k = r['Kernel_Name']
-    name = 'k_estep' if 'k_estep' in k else ('copy' if 'opy' in k else None)
+    name = ('k_estep_light(P1)' if 'k_estep_light' in k else 'k_estep(P2/ALL)' if 'k_estep' in k
+            else ('copy' if 'opy' in k else None))
     if name and r['Counter_Name'] == sys.argv[2]:
         d[name].append(float(r['Counter_Value']))
 for k, v in d.items():
