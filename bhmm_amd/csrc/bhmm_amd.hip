@@ -658,11 +658,11 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
     const int K = c->K;
     int L = chunk;
     if (L <= 0) {
-        // k_estep uses N/2 lanes per chunk: 32768 chunks put two 64-lane wavefronts on every
+        // k_estep uses N/2 lanes per chunk: 32768 chunks (N = 8) put two 64-lane wavefronts on every
         // SIMD of the 256 CUs.  Fewer, longer chunks amortise the warm-up of the speculative
         // boundaries (W / L extra steps); more chunks only help occupancy (measured optimum on
         // configs[1]: profiles/r01).
-        const int64_t target = 32768;
+        const int64_t target = 32768 * 4 / std::max(1, c->N / 2); // N/2 lanes per chunk
         int64_t l = (c->total + target - 1) / target;
         L = (int)std::min<int64_t>(std::max<int64_t>(l, 32), (int64_t)1 << 20);
     }
