@@ -143,7 +143,8 @@ struct Runner {
                                    c->d_aentry.p, c->d_bexit.p, c->d_aexit.p, c->d_bentry.p,
                                    c->spec_W, c->d_ws.p,
                                    store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
-                                   c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p, flag_words);
+                                   c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p, flag_words,
+                                   c->d_ea.p);
                 return BHMM_OK;
             };
             // the branch-free instantiation needs the verdict round trip of the speculative
@@ -170,7 +171,7 @@ struct Runner {
                                            (const double *)c->d_Bt.p, c->d_aentry.p, c->d_bexit.p,
                                            c->d_aexit.p, c->d_bentry.p, c->spec_W, c->d_ws.p,
                                            (double *)nullptr, c->d_logLc.p, c->d_gamma0.p,
-                                           c->d_partials.p, c->d_dpartials.p, flag_words);
+                                           c->d_partials.p, c->d_dpartials.p, flag_words, c->d_ea.p);
                         return BHMM_OK;
                     };
                     if ((rc = launch2(k_estep_light<N, KIND, SPEC, false, false, PH_P1>, 2 * nblk)))
@@ -568,7 +569,7 @@ struct Runner {
                            (const int64_t *)c->d_offsets.p, (const double *)c->d_Bt.p, c->d_aentry.p,
                            c->d_bexit.p, c->d_aexit.p, c->d_bentry.p, c->spec_W, c->d_ws.p,
                            (double *)nullptr, c->d_logLc.p, c->d_gamma0.p, c->d_partials.p,
-                           c->d_dpartials.p, c->d_specres.p);
+                           c->d_dpartials.p, c->d_specres.p, c->d_ea.p);
         BHMM_HIP(hipGetLastError());
         return BHMM_OK;
     }
@@ -791,6 +792,7 @@ static int alloc_work(bhmm_ctx *c)
     if ((rc = c->d_M.ensure((size_t)c->Gp * (N * N + N))) ||
         (rc = c->d_aentry.ensure((size_t)c->Gp * N)) || (rc = c->d_bexit.ensure((size_t)c->Gp * N)) ||
         (rc = c->d_ws.ensure((size_t)ci_records(c) * N * 64)) ||
+        (rc = c->d_ea.ensure((size_t)c->Gp + (size_t)ci_records(c) * 64)) ||
         (rc = c->d_logLc.ensure(c->Gp)) || (rc = c->d_logLk.ensure(std::max(c->K, 1))) ||
         (rc = c->d_gamma0.ensure((size_t)std::max(c->K, 1) * N)) ||
         (rc = c->d_partials.ensure((size_t)(c->Gp / 64) * S)) ||
@@ -984,6 +986,7 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     if (c->h_raw)
         (void)hipHostFree(c->h_raw);
     c->d_tail.release();
+    c->d_ea.release();
     c->d_probe.release();
     for (auto &ev : c->ev)
         if (ev)

@@ -97,6 +97,7 @@ struct bhmm_ctx {
     float spec_last_dev = 0.f;
     bhmm::DevBuf<double> d_aexit, d_bentry;
     bhmm::DevBuf<unsigned int> d_specres;
+    bhmm::DevBuf<int32_t> d_ea;       // exponents of the stored alpha rows (k_estep PH_P1 -> PH_P2)
     bhmm::DevBuf<double> d_tail;      // same layout as h_raw, written by k_tail (one D2H copy)
     int tail_slot = 0;                // verdict word set of the next E-step
     unsigned int viterbi_close = 0;   // ... number of lanes that met a close decision

@@ -408,7 +408,9 @@ __device__ __forceinline__ void estep_body(
     double *gamma0,        // [K][N] gamma at t = 0 of every trajectory
     double *partials,      // [gridDim.x][S] register statistics per workgroup
     double *disc_partials, // [gridDim.x][M*N] discrete emission statistics per workgroup
-    unsigned int *flags)   // !CAREFUL: flags[2] counts chunks that met a zero / denormal vector
+    unsigned int *flags,   // !CAREFUL: flags[2] counts chunks that met a zero / denormal vector
+    int32_t *ea_ci)        // PH_P1 -> PH_P2: [Gp] exponent of each chunk's last alpha row, then CI
+                           // [record][64] cumulative exponents of the stored alpha rows
 {
     using SL = StatLayout<N, KIND>;
     constexpr int H = N / 2;
@@ -453,6 +455,9 @@ __device__ __forceinline__ void estep_body(
     const int nreal = m.nreal;
     const unsigned long long gmask = ((1ull << H) - 1) << ((threadIdx.x & 63) / H * H);
     const int64_t rec0 = ci_rec(g, 0, ch.Lmax);
+    // exponent rows behind the [Gp] per-chunk entries (Gp = chunks of the launch)
+    int32_t *const ea_rows =
+        ea_ci + (int64_t)(PHASE == PH_P1 ? gridDim.x / 2 : gridDim.x) * 64;
 
     EmisPair em;
     double pi2[2];
@@ -503,6 +508,8 @@ __device__ __forceinline__ void estep_body(
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
                 eP = scaled_emit<N, KIND, CAREFUL, true>(in, q, nreal, gmask, pi2, p, a, hmin);
                 *ci_pair(ws, rec0, N, q, cl) = make_double2(a[0], a[1]);
+                if constexpr (PHASE == PH_P1)
+                    ea_rows[rec0 * 64 + cl] = eP;
                 s = 1;
             } else {
                 if constexpr (SPEC) {
@@ -592,15 +599,22 @@ __device__ __forceinline__ void estep_body(
                                                                         a, hmin);
                 out = make_double2(a[0], a[1]);
             };
+            // PH_P1: with every stored row goes the exponent removed so far (eP), one int per chunk;
+            // PH_P2 forms the gamma / xi normalisers from it without a reciprocal
+            int32_t *pe = nullptr;
             auto single = [&](ObsCursor<N, KIND> &po, double2 *&pw) {
                 double2 o;
                 fstep(po.at(0), o, std::true_type());
                 *pw = o;
+                if constexpr (PHASE == PH_P1)
+                    *pe = eP;
                 po.move(1);
                 pw += RS;
+                pe += 64;
             };
             ObsCursor<N, KIND> po(obs_ci, rec0 + s, cl, q);
             double2 *pw = ci_pair(ws, rec0 + s, N, q, cl);
+            pe = ea_rows + (rec0 + s) * 64 + cl;
             constexpr int PF = ESTEP_PF_F;
             constexpr bool CKPT = ESTEP_CKPT && !FWDONLY; // a forward-only pass keeps every row
             static_assert(PF % 2 == 0, "row parity inside the unrolled groups");
@@ -624,8 +638,11 @@ __device__ __forceinline__ void estep_body(
                         y[j] = po.at(PF + j);
                     unrolled<PF>([&](auto j) {
                         fstep(x[j], ox[j], sc_at<j>());
-                        if constexpr (!CKPT || j % 2 == 0)
+                        if constexpr (!CKPT || j % 2 == 0) {
                             pw[j * RS] = ox[j];
+                            if constexpr (PHASE == PH_P1)
+                                pe[j * 64] = eP;
+                        }
                     });
                     if (rem > 2 * PF) {
 #pragma unroll
@@ -634,8 +651,11 @@ __device__ __forceinline__ void estep_body(
                     }
                     unrolled<PF>([&](auto j) {
                         fstep(y[j], oy[j], sc_at<PF + j>());
-                        if constexpr (!CKPT || j % 2 == 0)
+                        if constexpr (!CKPT || j % 2 == 0) {
                             pw[(PF + j) * RS] = oy[j];
+                            if constexpr (PHASE == PH_P1)
+                                pe[(PF + j) * 64] = eP;
+                        }
                     });
                     if constexpr (CKPT) {
                         // the backward sweep reads the last (len-1) % 4 + 1 rows directly: if the
@@ -650,6 +670,7 @@ __device__ __forceinline__ void estep_body(
                     }
                     po.move(2 * PF);
                     pw += 2 * PF * RS;
+                    pe += 2 * PF * 64;
                 }
             }
             for (int i = tail; i > 0; --i)
@@ -662,6 +683,8 @@ __device__ __forceinline__ void estep_body(
                 logL_chunk[g] = log(Sfin / Sin) + (double)eP * 0.693147180559945309417232121458;
             if constexpr (SPEC)
                 *reinterpret_cast<double2 *>(a_exit + g * N + 2 * q) = make_double2(a[0], a[1]);
+            if constexpr (PHASE == PH_P1)
+                ea_ci[g] = eP;
         }
 
         if constexpr (!FWDONLY) {
@@ -1032,10 +1055,10 @@ __device__ __forceinline__ void estep_body(
     const Model<N> m, const Chunks ch, const void *obs_ci, const void *obs_rm, const int64_t *toff, \
         const double *Bt_g, double *alpha_entry, double *beta_exit, double *a_exit,              \
         double *b_entry, int W, double *ws, double *gamma_ci, double *logL_chunk, double *gamma0, \
-        double *partials, double *disc_partials, unsigned int *flags
+        double *partials, double *disc_partials, unsigned int *flags, int32_t *ea_ci
 #define ESTEP_PASS                                                                               \
     m, ch, obs_ci, obs_rm, toff, Bt_g, alpha_entry, beta_exit, a_exit, b_entry, W, ws, gamma_ci,   \
-        logL_chunk, gamma0, partials, disc_partials, flags
+        logL_chunk, gamma0, partials, disc_partials, flags, ea_ci
 
 // the sweeps that carry the xi accumulators: two wavefronts per SIMD, up to 256 VGPRs
 template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE = PH_ALL>
