@@ -326,7 +326,7 @@ __device__ __forceinline__ void beta_step(const G &gather, const ObsIn &in, int 
                                           int nreal, unsigned long long gmask,
                                           const double (&Ar)[2][N], double (&p)[2],
                                           const double (&b)[2], double (&bf)[N], double (&r)[2],
-                                          double (&bnew)[2], int &hmin)
+                                          double (&bnew)[2], int &hmin, int &eacc)
 {
     constexpr int H = N / 2;
     int hm;
@@ -354,6 +354,7 @@ __device__ __forceinline__ void beta_step(const G &gather, const ObsIn &in, int 
     const int ne = 1022 - (hm >> 20); // see scaled_emit
     bnew[0] = ldexp(r[0], ne);
     bnew[1] = ldexp(r[1], ne);
+    eacc -= ne; // exponent removed so far
 }
 
 // =========================================================================================
@@ -710,8 +711,9 @@ __device__ __forceinline__ void estep_body(
             auto wstep = [&](const ObsIn &in, auto sc) {
                 double p[2], d[2], bf[N], r[2], bn[2];
                 emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                int unused = 0;
                 beta_step<N, KIND, CAREFUL, decltype(sc)::value>(gather, in, q, nreal, gmask, Ar, p,
-                                                                 b2, bf, r, bn, hmin);
+                                                                 b2, bf, r, bn, hmin, unused);
                 b2[0] = bn[0];
                 b2[1] = bn[1];
             };
@@ -753,15 +755,25 @@ __device__ __forceinline__ void estep_body(
             b2[1] = x.y;
         }
         if constexpr (HAS_BWD) {
+        // Normaliser of gamma and xi.  S = sum_i alpha[i] (A (p o beta))[i] is the same bilinear form
+        // at every step of the chunk, only the powers of two removed from alpha (ea, recorded by
+        // PH_P1) and from beta (Eb) differ: PH_P2 takes one reciprocal per chunk (rS0, at the
+        // last step, where alpha carries the exponent ebase) and scales it, 1/S = rS0 2^(ea + Eb -
+        // ebase), instead of a sum over the group and a reciprocal per step.  The single steps and
+        // the other instantiations sum and divide as before.
+        constexpr bool EXPO = PHASE == PH_P2 && !CAREFUL;
+        double rS0 = 0.0;
+        int Eb = 0;
+        const int ebase = EXPO ? ea_ci[g] : 0;
         {
 #ifdef ESTEP_CLOCKPROBE
             pr3 = wall_clock64();
 #endif
             gam[0] = a[0] * b2[0];
             gam[1] = a[1] * b2[1];
-            const double rS = fast_rcp(grp_sum<H>(gam[0] + gam[1]));
-            gam[0] *= rS;
-            gam[1] *= rS;
+            rS0 = fast_rcp(grp_sum<H>(gam[0] + gam[1]));
+            gam[0] *= rS0;
+            gam[1] *= rS0;
         }
         // consume gamma_s: state counts, emission statistics, optional gamma row
         constexpr int RS = (N / 2) * 64; // double2 elements per CI record of N doubles
@@ -788,7 +800,7 @@ __device__ __forceinline__ void estep_body(
             double bf[N], r[2], bn[2];
             consume(in, d, gdst);
             beta_step<N, KIND, CAREFUL, decltype(sc)::value>(gather, in, q, nreal, gmask, Ar, p, b2,
-                                                             bf, r, bn, hmin);
+                                                             bf, r, bn, hmin, Eb);
             const double q0 = apv.x * r[0], q1 = apv.y * r[1];
             const double rS = fast_rcp(grp_sum<H>(q0 + q1));
             gam[0] = q0 * rS;
@@ -810,7 +822,7 @@ __device__ __forceinline__ void estep_body(
         // steps s and s-1 from the stored row alpha_{s-2}: alpha_{s-1} = (alpha_{s-2} A) o p_{s-1}
         // up to a scale, which gamma and xi do not see
         // second half of a backward step, from the gathered p o beta: beta_{s-1}, gamma_{s-1}, xi
-        auto bfinish = [&](const double (&bf)[N], const double2 &apv, auto sc) {
+        auto bfinish = [&](const double (&bf)[N], const double2 &apv, int ea, auto sc) {
             double r[2];
             r[0] = Ar[0][0] * bf[0];
             r[1] = Ar[1][0] * bf[0];
@@ -820,7 +832,11 @@ __device__ __forceinline__ void estep_body(
                 r[1] = fma(Ar[1][j], bf[j], r[1]);
             }
             const double q0 = apv.x * r[0], q1 = apv.y * r[1];
-            const double rS = fast_rcp(grp_sum<H>(q0 + q1));
+            double rS;
+            if constexpr (EXPO)
+                rS = ldexp(rS0, ea + Eb - ebase);
+            else
+                rS = fast_rcp(grp_sum<H>(q0 + q1));
             gam[0] = q0 * rS;
             gam[1] = q1 * rS;
             const double w0 = apv.x * rS, w1 = apv.y * rS;
@@ -835,6 +851,7 @@ __device__ __forceinline__ void estep_body(
                 const int ne = 1022 - (hm >> 20);
                 b2[0] = ldexp(r[0], ne);
                 b2[1] = ldexp(r[1], ne);
+                Eb -= ne;
             } else {
                 b2[0] = r[0];
                 b2[1] = r[1];
@@ -844,8 +861,8 @@ __device__ __forceinline__ void estep_body(
         // up to a scale, which gamma and xi do not see.  Branch-free variant: the three LDS
         // exchanges of the pair are issued as early as their inputs allow and the two exp
         // evaluations sit in their shadows.
-        auto bpair = [&](const ObsIn &hi, const ObsIn &lo, const double2 &alo, double2 *gdst,
-                         auto sc_hi, auto sc_lo) {
+        auto bpair = [&](const ObsIn &hi, const ObsIn &lo, const double2 &alo, int ea,
+                         double2 *gdst, auto sc_hi, auto sc_lo) {
             double p_hi[2], d_hi[2], p_lo[2], d_lo[2], sv[2], ah[2];
             const double al[2] = {alo.x, alo.y};
             if constexpr (CAREFUL && KIND == EMIT_GAUSS) {
@@ -874,13 +891,13 @@ __device__ __forceinline__ void estep_body(
                 sched_fence();
                 ah[0] = sv[0] * p_lo[0];
                 ah[1] = sv[1] * p_lo[1];
-                bfinish(bf, make_double2(ah[0], ah[1]), sc_hi);
+                bfinish(bf, make_double2(ah[0], ah[1]), ea, sc_hi);
                 consume(lo, d_lo, gdst - RS);
                 {
                     const double bb[2] = {p_lo[0] * b2[0], p_lo[1] * b2[1]};
                     gather(bb, bf); // (3) p o beta of step s-1
                 }
-                bfinish(bf, alo, sc_lo);
+                bfinish(bf, alo, ea, sc_lo);
             }
         };
         // the observation of step 0 is needed last: fetch it now
@@ -903,22 +920,30 @@ __device__ __forceinline__ void estep_body(
                 }
                 rem -= rem % 4;
                 if (rem > 0) {
+                    // exponents of the stored rows: same record index as the rows themselves
+                    const int32_t *pea = ea_rows + (rec0 + rem) * 64 + cl;
                     ObsIn xh = po.at(0), xl = po.at(-1), yh, yl;
                     double2 xa = pa[-2 * RS], ya;
+                    int xe = EXPO ? pea[-2 * 64] : 0, ye = 0;
                     for (; rem > 0; rem -= 4) {
                         yh = po.at(-2);
                         yl = po.at(-3);
                         ya = pa[-4 * RS];
-                        bpair(xh, xl, xa, pg, sc_at<0>(), sc_at<1>());
+                        if constexpr (EXPO)
+                            ye = pea[-4 * 64];
+                        bpair(xh, xl, xa, xe, pg, sc_at<0>(), sc_at<1>());
                         if (rem > 4) {
                             xh = po.at(-4);
                             xl = po.at(-5);
                             xa = pa[-6 * RS];
+                            if constexpr (EXPO)
+                                xe = pea[-6 * 64];
                         }
-                        bpair(yh, yl, ya, pg - 2 * RS, sc_at<2>(), sc_at<3>());
+                        bpair(yh, yl, ya, ye, pg - 2 * RS, sc_at<2>(), sc_at<3>());
                         po.move(-4);
                         pa -= 4 * RS;
                         pg -= 4 * RS;
+                        pea -= 4 * 64;
                     }
                 }
             } else {
