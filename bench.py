@@ -235,7 +235,7 @@ def main():
         alg_bytes_launch = B_ALG_GAUSS * K * T
         achieved = alg_bytes_launch / (kern_ms[2] * 1e-3) / 1e9
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01", "r01p_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r01", "r01q_traffic.json")
         if os.path.exists(tj) and (K, T) == (256, 100000):
             # HBM bytes of the two sweep launches of one E-step from the PMC counters (collected offline with
             # rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)
@@ -259,7 +259,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_estep_light<8,gauss,spec,P1> + k_estep<8,gauss,spec,P2> (the sweep of one E-step)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, profiles/r01/r01p_traffic.json)",
+                         "traffic_unit": "bytes per launch (PMC, profiles/r01/r01q_traffic.json)",
                          "alg_bytes_per_launch": alg_bytes_launch,
                          "alg_bytes_per_timestep": B_ALG_GAUSS,
                          "whole_estep_frac": B_ALG_GAUSS * value / world / 1e9 / HBM_PEAK_GBS},
