@@ -36,9 +36,6 @@ enum { EMIT_GAUSS = 0, EMIT_DISC = 1, EMIT_EXPL = 2 };
 enum { MODE_ESTEP = 0, MODE_FWD = 1, MODE_BWD = 2 };
 
 constexpr int BLOCK = 256;
-#ifndef FB_MINW
-#define FB_MINW 1
-#endif
 
 // Model parameters, passed by value as kernel arguments (uniform -> scalar registers).
 // N is the padded state count (2, 4 or 8); states >= nreal are inert (pi = 0, p = 0).
