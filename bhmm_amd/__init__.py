@@ -9,12 +9,12 @@ Names follow the reference (bhmm/__init__.py:23-43); the two identifiers BASELIN
 """
 from .util import config  # noqa: F401
 from . import hidden  # noqa: F401
-from .hmm import HMM  # noqa: F401
+from .hmm import HMM, SampledHMM  # noqa: F401
 from .output_models import OutputModel, GaussianOutputModel, DiscreteOutputModel  # noqa: F401
 from .estimators.maximum_likelihood import MaximumLikelihoodEstimator  # noqa: F401
 from .estimators.bayesian_sampling import BayesianHMMSampler  # noqa: F401
 from .api import (estimate_hmm, bayesian_hmm, lag_observations, gaussian_hmm,  # noqa: F401
-                  discrete_hmm)
+                  discrete_hmm, init_hmm, init_gaussian_hmm, init_discrete_hmm)
 
 MLHMM = MaximumLikelihoodEstimator          # bhmm/__init__.py:36
 BHMM = BayesianHMMSampler                   # bhmm/__init__.py:35

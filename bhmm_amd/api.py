@@ -4,7 +4,7 @@ import numpy as np
 
 from .estimators.bayesian_sampling import BayesianHMMSampler
 from .estimators.maximum_likelihood import MaximumLikelihoodEstimator
-from .hmm import HMM
+from .hmm import HMM, SampledHMM
 from .output_models import DiscreteOutputModel, GaussianOutputModel
 
 
@@ -40,6 +40,39 @@ def discrete_hmm(pi, P, pout):
     return HMM(pi, P, DiscreteOutputModel(pout))
 
 
+def init_gaussian_hmm(observations, nstates, lag=1, reversible=True):
+    """bhmm/api.py:202-228."""
+    from .init.gaussian import init_model_gaussian1d
+    if lag > 1:
+        observations = lag_observations(observations, lag)
+    hmm0 = init_model_gaussian1d(observations, nstates, reversible=reversible)
+    hmm0._lag = lag
+    return hmm0
+
+
+def init_discrete_hmm(observations, nstates, lag=1, reversible=True, stationary=True,
+                      regularize=True, method='connect-spectral', separate=None):
+    """bhmm/api.py:231-306."""
+    from .init import discrete as _init
+    p0, P, B = _init.init_discrete_hmm(observations, nstates, lag=lag, reversible=reversible,
+                                       stationary=stationary, regularize=regularize,
+                                       method=method, separate=separate)
+    hmm0 = discrete_hmm(p0, P, B)
+    hmm0._lag = lag
+    return hmm0
+
+
+def init_hmm(observations, nstates, lag=1, output=None, reversible=True):
+    """bhmm/api.py:161-199."""
+    if output is None:
+        output = _guess_output_type(observations)
+    if output == 'discrete':
+        return init_discrete_hmm(observations, nstates, lag=lag, reversible=reversible)
+    if output == 'gaussian':
+        return init_gaussian_hmm(observations, nstates, lag=lag, reversible=reversible)
+    raise NotImplementedError('output model type ' + str(output) + ' not yet implemented.')
+
+
 def estimate_hmm(observations, nstates, lag=1, initial_model=None, output=None, reversible=True,
                  stationary=False, p=None, accuracy=1e-3, maxit=1000, maxit_P=100000,
                  mincount_connectivity=1e-2, **engine_kwargs):
@@ -60,12 +93,13 @@ def estimate_hmm(observations, nstates, lag=1, initial_model=None, output=None, 
 def bayesian_hmm(observations, estimated_hmm, nsample=100, reversible=True, stationary=False,
                  p0_prior='mixed', transition_matrix_prior='mixed', store_hidden=False,
                  call_back=None, **engine_kwargs):
-    """bhmm/api.py:375-470.  Returns the list of sampled HMMs (the reference wraps them in a
-    SampledHMM statistics container, which is outside the accelerated path)."""
+    """bhmm/api.py:375-470.  Returns a SampledHMM (which also iterates over / indexes the
+    sampled models)."""
     sampler = BayesianHMMSampler(observations, estimated_hmm.nstates, initial_model=estimated_hmm,
                                  reversible=reversible, stationary=stationary,
                                  transition_matrix_sampling_steps=1000, p0_prior=p0_prior,
                                  transition_matrix_prior=transition_matrix_prior,
                                  output=estimated_hmm.output_model.model_type, **engine_kwargs)
-    return sampler.sample(nsamples=nsample, save_hidden_state_trajectory=store_hidden,
-                          call_back=call_back)
+    sampled = sampler.sample(nsamples=nsample, save_hidden_state_trajectory=store_hidden,
+                             call_back=call_back)
+    return SampledHMM(estimated_hmm, sampled)

@@ -38,6 +38,27 @@ def is_connected(C, mincount_connectivity=0, strong=True):
     return len(connected_sets(C, mincount_connectivity=mincount_connectivity, strong=strong)) == 1
 
 
+def closed_sets(C, mincount_connectivity=0):
+    """_tmatrix_disconnected.py:46-56: strongly connected sets without outgoing counts."""
+    C = np.asarray(C, dtype=np.float64)
+    n = C.shape[0]
+    closed = []
+    for s in connected_sets(C, mincount_connectivity=mincount_connectivity, strong=True):
+        mask = np.zeros(n, dtype=bool)
+        mask[s] = True
+        if C[np.ix_(mask, ~mask)].sum() == 0:
+            closed.append(s)
+    return closed
+
+
+def nonempty_set(C, mincount_connectivity=0):
+    """_tmatrix_disconnected.py:59-65."""
+    C = np.asarray(C, dtype=np.float64)
+    if mincount_connectivity > 0:
+        C = np.where(C < mincount_connectivity, 0.0, C)
+    return np.where(C.sum(axis=0) + C.sum(axis=1) > 0)[0]
+
+
 def stationary_vector(P):
     """Stationary distribution of an irreducible stochastic matrix (dense eigen-solve with a
     linear-system fallback)."""
@@ -178,6 +199,69 @@ def stationary_distribution(P, C=None, mincount_connectivity=0):
         w = C[s, :].sum() / ctot
         pi[s] = w * stationary_vector(P[s, :][:, s])
     return pi / pi.sum()
+
+
+def enforce_reversible_on_closed(P):
+    """_tmatrix_disconnected.py:193-209: symmetrise the stationary flux of every closed set."""
+    P = np.asarray(P, dtype=np.float64)
+    Prev = P.copy()
+    for s in closed_sets(P):
+        I = np.ix_(s, s)
+        X = stationary_vector(P[I])[:, None] * P[I]
+        X = 0.5 * (X + X.T)
+        Prev[I] = X / X.sum(axis=1)[:, None]
+    return Prev
+
+
+def _rdl_block(P, reversible):
+    """Right eigenvectors (columns), eigenvalues, left eigenvectors (rows) of an irreducible
+    block, sorted by decreasing modulus; L R = 1, L[0] = stationary vector, R[:, 0] = 1
+    (the 'reversible' / 'standard' normalisations of msmtools.analysis.rdl_decomposition)."""
+    if reversible:
+        pi = stationary_vector(P)
+        sq = np.sqrt(pi)
+        S = sq[:, None] * P / sq[None, :]
+        w, V = np.linalg.eigh(0.5 * (S + S.T))
+        order = np.argsort(-np.abs(w), kind='stable')
+        w, V = w[order], V[:, order]
+        R = V / sq[:, None]
+        L = (V * sq[:, None]).T
+        s0 = L[0].sum()
+        L[0] /= s0
+        R[:, 0] *= s0
+        for i in range(1, len(w)):       # fix the sign: largest component of R positive
+            if R[np.argmax(np.abs(R[:, i])), i] < 0:
+                R[:, i] *= -1.0
+                L[i] *= -1.0
+        return R, w, L
+    w, R = np.linalg.eig(P)
+    order = np.argsort(-np.abs(w), kind='stable')
+    w, R = w[order], R[:, order]
+    L = np.linalg.inv(R)
+    s0 = L[0].sum()
+    L[0] /= s0
+    R[:, 0] *= s0
+    return R, w, L
+
+
+def rdl_decomposition(P, reversible=True):
+    """_tmatrix_disconnected.py:254-289: block-wise over the strongly connected sets."""
+    P = np.asarray(P, dtype=np.float64)
+    n = P.shape[0]
+    dtype = np.float64 if reversible else complex
+    R = np.zeros((n, n), dtype=dtype)
+    D = np.zeros((n, n), dtype=dtype)
+    L = np.zeros((n, n), dtype=dtype)
+    for s in connected_sets(P, strong=True):
+        I = np.ix_(s, s)
+        if len(s) > 1:
+            r, d, l = _rdl_block(P[I] / P[I].sum(axis=1)[:, None], reversible)
+            R[I], D[I], L[I] = r, np.diag(d), l
+        else:
+            R[I] = 1
+            D[I] = 1
+            L[I] = 1
+    return R, D, L
 
 
 def is_reversible(P):

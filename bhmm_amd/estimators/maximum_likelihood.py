@@ -39,14 +39,11 @@ class MaximumLikelihoodEstimator(object):
         self._stationary = stationary
         if initial_model is None:
             # maximum_likelihood.py:112-118 -> bhmm.init_hmm.  Gaussian: mixture fit +
-            # fractional counts (bhmm_amd/init/gaussian.py); the discrete initialiser of the
-            # reference (lagged count matrix + PCCA+, init/discrete.py:167-338) is not part of
-            # this package.
-            if output != 'gaussian':
-                raise NotImplementedError('bhmm_amd needs an initial_model (HMM) for discrete '
-                                          'output; only the gaussian initialiser is provided')
-            from ..init import init_model_gaussian1d
-            initial_model = init_model_gaussian1d(observations, nstates, reversible=reversible)
+            # fractional counts (bhmm_amd/init/gaussian.py); discrete: count matrix + PCCA+
+            # (bhmm_amd/init/discrete.py).
+            from .. import api as _api
+            initial_model = _api.init_hmm(observations, nstates, output=output,
+                                          reversible=reversible)
         self._hmm = copy.deepcopy(initial_model)
         if self._hmm.nstates != nstates:
             raise ValueError('initial_model has %d states, nstates=%d' % (self._hmm.nstates, nstates))

@@ -1,10 +1,11 @@
-"""Plain model container: the fields of bhmm/hmm/generic_hmm.py:25-93 the hot path reads and
-writes (initial distribution, transition matrix, output model, hidden paths, likelihood).
-Spectral analysis, sub-models and synthetic data generation of the reference class are out
-of scope."""
+"""Model container: the fields of bhmm/hmm/generic_hmm.py:25-93 the hot path reads and writes
+(initial distribution, transition matrix, output model, hidden paths, likelihood), the
+spectral properties SampledHMM reports (:124-274) and sub-models (:276-296).  Synthetic data
+generation of the reference class is out of scope."""
 import numpy as np
 
 from .estimators import _tmatrix
+from .util.statistics import confidence_interval_arr
 
 
 class HMM(object):
@@ -14,6 +15,7 @@ class HMM(object):
         self.output_model = output_model
         self.hidden_state_trajectories = None
         self.likelihood = None
+        self._spectral = None
         self.update(Pi, Tij)
 
     def update(self, Pi, Tij):
@@ -27,6 +29,7 @@ class HMM(object):
         assert np.all(Pi >= 0), 'Given initial distribution contains negative elements.'
         assert np.any(Pi > 0), 'Given initial distribution is zero'
         self._Pi = np.array(Pi) / np.sum(Pi)
+        self._spectral = None
 
     def __repr__(self):
         return 'HMM(%r, %r, %r)' % (self._Pi, self._Tij, self.output_model)
@@ -73,6 +76,49 @@ class HMM(object):
         assert self.is_strongly_connected, 'No unique stationary distribution: not connected.'
         return _tmatrix.stationary_vector(self._Tij)
 
+    def _rdl(self):
+        if self._spectral is None:
+            R, D, L = _tmatrix.rdl_decomposition(self._Tij, reversible=self.is_reversible)
+            self._spectral = (R, np.diag(D), L)
+        return self._spectral
+
+    @property
+    def eigenvalues(self):
+        """generic_hmm.py:203-213: sorted by descending norm (within a connected set)."""
+        return self._rdl()[1]
+
+    @property
+    def eigenvectors_left(self):
+        """generic_hmm.py:215-226: row matrix."""
+        return self._rdl()[2]
+
+    @property
+    def eigenvectors_right(self):
+        """generic_hmm.py:228-239: column matrix."""
+        return self._rdl()[0]
+
+    @property
+    def timescales(self):
+        """generic_hmm.py:241-257: -lag / ln|lambda_i|, i >= 2 (infinite for |lambda| = 1)."""
+        lam = np.abs(self.eigenvalues[1:])
+        with np.errstate(divide='ignore'):
+            return np.where(lam >= 1.0, np.inf, -self._lag / np.log(lam))
+
+    @property
+    def lifetimes(self):
+        """generic_hmm.py:259-274: -lag / ln p_ii."""
+        return -self._lag / np.log(np.diag(self._Tij))
+
+    def sub_hmm(self, states):
+        """generic_hmm.py:276-296."""
+        states = np.asarray(states)
+        pi_sub = self._Pi[states] / self._Pi[states].sum()
+        P_sub = self._Tij[states, :][:, states]
+        assert np.all(P_sub.sum(axis=1) > 0), \
+            'Illegal sub_hmm request: transition matrix cannot be normalized on ' + str(states)
+        P_sub = P_sub / P_sub.sum(axis=1)[:, None]
+        return HMM(pi_sub, P_sub, self.output_model.sub_output_model(states), lag=self.lag)
+
     def count_matrix(self):
         """generic_hmm.py:297-319: lag-1 transition counts of the hidden paths."""
         if self.hidden_state_trajectories is None:
@@ -97,3 +143,116 @@ class HMM(object):
         parts = [np.asarray(o)[np.asarray(s) == state_index]
                  for s, o in zip(self.hidden_state_trajectories, observations)]
         return np.concatenate(parts) if parts else np.array([])
+
+
+def _stat_property(name, doc):
+    def samples(self):
+        return np.array([np.asarray(getattr(h, name)) for h in self._sampled_hmms])
+
+    def mean(self):
+        return np.mean(samples(self), axis=0)
+
+    def std(self):
+        return np.std(samples(self), axis=0)
+
+    def conf(self):
+        return confidence_interval_arr(samples(self), conf=self._conf)
+
+    return (property(samples, doc=doc + ' of every sample'), property(mean), property(std),
+            property(conf))
+
+
+class SampledHMM(HMM):
+    """bhmm/hmm/generic_sampled_hmm.py:27-251: the estimated model plus statistics (mean, std,
+    confidence interval) of a list of sampled models.  The Gaussian / discrete output
+    statistics of SampledGaussianHMM / SampledDiscreteHMM (gaussian_hmm.py:66-112,
+    discrete_hmm.py:62-83) are available on the same object when the output model has them.
+    Iterating or indexing gives the sampled models."""
+
+    def __init__(self, estimated_hmm, sampled_hmms, conf=0.95):
+        HMM.__init__(self, estimated_hmm.initial_distribution, estimated_hmm.transition_matrix,
+                     estimated_hmm.output_model, lag=estimated_hmm.lag)
+        self.hidden_state_trajectories = estimated_hmm.hidden_state_trajectories
+        self.likelihood = estimated_hmm.likelihood
+        self._sampled_hmms = list(sampled_hmms)
+        self._nsamples = len(self._sampled_hmms)
+        self.set_confidence(conf)
+
+    def set_confidence(self, conf):
+        self._conf = conf
+
+    @property
+    def nsamples(self):
+        return self._nsamples
+
+    @property
+    def sampled_hmms(self):
+        return self._sampled_hmms
+
+    @property
+    def confidence_interval(self):
+        return self._conf
+
+    def __len__(self):
+        return self._nsamples
+
+    def __iter__(self):
+        return iter(self._sampled_hmms)
+
+    def __getitem__(self, i):
+        return self._sampled_hmms[i]
+
+    (initial_distribution_samples, initial_distribution_mean, initial_distribution_std,
+     initial_distribution_conf) = _stat_property('initial_distribution', 'initial distribution')
+    (transition_matrix_samples, transition_matrix_mean, transition_matrix_std,
+     transition_matrix_conf) = _stat_property('transition_matrix', 'transition matrix')
+    (eigenvalues_samples, eigenvalues_mean, eigenvalues_std,
+     eigenvalues_conf) = _stat_property('eigenvalues', 'eigenvalues')
+    (eigenvectors_left_samples, eigenvectors_left_mean, eigenvectors_left_std,
+     eigenvectors_left_conf) = _stat_property('eigenvectors_left', 'left eigenvectors')
+    (eigenvectors_right_samples, eigenvectors_right_mean, eigenvectors_right_std,
+     eigenvectors_right_conf) = _stat_property('eigenvectors_right', 'right eigenvectors')
+    (timescales_samples, timescales_mean, timescales_std,
+     timescales_conf) = _stat_property('timescales', 'relaxation timescales')
+    (lifetimes_samples, lifetimes_mean, lifetimes_std,
+     lifetimes_conf) = _stat_property('lifetimes', 'state lifetimes')
+
+    @property
+    def stationary_distribution_samples(self):
+        """generic_sampled_hmm.py:92-98."""
+        if self.is_stationary:
+            return self.initial_distribution_samples
+        return np.array([h.stationary_distribution for h in self._sampled_hmms])
+
+    @property
+    def stationary_distribution_mean(self):
+        return np.mean(self.stationary_distribution_samples, axis=0)
+
+    @property
+    def stationary_distribution_std(self):
+        return np.std(self.stationary_distribution_samples, axis=0)
+
+    @property
+    def stationary_distribution_conf(self):
+        return confidence_interval_arr(self.stationary_distribution_samples, conf=self._conf)
+
+    def _output_samples(self, name):
+        return np.array([np.asarray(getattr(h.output_model, name)) for h in self._sampled_hmms])
+
+    def __getattr__(self, attr):
+        # means_* / sigmas_* (Gaussian) and output_probabilities_* (discrete)
+        if attr.startswith('_') or attr == 'output_model':
+            raise AttributeError(attr)
+        for base in ('means', 'sigmas', 'output_probabilities'):
+            if attr.startswith(base + '_') and hasattr(self.output_model, base):
+                x = self._output_samples(base)
+                kind = attr[len(base) + 1:]
+                if kind == 'samples':
+                    return x
+                if kind == 'mean':
+                    return np.mean(x, axis=0)
+                if kind == 'std':
+                    return np.std(x, axis=0)
+                if kind == 'conf':
+                    return confidence_interval_arr(x, conf=self._conf)
+        raise AttributeError(attr)

@@ -85,3 +85,32 @@ def test_estimate_hmm_from_raw_gaussian_data():
     np.testing.assert_allclose(hmm.output_model.means[order], mu, atol=0.1)
     np.testing.assert_allclose(hmm.output_model.sigmas[order], sg, atol=0.1)
     np.testing.assert_allclose(hmm.transition_matrix[np.ix_(order, order)], P, atol=0.03)
+
+
+def test_estimate_hmm_from_raw_discrete_data():
+    """estimate_hmm(dtrajs, nstates) without an initial model: count matrix + PCCA+ start
+    (bhmm/init/discrete.py) and Baum-Welch on the GPU recover a hidden 2-state chain seen
+    through 6 symbols; then bayesian_hmm gives a SampledHMM whose statistics bracket it."""
+    from test_host_logic import _markov_chain
+    P = np.array([[0.97, 0.03], [0.05, 0.95]])
+    B = np.array([[0.5, 0.3, 0.15, 0.05, 0.0, 0.0], [0.0, 0.0, 0.05, 0.15, 0.3, 0.5]])
+    rng = np.random.RandomState(4)
+    obs = []
+    for k, T in enumerate((20000, 15000)):
+        s = _markov_chain(P, T, 10 + k)
+        cs = np.cumsum(B, axis=1)
+        obs.append(np.minimum((rng.random_sample(T)[:, None] > cs[s]).sum(axis=1), 5).astype(np.int32))
+    hmm = bhmm_amd.estimate_hmm(obs, 2, accuracy=1e-4, maxit=200)
+    A, Bh = hmm.transition_matrix, hmm.output_model.output_probabilities
+    if Bh[0, 0] < Bh[1, 0]:
+        A, Bh = A[::-1, ::-1], Bh[::-1]
+    np.testing.assert_allclose(A, P, atol=0.01)
+    np.testing.assert_allclose(Bh, B, atol=0.02)
+    assert hmm.is_reversible
+    np.random.seed(3)
+    sampled = bhmm_amd.bayesian_hmm(obs, hmm, nsample=20, reversible=True)
+    assert isinstance(sampled, bhmm_amd.SampledHMM) and sampled.nsamples == 20
+    lo, hi = sampled.transition_matrix_conf
+    assert np.all(lo <= hmm.transition_matrix + 0.02) and np.all(hi >= hmm.transition_matrix - 0.02)
+    assert sampled.output_probabilities_mean.shape == (2, 6)
+    assert np.all(sampled.timescales_mean > 5)

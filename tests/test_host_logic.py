@@ -140,12 +140,13 @@ def test_em_loop_semantics_and_monotone_likelihood():
 
 def test_estimator_argument_handling():
     obs, init = _gauss_problem(K=2, T=50)
-    # no initial model: gaussian data get the heuristic start, discrete data must bring one
+    # no initial model: both kinds of data get the heuristic start of bhmm.init_hmm
     est = bhmm_amd.MaximumLikelihoodEstimator(obs, 3, engine_factory=OracleEngine)
     assert est.hmm.nstates == 3 and est.hmm.output_model.model_type == 'gaussian'
-    with pytest.raises(NotImplementedError):
-        bhmm_amd.MaximumLikelihoodEstimator([np.array([0, 1, 1, 0, 2])], 2, output='discrete',
-                                            engine_factory=OracleEngine)
+    est = bhmm_amd.MaximumLikelihoodEstimator([np.array([0, 1, 1, 0, 2, 2, 1, 0])], 2,
+                                              output='discrete', engine_factory=OracleEngine)
+    assert est.hmm.nstates == 2 and est.hmm.output_model.model_type == 'discrete'
+    assert est.hmm.output_model.output_probabilities.shape == (2, 3)
     with pytest.raises(ValueError):
         bhmm_amd.MaximumLikelihoodEstimator(obs, 2, initial_model=init, engine_factory=OracleEngine)
     # fixed initial distribution (p with stationary=False), maximum_likelihood.py:118-126
@@ -225,3 +226,169 @@ def test_gaussian_initial_model_heuristic():
         np.testing.assert_allclose(hmm.initial_distribution @ T, hmm.initial_distribution, atol=1e-8)
         np.testing.assert_allclose(np.diag(T), np.diag(P), atol=0.12)   # metastable as generated (a start, not a fit)
         assert hmm.output_model.model_type == 'gaussian'
+
+
+def _markov_chain(P, T, seed):
+    rng = np.random.RandomState(seed)
+    cs = np.cumsum(P, axis=1)
+    u = rng.random_sample(T)
+    s = np.zeros(T, dtype=np.int32)
+    for t in range(1, T):
+        s[t] = min(np.searchsorted(cs[s[t - 1]], u[t]), P.shape[0] - 1)
+    return s
+
+
+_SPLIT = np.array([0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2,
+                   0, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 0, 1, 2, 2, 2, 2, 2, 2])
+
+
+def test_discrete_initial_model_reference_values():
+    """The known answers of bhmm/tests/test_init_discrete.py:182-213 (state splitting with and
+    without empty labels): they pin the count matrix, the neighbour prior, the reversible
+    estimator, the coarse-graining and the regularisation."""
+    piref = np.array([0.35801876, 0.55535398, 0.08662726])
+    Aref = np.array([[0.76462978, 0.10261978, 0.13275044],
+                     [0.06615566, 0.89464821, 0.03919614],
+                     [0.54863966, 0.25128039, 0.20007995]])
+    h = bhmm_amd.init_discrete_hmm([_SPLIT], 3, separate=[0])
+    np.testing.assert_allclose(h.initial_distribution, piref, atol=1e-6)
+    np.testing.assert_allclose(h.transition_matrix, Aref, atol=1e-6)
+    Bref = np.array([[0, 1, 0], [0, 0, 1], [1, 0, 0]])
+    assert np.max(np.abs(h.output_model.output_probabilities - Bref)) < 0.01
+    h = bhmm_amd.init_discrete_hmm([_SPLIT + 2], 3, separate=[1, 2])
+    np.testing.assert_allclose(h.initial_distribution, piref, atol=1e-6)
+    np.testing.assert_allclose(h.transition_matrix, Aref, atol=1e-6)
+    Bref = np.array([[0, 0, 0, 1, 0], [0, 0, 0, 0, 1], [0, 0, 1, 0, 0]])
+    assert np.max(np.abs(h.output_model.output_probabilities - Bref)) < 0.01
+    with pytest.raises(ValueError):                          # test_init_discrete.py:215-218
+        bhmm_amd.init_discrete_hmm([np.array([0, 0, 1, 1])], 2, separate=[0, 2])
+
+
+def test_discrete_initial_model_metastable_chains():
+    """test_init_discrete.py:33-109: metastable chains coarse-grain to their blocks (PCCA+)."""
+    from bhmm_amd.init.discrete import pcca_memberships, count_matrix
+    P2 = np.array([[0.99, 0.01], [0.01, 0.99]])
+    h = bhmm_amd.init_discrete_hmm([_markov_chain(P2, 10000, 1)], 2)
+    A, B = h.transition_matrix, h.output_model.output_probabilities
+    if B[0, 0] < B[1, 0]:
+        B = B[::-1]
+    assert np.max(A - P2) < 0.01 and np.max(B - np.eye(2)) < 0.01
+    P4 = np.array([[0.90, 0.10, 0.00, 0.00], [0.10, 0.89, 0.01, 0.00],
+                   [0.00, 0.01, 0.89, 0.10], [0.00, 0.00, 0.10, 0.90]])
+    h = bhmm_amd.init_discrete_hmm([_markov_chain(P4, 10000, 2)], 2)
+    A, B = h.transition_matrix, h.output_model.output_probabilities
+    Bref = np.array([[0.5, 0.5, 0.0, 0.0], [0.0, 0.0, 0.5, 0.5]])
+    assert np.max(A - np.array([[0.99, 0.01], [0.01, 0.99]])) < 0.01
+    assert np.max(B - Bref) < 0.05 or np.max(B[::-1] - Bref) < 0.05
+    P6 = np.array([[0.90, 0.10, 0.00, 0.00, 0.00, 0.00], [0.20, 0.79, 0.01, 0.00, 0.00, 0.00],
+                   [0.00, 0.01, 0.84, 0.15, 0.00, 0.00], [0.00, 0.00, 0.05, 0.94, 0.01, 0.00],
+                   [0.00, 0.00, 0.00, 0.02, 0.78, 0.20], [0.00, 0.00, 0.00, 0.00, 0.10, 0.90]])
+    d6 = _markov_chain(P6, 10000, 3)
+    h = bhmm_amd.init_discrete_hmm([d6], 3)
+    assert _tmatrix.is_transition_matrix(h.transition_matrix) and h.is_reversible
+    np.testing.assert_allclose(h.output_model.output_probabilities.sum(axis=1), 1.0)
+    # memberships: a partition of unity whose crisp assignment is the three blocks
+    chi = pcca_memberships(_tmatrix.mle_reversible(count_matrix([d6], 1)), 3)
+    np.testing.assert_allclose(chi.sum(axis=1), 1.0, atol=1e-12)
+    assert chi.min() >= 0 and chi.max(axis=1).min() > 0.9
+    crisp = chi.argmax(axis=1)
+    assert crisp[0] == crisp[1] and crisp[2] == crisp[3] and crisp[4] == crisp[5]
+    assert len(set(crisp)) == 3
+    # disconnected matrix: one metastable state per closed set, transient states by absorption
+    Pd = np.array([[0.9, 0.1, 0.0, 0.0, 0.0], [0.1, 0.9, 0.0, 0.0, 0.0],
+                   [0.0, 0.0, 0.8, 0.2, 0.0], [0.0, 0.0, 0.2, 0.8, 0.0],
+                   [0.0, 0.3, 0.3, 0.0, 0.4]])
+    chi = pcca_memberships(Pd, 2)
+    np.testing.assert_allclose(chi[:4], [[1, 0], [1, 0], [0, 1], [0, 1]])
+    np.testing.assert_allclose(chi[4], [0.5, 0.5])
+    with pytest.raises(ValueError):
+        pcca_memberships(Pd, 1)
+
+
+def test_discrete_initial_model_pathological():
+    """test_init_discrete.py:115-180."""
+    from bhmm_amd.init.discrete import init_discrete_hmm_spectral, count_matrix
+    for rev in (True, False):
+        h = bhmm_amd.init_discrete_hmm([np.array([0, 0, 0, 0, 0])], 1, reversible=rev)
+        assert np.allclose(h.transition_matrix, [[1.0]])
+        assert np.allclose(h.output_model.output_probabilities, [[1.0]])
+        h = bhmm_amd.init_discrete_hmm([np.array([0, 0, 0, 0, 1])], 1, reversible=rev)
+        B = h.output_model.output_probabilities
+        assert np.allclose(h.transition_matrix, [[1.0]]) and B.shape == (1, 2) and np.all(B > 0)
+        C = count_matrix([np.array([0, 0, 1, 1, 0])], 1)
+        p0, A0, B0 = init_discrete_hmm_spectral(C, 1, reversible=rev,
+                                                P=_tmatrix.estimate_P(C, reversible=rev))
+        assert np.allclose(A0, [[1.0]]) and B0.shape == (1, 2) and np.all(B0 > 0)
+        h = bhmm_amd.init_discrete_hmm([np.array([0, 0, 0, 0, 1])], 2, reversible=rev,
+                                       method='spectral', regularize=False)
+        assert np.allclose(h.transition_matrix, [[0.75, 0.25], [0, 1]])
+        assert np.allclose(h.output_model.output_probabilities, np.eye(2))
+        h = bhmm_amd.init_discrete_hmm([np.array([0, 1, 2, 0, 3, 4])], 3, reversible=rev)
+        assert _tmatrix.is_transition_matrix(h.transition_matrix)
+        assert (not rev) or h.is_reversible
+        assert np.allclose(h.output_model.output_probabilities.sum(axis=1), 1)
+    with pytest.raises(NotImplementedError):
+        bhmm_amd.init_discrete_hmm([np.array([0, 1, 0, 0, 1, 1])], 3, reversible=False)
+    h = bhmm_amd.init_hmm([_SPLIT], 2, lag=2)
+    assert h.lag == 2 and h.output_model.model_type == 'discrete'
+
+
+def test_spectral_properties_and_sampled_statistics():
+    """generic_hmm.py:203-296 and generic_sampled_hmm.py / util/statistics.py."""
+    from bhmm_amd.util.statistics import confidence_interval, confidence_interval_arr
+    P = np.array([[0.9, 0.1, 0.0], [0.1, 0.8, 0.1], [0.0, 0.1, 0.9]])
+    h = bhmm_amd.gaussian_hmm([1 / 3.] * 3, P, [-1.0, 0.0, 1.0], [1.0, 1.0, 1.0])
+    h._lag = 2
+    lam = np.sort(np.linalg.eigvals(P).real)[::-1]
+    np.testing.assert_allclose(h.eigenvalues, lam, atol=1e-12)
+    R, L = h.eigenvectors_right, h.eigenvectors_left
+    np.testing.assert_allclose(L @ R, np.eye(3), atol=1e-12)
+    np.testing.assert_allclose(R @ np.diag(h.eigenvalues) @ L, P, atol=1e-12)
+    np.testing.assert_allclose(L[0], h.stationary_distribution, atol=1e-12)
+    np.testing.assert_allclose(R[:, 0], 1.0, atol=1e-12)
+    np.testing.assert_allclose(h.timescales, -2.0 / np.log(lam[1:]))
+    np.testing.assert_allclose(h.lifetimes, -2.0 / np.log(np.diag(P)))
+    sub = h.sub_hmm([0, 1])
+    np.testing.assert_allclose(sub.transition_matrix, [[0.9, 0.1], [1 / 9., 8 / 9.]])
+    assert np.array_equal(sub.output_model.means, [-1.0, 0.0])
+    # non-reversible model: complex decomposition, still L R = 1
+    Pn = np.array([[0.8, 0.2, 0.0], [0.0, 0.7, 0.3], [0.4, 0.0, 0.6]])
+    hn = bhmm_amd.discrete_hmm([1, 0, 0], Pn, np.eye(3))
+    assert not hn.is_reversible
+    np.testing.assert_allclose(hn.eigenvectors_left @ hn.eigenvectors_right, np.eye(3), atol=1e-12)
+    assert abs(hn.eigenvalues[0] - 1) < 1e-12
+    # confidence interval: the reference's interpolation on a known sample
+    data = np.arange(101, dtype=float)
+    m, lo, hi = confidence_interval(data, 0.9)
+    assert m == 50.0 and abs(lo - 5.0) < 1e-12 and abs(hi - 95.9) < 1e-12
+    with pytest.raises(ValueError):
+        confidence_interval(data, 1.5)
+    rng = np.random.RandomState(0)
+    arr = rng.normal(size=(2000, 2, 3))
+    lo, hi = confidence_interval_arr(arr, conf=0.95)
+    assert lo.shape == (2, 3) and np.all(np.abs(lo + 1.96) < 0.2) and np.all(np.abs(hi - 1.96) < 0.2)
+    # SampledHMM over perturbed copies
+    samples = []
+    for k in range(50):
+        Pk = P + 0.01 * rng.random_sample((3, 3))
+        Pk /= Pk.sum(axis=1)[:, None]
+        samples.append(bhmm_amd.gaussian_hmm([1 / 3.] * 3, Pk, np.array([-1.0, 0.0, 1.0]) + 0.1 * rng.normal(size=3),
+                                             [1.0, 1.0, 1.0]))
+    sh = bhmm_amd.SampledHMM(h, samples, conf=0.9)
+    assert sh.nsamples == 50 and len(sh) == 50 and sh[3] is samples[3]
+    assert sh.transition_matrix_samples.shape == (50, 3, 3)
+    np.testing.assert_allclose(sh.transition_matrix_mean,
+                               np.mean([x.transition_matrix for x in samples], axis=0))
+    np.testing.assert_allclose(sh.transition_matrix_std,
+                               np.std([x.transition_matrix for x in samples], axis=0))
+    lo, hi = sh.transition_matrix_conf
+    assert np.all(lo <= sh.transition_matrix_mean + 1e-15) and np.all(hi >= sh.transition_matrix_mean - 1e-15)
+    assert sh.eigenvalues_mean.shape == (3,) and sh.timescales_samples.shape == (50, 2)
+    assert sh.lifetimes_std.shape == (3,) and sh.eigenvectors_left_mean.shape == (3, 3)
+    assert sh.stationary_distribution_mean.shape == (3,)
+    assert sh.means_samples.shape == (50, 3) and sh.sigmas_std.shape == (3,)
+    lo, hi = sh.means_conf
+    assert np.all(lo < hi)
+    with pytest.raises(AttributeError):
+        sh.output_probabilities_mean
+    np.testing.assert_allclose(sh.transition_matrix, P)       # the estimated model itself
