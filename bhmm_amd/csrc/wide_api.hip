@@ -89,7 +89,7 @@ static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
 {
     constexpr int GP = 64 / NP;
     const Segs sg = segs_of(c, which);
-    const size_t sm = (size_t)(NP * (NP + 1) + GP * NP) * sizeof(double);
+    const size_t sm = (size_t)(NP * wide_pitch(NP) + GP * NP) * sizeof(double);
     hipLaunchKernelGGL((k_wide_bwd<NP, KIND>), dim3((sg.nseg + GP - 1) / GP), dim3(64), sm, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, (const void *)c->d_obs_rm.p,
                        (const double *)c->d_alpha_rm.p,
@@ -313,7 +313,7 @@ int wide_backward(bhmm_ctx *c, const double *A)
     if (rc)
         return rc;
     const int NP = c->N, GP = 64 / NP;
-    const size_t sm = (size_t)(NP * (NP + 1) + GP * NP) * sizeof(double);
+    const size_t sm = (size_t)(NP * wide_pitch(NP) + GP * NP) * sizeof(double);
     const dim3 grid((c->K + GP - 1) / GP), blk(64);
     const double *pobs = reinterpret_cast<const double *>(c->d_obs_rm.p);
     if (NP == 16)
@@ -361,7 +361,7 @@ int wide_transition_counts(double *C, const double *A, const double *pobs, const
     if (e == hipSuccess) e = hipMemcpy(db, beta, cnt * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(dpart, 0, (size_t)nslab * n * n * sizeof(double));
     if (e == hipSuccess) {
-        const size_t sm = (size_t)(NP * (NP + 1) + GP * NP) * sizeof(double);
+        const size_t sm = (size_t)(NP * wide_pitch(NP) + GP * NP) * sizeof(double);
         const dim3 grid((nslab + GP - 1) / GP), blk(64);
         if (NP == 16)
             hipLaunchKernelGGL((k_wide_xi<16>), grid, blk, sm, 0, (const double *)dA, (const double *)dp,

@@ -17,7 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "estep_kernels.hpp"
+#include "estep_sweep.hpp"
 
 namespace bhmm {
 
@@ -29,10 +29,117 @@ struct WideModel {
     int n, M;
 };
 
+// ---- 64 states, one trajectory segment per wavefront: cross-lane forms of gfx950 ----------------
+// A matrix-vector product needs every lane to see every element of the state vector.  Going
+// through LDS costs a write, a wait and 32 broadcast reads per step, and with one wavefront per
+// SIMD (the recursion is serial, the registers are full) nothing hides those latencies.  Instead:
+//   * v_permlane32_swap / v_permlane16_swap make four copies of the vector in which every row of
+//     16 lanes holds row r of the original (6 swaps);
+//   * v_fmac_f64 with the DPP modifier row_newbcast:i multiplies by lane i of the own row, i.e.
+//     by element 16 r + i, in the same instruction: 64 FMAs per product and no other traffic.
+// The DPP instructions are inline assembly (the compiler does not fold a 64-bit row_newbcast
+// move into the FMA); a DPP read of a VGPR needs two wait states after the VALU write of that
+// VGPR, which the first instruction of every row group provides itself.
+constexpr __host__ __device__ int wide_pitch(int np) { return np == 64 ? np + 2 : np + 1; }
+
+struct Rows4 {
+    double r[4];
+};
+
+__device__ __forceinline__ void swap32_f64(double &x, double &y)
+{
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi.x, (int)lo.x);
+    y = __hiloint2double((int)hi.y, (int)lo.y);
+}
+
+__device__ __forceinline__ void swap16_f64(double &x, double &y)
+{
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi.x, (int)lo.x);
+    y = __hiloint2double((int)hi.y, (int)lo.y);
+}
+
+// r[k]: every row of 16 lanes holds row k of v
+__device__ __forceinline__ Rows4 rows_of(double v)
+{
+    Rows4 o;
+    double lo = v, hi = v;
+    swap32_f64(lo, hi); // lo: rows (0,1,0,1)   hi: rows (2,3,2,3)
+    o.r[0] = lo;
+    o.r[1] = lo;
+    swap16_f64(o.r[0], o.r[1]); // (0,0,0,0) and (1,1,1,1)
+    o.r[2] = hi;
+    o.r[3] = hi;
+    swap16_f64(o.r[2], o.r[3]);
+    return o;
+}
+
+template <int I, bool FIRST>
+__device__ __forceinline__ void fmac_bcast(double &acc, const double &src, const double &w)
+{
+    if constexpr (FIRST)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(src), "v"(w), "n"(I));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(src), "v"(w), "n"(I));
+}
+
+// acc[i & 3] += v[16 ROW + i] * w(i), i = 0..15, with v given as its row copy `src`
+template <typename WF>
+__device__ __forceinline__ void dot16(double (&acc)[4], const double &src, WF &&w)
+{
+    unrolled<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        fmac_bcast<i, i == 0>(acc[i & 3], src, w(ic));
+    });
+}
+
+// sum / max over all 64 lanes, result in every lane (fixed order)
+__device__ __forceinline__ double wave64_sum(double v)
+{
+    v += xchg_f64<1>(v);
+    v += xchg_f64<2>(v);
+    v += xchg_f64<4>(v);
+    {
+        const int lo = dpp_i32<0x140>(__double2loint(v)); // row_mirror
+        const int hi = dpp_i32<0x140>(__double2hiint(v));
+        v += __hiloint2double(hi, lo);
+    }
+    double a = v, b = v;
+    swap32_f64(a, b); // rows (0,1,0,1) / (2,3,2,3)
+    a += b;
+    b = a;
+    swap16_f64(a, b); // all rows: 0+2 / 1+3
+    return a + b;
+}
+
+__device__ __forceinline__ int wave64_max(int v)
+{
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    v = max(v, xchg_i32<1>(v));
+    v = max(v, xchg_i32<2>(v));
+    v = max(v, xchg_i32<4>(v));
+    v = max(v, dpp_i32<0x140>(v));
+    u2 s = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    v = max((int)s.x, (int)s.y);
+    s = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return max((int)s.x, (int)s.y);
+}
+
 template <int NP>
 __device__ __forceinline__ double wgroup_sum(double v)
 {
     // lanes of one row (16) first, on DPP; then across rows with wave shuffles
+    if constexpr (NP == 64)
+        return wave64_sum(v);
     v += xchg_f64<1>(v);
     v += xchg_f64<2>(v);
     v += xchg_f64<4>(v);
@@ -51,6 +158,8 @@ __device__ __forceinline__ double wgroup_sum(double v)
 template <int NP>
 __device__ __forceinline__ int wgroup_max(int v)
 {
+    if constexpr (NP == 64)
+        return wave64_max(v);
     v = max(v, xchg_i32<1>(v));
     v = max(v, xchg_i32<2>(v));
     v = max(v, xchg_i32<4>(v));
@@ -62,6 +171,7 @@ __device__ __forceinline__ int wgroup_max(int v)
     return v;
 }
 
+
 template <int NP>
 __device__ __forceinline__ unsigned long long wgroup_mask(int lane)
 {
@@ -71,25 +181,50 @@ __device__ __forceinline__ unsigned long long wgroup_mask(int lane)
         return ((1ull << NP) - 1) << (lane / NP * NP);
 }
 
-// emission probability of MY state at global step gt (+ outlier rule over the group)
+// What one step reads from the observation stream.  Loading it is separated from using it so
+// that the recursions can fetch WIDE_PF steps ahead: they are serial in t with one or two
+// wavefronts per SIMD, and a load issued in the step that needs it costs a full memory latency
+// (about 1 us under load) per step.
+#ifndef WIDE_PF
+#define WIDE_PF 8
+#endif
+struct WideIn {
+    double o; // Gaussian: the observation; explicit: p_obs of my state
+    int sym;  // discrete: the symbol
+};
+
+template <int KIND>
+__device__ __forceinline__ WideIn wide_load(const WideModel &m, int j, bool real, int64_t gt,
+                                            const void *obs_rm)
+{
+    WideIn in;
+    in.o = 0.0;
+    in.sym = 0;
+    if constexpr (KIND == EMIT_GAUSS)
+        in.o = static_cast<const double *>(obs_rm)[gt];
+    else if constexpr (KIND == EMIT_DISC)
+        in.sym = static_cast<const int32_t *>(obs_rm)[gt];
+    else
+        in.o = real ? static_cast<const double *>(obs_rm)[gt * m.n + j] : 0.0;
+    return in;
+}
+
+// emission probability of MY state (+ outlier rule over the group)
 template <int NP, int KIND>
-__device__ __forceinline__ double wide_emit(const WideModel &m, int j, bool real, int64_t gt,
-                                            const void *obs_rm, double mu_j, double is_j,
-                                            double cn_j, unsigned long long gmask, double &o,
-                                            int &sym)
+__device__ __forceinline__ double wide_emit(const WideModel &m, int j, bool real, const WideIn &in,
+                                            double mu_j, double is_j, double cn_j,
+                                            unsigned long long gmask)
 {
     double p = 0.0;
     if constexpr (KIND == EMIT_GAUSS) {
-        o = static_cast<const double *>(obs_rm)[gt];
-        const double z = (o - mu_j) * is_j;
-        p = real ? cn_j * exp(-0.5 * z * z) : 0.0;
+        const double z = (in.o - mu_j) * is_j;
+        p = real ? cn_j * exp_nonpos(-0.5 * z * z) : 0.0;
         if ((__ballot(p != 0.0) & gmask) == 0ull)
             p = real ? 1.0 : 0.0; // outputmodel.py:126-130
     } else if constexpr (KIND == EMIT_DISC) {
-        sym = static_cast<const int32_t *>(obs_rm)[gt];
-        p = real ? m.B[(int64_t)j * m.M + sym] : 0.0;
+        p = real ? m.B[(int64_t)j * m.M + in.sym] : 0.0;
     } else {
-        p = real ? static_cast<const double *>(obs_rm)[gt * m.n + j] : 0.0;
+        p = in.o;
     }
     return p;
 }
@@ -142,35 +277,57 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
     const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0; // warm-up start (0: exact start)
     double a = real ? 1.0 / (double)n : 0.0, P = 1.0;
     int eP = 0;
-    for (int64_t t = tw; t < t1; ++t) {
-        double o;
-        int sym;
-        const double p = wide_emit<NP, KIND>(m, j, real, o0 + t, obs_rm, mu_j, is_j, cn_j, gmask,
-                                             o, sym);
-        double nj;
-        if (t == 0) {
-            nj = pi_j * p;
-        } else {
-            xch[gi][j] = a;
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    WideIn ring[WIDE_PF];
 #pragma unroll
-            for (int i = 0; i < NP; i += 2) {
-                const double2 x = *reinterpret_cast<const double2 *>(&xch[gi][i]);
-                acc[(i / 2) & 3] = fma(x.x, Acol[i], acc[(i / 2) & 3]);
-                acc[(i / 2) & 3] = fma(x.y, Acol[i + 1], acc[(i / 2) & 3]);
+    for (int u = 0; u < WIDE_PF; ++u)
+        ring[u] = wide_load<KIND>(m, j, real, o0 + (tw + u < t1 ? tw + u : t1 - 1), obs_rm);
+    for (int64_t tb = tw; tb < t1; tb += WIDE_PF) {
+#pragma unroll
+        for (int u = 0; u < WIDE_PF; ++u) {
+            const int64_t t = tb + u;
+            if (t >= t1)
+                break;
+            const WideIn in = ring[u];
+            {
+                const int64_t tn = t + WIDE_PF;
+                ring[u] = wide_load<KIND>(m, j, real, o0 + (tn < t1 ? tn : t1 - 1), obs_rm);
             }
-            nj = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * p;
-        }
-        const double c = wgroup_sum<NP>(nj);
-        a = nj * fast_rcp(c);
-        if (t >= t0) {
-            int e;
-            P = frexp(P * c, &e);
-            eP += e;
-            if (real)
-                alpha_rm[(o0 + t) * n + j] = a;
-        } else if (t == t0 - 1 && real) {
-            a_entry[(int64_t)s * n + j] = a; // the entry vector this segment derived
+            const double p = wide_emit<NP, KIND>(m, j, real, in, mu_j, is_j, cn_j, gmask);
+            double nj;
+            if (t == 0) {
+                nj = pi_j * p;
+            } else {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                if constexpr (NP == 64) {
+                    const Rows4 ar = rows_of(a);
+                    unrolled<4>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        dot16(acc, ar.r[r], [&](auto ic) -> const double & {
+                            return Acol[16 * r + decltype(ic)::value];
+                        });
+                    });
+                } else {
+                    xch[gi][j] = a;
+#pragma unroll
+                    for (int i = 0; i < NP; i += 2) {
+                        const double2 x = *reinterpret_cast<const double2 *>(&xch[gi][i]);
+                        acc[(i / 2) & 3] = fma(x.x, Acol[i], acc[(i / 2) & 3]);
+                        acc[(i / 2) & 3] = fma(x.y, Acol[i + 1], acc[(i / 2) & 3]);
+                    }
+                }
+                nj = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * p;
+            }
+            const double c = wgroup_sum<NP>(nj);
+            a = nj * fast_rcp(c);
+            if (t >= t0) {
+                int e;
+                P = frexp(P * c, &e);
+                eP += e;
+                if (real)
+                    alpha_rm[(o0 + t) * n + j] = a;
+            } else if (t == t0 - 1 && real) {
+                a_entry[(int64_t)s * n + j] = a; // the entry vector this segment derived
+            }
         }
     }
     if (real)
@@ -189,14 +346,17 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
 {
     constexpr int GP = 64 / NP;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *sA = smem;                          // [NP][NP + 1] padded rows of A
-    double *xb = smem + NP * (NP + 1);          // [GP][NP]  (NP*(NP+1) is even: 16-byte aligned)
+    // rows of A, padded: lane i reads row i.  64 states: pitch NP + 2, so that a row is read in
+    // 16-byte pieces without bank conflicts; otherwise NP + 1 and 8-byte pieces.
+    constexpr int PITCH = wide_pitch(NP);
+    double *sA = smem;                          // [NP][PITCH]
+    double *xb = smem + NP * PITCH;             // [GP][NP]  (NP * PITCH is even: 16-byte aligned)
     const int lane = threadIdx.x;
     const int gi = lane / NP, i = lane % NP;
     const int n = m.n;
     for (int e = lane; e < NP * NP; e += 64) {
         const int r = e / NP, c = e % NP;
-        sA[r * (NP + 1) + c] = (r < n && c < n) ? m.A[(int64_t)r * n + c] : 0.0;
+        sA[r * PITCH + c] = (r < n && c < n) ? m.A[(int64_t)r * n + c] : 0.0;
     }
     __syncthreads();
     const int s = blockIdx.x * GP + gi;
@@ -223,17 +383,33 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         const double mu_i = (KIND == EMIT_GAUSS && real) ? m.mu[i] : 0.0;
         const double is_i = (KIND == EMIT_GAUSS && real) ? m.isig[i] : 0.0;
         const double cn_i = (KIND == EMIT_GAUSS && real) ? m.cnorm[i] : 0.0;
-        const double *arow = sA + i * (NP + 1);
+        const double *arow = sA + i * PITCH;
         double *xg = xb + gi * NP;
         // one backward step: b <- A (p o b), rescaled by a power of two; returns A (p o b)[i]
+        Rows4 xr; // 64 states: the row copies of p o b of the current step (back() sets them)
         auto back = [&](double p, double b) {
-            xg[i] = p * b;
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (NP == 64) {
+                xr = rows_of(p * b);
+                unrolled<4>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    double2 av[8];
 #pragma unroll
-            for (int c = 0; c < NP; c += 2) {
-                const double2 x = *reinterpret_cast<const double2 *>(&xg[c]);
-                acc[(c / 2) & 3] = fma(arow[c], x.x, acc[(c / 2) & 3]);
-                acc[(c / 2) & 3] = fma(arow[c + 1], x.y, acc[(c / 2) & 3]);
+                    for (int q = 0; q < 8; ++q)
+                        av[q] = *reinterpret_cast<const double2 *>(&arow[16 * r + 2 * q]);
+                    dot16(acc, xr.r[r], [&](auto ic) -> const double & {
+                        constexpr int c = decltype(ic)::value;
+                        return (c & 1) ? av[c / 2].y : av[c / 2].x;
+                    });
+                });
+            } else {
+                xg[i] = p * b;
+#pragma unroll
+                for (int c = 0; c < NP; c += 2) {
+                    const double2 x = *reinterpret_cast<const double2 *>(&xg[c]);
+                    acc[(c / 2) & 3] = fma(arow[c], x.x, acc[(c / 2) & 3]);
+                    acc[(c / 2) & 3] = fma(arow[c + 1], x.y, acc[(c / 2) & 3]);
+                }
             }
             return (acc[0] + acc[1]) + (acc[2] + acc[3]);
         };
@@ -245,12 +421,24 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         double b = real ? 1.0 / (double)n : 0.0; // _hidden.c:79-88
         if (t1 < T) { // warm-up from te down to t1: beta at t1 - 1
             const int64_t te = (t1 - 1 + sg.W < T - 1) ? t1 - 1 + sg.W : T - 1;
-            for (int64_t t = te; t >= t1; --t) {
-                double o;
-                int sym;
-                const double p = wide_emit<NP, KIND>(m, i, real, o0 + t, obs_rm, mu_i, is_i, cn_i,
-                                                     gmask, o, sym);
-                b = rescale(back(p, b));
+            WideIn ring[WIDE_PF];
+#pragma unroll
+            for (int u = 0; u < WIDE_PF; ++u)
+                ring[u] = wide_load<KIND>(m, i, real, o0 + (te - u > t1 ? te - u : t1), obs_rm);
+            for (int64_t tb = te; tb >= t1; tb -= WIDE_PF) {
+#pragma unroll
+                for (int u = 0; u < WIDE_PF; ++u) {
+                    const int64_t t = tb - u;
+                    if (t < t1)
+                        break;
+                    const WideIn in = ring[u];
+                    {
+                        const int64_t tn = t - WIDE_PF;
+                        ring[u] = wide_load<KIND>(m, i, real, o0 + (tn > t1 ? tn : t1), obs_rm);
+                    }
+                    const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, is_i, cn_i, gmask);
+                    b = rescale(back(p, b));
+                }
             }
             if (real)
                 b_exit[(int64_t)s * n + i] = b;
@@ -261,44 +449,70 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
             const double g = a * b;
             gam = g * fast_rcp(wgroup_sum<NP>(g));
         }
-        for (int64_t t = t1 - 1; t >= t0; --t) {
-            double o = 0.0;
-            int sym = 0;
-            const double p = wide_emit<NP, KIND>(m, i, real, o0 + t, obs_rm, mu_i, is_i, cn_i,
-                                                 gmask, o, sym);
-            // consume gamma_t
-            sgm += gam;
-            if constexpr (KIND == EMIT_GAUSS) {
-                const double d = o - mu_i;
-                const double gd = gam * d;
-                sd += gd;
-                sdd = fma(gd, d, sdd);
-            }
-            if constexpr (KIND == EMIT_DISC)
-                if (real)
-                    mytab[(int64_t)i * m.M + sym] += gam; // row i is private to this lane
-            if (gamma_rm && real)
-                gamma_rm[(o0 + t) * n + i] = gam;
-            if (t == 0) {
-                if (real)
-                    gamma0[(int64_t)k * n + i] = gam;
-                break;
-            }
-            const double ap = real ? alpha_rm[(o0 + t - 1) * n + i] : 0.0;
-            const double br = back(p, b);
-            const double q = ap * br;
-            const double rS = fast_rcp(wgroup_sum<NP>(q));
-            gam = q * rS;
-            const double w = ap * rS;
+        // rings: observation of step t and alpha of step t - 1, WIDE_PF steps ahead
+        WideIn ro[WIDE_PF];
+        double ra[WIDE_PF];
+        auto fetch = [&](int u, int64_t t) {
+            const int64_t tt = t > t0 ? t : t0;
+            ro[u] = wide_load<KIND>(m, i, real, o0 + tt, obs_rm);
+            ra[u] = real ? alpha_rm[(o0 + (tt > 0 ? tt - 1 : 0)) * n + i] : 0.0;
+        };
 #pragma unroll
-            for (int c = 0; c < NP; c += 2) {
-                const double2 x = *reinterpret_cast<const double2 *>(&xg[c]);
-                Crow[c] = fma(w, x.x, Crow[c]);
-                Crow[c + 1] = fma(w, x.y, Crow[c + 1]);
+        for (int u = 0; u < WIDE_PF; ++u)
+            fetch(u, t1 - 1 - u);
+        for (int64_t tb = t1 - 1; tb >= t0; tb -= WIDE_PF) {
+#pragma unroll
+            for (int u = 0; u < WIDE_PF; ++u) {
+                const int64_t t = tb - u;
+                if (t < t0)
+                    break;
+                const WideIn in = ro[u];
+                const double ap = ra[u];
+                fetch(u, t - WIDE_PF);
+                const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, is_i, cn_i, gmask);
+                // consume gamma_t
+                sgm += gam;
+                if constexpr (KIND == EMIT_GAUSS) {
+                    const double d = in.o - mu_i;
+                    const double gd = gam * d;
+                    sd += gd;
+                    sdd = fma(gd, d, sdd);
+                }
+                if constexpr (KIND == EMIT_DISC)
+                    if (real)
+                        mytab[(int64_t)i * m.M + in.sym] += gam; // row i is private to this lane
+                if (gamma_rm && real)
+                    gamma_rm[(o0 + t) * n + i] = gam;
+                if (t == 0) { // the last step of the loop (t0 == 0)
+                    if (real)
+                        gamma0[(int64_t)k * n + i] = gam;
+                } else {
+                    const double br = back(p, b);
+                    const double q = ap * br;
+                    const double rS = fast_rcp(wgroup_sum<NP>(q));
+                    gam = q * rS;
+                    const double w = ap * rS;
+                    if constexpr (NP == 64) {
+                        unrolled<4>([&](auto rc) {
+                            constexpr int r = decltype(rc)::value;
+                            unrolled<16>([&](auto ic) {
+                                constexpr int c = decltype(ic)::value;
+                                fmac_bcast<c, c == 0>(Crow[16 * r + c], xr.r[r], w);
+                            });
+                        });
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NP; c += 2) {
+                            const double2 x = *reinterpret_cast<const double2 *>(&xg[c]);
+                            Crow[c] = fma(w, x.x, Crow[c]);
+                            Crow[c + 1] = fma(w, x.y, Crow[c + 1]);
+                        }
+                    }
+                    b = rescale(br);
+                    if (t == t0 && real) // beta one step before this segment, as derived here
+                        b_entry[(int64_t)s * n + i] = b;
+                }
             }
-            b = rescale(br);
-            if (t == t0 && real) // beta one step before this segment, as derived here
-                b_entry[(int64_t)s * n + i] = b;
         }
     }
     if (real) {
