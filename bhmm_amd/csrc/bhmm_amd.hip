@@ -902,6 +902,12 @@ int bhmm_ctx_create(bhmm_ctx **out, int device, void *stream)
     if (!c)
         return BHMM_ERR_NO_MEM;
     c->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            c->num_simd = 4 * cus;
+        (void)hipGetLastError();
+    }
     if (const char *e = getenv("BHMM_AMD_SPEC"))
         c->spec_enabled = atoi(e) != 0;
     if (const char *e = getenv("BHMM_AMD_SPEC_W")) {

@@ -55,6 +55,7 @@ struct DevBuf {
 
 struct bhmm_ctx {
     int device = 0;
+    int num_simd = 1024; // 4 per compute unit (set at creation)
     hipStream_t stream = nullptr;
     bool own_stream = false;
 

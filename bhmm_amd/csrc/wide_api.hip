@@ -111,6 +111,17 @@ static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
      : (c)->N == 32 ? fn<32, KIND>(__VA_ARGS__)                       \
                     : fn<64, KIND>(__VA_ARGS__))
 
+// Segment length that fills the chip.  64 states: one segment per wavefront, and the recursion
+// is issue-bound with a single wavefront per SIMD already -- a SIMD that gets a second wavefront
+// takes almost twice as long, so the plan aims at exactly one per SIMD (or a multiple).  Fewer
+// states run 64 / N segments per wavefront and are latency-bound: four wavefronts per SIMD.
+static int64_t wide_fill_len(const bhmm_ctx *c)
+{
+    const int64_t groups_per_wave = 64 / c->N;
+    const int64_t want = (c->N == 64) ? (int64_t)c->num_simd : 4 * (int64_t)c->num_simd * groups_per_wave;
+    return (c->total + want - 1) / want;
+}
+
 // segment plan `which` with segments of at most seglen steps (seglen <= 0: one per trajectory)
 static int wide_plan(bhmm_ctx *c, int which, int64_t seglen)
 {
@@ -164,11 +175,8 @@ int wide_alloc(bhmm_ctx *c)
     c->w_nseg[1] = 0;
     {
         int64_t seglen = c->wseg_len;
-        if (seglen <= 0) {
-            const int64_t groups_per_wave = 64 / c->N;
-            seglen = std::max<int64_t>((c->total + 4096 * groups_per_wave - 1) / (4096 * groups_per_wave),
-                                       8 * (int64_t)c->spec_W);
-        }
+        if (seglen <= 0)
+            seglen = std::max<int64_t>(wide_fill_len(c), 8 * (int64_t)c->spec_W);
         int64_t maxT = 0;
         for (int k = 0; k < c->K; ++k)
             maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
@@ -284,10 +292,8 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         f = std::min(std::max(f, 1.25), 8.0);
         const int64_t Wn = ((int64_t)ceil(c->spec_W * f) + 7) / 8 * 8;
         int64_t seglen = c->wseg_len > 0 ? (int64_t)c->wseg_len : 4 * Wn;
-        if (c->wseg_len <= 0) {
-            const int64_t groups_per_wave = 64 / c->N;
-            seglen = std::max(seglen, (c->total + 4096 * groups_per_wave - 1) / (4096 * groups_per_wave));
-        }
+        if (c->wseg_len <= 0)
+            seglen = std::max(seglen, wide_fill_len(c));
         if (c->wide_replans >= 3 || seglen >= maxT || Wn >= maxT / 2) {
             c->wseg_given_up = true;
         } else {

@@ -79,6 +79,18 @@ __device__ __forceinline__ Rows4 rows_of(double v)
     return o;
 }
 
+// v[k] (k = 0..3) are four 64-lane vectors; on return row k of v[I] is row I of the old v[k]:
+// the 16 x 4 / 4 x 16 operand layout of v_mfma_f64_16x16x4 (lane = 16 k + i) for block I.
+__device__ __forceinline__ void rows_transpose4(double (&v)[4])
+{
+    swap32_f64(v[0], v[2]);
+    swap32_f64(v[1], v[3]);
+    swap16_f64(v[0], v[1]);
+    swap16_f64(v[2], v[3]);
+}
+
+typedef double wide_d4 __attribute__((ext_vector_type(4)));
+
 template <int I, bool FIRST>
 __device__ __forceinline__ void fmac_bcast(double &acc, const double &src, const double &w)
 {
@@ -354,11 +366,13 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
     const int lane = threadIdx.x;
     const int gi = lane / NP, i = lane % NP;
     const int n = m.n;
-    for (int e = lane; e < NP * NP; e += 64) {
-        const int r = e / NP, c = e % NP;
-        sA[r * PITCH + c] = (r < n && c < n) ? m.A[(int64_t)r * n + c] : 0.0;
+    if constexpr (NP < 64) {
+        for (int e = lane; e < NP * NP; e += 64) {
+            const int r = e / NP, c = e % NP;
+            sA[r * PITCH + c] = (r < n && c < n) ? m.A[(int64_t)r * n + c] : 0.0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int s = blockIdx.x * GP + gi;
     if (s >= sg.nseg)
         return;
@@ -373,10 +387,45 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
     if (KIND == EMIT_DISC && real)
         for (int q = 0; q < m.M; ++q)
             mytab[(int64_t)i * m.M + q] = 0.0;
-    double Crow[NP];
+    // xi accumulators.  Fewer than 64 states: lane i keeps row i of C' and adds w_i x_c per step.
+    // 64 states: the rank-1 updates of four consecutive steps are one rank-4 update on the
+    // matrix cores -- C'(16 I.., 16 J..) += W_I X_J^T with v_mfma_f64_16x16x4, W_I / X_J being
+    // the rows 16 I.. of the four buffered w / x vectors (rows_transpose4) -- so the 64 x 64
+    // accumulators live in the accumulation registers, A's row i stays in the vector registers
+    // and the step issues 4 matrix instructions instead of 64 FMAs.
+    constexpr int NCROW = (NP == 64) ? 1 : NP;
+    double Crow[NCROW];
 #pragma unroll
-    for (int c = 0; c < NP; ++c)
+    for (int c = 0; c < NCROW; ++c)
         Crow[c] = 0.0;
+    wide_d4 Cacc[4][4];
+    double wq[4] = {0.0, 0.0, 0.0, 0.0}, xq[4] = {0.0, 0.0, 0.0, 0.0};
+    double Arow[NP == 64 ? 64 : 1];
+    if constexpr (NP == 64) {
+#pragma unroll
+        for (int I = 0; I < 4; ++I)
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+                Cacc[I][J] = wide_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < 64; ++c)
+            Arow[c] = (real && c < n) ? m.A[(int64_t)i * n + c] : 0.0;
+    }
+    auto xi_flush = [&]() {
+        if constexpr (NP == 64) {
+            double ow[4] = {wq[0], wq[1], wq[2], wq[3]}, ox[4] = {xq[0], xq[1], xq[2], xq[3]};
+            rows_transpose4(ow);
+            rows_transpose4(ox);
+#pragma unroll
+            for (int I = 0; I < 4; ++I)
+#pragma unroll
+                for (int J = 0; J < 4; ++J)
+                    Cacc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ow[I], ox[J], Cacc[I][J], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                wq[q] = 0.0;
+        }
+    };
     double sgm = 0.0, sd = 0.0, sdd = 0.0;
     if (t1 > t0) {
         const unsigned long long gmask = wgroup_mask<NP>(lane);
@@ -386,20 +435,16 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         const double *arow = sA + i * PITCH;
         double *xg = xb + gi * NP;
         // one backward step: b <- A (p o b), rescaled by a power of two; returns A (p o b)[i]
-        Rows4 xr; // 64 states: the row copies of p o b of the current step (back() sets them)
+        double xcur = 0.0; // 64 states: p o b of the current step (back() sets it)
         auto back = [&](double p, double b) {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             if constexpr (NP == 64) {
-                xr = rows_of(p * b);
+                xcur = p * b;
+                const Rows4 xr = rows_of(xcur);
                 unrolled<4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    double2 av[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        av[q] = *reinterpret_cast<const double2 *>(&arow[16 * r + 2 * q]);
                     dot16(acc, xr.r[r], [&](auto ic) -> const double & {
-                        constexpr int c = decltype(ic)::value;
-                        return (c & 1) ? av[c / 2].y : av[c / 2].x;
+                        return Arow[16 * r + decltype(ic)::value];
                     });
                 });
             } else {
@@ -493,13 +538,10 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                     gam = q * rS;
                     const double w = ap * rS;
                     if constexpr (NP == 64) {
-                        unrolled<4>([&](auto rc) {
-                            constexpr int r = decltype(rc)::value;
-                            unrolled<16>([&](auto ic) {
-                                constexpr int c = decltype(ic)::value;
-                                fmac_bcast<c, c == 0>(Crow[16 * r + c], xr.r[r], w);
-                            });
-                        });
+                        wq[u & 3] = w;
+                        xq[u & 3] = xcur;
+                        if ((u & 3) == 3)
+                            xi_flush();
                     } else {
 #pragma unroll
                         for (int c = 0; c < NP; c += 2) {
@@ -515,11 +557,27 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
             }
         }
     }
-    if (real) {
+    if constexpr (NP == 64) {
+        xi_flush(); // the steps of an incomplete group of four (empty slots hold w = 0)
+        // C / D layout of v_mfma_f64_16x16x4: column = lane & 15, row = (lane >> 4) + 4 r
 #pragma unroll
-        for (int c = 0; c < NP; ++c)
-            if (c < n)
-                mypart[(int64_t)i * n + c] = Crow[c];
+        for (int I = 0; I < 4; ++I)
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * I + (lane >> 4) + 4 * r, col = 16 * J + (lane & 15);
+                    if (row < n && col < n)
+                        mypart[(int64_t)row * n + col] = Cacc[I][J][r];
+                }
+    }
+    if (real) {
+        if constexpr (NP < 64) {
+#pragma unroll
+            for (int c = 0; c < NP; ++c)
+                if (c < n)
+                    mypart[(int64_t)i * n + c] = Crow[c];
+        }
         mypart[n * n + i] = sgm;
         if constexpr (KIND == EMIT_GAUSS) {
             mypart[n * n + n + i] = sd;
