@@ -1040,6 +1040,7 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         c->spec_W = 288;
     c->wide_replans = 0;
     c->wseg_given_up = false;
+    c->wide_careful = false;
     if (kind == BHMM_EMIT_DISCRETE) {
         const size_t sm = smem_fwdbwd<8, EMIT_DISC>(c->M);
         if (sm > 160 * 1024)
@@ -1182,7 +1183,7 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
     else if (n == "spec_last_dev")
         *value = c->spec_last_dev;
     else if (n == "careful")
-        *value = c->careful ? 1.0 : 0.0;
+        *value = (c->careful || c->wide_careful) ? 1.0 : 0.0;
     else if (n == "viterbi_chunked")
         *value = c->viterbi_chunked ? 1.0 : 0.0;
     else if (n == "viterbi_close")

@@ -128,6 +128,7 @@ struct bhmm_ctx {
     bool gamma_valid = false;
     bool careful = false;       // E-steps use the kernel with the per-step outlier branch
     bool careful_retry = false; // the last verdict asked for a repeat with that kernel
+    bool wide_careful = false;  // 9..64 states: lazily scaled kernels left their range on these data
     bool prefetched = false;          // stats + logL_k of the last E-step already sit in h_pinned
     bool last_stats_internal = true;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -68,13 +68,25 @@ static Segs segs_of(bhmm_ctx *c, int which)
 }
 
 template <int NP, int KIND>
-static int wide_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
+static int wide_launch_fwd(bhmm_ctx *c, const WideModel &m, int which, bool lazy = false)
 {
     constexpr int GP = 64 / NP;
     const Segs sg = segs_of(c, which);
-    hipLaunchKernelGGL((k_wide_fwd<NP, KIND>), dim3((sg.nseg + GP - 1) / GP), dim3(64), 0, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, sg, (const void *)c->d_obs_rm.p,
-                       c->d_alpha_rm.p, c->d_wlogLseg.p, c->d_waentry.p, c->d_waexit.p);
+    if (lazy && NP == 64 && c->n == 64) // the shape of BASELINE configs[3]
+        hipLaunchKernelGGL((k_wide_fwd<NP, KIND, true, NP == 64>), dim3((sg.nseg + GP - 1) / GP),
+                           dim3(64), 0, c->stream, m, (const int64_t *)c->d_offsets.p, sg,
+                           (const void *)c->d_obs_rm.p, c->d_alpha_rm.p, c->d_wlogLseg.p,
+                           c->d_waentry.p, c->d_waexit.p, c->d_specres.p);
+    else if (lazy)
+        hipLaunchKernelGGL((k_wide_fwd<NP, KIND, true>), dim3((sg.nseg + GP - 1) / GP), dim3(64), 0,
+                           c->stream, m, (const int64_t *)c->d_offsets.p, sg,
+                           (const void *)c->d_obs_rm.p, c->d_alpha_rm.p, c->d_wlogLseg.p,
+                           c->d_waentry.p, c->d_waexit.p, c->d_specres.p);
+    else
+        hipLaunchKernelGGL((k_wide_fwd<NP, KIND, false>), dim3((sg.nseg + GP - 1) / GP), dim3(64), 0,
+                           c->stream, m, (const int64_t *)c->d_offsets.p, sg,
+                           (const void *)c->d_obs_rm.p, c->d_alpha_rm.p, c->d_wlogLseg.p,
+                           c->d_waentry.p, c->d_waexit.p, (unsigned int *)nullptr);
     BHMM_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_logl, dim3(c->K), dim3(64), 0, c->stream,
                        (const int32_t *)c->d_wseg_traj0[which].p, c->K,
@@ -85,16 +97,30 @@ static int wide_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
 
 template <int NP, int KIND>
 static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool store_gamma,
-                           double *stats_dev)
+                           double *stats_dev, bool lazy = false)
 {
     constexpr int GP = 64 / NP;
     const Segs sg = segs_of(c, which);
     const size_t sm = (size_t)(NP * wide_pitch(NP) + GP * NP) * sizeof(double);
-    hipLaunchKernelGGL((k_wide_bwd<NP, KIND>), dim3((sg.nseg + GP - 1) / GP), dim3(64), sm, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, sg, (const void *)c->d_obs_rm.p,
-                       (const double *)c->d_alpha_rm.p,
-                       store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_gamma0.p,
-                       c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p);
+    double *gam = store_gamma ? c->d_gamma_ci.p : (double *)nullptr;
+    if (lazy && NP == 64 && c->n == 64)
+        hipLaunchKernelGGL((k_wide_bwd<NP, KIND, true, NP == 64>), dim3((sg.nseg + GP - 1) / GP),
+                           dim3(64), sm, c->stream, m, (const int64_t *)c->d_offsets.p, sg,
+                           (const void *)c->d_obs_rm.p, (const double *)c->d_alpha_rm.p, gam,
+                           c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p,
+                           c->d_wbentry.p, c->d_specres.p);
+    else if (lazy)
+        hipLaunchKernelGGL((k_wide_bwd<NP, KIND, true>), dim3((sg.nseg + GP - 1) / GP), dim3(64), sm,
+                           c->stream, m, (const int64_t *)c->d_offsets.p, sg,
+                           (const void *)c->d_obs_rm.p, (const double *)c->d_alpha_rm.p, gam,
+                           c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p,
+                           c->d_wbentry.p, c->d_specres.p);
+    else
+        hipLaunchKernelGGL((k_wide_bwd<NP, KIND, false>), dim3((sg.nseg + GP - 1) / GP), dim3(64), sm,
+                           c->stream, m, (const int64_t *)c->d_offsets.p, sg,
+                           (const void *)c->d_obs_rm.p, (const double *)c->d_alpha_rm.p, gam,
+                           c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p,
+                           c->d_wbentry.p, (unsigned int *)nullptr);
     BHMM_HIP(hipGetLastError());
     const int n = c->n;
     const int nfin = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0) + (KIND == EMIT_DISC ? n * c->M : 0) +
@@ -230,26 +256,26 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     const bool sg = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
     if (sg && (rc = c->d_gamma_ci.ensure((size_t)c->total * c->n)))
         return rc;
-    auto run = [&](int which) -> int {
+    auto run = [&](int which, bool lazy) -> int {
         int r;
         BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
         BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
         BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
         switch (c->kind) {
         case EMIT_GAUSS:
-            if ((r = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m, which)))
+            if ((r = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m, which, lazy)))
                 return r;
-            r = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_bwd, c, m, which, sg, stats_dev);
+            r = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_bwd, c, m, which, sg, stats_dev, lazy);
             break;
         case EMIT_DISC:
-            if ((r = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m, which)))
+            if ((r = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m, which, lazy)))
                 return r;
-            r = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_bwd, c, m, which, sg, stats_dev);
+            r = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_bwd, c, m, which, sg, stats_dev, lazy);
             break;
         default:
-            if ((r = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m, which)))
+            if ((r = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m, which, lazy)))
                 return r;
-            r = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_bwd, c, m, which, sg, stats_dev);
+            r = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_bwd, c, m, which, sg, stats_dev, lazy);
         }
         if (r)
             return r;
@@ -259,8 +285,10 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     };
     if (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) {
         // time-segmented run with warm-up boundaries, verified afterwards
-        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 2 * sizeof(unsigned int), c->stream));
-        if ((rc = run(1)))
+        // lazily scaled kernels unless an earlier E-step on these data left their range
+        const bool lazy = !c->careful && !c->wide_careful;
+        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 3 * sizeof(unsigned int), c->stream));
+        if ((rc = run(1, lazy)))
             return rc;
         const Segs sgs = segs_of(c, 1);
         hipLaunchKernelGGL(k_wide_check, dim3((sgs.nseg + 255) / 256), dim3(256), 0, c->stream, sgs,
@@ -268,9 +296,15 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
                            (const double *)c->d_wbexit.p, (const double *)c->d_wbentry.p, 1e-11,
                            c->d_specres.p);
         BHMM_HIP(hipGetLastError());
-        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 2 * sizeof(unsigned int),
+        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 3 * sizeof(unsigned int),
                                 hipMemcpyDeviceToHost, c->stream));
         BHMM_HIP(hipStreamSynchronize(c->stream));
+        if (lazy && c->h_specres[2] != 0) {
+            // a vector left the range the lazy scaling covers: per-step normalisation from now on
+            c->wide_careful = true;
+            c->careful_retry = true;
+            return wide_estep(c, A, pi, par0, par1, stats_dev, flags);
+        }
         float dev;
         memcpy(&dev, &c->h_specres[1], sizeof(float));
         c->spec_last_dev = dev;
@@ -305,7 +339,7 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
                 c->wseg_given_up = true;
         }
     }
-    if ((rc = run(0)))
+    if ((rc = run(0, false)))
         return rc;
     c->ev_pending = true;
     return BHMM_OK;

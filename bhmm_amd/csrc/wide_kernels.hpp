@@ -29,6 +29,37 @@ struct WideModel {
     int n, M;
 };
 
+// exp_nonpos (estep_sweep.hpp) with the Horner steps pinned to the three-address v_fma_f64: the
+// compiler otherwise picks the two-address v_fmac_f64 and copies every coefficient into the
+// accumulator first (10 extra moves per call), and these kernels are bound by instruction issue.
+__device__ __forceinline__ double horner_step(double q, double r, double c)
+{
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(q), "v"(r), "v"(c));
+    return o;
+}
+
+__device__ __forceinline__ double exp_nonpos_issue(double x)
+{
+    x = fmax(x, -750.0);
+    const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma(k, -0x1.62e42fefa39efp-1, x);
+    r = fma(k, -0x1.abc9e3b39803fp-56, r);
+    double q = 0x1.ad7e38e167506p-26;
+    q = horner_step(q, r, 0x1.28ae7908135d8p-22);
+    q = horner_step(q, r, 0x1.71df27c33abefp-19);
+    q = horner_step(q, r, 0x1.a01998fd42e01p-16);
+    q = horner_step(q, r, 0x1.a01a012882c92p-13);
+    q = horner_step(q, r, 0x1.6c16c184889e3p-10);
+    q = horner_step(q, r, 0x1.111111112836cp-7);
+    q = horner_step(q, r, 0x1.55555555506eap-5);
+    q = horner_step(q, r, 0x1.55555555554f7p-3);
+    q = horner_step(q, r, 0x1.000000000000ap-1);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(q, (int)k);
+}
+
 // ---- 64 states, one trajectory segment per wavefront: cross-lane forms of gfx950 ----------------
 // A matrix-vector product needs every lane to see every element of the state vector.  Going
 // through LDS costs a write, a wait and 32 broadcast reads per step, and with one wavefront per
@@ -230,7 +261,7 @@ __device__ __forceinline__ double wide_emit(const WideModel &m, int j, bool real
     double p = 0.0;
     if constexpr (KIND == EMIT_GAUSS) {
         const double z = (in.o - mu_j) * is_j;
-        p = real ? cn_j * exp_nonpos(-0.5 * z * z) : 0.0;
+        p = real ? cn_j * exp_nonpos_issue(-0.5 * z * z) : 0.0;
         if ((__ballot(p != 0.0) & gmask) == 0ull)
             p = real ? 1.0 : 0.0; // outputmodel.py:126-130
     } else if constexpr (KIND == EMIT_DISC) {
@@ -254,20 +285,30 @@ struct Segs {
     int W;
 };
 
-template <int NP, int KIND>
+// LAZY (E-step only): alpha is carried un-normalised, up to a power of two that is refreshed every
+// fourth step -- the per-step sum over the states and its reciprocal leave the serial chain.  The
+// backward pass only uses alpha through scale-free ratios, and the log-likelihood of a segment
+// telescopes: log sum(alpha at the last step) - log sum(alpha at the entry) + ln 2 * (exponents
+// removed in between).  A vector whose largest element falls below 2^-900 between two refreshes
+// raises flags[2]; the host then repeats the E-step with the per-step normalisation.
+#define WIDE_TROUBLE_EXP (-900)
+// FULL: n == NP (no padded lanes; the row pitch is a constant)
+template <int NP, int KIND, bool LAZY = false, bool FULL = false>
 __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_t *off, const Segs sg,
                                                  const void *obs_rm, double *alpha_rm,
-                                                 double *logL_seg, double *a_entry, double *a_exit)
+                                                 double *logL_seg, double *a_entry, double *a_exit,
+                                                 unsigned int *flags = nullptr)
 {
     constexpr int GP = 64 / NP;
     __shared__ __attribute__((aligned(16))) double xch[GP][NP];
     const int lane = threadIdx.x;
     const int gi = lane / NP, j = lane % NP;
-    const int s = blockIdx.x * GP + gi;
+    // one segment per wavefront (64 states): everything about the segment is wave-uniform
+    const int s = (NP == 64) ? (int)blockIdx.x : (int)blockIdx.x * GP + gi;
     if (s >= sg.nseg)
         return;
-    const int n = m.n;
-    const bool real = j < n;
+    const int n = FULL ? NP : m.n;
+    const bool real = FULL || j < n;
     const int k = sg.traj[s];
     const int64_t o0 = off[k];
     const int64_t t0 = sg.t0[s], t1 = t0 + sg.len[s];
@@ -289,24 +330,30 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
     const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0; // warm-up start (0: exact start)
     double a = real ? 1.0 / (double)n : 0.0, P = 1.0;
     int eP = 0;
+    double S_start = 1.0; // LAZY: sum of the vector the segment starts from
+    bool trouble = false;
     WideIn ring[WIDE_PF];
 #pragma unroll
     for (int u = 0; u < WIDE_PF; ++u)
         ring[u] = wide_load<KIND>(m, j, real, o0 + (tw + u < t1 ? tw + u : t1 - 1), obs_rm);
-    for (int64_t tb = tw; tb < t1; tb += WIDE_PF) {
+    // steps are counted relative to the warm-up start in 32 bits (scalar compares)
+    const int nsteps = (int)(t1 - tw), r0 = (int)(t0 - tw);
+    const bool from_start = tw == 0;
+    for (int rb = 0; rb < nsteps; rb += WIDE_PF) {
 #pragma unroll
         for (int u = 0; u < WIDE_PF; ++u) {
-            const int64_t t = tb + u;
-            if (t >= t1)
+            const int r = rb + u;
+            if (r >= nsteps)
                 break;
+            const int64_t t = tw + r;
             const WideIn in = ring[u];
             {
-                const int64_t tn = t + WIDE_PF;
-                ring[u] = wide_load<KIND>(m, j, real, o0 + (tn < t1 ? tn : t1 - 1), obs_rm);
+                const int rn = r + WIDE_PF < nsteps ? r + WIDE_PF : nsteps - 1;
+                ring[u] = wide_load<KIND>(m, j, real, o0 + tw + rn, obs_rm);
             }
             const double p = wide_emit<NP, KIND>(m, j, real, in, mu_j, is_j, cn_j, gmask);
             double nj;
-            if (t == 0) {
+            if (from_start && r == 0) {
                 nj = pi_j * p;
             } else {
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -329,32 +376,63 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
                 }
                 nj = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * p;
             }
-            const double c = wgroup_sum<NP>(nj);
-            a = nj * fast_rcp(c);
-            if (t >= t0) {
-                int e;
-                P = frexp(P * c, &e);
-                eP += e;
-                if (real)
-                    alpha_rm[(o0 + t) * n + j] = a;
-            } else if (t == t0 - 1 && real) {
-                a_entry[(int64_t)s * n + j] = a; // the entry vector this segment derived
+            if constexpr (LAZY) {
+                a = nj;
+                if ((u & 3) == 3) {
+                    const int E = wgroup_max<NP>(a > 0.0 ? exponent_of(a) : -(1 << 28));
+                    trouble |= E < WIDE_TROUBLE_EXP;
+                    a = ldexp(a, -E);
+                    if (r >= r0)
+                        eP += E;
+                }
+                if (r >= r0) {
+                    if (real)
+                        alpha_rm[(o0 + t) * n + j] = a;
+                } else if (r == r0 - 1) {
+                    if (real)
+                        a_entry[(int64_t)s * n + j] = a;
+                    S_start = wgroup_sum<NP>(a);
+                }
+            } else {
+                const double c = wgroup_sum<NP>(nj);
+                a = nj * fast_rcp(c);
+                if (r >= r0) {
+                    int e;
+                    P = frexp(P * c, &e);
+                    eP += e;
+                    if (real)
+                        alpha_rm[(o0 + t) * n + j] = a;
+                } else if (r == r0 - 1 && real) {
+                    a_entry[(int64_t)s * n + j] = a; // the entry vector this segment derived
+                }
             }
         }
     }
     if (real)
         a_exit[(int64_t)s * n + j] = a;
-    if (j == 0)
-        logL_seg[s] = log(P) + (double)eP * 0.693147180559945309417232121458;
+    if constexpr (LAZY) {
+        const double S_end = wgroup_sum<NP>(a);
+        trouble |= !(S_end > 0.0) || !(S_start > 0.0);
+        if (j == 0) {
+            logL_seg[s] = (log(S_end) - log(S_start)) + (double)eP * 0.693147180559945309417232121458;
+            if (trouble)
+                atomicOr(&flags[2], 1u);
+        }
+    } else {
+        if (j == 0)
+            logL_seg[s] = log(P) + (double)eP * 0.693147180559945309417232121458;
+    }
 }
 
 // statistics per segment: [n*n C' rows | n sum gamma | (gauss) n sum gamma d | n sum gamma d^2]
 // discrete symbol table: [nseg][n][M] (dstat)
-template <int NP, int KIND>
+// LAZY: beta is refreshed to a power of two every fourth step instead of every step (see k_wide_fwd)
+template <int NP, int KIND, bool LAZY = false, bool FULL = false>
 __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_t *off, const Segs sg,
                                                  const void *obs_rm, const double *alpha_rm,
                                                  double *gamma_rm, double *gamma0, double *part,
-                                                 double *dstat, double *b_exit, double *b_entry)
+                                                 double *dstat, double *b_exit, double *b_entry,
+                                                 unsigned int *flags = nullptr)
 {
     constexpr int GP = 64 / NP;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -365,7 +443,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
     double *xb = smem + NP * PITCH;             // [GP][NP]  (NP * PITCH is even: 16-byte aligned)
     const int lane = threadIdx.x;
     const int gi = lane / NP, i = lane % NP;
-    const int n = m.n;
+    const int n = FULL ? NP : m.n;
     if constexpr (NP < 64) {
         for (int e = lane; e < NP * NP; e += 64) {
             const int r = e / NP, c = e % NP;
@@ -373,10 +451,10 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         }
         __syncthreads();
     }
-    const int s = blockIdx.x * GP + gi;
+    const int s = (NP == 64) ? (int)blockIdx.x : (int)blockIdx.x * GP + gi;
     if (s >= sg.nseg)
         return;
-    const bool real = i < n;
+    const bool real = FULL || i < n;
     const int k = sg.traj[s];
     const int64_t o0 = off[k];
     const int64_t T = off[k + 1] - o0;
@@ -458,8 +536,11 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
             }
             return (acc[0] + acc[1]) + (acc[2] + acc[3]);
         };
+        bool trouble = false;
         auto rescale = [&](double br) {
             const int E = wgroup_max<NP>(br > 0.0 ? exponent_of(br) : -(1 << 28));
+            if constexpr (LAZY)
+                trouble |= E < WIDE_TROUBLE_EXP;
             return ldexp(br, -E);
         };
 
@@ -470,19 +551,22 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
 #pragma unroll
             for (int u = 0; u < WIDE_PF; ++u)
                 ring[u] = wide_load<KIND>(m, i, real, o0 + (te - u > t1 ? te - u : t1), obs_rm);
-            for (int64_t tb = te; tb >= t1; tb -= WIDE_PF) {
+            const int nwarm = (int)(te - t1) + 1;
+            for (int rb = 0; rb < nwarm; rb += WIDE_PF) {
 #pragma unroll
                 for (int u = 0; u < WIDE_PF; ++u) {
-                    const int64_t t = tb - u;
-                    if (t < t1)
+                    const int r = rb + u;
+                    if (r >= nwarm)
                         break;
                     const WideIn in = ring[u];
                     {
-                        const int64_t tn = t - WIDE_PF;
-                        ring[u] = wide_load<KIND>(m, i, real, o0 + (tn > t1 ? tn : t1), obs_rm);
+                        const int rn = r + WIDE_PF < nwarm ? r + WIDE_PF : nwarm - 1;
+                        ring[u] = wide_load<KIND>(m, i, real, o0 + te - rn, obs_rm);
                     }
                     const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, is_i, cn_i, gmask);
-                    b = rescale(back(p, b));
+                    b = back(p, b);
+                    if (!LAZY || (u & 3) == 3)
+                        b = rescale(b);
                 }
             }
             if (real)
@@ -497,23 +581,28 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         // rings: observation of step t and alpha of step t - 1, WIDE_PF steps ahead
         WideIn ro[WIDE_PF];
         double ra[WIDE_PF];
-        auto fetch = [&](int u, int64_t t) {
-            const int64_t tt = t > t0 ? t : t0;
+        const int nmain = (int)(t1 - t0); // step r of the loop is t = t1 - 1 - r
+        auto fetch = [&](int u, int r) {
+            const int64_t tt = t1 - 1 - (r < nmain ? r : nmain - 1);
             ro[u] = wide_load<KIND>(m, i, real, o0 + tt, obs_rm);
             ra[u] = real ? alpha_rm[(o0 + (tt > 0 ? tt - 1 : 0)) * n + i] : 0.0;
         };
 #pragma unroll
         for (int u = 0; u < WIDE_PF; ++u)
-            fetch(u, t1 - 1 - u);
-        for (int64_t tb = t1 - 1; tb >= t0; tb -= WIDE_PF) {
+            fetch(u, u);
+        const bool to_start = t0 == 0;
+        for (int rb = 0; rb < nmain; rb += WIDE_PF) {
 #pragma unroll
             for (int u = 0; u < WIDE_PF; ++u) {
-                const int64_t t = tb - u;
-                if (t < t0)
-                    break;
+                const int r = rb + u;
+                // no early exit: the matrix-core accumulators must have one definition per
+                // iteration (a second loop exit makes the compiler copy all 128 of them)
+                if (r < nmain) {
+                const int64_t t = t1 - 1 - r;
+                const bool last = r == nmain - 1;
                 const WideIn in = ro[u];
                 const double ap = ra[u];
-                fetch(u, t - WIDE_PF);
+                fetch(u, r + WIDE_PF);
                 const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, is_i, cn_i, gmask);
                 // consume gamma_t
                 sgm += gam;
@@ -528,7 +617,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                         mytab[(int64_t)i * m.M + in.sym] += gam; // row i is private to this lane
                 if (gamma_rm && real)
                     gamma_rm[(o0 + t) * n + i] = gam;
-                if (t == 0) { // the last step of the loop (t0 == 0)
+                if (to_start && last) { // t == 0
                     if (real)
                         gamma0[(int64_t)k * n + i] = gam;
                 } else {
@@ -540,8 +629,6 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                     if constexpr (NP == 64) {
                         wq[u & 3] = w;
                         xq[u & 3] = xcur;
-                        if ((u & 3) == 3)
-                            xi_flush();
                     } else {
 #pragma unroll
                         for (int c = 0; c < NP; c += 2) {
@@ -550,15 +637,21 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                             Crow[c + 1] = fma(w, x.y, Crow[c + 1]);
                         }
                     }
-                    b = rescale(br);
-                    if (t == t0 && real) // beta one step before this segment, as derived here
+                    b = (!LAZY || (u & 3) == 3) ? rescale(br) : br;
+                    if (last && real) // beta one step before this segment, as derived here
                         b_entry[(int64_t)s * n + i] = b;
                 }
+                }
+                if constexpr (NP == 64)
+                    if ((u & 3) == 3)
+                        xi_flush(); // slots of steps that did not run hold w = 0
             }
         }
+        if constexpr (LAZY)
+            if (trouble && i == 0)
+                atomicOr(&flags[2], 1u);
     }
     if constexpr (NP == 64) {
-        xi_flush(); // the steps of an incomplete group of four (empty slots hold w = 0)
         // C / D layout of v_mfma_f64_16x16x4: column = lane & 15, row = (lane >> 4) + 4 r
 #pragma unroll
         for (int I = 0; I < 4; ++I)
@@ -567,7 +660,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * I + (lane >> 4) + 4 * r, col = 16 * J + (lane & 15);
-                    if (row < n && col < n)
+                    if (FULL || (row < n && col < n))
                         mypart[(int64_t)row * n + col] = Cacc[I][J][r];
                 }
     }

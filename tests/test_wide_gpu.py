@@ -214,3 +214,37 @@ def test_wide_time_segments_verified_or_fallback():
     res = eng.estep(A, pi, B)
     _check(res, ref)
     eng.close()
+
+
+def test_wide64_segments_lazy_scaling_and_mfma_counts():
+    """64 states, time segments: the kernels that run here carry alpha / beta lazily scaled,
+    multiply on DPP row broadcasts and accumulate the transition counts on the matrix cores.
+    Result = the serial reference recursion; a stretch of observations ~35 sigma away from every
+    state drives the lazily scaled vectors out of range, which must be noticed and repeated with
+    the per-step normalisation."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(77)
+    n = 64
+    A, pi, mu, sig = _random_model(n, rng, "gaussian")
+    obs = [rng.normal(0, 4, T) for T in (6001, 500, 3, 2500, 1)]
+    for far, careful in ((False, 0.0), (True, 1.0)):
+        if far:
+            obs[0][3000:3007] = 47.0 + rng.normal(0, 0.1, 7)
+            obs[3][100:104] = -46.0
+        ref = orc.estep("gaussian", obs, A, pi, mu, sig, want_gamma=True)
+        eng = Engine(0)
+        eng.set_option("wide_segment_len", 500)
+        eng.set_option("spec_W", 200)
+        eng.set_observations("gaussian", obs, n)
+        assert eng.get_option("wide_segments") > len(obs)
+        res = eng.estep(A, pi, mu, sig, store_gamma=True)
+        assert eng.get_option("spec_ok") >= 1 and eng.get_option("spec_fail") == 0
+        assert eng.get_option("careful") == careful
+        _check(res, ref)
+        for k in (0, 3):
+            np.testing.assert_allclose(eng.gamma(k), ref["gammas"][k], rtol=1e-8, atol=1e-13)
+        sd = sum((g * (o[:, None] - mu[None, :])).sum(axis=0) for o, g in zip(obs, ref["gammas"]))
+        np.testing.assert_allclose(res.sum_gd, sd, rtol=1e-8, atol=1e-9)
+        r2 = eng.estep(A, pi, mu, sig)
+        assert np.array_equal(res.packed, r2.packed)
+        eng.close()
