@@ -248,3 +248,87 @@ def test_wide64_segments_lazy_scaling_and_mfma_counts():
         r2 = eng.estep(A, pi, mu, sig)
         assert np.array_equal(res.packed, r2.packed)
         eng.close()
+
+
+def test_configs3_full_size_properties():
+    """BASELINE configs[3] shape (64 states, 128 x 1e5 Gaussian), size-independent checks:
+    (1) sum gamma = K T, sum C = K (T - 1), sum gamma_0 = K;  (2) the time-segmented run (lazy
+    scaling, DPP products, counts on the matrix cores, verified warm-up boundaries) equals the
+    serial plan (one segment per trajectory, per-step normalisation);  (3) one trajectory
+    against the oracle."""
+    import torch
+    from bench import metastable_matrix, stationary
+    from bhmm_amd.engine import Engine
+    n, K, T = 64, 128, 100000
+    rng = np.random.default_rng(64)
+    A = metastable_matrix(n, rng)
+    pi = stationary(A)
+    mu, sig = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    dwell = 50
+    s = torch.randint(0, n, (K, T // dwell), device="cuda:0", generator=g).repeat_interleave(dwell, dim=1)
+    obs = (torch.tensor(mu, device="cuda:0")[s] + torch.tensor(sig, device="cuda:0")[s]
+           * torch.randn((K, T), device="cuda:0", dtype=torch.float64, generator=g)).reshape(-1)
+    off = np.arange(K + 1, dtype=np.int64) * T
+    args = (0.9 * A + 0.1 / n, pi, mu + 0.05, sig)
+    eng = Engine(0)
+    eng.set_observations_device("gaussian", obs.data_ptr(), off, n)
+    assert eng.get_option("wide_segments") >= 1024
+    for _ in range(4):                      # the segment plan settles on a warm-up that verifies
+        res = eng.estep(*args)
+        if eng.get_option("spec_ok") >= 1:
+            break
+    assert eng.get_option("spec_ok") >= 1 and eng.get_option("spec_last_dev") < 1e-11
+    assert eng.get_option("careful") == 0.0
+    assert np.all(np.isfinite(res.logL_k))
+    np.testing.assert_allclose(res.state_counts.sum(), K * T, rtol=1e-10)
+    np.testing.assert_allclose(res.C.sum(), K * (T - 1), rtol=1e-10)
+    np.testing.assert_allclose(res.gamma0_sum.sum(), K, rtol=1e-10)
+    ser = Engine(0)
+    ser.set_option("wide_segments", 0)
+    ser.set_observations_device("gaussian", obs.data_ptr(), off, n)
+    assert ser.get_option("wide_segments") == 0
+    rs = ser.estep(*args)
+    np.testing.assert_allclose(res.logL_k, rs.logL_k, rtol=1e-11)
+    np.testing.assert_allclose(res.C, rs.C, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(res.state_counts, rs.state_counts, rtol=1e-9)
+    np.testing.assert_allclose(res.sum_gd, rs.sum_gd, rtol=1e-7, atol=1e-6)
+    np.testing.assert_allclose(res.sum_gdd, rs.sum_gdd, rtol=1e-8)
+    o0 = obs[:T].cpu().numpy()
+    ref = orc.estep("gaussian", [o0], *args)
+    np.testing.assert_allclose(res.logL_k[0], ref["logL"][0], rtol=1e-11)
+    eng.close()
+    ser.close()
+    del obs, s
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_wide64_segmented_fuzz(seed):
+    """Randomised 64-state problems on the segmented plan: ragged lengths (shorter than a group
+    of four steps, shorter than the warm-up, not a multiple of the segment length), random
+    segment length and warm-up, n = 64 and n < 64 padded to 64 lanes.  The result must equal the
+    oracle whether the boundaries verify or the serial plan takes over, and repeat bit-for-bit."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(1000 + seed)
+    n = (64, 50, 64)[seed - 1]
+    A, pi, mu, sig = _random_model(n, rng, "gaussian")
+    lengths = [int(x) for x in rng.integers(1, 40, 4)] + [int(x) for x in rng.integers(300, 3000, 3)] + [1, 2, 5]
+    rng.shuffle(lengths)
+    obs = [rng.normal(0, 4, T) for T in lengths]
+    ref = orc.estep("gaussian", obs, A, pi, mu, sig, want_gamma=True)
+    eng = Engine(0)
+    eng.set_option("wide_segment_len", int(rng.integers(37, 400)))
+    eng.set_option("spec_W", int(rng.integers(120, 260)))
+    eng.set_observations("gaussian", obs, n)
+    assert eng.get_option("wide_segments") > len(obs)
+    res = eng.estep(A, pi, mu, sig, store_gamma=True)
+    _check(res, ref)
+    k = int(np.argmax(lengths))
+    np.testing.assert_allclose(eng.gamma(k), ref["gammas"][k], rtol=1e-8, atol=1e-13)
+    r2 = eng.estep(A, pi, mu, sig, store_gamma=True)
+    _check(r2, ref)
+    r3 = eng.estep(A, pi, mu, sig, store_gamma=True)
+    assert np.array_equal(r2.packed, r3.packed)
+    eng.close()
