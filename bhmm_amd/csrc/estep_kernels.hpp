@@ -889,7 +889,7 @@ __device__ __forceinline__ void logl_one(int k, const int32_t *traj_c0, const do
     }
 }
 
-static __global__ __launch_bounds__(64) void k_logl(const int32_t *traj_c0, int K,
+[[maybe_unused]] static __global__ __launch_bounds__(64) void k_logl(const int32_t *traj_c0, int K,
                                                     const double *logL_chunk, double *logL_k)
 {
     logl_one(blockIdx.x, traj_c0, logL_chunk, logL_k);

@@ -52,7 +52,7 @@ __device__ __forceinline__ double exp_nonpos(double x)
     return ldexp(q, (int)k);
 }
 
-static __global__ void k_exp_nonpos(const double *x, double *y, int64_t n)
+[[maybe_unused]] static __global__ void k_exp_nonpos(const double *x, double *y, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)

@@ -95,6 +95,11 @@ __device__ __forceinline__ void swap16_f64(double &x, double &y)
     y = __hiloint2double((int)hi.y, (int)lo.y);
 }
 
+// NP = 32 (two segments per wavefront, rows 0-1 and 2-3): r[k], k = 0 / 1, holds in every row of
+// a segment that segment's row k.  NP = 16: a row is a segment, the vector itself.
+template <int NP>
+__device__ __forceinline__ Rows4 rows_of_group(double v);
+
 // r[k]: every row of 16 lanes holds row k of v
 __device__ __forceinline__ Rows4 rows_of(double v)
 {
@@ -121,6 +126,26 @@ __device__ __forceinline__ void rows_transpose4(double (&v)[4])
 }
 
 typedef double wide_d4 __attribute__((ext_vector_type(4)));
+
+template <int NP>
+__device__ __forceinline__ Rows4 rows_of_group(double v)
+{
+    if constexpr (NP == 64) {
+        return rows_of(v);
+    } else if constexpr (NP == 32) {
+        Rows4 o;
+        o.r[0] = v;
+        o.r[1] = v;
+        swap16_f64(o.r[0], o.r[1]); // rows (0,0,2,2) and (1,1,3,3)
+        o.r[2] = o.r[3] = 0.0;
+        return o;
+    } else {
+        Rows4 o;
+        o.r[0] = v;
+        o.r[1] = o.r[2] = o.r[3] = 0.0;
+        return o;
+    }
+}
 
 template <int I, bool FIRST>
 __device__ __forceinline__ void fmac_bcast(double &acc, const double &src, const double &w)
@@ -300,7 +325,6 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
                                                  unsigned int *flags = nullptr)
 {
     constexpr int GP = 64 / NP;
-    __shared__ __attribute__((aligned(16))) double xch[GP][NP];
     const int lane = threadIdx.x;
     const int gi = lane / NP, j = lane % NP;
     // one segment per wavefront (64 states): everything about the segment is wave-uniform
@@ -357,22 +381,14 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
                 nj = pi_j * p;
             } else {
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                if constexpr (NP == 64) {
-                    const Rows4 ar = rows_of(a);
-                    unrolled<4>([&](auto rc) {
+                {
+                    const Rows4 ar = rows_of_group<NP>(a);
+                    unrolled<NP / 16>([&](auto rc) {
                         constexpr int r = decltype(rc)::value;
                         dot16(acc, ar.r[r], [&](auto ic) -> const double & {
                             return Acol[16 * r + decltype(ic)::value];
                         });
                     });
-                } else {
-                    xch[gi][j] = a;
-#pragma unroll
-                    for (int i = 0; i < NP; i += 2) {
-                        const double2 x = *reinterpret_cast<const double2 *>(&xch[gi][i]);
-                        acc[(i / 2) & 3] = fma(x.x, Acol[i], acc[(i / 2) & 3]);
-                        acc[(i / 2) & 3] = fma(x.y, Acol[i + 1], acc[(i / 2) & 3]);
-                    }
                 }
                 nj = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * p;
             }
@@ -440,7 +456,6 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
     // 16-byte pieces without bank conflicts; otherwise NP + 1 and 8-byte pieces.
     constexpr int PITCH = wide_pitch(NP);
     double *sA = smem;                          // [NP][PITCH]
-    double *xb = smem + NP * PITCH;             // [GP][NP]  (NP * PITCH is even: 16-byte aligned)
     const int lane = threadIdx.x;
     const int gi = lane / NP, i = lane % NP;
     const int n = FULL ? NP : m.n;
@@ -511,9 +526,9 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         const double is_i = (KIND == EMIT_GAUSS && real) ? m.isig[i] : 0.0;
         const double cn_i = (KIND == EMIT_GAUSS && real) ? m.cnorm[i] : 0.0;
         const double *arow = sA + i * PITCH;
-        double *xg = xb + gi * NP;
         // one backward step: b <- A (p o b), rescaled by a power of two; returns A (p o b)[i]
-        double xcur = 0.0; // 64 states: p o b of the current step (back() sets it)
+        double xcur = 0.0; // p o b of the current step (back() sets it)
+        Rows4 xrows;       // fewer than 64 states: its row copies
         auto back = [&](double p, double b) {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             if constexpr (NP == 64) {
@@ -526,13 +541,20 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                     });
                 });
             } else {
-                xg[i] = p * b;
+                // A's row from LDS (NP doubles per lane do not fit beside the xi row), p o b on
+                // DPP row broadcasts
+                xcur = p * b;
+                xrows = rows_of_group<NP>(xcur);
+                unrolled<NP / 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    double av[16];
 #pragma unroll
-                for (int c = 0; c < NP; c += 2) {
-                    const double2 x = *reinterpret_cast<const double2 *>(&xg[c]);
-                    acc[(c / 2) & 3] = fma(arow[c], x.x, acc[(c / 2) & 3]);
-                    acc[(c / 2) & 3] = fma(arow[c + 1], x.y, acc[(c / 2) & 3]);
-                }
+                    for (int q = 0; q < 16; ++q)
+                        av[q] = arow[16 * r + q];
+                    dot16(acc, xrows.r[r], [&](auto ic) -> const double & {
+                        return av[decltype(ic)::value];
+                    });
+                });
             }
             return (acc[0] + acc[1]) + (acc[2] + acc[3]);
         };
@@ -630,12 +652,13 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                         wq[u & 3] = w;
                         xq[u & 3] = xcur;
                     } else {
-#pragma unroll
-                        for (int c = 0; c < NP; c += 2) {
-                            const double2 x = *reinterpret_cast<const double2 *>(&xg[c]);
-                            Crow[c] = fma(w, x.x, Crow[c]);
-                            Crow[c + 1] = fma(w, x.y, Crow[c + 1]);
-                        }
+                        unrolled<NP / 16>([&](auto rc) {
+                            constexpr int r = decltype(rc)::value;
+                            unrolled<16>([&](auto ic) {
+                                constexpr int c = decltype(ic)::value;
+                                fmac_bcast<c, c == 0>(Crow[16 * r + c], xrows.r[r], w);
+                            });
+                        });
                     }
                     b = (!LAZY || (u & 3) == 3) ? rescale(br) : br;
                     if (last && real) // beta one step before this segment, as derived here
@@ -680,7 +703,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
 }
 
 // boundary consistency of a segmented run (see k_spec_check): one thread per segment
-static __global__ void k_wide_check(const Segs sg, int n, const double *a_entry,
+[[maybe_unused]] static __global__ void k_wide_check(const Segs sg, int n, const double *a_entry,
                                     const double *a_exit, const double *b_exit,
                                     const double *b_entry, double tol, unsigned int *result)
 {
@@ -870,7 +893,7 @@ __global__ __launch_bounds__(64) void k_wide_xi(const double *A, const double *p
                 part[((int64_t)slab * n + i) * n + c] = Crow[c];
 }
 
-static __global__ __launch_bounds__(64) void k_wide_xi_sum(const double *A, const double *part,
+[[maybe_unused]] static __global__ __launch_bounds__(64) void k_wide_xi_sum(const double *A, const double *part,
                                                            int n, int nslab, double *C)
 {
     const int e = blockIdx.x;
