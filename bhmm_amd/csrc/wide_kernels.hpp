@@ -604,6 +604,10 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         WideIn ro[WIDE_PF];
         double ra[WIDE_PF];
         const int nmain = (int)(t1 - t0); // step r of the loop is t = t1 - 1 - r
+        constexpr bool SPARSE_SUM = LAZY && NP == 64;
+        // alpha_t was rescaled by the forward pass where (t - tw) % 4 == 3, tw its warm-up start
+        const int phase = (int)((t1 - 1 - ((t0 - sg.W > 0) ? t0 - sg.W : 0)) & 3);
+        double rS_keep = 0.0;
         auto fetch = [&](int u, int r) {
             const int64_t tt = t1 - 1 - (r < nmain ? r : nmain - 1);
             ro[u] = wide_load<KIND>(m, i, real, o0 + tt, obs_rm);
@@ -645,7 +649,17 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                 } else {
                     const double br = back(p, b);
                     const double q = ap * br;
-                    const double rS = fast_rcp(wgroup_sum<NP>(q));
+                    // sum_i alpha_{t-1}[i] (A (p_t o beta_t))[i] = sum_j alpha_t[j] beta_t[j]: as long as
+                    // neither vector has been rescaled, the normaliser of gamma is the one of the
+                    // step before.  The lazily scaled forward pass rescales every fourth step (known
+                    // phase) and beta is rescaled on the same steps here, so three of four steps reuse
+                    // the reciprocal (64 states; the chain restarts after four steps: no drift).
+                    bool need = true;
+                    if constexpr (SPARSE_SUM)
+                        need = r == 0 || last || ((phase - r) & 3) == 3;
+                    if (need)
+                        rS_keep = fast_rcp(wgroup_sum<NP>(q));
+                    const double rS = rS_keep;
                     gam = q * rS;
                     const double w = ap * rS;
                     if constexpr (NP == 64) {
@@ -660,7 +674,10 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                             });
                         });
                     }
-                    b = (!LAZY || (u & 3) == 3) ? rescale(br) : br;
+                    bool refresh = !LAZY || (u & 3) == 3;
+                    if constexpr (SPARSE_SUM)
+                        refresh = ((phase - (r + 1)) & 3) == 3;
+                    b = refresh ? rescale(br) : br;
                     if (last && real) // beta one step before this segment, as derived here
                         b_entry[(int64_t)s * n + i] = b;
                 }
