@@ -120,6 +120,7 @@ struct bhmm_ctx {
     bhmm::DevBuf<int64_t> d_wseg_t0[2];
     bhmm::DevBuf<double> d_wlogLseg, d_waentry, d_waexit, d_wbexit, d_wbentry;
     bool wseg_enabled = true;
+    int64_t wseg_cur_len = 0;   // segment length of plan 1 (re-plans only lengthen: buffers are sized once)
     int wseg_len = 0;                // 0 = automatic
     double *h_raw = nullptr;         // pinned: [verdict words, 2 sets (4 doubles) | stats | logL_k]
     double *h_pinned = nullptr;      // = h_raw + 4: stats + logL_k landing zone

@@ -206,6 +206,7 @@ int wide_alloc(bhmm_ctx *c)
         int64_t maxT = 0;
         for (int k = 0; k < c->K; ++k)
             maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+        c->wseg_cur_len = seglen;
         if (c->wseg_enabled && maxT > seglen && (rc = wide_plan(c, 1, seglen)))
             return rc;
     }
@@ -226,6 +227,63 @@ int wide_alloc(bhmm_ctx *c)
                                hipHostMallocDefault));
     BHMM_HIP(hipMemsetAsync(c->d_gamma0.p, 0, (size_t)std::max(c->K, 1) * n * sizeof(double),
                             c->stream));
+    return BHMM_OK;
+}
+
+// Measure the forgetting curve (k_wide_probe) and set the warm-up length of the time segments
+// from it: W = first length after which two chains started differently agree to 1e-13 at every
+// sampled position, + 15 %.  W_out = 0: no statement (trajectories too short, curve not below
+// the target within Wmax).
+template <int NP, int KIND>
+static int wide_probe_run(bhmm_ctx *c, const WideModel &m, int *W_out)
+{
+    *W_out = 0;
+    int64_t maxT = 0;
+    for (int k = 0; k < c->K; ++k)
+        maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+    const int Wmax = (int)std::min<int64_t>(8192, maxT / 2) / 8 * 8;
+    if (Wmax < 64)
+        return BHMM_OK;
+    std::vector<int> longk;
+    for (int k = 0; k < c->K; ++k)
+        if (c->offsets[k + 1] - c->offsets[k] >= Wmax)
+            longk.push_back(k);
+    const int S = 256;
+    std::vector<int64_t> starts(S);
+    for (int i = 0; i < S; ++i) { // positions relative to the first observation of the context
+        const int k = longk[i % longk.size()];
+        const int64_t room = c->offsets[k + 1] - c->offsets[k] - Wmax + 1;
+        const int64_t rep = i / (int64_t)longk.size(), reps = (S + longk.size() - 1) / longk.size();
+        starts[i] = c->offsets[k] + (room - 1) * rep / std::max<int64_t>(reps - 1, 1);
+    }
+    const size_t bytes = S * sizeof(int64_t) + 2 * (size_t)Wmax * sizeof(unsigned int);
+    int rc;
+    if ((rc = c->d_probe.ensure(bytes)))
+        return rc;
+    int64_t *d_starts = reinterpret_cast<int64_t *>(c->d_probe.p);
+    unsigned int *d_curve = reinterpret_cast<unsigned int *>(d_starts + S);
+    BHMM_HIP(hipMemcpyAsync(d_starts, starts.data(), S * sizeof(int64_t), hipMemcpyHostToDevice,
+                            c->stream));
+    BHMM_HIP(hipMemsetAsync(d_curve, 0, 2 * (size_t)Wmax * sizeof(unsigned int), c->stream));
+    constexpr int GP = 64 / NP;
+    hipLaunchKernelGGL((k_wide_probe<NP, KIND>), dim3((2 * S + GP - 1) / GP), dim3(64), 0, c->stream, m,
+                       (const void *)c->d_obs_rm.p, (const int64_t *)d_starts, S, Wmax, d_curve);
+    BHMM_HIP(hipGetLastError());
+    std::vector<float> curve(2 * (size_t)Wmax);
+    BHMM_HIP(hipMemcpyAsync(curve.data(), d_curve, curve.size() * sizeof(float), hipMemcpyDeviceToHost,
+                            c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream)); // starts / curve are temporaries
+    int last = -1;
+    for (int w = 0; w < Wmax; ++w)
+        if (std::max(curve[w], curve[Wmax + w]) >= 1e-13f)
+            last = w;
+    if (last + 2 >= Wmax)
+        return BHMM_OK; // not forgotten within Wmax: no statement
+    // the boundary check looks at every segment boundary, the probe at S positions: the worst
+    // boundary lags the worst sample (measured: 1.3x in warm-up steps); an E-step that fails the
+    // check costs eight good ones, a longer warm-up a few per cent
+    int W = (int)std::ceil(1.5 * (last + 2));
+    *W_out = std::max(16, (W + 7) / 8 * 8);
     return BHMM_OK;
 }
 
@@ -283,6 +341,45 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
         return BHMM_OK;
     };
+    if (c->wseg_enabled && !c->spec_calibrated && c->w_nseg[1] > c->w_nseg[0]) {
+        // first E-step on these observations: measure how fast this model forgets and plan the
+        // segments for that warm-up length (at least four warm-ups long, or what fills the chip)
+        c->spec_calibrated = true;
+        int W = 0;
+        switch (c->kind) {
+        case EMIT_GAUSS:
+            rc = WIDE_DISPATCH(c, EMIT_GAUSS, wide_probe_run, c, m, &W);
+            break;
+        case EMIT_DISC:
+            rc = WIDE_DISPATCH(c, EMIT_DISC, wide_probe_run, c, m, &W);
+            break;
+        default:
+            rc = WIDE_DISPATCH(c, EMIT_EXPL, wide_probe_run, c, m, &W);
+        }
+        if (rc)
+            return rc;
+        const int W_planned = c->spec_W;
+        if (W > 0)
+            c->spec_W = W;
+        if (W > W_planned) { // longer warm-ups than the plan assumed: longer segments
+            int64_t maxT = 0;
+            for (int k = 0; k < c->K; ++k)
+                maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+            int64_t seglen = c->wseg_len;
+            if (seglen <= 0)
+                seglen = std::max<int64_t>(wide_fill_len(c), 4 * (int64_t)W);
+            seglen = std::max(seglen, c->wseg_cur_len); // never more segments than allocated for
+            if (seglen >= maxT) {
+                c->wseg_given_up = true;
+            } else if (seglen > c->wseg_cur_len) {
+                c->wseg_cur_len = seglen;
+                if ((rc = wide_plan(c, 1, seglen)))
+                    return rc;
+                if (c->w_nseg[1] <= c->w_nseg[0])
+                    c->wseg_given_up = true;
+            }
+        }
+    }
     if (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) {
         // time-segmented run with warm-up boundaries, verified afterwards
         // lazily scaled kernels unless an earlier E-step on these data left their range
@@ -328,13 +425,17 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         int64_t seglen = c->wseg_len > 0 ? (int64_t)c->wseg_len : 4 * Wn;
         if (c->wseg_len <= 0)
             seglen = std::max(seglen, wide_fill_len(c));
+        seglen = std::max(seglen, c->wseg_cur_len); // never more segments than allocated for
         if (c->wide_replans >= 3 || seglen >= maxT || Wn >= maxT / 2) {
             c->wseg_given_up = true;
         } else {
             ++c->wide_replans;
             c->spec_W = (int)Wn;
-            if ((rc = wide_plan(c, 1, seglen)))
-                return rc;
+            if (seglen > c->wseg_cur_len) {
+                c->wseg_cur_len = seglen;
+                if ((rc = wide_plan(c, 1, seglen)))
+                    return rc;
+            }
             if (c->w_nseg[1] <= c->w_nseg[0])
                 c->wseg_given_up = true;
         }

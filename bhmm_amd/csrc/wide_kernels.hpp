@@ -719,6 +719,73 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
     }
 }
 
+// =========================================================================================
+// k_wide_probe: the forgetting curve of THIS model on THIS data for 9..64 states (the role of
+// k_forget_probe for N <= 8).  One lane group per (sample position, direction): the forward
+// (dir 0) or backward (dir 1) recursion runs over the same stretch of observations from two
+// start vectors -- uniform / all mass on one state -- and curve[dir][w] receives the largest
+// componentwise relative deviation between the two normalised vectors after w + 1 steps (float
+// bits, maximum over the samples).  The host reads the warm-up length of the time segments off
+// the curve before the first E-step instead of finding it by a failed boundary check.
+// =========================================================================================
+template <int NP, int KIND>
+__global__ __launch_bounds__(64) void k_wide_probe(const WideModel m, const void *obs_rm,
+                                                   const int64_t *starts, int S, int Wmax,
+                                                   unsigned int *curve)
+{
+    constexpr int GP = 64 / NP;
+    const int lane = threadIdx.x;
+    const int gi = lane / NP, j = lane % NP;
+    const int id = blockIdx.x * GP + gi;
+    const bool act = id < 2 * S;
+    const int dir = act ? id / S : 0, idx = act ? id % S : 0;
+    const int n = m.n;
+    const bool real = j < n;
+    const unsigned long long gmask = wgroup_mask<NP>(lane);
+    const int64_t pos0 = starts[idx];
+    // dir 0: column j of A (new_j = sum_c v_c A[c][j]); dir 1: row j (new_j = sum_c A[j][c] v_c)
+    double Areg[NP];
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+        Areg[c] = (real && c < n) ? (dir == 0 ? m.A[(int64_t)c * n + j] : m.A[(int64_t)j * n + c]) : 0.0;
+    const double mu_j = (KIND == EMIT_GAUSS && real) ? m.mu[j] : 0.0;
+    const double is_j = (KIND == EMIT_GAUSS && real) ? m.isig[j] : 0.0;
+    const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
+    double x = real ? 1.0 / (double)n : 0.0, y = (j == idx % n) ? 1.0 : 0.0;
+    auto matvec = [&](double v) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        const Rows4 vr = rows_of_group<NP>(v);
+        unrolled<NP / 16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            dot16(acc, vr.r[r], [&](auto ic) -> const double & {
+                return Areg[16 * r + decltype(ic)::value];
+            });
+        });
+        return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    };
+    for (int w = 0; w < Wmax; ++w) {
+        const int64_t t = dir == 0 ? pos0 + w : pos0 + Wmax - 1 - w;
+        const WideIn in = wide_load<KIND>(m, j, real, t, obs_rm);
+        const double p = wide_emit<NP, KIND>(m, j, real, in, mu_j, is_j, cn_j, gmask);
+        auto step = [&](double v) {
+            const double r = dir == 0 ? matvec(v) * p : matvec(p * v);
+            return r * fast_rcp(wgroup_sum<NP>(r));
+        };
+        x = step(x);
+        y = step(y);
+        const double d = fabs(x - y), lo = fmin(x, y);
+        double dev = lo > 1e-280 ? d / lo : (d > 1e-280 ? 1.0 : 0.0);
+        if (!(dev == dev))
+            dev = 1.0;
+        dev = fmin(dev, 1.0);
+        const int devmax = wgroup_max<NP>(__float_as_int((float)dev)); // non-negative floats order as ints
+        if (act && j == 0)
+            atomicMax(&curve[dir * Wmax + w], (unsigned int)devmax);
+        if (__all(__int_as_float(devmax) < 1e-14f)) // every chain of the wavefront has merged
+            break;
+    }
+}
+
 // boundary consistency of a segmented run (see k_spec_check): one thread per segment
 [[maybe_unused]] static __global__ void k_wide_check(const Segs sg, int n, const double *a_entry,
                                     const double *a_exit, const double *b_exit,
