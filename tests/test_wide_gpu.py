@@ -275,11 +275,9 @@ def test_configs3_full_size_properties():
     eng = Engine(0)
     eng.set_observations_device("gaussian", obs.data_ptr(), off, n)
     assert eng.get_option("wide_segments") >= 1024
-    for _ in range(4):                      # the segment plan settles on a warm-up that verifies
-        res = eng.estep(*args)
-        if eng.get_option("spec_ok") >= 1:
-            break
-    assert eng.get_option("spec_ok") >= 1 and eng.get_option("spec_last_dev") < 1e-11
+    res = eng.estep(*args)                  # the probe sets a warm-up that verifies at once
+    assert eng.get_option("spec_ok") == 1 and eng.get_option("spec_fail") == 0
+    assert eng.get_option("spec_last_dev") < 1e-11 and eng.get_option("spec_W") != 288
     assert eng.get_option("careful") == 0.0
     assert np.all(np.isfinite(res.logL_k))
     np.testing.assert_allclose(res.state_counts.sum(), K * T, rtol=1e-10)
@@ -331,4 +329,32 @@ def test_wide64_segmented_fuzz(seed):
     _check(r2, ref)
     r3 = eng.estep(A, pi, mu, sig, store_gamma=True)
     assert np.array_equal(r2.packed, r3.packed)
+    eng.close()
+
+
+def test_wide_probe_sets_warmup_before_first_estep():
+    """Default options, 24 states (32 lanes per segment): the forgetting-curve probe measures the
+    warm-up length on the data, the first E-step already verifies its segment boundaries, and the
+    result is the oracle's."""
+    from bench import metastable_matrix, stationary
+    from bhmm_amd.engine import Engine
+    n, K, T = 24, 6, 30000
+    rng = np.random.default_rng(24)
+    A = 0.9 * metastable_matrix(n, rng) + 0.1 / n
+    pi = stationary(A)
+    mu, sig = np.linspace(-5, 5, n), np.linspace(0.5, 1.0, n)
+    s = np.repeat(rng.integers(0, n, (K, T // 50)), 50, axis=1)
+    obs = [mu[s[k]] + sig[s[k]] * rng.standard_normal(T) for k in range(K)]
+    ref = orc.estep("gaussian", obs, A, pi, mu + 0.05, sig)
+    eng = Engine(0)
+    eng.set_option("wide_segment_len", 3000)
+    eng.set_observations("gaussian", obs, n)
+    assert eng.get_option("wide_segments") == 60
+    res = eng.estep(A, pi, mu + 0.05, sig)
+    assert eng.get_option("spec_ok") == 1 and eng.get_option("spec_fail") == 0
+    W = eng.get_option("spec_W")
+    assert W != 288 and 32 <= W <= 3000
+    _check(res, ref)
+    r2 = eng.estep(A, pi, mu + 0.05, sig)
+    assert np.array_equal(res.packed, r2.packed) and eng.get_option("spec_W") == W
     eng.close()
