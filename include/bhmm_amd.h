@@ -151,8 +151,8 @@ int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const do
  *   "spec_W"        warm-up length in time steps.  By default it is read off the forgetting
  *                   curve that the first E-step on new observations measures for the model at
  *                   hand (two differently started chains on 256 sampled stretches, both
- *                   directions; +15 %); a failed check re-measures and lengthens it.  Setting
- *                   it (or BHMM_AMD_SPEC_W) fixes it
+ *                   directions; +15 %, 9..64 states: +50 %); a failed check re-measures and
+ *                   lengthens it.  Setting it (or BHMM_AMD_SPEC_W) fixes it
  *   "wide_segments" 1/0  (9..64 states) cut trajectories into time segments with the same
  *                        verified warm-up boundaries; reading it returns the segment count in use
  *   "wide_segment_len"   segment length for the next bhmm_ctx_set_observations (0 = automatic)
@@ -160,7 +160,8 @@ int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const do
  *   "spec_last_dev" (read-only) largest relative boundary deviation of the last check
  *   "careful"       (read-only) 1 after an E-step met an all-zero emission row (gaussian
  *                   outlier rule, outputmodel.py:126-130) and switched to the kernel that
- *                   applies the rule per step
+ *                   applies the rule per step; 9..64 states: 1 after a lazily scaled vector
+ *                   left its range and the E-step was repeated with per-step normalisation
  *   "viterbi_chunked" (read-only) 1 if the last bhmm_viterbi_batch ran parallel over time
  *                   chunks (boundaries verified, no close decision), 0 if it ran serially */
 int bhmm_ctx_set_option(bhmm_ctx *ctx, const char *name, double value);
