@@ -101,7 +101,8 @@ static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
 {
     constexpr int GP = 64 / NP;
     const Segs sg = segs_of(c, which);
-    const size_t sm = (size_t)(NP * wide_pitch(NP) + GP * NP) * sizeof(double);
+    // A's rows in LDS for fewer than 64 lanes per segment; the 64-lane kernel keeps them in VGPRs
+    const size_t sm = NP == 64 ? 0 : (size_t)(NP * wide_pitch(NP)) * sizeof(double);
     double *gam = store_gamma ? c->d_gamma_ci.p : (double *)nullptr;
     if (lazy && NP == 64 && c->n == 64)
         hipLaunchKernelGGL((k_wide_bwd<NP, KIND, true, NP == 64>), dim3((sg.nseg + GP - 1) / GP),

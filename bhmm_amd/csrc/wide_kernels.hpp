@@ -71,7 +71,7 @@ __device__ __forceinline__ double exp_nonpos_issue(double x)
 // The DPP instructions are inline assembly (the compiler does not fold a 64-bit row_newbcast
 // move into the FMA); a DPP read of a VGPR needs two wait states after the VALU write of that
 // VGPR, which the first instruction of every row group provides itself.
-constexpr __host__ __device__ int wide_pitch(int np) { return np == 64 ? np + 2 : np + 1; }
+constexpr __host__ __device__ int wide_pitch(int np) { return np + 1; } // odd: lane i reads row i conflict-free
 
 struct Rows4 {
     double r[4];
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
 {
     constexpr int GP = 64 / NP;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    // rows of A, padded: lane i reads row i.  64 states: pitch NP + 2, so that a row is read in
-    // 16-byte pieces without bank conflicts; otherwise NP + 1 and 8-byte pieces.
+    // fewer than 64 lanes per segment: rows of A in LDS, padded (lane i reads row i); the 64-lane
+    // kernel keeps row i in VGPRs and uses no LDS
     constexpr int PITCH = wide_pitch(NP);
     double *sA = smem;                          // [NP][PITCH]
     const int lane = threadIdx.x;
