@@ -9,7 +9,8 @@ Names follow the reference (bhmm/__init__.py:23-43); the two identifiers BASELIN
 """
 from .util import config  # noqa: F401
 from . import hidden  # noqa: F401
-from .hmm import HMM, SampledHMM  # noqa: F401
+from .hmm import (HMM, SampledHMM, GaussianHMM, DiscreteHMM, SampledGaussianHMM,  # noqa: F401
+                  SampledDiscreteHMM)
 from .output_models import OutputModel, GaussianOutputModel, DiscreteOutputModel  # noqa: F401
 from .estimators.maximum_likelihood import MaximumLikelihoodEstimator  # noqa: F401
 from .estimators.bayesian_sampling import BayesianHMMSampler  # noqa: F401

@@ -256,3 +256,50 @@ class SampledHMM(HMM):
                 if kind == 'conf':
                     return confidence_interval_arr(x, conf=self._conf)
         raise AttributeError(attr)
+
+
+# ---- typed convenience views (bhmm/hmm/gaussian_hmm.py, discrete_hmm.py) ---------------------
+# The reference builds these by multiple inheritance from the output-model classes; here they are
+# HMM objects that forward the output model's attributes, which is all their users read.
+class _TypedHMM(HMM):
+    _kind = None
+
+    def __init__(self, hmm):
+        if hmm.output_model.model_type != self._kind:
+            raise TypeError('Given hmm is not a %s HMM, but has an output model of type: %s'
+                            % (self._kind, type(hmm.output_model)))
+        HMM.__init__(self, hmm.initial_distribution, hmm.transition_matrix, hmm.output_model,
+                     lag=hmm.lag)
+        self.hidden_state_trajectories = hmm.hidden_state_trajectories
+        self.likelihood = hmm.likelihood
+
+    def __getattr__(self, attr):
+        if attr.startswith('_') or attr == 'output_model':
+            raise AttributeError(attr)
+        return getattr(self.output_model, attr)
+
+
+class GaussianHMM(_TypedHMM):
+    """gaussian_hmm.py:29-40: `means`, `sigmas`, ... of the output model on the HMM itself."""
+    _kind = 'gaussian'
+
+
+class DiscreteHMM(_TypedHMM):
+    """discrete_hmm.py:29-40: `output_probabilities`, `nsymbols`, ... on the HMM itself."""
+    _kind = 'discrete'
+
+
+class SampledGaussianHMM(SampledHMM):
+    """gaussian_hmm.py:43-112: means_* / sigmas_* statistics over the samples."""
+
+    def __init__(self, estimated_hmm, sampled_hmms, conf=0.95):
+        GaussianHMM(estimated_hmm)      # type check
+        SampledHMM.__init__(self, estimated_hmm, sampled_hmms, conf=conf)
+
+
+class SampledDiscreteHMM(SampledHMM):
+    """discrete_hmm.py:43-83: output_probabilities_* statistics over the samples."""
+
+    def __init__(self, estimated_hmm, sampled_hmms, conf=0.95):
+        DiscreteHMM(estimated_hmm)      # type check
+        SampledHMM.__init__(self, estimated_hmm, sampled_hmms, conf=conf)

@@ -392,3 +392,14 @@ def test_spectral_properties_and_sampled_statistics():
     with pytest.raises(AttributeError):
         sh.output_probabilities_mean
     np.testing.assert_allclose(sh.transition_matrix, P)       # the estimated model itself
+    # typed views (gaussian_hmm.py / discrete_hmm.py)
+    gh = bhmm_amd.GaussianHMM(h)
+    assert np.array_equal(gh.means, h.output_model.means) and gh.nstates == 3 and gh.lag == 2
+    with pytest.raises(TypeError):
+        bhmm_amd.DiscreteHMM(h)
+    dh = bhmm_amd.DiscreteHMM(hn)
+    assert dh.nsymbols == 3 and np.array_equal(dh.output_probabilities, np.eye(3))
+    sg = bhmm_amd.SampledGaussianHMM(h, samples)
+    assert sg.means_mean.shape == (3,)
+    with pytest.raises(TypeError):
+        bhmm_amd.SampledDiscreteHMM(h, samples)
