@@ -79,6 +79,22 @@ class DiscreteOutputModel(OutputModel):
             if np.any(positive):
                 self._output_probabilities[i, positive] = rng.dirichlet(count[positive])
 
+    def sample(self, observations_by_state, rng=np.random):
+        """discrete.py:217-251 with the reference's signature: observations_by_state[k] are the
+        symbols observed while the hidden path was in state k."""
+        counts = [np.bincount(np.asarray(o, dtype=np.int64), minlength=self._nsymbols)[:self._nsymbols]
+                  for o in observations_by_state]
+        self.sample_from_statistics(counts, rng=rng)
+
+    def generate_observation_from_state(self, state_index, rng=np.random):
+        """discrete.py:253-282."""
+        return int(rng.choice(self._nsymbols, p=self._output_probabilities[state_index]))
+
+    def generate_observations_from_state(self, state_index, nobs, rng=np.random):
+        """discrete.py:284-318."""
+        return rng.choice(self._nsymbols, size=nobs,
+                          p=self._output_probabilities[state_index]).astype(np.int32)
+
     def generate_observation_trajectory(self, s_t, rng=np.random):
         s_t = np.asarray(s_t)
         cdf = np.cumsum(self._output_probabilities, axis=1)

@@ -114,6 +114,27 @@ class GaussianOutputModel(OutputModel):
                     sigmahat2 = (sum_dd[i] - 2.0 * shift * sum_d[i]) / n + shift * shift
                     self._sigmas[i] = np.sqrt(max(sigmahat2, 0.0)) / np.sqrt(chi2 / n)
 
+    def sample(self, observations, prior=None, rng=np.random):
+        """gaussian.py:274-320 with the reference's signature: observations[k] are the
+        observations assigned to state k.  (The Gibbs sampler of this package feeds
+        sample_from_statistics with sums the GPU path pass already produced.)"""
+        n_i = np.zeros(self.nstates)
+        sum_d = np.zeros(self.nstates)
+        sum_dd = np.zeros(self.nstates)
+        for i in range(self.nstates):
+            o = np.asarray(observations[i], dtype=np.float64)
+            d = o - self._means[i]
+            n_i[i], sum_d[i], sum_dd[i] = o.size, d.sum(), np.dot(d, d)
+        self.sample_from_statistics(n_i, sum_d, sum_dd, rng=rng)
+
+    def generate_observation_from_state(self, state_index, rng=np.random):
+        """gaussian.py:322-350."""
+        return self._sigmas[state_index] * rng.standard_normal() + self._means[state_index]
+
+    def generate_observations_from_state(self, state_index, nobs, rng=np.random):
+        """gaussian.py:352-382."""
+        return self._sigmas[state_index] * rng.standard_normal(nobs) + self._means[state_index]
+
     def generate_observation_trajectory(self, s_t, rng=np.random):
         s_t = np.asarray(s_t)
         return self._means[s_t] + self._sigmas[s_t] * rng.standard_normal(s_t.shape[0])

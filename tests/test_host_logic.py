@@ -403,3 +403,30 @@ def test_spectral_properties_and_sampled_statistics():
     assert sg.means_mean.shape == (3,)
     with pytest.raises(TypeError):
         bhmm_amd.SampledDiscreteHMM(h, samples)
+
+
+def test_output_model_sampling_with_reference_signatures():
+    """gaussian.py:274-382, discrete.py:217-318: sample(observations per state) and the per-state
+    generators; sample() must equal sample_from_statistics on the same statistics and stream."""
+    om = bhmm_amd.GaussianOutputModel(3, means=[-1.0, 0.0, 1.0], sigmas=[0.5, 1.0, 2.0])
+    rs = np.random.RandomState(0)
+    obs = [om.generate_observations_from_state(i, 5000, rng=rs) for i in range(3)]
+    assert all(o.shape == (5000,) for o in obs)
+    om2 = bhmm_amd.GaussianOutputModel(3, means=[-1.0, 0.0, 1.0], sigmas=[0.5, 1.0, 2.0])
+    om.sample(obs, rng=np.random.RandomState(7))
+    d = [o - m for o, m in zip(obs, [-1.0, 0.0, 1.0])]
+    om2.sample_from_statistics([5000] * 3, [x.sum() for x in d], [np.dot(x, x) for x in d],
+                               rng=np.random.RandomState(7))
+    np.testing.assert_allclose(om.means, om2.means, rtol=1e-12)
+    np.testing.assert_allclose(om.sigmas, om2.sigmas, rtol=1e-12)
+    np.testing.assert_allclose(om.means, [-1.0, 0.0, 1.0], atol=0.1)
+    np.testing.assert_allclose(om.sigmas, [0.5, 1.0, 2.0], rtol=0.05)
+    assert np.isfinite(om.generate_observation_from_state(2, rng=rs))
+    dm = bhmm_amd.DiscreteOutputModel(np.array([[0.5, 0.5, 0.0], [0.1, 0.2, 0.7]]))
+    o = [dm.generate_observations_from_state(i, 4000, rng=rs) for i in range(2)]
+    assert o[0].max() <= 1 and o[1].dtype == np.int32
+    dm.sample(o, rng=rs)
+    B = dm.output_probabilities
+    np.testing.assert_allclose(B.sum(axis=1), 1.0)
+    assert B[0, 2] == 0.0 and abs(B[1, 2] - 0.7) < 0.05      # unseen symbols keep probability 0
+    assert dm.generate_observation_from_state(0, rng=rs) in (0, 1)
