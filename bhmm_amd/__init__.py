@@ -8,6 +8,7 @@ Names follow the reference (bhmm/__init__.py:23-43); the two identifiers BASELIN
 (PyEMMA spellings) are provided as aliases.
 """
 from .util import config  # noqa: F401
+from .util import testsystems  # noqa: F401
 from . import hidden  # noqa: F401
 from .hmm import (HMM, SampledHMM, GaussianHMM, DiscreteHMM, SampledGaussianHMM,  # noqa: F401
                   SampledDiscreteHMM)

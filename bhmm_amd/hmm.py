@@ -144,6 +144,48 @@ class HMM(object):
                  for s, o in zip(self.hidden_state_trajectories, observations)]
         return np.concatenate(parts) if parts else np.array([])
 
+    # ---- synthetic data (generic_hmm.py:433-589) ------------------------------------------------
+    def generate_synthetic_state_trajectory(self, nsteps, initial_Pi=None, start=None, stop=None,
+                                            dtype=np.int32, rng=np.random):
+        """generic_hmm.py:433-479: a Markov chain of the hidden transition matrix (inverse-CDF
+        draws; the reference delegates to msmtools.generation.generate_traj)."""
+        if initial_Pi is not None and start is not None:
+            raise ValueError('Arguments initial_Pi and start are exclusive. Only set one of them.')
+        if start is None:
+            p0 = self._Pi if initial_Pi is None else np.asarray(initial_Pi, dtype=np.float64)
+            start = int(rng.choice(self._nstates, p=p0 / p0.sum()))
+        cdf = np.cumsum(self._Tij, axis=1)
+        u = rng.random_sample(int(nsteps))
+        traj = np.empty(int(nsteps), dtype=dtype)
+        s = int(start)
+        for t in range(int(nsteps)):
+            if t > 0:
+                s = min(int(np.searchsorted(cdf[s], u[t], side='right')), self._nstates - 1)
+            traj[t] = s
+            if stop is not None and s == stop:
+                return traj[:t + 1]
+        return traj
+
+    def generate_synthetic_observation(self, state, rng=np.random):
+        """generic_hmm.py:481-504."""
+        return self.output_model.generate_observation_from_state(state, rng=rng)
+
+    def generate_synthetic_observation_trajectory(self, length, initial_Pi=None, rng=np.random):
+        """generic_hmm.py:506-545: (observations, hidden states)."""
+        s_t = self.generate_synthetic_state_trajectory(length, initial_Pi=initial_Pi, rng=rng)
+        return [self.output_model.generate_observation_trajectory(s_t, rng=rng), s_t]
+
+    def generate_synthetic_observation_trajectories(self, ntrajectories, length, initial_Pi=None,
+                                                    rng=np.random):
+        """generic_hmm.py:547-589: ([observations], [hidden states])."""
+        O, S = [], []
+        for _ in range(ntrajectories):
+            o_t, s_t = self.generate_synthetic_observation_trajectory(length, initial_Pi=initial_Pi,
+                                                                      rng=rng)
+            O.append(o_t)
+            S.append(s_t)
+        return [O, S]
+
 
 def _stat_property(name, doc):
     def samples(self):

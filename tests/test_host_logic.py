@@ -430,3 +430,25 @@ def test_output_model_sampling_with_reference_signatures():
     np.testing.assert_allclose(B.sum(axis=1), 1.0)
     assert B[0, 2] == 0.0 and abs(B[1, 2] - 0.7) < 0.05      # unseen symbols keep probability 0
     assert dm.generate_observation_from_state(0, rng=rs) in (0, 1)
+
+
+def test_testsystems_and_synthetic_trajectories():
+    """testsystems.py:26-250, generic_hmm.py:433-589."""
+    rs = np.random.RandomState(3)
+    T = bhmm_amd.testsystems.generate_transition_matrix(5, rng=rs)
+    assert _tmatrix.is_transition_matrix(T) and _tmatrix.is_reversible(T)
+    lt = np.linspace(np.log(10), np.log(100), 5)
+    np.testing.assert_allclose(np.diag(T), 1 - np.exp(-lt), rtol=1e-12)     # lifetimes 10 .. 100
+    model, O, S = bhmm_amd.testsystems.generate_synthetic_observations(
+        nstates=3, ntrajectories=4, length=3000, rng=rs)
+    assert model.is_stationary and len(O) == 4 and O[0].shape == (3000,) and S[0].dtype == np.int32
+    assert bhmm_amd.testsystems.total_state_visits(3, S).sum() == 12000
+    emp = np.array([O[0][S[0] == i].mean() for i in range(3) if np.any(S[0] == i)])
+    assert np.all(np.diff(emp) > 0)                           # means -5, 0, 5 in state order
+    md, Od, Sd = bhmm_amd.testsystems.generate_synthetic_observations(
+        nstates=3, ntrajectories=2, length=500, output='discrete', rng=rs)
+    assert md.output_model.model_type == 'discrete' and Od[0].max() <= 2
+    s = model.generate_synthetic_state_trajectory(50, start=1, stop=2, rng=rs)
+    assert s[0] == 1 and (s[-1] == 2 or len(s) == 50) and 2 not in s[:-1]
+    with pytest.raises(ValueError):
+        model.generate_synthetic_state_trajectory(5, initial_Pi=[1, 0, 0], start=0)
