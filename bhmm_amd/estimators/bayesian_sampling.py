@@ -38,8 +38,7 @@ class BayesianHMMSampler(object):
         self.Ts = [len(o) for o in observations]
         self.maxT = np.max(self.Ts)
         if not initial_model:
-            raise NotImplementedError('bhmm_amd needs an initial_model (e.g. the result of '
-                                      'MaximumLikelihoodEstimator.fit())')
+            initial_model = self._generateInitialModel(output, device, process_group, engine_factory)
         self.model = copy.deepcopy(initial_model)
         self._output = self.model.output_model.model_type
 
@@ -93,6 +92,16 @@ class BayesianHMMSampler(object):
                                       nstates, nsymbols=M)
         self._sweep = 0
         self._rng = np.random
+
+    def _generateInitialModel(self, output_model_type, device=None, process_group=None,
+                              engine_factory=None):
+        """bayesian_sampling.py:375-385: a maximum-likelihood fit from the heuristic start."""
+        from .maximum_likelihood import MaximumLikelihoodEstimator
+        mlhmm = MaximumLikelihoodEstimator(self.observations, self.nstates,
+                                           reversible=self.reversible, output=output_model_type,
+                                           device=device, process_group=process_group,
+                                           engine_factory=engine_factory)
+        return mlhmm.fit()
 
     def sample(self, nsamples, nburn=0, nthin=1, save_hidden_state_trajectory=False,
                call_back=None, seed=None):

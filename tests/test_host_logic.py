@@ -184,6 +184,9 @@ def test_bayesian_sampler_sweeps():
     models = bhmm_amd.bayesian_hmm(obs, mle, nsample=2, reversible=True, engine_factory=OracleEngine)
     for m in models:
         assert _tmatrix.is_reversible(m.transition_matrix)
+    # no initial model: a maximum-likelihood fit from the heuristic start (bayesian_sampling.py:375-385)
+    smp = bhmm_amd.BayesianHMMSampler(obs, 3, reversible=False, engine_factory=OracleEngine)
+    assert smp.model.nstates == 3 and np.all(np.diff(smp.model.output_model.means) > 0)
     dis = bhmm_amd.gaussian_hmm([0.5, 0.5], np.eye(2), [0.0, 1.0], [1.0, 1.0])
     with pytest.raises(NotImplementedError):                 # bayesian_sampling.py:187-191
         bhmm_amd.BayesianHMMSampler(obs, 2, initial_model=dis, reversible=True,
