@@ -77,10 +77,18 @@ class HMM(object):
         return _tmatrix.stationary_vector(self._Tij)
 
     def _rdl(self):
+        self._ensure_spectral_decomposition()
+        return self._spectral
+
+    # generic_hmm.py:127-136 (names kept: the reference's tests look for them)
+    @property
+    def _spectral_decomp_available(self):
+        return self._spectral is not None
+
+    def _ensure_spectral_decomposition(self):
         if self._spectral is None:
             R, D, L = _tmatrix.rdl_decomposition(self._Tij, reversible=self.is_reversible)
             self._spectral = (R, np.diag(D), L)
-        return self._spectral
 
     @property
     def eigenvalues(self):

@@ -238,6 +238,12 @@ def init_discrete_hmm_spectral(C_full, nstates, reversible=True, stationary=True
         P_ans = _tmatrix.estimate_P(C_ans, reversible=True)
 
     if active_nonseparate.size > nmeta:
+        # the reference's PCCA object starts from msmtools' stationary distribution, which refuses
+        # a matrix that is not (weakly) connected: estimation on disconnected data raises
+        # ValueError there (bhmm/tests/test_mlhmm.py:127-140), and so does this
+        if not _tmatrix.is_connected(P_ans, strong=False):
+            raise ValueError('Input matrix is not weakly connected. Therefore it has no unique '
+                             'stationary distribution.')
         M_ans = pcca_memberships(P_ans, nmeta)
         w = M_ans * _tmatrix.stationary_distribution(P_ans, C=C_ans)[:, None]
         B_ans = (w / w.sum(axis=0)[None, :]).T

@@ -334,6 +334,10 @@ def test_discrete_initial_model_pathological():
         bhmm_amd.init_discrete_hmm([np.array([0, 1, 0, 0, 1, 1])], 3, reversible=False)
     h = bhmm_amd.init_hmm([_SPLIT], 2, lag=2)
     assert h.lag == 2 and h.output_model.model_type == 'discrete'
+    # two disconnected symbol sets: ValueError (test_mlhmm.py:127-140)
+    rng = np.random.RandomState(1)
+    with pytest.raises(ValueError):
+        bhmm_amd.init_discrete_hmm([rng.randint(0, 5, 100), rng.randint(6, 11, 100)], 2, lag=5)
 
 
 def test_spectral_properties_and_sampled_statistics():
@@ -351,6 +355,7 @@ def test_spectral_properties_and_sampled_statistics():
     np.testing.assert_allclose(R[:, 0], 1.0, atol=1e-12)
     np.testing.assert_allclose(h.timescales, -2.0 / np.log(lam[1:]))
     np.testing.assert_allclose(h.lifetimes, -2.0 / np.log(np.diag(P)))
+    assert h._spectral_decomp_available and hasattr(h, '_ensure_spectral_decomposition')
     sub = h.sub_hmm([0, 1])
     np.testing.assert_allclose(sub.transition_matrix, [[0.9, 0.1], [1 / 9., 8 / 9.]])
     assert np.array_equal(sub.output_model.means, [-1.0, 0.0])
