@@ -277,7 +277,7 @@ def test_configs3_full_size_properties():
     assert eng.get_option("wide_segments") >= 1024
     res = eng.estep(*args)                  # the probe sets a warm-up that verifies at once
     assert eng.get_option("spec_ok") == 1 and eng.get_option("spec_fail") == 0
-    assert eng.get_option("spec_last_dev") < 1e-11 and eng.get_option("spec_W") != 288
+    assert eng.get_option("spec_last_dev") < 1e-11 and eng.get_option("spec_W") > 288  # measured
     assert eng.get_option("careful") == 0.0
     assert np.all(np.isfinite(res.logL_k))
     np.testing.assert_allclose(res.state_counts.sum(), K * T, rtol=1e-10)
@@ -353,7 +353,7 @@ def test_wide_probe_sets_warmup_before_first_estep():
     res = eng.estep(A, pi, mu + 0.05, sig)
     assert eng.get_option("spec_ok") == 1 and eng.get_option("spec_fail") == 0
     W = eng.get_option("spec_W")
-    assert W != 288 and 32 <= W <= 3000
+    assert 32 <= W <= 3000
     _check(res, ref)
     r2 = eng.estep(A, pi, mu + 0.05, sig)
     assert np.array_equal(res.packed, r2.packed) and eng.get_option("spec_W") == W
