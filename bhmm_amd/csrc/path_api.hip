@@ -64,14 +64,19 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     const int P = c->Lmax >= 256 ? 4 : 1;       // parts per chunk for the map kernels
     const int nblk = (c->Gp / BLOCK) * P;
     const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)N : (c->kind == EMIT_DISC ? (size_t)c->M * N : 0);
-    // scratch2: [path] | status | part maps | next-part states
+    // scratch2: [path] | status | part maps | next-part states | lowest non-final step per part |
+    // nibbles of the final steps (8 per word)
     const size_t npath = paths ? (size_t)c->total : 0;
-    if ((rc = c->d_scratch2.ensure((npath + 4 + 2 * (size_t)c->Gp * P) * sizeof(int32_t))))
+    const int W8 = (c->Lmax / P + 1 + 7) / 8 + 1;
+    if ((rc = c->d_scratch2.ensure((npath + 4 + (3 + (size_t)W8) * (size_t)c->Gp * P) * sizeof(int32_t))))
         return rc;
     int32_t *path = paths ? reinterpret_cast<int32_t *>(c->d_scratch2.p) : nullptr;
     int *status = reinterpret_cast<int *>(reinterpret_cast<int32_t *>(c->d_scratch2.p) + npath);
     uint32_t *fmap = reinterpret_cast<uint32_t *>(status + 4);
     int32_t *nstate = reinterpret_cast<int32_t *>(fmap + (size_t)c->Gp * P);
+    int32_t *dmark = nstate + (size_t)c->Gp * P;
+    uint32_t *nib = reinterpret_cast<uint32_t *>(dmark + (size_t)c->Gp * P);
+    const int64_t Gp64 = c->Gp;
     // scratch: counts | emission partials | reduced emission | u
     const size_t dbl = nstat + (size_t)nblk * esz + esz + (u ? (size_t)c->total : 0) + 8;
     if ((rc = c->d_scratch.ensure(dbl * sizeof(double))))
@@ -97,7 +102,8 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         const int64_t *offd = c->d_offsets.p;
         const void *obs_ci = c->d_obs_ci.p;
         hipLaunchKernelGGL((k_smp_maps<N>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd,
-                           (const double *)c->d_ws.p, (const double *)udev, seed, P, fmap, status);
+                           (const double *)c->d_ws.p, (const double *)udev, seed, P, fmap, status, dmark,
+                           nib, W8, Gp64);
         BHMM_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_smp_stitch, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB), dim3(64), 0,
                            c->stream,
@@ -106,16 +112,19 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         if (c->kind == EMIT_GAUSS)
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
                                chs, offd, (const double *)c->d_ws.p, obs_ci, (const double *)udev,
-                               seed, P, (const int32_t *)nstate, path, cnt, epart, status);
+                               seed, P, (const int32_t *)nstate, path, cnt, epart, status,
+                               (const int32_t *)dmark, (const uint32_t *)nib, W8, Gp64);
         else if (c->kind == EMIT_DISC)
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK),
                                (size_t)c->M * N * sizeof(double), c->stream, m, chs, offd,
                                (const double *)c->d_ws.p, obs_ci, (const double *)udev, seed, P,
-                               (const int32_t *)nstate, path, cnt, epart, status);
+                               (const int32_t *)nstate, path, cnt, epart, status,
+                               (const int32_t *)dmark, (const uint32_t *)nib, W8, Gp64);
         else
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
                                chs, offd, (const double *)c->d_ws.p, obs_ci, (const double *)udev,
-                               seed, P, (const int32_t *)nstate, path, cnt, epart, status);
+                               seed, P, (const int32_t *)nstate, path, cnt, epart, status,
+                               (const int32_t *)dmark, (const uint32_t *)nib, W8, Gp64);
         BHMM_HIP(hipGetLastError());
         if (esz) {
             hipLaunchKernelGGL(k_add_partials, dim3((unsigned)esz), dim3(64), 0,

@@ -155,11 +155,17 @@ __device__ __forceinline__ void stage_At(double *sAt, const Model<N> &m)
 // The maps are built on a partition finer than the E-step chunks (every chunk is cut into P
 // parts, P workgroups walk the same 256 chunks): these kernels keep one lane per (chunk, part),
 // so more parts = more wavefronts in flight; composition does not care where the cuts are.
+// Once the 8 images have coalesced, every further step of the part is the same whatever follows
+// the part, i.e. it IS the sampled path there.  Those states are kept, one nibble per step (8 steps
+// per word, word w of part p of chunk g at nib[(p * W8 + w) * Gp + g], filled from the top of the
+// part downwards), and dmark[part] = the lowest step that still depends on the part's successor:
+// k_smp_apply reads alpha again only for [dmark, end of part) and takes the rest from the nibbles.
 template <int N>
 __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks ch,
                                                   const int64_t *off, const double *alpha_ci,
                                                   const double *u, uint64_t seed, int P,
-                                                  uint32_t *Fmap, int *status)
+                                                  uint32_t *Fmap, int *status, int32_t *dmark,
+                                                  uint32_t *nib, int W8, int64_t Gp)
 {
     __shared__ __attribute__((aligned(16))) double sAt[N * N];
     stage_At<N>(sAt, m);
@@ -175,16 +181,24 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
     const int n = m.nreal;
     const int s_lo = (int)((int64_t)len * part / P), s_hi = (int)((int64_t)len * (part + 1) / P);
     uint32_t cur = 0x76543210u; // nibble j = image of next-part state j (identity)
+    int dm = s_hi;
+    uint32_t word = 0;
+    uint32_t *mynib = nib + ((int64_t)part * W8) * Gp + g;
     for (int s = s_hi - 1; s >= s_lo; --s) {
         double a[N];
         ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
         const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
         const bool last = (t0 + s == Tk - 1);
         const uint32_t c0 = cur & 7u;
+        const int j = s_hi - 1 - s; // position from the top of the part
         if (cur == c0 * 0x11111111u || last) { // coalesced (or constant map): one image
             const int x = pick_state<N>(a, last ? nullptr : sAt + c0 * N, r, n, status);
             cur = (uint32_t)x * 0x11111111u;
+            if (last)
+                dm = s; // no successor state: k_smp_apply takes this step
+            word |= (uint32_t)x << (4 * (j & 7));
         } else {
+            dm = s;
             uint32_t G = 0;
 #pragma unroll
             for (int x = 0; x < N; ++x)
@@ -196,8 +210,13 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
                 nw |= ((G >> (4 * ((cur >> (4 * j)) & 7u))) & 7u) << (4 * j);
             cur = nw;
         }
+        if ((j & 7) == 7 || s == s_lo) {
+            mynib[(int64_t)(j >> 3) * Gp] = word;
+            word = 0;
+        }
     }
     Fmap[g * P + part] = cur;
+    dmark[g * P + part] = dm;
 }
 
 // state at the first step of the NEXT part, for every (chunk, part) (0 behind a trajectory's
@@ -244,7 +263,9 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
                                                    const void *obs_ci, const double *u,
                                                    uint64_t seed, int P, const int32_t *next_state,
                                                    int32_t *path, unsigned long long *counts,
-                                                   double *epartials, int *status)
+                                                   double *epartials, int *status,
+                                                   const int32_t *dmark, const uint32_t *nib, int W8,
+                                                   int64_t Gp)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[]; // discrete: [M][N] counts
     __shared__ __attribute__((aligned(16))) double sAt[N * N];
@@ -272,13 +293,24 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
         const int n = m.nreal;
         const int s_lo = (int)((int64_t)len * part / P), s_hi = (int)((int64_t)len * (part + 1) / P);
         int nxt = next_state[g * P + part];
+        const int dm = dmark[g * P + part]; // steps below dm: the state k_smp_maps recorded
+        const uint32_t *mynib = nib + ((int64_t)part * W8) * Gp + g;
+        uint32_t word = 0;
         for (int s = s_hi - 1; s >= s_lo; --s) {
-            double a[N];
             const int64_t rec = ci_rec(g, s, ch.Lmax);
-            ci_load<N>(alpha_ci, rec, lane, a);
-            const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
             const bool last = (t0 + s == Tk - 1);
-            const int st = pick_state<N>(a, last ? nullptr : sAt + nxt * N, r, n, status);
+            const int j = s_hi - 1 - s;
+            if ((j & 7) == 0 || s == dm - 1)
+                word = mynib[(int64_t)(j >> 3) * Gp];
+            int st;
+            if (s >= dm) {
+                double a[N];
+                ci_load<N>(alpha_ci, rec, lane, a);
+                const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
+                st = pick_state<N>(a, last ? nullptr : sAt + nxt * N, r, n, status);
+            } else {
+                st = (int)((word >> (4 * (j & 7))) & 7u);
+            }
             if (path)
                 path[base + s] = st;
             if (!last)
