@@ -67,8 +67,11 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     // scratch2: [path] | status | part maps | next-part states | lowest non-final step per part |
     // nibbles of the final steps (8 per word)
     const size_t npath = paths ? (size_t)c->total : 0;
-    const int W8 = (c->Lmax / P + 1 + 7) / 8 + 1;
-    if ((rc = c->d_scratch2.ensure((npath + 4 + (3 + (size_t)W8) * (size_t)c->Gp * P) * sizeof(int32_t))))
+    const int Lp = c->Lmax / P + 2;          // steps per part (upper bound)
+    const int W8 = (Lp + 7) / 8 + 1;
+    // ... | full step maps above the coalescence point (one word per step)
+    if ((rc = c->d_scratch2.ensure((npath + 4 + (3 + (size_t)W8 + (size_t)Lp) * (size_t)c->Gp * P) *
+                                   sizeof(int32_t))))
         return rc;
     int32_t *path = paths ? reinterpret_cast<int32_t *>(c->d_scratch2.p) : nullptr;
     int *status = reinterpret_cast<int *>(reinterpret_cast<int32_t *>(c->d_scratch2.p) + npath);
@@ -76,6 +79,7 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     int32_t *nstate = reinterpret_cast<int32_t *>(fmap + (size_t)c->Gp * P);
     int32_t *dmark = nstate + (size_t)c->Gp * P;
     uint32_t *nib = reinterpret_cast<uint32_t *>(dmark + (size_t)c->Gp * P);
+    uint32_t *gw = nib + (size_t)W8 * c->Gp * P;
     const int64_t Gp64 = c->Gp;
     // scratch: counts | emission partials | reduced emission | u
     const size_t dbl = nstat + (size_t)nblk * esz + esz + (u ? (size_t)c->total : 0) + 8;
@@ -103,28 +107,24 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         const void *obs_ci = c->d_obs_ci.p;
         hipLaunchKernelGGL((k_smp_maps<N>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd,
                            (const double *)c->d_ws.p, (const double *)udev, seed, P, fmap, status, dmark,
-                           nib, W8, Gp64);
+                           nib, W8, Gp64, gw, Lp);
         BHMM_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_smp_stitch, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB), dim3(64), 0,
                            c->stream,
                            (const int32_t *)c->d_traj_c0.p, K, P, (const uint32_t *)fmap, nstate);
         BHMM_HIP(hipGetLastError());
+        const int32_t *ns = nstate, *dmk = dmark;
+        const uint32_t *nb = nib, *gwc = gw;
         if (c->kind == EMIT_GAUSS)
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
-                               chs, offd, (const double *)c->d_ws.p, obs_ci, (const double *)udev,
-                               seed, P, (const int32_t *)nstate, path, cnt, epart, status,
-                               (const int32_t *)dmark, (const uint32_t *)nib, W8, Gp64);
+                               chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
         else if (c->kind == EMIT_DISC)
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK),
-                               (size_t)c->M * N * sizeof(double), c->stream, m, chs, offd,
-                               (const double *)c->d_ws.p, obs_ci, (const double *)udev, seed, P,
-                               (const int32_t *)nstate, path, cnt, epart, status,
-                               (const int32_t *)dmark, (const uint32_t *)nib, W8, Gp64);
+                               (size_t)c->M * N * sizeof(double), c->stream, m, chs, offd, obs_ci, P, ns,
+                               path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
         else
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
-                               chs, offd, (const double *)c->d_ws.p, obs_ci, (const double *)udev,
-                               seed, P, (const int32_t *)nstate, path, cnt, epart, status,
-                               (const int32_t *)dmark, (const uint32_t *)nib, W8, Gp64);
+                               chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
         BHMM_HIP(hipGetLastError());
         if (esz) {
             hipLaunchKernelGGL(k_add_partials, dim3((unsigned)esz), dim3(64), 0,

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
                                                   const int64_t *off, const double *alpha_ci,
                                                   const double *u, uint64_t seed, int P,
                                                   uint32_t *Fmap, int *status, int32_t *dmark,
-                                                  uint32_t *nib, int W8, int64_t Gp)
+                                                  uint32_t *nib, int W8, int64_t Gp, uint32_t *gw,
+                                                  int Lp)
 {
     __shared__ __attribute__((aligned(16))) double sAt[N * N];
     stage_At<N>(sAt, m);
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
     int dm = s_hi;
     uint32_t word = 0;
     uint32_t *mynib = nib + ((int64_t)part * W8) * Gp + g;
+    // steps above the coalescence point: the whole map of the step (8 nibbles, next state ->
+    // state), word j of part p of chunk g at gw[(p * Lp + j) * Gp + g] -- k_smp_apply then needs
+    // neither alpha nor the uniforms again
+    uint32_t *mygw = gw + ((int64_t)part * Lp) * Gp + g;
     for (int s = s_hi - 1; s >= s_lo; --s) {
         double a[N];
         ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
@@ -194,8 +199,10 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
         if (cur == c0 * 0x11111111u || last) { // coalesced (or constant map): one image
             const int x = pick_state<N>(a, last ? nullptr : sAt + c0 * N, r, n, status);
             cur = (uint32_t)x * 0x11111111u;
-            if (last)
-                dm = s; // no successor state: k_smp_apply takes this step
+            if (last) {
+                dm = s; // no successor state: k_smp_apply takes this step (a constant map)
+                mygw[(int64_t)j * Gp] = cur;
+            }
             word |= (uint32_t)x << (4 * (j & 7));
         } else {
             dm = s;
@@ -204,10 +211,11 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
             for (int x = 0; x < N; ++x)
                 if (x < n) // padded (inert) states are never a next state
                     G |= (uint32_t)pick_state<N>(a, sAt + x * N, r, n, status) << (4 * x);
+            mygw[(int64_t)j * Gp] = G;
             uint32_t nw = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                nw |= ((G >> (4 * ((cur >> (4 * j)) & 7u))) & 7u) << (4 * j);
+            for (int jj = 0; jj < 8; ++jj)
+                nw |= ((G >> (4 * ((cur >> (4 * jj)) & 7u))) & 7u) << (4 * jj);
             cur = nw;
         }
         if ((j & 7) == 7 || s == s_lo) {
@@ -253,25 +261,22 @@ static __global__ __launch_bounds__(64) void k_smp_stitch(const int32_t *traj_c0
     }
 }
 
-// re-walk every part from its known start state: the sampled path (optional output) and the
-// hidden-path statistics of the Gibbs sweep (generic_hmm.py:297-334,398-431): integer
-// transition / start counts (exact) and per-state emission sums, fused so that neither the path
-// nor the observations are read again.
+// walk every part from its known start state with what k_smp_maps left behind -- the full step maps
+// above the part's coalescence point, one nibble per step below it -- and emit the sampled path
+// (optional output) and the hidden-path statistics of the Gibbs sweep (generic_hmm.py:297-334,
+// 398-431): integer transition / start counts (exact) and per-state emission sums, fused so that
+// neither the path nor the observations are read again.  alpha and the uniforms are not needed here.
 template <int N, int KIND>
 __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunks ch,
-                                                   const int64_t *off, const double *alpha_ci,
-                                                   const void *obs_ci, const double *u,
-                                                   uint64_t seed, int P, const int32_t *next_state,
-                                                   int32_t *path, unsigned long long *counts,
-                                                   double *epartials, int *status,
+                                                   const int64_t *off, const void *obs_ci, int P,
+                                                   const int32_t *next_state, int32_t *path,
+                                                   unsigned long long *counts, double *epartials,
                                                    const int32_t *dmark, const uint32_t *nib, int W8,
-                                                   int64_t Gp)
+                                                   int64_t Gp, const uint32_t *gw, int Lp)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[]; // discrete: [M][N] counts
-    __shared__ __attribute__((aligned(16))) double sAt[N * N];
     __shared__ unsigned int cnt[N * N + N];
     __shared__ double red[4][3 * N];
-    stage_At<N>(sAt, m);
     for (int e = threadIdx.x; e < N * N + N; e += blockDim.x)
         cnt[e] = 0u;
     if constexpr (KIND == EMIT_DISC)
@@ -290,27 +295,53 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
         const int k = ch.traj[g];
         const int64_t t0 = ch.t0[g], base = ch.goff[g];
         const int64_t Tk = off[k + 1] - off[k];
-        const int n = m.nreal;
         const int s_lo = (int)((int64_t)len * part / P), s_hi = (int)((int64_t)len * (part + 1) / P);
         int nxt = next_state[g * P + part];
-        const int dm = dmark[g * P + part]; // steps below dm: the state k_smp_maps recorded
+        const int dm = dmark[g * P + part]; // steps below dm: the state itself is recorded
         const uint32_t *mynib = nib + ((int64_t)part * W8) * Gp + g;
-        uint32_t word = 0;
-        for (int s = s_hi - 1; s >= s_lo; --s) {
-            const int64_t rec = ci_rec(g, s, ch.Lmax);
+        const uint32_t *mygw = gw + ((int64_t)part * Lp) * Gp + g;
+        // The walk is a dependent chain of table look-ups, one observation per step: everything it
+        // reads is fetched SMP_PF steps ahead (a step would otherwise wait a full memory latency,
+        // and there are only two wavefronts per SIMD to hide it).
+        constexpr int SMP_PF = 4;
+        const int nst = s_hi - s_lo;
+        double oring[SMP_PF];
+        int yring[SMP_PF];
+        uint32_t gring[SMP_PF];
+        auto fetch = [&](int q, int j) {
+            const int jc = j < nst ? j : nst - 1;
+            const int sc = s_hi - 1 - jc;
+            const int64_t r = ci_rec(g, sc, ch.Lmax) * 64 + lane;
+            if constexpr (KIND == EMIT_GAUSS)
+                oring[q] = static_cast<const double *>(obs_ci)[r];
+            if constexpr (KIND == EMIT_DISC)
+                yring[q] = static_cast<const int32_t *>(obs_ci)[r];
+            // above dm the step's full map, below it the word that holds the step's nibble
+            gring[q] = sc >= dm ? mygw[(int64_t)jc * Gp] : mynib[(int64_t)(jc >> 3) * Gp];
+        };
+#pragma unroll
+        for (int q = 0; q < SMP_PF; ++q) {
+            oring[q] = 0.0;
+            yring[q] = 0;
+            gring[q] = 0u;
+            if (nst > 0)
+                fetch(q, q);
+        }
+        for (int jb = 0; jb < nst; jb += SMP_PF) {
+#pragma unroll
+        for (int q = 0; q < SMP_PF; ++q) {
+            const int j = jb + q;
+            if (j >= nst)
+                break;
+            const int s = s_hi - 1 - j;
+            const double o_cur = oring[q];
+            const int y_cur = yring[q];
+            const uint32_t g_cur = gring[q];
+            fetch(q, j + SMP_PF);
+            (void)o_cur;
+            (void)y_cur;
             const bool last = (t0 + s == Tk - 1);
-            const int j = s_hi - 1 - s;
-            if ((j & 7) == 0 || s == dm - 1)
-                word = mynib[(int64_t)(j >> 3) * Gp];
-            int st;
-            if (s >= dm) {
-                double a[N];
-                ci_load<N>(alpha_ci, rec, lane, a);
-                const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
-                st = pick_state<N>(a, last ? nullptr : sAt + nxt * N, r, n, status);
-            } else {
-                st = (int)((word >> (4 * (j & 7))) & 7u);
-            }
+            const int st = (int)((g_cur >> (4 * (s >= dm ? nxt : (j & 7)))) & 7u);
             if (path)
                 path[base + s] = st;
             if (!last)
@@ -318,7 +349,7 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
             if (t0 + s == 0)
                 atomicAdd(&cnt[N * N + st], 1u);
             if constexpr (KIND == EMIT_GAUSS) {
-                const double o = static_cast<const double *>(obs_ci)[rec * 64 + lane];
+                const double o = o_cur;
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
                     const double d = o - m.e0[i];
@@ -329,10 +360,11 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
                 }
             }
             if constexpr (KIND == EMIT_DISC) {
-                const int sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + lane];
+                const int sym = y_cur;
                 atomicAdd(&lds[sym * N + st], 1.0); // integer-valued: exact, order-independent
             }
             nxt = st;
+        }
         }
     }
     __syncthreads();
