@@ -97,9 +97,13 @@ __global__ __launch_bounds__(64) void k_sample_path(const Model<N> m, const int6
 // decomposition are processed independently:
 //   k_smp_maps   : per chunk, F_c = g_{t0} o ... o g_{t1-1} as 8 nibbles (state at the first
 //                  step of the NEXT chunk -> state at t0).  All 8 images are tracked until they
-//                  coalesce (they usually do within a few steps), then a single image.
+//                  coalesce (within tens of steps), then a single image -- which from there on IS
+//                  the sampled path, whatever follows the chunk.  The kernel leaves both behind:
+//                  the full map g_t of every step above the coalescence point, the state itself
+//                  (one nibble) of every step below it.
 //   k_smp_stitch : per trajectory, backwards over chunks: the state each chunk starts from.
-//   k_smp_apply  : per chunk, re-walk with the known start state and emit the path.
+//   k_smp_apply  : per chunk, walk those tables from the known start state: the path (optional
+//                  output) and its statistics; alpha and the uniforms are not read again.
 // One draw is decided on the unnormalised partial sums (c_i >= u*S) when the margin exceeds
 // 1e-13*S -- 50x the worst-case rounding difference to the reference's normalise-then-cumsum
 // arithmetic -- and falls back to exactly that arithmetic (IEEE division, ascending sums)
