@@ -4,8 +4,8 @@ The reference fits a Gaussian mixture to the pooled observations (its vendored s
 random k-means start), takes the mixture weights / means / variances as emission model, turns the
 per-step posterior memberships into fractional transition counts `N += outer(w_t, w_{t+1})` and
 estimates the transition matrix from them.  Same construction here, written from scratch: the
-mixture is fitted by plain EM from a deterministic quantile start (so that the initial model --
-and with it the whole estimation -- is reproducible), the counts are one matrix product per
+mixture is fitted by plain EM from three deterministic starts, best likelihood wins (so that the
+initial model -- and with it the whole estimation -- is reproducible), the counts are one matrix product per
 trajectory, the transition matrix comes from bhmm_amd.estimators._tmatrix.
 """
 import numpy as np
@@ -20,22 +20,10 @@ def _log_pdf(x, means, sigmas):
     return -0.5 * z * z - np.log(sigmas)[None, :] - 0.5 * np.log(2.0 * np.pi)
 
 
-def fit_gmm1d(x, ncomp, maxit=200, tol=1e-6, min_sigma=None, max_points=2000000, seed=0):
-    """EM for a 1-D Gaussian mixture.  Returns (weights, means, sigmas), components sorted by
-    mean.  Start: means at the (i + 1/2)/ncomp quantiles, common sigma, equal weights.  Data sets
-    above `max_points` are subsampled (seeded) for the fit."""
-    x = np.asarray(x, dtype=np.float64).ravel()
-    if x.size > max_points:
-        x = np.random.RandomState(seed).choice(x, max_points, replace=False)
-    if x.size < ncomp:
-        raise ValueError('fewer observations than mixture components')
-    spread = x.std()
-    if min_sigma is None:
-        min_sigma = max(1e-3 * spread, 1e-12)
-    means = np.quantile(x, (np.arange(ncomp) + 0.5) / ncomp)
-    sigmas = np.full(ncomp, max(spread / ncomp, min_sigma))
-    weights = np.full(ncomp, 1.0 / ncomp)
+def _em_gmm1d(x, weights, means, sigmas, maxit, tol, min_sigma):
+    """Plain EM from the given start; returns (mean log-likelihood, weights, means, sigmas)."""
     last = -np.inf
+    ll = -np.inf
     for _ in range(maxit):
         lp = _log_pdf(x, means, sigmas) + np.log(weights)[None, :]
         m = lp.max(axis=1, keepdims=True)
@@ -47,9 +35,59 @@ def fit_gmm1d(x, ncomp, maxit=200, tol=1e-6, min_sigma=None, max_points=2000000,
         means = (resp * x[:, None]).sum(axis=0) / nk
         var = (resp * (x[:, None] - means[None, :]) ** 2).sum(axis=0) / nk
         sigmas = np.sqrt(np.maximum(var, min_sigma ** 2))
-        if ll - last < tol * max(1.0, abs(ll)):
+        if ll - last < tol:
             break
         last = ll
+    return ll, weights, means, sigmas
+
+
+def fit_gmm1d(x, ncomp, maxit=60, tol=1e-6, min_sigma=None, max_points=100000, seed=0):
+    """EM for a 1-D Gaussian mixture.  Returns (weights, means, sigmas), components sorted by
+    mean.  EM only finds the optimum next to its start, and one start is easily a bad one (a
+    rarely visited state far from the bulk is missed by quantiles, a dense one by equal-width
+    bins), so three deterministic starts are run -- quantiles, equal-width bins over the central
+    99 % of the data, and 1-D k-means from those bins -- and the fit with the highest likelihood
+    wins.  Data sets above `max_points` are subsampled (seeded) for the fit."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    if x.size > max_points:
+        x = np.random.RandomState(seed).choice(x, max_points, replace=False)
+    if x.size < ncomp:
+        raise ValueError('fewer observations than mixture components')
+    spread = x.std()
+    if min_sigma is None:
+        min_sigma = max(1e-3 * spread, 1e-12)
+    equal = np.full(ncomp, 1.0 / ncomp)
+    starts = []
+    # (1) quantiles, common sigma
+    starts.append((equal, np.quantile(x, (np.arange(ncomp) + 0.5) / ncomp),
+                   np.full(ncomp, max(spread / ncomp, min_sigma))))
+    # (2) equal-width bins over the central 99 %
+    lo, hi = np.quantile(x, [0.005, 0.995])
+    width = max(hi - lo, 1e-300) / ncomp
+    centres = lo + (np.arange(ncomp) + 0.5) * width
+    starts.append((equal, centres, np.full(ncomp, max(0.5 * width, min_sigma))))
+    # (3) 1-D k-means (Lloyd) from those centres
+    c = centres.copy()
+    for _ in range(50):
+        edges = 0.5 * (c[1:] + c[:-1])
+        lab = np.searchsorted(edges, x)
+        cn = np.array([x[lab == k].mean() if np.any(lab == k) else c[k] for k in range(ncomp)])
+        if np.allclose(cn, c, rtol=0, atol=1e-9 * max(spread, 1e-300)):
+            break
+        c = np.sort(cn)
+    edges = 0.5 * (c[1:] + c[:-1])
+    lab = np.searchsorted(edges, x)
+    frac = np.array([max(np.mean(lab == k), 1e-6) for k in range(ncomp)])
+    sd = np.array([x[lab == k].std() if np.sum(lab == k) > 1 else spread / ncomp for k in range(ncomp)])
+    starts.append((frac / frac.sum(), c, np.maximum(sd, min_sigma)))
+    # short runs on a thinned sample choose the start, the winner is finished on the full sample
+    xs = x[::max(1, x.size // 25000)]
+    best = None
+    for w0, m0, s0 in starts:
+        fit = _em_gmm1d(xs, w0, m0, s0, 60, 1e-6, min_sigma)
+        if best is None or fit[0] > best[0] + 1e-12:
+            best = fit
+    _, weights, means, sigmas = _em_gmm1d(x, best[1], best[2], best[3], maxit, tol, min_sigma)
     order = np.argsort(means)
     return weights[order], means[order], sigmas[order]
 

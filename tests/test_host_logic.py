@@ -460,3 +460,19 @@ def test_testsystems_and_synthetic_trajectories():
     assert s[0] == 1 and (s[-1] == 2 or len(s) == 50) and 2 not in s[:-1]
     with pytest.raises(ValueError):
         model.generate_synthetic_state_trajectory(5, initial_Pi=[1, 0, 0], start=0)
+
+
+def test_gaussian_mixture_start_finds_rare_distant_state():
+    """A state visited 6 % of the time, far from the bulk, is missed by a quantile start (EM then
+    converges to a poor optimum and so does the whole estimation); the multi-start fit finds it."""
+    from bhmm_amd.init.gaussian import fit_gmm1d
+    rs = np.random.RandomState(0)
+    model, O, S = bhmm_amd.testsystems.generate_synthetic_observations(
+        nstates=3, ntrajectories=8, length=20000, rng=rs)
+    w, m, sg = fit_gmm1d(np.concatenate(O), 3)
+    np.testing.assert_allclose(m, [-5.0, 0.0, 5.0], atol=0.15)
+    np.testing.assert_allclose(sg, [0.5, 1.25, 2.0], rtol=0.1)
+    frac = np.bincount(np.concatenate(S), minlength=3) / (8 * 20000.0)
+    np.testing.assert_allclose(w, frac, atol=0.02)
+    w2, m2, sg2 = fit_gmm1d(np.concatenate(O), 3)
+    assert np.array_equal(m, m2) and np.array_equal(sg, sg2)          # reproducible
