@@ -37,6 +37,7 @@ class MaximumLikelihoodEstimator(object):
         self._nstates = nstates
         self._reversible = reversible
         self._stationary = stationary
+        self._alternative_starts = []
         if initial_model is None:
             # maximum_likelihood.py:112-118 -> bhmm.init_hmm.  Gaussian: mixture fit +
             # fractional counts (bhmm_amd/init/gaussian.py); discrete: count matrix + PCCA+
@@ -44,6 +45,14 @@ class MaximumLikelihoodEstimator(object):
             from .. import api as _api
             initial_model = _api.init_hmm(observations, nstates, output=output,
                                           reversible=reversible)
+            if output == 'gaussian' and nstates > 1:
+                # EM only finds the optimum next to its start and an E-step costs milliseconds
+                # here: a second, kinetic start is tried for a few iterations in fit() and the
+                # better one continues (init/gaussian.py: init_model_gaussian1d_kinetic)
+                from ..init.gaussian import init_model_gaussian1d_kinetic
+                alt = init_model_gaussian1d_kinetic(observations, nstates, reversible=reversible)
+                if alt is not None:
+                    self._alternative_starts.append(alt)
         self._hmm = copy.deepcopy(initial_model)
         if self._hmm.nstates != nstates:
             raise ValueError('initial_model has %d states, nstates=%d' % (self._hmm.nstates, nstates))
@@ -209,8 +218,34 @@ class MaximumLikelihoodEstimator(object):
                 paths[k] = pth
         return paths
 
+    def _select_start(self, ntrial=20):
+        """Multi-start: run `ntrial` EM iterations from every candidate initial model (only when
+        the caller gave none) and keep the model with the highest likelihood.  The iterations of
+        the winner are not wasted -- fit() continues from where they ended."""
+        if not self._alternative_starts:
+            return
+        candidates = [self._hmm] + [copy.deepcopy(h) for h in self._alternative_starts]
+        self._alternative_starts = []
+        best, best_ll = None, -np.inf
+        for cand in candidates:
+            self._hmm = cand
+            cand.output_model.set_implementation(config.kernel)
+            ll = -np.inf
+            try:
+                for _ in range(ntrial):
+                    res = self._estep()
+                    self._update_model(res, maxiter=self._maxit_P)
+                ll = self._estep().loglik
+            except (AssertionError, RuntimeError, ValueError, FloatingPointError):
+                ll = -np.inf        # a start that degenerates is simply not chosen
+            if ll > best_ll:
+                best, best_ll = cand, ll
+        if best is not None:
+            self._hmm = best
+
     def fit(self):
         """maximum_likelihood.py:354-446."""
+        self._select_start()
         it = 0
         self._likelihoods = np.zeros(self.maxit)
         loglik = 0.0

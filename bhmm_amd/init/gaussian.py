@@ -115,3 +115,57 @@ def init_model_gaussian1d(observations, nstates, reversible=True):
     P = _tmatrix.estimate_P(N, reversible=reversible)
     pi = _tmatrix.stationary_distribution(P, C=N)
     return HMM(pi, P, GaussianOutputModel(nstates, means=means, sigmas=sigmas))
+
+
+def init_model_gaussian1d_kinetic(observations, nstates, reversible=True, nbins=100):
+    """A second, kinetic start for Gaussian data: the mixture start above sees only the marginal
+    distribution of the observations, which hardly identifies overlapping states; their slow
+    kinetics does.  The observations are binned (equal width over the central 99.9 %), the bins
+    get a reversible Markov model and PCCA+ memberships as in the discrete initialiser
+    (init/discrete.py), and every metastable set becomes one Gaussian (membership- and
+    population-weighted moments of the bin centres) with the coarse-grained transition matrix.
+    Returns an HMM, or None where the construction does not apply (too few populated bins,
+    disconnected bin dynamics).  MaximumLikelihoodEstimator tries both starts (see there)."""
+    from . import discrete as _disc
+    x = np.concatenate([np.asarray(o, dtype=np.float64) for o in observations])
+    if x.size < 10 * nbins:
+        return None
+    lo, hi = np.quantile(x, [0.0005, 0.9995])
+    if not hi > lo:
+        return None
+    edges = np.linspace(lo, hi, nbins + 1)[1:-1]
+    dtrajs = [np.searchsorted(edges, np.asarray(o, dtype=np.float64)).astype(np.int32)
+              for o in observations]
+    C = _disc.count_matrix(dtrajs, 1, nstates=nbins)
+    C = C + _disc.prior_neighbor(C, 0.001)
+    used = np.where(C.sum(axis=0) + C.sum(axis=1) > 0)[0]
+    if used.size <= nstates:
+        return None
+    Cu = C[np.ix_(used, used)]
+    try:
+        P = _tmatrix.estimate_P(Cu, reversible=True, maxiter=10000)
+        if not _tmatrix.is_connected(P, strong=False):
+            return None
+        pi = _tmatrix.stationary_distribution(P, C=Cu)
+        chi = _disc.pcca_memberships(P, nstates)
+    except (ValueError, np.linalg.LinAlgError):
+        return None
+    left = np.concatenate([[lo], edges])
+    right = np.concatenate([edges, [hi]])
+    centres = 0.5 * (left + right)[used]
+    w = chi * pi[:, None]
+    wsum = w.sum(axis=0)
+    if np.any(wsum <= 0):
+        return None
+    means = (w * centres[:, None]).sum(axis=0) / wsum
+    width = (hi - lo) / nbins
+    var = (w * (centres[:, None] - means[None, :]) ** 2).sum(axis=0) / wsum + width * width / 12.0
+    order = np.argsort(means)
+    T = _disc.coarse_grain_transition_matrix(P, chi)[np.ix_(order, order)]
+    T = np.maximum(T, 0.01 / nstates)
+    T /= T.sum(axis=1)[:, None]
+    if reversible:
+        T = _tmatrix.enforce_reversible_on_closed(T)
+    return HMM(_tmatrix.stationary_vector(T), T,
+               GaussianOutputModel(nstates, means=means[order], sigmas=np.sqrt(var[order])))
+

@@ -114,3 +114,18 @@ def test_estimate_hmm_from_raw_discrete_data():
     assert np.all(lo <= hmm.transition_matrix + 0.02) and np.all(hi >= hmm.transition_matrix - 0.02)
     assert sampled.output_probabilities_mean.shape == (2, 6)
     assert np.all(sampled.timescales_mean > 5)
+
+
+def test_estimate_hmm_multi_start_five_overlapping_states():
+    """estimate_hmm(observations, 5) on the reference's dalton test system (means -5 .. 5, sigmas
+    0.5 .. 2, lifetimes 10 .. 100): the estimator tries the mixture start and the kinetic start for
+    a few GPU iterations each and recovers the generating model."""
+    rs = np.random.RandomState(3)
+    model, O, S = bhmm_amd.testsystems.generate_synthetic_observations(
+        nstates=5, ntrajectories=10, length=30000, rng=rs)
+    hmm = bhmm_amd.estimate_hmm(O, 5)
+    np.testing.assert_allclose(hmm.output_model.means, model.output_model.means, atol=0.05)
+    np.testing.assert_allclose(hmm.output_model.sigmas, model.output_model.sigmas, atol=0.05)
+    np.testing.assert_allclose(hmm.transition_matrix, model.transition_matrix, atol=0.02)
+    paths = hmm.hidden_state_trajectories
+    assert np.mean(np.concatenate(paths) == np.concatenate(S)) > 0.9

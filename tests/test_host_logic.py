@@ -476,3 +476,23 @@ def test_gaussian_mixture_start_finds_rare_distant_state():
     np.testing.assert_allclose(w, frac, atol=0.02)
     w2, m2, sg2 = fit_gmm1d(np.concatenate(O), 3)
     assert np.array_equal(m, m2) and np.array_equal(sg, sg2)          # reproducible
+
+
+def test_multi_start_recovers_overlapping_states():
+    """estimate_hmm from raw data, 4 overlapping Gaussian states (the reference's dalton model):
+    the mixture start alone ends in a poor optimum (the marginal distribution hardly identifies the
+    states), the kinetic start (bins -> Markov model -> PCCA+) finds the generating model; the
+    estimator tries both for a few iterations and continues with the better one."""
+    from bhmm_amd.init.gaussian import init_model_gaussian1d_kinetic
+    rs = np.random.RandomState(2)
+    model, O, S = bhmm_amd.testsystems.generate_synthetic_observations(
+        nstates=4, ntrajectories=4, length=20000, rng=rs)
+    alt = init_model_gaussian1d_kinetic(O, 4)
+    assert alt is not None and alt.nstates == 4 and _tmatrix.is_reversible(alt.transition_matrix)
+    assert np.all(np.diff(alt.output_model.means) > 0)
+    assert init_model_gaussian1d_kinetic([np.zeros(50)], 2) is None          # does not apply
+    est = bhmm_amd.MaximumLikelihoodEstimator(O, 4, engine_factory=OracleEngine, maxit=100)
+    h = est.fit()
+    np.testing.assert_allclose(h.output_model.means, model.output_model.means, atol=0.1)
+    np.testing.assert_allclose(h.output_model.sigmas, model.output_model.sigmas, atol=0.1)
+    np.testing.assert_allclose(h.transition_matrix, model.transition_matrix, atol=0.03)
