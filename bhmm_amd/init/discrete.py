@@ -102,8 +102,14 @@ def _pcca_connected(P, m, pi):
             evec[:, i] *= -1.0
     index = _inner_simplex(evec)
     rot = np.linalg.inv(evec[index])
-    best = fmin(_crispness, rot[1:, 1:].reshape(-1), args=(evec, m), disp=False)
-    rot = _complete_rotation(best.reshape(m - 1, m - 1), evec)
+    # the simplex search has (m - 1)^2 unknowns and no gradient: beyond ~8 metastable states it
+    # costs minutes for a refinement an initial model does not need -- the inner-simplex solution
+    # (already a feasible transformation) is used as it is
+    if (m - 1) ** 2 <= 64:
+        best = fmin(_crispness, rot[1:, 1:].reshape(-1), args=(evec, m), disp=False)
+        rot = _complete_rotation(best.reshape(m - 1, m - 1), evec)
+    else:
+        rot = _complete_rotation(rot[1:, 1:], evec)
     chi = np.clip(evec.dot(rot), 0.0, 1.0)
     return chi / chi.sum(axis=1)[:, None]
 

@@ -117,7 +117,7 @@ def init_model_gaussian1d(observations, nstates, reversible=True):
     return HMM(pi, P, GaussianOutputModel(nstates, means=means, sigmas=sigmas))
 
 
-def init_model_gaussian1d_kinetic(observations, nstates, reversible=True, nbins=100):
+def init_model_gaussian1d_kinetic(observations, nstates, reversible=True, nbins=None):
     """A second, kinetic start for Gaussian data: the mixture start above sees only the marginal
     distribution of the observations, which hardly identifies overlapping states; their slow
     kinetics does.  The observations are binned (equal width over the central 99.9 %), the bins
@@ -127,6 +127,8 @@ def init_model_gaussian1d_kinetic(observations, nstates, reversible=True, nbins=
     Returns an HMM, or None where the construction does not apply (too few populated bins,
     disconnected bin dynamics).  MaximumLikelihoodEstimator tries both starts (see there)."""
     from . import discrete as _disc
+    if nbins is None:
+        nbins = max(100, 12 * nstates)
     x = np.concatenate([np.asarray(o, dtype=np.float64) for o in observations])
     if x.size < 10 * nbins:
         return None
