@@ -108,7 +108,21 @@ def fractional_counts(observations, means, sigmas):
     return N
 
 
+def _few_million_steps(observations, limit=4000000):
+    """A start needs no more than a few million steps: whole trajectories, longest first."""
+    if sum(len(o) for o in observations) <= limit:
+        return observations
+    keep, total = [], 0
+    for k in sorted(range(len(observations)), key=lambda k: -len(observations[k])):
+        keep.append(k)
+        total += len(observations[k])
+        if total >= limit:
+            break
+    return [observations[k] for k in sorted(keep)]
+
+
 def init_model_gaussian1d(observations, nstates, reversible=True):
+    observations = _few_million_steps(observations)
     pooled = np.concatenate([np.asarray(o, dtype=np.float64).ravel() for o in observations])
     weights, means, sigmas = fit_gmm1d(pooled, nstates)
     N = fractional_counts(observations, means, sigmas)
@@ -129,6 +143,7 @@ def init_model_gaussian1d_kinetic(observations, nstates, reversible=True, nbins=
     from . import discrete as _disc
     if nbins is None:
         nbins = max(100, 12 * nstates)
+    observations = _few_million_steps(observations)
     x = np.concatenate([np.asarray(o, dtype=np.float64) for o in observations])
     if x.size < 10 * nbins:
         return None
