@@ -20,20 +20,23 @@ def _log_pdf(x, means, sigmas):
     return -0.5 * z * z - np.log(sigmas)[None, :] - 0.5 * np.log(2.0 * np.pi)
 
 
-def _em_gmm1d(x, weights, means, sigmas, maxit, tol, min_sigma):
-    """Plain EM from the given start; returns (mean log-likelihood, weights, means, sigmas)."""
+def _em_gmm1d(c, cnt, width, weights, means, sigmas, maxit, tol, min_sigma):
+    """Plain EM on histogram data (bin centres c, counts cnt, bin width) from the given start;
+    returns (mean log-likelihood, weights, means, sigmas)."""
     last = -np.inf
     ll = -np.inf
+    ntot = cnt.sum()
+    corr = width * width / 12.0 # variance of a value inside its bin
     for _ in range(maxit):
-        lp = _log_pdf(x, means, sigmas) + np.log(weights)[None, :]
+        lp = _log_pdf(c, means, sigmas) + np.log(weights)[None, :]
         m = lp.max(axis=1, keepdims=True)
         norm = m[:, 0] + np.log(np.exp(lp - m).sum(axis=1))
-        resp = np.exp(lp - norm[:, None])
-        ll = norm.mean()
+        resp = np.exp(lp - norm[:, None]) * cnt[:, None]
+        ll = np.dot(cnt, norm) / ntot
         nk = resp.sum(axis=0) + 1e-300
         weights = nk / nk.sum()
-        means = (resp * x[:, None]).sum(axis=0) / nk
-        var = (resp * (x[:, None] - means[None, :]) ** 2).sum(axis=0) / nk
+        means = (resp * c[:, None]).sum(axis=0) / nk
+        var = (resp * (c[:, None] - means[None, :]) ** 2).sum(axis=0) / nk + corr
         sigmas = np.sqrt(np.maximum(var, min_sigma ** 2))
         if ll - last < tol:
             break
@@ -41,53 +44,69 @@ def _em_gmm1d(x, weights, means, sigmas, maxit, tol, min_sigma):
     return ll, weights, means, sigmas
 
 
-def fit_gmm1d(x, ncomp, maxit=60, tol=1e-6, min_sigma=None, max_points=100000, seed=0):
+def fit_gmm1d(x, ncomp, maxit=300, tol=1e-9, min_sigma=None, nbins=4096):
     """EM for a 1-D Gaussian mixture.  Returns (weights, means, sigmas), components sorted by
-    mean.  EM only finds the optimum next to its start, and one start is easily a bad one (a
-    rarely visited state far from the bulk is missed by quantiles, a dense one by equal-width
-    bins), so three deterministic starts are run -- quantiles, equal-width bins over the central
-    99 % of the data, and 1-D k-means from those bins -- and the fit with the highest likelihood
-    wins.  Data sets above `max_points` are subsampled (seeded) for the fit."""
+    mean.  The data enter as a fine histogram (4096 equal bins over their range: the bins are far
+    narrower than any component that can be told apart, and an EM iteration then costs the same
+    for a thousand observations and for a hundred million).  EM only finds the optimum next to
+    its start, and one start is easily a bad one (a rarely visited state far from the bulk is
+    missed by quantiles, a dense one by equal-width bins), so three deterministic starts are run
+    -- quantiles, equal-width bins over the central 99 % of the data, and 1-D k-means from those
+    bins -- and the fit with the highest likelihood wins."""
     x = np.asarray(x, dtype=np.float64).ravel()
-    if x.size > max_points:
-        x = np.random.RandomState(seed).choice(x, max_points, replace=False)
     if x.size < ncomp:
         raise ValueError('fewer observations than mixture components')
-    spread = x.std()
+    lo_all, hi_all = float(x.min()), float(x.max())
+    if not hi_all > lo_all:
+        hi_all = lo_all + 1.0
+    cnt, edges = np.histogram(x, bins=nbins, range=(lo_all, hi_all))
+    keep = cnt > 0
+    c = (0.5 * (edges[1:] + edges[:-1]))[keep]
+    cnt = cnt[keep].astype(np.float64)
+    width = (hi_all - lo_all) / nbins
+    ntot = cnt.sum()
+    mean_all = np.dot(cnt, c) / ntot
+    spread = np.sqrt(np.dot(cnt, (c - mean_all) ** 2) / ntot + width * width / 12.0)
     if min_sigma is None:
         min_sigma = max(1e-3 * spread, 1e-12)
+    cdf = np.cumsum(cnt) / ntot
+
+    def quantile(q):
+        return c[np.minimum(np.searchsorted(cdf, q), c.size - 1)]
+
     equal = np.full(ncomp, 1.0 / ncomp)
     starts = []
     # (1) quantiles, common sigma
-    starts.append((equal, np.quantile(x, (np.arange(ncomp) + 0.5) / ncomp),
+    starts.append((equal, quantile((np.arange(ncomp) + 0.5) / ncomp),
                    np.full(ncomp, max(spread / ncomp, min_sigma))))
     # (2) equal-width bins over the central 99 %
-    lo, hi = np.quantile(x, [0.005, 0.995])
-    width = max(hi - lo, 1e-300) / ncomp
-    centres = lo + (np.arange(ncomp) + 0.5) * width
-    starts.append((equal, centres, np.full(ncomp, max(0.5 * width, min_sigma))))
-    # (3) 1-D k-means (Lloyd) from those centres
-    c = centres.copy()
-    for _ in range(50):
-        edges = 0.5 * (c[1:] + c[:-1])
-        lab = np.searchsorted(edges, x)
-        cn = np.array([x[lab == k].mean() if np.any(lab == k) else c[k] for k in range(ncomp)])
-        if np.allclose(cn, c, rtol=0, atol=1e-9 * max(spread, 1e-300)):
+    lo, hi = quantile(np.array([0.005, 0.995]))
+    w2 = max(hi - lo, 1e-300) / ncomp
+    centres = lo + (np.arange(ncomp) + 0.5) * w2
+    starts.append((equal, centres, np.full(ncomp, max(0.5 * w2, min_sigma))))
+    # (3) 1-D k-means (Lloyd, weighted by the counts) from those centres
+    km = centres.copy()
+    for _ in range(100):
+        lab = np.searchsorted(0.5 * (km[1:] + km[:-1]), c)
+        wsum = np.bincount(lab, weights=cnt, minlength=ncomp)
+        csum = np.bincount(lab, weights=cnt * c, minlength=ncomp)
+        kn = np.sort(np.where(wsum > 0, csum / np.maximum(wsum, 1e-300), km))
+        if np.allclose(kn, km, rtol=0, atol=1e-9 * max(spread, 1e-300)):
             break
-        c = np.sort(cn)
-    edges = 0.5 * (c[1:] + c[:-1])
-    lab = np.searchsorted(edges, x)
-    frac = np.array([max(np.mean(lab == k), 1e-6) for k in range(ncomp)])
-    sd = np.array([x[lab == k].std() if np.sum(lab == k) > 1 else spread / ncomp for k in range(ncomp)])
-    starts.append((frac / frac.sum(), c, np.maximum(sd, min_sigma)))
-    # short runs on a thinned sample choose the start, the winner is finished on the full sample
-    xs = x[::max(1, x.size // 25000)]
+        km = kn
+    lab = np.searchsorted(0.5 * (km[1:] + km[:-1]), c)
+    wsum = np.bincount(lab, weights=cnt, minlength=ncomp)
+    vsum = np.bincount(lab, weights=cnt * (c - km[lab]) ** 2, minlength=ncomp)
+    sd = np.where(wsum > 1, np.sqrt(vsum / np.maximum(wsum, 1e-300) + width * width / 12.0),
+                  spread / ncomp)
+    frac = np.maximum(wsum / ntot, 1e-6)
+    starts.append((frac / frac.sum(), km, np.maximum(sd, min_sigma)))
     best = None
     for w0, m0, s0 in starts:
-        fit = _em_gmm1d(xs, w0, m0, s0, 60, 1e-6, min_sigma)
+        fit = _em_gmm1d(c, cnt, width, w0, m0, s0, maxit, tol, min_sigma)
         if best is None or fit[0] > best[0] + 1e-12:
             best = fit
-    _, weights, means, sigmas = _em_gmm1d(x, best[1], best[2], best[3], maxit, tol, min_sigma)
+    _, weights, means, sigmas = best
     order = np.argsort(means)
     return weights[order], means[order], sigmas[order]
 
