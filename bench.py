@@ -11,8 +11,15 @@ Workload at N GPUs: BASELINE.json configs[1] per GPU -- 8-state Gaussian HMM,
 its own 256 trajectories; the packed sufficient statistics are all-reduced over RCCL).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...        # WORLD_SIZE unset: starts N ranks itself (torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+At N = 1 the same JSON line also carries `cpu_baseline` (the reference's own C kernels on one
+core, plus `all_cores`), and `secondary`: the other BASELINE configs on the same GPU -- first of
+all configs[2] on ONE GPU (8-state discrete, 1024 x 1e6: the north-star target shape, with its
+own CPU figure and the >= 50x check), then Viterbi and the Gibbs sweep at the configs[1] shape and
+configs[3] (64 states).
 """
 import argparse
 import json
@@ -99,46 +106,222 @@ def synth_gaussian_device(model, K, T, seed, device):
 
 # ---------------------------------------------------------------------------------------
 # CPU baseline: the reference's own C kernels (oracle/_ref, compiled from the reference
-# sources) driven through the call sequence of maximum_likelihood.py:249-265, one core.
+# sources) driven through the call sequence of maximum_likelihood.py:249-265.  The reference
+# is single-threaded by construction (maximum_likelihood.py:26-27), so ONE core is the
+# like-for-like figure; "all_cores" runs the same per-trajectory sequence on a thread per host
+# core (ctypes and numpy release the GIL inside the kernels; every thread owns its buffers).
 # Falls back to this repo's restatement (oracle/liboracle.so, kind "port").
 # ---------------------------------------------------------------------------------------
-def cpu_baseline(model, obs_sample):
+def _cpu_estep_traj(orc, use_ref, kind, o, A, pi, par0, par1, bufs):
+    """p_obs + forward + backward + gamma + xi of ONE trajectory; returns its log-likelihood."""
+    pobs, alpha, beta, gamma, C = bufs
+    if not use_ref:
+        return orc.estep(kind, [o], A, pi, par0, par1)["logL"][0]
+    if kind == "gaussian":
+        orc.ref_pobs_gaussian(o, par0, par1, out=pobs)
+        outl = np.where(pobs.sum(axis=1) == 0)[0]          # outputmodel.py:126-130
+        if outl.size:
+            pobs[outl, :] = 1.0
+    else:
+        np.copyto(pobs, par0[:, o].T)                      # discrete.py:150-153
+    l, _ = orc.ref_forward(A, pobs, pi, alpha)
+    orc.ref_backward(A, pobs, beta)
+    orc.ref_gamma(alpha, beta, out=gamma)                  # hidden/api.py:176-186
+    orc.ref_transition_counts(alpha, beta, A, pobs, C)
+    return l
+
+
+def cpu_baseline(kind, A, pi, par0, par1, obs_sample, threads=1):
+    """obs_sample: (K, T) array.  Returns (dict, list of per-trajectory log-likelihoods)."""
     from oracle import oracle as orc
-    A = np.ascontiguousarray(model["A_eval"])
-    pi = np.ascontiguousarray(model["pi"])
-    mu = np.ascontiguousarray(model["mu_eval"])
-    sig = np.ascontiguousarray(model["sigma"])
+    A, pi, par0 = (np.ascontiguousarray(x, dtype=np.float64) for x in (A, pi, par0))
+    par1 = np.ascontiguousarray(par1, dtype=np.float64) if par1 is not None else None
     K, T = obs_sample.shape
     n = A.shape[0]
     use_ref = orc.ref_available()
-    pobs = np.zeros((T, n))
-    alpha = np.zeros((T, n))
-    beta = np.zeros((T, n))
-    gamma = np.zeros((T, n))
-    C = np.zeros((n, n))
-    ll = 0.0
+    if use_ref:
+        orc.ref()
+
+    def work(ks):
+        bufs = [np.zeros((T, n)) for _ in range(4)] + [np.zeros((n, n))]
+        return [(k, _cpu_estep_traj(orc, use_ref, kind, np.ascontiguousarray(obs_sample[k]), A, pi,
+                                    par0, par1, bufs)) for k in ks]
+
     t0 = time.perf_counter()
-    for k in range(K):
-        o = np.ascontiguousarray(obs_sample[k])
-        if use_ref:
-            orc.ref_pobs_gaussian(o, mu, sig, out=pobs)
-            outl = np.where(pobs.sum(axis=1) == 0)[0]      # outputmodel.py:126-130
-            if outl.size:
-                pobs[outl, :] = 1.0
-            l, _ = orc.ref_forward(A, pobs, pi, alpha)
-            orc.ref_backward(A, pobs, beta)
-            orc.ref_gamma(alpha, beta, out=gamma)           # hidden/api.py:176-186
-            orc.ref_transition_counts(alpha, beta, A, pobs, C)
-        else:
-            r = orc.estep("gaussian", [o], A, pi, mu, sig)
-            l = r["logL"][0]
-        ll += l
+    if threads <= 1:
+        res = work(range(K))
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as ex:
+            res = sum(ex.map(work, [range(w, K, threads) for w in range(threads)]), [])
     dt = time.perf_counter() - t0
-    return dict(value=K * T / dt, unit="timesteps/s", cores=1,
+    ll = [l for _, l in sorted(res)]
+    return dict(value=K * T / dt, unit="timesteps/s", cores=threads,
                 kind="reference" if use_ref else "port",
-                sample="%d of the workload's trajectories x %d steps, 8-state Gaussian, "
+                sample="%d of the workload's trajectories x %d steps, %d-state %s, "
                        "p_obs+forward+backward+gamma+xi per trajectory as in "
-                       "maximum_likelihood.py:249-265, %.1f s on one core" % (K, T, dt)), ll
+                       "maximum_likelihood.py:249-265, %.1f s on %d core(s)"
+                       % (K, T, n, kind, dt, threads)), ll
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+# ---------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves.  This parent never touches the GPU.
+# ---------------------------------------------------------------------------------------
+def self_launch(args, argv):
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in p.stdout.decode("utf-8", "replace").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    elif p.returncode == 0:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
+def timeit(fn, reps, sync):
+    fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+# ---------------------------------------------------------------------------------------
+# secondary measurements (N = 1): the other BASELINE configs on the same GPU
+# ---------------------------------------------------------------------------------------
+def secondary_c3(torch, dev, local, args):
+    """configs[2] on ONE GPU: 8-state discrete (M = 64), 1024 x 1e6 -- the north-star target
+    shape.  Observations are drawn on the device (bhmm_synth_observations)."""
+    from bhmm_amd.engine import Engine, synth_observations
+    rng = np.random.default_rng(3000)
+    n, M, K, T = 8, 64, args.c3_ntraj, args.c3_length
+    A = metastable_matrix(n, rng)
+    pi = stationary(A)
+    B = rng.dirichlet(np.ones(M), size=n)
+    A_eval, B_eval = 0.9 * A + 0.1 / n, 0.8 * B + 0.2 / M
+    obs = torch.empty(K * T, dtype=torch.int32, device=dev)
+    t0 = time.perf_counter()
+    synth_observations("discrete", obs.data_ptr(), A, pi, B, None, K, T, seed=3000, device=local)
+    t_gen = time.perf_counter() - t0
+    eng = Engine(local)
+    eng.set_observations_device("discrete", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T,
+                                n, nsymbols=M)
+    eng.estep(A_eval, pi, B_eval)                      # measures the warm-up length, verifies
+    dt = timeit(lambda: eng.estep(A_eval, pi, B_eval), args.c3_steps, eng.sync)
+    r = eng.estep(A_eval, pi, B_eval)
+    kms = eng.kernel_ms(2)
+    np.testing.assert_allclose(r.state_counts.sum(), K * T, rtol=1e-9)
+    np.testing.assert_allclose(r.C.sum(), K * (T - 1), rtol=1e-9)
+    b_alg = 2 * 4 + 16 * n                               # 136 B / step, SURVEY.md 8(d)
+    out = {"config": "configs[2] on ONE GPU: 8-state discrete HMM (M=64), %d trajectories x %d "
+                     "timesteps, one full E-step" % (K, T),
+           "ms": 1e3 * dt, "timesteps_per_s": K * T / dt,
+           "roofline": {"bound": "hbm", "alg_bytes_per_timestep": b_alg,
+                        "achieved": b_alg * K * T / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": b_alg * K * T / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "kernel_ms": kms, "whole_estep_frac": b_alg * K * T / dt / 1e9 / HBM_PEAK_GBS},
+           "chunk_len": eng.chunk_len, "chunks": eng.num_chunks,
+           "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")},
+           "synth_seconds": t_gen}
+    if not args.no_cpu:
+        kc = min(args.c3_cpu_traj, K)
+        sample = obs[: kc * T].cpu().numpy().reshape(kc, T)
+        cb, ll = cpu_baseline("discrete", A_eval, pi, B_eval, None, sample, threads=1)
+        rel = float(np.max(np.abs((r.logL_k[:kc] - np.array(ll)) / np.array(ll))))
+        assert rel < 1e-9, "configs[2]: GPU/CPU log-likelihood mismatch %g" % rel
+        cb["loglik_rel_diff_vs_gpu"] = rel
+        out["cpu_baseline"] = cb
+        out["speedup_vs_1core"] = out["timesteps_per_s"] / cb["value"]
+        out["target_50x_met"] = bool(out["speedup_vs_1core"] >= 50.0)
+        assert out["target_50x_met"], "north-star target (>= 50x the reference CPU path) missed"
+    eng.close()
+    del obs
+    return out
+
+
+def secondary_c2_paths(torch, dev, local, eng, model, K, T, args):
+    """Viterbi (bit-exact, one byte per step, device-resident result) and the Gibbs hidden-path
+    sweep on the headline workload's engine (configs[1] shape; configs[4] is this sweep x 100)."""
+    margs = (model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
+    res = []
+    pdev = torch.empty(K * T, dtype=torch.uint8, device=dev)
+    dt = timeit(lambda: eng.viterbi_u8(*margs, out=pdev), 5, eng.sync)
+    ppin = torch.empty(K * T, dtype=torch.uint8).pin_memory()
+    dth = timeit(lambda: eng.viterbi_u8(*margs, out=ppin), 5, eng.sync)
+    assert torch.equal(pdev.cpu(), ppin)
+    b_alg = 8 + 2 * 4 * 8 + 4       # SURVEY.md 8(d): obs + int32 back-pointers written and read + path
+    res.append({"config": "Viterbi at the configs[1] shape (8-state Gaussian, %d x %d), paths as "
+                          "uint8" % (K, T),
+                "ms_device_result": 1e3 * dt, "ms_pinned_host_result": 1e3 * dth,
+                "timesteps_per_s": K * T / dt, "chunked": eng.get_option("viterbi_chunked"),
+                "roofline": {"bound": "hbm", "alg_bytes_per_timestep": b_alg,
+                             "frac": b_alg * K * T / dt / 1e9 / HBM_PEAK_GBS}})
+    sbuf = torch.zeros(eng.path_stats_size, dtype=torch.float64, device=dev)
+    dt = timeit(lambda: eng.sample_paths_dev(*margs, sbuf.data_ptr(), seed=1), 10, eng.sync)
+    C, n0, _ = eng.unpack_path_stats(sbuf.cpu().numpy())
+    assert C.sum() == K * (T - 1) and n0.sum() == K
+    b_alg = 2 * 8 + 16 * 8 + 4                           # SURVEY.md 8(d): Gibbs path sweep
+    res.append({"config": "configs[4] sweep: Gibbs hidden-path step (forward + backward sampling + "
+                          "path statistics), 8-state Gaussian, %d x %d, one GPU" % (K, T),
+                "ms": 1e3 * dt, "timesteps_per_s": K * T / dt, "sweeps_100_seconds": 100 * dt,
+                "roofline": {"bound": "hbm", "alg_bytes_per_timestep": b_alg,
+                             "frac": b_alg * K * T / dt / 1e9 / HBM_PEAK_GBS}})
+    return res
+
+
+def secondary_c4(torch, dev, local, args):
+    """configs[3]: 64-state Gaussian, 128 x 1e5 (fp64-throughput bound)."""
+    from bhmm_amd.engine import Engine, synth_observations
+    rng = np.random.default_rng(64)
+    n, K, T = 64, 128, 100000
+    A = metastable_matrix(n, rng)
+    pi = stationary(A)
+    mu, sig = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
+    obs = torch.empty(K * T, dtype=torch.float64, device=dev)
+    synth_observations("gaussian", obs.data_ptr(), A, pi, mu, sig, K, T, seed=6400, device=local)
+    eng = Engine(local)
+    eng.set_observations_device("gaussian", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, n)
+    margs = (0.9 * A + 0.1 / n, pi, mu + 0.05, sig)
+    for _ in range(3):                 # lets the segment plan settle on a warm-up that verifies
+        eng.estep(*margs)
+    dt = timeit(lambda: eng.estep(*margs), 3, eng.sync)
+    r = eng.estep(*margs)
+    np.testing.assert_allclose(r.state_counts.sum(), K * T, rtol=1e-9)
+    flops = 2.0 * 3 * n * n                              # forward, backward, xi: n*n FMAs each
+    out = {"config": "configs[3]: 64-state Gaussian HMM, %d x %d, one full E-step" % (K, T),
+           "ms": 1e3 * dt, "timesteps_per_s": K * T / dt,
+           "roofline": {"bound": "fp64", "alg_flop_per_timestep": flops,
+                        "achieved": flops * K * T / dt / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                        "frac": flops * K * T / dt / 1e12 / 78.6},
+           "segments": eng.get_option("wide_segments"),
+           "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")}}
+    eng.close()
+    return out
 
 
 # ---------------------------------------------------------------------------------------
@@ -150,34 +333,66 @@ def main():
     ap.add_argument("--ntraj", type=int, default=256)
     ap.add_argument("--length", type=int, default=100000)
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--cpu-traj", type=int, default=200, help="trajectories in the CPU baseline")
+    ap.add_argument("--cpu-traj", type=int, default=200, help="trajectories in the 1-core CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--c3-ntraj", type=int, default=1024)
+    ap.add_argument("--c3-length", type=int, default=1000000)
+    ap.add_argument("--c3-steps", type=int, default=5)
+    ap.add_argument("--c3-cpu-traj", type=int, default=6)
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST AID for boxes with fewer GPUs than ranks: ranks share GPUs "
+                         "(local rank modulo device count) and the all-reduce runs over gloo")
     args = ap.parse_args()
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        # never exec / re-exec from a process that touched the GPU: this parent has not
+        sys.exit(self_launch(args, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    distributed = launched
+
+    K, T = args.ntraj, args.length
+    model = make_c2_model()
+    obs_host = synth_gaussian(model, K, T, seed=1000 * 2 + rank)   # this rank's trajectories
+    off = np.arange(K + 1, dtype=np.int64) * T
+
+    # CPU legs first, before this process initialises the GPU (rank 0, N = 1 only)
+    cb = cb_all = ll_cpu = None
+    if world == 1 and not args.no_cpu:
+        mcpu = (model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
+        cb, ll_cpu = cpu_baseline("gaussian", *mcpu, obs_host[: args.cpu_traj], threads=1)
+        nc = host_cores()
+        if nc > 1:
+            cb_all, ll_all = cpu_baseline("gaussian", *mcpu, obs_host, threads=nc)
+            assert np.allclose(ll_all[: args.cpu_traj], ll_cpu, rtol=1e-13)
 
     import torch
     import torch.distributed as dist
     from bhmm_amd.engine import Engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # launched by torch.distributed.run (even with one rank): bring up RCCL
-    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count()
+    if args.oversubscribe:
+        local = local % max(ndev, 1)
+    assert local < ndev, "rank %d wants GPU %d but only %d visible" % (rank, local, ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = "gloo" if args.oversubscribe else "nccl"
     if distributed:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    K, T = args.ntraj, args.length
-    model = make_c2_model()
-    obs_host = synth_gaussian(model, K, T, seed=1000 * 2 + rank)   # this rank's trajectories
     obs_dev = torch.from_numpy(obs_host.reshape(-1)).to(dev)
-    off = np.arange(K + 1, dtype=np.int64) * T
-
     stream = torch.cuda.current_stream(dev)
     eng = Engine(local, stream=stream.cuda_stream)
     eng.set_observations_device("gaussian", obs_dev.data_ptr(), off, NSTATES, chunk=args.chunk)
@@ -193,9 +408,13 @@ def main():
             return host_stats
         eng.estep_launch(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"],
                          stats_dev=stats.data_ptr())
-        dist.all_reduce(stats)                          # RCCL sum of the packed statistics
-        host_stats.copy_(stats, non_blocking=True)
-        stream.synchronize()                            # statistics are on the host
+        if backend == "nccl":
+            dist.all_reduce(stats)                      # RCCL sum of the packed statistics
+            host_stats.copy_(stats, non_blocking=True)
+            stream.synchronize()                        # statistics are on the host
+        else:
+            host_stats.copy_(stats)
+            dist.all_reduce(host_stats)
         return host_stats
 
     def fence():
@@ -216,12 +435,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     res = eng.unpack(host_stats.numpy().copy())
     assert np.isfinite(res.loglik)
-    # sanity of the reduced statistics: every step carries unit gamma mass
+    # sanity of the reduced statistics: every step of every rank carries unit gamma mass
     np.testing.assert_allclose(res.state_counts.sum(), world * K * T, rtol=1e-9)
 
     if rank == 0:
@@ -234,13 +453,16 @@ def main():
         # kernel k_estep carries them (obs twice, alpha written once and read once).
         alg_bytes_launch = B_ALG_GAUSS * K * T
         achieved = alg_bytes_launch / (kern_ms[2] * 1e-3) / 1e9
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01", "r01q_traffic.json")
-        if os.path.exists(tj) and (K, T) == (256, 100000):
-            # HBM bytes of the two sweep launches of one E-step from the PMC counters (collected offline with
-            # rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)
-            if eng.get_option("spec_ok") > 0 and eng.get_option("spec_fail") == 0:
-                traffic = json.load(open(tj))["traffic_bytes_per_launch"]
+        traffic, traffic_file = None, None
+        for cand in ("r02/r02_traffic.json", "r01/r01q_traffic.json"):
+            tj = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(tj) and (K, T) == (256, 100000):
+                # HBM bytes of the sweep launches of one E-step from the PMC counters: collected
+                # OFFLINE with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+                # correction applied), same workload and kernels -- not re-measured by this run
+                if eng.get_option("spec_ok") > 0 and eng.get_option("spec_fail") == 0:
+                    traffic, traffic_file = json.load(open(tj))["traffic_bytes_per_launch"], cand
+                break
         out = {
             "metric": "timesteps/sec forward-backward (whole node), N=8 states",
             "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
@@ -254,31 +476,45 @@ def main():
                        "speculative_boundaries": {k: eng.get_option(k) for k in
                                                   ("spec_enabled", "spec_W", "spec_ok", "spec_fail",
                                                    "spec_last_dev")},
-                       "parallelism": "trajectories sharded over %d GPU(s), RCCL all-reduce of "
+                       "collective": ("RCCL all-reduce" if backend == "nccl" else
+                                      "gloo all-reduce (--oversubscribe test aid: ranks share GPUs)")
+                                     if distributed else "none (one process)",
+                       "parallelism": "trajectories sharded over %d GPU(s), all-reduce of "
                                       "%d statistics" % (world, S)},
             "roofline": {"bound": "hbm", "kernel": "k_estep_light<8,gauss,spec,P1> + k_estep<8,gauss,spec,P2> (the sweep of one E-step)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, profiles/r01/r01q_traffic.json)",
+                         "traffic_is_live": False,
+                         "traffic_source": ("offline rocprofv3 PMC passes on the same workload, "
+                                            "profiles/%s" % traffic_file) if traffic_file else None,
                          "alg_bytes_per_launch": alg_bytes_launch,
                          "alg_bytes_per_timestep": B_ALG_GAUSS,
                          "whole_estep_frac": B_ALG_GAUSS * value / world / 1e9 / HBM_PEAK_GBS},
             "kernel_ms": {names[i]: float(kern_ms[i]) for i in range(5)},
             "dominant_kernel": names[dom],
         }
-        if world == 1 and not args.no_cpu:
-            cb, ll_cpu = cpu_baseline(model, obs_host[: args.cpu_traj])
+        if cb is not None:
             # parity on the very same trajectories, asserted in the same run
             eng2 = Engine(local, stream=stream.cuda_stream)
             sub = obs_dev[: args.cpu_traj * T]
             eng2.set_observations_device("gaussian", sub.data_ptr(),
                                          off[: args.cpu_traj + 1], NSTATES)
             r2 = eng2.estep(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
-            rel = abs(r2.loglik - ll_cpu) / abs(ll_cpu)
+            rel = abs(r2.loglik - sum(ll_cpu)) / abs(sum(ll_cpu))
             assert rel < 1e-9, "GPU/CPU log-likelihood mismatch %g" % rel
             cb["loglik_rel_diff_vs_gpu"] = rel
             eng2.close()
+            if cb_all is not None:
+                cb["all_cores"] = {k: cb_all[k] for k in ("value", "unit", "cores", "sample")}
             out["cpu_baseline"] = cb
+        if world == 1 and not args.no_secondary:
+            sec = secondary_c2_paths(torch, dev, local, eng, model, K, T, args)
+            eng.close()
+            del obs_dev
+            torch.cuda.empty_cache()
+            sec.insert(0, secondary_c3(torch, dev, local, args))
+            sec.append(secondary_c4(torch, dev, local, args))
+            out["secondary"] = sec
         print(json.dumps(out))
     eng.close()
     if distributed:

@@ -66,6 +66,13 @@ SIGNATURES = {
     "bhmm_get_gamma": (ctypes.c_int, [c_void_p, ctypes.c_int, c_double_p]),
     "bhmm_viterbi_batch": (ctypes.c_int, [c_void_p, c_double_p, c_double_p, c_double_p,
                                           c_double_p, c_int32_p]),
+    "bhmm_viterbi_batch_u8": (ctypes.c_int, [c_void_p, c_double_p, c_double_p, c_double_p,
+                                             c_double_p, c_void_p, ctypes.c_int]),
+    "bhmm_ctx_path_stats_size": (ctypes.c_int, [c_void_p]),
+    "bhmm_ctx_set_stream_offsets": (ctypes.c_int, [c_void_p, c_int64_p]),
+    "bhmm_sample_paths_dev": (ctypes.c_int, [c_void_p, c_double_p, c_double_p, c_double_p,
+                                             c_double_p, c_double_p, ctypes.c_uint64, c_int32_p,
+                                             c_void_p]),
     "bhmm_sample_paths": (ctypes.c_int, [c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                          c_double_p, ctypes.c_uint64, c_int32_p, c_int64_p,
                                          c_int64_p, c_double_p]),
@@ -77,6 +84,10 @@ SIGNATURES = {
     "bhmm_ctx_last_kernel_ms": (ctypes.c_double, [c_void_p, ctypes.c_int]),
     "bhmm_ctx_stream": (c_void_p, [c_void_p]),
     "bhmm_ctx_sync": (ctypes.c_int, [c_void_p]),
+    "bhmm_synth_observations": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p,
+                                               ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                               c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int64, ctypes.c_uint64]),
     "bhmm_diag_exp_nonpos": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int64]),
 }
 

@@ -942,6 +942,7 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
+    c->d_soff.release();
     c->d_ctraj.release();
     c->d_clen.release();
     c->d_traj_c0.release();
@@ -1016,6 +1017,8 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         return invalid("nsymbols must be >= 1 for discrete emissions");
     BHMM_HIP(hipSetDevice(c->device));
     BHMM_HIP(hipStreamSynchronize(c->stream));
+    c->d_soff.release(); // random-stream positions belong to the previous trajectories
+    c->last_stats = nullptr;
     c->kind = kind;
     c->n = nstates;
     c->wide = nstates > 8;
@@ -1240,6 +1243,7 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     c->gamma_valid = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
     double *sd = stats_dev ? stats_dev : c->d_stats.p;
     c->last_stats_internal = (stats_dev == nullptr);
+    c->last_stats = sd;
     c->prefetched = false;
     c->ev_lean = false;
     if (c->wide)
@@ -1253,8 +1257,12 @@ int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
         return invalid("no observations loaded");
     BHMM_HIP(hipSetDevice(c->device));
     const int S = stats_size(c);
-    if (!(c->prefetched && c->last_stats_internal)) {
-        BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->d_stats.p, S * sizeof(double), hipMemcpyDeviceToHost,
+    // statistics come from the buffer the E-step wrote (the caller's, if it gave one: a caller that
+    // all-reduces that buffer in place fetches before reducing, or asks for logL_k only)
+    if (!c->prefetched) {
+        if (!c->last_stats)
+            return invalid("no E-step has run on these observations");
+        BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->last_stats, S * sizeof(double), hipMemcpyDeviceToHost,
                                 c->stream));
         BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, c->K * sizeof(double),
                                 hipMemcpyDeviceToHost, c->stream));

@@ -82,6 +82,8 @@ struct bhmm_ctx {
     bhmm::DevBuf<char> d_scratch;    // paths, uniforms, pointer tables ...
     bhmm::DevBuf<char> d_scratch2;
     bhmm::DevBuf<int64_t> d_offsets; // [K+1] trajectory offsets (time steps)
+    bhmm::DevBuf<int64_t> d_soff;    // [K] position of each trajectory in the device random stream
+                                     // (unset: its offset here; a sharded caller sets global ones)
     bhmm::DevBuf<double> d_Brm;      // [n][M] emission matrix, row-major (path kernels)
     bhmm::DevBuf<double> d_alpha_rm; // [total][n] alpha, trajectory-major (path sampling)
     bhmm::DevBuf<double> d_wmodel;   // model parameters of the 9..64-state family
@@ -132,6 +134,7 @@ struct bhmm_ctx {
     bool wide_careful = false;  // 9..64 states: lazily scaled kernels left their range on these data
     bool prefetched = false;          // stats + logL_k of the last E-step already sit in h_pinned
     bool last_stats_internal = true;
+    double *last_stats = nullptr;     // device buffer the last E-step wrote its statistics to
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_pending = false;
     double last_ms[5] = {0, 0, 0, 0, 0};

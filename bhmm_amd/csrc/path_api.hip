@@ -54,7 +54,7 @@ struct Tmp { // scoped raw device allocations for the context-free entry points
 template <int N>
 int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1, const double *u, uint64_t seed, int32_t *paths, int64_t *counts,
-               int64_t *n0, double *emis)
+               int64_t *n0, double *emis, double *stats_dev)
 {
     int rc = forward_ci(c, A, pi, par0, par1); // alpha -> CI workspace
     if (rc)
@@ -106,6 +106,7 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         const int64_t *offd = c->d_offsets.p;
         const void *obs_ci = c->d_obs_ci.p;
         hipLaunchKernelGGL((k_smp_maps<N>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd,
+                           (const int64_t *)(c->d_soff.p ? c->d_soff.p : c->d_offsets.p),
                            (const double *)c->d_ws.p, (const double *)udev, seed, P, fmap, status, dmark,
                            nib, W8, Gp64, gw, Lp);
         BHMM_HIP(hipGetLastError());
@@ -135,12 +136,20 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     std::vector<unsigned long long> hc(nstat);
     std::vector<double> he(esz);
     int hstatus = 0;
-    BHMM_HIP(hipMemcpyAsync(hc.data(), cnt, nstat * sizeof(unsigned long long),
-                            hipMemcpyDeviceToHost, c->stream));
+    if (stats_dev) {
+        // statistics stay on the device, packed for the caller's all-reduce
+        hipLaunchKernelGGL(k_pack_path_stats, dim3(1), dim3(256), 0, c->stream,
+                           (const unsigned long long *)cnt, (const double *)ered, n, N, c->M, c->kind,
+                           1, stats_dev);
+        BHMM_HIP(hipGetLastError());
+    } else {
+        BHMM_HIP(hipMemcpyAsync(hc.data(), cnt, nstat * sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, c->stream));
+        if (esz)
+            BHMM_HIP(hipMemcpyAsync(he.data(), ered, esz * sizeof(double), hipMemcpyDeviceToHost,
+                                    c->stream));
+    }
     BHMM_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (esz)
-        BHMM_HIP(hipMemcpyAsync(he.data(), ered, esz * sizeof(double), hipMemcpyDeviceToHost,
-                                c->stream));
     if (paths)
         BHMM_HIP(hipMemcpyAsync(paths, path, (size_t)c->total * sizeof(int32_t),
                                 hipMemcpyDeviceToHost, c->stream));
@@ -149,6 +158,8 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         set_error("random choice found no state: alpha/A not normalisable (_hidden.c:299-304)");
         return hstatus;
     }
+    if (stats_dev)
+        return BHMM_OK;
     if (counts)
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j)
@@ -170,8 +181,11 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
 }
 
 // ---- 9..64 states ---------------------------------------------------------------------
+// out_fmt: 0 = int32 paths to a host buffer (the reference's type, hidden.pyx:161-162),
+// 1 = one byte per step to a host buffer, 2 = one byte per step into a device buffer of the
+// context's device (written by the back-trace kernels directly, no copy at all)
 int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
-                     const double *par1, int32_t *paths_host)
+                     const double *par1, void *paths_out, int out_fmt)
 {
     WideModel m;
     int rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m);
@@ -186,6 +200,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     uint8_t *ptr = reinterpret_cast<uint8_t *>(c->d_scratch.p);
     int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
     int32_t *path = last + K;
+    uint8_t *path8 = out_fmt == 2 ? static_cast<uint8_t *>(paths_out) : reinterpret_cast<uint8_t *>(path);
     uint32_t *vmaps = reinterpret_cast<uint32_t *>(path + c->total); // chunked run: chunk maps,
     int32_t *vend = reinterpret_cast<int32_t *>(vmaps + gpad);       // state at each chunk's end
     // U trajectories per lane group.  Measured on configs[1] (256 trajectories): the kernel is
@@ -285,32 +300,50 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         hipLaunchKernelGGL(k_smp_stitch, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB), dim3(64), 0,
                            c->stream, (const int32_t *)c->d_traj_c0.p, K, 1, (const uint32_t *)vmaps,
                            vend, (const int32_t *)last);
-        hipLaunchKernelGGL((k_vit_walk<8, true>), wg, dim3(64), 0, c->stream, chs, c->G, n,
-                           (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path);
-    } else {
-        hipLaunchKernelGGL(k_wide_viterbi_trace, dim3(K), dim3(64), 0, c->stream, off, K, n,
+        if (out_fmt == 0)
+            hipLaunchKernelGGL((k_vit_walk<8, true, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path);
+        else
+            hipLaunchKernelGGL((k_vit_walk<8, true, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path8);
+    } else if (out_fmt == 0) {
+        hipLaunchKernelGGL(k_wide_viterbi_trace<int32_t>, dim3(K), dim3(64), 0, c->stream, off, K, n,
                            (const uint8_t *)ptr, (const int32_t *)last, path);
+    } else {
+        hipLaunchKernelGGL(k_wide_viterbi_trace<uint8_t>, dim3(K), dim3(64), 0, c->stream, off, K, n,
+                           (const uint8_t *)ptr, (const int32_t *)last, path8);
     }
     BHMM_HIP(hipGetLastError());
-    // large results: pin the caller's buffer for the transfer (a pageable destination goes
-    // through the runtime's staging buffers at a fraction of the link rate)
-    const size_t pbytes = (size_t)c->total * sizeof(int32_t);
-    const bool pinned = pbytes >= ((size_t)8 << 20) &&
-                        hipHostRegister(paths_host, pbytes, hipHostRegisterDefault) == hipSuccess;
+    if (out_fmt == 2) { // the paths are where the caller wants them; the call still completes them
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        return BHMM_OK;
+    }
+    // large results into a pageable buffer: pin it for the transfer (a pageable destination goes
+    // through the runtime's staging buffers at a fraction of the link rate); a buffer the caller
+    // pinned already (hipHostMalloc / hipHostRegister, torch pin_memory) is used as it is
+    const size_t pbytes = (size_t)c->total * (out_fmt == 0 ? sizeof(int32_t) : sizeof(uint8_t));
+    hipPointerAttribute_t attr;
+    bool caller_pinned = hipPointerGetAttributes(&attr, paths_out) == hipSuccess &&
+                         attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    const bool pinned = !caller_pinned && pbytes >= ((size_t)8 << 20) &&
+                        hipHostRegister(paths_out, pbytes, hipHostRegisterDefault) == hipSuccess;
     if (!pinned)
         (void)hipGetLastError();
-    hipError_t ce = hipMemcpyAsync(paths_host, path, pbytes, hipMemcpyDeviceToHost, c->stream);
+    hipError_t ce = hipMemcpyAsync(paths_out, out_fmt == 0 ? static_cast<const void *>(path)
+                                                           : static_cast<const void *>(path8),
+                                   pbytes, hipMemcpyDeviceToHost, c->stream);
     if (ce == hipSuccess)
         ce = hipStreamSynchronize(c->stream);
     if (pinned)
-        (void)hipHostUnregister(paths_host);
+        (void)hipHostUnregister(paths_out);
     BHMM_HIP(ce);
     return BHMM_OK;
 }
 
 int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                     const double *par1, const double *u, uint64_t seed, int32_t *paths,
-                    int64_t *counts, int64_t *n0, double *emis)
+                    int64_t *counts, int64_t *n0, double *emis, double *stats_dev)
 {
     int rc = wide_forward(c, A, pi, par0, par1); // alpha (row-major) in d_alpha_rm
     if (rc)
@@ -346,15 +379,18 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
     const int64_t *off = c->d_offsets.p;
     if (NP == 16)
         hipLaunchKernelGGL((k_wide_sample_path<16>), grid, blk, 0, c->stream, m, off, K,
-                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status);
+                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,
+                           (const int64_t *)c->d_soff.p);
     else if (NP == 32)
         hipLaunchKernelGGL((k_wide_sample_path<32>), grid, blk, 0, c->stream, m, off, K,
-                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status);
+                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,
+                           (const int64_t *)c->d_soff.p);
     else
         hipLaunchKernelGGL((k_wide_sample_path<64>), grid, blk, 0, c->stream, m, off, K,
-                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status);
+                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,
+                           (const int64_t *)c->d_soff.p);
     BHMM_HIP(hipGetLastError());
-    if (counts || n0 || emis) {
+    if (counts || n0 || emis || stats_dev) {
         const size_t sm = esz * sizeof(double) + nstat * sizeof(unsigned int);
         const void *obs = c->d_obs_rm.p;
         if (c->kind == EMIT_GAUSS)
@@ -376,12 +412,19 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
     std::vector<unsigned long long> hc(nstat);
     std::vector<double> he(esz);
     int hstatus = 0;
-    BHMM_HIP(hipMemcpyAsync(hc.data(), cnt, nstat * sizeof(unsigned long long),
-                            hipMemcpyDeviceToHost, c->stream));
+    if (stats_dev) {
+        hipLaunchKernelGGL(k_pack_path_stats, dim3(16), dim3(256), 0, c->stream,
+                           (const unsigned long long *)cnt, (const double *)ered, n, n, c->M, c->kind,
+                           0, stats_dev);
+        BHMM_HIP(hipGetLastError());
+    } else {
+        BHMM_HIP(hipMemcpyAsync(hc.data(), cnt, nstat * sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, c->stream));
+        if (esz)
+            BHMM_HIP(hipMemcpyAsync(he.data(), ered, esz * sizeof(double), hipMemcpyDeviceToHost,
+                                    c->stream));
+    }
     BHMM_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (esz)
-        BHMM_HIP(hipMemcpyAsync(he.data(), ered, esz * sizeof(double), hipMemcpyDeviceToHost,
-                                c->stream));
     if (paths)
         BHMM_HIP(hipMemcpyAsync(paths, path, (size_t)c->total * sizeof(int32_t),
                                 hipMemcpyDeviceToHost, c->stream));
@@ -390,6 +433,8 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
         set_error("random choice found no state: alpha/A not normalisable (_hidden.c:299-304)");
         return hstatus;
     }
+    if (stats_dev)
+        return BHMM_OK;
     if (counts)
         for (size_t e = 0; e < (size_t)n * n; ++e)
             counts[e] = (int64_t)hc[e];
@@ -436,7 +481,22 @@ int bhmm_viterbi_batch(bhmm_ctx *c, const double *A, const double *pi, const dou
         return invalid_arg("discrete emissions need B");
     BHMM_HIP(hipSetDevice(c->device));
     // all state counts use the LDS-exchange kernels (k_wide_viterbi_*)
-    return wide_viterbi_run(c, A, pi, par0, par1, paths);
+    return wide_viterbi_run(c, A, pi, par0, par1, paths, 0);
+}
+
+int bhmm_viterbi_batch_u8(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                          const double *par1, uint8_t *paths, int paths_on_device)
+{
+    if (!c || c->kind < 0)
+        return invalid_arg("no observations loaded");
+    if (!A || !pi || !paths)
+        return invalid_arg("NULL argument");
+    if (c->kind == BHMM_EMIT_GAUSSIAN && (!par0 || !par1))
+        return invalid_arg("gaussian emissions need means and sigmas");
+    if (c->kind == BHMM_EMIT_DISCRETE && !par0)
+        return invalid_arg("discrete emissions need B");
+    BHMM_HIP(hipSetDevice(c->device));
+    return wide_viterbi_run(c, A, pi, par0, par1, paths, paths_on_device ? 2 : 1);
 }
 
 int bhmm_sample_paths(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
@@ -449,14 +509,60 @@ int bhmm_sample_paths(bhmm_ctx *c, const double *A, const double *pi, const doub
         return invalid_arg("NULL argument");
     BHMM_HIP(hipSetDevice(c->device));
     if (c->wide)
-        return wide_sample_run(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis);
+        return wide_sample_run(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, nullptr);
     switch (c->N) {
     case 2:
-        return sample_run<2>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis);
+        return sample_run<2>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, nullptr);
     case 4:
-        return sample_run<4>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis);
+        return sample_run<4>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, nullptr);
     default:
-        return sample_run<8>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis);
+        return sample_run<8>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, nullptr);
+    }
+}
+
+int bhmm_ctx_set_stream_offsets(bhmm_ctx *c, const int64_t *soff)
+{
+    if (!c || c->kind < 0)
+        return invalid_arg("no observations loaded");
+    BHMM_HIP(hipSetDevice(c->device));
+    if (!soff) {
+        c->d_soff.release();
+        return BHMM_OK;
+    }
+    int rc = c->d_soff.ensure((size_t)std::max(c->K, 1));
+    if (rc)
+        return rc;
+    BHMM_HIP(hipMemcpy(c->d_soff.p, soff, (size_t)c->K * sizeof(int64_t), hipMemcpyHostToDevice));
+    return BHMM_OK;
+}
+
+int bhmm_ctx_path_stats_size(const bhmm_ctx *c)
+{
+    if (!c || c->kind < 0)
+        return 0;
+    const int n = c->n;
+    return n * n + n + (c->kind == EMIT_GAUSS ? 3 * n : (c->kind == EMIT_DISC ? n * c->M : 0));
+}
+
+int bhmm_sample_paths_dev(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                          const double *par1, const double *u, uint64_t seed, int32_t *paths,
+                          double *stats_dev)
+{
+    if (!c || c->kind < 0)
+        return invalid_arg("no observations loaded");
+    if (!A || !pi || !stats_dev)
+        return invalid_arg("NULL argument");
+    BHMM_HIP(hipSetDevice(c->device));
+    if (c->wide)
+        return wide_sample_run(c, A, pi, par0, par1, u, seed, paths, nullptr, nullptr, nullptr,
+                               stats_dev);
+    switch (c->N) {
+    case 2:
+        return sample_run<2>(c, A, pi, par0, par1, u, seed, paths, nullptr, nullptr, nullptr, stats_dev);
+    case 4:
+        return sample_run<4>(c, A, pi, par0, par1, u, seed, paths, nullptr, nullptr, nullptr, stats_dev);
+    default:
+        return sample_run<8>(c, A, pi, par0, par1, u, seed, paths, nullptr, nullptr, nullptr, stats_dev);
     }
 }
 

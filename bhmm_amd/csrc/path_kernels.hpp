@@ -166,7 +166,8 @@ __device__ __forceinline__ void stage_At(double *sAt, const Model<N> &m)
 // k_smp_apply reads alpha again only for [dmark, end of part) and takes the rest from the nibbles.
 template <int N>
 __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks ch,
-                                                  const int64_t *off, const double *alpha_ci,
+                                                  const int64_t *off, const int64_t *soff,
+                                                  const double *alpha_ci,
                                                   const double *u, uint64_t seed, int P,
                                                   uint32_t *Fmap, int *status, int32_t *dmark,
                                                   uint32_t *nib, int W8, int64_t Gp, uint32_t *gw,
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
     const int k = ch.traj[g];
     const int64_t t0 = ch.t0[g], base = ch.goff[g];
     const int64_t Tk = off[k + 1] - off[k];
+    const int64_t sbase = soff[k] + t0; // position of this chunk in the random stream
     const int n = m.nreal;
     const int s_lo = (int)((int64_t)len * part / P), s_hi = (int)((int64_t)len * (part + 1) / P);
     uint32_t cur = 0x76543210u; // nibble j = image of next-part state j (identity)
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
     for (int s = s_hi - 1; s >= s_lo; --s) {
         double a[N];
         ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
-        const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(base + s));
+        const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(sbase + s));
         const bool last = (t0 + s == Tk - 1);
         const uint32_t c0 = cur & 7u;
         const int j = s_hi - 1 - s; // position from the top of the part
@@ -542,6 +544,34 @@ __global__ __launch_bounds__(64) void k_add_partials(const double *partials, int
     s = wave_sum(s);
     if (threadIdx.x == 0)
         dst[e] += s;
+}
+
+// Hidden-path statistics as ONE packed fp64 vector in the caller's layout,
+// [counts n*n | n0 n | emission block], so that several ranks can sum them with a single
+// all-reduce.  Counts are integers below 2^53: their fp64 sums are exact in any order.
+//   cnt  : [Ns*Ns + Ns] integer counts with row stride Ns (the padded state count)
+//   ered : gaussian [3][Ns]; discrete [M][Ns] when `transposed`, else [n][M]
+__global__ void k_pack_path_stats(const unsigned long long *cnt, const double *ered, int n, int Ns,
+                                  int M, int kind, int transposed, double *out)
+{
+    const int nn = n * n;
+    const int esz = kind == EMIT_GAUSS ? 3 * n : (kind == EMIT_DISC ? n * M : 0);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nn + n + esz;
+         e += gridDim.x * blockDim.x) {
+        double v;
+        if (e < nn)
+            v = (double)cnt[(e / n) * Ns + e % n];
+        else if (e < nn + n)
+            v = (double)cnt[Ns * Ns + (e - nn)];
+        else {
+            const int q = e - nn - n;
+            if (kind == EMIT_GAUSS)
+                v = ered[(q / n) * Ns + q % n];
+            else
+                v = transposed ? ered[(size_t)(q % M) * Ns + q / M] : ered[q];
+        }
+        out[e] = v;
+    }
 }
 
 // =========================================================================================
@@ -891,10 +921,10 @@ __global__ void k_viterbi_check(const Chunks ch, int G, const double *v_entry, c
 // trajectory from its final state, k_vit_walk<true> re-walks every chunk from its known last state
 // and writes the path (_hidden.c:269-272).  Back-pointer rows are staged through LDS 64 steps at
 // a time; a dependent chain of global byte loads would be latency bound.
-template <int NP, bool APPLY>
+template <int NP, bool APPLY, typename PT = int32_t>
 __global__ __launch_bounds__(64) void k_vit_walk(const Chunks ch, int G, int n, const uint8_t *ptr,
                                                  const int32_t *end_state, uint32_t *maps,
-                                                 int32_t *path)
+                                                 PT *path)
 {
     constexpr int GP = 64 / NP;
     __shared__ uint8_t tile[GP][64 * NP];
@@ -912,7 +942,7 @@ __global__ __launch_bounds__(64) void k_vit_walk(const Chunks ch, int G, int n, 
         const int s_lo = (APPLY || first) ? 1 : 0;
         int cur = APPLY ? end_state[g] : e;
         if (APPLY && e == 0)
-            path[goff + len - 1] = cur;
+            path[goff + len - 1] = (PT)cur;
         for (int hi = len - 1; hi >= s_lo; hi -= 64) {
             const int lo = hi - 63 > s_lo ? hi - 63 : s_lo;
             const int cnt = hi - lo + 1;
@@ -926,7 +956,7 @@ __global__ __launch_bounds__(64) void k_vit_walk(const Chunks ch, int G, int n, 
             }
             if constexpr (APPLY)
                 for (int q = e; q < cnt; q += NP)
-                    path[goff + lo - 1 + q] = outp[gi][q];
+                    path[goff + lo - 1 + q] = (PT)outp[gi][q];
         }
         packed = (unsigned int)cur << (4 * e);
     }
@@ -971,10 +1001,11 @@ __global__ void k_pobs_all(const WideModel m, const void *obs_rm, int64_t total,
 
 // back-trace: one wavefront per trajectory stages 64 steps of back-pointers in LDS
 // (coalesced), lane 0 chases them (_hidden.c:269-272)
+template <typename PT>
 __global__ __launch_bounds__(64) void k_wide_viterbi_trace(const int64_t *off, int K, int n,
                                                            const uint8_t *ptr,
                                                            const int32_t *last_state,
-                                                           int32_t *path)
+                                                           PT *path)
 {
     __shared__ uint8_t tile[64 * 64];
     __shared__ int32_t outp[64];
@@ -986,7 +1017,7 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_trace(const int64_t *off, i
         return;
     int cur = last_state[k];
     if (lane == 0)
-        path[o0 + T - 1] = cur;
+        path[o0 + T - 1] = (PT)cur;
     // steps t = hi .. lo (descending) use ptr[t] to produce path[t-1]
     for (int64_t hi = T - 1; hi >= 1; hi -= 64) {
         const int64_t lo = (hi - 63 > 1) ? hi - 63 : 1;
@@ -1003,7 +1034,7 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_trace(const int64_t *off, i
         }
         __syncthreads();
         if (lane < cnt)
-            path[o0 + lo + lane - 1] = outp[lane];
+            path[o0 + lo + lane - 1] = (PT)outp[lane];
         cur = outp[0];
         __syncthreads();
     }
@@ -1013,7 +1044,8 @@ template <int NP>
 __global__ __launch_bounds__(64) void k_wide_sample_path(const WideModel m, const int64_t *off,
                                                          int K, const double *alpha_rm,
                                                          const double *u, uint64_t seed,
-                                                         int32_t *path, int *status)
+                                                         int32_t *path, int *status,
+                                                         const int64_t *soff = nullptr)
 {
     constexpr int GP = 64 / NP;
     __shared__ __attribute__((aligned(16))) double xs[GP][NP];
@@ -1028,6 +1060,7 @@ __global__ __launch_bounds__(64) void k_wide_sample_path(const WideModel m, cons
     const int64_t T = off[k + 1] - o0;
     if (T <= 0)
         return;
+    const int64_t s0 = soff ? soff[k] : o0; // position of this trajectory in the random stream
     int nxt = 0;
     for (int64_t t = T - 1; t >= 0; --t) {
         const double a = real ? alpha_rm[(o0 + t) * n + i] : 0.0;
@@ -1041,7 +1074,7 @@ __global__ __launch_bounds__(64) void k_wide_sample_path(const WideModel m, cons
             S += xs[gi][q]; // _normalize, ascending
         const double pn = ps / S;
         xs[gi][i] = pn;
-        const double r = u ? u[o0 + t] : uniform01(seed, (uint64_t)(o0 + t));
+        const double r = u ? u[o0 + t] : uniform01(seed, (uint64_t)(s0 + t));
         double acc = 0.0;
         int pick = -1;
 #pragma unroll

@@ -45,6 +45,7 @@ class Engine(object):
         _lib.check(self._L.bhmm_ctx_create(ctypes.byref(h), int(device),
                                            ctypes.c_void_p(stream) if stream else None))
         self._h = h
+        self.device = int(device)
         self.kind = None
         self.nstates = 0
         self.nsymbols = 0
@@ -162,6 +163,13 @@ class Engine(object):
         _lib.check(self._L.bhmm_estep_fetch(self._h, _lib.dp(packed), _lib.dp(logL_k)))
         return EStepResult(self.kind, self.nstates, self.nsymbols, packed, logL_k)
 
+    def estep_fetch_logL(self):
+        """Per-trajectory log-likelihoods of the last E-step only (waits for it).  Used when the
+        packed statistics stay on the device for an all-reduce."""
+        logL_k = np.empty(len(self.lengths))
+        _lib.check(self._L.bhmm_estep_fetch(self._h, None, _lib.dp(logL_k)))
+        return logL_k
+
     def estep(self, A, pi, par0=None, par1=None, store_gamma=False):
         self.estep_launch(A, pi, par0, par1, store_gamma=store_gamma)
         return self.estep_fetch()
@@ -182,6 +190,75 @@ class Engine(object):
         _lib.check(self._L.bhmm_viterbi_batch(self._h, _lib.dp(A), _lib.dp(pi), _lib.dp(p0),
                                               _lib.dp(p1), _lib.ip(paths)))
         return [paths[self.offsets[k]:self.offsets[k + 1]] for k in range(len(self.lengths))]
+
+    def viterbi_u8(self, A, pi, par0=None, par1=None, out=None):
+        """Viterbi paths as one byte per step.  out: None (a numpy uint8 array is allocated), a
+        numpy uint8 array, or any object with data_ptr()/is_cuda (a torch uint8 tensor: on this
+        engine's GPU the kernels write it directly, pinned host memory is copied at link rate).
+        Returns `out` (concatenated over trajectories like the observations)."""
+        A, pi, p0, p1 = self._model_ptrs(A, pi, par0, par1)
+        total = int(self.offsets[-1])
+        on_dev = 0
+        if out is None:
+            out = np.empty(total, dtype=np.uint8)
+        if isinstance(out, np.ndarray):
+            if out.dtype != np.uint8 or out.size < total or not out.flags.c_contiguous:
+                raise ValueError("out must be a contiguous uint8 array of sum(T_k) elements")
+            ptr = out.ctypes.data
+        else:
+            if out.numel() < total or out.element_size() != 1 or not out.is_contiguous():
+                raise ValueError("out must be a contiguous uint8 tensor of sum(T_k) elements")
+            on_dev = 1 if out.is_cuda else 0
+            if on_dev and out.device.index != self.device:
+                raise ValueError("out lives on another GPU than this engine")
+            ptr = out.data_ptr()
+        _lib.check(self._L.bhmm_viterbi_batch_u8(self._h, _lib.dp(A), _lib.dp(pi), _lib.dp(p0),
+                                                 _lib.dp(p1), ctypes.c_void_p(int(ptr)), on_dev))
+        return out
+
+    def set_stream_offsets(self, soff):
+        """Position of each loaded trajectory in the device random stream (include/bhmm_amd.h):
+        a sharded caller passes the offsets in the unsharded concatenation, None resets."""
+        if soff is None:
+            _lib.check(self._L.bhmm_ctx_set_stream_offsets(self._h, None))
+            return
+        soff = np.ascontiguousarray(soff, dtype=np.int64)
+        if soff.shape != (len(self.lengths),):
+            raise ValueError("one stream offset per loaded trajectory")
+        _lib.check(self._L.bhmm_ctx_set_stream_offsets(self._h, _lib.lp(soff)))
+
+    @property
+    def path_stats_size(self):
+        return self._L.bhmm_ctx_path_stats_size(self._h)
+
+    def sample_paths_dev(self, A, pi, par0, par1, stats_dev, u=None, seed=0, want_paths=False):
+        """Gibbs hidden-path step with the packed path statistics left in the device buffer
+        `stats_dev` (integer address, path_stats_size doubles).  Returns paths or None."""
+        A, pi, p0, p1 = self._model_ptrs(A, pi, par0, par1)
+        total = int(self.offsets[-1])
+        paths = np.empty(total, dtype=np.int32) if want_paths else None
+        uu = _lib.f64(np.concatenate(u)) if u is not None else None
+        _lib.check(self._L.bhmm_sample_paths_dev(self._h, _lib.dp(A), _lib.dp(pi), _lib.dp(p0),
+                                                 _lib.dp(p1), _lib.dp(uu), ctypes.c_uint64(int(seed)),
+                                                 _lib.ip(paths), ctypes.c_void_p(int(stats_dev))))
+        if not want_paths:
+            return None
+        return [paths[self.offsets[k]:self.offsets[k + 1]] for k in range(len(self.lengths))]
+
+    def unpack_path_stats(self, packed):
+        """[counts n*n | n0 n | emission block] -> (C int64 (n,n), n0 int64 (n,), emis)."""
+        n, M = self.nstates, self.nsymbols
+        packed = np.asarray(packed, dtype=np.float64)
+        C = np.rint(packed[:n * n]).astype(np.int64).reshape(n, n)
+        n0 = np.rint(packed[n * n:n * n + n]).astype(np.int64)
+        rest = packed[n * n + n:]
+        if self.kind == 'gaussian':
+            emis = rest[:3 * n].reshape(3, n).copy()
+        elif self.kind == 'discrete':
+            emis = rest[:n * M].reshape(n, M).copy()
+        else:
+            emis = None
+        return C, n0, emis
 
     def sample_paths(self, A, pi, par0=None, par1=None, u=None, seed=0, want_paths=True):
         """Gibbs hidden-path step.  Returns (paths or None, C int64 (n,n), n0 int64 (n,), emis)."""
@@ -206,3 +283,22 @@ class Engine(object):
         if want_paths:
             plist = [paths[self.offsets[k]:self.offsets[k + 1]] for k in range(len(self.lengths))]
         return plist, C, n0, emis
+
+
+def synth_observations(kind, obs_dev, A, pi, par0, par1, K, T, seed, device=0, stream=None,
+                       states_dev=None):
+    """Draw K synthetic trajectories of T steps on the GPU into the device buffer at address
+    `obs_dev` (K*T doubles for 'gaussian', int32 for 'discrete'); see bhmm_synth_observations in
+    include/bhmm_amd.h.  states_dev: optional device address of K*T bytes for the hidden paths."""
+    L = _lib.load()
+    _lib.require_device()
+    A = _lib.f64(A)
+    n = A.shape[0]
+    p0 = _lib.f64(par0)
+    p1 = _lib.f64(par1) if par1 is not None else None
+    M = p0.shape[1] if kind == 'discrete' else 0
+    _lib.check(L.bhmm_synth_observations(
+        ctypes.c_void_p(int(obs_dev)), ctypes.c_void_p(int(states_dev)) if states_dev else None,
+        int(device), ctypes.c_void_p(stream) if stream else None, _KINDS[kind], _lib.dp(A),
+        _lib.dp(_lib.f64(pi)), _lib.dp(p0), _lib.dp(p1), int(n), int(M), int(K), int(T),
+        ctypes.c_uint64(int(seed))))

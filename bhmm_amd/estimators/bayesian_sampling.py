@@ -23,6 +23,19 @@ def _default_engine_factory(device):
     return Engine(device)
 
 
+def _unpack_path_stats(packed, kind, n, M):
+    """[counts n*n | n0 n | emission block] (include/bhmm_amd.h, bhmm_sample_paths_dev)."""
+    packed = np.asarray(packed, dtype=np.float64)
+    C = np.rint(packed[:n * n]).astype(np.int64).reshape(n, n)
+    n0 = np.rint(packed[n * n:n * n + n]).astype(np.int64)
+    rest = packed[n * n + n:]
+    if kind == 'gaussian':
+        return C, n0, rest[:3 * n].reshape(3, n).copy()
+    if kind == 'discrete':
+        return C, n0, rest[:n * M].reshape(n, M).copy()
+    return C, n0, None
+
+
 class BayesianHMMSampler(object):
     def __init__(self, observations, nstates, initial_model=None, reversible=True,
                  stationary=False, transition_matrix_sampling_steps=1000, p0_prior='mixed',
@@ -84,12 +97,21 @@ class BayesianHMMSampler(object):
         self._parts = lpt_partition(self.Ts, self._comm.world)
         self._mine = self._parts[self._comm.rank]
         if device is None:
-            device = self._comm.rank if self._comm.active else 0
+            from .maximum_likelihood import default_device
+            device = default_device(self._comm)
+        self._comm.bind_device(device)       # collectives run on the engine's GPU
         factory = engine_factory or _default_engine_factory
         self._engine = factory(device)
         M = self.model.output_model.nsymbols if self._output == 'discrete' else 0
-        self._engine.set_observations(self._output, [self.observations[k] for k in self._mine],
-                                      nstates, nsymbols=M)
+        self._nsymbols = M
+        if self._mine:
+            self._engine.set_observations(self._output, [self.observations[k] for k in self._mine],
+                                          nstates, nsymbols=M)
+            if self._comm.active:
+                # uniforms are addressed by the position in the UNSHARDED concatenation of all
+                # trajectories: the sampled paths do not depend on the partition over ranks
+                goff = np.concatenate([[0], np.cumsum(self.Ts)]).astype(np.int64)
+                self._engine.set_stream_offsets(goff[self._mine])
         self._sweep = 0
         self._rng = np.random
 
@@ -125,10 +147,48 @@ class BayesianHMMSampler(object):
         return models
 
     def _update(self, seed=None, keep_paths=False):
-        """One Gibbs sweep, bayesian_sampling.py:269-281."""
+        """One Gibbs sweep, bayesian_sampling.py:269-281.  With several ranks the hidden-path
+        step runs sharded; the parameters are then drawn ONCE, on rank 0, and broadcast, so the
+        chain does not depend on how the ranks' random generators were seeded."""
         C, n0, emis = self._updateHiddenStateTrajectories(seed=seed, keep_paths=keep_paths)
-        self._updateEmissionProbabilities(emis)
-        self._updateTransitionMatrix(C, n0)
+        if not self._comm.active:
+            self._updateEmissionProbabilities(emis)
+            self._updateTransitionMatrix(C, n0)
+            return
+        err = None
+        if self._comm.rank == 0:
+            try:
+                self._updateEmissionProbabilities(emis)
+                self._updateTransitionMatrix(C, n0)
+            except Exception as e:      # the other ranks wait in the broadcast: tell them
+                err = e
+        self._broadcast_parameters(failed=err is not None)
+        if err is not None:
+            raise err
+
+    def _broadcast_parameters(self, failed=False):
+        """[ok | T (n*n) | p0 (n) | emission parameters] from rank 0 to every rank."""
+        n = self.nstates
+        om = self.model.output_model
+        par0, par1 = om.parameters()
+        parts = [np.array([0.0 if failed else 1.0]), np.ravel(self.model.transition_matrix),
+                 np.ravel(self.model.initial_distribution), np.ravel(par0)]
+        if par1 is not None:
+            parts.append(np.ravel(par1))
+        vec = self._comm.broadcast_numpy(np.concatenate(parts).astype(np.float64), src=0)
+        if vec[0] != 1.0:
+            if self._comm.rank != 0:
+                raise RuntimeError('parameter update failed on rank 0 (see its exception)')
+            return
+        if self._comm.rank != 0:
+            o = 1
+            Tij = vec[o:o + n * n].reshape(n, n); o += n * n
+            p0 = vec[o:o + n]; o += n
+            k0 = np.size(par0)
+            new0 = vec[o:o + k0].reshape(np.shape(par0)); o += k0
+            new1 = vec[o:o + np.size(par1)].reshape(np.shape(par1)) if par1 is not None else None
+            om.set_parameters(new0, new1)
+            self.model.update(p0, Tij)
 
     def _updateHiddenStateTrajectories(self, seed=None, keep_paths=False):
         """bayesian_sampling.py:283-331 for all trajectories at once, plus the hidden-path
@@ -136,17 +196,37 @@ class BayesianHMMSampler(object):
         if seed is not None:
             self._seed_base = int(seed)
         base = getattr(self, '_seed_base', 0x5EED)
-        sweep_seed = (base * 1000003 + self._sweep * 7919 + self._comm.rank) & 0xFFFFFFFFFFFF
+        sweep_seed = (base * 1000003 + self._sweep * 7919) & 0xFFFFFFFFFFFF   # same on every rank
         self._sweep += 1
         om = self.model.output_model
         par0, par1 = om.parameters()
-        paths, C, n0, emis = self._engine.sample_paths(
-            self.model.transition_matrix, self.model.initial_distribution, par0, par1,
-            seed=sweep_seed, want_paths=keep_paths)
-        if self._comm.active:
-            C = self._comm.allreduce_sum_numpy(C)
-            n0 = self._comm.allreduce_sum_numpy(n0)
-            emis = self._comm.allreduce_sum_numpy(emis)
+        eng, comm = self._engine, self._comm
+        A, pi = self.model.transition_matrix, self.model.initial_distribution
+        n, M = self.nstates, self._nsymbols
+        esz = 3 * n if self._output == 'gaussian' else (n * M if self._output == 'discrete' else 0)
+        paths = []
+        if not comm.active:
+            paths, C, n0, emis = eng.sample_paths(A, pi, par0, par1, seed=sweep_seed,
+                                                  want_paths=keep_paths)
+        elif hasattr(eng, 'sample_paths_dev'):
+            # ONE packed fp64 vector [C | n0 | emission block] stays on the engine's GPU, ONE
+            # all-reduce, ONE copy to the host; the integer counts are exact in fp64 (< 2^53)
+            buf = comm.stats_buffer(n * n + n + esz)
+            if self._mine:
+                paths = eng.sample_paths_dev(A, pi, par0, par1, buf.data_ptr(), seed=sweep_seed,
+                                             want_paths=keep_paths)
+            else:
+                buf.zero_()
+            C, n0, emis = _unpack_path_stats(comm.allreduce_stats(buf), self._output, n, M)
+        else:
+            # host-side engine (CPU test double): same packed vector, host all-reduce
+            packed = np.zeros(n * n + n + esz)
+            if self._mine:
+                paths, C, n0, emis = eng.sample_paths(A, pi, par0, par1, seed=sweep_seed,
+                                                      want_paths=keep_paths)
+                packed = np.concatenate([np.ravel(C).astype(np.float64), np.ravel(n0).astype(np.float64)]
+                                        + ([np.ravel(emis)] if esz else []))
+            C, n0, emis = _unpack_path_stats(comm.allreduce_sum_numpy(packed), self._output, n, M)
         if keep_paths:
             full = [None] * self.nobs
             if self._comm.active:

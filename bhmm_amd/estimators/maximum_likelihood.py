@@ -14,6 +14,7 @@ import time
 import numpy as np
 
 from .. import hidden
+from ..engine import EStepResult
 from ..sharding import Comm, lpt_partition
 from ..util import config
 from . import _tmatrix
@@ -24,11 +25,29 @@ def _default_engine_factory(device):
     return Engine(device)
 
 
+def default_device(comm):
+    """One process per GPU: rank r drives GPU r (modulo the GPUs visible to this process).
+    Counting devices does not initialise the GPU."""
+    if not comm.active:
+        return 0
+    try:
+        import torch
+        ndev = torch.cuda.device_count()
+    except ImportError:
+        ndev = 0
+    return comm.rank % ndev if ndev > 0 else comm.rank
+
+
+def packed_stats_size(kind, n, M):
+    """Length of the packed E-step statistics vector (include/bhmm_amd.h, bhmm_ctx_stats_size)."""
+    return 1 + n + n * n + n + (2 * n if kind == 'gaussian' else (n * M if kind == 'discrete' else 0))
+
+
 class MaximumLikelihoodEstimator(object):
     def __init__(self, observations, nstates, initial_model=None, output='gaussian',
                  reversible=True, stationary=False, p=None, accuracy=1e-3, maxit=1000,
                  maxit_P=100000, device=None, process_group=None, store_gamma=False,
-                 engine_factory=None):
+                 engine_factory=None, multi_start=False):
         # maximum_likelihood.py:101-104
         self._observations = copy.deepcopy(observations)
         self._nobs = len(observations)
@@ -45,10 +64,11 @@ class MaximumLikelihoodEstimator(object):
             from .. import api as _api
             initial_model = _api.init_hmm(observations, nstates, output=output,
                                           reversible=reversible)
-            if output == 'gaussian' and nstates > 1:
-                # EM only finds the optimum next to its start and an E-step costs milliseconds
-                # here: a second, kinetic start is tried for a few iterations in fit() and the
-                # better one continues (init/gaussian.py: init_model_gaussian1d_kinetic)
+            if multi_start and output == 'gaussian' and nstates > 1:
+                # opt-in extension (the reference starts from init_hmm alone, :111-116): EM only
+                # finds the optimum next to its start and an E-step costs milliseconds here, so a
+                # second, kinetic start is tried for a few iterations in fit() and the better one
+                # continues (init/gaussian.py: init_model_gaussian1d_kinetic)
                 from ..init.gaussian import init_model_gaussian1d_kinetic
                 alt = init_model_gaussian1d_kinetic(observations, nstates, reversible=reversible)
                 if alt is not None:
@@ -79,19 +99,17 @@ class MaximumLikelihoodEstimator(object):
         self._parts = lpt_partition(self._Ts, self._comm.world)
         self._mine = self._parts[self._comm.rank]
         if device is None:
-            device = self._comm.rank if self._comm.active else 0
-            try:
-                import torch
-                if torch.cuda.is_available():
-                    device = device % max(torch.cuda.device_count(), 1)
-            except ImportError:
-                pass
+            device = default_device(self._comm)
         self._device = device
+        self._comm.bind_device(device)       # collectives run on the engine's GPU, not on "current"
         factory = engine_factory or _default_engine_factory
         self._engine = factory(device)
         M = self._hmm.output_model.nsymbols if self._output == 'discrete' else 0
-        self._engine.set_observations(self._output, [self._observations[k] for k in self._mine],
-                                      nstates, nsymbols=M)
+        self._nsymbols = M
+        if self._mine:
+            self._engine.set_observations(self._output,
+                                          [self._observations[k] for k in self._mine],
+                                          nstates, nsymbols=M)
 
     # ---- properties (maximum_likelihood.py:145-219) -------------------------------------
     @property
@@ -143,6 +161,11 @@ class MaximumLikelihoodEstimator(object):
         return out
 
     @property
+    def local_trajectories(self):
+        """Indices of the trajectories this rank holds (all of them in a single process)."""
+        return list(self._mine)
+
+    @property
     def hmm(self):
         return self._hmm
 
@@ -169,11 +192,35 @@ class MaximumLikelihoodEstimator(object):
         (maximum_likelihood.py:221-282, 383-385).  Returns an EStepResult."""
         om = self._hmm.output_model
         par0, par1 = om.parameters()
-        res = self._engine.estep(self._hmm.transition_matrix, self._hmm.initial_distribution,
-                                 par0, par1, store_gamma=self._store_gamma)
-        if self._comm.active:
-            packed = self._comm.allreduce_sum_numpy(res.packed)
-            res = self._engine.unpack(packed, res.logL_k)
+        eng, comm = self._engine, self._comm
+        A, pi = self._hmm.transition_matrix, self._hmm.initial_distribution
+        if not comm.active:
+            res = eng.estep(A, pi, par0, par1, store_gamma=self._store_gamma)
+        elif hasattr(eng, 'estep_launch'):
+            # the E-step leaves its packed statistics in a device buffer on the engine's GPU; ONE
+            # in-place all-reduce (RCCL over xGMI) and ONE device-to-host copy follow -- the
+            # distributed form of the sums at maximum_likelihood.py:271-282
+            S = packed_stats_size(self._output, self._nstates, self._nsymbols)
+            buf = comm.stats_buffer(S)
+            logL_k = np.zeros(0)
+            if self._mine:
+                eng.estep_launch(A, pi, par0, par1, stats_dev=buf.data_ptr(),
+                                 store_gamma=self._store_gamma)
+                logL_k = eng.estep_fetch_logL()          # waits for the E-step of this shard
+            else:
+                buf.zero_()
+            packed = comm.allreduce_stats(buf)
+            res = EStepResult(self._output, self._nstates, self._nsymbols, packed, logL_k)
+        else:
+            # host-side engine (the CPU test double of tests/): host all-reduce
+            if self._mine:
+                res = eng.estep(A, pi, par0, par1, store_gamma=self._store_gamma)
+                packed, logL_k = res.packed, res.logL_k
+            else:
+                packed = np.zeros(packed_stats_size(self._output, self._nstates, self._nsymbols))
+                logL_k = np.zeros(0)
+            packed = comm.allreduce_sum_numpy(packed)
+            res = EStepResult(self._output, self._nstates, self._nsymbols, packed, logL_k)
         assert np.isfinite(res.loglik)       # maximum_likelihood.py:385
         return res
 
@@ -206,8 +253,10 @@ class MaximumLikelihoodEstimator(object):
         ranks they are gathered so that every rank returns the full list."""
         om = self._hmm.output_model
         par0, par1 = om.parameters()
-        local = self._engine.viterbi(self._hmm.transition_matrix, self._hmm.initial_distribution,
-                                     par0, par1)
+        local = []
+        if self._mine:
+            local = self._engine.viterbi(self._hmm.transition_matrix,
+                                         self._hmm.initial_distribution, par0, par1)
         paths = np.empty(self._nobs, dtype=object)
         if self._comm.active:
             for part, plist in zip(self._parts, self._comm.gather_objects(local)):

@@ -35,6 +35,11 @@ class DiscreteOutputModel(OutputModel):
     def parameters(self):
         return self._output_probabilities, None
 
+    def set_parameters(self, B, _unused=None):
+        """Adopt parameters drawn elsewhere (Gibbs: rank 0 draws, the others receive)."""
+        self._output_probabilities = np.array(B, dtype=np.float64).reshape(
+            self._output_probabilities.shape)
+
     def sub_output_model(self, states):
         return DiscreteOutputModel(self._output_probabilities[states])
 

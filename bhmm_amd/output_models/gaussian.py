@@ -46,6 +46,11 @@ class GaussianOutputModel(OutputModel):
         """(par0, par1) as the C ABI wants them for BHMM_EMIT_GAUSSIAN."""
         return self._means, self._sigmas
 
+    def set_parameters(self, means, sigmas):
+        """Adopt parameters drawn elsewhere (Gibbs: rank 0 draws, the others receive)."""
+        self._means = np.array(means, dtype=np.float64).reshape(self.nstates)
+        self._sigmas = np.array(sigmas, dtype=np.float64).reshape(self.nstates)
+
     def sub_output_model(self, states):
         return GaussianOutputModel(len(states), self._means[states], self._sigmas[states])
 

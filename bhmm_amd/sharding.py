@@ -25,18 +25,26 @@ def lpt_partition(lengths, world_size):
 
 
 class Comm(object):
-    """Thin view of torch.distributed (or a single process)."""
+    """Thin view of torch.distributed (or a single process), bound to the GPU of ONE engine.
 
-    def __init__(self, group=None):
+    All device traffic of the collectives happens on `device` (the engine's HIP ordinal), never
+    on torch's "current" device: a caller that did not `torch.cuda.set_device` would otherwise
+    land every rank on GPU 0 (RCCL: "duplicate GPU")."""
+
+    def __init__(self, group=None, device=None):
         self.group = group
         self.dist = None
+        self.backend = None
         self.rank, self.world = 0, 1
+        self.device = device
+        self._bufs = {}
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
                 self.dist = dist
                 self.rank = dist.get_rank(group)
                 self.world = dist.get_world_size(group)
+                self.backend = dist.get_backend(group)
         except ImportError:
             pass
 
@@ -44,27 +52,73 @@ class Comm(object):
     def active(self):
         return self.world > 1
 
-    def allreduce_sum_(self, tensor):
-        """In-place sum over ranks of a torch tensor (device tensor -> RCCL, CPU -> gloo)."""
-        if self.active:
-            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
-        return tensor
+    def bind_device(self, device):
+        self.device = None if device is None else int(device)
+        self._bufs = {}
 
-    def allreduce_sum_numpy(self, arr):
-        """Sum a host array over ranks (used for int64 Gibbs counts and CPU tests)."""
+    def _torch_device(self):
+        import torch
+        if self.device is None:
+            raise RuntimeError("Comm is not bound to an engine device")
+        return torch.device("cuda", self.device)
+
+    # -- device-resident statistics ------------------------------------------------------
+    def stats_buffer(self, n):
+        """fp64 device tensor of n entries on the engine's GPU (cached): the E-step / Gibbs step
+        writes its packed statistics into it, `allreduce_stats` sums it over ranks."""
+        import torch
+        t = self._bufs.get(n)
+        if t is None:
+            t = torch.zeros(int(n), dtype=torch.float64, device=self._torch_device())
+            self._bufs[n] = t
+        return t
+
+    def allreduce_stats(self, t):
+        """Sum the device tensor `t` over ranks and return the result as a host array: with RCCL
+        one in-place all-reduce on the device buffer and one device-to-host copy; with gloo
+        (tests: several ranks on one GPU) one copy and a host all-reduce."""
         if not self.active:
-            return arr
+            return t.cpu().numpy()
+        if self.backend == 'nccl':
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            return t.cpu().numpy()
+        h = t.cpu()
+        self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+        return h.numpy()
+
+    # -- host arrays ---------------------------------------------------------------------
+    def _on_wire(self, arr):
         import torch
         t = torch.from_numpy(np.ascontiguousarray(arr))
-        backend = self.dist.get_backend(self.group)
-        if backend == 'nccl':
-            t = t.cuda()
+        if self.backend == 'nccl':
+            t = t.to(self._torch_device())
+        return t
+
+    def allreduce_sum_numpy(self, arr):
+        """Sum a host array over ranks (CPU test doubles; small host-side quantities)."""
+        if not self.active:
+            return arr
+        t = self._on_wire(arr)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def broadcast_numpy(self, arr, src=0):
+        """Every rank returns rank `src`'s array (same shape/dtype on all ranks)."""
+        if not self.active:
+            return arr
+        t = self._on_wire(arr)
+        gsrc = src if self.group is None else self.dist.get_global_rank(self.group, src)
+        self.dist.broadcast(t, src=gsrc, group=self.group)
         return t.cpu().numpy()
 
     def gather_objects(self, obj):
         if not self.active:
             return [obj]
         out = [None] * self.world
-        self.dist.all_gather_object(out, obj, group=self.group)
+        if self.backend == 'nccl':
+            import torch
+            with torch.cuda.device(self._torch_device()):
+                self.dist.all_gather_object(out, obj, group=self.group)
+        else:
+            self.dist.all_gather_object(out, obj, group=self.group)
         return out

@@ -133,6 +133,16 @@ int bhmm_get_gamma(bhmm_ctx *ctx, int k, double *gamma);
 int bhmm_viterbi_batch(bhmm_ctx *ctx, const double *A, const double *pi, const double *par0,
                        const double *par1, int32_t *paths);
 
+/* Same paths as bhmm_viterbi_batch, one byte per step (N <= 64 states fit a byte; the int32 form
+ * above is the reference's return type, hidden.pyx:161-162, and costs four times the copy).
+ * paths_on_device == 0: paths is a host buffer of sum_k T_k bytes -- pass pinned memory
+ * (hipHostMalloc / torch pin_memory) for the full link rate, a pageable buffer is pinned for the
+ * duration of the copy.  paths_on_device != 0: paths is a device buffer on the context's device
+ * and the back-trace kernels write it directly (no copy).  Replaces the Python loop at
+ * maximum_likelihood.py:332-352 for callers that keep or post-process paths on the GPU. */
+int bhmm_viterbi_batch_u8(bhmm_ctx *ctx, const double *A, const double *pi, const double *par0,
+                          const double *par1, uint8_t *paths, int paths_on_device);
+
 /* Gibbs hidden-path step (bayesian_sampling.py:283-331): forward pass + backward sampling
  * of every trajectory.  Uniforms come either from u (host, concatenated like obs; u[t]
  * used at step t) or, when u == NULL, from a counter-based generator seeded with `seed`.
@@ -144,6 +154,23 @@ int bhmm_viterbi_batch(bhmm_ctx *ctx, const double *A, const double *pi, const d
 int bhmm_sample_paths(bhmm_ctx *ctx, const double *A, const double *pi, const double *par0,
                       const double *par1, const double *u, uint64_t seed, int32_t *paths,
                       int64_t *counts, int64_t *n0, double *emis);
+
+/* The same Gibbs step with the hidden-path statistics left ON THE DEVICE as one packed fp64
+ * vector of bhmm_ctx_path_stats_size() doubles,
+ *   [ counts N*N | n0 N | emission block (gaussian 3N: n_i, sum d, sum d^2; discrete N*M) ],
+ * so that several ranks reduce them with ONE all-reduce (RCCL) and ONE device-to-host copy -- the
+ * distributed form of generic_hmm.py:297-334,398-431.  The integer counts are < 2^53, so their
+ * fp64 sums are exact whatever the order.  paths (host int32, concatenated) may be NULL. */
+int bhmm_ctx_path_stats_size(const bhmm_ctx *ctx);
+/* Position of each loaded trajectory in the device random stream used when u == NULL: step t of
+ * trajectory k draws uniform(seed, soff[k] + t).  Default (soff == NULL, and after every
+ * bhmm_ctx_set_observations): the trajectory's offset in this context.  A caller that shards
+ * trajectories over several contexts / GPUs passes their offsets in the UNSHARDED concatenation,
+ * so that the sampled paths do not depend on the partition.  soff: host, K entries. */
+int bhmm_ctx_set_stream_offsets(bhmm_ctx *ctx, const int64_t *soff);
+int bhmm_sample_paths_dev(bhmm_ctx *ctx, const double *A, const double *pi, const double *par0,
+                          const double *par1, const double *u, uint64_t seed, int32_t *paths,
+                          double *stats_dev);
 
 /* Tuning / introspection knobs by name (returns BHMM_ERR_INVALID for an unknown name):
  *   "spec_enabled"  1/0  use speculative, verified chunk boundaries in bhmm_estep (default 1;
@@ -177,6 +204,19 @@ int bhmm_ctx_chunk_len(const bhmm_ctx *ctx);
 double bhmm_ctx_last_kernel_ms(bhmm_ctx *ctx, int which);
 void *bhmm_ctx_stream(bhmm_ctx *ctx);
 int bhmm_ctx_sync(bhmm_ctx *ctx);
+/* Measurement / test support: K synthetic trajectories of T steps each, drawn ON
+ * THE DEVICE from the HMM (A, pi, emission) -- hidden path by inverse CDF of pi / the rows of A,
+ * one emission per step (recipe of bhmm/hmm/generic_hmm.py:435-507) -- with the counter-based
+ * stream of bhmm_sample_paths: step t of trajectory k uses uniform(seed, 2*(k*T+t)) for the state
+ * and uniform(seed, 2*(k*T+t)+1) for the emission, so the result does not depend on launch
+ * geometry and a host restatement reproduces discrete trajectories bit for bit.
+ *   obs_dev    : device buffer, K*T elements, trajectory-concatenated (double | int32 per kind)
+ *   states_dev : optional device buffer of K*T bytes receiving the hidden path (may be NULL)
+ *   stream     : hipStream_t or NULL;  par0/par1 as for the emission kinds above. */
+int bhmm_synth_observations(void *obs_dev, uint8_t *states_dev, int device, void *stream, int kind,
+                            const double *A, const double *pi, const double *par0,
+                            const double *par1, int N, int M, int K, int64_t T, uint64_t seed);
+
 /* diagnostics: y[i] = the E-step kernels' exp() for non-positive arguments (the exponential
  * of the gaussian density, _gaussian.c:18), so that tests can bound its error in ulps */
 int bhmm_diag_exp_nonpos(double *y, const double *x, int64_t n);

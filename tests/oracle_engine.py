@@ -10,13 +10,30 @@ from bhmm_amd.engine import EStepResult
 from oracle import oracle as orc
 
 
+def device_uniforms(seed, start, count):
+    """numpy restatement of the engine's counter-based stream (path_kernels.hpp uniform01):
+    u[t] = splitmix64-finaliser(seed + golden * (start + t + 1)) >> 11, scaled to [0, 1)."""
+    with np.errstate(over='ignore'):
+        x = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
 class OracleEngine(object):
     def __init__(self, device=0):
         self.device = device
+        self.soff = None
+
+    def set_stream_offsets(self, soff):
+        self.soff = None if soff is None else np.asarray(soff, dtype=np.int64)
 
     def set_observations(self, kind, observations, nstates, nsymbols=0, chunk=0):
         self.kind, self.obs, self.n, self.M = kind, [np.asarray(o) for o in observations], nstates, nsymbols
         self.lengths = np.array([len(o) for o in observations], dtype=np.int64)
+        self.soff = None
         self._gammas = None
 
     def _pobs(self, o, par0, par1):
@@ -57,11 +74,11 @@ class OracleEngine(object):
 
     def sample_paths(self, A, pi, par0=None, par1=None, u=None, seed=0, want_paths=True):
         n = self.n
-        rng = np.random.default_rng(seed)
         paths = []
+        soff = self.soff if self.soff is not None else np.concatenate([[0], np.cumsum(self.lengths)])
         for k, o in enumerate(self.obs):
             _, alpha = orc.forward(A, self._pobs(o, par0, par1), pi)
-            uu = u[k] if u is not None else rng.random(len(o))
+            uu = u[k] if u is not None else device_uniforms(seed, int(soff[k]), len(o))
             paths.append(orc.sample_path(alpha, A, u=uu))
         C, n0 = orc.path_counts(paths, n) if paths else (np.zeros((n, n), np.int64), np.zeros(n, np.int64))
         if self.kind == 'gaussian':

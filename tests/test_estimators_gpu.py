@@ -118,12 +118,13 @@ def test_estimate_hmm_from_raw_discrete_data():
 
 def test_estimate_hmm_multi_start_five_overlapping_states():
     """estimate_hmm(observations, 5) on the reference's dalton test system (means -5 .. 5, sigmas
-    0.5 .. 2, lifetimes 10 .. 100): the estimator tries the mixture start and the kinetic start for
-    a few GPU iterations each and recovers the generating model."""
+    0.5 .. 2, lifetimes 10 .. 100): with the opt-in multi_start=True the estimator tries the mixture
+    start and the kinetic start for a few GPU iterations each and recovers the generating model
+    (the default is the reference's single start, maximum_likelihood.py:111-116)."""
     rs = np.random.RandomState(3)
     model, O, S = bhmm_amd.testsystems.generate_synthetic_observations(
         nstates=5, ntrajectories=10, length=30000, rng=rs)
-    hmm = bhmm_amd.estimate_hmm(O, 5)
+    hmm = bhmm_amd.estimate_hmm(O, 5, multi_start=True)
     np.testing.assert_allclose(hmm.output_model.means, model.output_model.means, atol=0.05)
     np.testing.assert_allclose(hmm.output_model.sigmas, model.output_model.sigmas, atol=0.05)
     np.testing.assert_allclose(hmm.transition_matrix, model.transition_matrix, atol=0.02)

@@ -1,0 +1,56 @@
+"""N > 1 on the GPU: two fresh processes (started before this pytest process initialised the
+GPU, through the launcher of conftest.py), both driving the HIP engine on GPU 0, sharded
+trajectories, the E-step's device statistics buffer summed over ranks, Gibbs parameters drawn on
+rank 0 and broadcast.  Their results must be the single-process results:
+maximum_likelihood.py:271-282 (sums over trajectories) is what the all-reduce replaces."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+WORKER = os.path.join(HERE, "multirank_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_gpu_equal_one_process(launcher):
+    with tempfile.TemporaryDirectory() as d:
+        one = launcher.run([[sys.executable, WORKER, "0", "1", "0", d]], timeout=600)
+        assert one[0]["rc"] == 0, one[0]["out"]
+        port = str(_free_port())
+        two = launcher.run([[sys.executable, WORKER, str(r), "2", port, d] for r in range(2)],
+                           timeout=600)
+        for r in two:
+            assert r["rc"] == 0, r["out"]
+        ref = np.load(os.path.join(d, "w1_r0.npz"))
+        ranks = [np.load(os.path.join(d, "w2_r%d.npz" % r)) for r in range(2)]
+    assert int(ref["nlocal"]) == 7
+    assert sorted(int(r["nlocal"]) for r in ranks) == [3, 4]     # really sharded
+    for r in ranks:
+        # EM: same likelihood history (summation order differs -> 1e-12), same model, same paths
+        assert len(r["L"]) == len(ref["L"])
+        np.testing.assert_allclose(r["L"], ref["L"], rtol=1e-11)
+        np.testing.assert_allclose(r["A"], ref["A"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(r["mu"], ref["mu"], rtol=1e-9)
+        np.testing.assert_allclose(r["sig"], ref["sig"], rtol=1e-9)
+        np.testing.assert_allclose(r["C"], ref["C"], rtol=1e-9)
+        assert np.array_equal(r["v"], ref["v"])
+        # Gibbs: uniforms addressed by global position + parameters from rank 0 only -> the chain
+        # of the sharded run is the single-process chain, on every rank
+        np.testing.assert_allclose(r["chain_A"], ref["chain_A"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(r["chain_mu"], ref["chain_mu"], rtol=1e-8)
+        np.testing.assert_allclose(r["chain_sig"], ref["chain_sig"], rtol=1e-8)
+        assert np.array_equal(r["chain_paths"], ref["chain_paths"])
+    assert np.array_equal(ranks[0]["chain_paths"], ranks[1]["chain_paths"])

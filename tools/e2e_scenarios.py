@@ -17,7 +17,7 @@ def gaussian(n, K, T, seed, **kw):
     model, O, S = bhmm.testsystems.generate_synthetic_observations(nstates=n, ntrajectories=K, length=T,
                                                                    rng=rs, **kw)
     t = time.perf_counter()
-    h = bhmm.estimate_hmm(O, n)
+    h = bhmm.estimate_hmm(O, n, multi_start=True)
     dt = time.perf_counter() - t
     agree = np.mean(np.concatenate(h.hidden_state_trajectories) == np.concatenate(S))
     print("gaussian n=%2d %4d x %6d: fit %5.1f s  mu err %.3f  sigma err %.3f  T err %.3f  viterbi %.3f" % (
