@@ -1,0 +1,288 @@
+"""GPU parity at the BASELINE.json sizes that fixture-sized tests cannot reach, plus the entry
+points added for them (device-side synthetic workloads, one-byte Viterbi paths, device-resident
+Gibbs statistics, partition-independent random stream).
+
+Full-size evidence comes in two forms: ONE trajectory of the batch against the CPU oracle
+(seconds of CPU time), and size-independent properties of the whole batch (unit gamma mass per
+step, T-1 transitions per trajectory, sub-batch invariance of per-trajectory results)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from bhmm_amd.engine import Engine
+    return Engine(0)
+
+
+def _c3_model():
+    from bench import metastable_matrix, stationary
+    rng = np.random.default_rng(3000)
+    n, M = 8, 64
+    A = metastable_matrix(n, rng)
+    pi = stationary(A)
+    B = rng.dirichlet(np.ones(M), size=n)
+    return n, M, A, pi, B, 0.9 * A + 0.1 / n, 0.8 * B + 0.2 / M
+
+
+# ---- device-side synthetic workloads -----------------------------------------------------
+def test_device_generator_equals_host_restatement():
+    """bhmm_synth_observations: discrete trajectories and hidden paths bit for bit, Gaussian
+    observations to rounding (libm vs device log/cos), ragged K (not a multiple of 64), T not a
+    multiple of the 64-step tile."""
+    import torch
+    from bhmm_amd.engine import synth_observations
+    from synth_host import synth_discrete, synth_gaussian
+    n, M, A, pi, B, _, _ = _c3_model()
+    K, T = 70, 333
+    obs = torch.empty(K * T, dtype=torch.int32, device="cuda:0")
+    st = torch.empty(K * T, dtype=torch.uint8, device="cuda:0")
+    synth_observations("discrete", obs.data_ptr(), A, pi, B, None, K, T, seed=99, states_dev=st.data_ptr())
+    o, s = obs.cpu().numpy().reshape(K, T), st.cpu().numpy().reshape(K, T)
+    for k in (0, 1, 63, 64, 69):
+        ho, hs = synth_discrete(A, pi, B, k, T, 99)
+        assert np.array_equal(o[k], ho) and np.array_equal(s[k], hs)
+    assert o.min() >= 0 and o.max() < M
+    mu, sig = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
+    og = torch.empty(K * T, dtype=torch.float64, device="cuda:0")
+    synth_observations("gaussian", og.data_ptr(), A, pi, mu, sig, K, T, seed=99, states_dev=st.data_ptr())
+    og, s = og.cpu().numpy().reshape(K, T), st.cpu().numpy().reshape(K, T)
+    for k in (0, 69):
+        ho, hs = synth_gaussian(A, pi, mu, sig, k, T, 99)
+        assert np.array_equal(s[k], hs)
+        np.testing.assert_allclose(og[k], ho, rtol=1e-12, atol=1e-12)
+    # the draws follow the model: state frequencies near the stationary vector
+    big = torch.empty(64 * 50000, dtype=torch.float64, device="cuda:0")
+    sb = torch.empty(64 * 50000, dtype=torch.uint8, device="cuda:0")
+    synth_observations("gaussian", big.data_ptr(), A, pi, mu, sig, 64, 50000, seed=5, states_dev=sb.data_ptr())
+    freq = np.bincount(sb.cpu().numpy(), minlength=n) / sb.numel()
+    np.testing.assert_allclose(freq, pi, atol=0.02)
+    z = (big.cpu().numpy() - mu[sb.cpu().numpy()]) / sig[sb.cpu().numpy()]
+    assert abs(z.mean()) < 0.005 and abs(z.std() - 1.0) < 0.005
+
+
+# ---- one-byte Viterbi paths ---------------------------------------------------------------
+def test_viterbi_u8_equals_int32(golden):
+    import torch
+    from conftest import split
+    g = golden("g8_ragged")
+    obs = split(g["obs"], g["lengths"])
+    eng = _engine()
+    eng.set_observations("gaussian", obs, 8, chunk=64)
+    margs = (g["A"], g["pi"], g["mu"], g["sigma"])
+    ref = np.concatenate(eng.viterbi(*margs))
+    total = ref.size
+    assert np.array_equal(eng.viterbi_u8(*margs), ref)                     # fresh numpy array
+    dev = torch.full((total,), 255, dtype=torch.uint8, device="cuda:0")
+    assert eng.viterbi_u8(*margs, out=dev) is dev
+    assert np.array_equal(dev.cpu().numpy(), ref)                          # device-resident
+    pin = torch.full((total,), 255, dtype=torch.uint8).pin_memory()
+    eng.viterbi_u8(*margs, out=pin)
+    assert np.array_equal(pin.numpy(), ref)                                # pinned host
+    with pytest.raises(ValueError):
+        eng.viterbi_u8(*margs, out=np.empty(total - 1, dtype=np.uint8))
+    eng.close()
+    # 9..64 states (serial back-trace kernel)
+    g = golden("g64")
+    obs = [g["obs"][:400], g["obs"][400:]]
+    eng = _engine()
+    eng.set_observations("gaussian", obs, 64)
+    margs = (g["A"], g["pi"], g["mu"], g["sigma"])
+    assert np.array_equal(eng.viterbi_u8(*margs), np.concatenate(eng.viterbi(*margs)))
+    eng.close()
+
+
+def test_viterbi_full_size_chunked_and_bit_exact():
+    """Batched Viterbi at 256 x 1e5 (configs[1] shape): the chunk-parallel run is accepted
+    (viterbi_chunked == 1), and trajectories of it are the oracle's paths bit for bit."""
+    import torch
+    from bench import make_c2_model
+    from bhmm_amd.engine import synth_observations
+    K, T = 256, 100000
+    m = make_c2_model()
+    obs = torch.empty(K * T, dtype=torch.float64, device="cuda:0")
+    synth_observations("gaussian", obs.data_ptr(), m["A"], m["pi"], m["mu"], m["sigma"], K, T, seed=21)
+    eng = _engine()
+    eng.set_observations_device("gaussian", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, 8)
+    margs = (m["A_eval"], m["pi"], m["mu_eval"], m["sigma"])
+    paths = torch.empty(K * T, dtype=torch.uint8, device="cuda:0")
+    eng.viterbi_u8(*margs, out=paths)
+    assert eng.get_option("viterbi_chunked") == 1
+    p = paths.cpu().numpy().reshape(K, T)
+    for k in (0, 131, 255):
+        o = obs[k * T:(k + 1) * T].cpu().numpy()
+        ref = orc.viterbi(m["A_eval"], orc.pobs_gaussian(o, m["mu_eval"], m["sigma"]), m["pi"])
+        assert np.array_equal(p[k], ref)
+    # the reference-typed int32 form returns the same paths
+    p32 = eng.viterbi(*margs)
+    assert p32[7].dtype == np.int32 and np.array_equal(p32[7], p[7])
+    eng.close()
+
+
+# ---- E-step at T = 1e6 and at the configs[2] batch -----------------------------------------
+def test_one_million_step_discrete_trajectory_vs_oracle():
+    """One T = 1e6 discrete trajectory (64-bit offsets inside a long trajectory, 1e6-term
+    log-likelihood sums) against the oracle: logL, C, sum gamma, emission counts."""
+    import torch
+    from bhmm_amd.engine import synth_observations
+    n, M, A, pi, B, A_eval, B_eval = _c3_model()
+    T = 1000000
+    obs = torch.empty(T, dtype=torch.int32, device="cuda:0")
+    synth_observations("discrete", obs.data_ptr(), A, pi, B, None, 1, T, seed=77)
+    o = obs.cpu().numpy()
+    ref = orc.estep("discrete", [o], A_eval, pi, B_eval, want_gamma=True)
+    for chunk in (0, 4099):
+        eng = _engine()
+        eng.set_observations_device("discrete", obs.data_ptr(), np.array([0, T], dtype=np.int64), n,
+                                    nsymbols=M, chunk=chunk)
+        res = eng.estep(A_eval, pi, B_eval)
+        np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-9)
+        np.testing.assert_allclose(res.C, ref["C"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-9)
+        np.testing.assert_allclose(res.gamma0_sum, ref["gamma0_sum"], rtol=1e-9, atol=1e-14)
+        cnt = np.zeros((n, M))
+        orc.update_pout(o, ref["gammas"][0], cnt)
+        np.testing.assert_allclose(res.symbol_counts, cnt, rtol=1e-9, atol=1e-9)
+        eng.close()
+
+
+def test_configs2_full_batch_properties():
+    """BASELINE configs[2] on one GPU: 8-state discrete (M = 64), 1024 x 1e6 -- 8.2e9 alpha
+    elements (64-bit indexing), 65 GB workspace.  Unit gamma mass per step, T-1 transitions per
+    trajectory, per-trajectory log-likelihoods equal to a 3-trajectory sub-batch (different chunk
+    plan) and, for one trajectory, to the oracle."""
+    import torch
+    from bhmm_amd.engine import synth_observations
+    n, M, A, pi, B, A_eval, B_eval = _c3_model()
+    K, T = 1024, 1000000
+    obs = torch.empty(K * T, dtype=torch.int32, device="cuda:0")
+    synth_observations("discrete", obs.data_ptr(), A, pi, B, None, K, T, seed=3000)
+    off = np.arange(K + 1, dtype=np.int64) * T
+    eng = _engine()
+    eng.set_observations_device("discrete", obs.data_ptr(), off, n, nsymbols=M)
+    res = eng.estep(A_eval, pi, B_eval)
+    assert eng.get_option("spec_ok") == 1 and eng.get_option("spec_fail") == 0
+    np.testing.assert_allclose(res.state_counts.sum(), K * T, rtol=1e-11)
+    np.testing.assert_allclose(res.C.sum(), K * (T - 1), rtol=1e-11)
+    np.testing.assert_allclose(res.gamma0_sum.sum(), K, rtol=1e-11)
+    np.testing.assert_allclose(res.symbol_counts.sum(), K * T, rtol=1e-11)
+    # gamma rows sum to one: the weighted count of symbol o over all states is its frequency
+    np.testing.assert_allclose(res.symbol_counts.sum(axis=0),
+                               torch.bincount(obs, minlength=M).cpu().numpy(), rtol=1e-11)
+    assert np.all(np.isfinite(res.logL_k)) and res.logL_k.shape == (K,)
+    np.testing.assert_allclose(res.loglik, res.logL_k.sum(), rtol=1e-12)
+    eng.close()                       # frees the 65 GB workspace
+    ks = [0, 511, 1023]               # sub-batch: first, middle, last trajectory
+    sub = torch.cat([obs[k * T:(k + 1) * T] for k in ks])
+    eng2 = _engine()
+    eng2.set_observations_device("discrete", sub.data_ptr(), off[:4], n, nsymbols=M, chunk=7001)
+    res2 = eng2.estep(A_eval, pi, B_eval)
+    np.testing.assert_allclose(res2.logL_k, res.logL_k[ks], rtol=1e-11)
+    eng2.close()
+    o = obs[1023 * T:].cpu().numpy()
+    ref = orc.estep("discrete", [o], A_eval, pi, B_eval)
+    np.testing.assert_allclose(res.logL_k[1023], ref["logL"][0], rtol=1e-11)
+    del obs, sub
+    torch.cuda.empty_cache()
+
+
+# ---- Gibbs hidden-path step ---------------------------------------------------------------
+def test_gibbs_device_stats_equal_host_stats_and_stream_is_partition_independent(golden):
+    """bhmm_sample_paths_dev leaves [C | n0 | emission block] on the device: same numbers as the
+    host-returning call.  With global stream offsets a shard of the trajectories samples exactly
+    the paths the full batch samples; and the device stream is the numpy restatement's."""
+    import torch
+    from conftest import split
+    from oracle_engine import OracleEngine
+    g = golden("g8_ragged")
+    obs = split(g["obs"], g["lengths"])
+    margs = (g["A"], g["pi"], g["mu"], g["sigma"])
+    eng = _engine()
+    eng.set_observations("gaussian", obs, 8, chunk=32)
+    paths, C, n0, emis = eng.sample_paths(*margs, seed=4242)
+    buf = torch.zeros(eng.path_stats_size, dtype=torch.float64, device="cuda:0")
+    assert eng.path_stats_size == 64 + 8 + 24
+    paths2 = eng.sample_paths_dev(*margs, buf.data_ptr(), seed=4242, want_paths=True)
+    C2, n02, emis2 = eng.unpack_path_stats(buf.cpu().numpy())
+    assert np.array_equal(C, C2) and np.array_equal(n0, n02)
+    np.testing.assert_allclose(emis2, emis, rtol=1e-13, atol=1e-13)
+    assert all(np.array_equal(a, b) for a, b in zip(paths, paths2))
+    # numpy restatement of the stream + oracle forward/sampling == device paths
+    ora = OracleEngine()
+    ora.set_observations("gaussian", obs, 8)
+    opaths, oC, on0, _ = ora.sample_paths(*margs, seed=4242)
+    assert all(np.array_equal(a, b) for a, b in zip(paths, opaths))
+    assert np.array_equal(C, oC) and np.array_equal(n0, on0)
+    # a shard with global stream offsets reproduces its trajectories of the full run
+    mine = [1, 3, 4]
+    goff = np.concatenate([[0], np.cumsum([len(o) for o in obs])]).astype(np.int64)
+    sh = _engine()
+    sh.set_observations("gaussian", [obs[k] for k in mine], 8, chunk=50)
+    sh.set_stream_offsets(goff[mine])
+    sp = sh.sample_paths(*margs, seed=4242)[0]
+    assert all(np.array_equal(sp[j], paths[k]) for j, k in enumerate(mine))
+    sh.set_stream_offsets(None)       # back to local positions: a different stream
+    sp = sh.sample_paths(*margs, seed=4242)[0]
+    assert not all(np.array_equal(sp[j], paths[k]) for j, k in enumerate(mine))
+    sh.close()
+    eng.close()
+    # discrete + 9..64 states: packed layout [n][M] / gaussian [3][n]
+    g = golden("d8_ragged")
+    obs = split(g["obs"], g["lengths"])
+    M = g["B"].shape[1]
+    eng = _engine()
+    eng.set_observations("discrete", obs, 8, nsymbols=M, chunk=40)
+    _, C, n0, emis = eng.sample_paths(g["A"], g["pi"], g["B"], seed=9)
+    buf = torch.zeros(eng.path_stats_size, dtype=torch.float64, device="cuda:0")
+    eng.sample_paths_dev(g["A"], g["pi"], g["B"], None, buf.data_ptr(), seed=9)
+    C2, n02, emis2 = eng.unpack_path_stats(buf.cpu().numpy())
+    assert np.array_equal(C, C2) and np.array_equal(n0, n02) and np.array_equal(emis, emis2)
+    eng.close()
+    g = golden("g64")
+    obs = [g["obs"][:400], g["obs"][400:]]
+    eng = _engine()
+    eng.set_observations("gaussian", obs, 64)
+    margs = (g["A"], g["pi"], g["mu"], g["sigma"])
+    _, C, n0, emis = eng.sample_paths(*margs, seed=9)
+    buf = torch.zeros(eng.path_stats_size, dtype=torch.float64, device="cuda:0")
+    eng.sample_paths_dev(*margs, buf.data_ptr(), seed=9)
+    C2, n02, emis2 = eng.unpack_path_stats(buf.cpu().numpy())
+    assert np.array_equal(C, C2) and np.array_equal(n0, n02)
+    np.testing.assert_allclose(emis2, emis, rtol=1e-13, atol=1e-13)
+    eng.close()
+
+
+def test_gibbs_full_size_sweep():
+    """configs[4] shape: one Gibbs hidden-path sweep over 256 x 1e5 (8 states).  Exact integer
+    counts (sum C == K (T-1), sum n0 == K, state occupancies == path histogram), and one
+    trajectory's path equal to the oracle's backward sampling given the same uniforms."""
+    import torch
+    from bench import make_c2_model
+    from bhmm_amd.engine import synth_observations
+    from oracle_engine import device_uniforms
+    K, T = 256, 100000
+    m = make_c2_model()
+    obs = torch.empty(K * T, dtype=torch.float64, device="cuda:0")
+    synth_observations("gaussian", obs.data_ptr(), m["A"], m["pi"], m["mu"], m["sigma"], K, T, seed=31)
+    eng = _engine()
+    eng.set_observations_device("gaussian", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, 8)
+    margs = (m["A_eval"], m["pi"], m["mu_eval"], m["sigma"])
+    paths, C, n0, emis = eng.sample_paths(*margs, seed=123)
+    assert C.dtype == np.int64 and C.sum() == K * (T - 1) and n0.sum() == K
+    allp = np.concatenate(paths)
+    assert np.array_equal(emis[0].astype(np.int64), np.bincount(allp, minlength=8))
+    assert np.array_equal(n0, np.bincount([p[0] for p in paths], minlength=8))
+    # transition counts are the histogram of consecutive pairs
+    pairs = np.zeros((8, 8), dtype=np.int64)
+    for p in paths[:16]:
+        np.add.at(pairs, (p[:-1], p[1:]), 1)
+    assert np.all(pairs <= C)
+    for k in (0, 200):
+        o = obs[k * T:(k + 1) * T].cpu().numpy()
+        _, alpha = orc.forward(m["A_eval"], orc.pobs_gaussian(o, m["mu_eval"], m["sigma"]), m["pi"])
+        ref = orc.sample_path(alpha, m["A_eval"], u=device_uniforms(123, k * T, T))
+        assert np.array_equal(paths[k], ref)
+    eng.close()

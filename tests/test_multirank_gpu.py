@@ -54,3 +54,22 @@ def test_two_ranks_on_the_gpu_equal_one_process(launcher):
         np.testing.assert_allclose(r["chain_sig"], ref["chain_sig"], rtol=1e-8)
         assert np.array_equal(r["chain_paths"], ref["chain_paths"])
     assert np.array_equal(ranks[0]["chain_paths"], ranks[1]["chain_paths"])
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks(launcher):
+    """`python bench.py --gpus 2` without a launcher environment starts two ranks itself and
+    reports n_gpus = 2 (here both ranks share the box's one GPU: --oversubscribe, gloo)."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = launcher.run([[sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                       "--oversubscribe", "--steps", "3", "--warmup", "1", "--ntraj", "16",
+                       "--length", "20000", "--no-cpu"]], timeout=600, env=env)[0]
+    assert r["rc"] == 0, r["out"]
+    line = [ln for ln in r["out"].splitlines() if ln.startswith('{"metric"')]
+    assert len(line) == 1, r["out"]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 16 * 20000 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
