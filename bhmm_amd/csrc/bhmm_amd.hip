@@ -63,6 +63,7 @@ static int disc_copies(int M)
 }
 
 static int stats_size(const bhmm_ctx *c);
+static int64_t ci_records(const bhmm_ctx *c) { return (int64_t)(c->Gp / 64) * c->Lmax; }
 
 #ifndef ESTEP_SPLIT
 #define ESTEP_SPLIT 1 // statistics-only speculative E-step in two launches (PH_P1, PH_P2)
@@ -564,13 +565,18 @@ struct Runner {
         if (sm > 64 * 1024)
             BHMM_HIP(hipFuncSetAttribute((const void *)kern,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        // every alpha row in fp32 (in the gamma_ci slot of the kernel), every FWD_CKPT-th in fp64
+        int rc = c->d_ws32.ensure((size_t)ci_records(c) * N * 64);
+        if (rc)
+            return rc;
         hipLaunchKernelGGL(kern, dim3(c->Gp / 64), dim3(32 * N), sm, c->stream, m, ch,
                            (const void *)c->d_obs_ci.p, (const void *)c->d_obs_rm.p,
                            (const int64_t *)c->d_offsets.p, (const double *)c->d_Bt.p, c->d_aentry.p,
                            c->d_bexit.p, c->d_aexit.p, c->d_bentry.p, c->spec_W, c->d_ws.p,
-                           (double *)nullptr, c->d_logLc.p, c->d_gamma0.p, c->d_partials.p,
-                           c->d_dpartials.p, c->d_specres.p, c->d_ea.p);
+                           reinterpret_cast<double *>(c->d_ws32.p), c->d_logLc.p, c->d_gamma0.p,
+                           c->d_partials.p, c->d_dpartials.p, c->d_specres.p, c->d_ea.p);
         BHMM_HIP(hipGetLastError());
+        c->rows32_valid = true;
         return BHMM_OK;
     }
 
@@ -608,6 +614,7 @@ struct Runner {
         }
         if ((rc = prescan_stitch<KIND>(c, m)))
             return rc;
+        c->rows32_valid = false; // the exact pass writes every row in fp64
         return fwdbwd<KIND, MODE_FWD>(c, m, false);
     }
 
@@ -756,7 +763,6 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
                const double *par1, double *stats_dev, int flags);
 int wide_backward(bhmm_ctx *c, const double *A);
 
-static int64_t ci_records(const bhmm_ctx *c) { return (int64_t)(c->Gp / 64) * c->Lmax; }
 
 static int stats_size(const bhmm_ctx *c)
 {
@@ -943,6 +949,7 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     c->d_soff.release();
+    c->d_ws32.release();
     c->d_ctraj.release();
     c->d_clen.release();
     c->d_traj_c0.release();

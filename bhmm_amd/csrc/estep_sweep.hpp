@@ -371,9 +371,13 @@ __device__ __forceinline__ void beta_step(const G &gather, const ObsIn &in, int 
 //   linearly.  Otherwise the host re-runs the E-step with the prescan / stitch kernels, which
 //   are exact unconditionally.
 //   GAMMA: the instantiation that can store the gamma rows (gamma_ci may still be null).
-//   PHASE: PH_ALL -- everything in one launch.  PH_FWDROWS -- forward sweep only, every alpha
-//   row stored (any power-of-two scale): the Gibbs hidden-path step samples from alpha and is
-//   indifferent to its scale (_hidden.c:330-378).  PH_P1 / PH_P2 -- the E-step in two launches:
+//   PHASE: PH_ALL -- everything in one launch.  PH_FWDROWS -- forward sweep only, for the Gibbs
+//   hidden-path step, which samples from alpha and is indifferent to its scale (_hidden.c:330-378):
+//   every alpha row is stored ROUNDED TO fp32 (rows32, passed in the gamma_ci slot; any
+//   power-of-two scale) and only the rows of the steps s % FWD_CKPT == 0 in fp64.  k_smp_maps
+//   decides a draw from the fp32 row when the decision is clear at that precision and otherwise
+//   rebuilds the exact fp64 row from the nearest stored one (path_kernels.hpp) -- half the alpha
+//   traffic of storing fp64 rows, which bound both kernels.  PH_P1 / PH_P2 -- the E-step in two launches:
 //   P1 has twice the workgroups, the first half run the forward sweep of their record group, the
 //   second half only the backward warm-up (beta at the chunk's last step); neither needs the xi
 //   accumulators, so four wavefronts fit a SIMD where PH_ALL has two, and the two halves hide
@@ -392,6 +396,9 @@ __device__ __forceinline__ void beta_step(const G &gather, const ObsIn &in, int 
 #endif
 #ifndef ESTEP_WAVES
 #define ESTEP_WAVES 2
+#endif
+#ifndef FWD_CKPT
+#define FWD_CKPT 16 // forward-only pass (Gibbs step): fp64 alpha rows of the steps s % FWD_CKPT == 0
 #endif
 enum { PH_ALL = 0, PH_FWDROWS = 1, PH_P1 = 2, PH_P2 = 3 };
 
@@ -603,10 +610,32 @@ __device__ __forceinline__ void estep_body(
             // PH_P1: with every stored row goes the exponent removed so far (eP), one int per chunk;
             // PH_P2 forms the gamma / xi normalisers from it without a reciprocal
             int32_t *pe = nullptr;
-            auto single = [&](ObsCursor<N, KIND> &po, double2 *&pw) {
+            // which fp64 rows reach HBM: the E-step keeps every second one (CKS = 2, the backward
+            // sweep rebuilds the others); the forward-only pass keeps every FWD_CKPT-th (and all
+            // rows in fp32, see PH_FWDROWS above)
+            constexpr int PF = ESTEP_PF_F;
+            constexpr bool CKPT = ESTEP_CKPT && !FWDONLY;
+            constexpr int CKS = FWDONLY ? FWD_CKPT : (CKPT ? 2 : 1);
+            constexpr int ALIGN = FWDONLY ? 2 * PF : 2;
+            static_assert(PF % 2 == 0 && (FWDONLY ? CKS % (2 * PF) == 0 : (2 * PF) % CKS == 0),
+                          "stored rows sit at fixed positions inside the unrolled groups");
+            [[maybe_unused]] float2 *pw32 = nullptr;
+            constexpr int RS32 = (N / 2) * 64; // float2 elements per fp32 CI record
+            if constexpr (FWDONLY) {
+                float2 *rows32 = reinterpret_cast<float2 *>(gamma_ci);
+                if (first) // row 0 (written in fp64 above)
+                    rows32[rec0 * RS32 + cl * (N / 2) + q] = make_float2((float)a[0], (float)a[1]);
+                pw32 = rows32 + (rec0 + s) * RS32 + cl * (N / 2) + q;
+            }
+            auto single = [&](ObsCursor<N, KIND> &po, double2 *&pw, bool store) {
                 double2 o;
                 fstep(po.at(0), o, std::true_type());
-                *pw = o;
+                if (!FWDONLY || store)
+                    *pw = o;
+                if constexpr (FWDONLY) {
+                    *pw32 = make_float2((float)o.x, (float)o.y);
+                    pw32 += RS32;
+                }
                 if constexpr (PHASE == PH_P1)
                     *pe = eP;
                 po.move(1);
@@ -616,11 +645,9 @@ __device__ __forceinline__ void estep_body(
             ObsCursor<N, KIND> po(obs_ci, rec0 + s, cl, q);
             double2 *pw = ci_pair(ws, rec0 + s, N, q, cl);
             pe = ea_rows + (rec0 + s) * 64 + cl;
-            constexpr int PF = ESTEP_PF_F;
-            constexpr bool CKPT = ESTEP_CKPT && !FWDONLY; // a forward-only pass keeps every row
-            static_assert(PF % 2 == 0, "row parity inside the unrolled groups");
-            if ((s & 1) && s < len) { // first chunk of a trajectory: bring the group base to an even step
-                single(po, pw);
+            // first chunk of a trajectory (s = 1): bring the group base to an aligned step
+            while ((s & (ALIGN - 1)) && s < len) {
+                single(po, pw, (s % CKS) == 0);
                 ++s;
             }
             // groups of 2 PF steps (two register sets, each loaded PF..2PF-1 steps before its
@@ -639,7 +666,11 @@ __device__ __forceinline__ void estep_body(
                         y[j] = po.at(PF + j);
                     unrolled<PF>([&](auto j) {
                         fstep(x[j], ox[j], sc_at<j>());
-                        if constexpr (!CKPT || j % 2 == 0) {
+                        if constexpr (FWDONLY) {
+                            pw32[j * RS32] = make_float2((float)ox[j].x, (float)ox[j].y);
+                            if (j == 0 && (s % CKS) == 0)
+                                pw[0] = ox[j];
+                        } else if constexpr (j % CKS == 0) {
                             pw[j * RS] = ox[j];
                             if constexpr (PHASE == PH_P1)
                                 pe[j * 64] = eP;
@@ -652,7 +683,9 @@ __device__ __forceinline__ void estep_body(
                     }
                     unrolled<PF>([&](auto j) {
                         fstep(y[j], oy[j], sc_at<PF + j>());
-                        if constexpr (!CKPT || j % 2 == 0) {
+                        if constexpr (FWDONLY) {
+                            pw32[(PF + j) * RS32] = make_float2((float)oy[j].x, (float)oy[j].y);
+                        } else if constexpr ((PF + j) % CKS == 0) {
                             pw[(PF + j) * RS] = oy[j];
                             if constexpr (PHASE == PH_P1)
                                 pe[(PF + j) * 64] = eP;
@@ -672,10 +705,14 @@ __device__ __forceinline__ void estep_body(
                     po.move(2 * PF);
                     pw += 2 * PF * RS;
                     pe += 2 * PF * 64;
+                    if constexpr (FWDONLY) {
+                        pw32 += 2 * PF * RS32;
+                        s += 2 * PF;
+                    }
                 }
             }
-            for (int i = tail; i > 0; --i)
-                single(po, pw);
+            for (int i = tail; i > 0; --i) // step len - i
+                single(po, pw, ((len - i) % CKS) == 0);
 #ifdef ESTEP_CLOCKPROBE
             pr2 = wall_clock64();
 #endif

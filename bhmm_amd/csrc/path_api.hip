@@ -105,10 +105,22 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         const Chunks chs = chunks_pub(c);
         const int64_t *offd = c->d_offsets.p;
         const void *obs_ci = c->d_obs_ci.p;
-        hipLaunchKernelGGL((k_smp_maps<N>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd,
-                           (const int64_t *)(c->d_soff.p ? c->d_soff.p : c->d_offsets.p),
-                           (const double *)c->d_ws.p, (const double *)udev, seed, P, fmap, status, dmark,
-                           nib, W8, Gp64, gw, Lp);
+        const int64_t *soffd = c->d_soff.p ? c->d_soff.p : c->d_offsets.p;
+        const double *wsd = c->d_ws.p, *Btd = c->d_Bt.p;
+        // fp32 copies of the alpha rows, if the forward pass that just ran wrote them
+        const float *r32 = c->rows32_valid ? c->d_ws32.p : nullptr;
+        if (c->kind == EMIT_GAUSS)
+            hipLaunchKernelGGL((k_smp_maps<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
+                               chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
+                               fmap, status, dmark, nib, W8, Gp64, gw, Lp);
+        else if (c->kind == EMIT_DISC)
+            hipLaunchKernelGGL((k_smp_maps<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
+                               chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
+                               fmap, status, dmark, nib, W8, Gp64, gw, Lp);
+        else
+            hipLaunchKernelGGL((k_smp_maps<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
+                               chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
+                               fmap, status, dmark, nib, W8, Gp64, gw, Lp);
         BHMM_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_smp_stitch, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB), dim3(64), 0,
                            c->stream,

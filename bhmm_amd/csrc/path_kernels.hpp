@@ -15,7 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "estep_kernels.hpp"
+#include "estep_sweep.hpp"
 #include "wide_kernels.hpp"
 
 namespace bhmm {
@@ -156,6 +156,128 @@ __device__ __forceinline__ void stage_At(double *sAt, const Model<N> &m)
     __syncthreads();
 }
 
+// Part p of a chunk of `len` steps covers [s_lo, s_hi) (k_smp_maps and k_smp_apply agree on this)
+__device__ __forceinline__ void smp_part_bounds(int len, int part, int P, int &s_lo, int &s_hi)
+{
+    s_lo = (int)((int64_t)len * part / P);
+    s_hi = (int)((int64_t)len * (part + 1) / P);
+}
+
+// What a lane fetches for one step of a rebuild: observation, symbol or pobs row.
+template <int N, int KIND>
+struct SmpRaw {
+    double o;    // gaussian: the observation
+    int sym;     // discrete: the symbol
+    double pv[KIND == EMIT_EXPL ? N : 1]; // explicit: the pobs row
+};
+template <int N, int KIND>
+__device__ __forceinline__ void smp_fetch(const void *obs_ci, int64_t rec, int lane,
+                                          SmpRaw<N, KIND> &raw)
+{
+    raw.o = 0.0;
+    raw.sym = 0;
+    if constexpr (KIND == EMIT_GAUSS)
+        raw.o = static_cast<const double *>(obs_ci)[rec * 64 + lane];
+    else if constexpr (KIND == EMIT_DISC)
+        raw.sym = static_cast<const int32_t *>(obs_ci)[rec * 64 + lane];
+    else
+        ci_load<N>(static_cast<const double *>(obs_ci), rec, lane, raw.pv);
+}
+
+// next = 2^e ((prev^T A) o p): one forward step (_hidden.c:41-55) of ONE lane holding all N
+// states, rescaled by a power of two like scaled_emit<CAREFUL> (the largest entry into [0.5, 1)),
+// with the outlier rule of the gaussian model (outputmodel.py:126-130) applied when the product
+// vanishes.  The emission probabilities are those of emit_raw (estep_sweep.hpp).
+// sAt[j*N + i] = A[i][j]; sEm = [mu | -1/(2 sigma^2) | 1/(sqrt(2 pi) sigma)] (both LDS).
+template <int N, int KIND>
+__device__ __forceinline__ void smp_rebuild(const double (&prev)[N], const double *sAt,
+                                            const double *sEm, const double *Bt_g,
+                                            const SmpRaw<N, KIND> &raw, int n, double (&next)[N])
+{
+    // the model tables are re-read from LDS at every step: hoisted out of the step loop they would
+    // occupy 2 N (N + 3) registers of every lane
+    asm volatile("" ::: "memory");
+    double sv[N];
+    int hm = 0;
+    bool nz = false;
+    [[maybe_unused]] double pb[KIND == EMIT_DISC ? N : 1];
+    if constexpr (KIND == EMIT_DISC) { // the symbol's row of B^T ([M][N], L2-resident)
+        const double2 *brow = reinterpret_cast<const double2 *>(Bt_g + (int64_t)raw.sym * N);
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const double2 x = brow[i];
+            pb[2 * i] = x.x;
+            pb[2 * i + 1] = x.y;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double acc = prev[0] * sAt[j * N];
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+            acc = fma(prev[i], sAt[j * N + i], acc);
+        sv[j] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double pj;
+        if constexpr (KIND == EMIT_GAUSS) {
+            const double d = raw.o - sEm[j];
+            pj = sEm[2 * N + j] * exp_nonpos(d * d * sEm[N + j]);
+        } else if constexpr (KIND == EMIT_DISC) {
+            pj = pb[j];
+        } else {
+            pj = raw.pv[j];
+        }
+        nz |= pj != 0.0;
+        next[j] = sv[j] * pj;
+        hm = max(hm, __double2hiint(next[j]));
+    }
+    if constexpr (KIND == EMIT_GAUSS) {
+        if (__builtin_expect(hm < 0x00100000 && !nz, 0)) { // all-zero emission row
+            const double one = (raw.o != raw.o) ? raw.o : 1.0; // a NaN observation stays NaN
+            hm = 0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                next[j] = j < n ? sv[j] * one : 0.0;
+                hm = max(hm, __double2hiint(next[j]));
+            }
+        }
+    }
+    const int ne = 1022 - (hm >> 20);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        next[j] = ldexp(next[j], ne);
+}
+
+// A draw decided from an alpha row that is only known to a relative accuracy (the fp32 copy):
+// the state if the decision is clear by more than `tol` (relative to the normaliser), -1 if not.
+// A normaliser below 1e-30 is never clear: the forward pass rescales its rows only every few
+// steps, so after a run of very unlikely observations an fp32 row may sit in the denormal range
+// (or be zero), where its relative accuracy is gone.
+template <int N>
+__device__ __forceinline__ int pick_clear(const double (&a)[N], const double *col, double r, int n,
+                                          double tol)
+{
+    double c[N], S = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        S += col ? a[i] * col[i] : a[i];
+        c[i] = S;
+    }
+    const double t = r * S, w = tol * S;
+    int pick = 0;
+    bool amb = !(S > 1e-30);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double d = c[i] - t;
+        const bool in = i < n;
+        amb |= in && (fabs(d) <= w);
+        pick += (in && d < 0.0) ? 1 : 0; // c is non-decreasing: first i with c_i >= t
+    }
+    return (amb || pick >= n) ? -1 : pick;
+}
+
 // The maps are built on a partition finer than the E-step chunks (every chunk is cut into P
 // parts, P workgroups walk the same 256 chunks): these kernels keep one lane per (chunk, part),
 // so more parts = more wavefronts in flight; composition does not care where the cuts are.
@@ -163,17 +285,37 @@ __device__ __forceinline__ void stage_At(double *sAt, const Model<N> &m)
 // the part, i.e. it IS the sampled path there.  Those states are kept, one nibble per step (8 steps
 // per word, word w of part p of chunk g at nib[(p * W8 + w) * Gp + g], filled from the top of the
 // part downwards), and dmark[part] = the lowest step that still depends on the part's successor:
-// k_smp_apply reads alpha again only for [dmark, end of part) and takes the rest from the nibbles.
-template <int N>
-__global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks ch,
-                                                  const int64_t *off, const int64_t *soff,
-                                                  const double *alpha_ci,
-                                                  const double *u, uint64_t seed, int P,
-                                                  uint32_t *Fmap, int *status, int32_t *dmark,
-                                                  uint32_t *nib, int W8, int64_t Gp, uint32_t *gw,
-                                                  int Lp)
+// k_smp_apply takes the steps [dmark, end of part) from the full step maps and the rest from the
+// nibbles.
+//
+// alpha.  The kernel is bound by reading the alpha rows (and the forward pass by writing them),
+// so the forward pass leaves every row rounded to fp32 (rows32, 4 N bytes per step) and only the
+// rows of the steps s % FWD_CKPT == 0 in fp64.  A draw compares partial sums of alpha_t[i] A[i][j]
+// with u S: with an fp32 row these are known to 1.5e-7 S, so whenever every partial sum is further
+// than SMP_TOL32 S from the threshold the fp32 row decides exactly as the fp64 row would.
+// Otherwise (a few hundred of 2.6e7 steps on configs[4]) the lane rebuilds the exact fp64 row
+// from the stored one below it with the forward recursion itself and decides with pick_state,
+// i.e. as before.  rows32 == nullptr: every fp64 row is in alpha_ci (the exact fallback pass of a
+// failed speculation wrote them) and is used directly.
+constexpr double SMP_TOL32 = 1e-6;
+template <int N, int KIND>
+__global__ __launch_bounds__(256, 2) void k_smp_maps(const Model<N> m, const Chunks ch,
+                                                     const int64_t *off, const int64_t *soff,
+                                                     const double *alpha_ci, const float *rows32,
+                                                     const void *obs_ci, const double *Bt_g,
+                                                     const double *u, uint64_t seed, int P,
+                                                     uint32_t *Fmap, int *status, int32_t *dmark,
+                                                     uint32_t *nib, int W8, int64_t Gp, uint32_t *gw,
+                                                     int Lp)
 {
     __shared__ __attribute__((aligned(16))) double sAt[N * N];
+    __shared__ __attribute__((aligned(16))) double sEm[3 * N];
+    if (threadIdx.x < N) {
+        const int i = threadIdx.x;
+        sEm[i] = m.e0[i];
+        sEm[N + i] = -0.5 * m.e1[i] * m.e1[i];
+        sEm[2 * N + i] = m.e2[i];
+    }
     stage_At<N>(sAt, m);
     const int part = blockIdx.x % P;
     const int64_t g = (int64_t)(blockIdx.x / P) * 256 + threadIdx.x;
@@ -186,7 +328,8 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
     const int64_t Tk = off[k + 1] - off[k];
     const int64_t sbase = soff[k] + t0; // position of this chunk in the random stream
     const int n = m.nreal;
-    const int s_lo = (int)((int64_t)len * part / P), s_hi = (int)((int64_t)len * (part + 1) / P);
+    int s_lo, s_hi;
+    smp_part_bounds(len, part, P, s_lo, s_hi);
     uint32_t cur = 0x76543210u; // nibble j = image of next-part state j (identity)
     int dm = s_hi;
     uint32_t word = 0;
@@ -195,29 +338,114 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
     // state), word j of part p of chunk g at gw[(p * Lp + j) * Gp + g] -- k_smp_apply then needs
     // neither alpha nor the uniforms again
     uint32_t *mygw = gw + ((int64_t)part * Lp) * Gp + g;
-    for (int s = s_hi - 1; s >= s_lo; --s) {
+    // exact fp64 row of step s: the stored row at or below it, taken forward over the steps between
+    auto exact_row = [&](int s, double (&a)[N]) {
+        const int cb = rows32 ? (s & ~(FWD_CKPT - 1)) : s;
+        ci_load<N>(alpha_ci, ci_rec(g, cb, ch.Lmax), lane, a);
+#pragma unroll 1
+        for (int q = cb + 1; q <= s; ++q) {
+            SmpRaw<N, KIND> raw;
+            smp_fetch<N, KIND>(obs_ci, ci_rec(g, q, ch.Lmax), lane, raw);
+            double nx[N];
+            smp_rebuild<N, KIND>(a, sAt, sEm, Bt_g, raw, n, nx);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                a[i] = nx[i];
+        }
+    };
+    // The walk is a dependent chain (the column of A a step needs is known only after the previous
+    // draw) and its alpha rows come straight from HBM: they are requested SMP_MPF steps ahead.
+    constexpr int SMP_MPF = 4;
+    constexpr int NF = N / 2; // float2 per fp32 row
+    const int nst = s_hi - s_lo;
+    float2 ring[SMP_MPF][NF];
+    auto fetch32 = [&](int q, int jj) {
+        const int sc = s_hi - 1 - (jj < nst ? jj : nst - 1);
+        const float2 *p32 =
+            reinterpret_cast<const float2 *>(rows32 + ci_rec(g, sc, ch.Lmax) * (int64_t)(N * 64)) +
+            lane * NF;
+        if constexpr (N >= 4) {
+#pragma unroll
+            for (int e = 0; e < N / 4; ++e) {
+                const float4 x = reinterpret_cast<const float4 *>(p32)[e];
+                ring[q][2 * e] = make_float2(x.x, x.y);
+                ring[q][2 * e + 1] = make_float2(x.z, x.w);
+            }
+        } else {
+            ring[q][0] = p32[0];
+        }
+    };
+    if (rows32 && nst > 0) {
+#pragma unroll
+        for (int q = 0; q < SMP_MPF; ++q)
+            fetch32(q, q);
+    }
+    for (int jb = 0; jb < nst; jb += SMP_MPF) {
+#pragma unroll
+    for (int qq = 0; qq < SMP_MPF; ++qq) {
+        const int j = jb + qq; // position from the top of the part
+        if (j >= nst)
+            break;
+        const int s = s_hi - 1 - j;
         double a[N];
-        ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
+        if (rows32) {
+#pragma unroll
+            for (int e = 0; e < NF; ++e) {
+                a[2 * e] = ring[qq][e].x;
+                a[2 * e + 1] = ring[qq][e].y;
+            }
+            fetch32(qq, j + SMP_MPF);
+        } else {
+            ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
+        }
         const double r = u ? u[base + s] : uniform01(seed, (uint64_t)(sbase + s));
         const bool last = (t0 + s == Tk - 1);
-        const uint32_t c0 = cur & 7u;
-        const int j = s_hi - 1 - s; // position from the top of the part
-        if (cur == c0 * 0x11111111u || last) { // coalesced (or constant map): one image
-            const int x = pick_state<N>(a, last ? nullptr : sAt + c0 * N, r, n, status);
-            cur = (uint32_t)x * 0x11111111u;
+        // Only the images that are still alive need a draw: the next state of this step is one of
+        // the nibbles of cur, whatever state the part is entered with.  Their number falls quickly
+        // (8 -> 2..3 within a few steps -> 1), so the loop below is short on most steps; a lane
+        // whose images have coalesced (or at the last step of a trajectory, a constant map) draws
+        // once.
+        uint32_t alive = 0;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            alive |= (jj < n ? 1u : 0u) << ((cur >> (4 * jj)) & 7u); // entry states are real states
+        if (last)
+            alive = 1u; // the draw does not depend on a next state (_hidden.c:347-355)
+        const bool one = (alive & (alive - 1)) == 0;
+        uint32_t G = 0;
+        bool clear = rows32 != nullptr;
+        if (clear) { // decide from the fp32 row where that is safe
+            uint32_t todo = alive;
+            while (todo) {
+                const int x = __ffs(todo) - 1;
+                todo &= todo - 1;
+                const int y = pick_clear<N>(a, last ? nullptr : sAt + x * N, r, n, SMP_TOL32);
+                clear = clear && y >= 0;
+                G |= (uint32_t)(y & 7) << (4 * x);
+            }
+        }
+        if (__builtin_expect(!clear, 0)) { // the exact fp64 row, the reference's decision rule
+            if (rows32)
+                exact_row(s, a);
+            G = 0;
+            uint32_t todo = alive;
+            while (todo) {
+                const int x = __ffs(todo) - 1;
+                todo &= todo - 1;
+                G |= (uint32_t)pick_state<N>(a, last ? nullptr : sAt + x * N, r, n, status) << (4 * x);
+            }
+        }
+        if (one) {
+            const uint32_t x1 = (G >> (4 * (__ffs(alive) - 1))) & 7u;
+            cur = x1 * 0x11111111u;
             if (last) {
                 dm = s; // no successor state: k_smp_apply takes this step (a constant map)
                 mygw[(int64_t)j * Gp] = cur;
             }
-            word |= (uint32_t)x << (4 * (j & 7));
+            word |= x1 << (4 * (j & 7));
         } else {
             dm = s;
-            uint32_t G = 0;
-#pragma unroll
-            for (int x = 0; x < N; ++x)
-                if (x < n) // padded (inert) states are never a next state
-                    G |= (uint32_t)pick_state<N>(a, sAt + x * N, r, n, status) << (4 * x);
-            mygw[(int64_t)j * Gp] = G;
+            mygw[(int64_t)j * Gp] = G; // (entries of states that are not alive are never looked up)
             uint32_t nw = 0;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj)
@@ -228,6 +456,7 @@ __global__ __launch_bounds__(256) void k_smp_maps(const Model<N> m, const Chunks
             mynib[(int64_t)(j >> 3) * Gp] = word;
             word = 0;
         }
+    }
     }
     Fmap[g * P + part] = cur;
     dmark[g * P + part] = dm;
@@ -301,7 +530,8 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
         const int k = ch.traj[g];
         const int64_t t0 = ch.t0[g], base = ch.goff[g];
         const int64_t Tk = off[k + 1] - off[k];
-        const int s_lo = (int)((int64_t)len * part / P), s_hi = (int)((int64_t)len * (part + 1) / P);
+        int s_lo, s_hi;
+        smp_part_bounds(len, part, P, s_lo, s_hi);
         int nxt = next_state[g * P + part];
         const int dm = dmark[g * P + part]; // steps below dm: the state itself is recorded
         const uint32_t *mynib = nib + ((int64_t)part * W8) * Gp + g;

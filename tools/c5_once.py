@@ -16,5 +16,9 @@ for _ in range(3):
     eng.sample_paths(*args, seed=1, want_paths=False)
 dt = timeit(lambda: eng.sample_paths(*args, seed=1, want_paths=False), 5)
 print("ms %.3f" % (dt * 1e3))
-dt = timeit(lambda: eng.viterbi(*args), 3)
-print("viterbi ms %.3f" % (dt * 1e3))
+pdev = torch.empty(K * T, dtype=torch.uint8, device="cuda:0")
+dt = timeit(lambda: eng.viterbi_u8(*args, out=pdev), 5)
+print("viterbi (uint8 paths, device-resident) ms %.3f" % (dt * 1e3))
+ppin = torch.empty(K * T, dtype=torch.uint8).pin_memory()
+dt = timeit(lambda: eng.viterbi_u8(*args, out=ppin), 5)
+print("viterbi (uint8 paths, pinned host) ms %.3f" % (dt * 1e3))
