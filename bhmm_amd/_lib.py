@@ -59,6 +59,10 @@ SIGNATURES = {
     "bhmm_ctx_set_observations": (ctypes.c_int, [c_void_p, ctypes.c_int, c_void_p, c_int64_p,
                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_int, ctypes.c_int]),
+    "bhmm_ctx_set_observations_lagged": (ctypes.c_int, [c_void_p, ctypes.c_int, c_void_p, c_int64_p,
+                                                        ctypes.c_int, ctypes.c_int, c_int32_p,
+                                                        c_int32_p, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "bhmm_ctx_stats_size": (ctypes.c_int, [c_void_p]),
     "bhmm_estep": (ctypes.c_int, [c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                   c_void_p, ctypes.c_int]),

@@ -18,15 +18,33 @@ def _guess_output_type(observations):
     raise TypeError('Observations is neither sequences of integers nor 1D-sequences of floats.')
 
 
+class LaggedObservations(list):
+    """What lag_observations returns: a plain list of sub-sampled trajectories (numpy views, so
+    existing code keeps working) that also remembers how it was made -- the original
+    trajectories, the lag, and (trajectory, shift) of every entry -- so that the estimators can
+    upload the ORIGINAL data once and cut the views on the GPU
+    (bhmm_ctx_set_observations_lagged) instead of uploading `lag` host-side copies."""
+
+    def __init__(self, base, lag, stride):
+        list.__init__(self)
+        self.base = [np.asarray(o) for o in base]
+        self.lag = int(lag)
+        self.stride = int(stride)
+        self.views = []          # (trajectory index, shift) of every entry
+
+
 def lag_observations(observations, lag, stride=1):
-    """bhmm/api.py:70-94: shifted sub-sampled copies (views) of every trajectory."""
-    obsnew = []
-    for obs in observations:
-        for shift in range(0, lag, stride):
-            obs_lagged = obs[shift:][::lag]
-            if len(obs_lagged) > 1:
-                obsnew.append(obs_lagged)
-    return obsnew
+    """Sub-sampled, shifted trajectories (bhmm/api.py:70-94): trajectory k contributes
+    obs_k[shift::lag] for shift = 0, stride, 2 stride, ... < lag; pieces with fewer than two
+    observations are left out (they carry no transition)."""
+    out = LaggedObservations(observations, lag, stride)
+    for k, traj in enumerate(out.base):
+        for shift in range(0, out.lag, out.stride):
+            piece = traj[shift::out.lag]
+            if piece.shape[0] > 1:
+                out.append(piece)
+                out.views.append((k, shift))
+    return out
 
 
 def gaussian_hmm(pi, P, means, sigmas):

@@ -1134,6 +1134,85 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     return BHMM_OK;
 }
 
+// ---- lagged views (bhmm/api.py:70-94) ---------------------------------------------------
+namespace bhmm {
+// view v, element i  <-  source element src_start[v] + i * lag  (elements of `words` 4-byte words)
+static __global__ void k_lag_gather(const uint32_t *src, uint32_t *dst, const int64_t *src_start,
+                                    const int64_t *dst_off, int lag, int words)
+{
+    const int v = blockIdx.y;
+    const int64_t len = dst_off[v + 1] - dst_off[v];
+    const int64_t s0 = src_start[v], d0 = dst_off[v];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t *ps = src + (s0 + i * lag) * words;
+        uint32_t *pd = dst + (d0 + i) * words;
+        for (int w = 0; w < words; ++w)
+            pd[w] = ps[w];
+    }
+}
+} // namespace bhmm
+
+int bhmm_ctx_set_observations_lagged(bhmm_ctx *c, int kind, const void *obs, const int64_t *offsets,
+                                     int K, int lag, const int32_t *view_traj,
+                                     const int32_t *view_shift, int V, int nstates, int nsymbols,
+                                     int chunk, int obs_on_device)
+{
+    if (!c || !obs || !offsets || K < 1 || !view_traj || !view_shift || V < 1)
+        return invalid("bad context / observations / views");
+    if (lag < 1)
+        return invalid("lag must be >= 1");
+    if (kind < 0 || kind > 2 || nstates < 1)
+        return invalid("unknown emission kind / nstates");
+    BHMM_HIP(hipSetDevice(c->device));
+    const size_t esz = kind == BHMM_EMIT_GAUSSIAN ? sizeof(double)
+                       : kind == BHMM_EMIT_DISCRETE ? sizeof(int32_t)
+                                                    : sizeof(double) * (size_t)nstates;
+    std::vector<int64_t> src_start(V), dst_off(V + 1, 0);
+    for (int v = 0; v < V; ++v) {
+        const int k = view_traj[v], sh = view_shift[v];
+        if (k < 0 || k >= K || sh < 0)
+            return invalid("view refers to a trajectory / shift that does not exist");
+        const int64_t T = offsets[k + 1] - offsets[k];
+        const int64_t len = T > sh ? (T - sh + lag - 1) / lag : 0; // len(obs[sh::lag])
+        src_start[v] = offsets[k] - offsets[0] + sh;
+        dst_off[v + 1] = dst_off[v] + len;
+    }
+    const int64_t total_src = offsets[K] - offsets[0], total_dst = dst_off[V];
+    if (total_dst <= 0)
+        return invalid("the views are empty");
+    // ONE upload of the original observations; the views are cut on the device
+    DevBuf<char> d_src, d_dst;
+    DevBuf<int64_t> d_tab;
+    int rc;
+    if ((rc = d_dst.ensure((size_t)total_dst * esz)) || (rc = d_tab.ensure(2 * (size_t)V + 1)))
+        return rc;
+    struct Free {
+        DevBuf<char> &a, &b;
+        DevBuf<int64_t> &t;
+        ~Free() { a.release(); b.release(); t.release(); }
+    } guard{d_src, d_dst, d_tab};
+    const char *src_dev = static_cast<const char *>(obs) + (size_t)offsets[0] * esz;
+    if (!obs_on_device) {
+        if ((rc = d_src.ensure((size_t)total_src * esz)))
+            return rc;
+        BHMM_HIP(hipMemcpyAsync(d_src.p, src_dev, (size_t)total_src * esz, hipMemcpyHostToDevice,
+                                c->stream));
+        src_dev = d_src.p;
+    }
+    BHMM_HIP(hipMemcpyAsync(d_tab.p, src_start.data(), (size_t)V * sizeof(int64_t),
+                            hipMemcpyHostToDevice, c->stream));
+    BHMM_HIP(hipMemcpyAsync(d_tab.p + V, dst_off.data(), ((size_t)V + 1) * sizeof(int64_t),
+                            hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_lag_gather, dim3(64, V), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint32_t *>(src_dev),
+                       reinterpret_cast<uint32_t *>(d_dst.p), (const int64_t *)d_tab.p,
+                       (const int64_t *)(d_tab.p + V), lag, (int)(esz / 4));
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipStreamSynchronize(c->stream)); // the host tables are temporaries
+    return bhmm_ctx_set_observations(c, kind, d_dst.p, dst_off.data(), V, nstates, nsymbols, chunk, 1);
+}
+
 int bhmm_diag_exp_nonpos(double *y, const double *x, int64_t n)
 {
     if (!y || !x || n < 1)

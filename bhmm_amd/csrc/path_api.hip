@@ -61,7 +61,9 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         return rc;
     const int K = c->K, n = c->n;
     const size_t nstat = (size_t)N * N + N;
-    const int P = c->Lmax >= 256 ? 4 : 1;       // parts per chunk for the map kernels
+    // parts per chunk for the map kernels (BHMM_AMD_SMP_PARTS overrides: kernel experiments)
+    static const int parts_env = getenv("BHMM_AMD_SMP_PARTS") ? atoi(getenv("BHMM_AMD_SMP_PARTS")) : 0;
+    const int P = parts_env > 0 ? parts_env : (c->Lmax >= 256 ? 4 : 1);
     const int nblk = (c->Gp / BLOCK) * P;
     const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)N : (c->kind == EMIT_DISC ? (size_t)c->M * N : 0);
     // scratch2: [path] | status | part maps | next-part states | lowest non-final step per part |

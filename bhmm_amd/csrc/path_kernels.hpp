@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_smp_maps(const Model<N> m, const Chu
     };
     // The walk is a dependent chain (the column of A a step needs is known only after the previous
     // draw) and its alpha rows come straight from HBM: they are requested SMP_MPF steps ahead.
+    uint32_t alive_set = (1u << n) - 1u; // the part may be entered with any real state
     constexpr int SMP_MPF = 4;
     constexpr int NF = N / 2; // float2 per fp32 row
     const int nst = s_hi - s_lo;
@@ -405,10 +406,8 @@ __global__ __launch_bounds__(256, 2) void k_smp_maps(const Model<N> m, const Chu
         // (8 -> 2..3 within a few steps -> 1), so the loop below is short on most steps; a lane
         // whose images have coalesced (or at the last step of a trajectory, a constant map) draws
         // once.
-        uint32_t alive = 0;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-            alive |= (jj < n ? 1u : 0u) << ((cur >> (4 * jj)) & 7u); // entry states are real states
+        // (alive_set = the set of nibbles of cur over the real entry states, carried along)
+        uint32_t alive = alive_set;
         if (last)
             alive = 1u; // the draw does not depend on a next state (_hidden.c:347-355)
         const bool one = (alive & (alive - 1)) == 0;
@@ -434,6 +433,16 @@ __global__ __launch_bounds__(256, 2) void k_smp_maps(const Model<N> m, const Chu
                 todo &= todo - 1;
                 G |= (uint32_t)pick_state<N>(a, last ? nullptr : sAt + x * N, r, n, status) << (4 * x);
             }
+        }
+        // the images of the next step down: G over the alive set
+        {
+            uint32_t nset = 0, todo = alive;
+            while (todo) {
+                const int x = __ffs(todo) - 1;
+                todo &= todo - 1;
+                nset |= 1u << ((G >> (4 * x)) & 7u);
+            }
+            alive_set = nset;
         }
         if (one) {
             const uint32_t x1 = (G >> (4 * (__ffs(alive) - 1))) & 7u;

@@ -86,6 +86,34 @@ class Engine(object):
             int(nstates), int(nsymbols), int(chunk), 0))
         self._adopt(kind, nstates, nsymbols, lengths)
 
+    def set_observations_lagged(self, kind, observations, lag, views, nstates, nsymbols=0, chunk=0):
+        """Lagged views (bhmm/api.py:70-94) cut on the device: `observations` are the ORIGINAL
+        trajectories (uploaded once), `views` a list of (trajectory index, shift); context
+        trajectory v becomes observations[k][shift::lag]."""
+        code = _KINDS[kind]
+        lens = np.array([len(o) for o in observations], dtype=np.int64)
+        off = np.zeros(len(observations) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        if kind == 'gaussian':
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(o, dtype=np.float64)
+                                                        for o in observations]))
+        elif kind == 'discrete':
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(o).astype(np.int32)
+                                                        for o in observations]))
+            if flat.size and (flat.min() < 0 or flat.max() >= nsymbols):
+                raise ValueError("discrete observation outside [0, nsymbols)")
+        else:
+            flat = np.ascontiguousarray(np.concatenate(
+                [np.asarray(o, dtype=np.float64).reshape(-1, nstates) for o in observations]))
+        vt = np.ascontiguousarray([k for k, _ in views], dtype=np.int32)
+        vs = np.ascontiguousarray([s for _, s in views], dtype=np.int32)
+        _lib.check(self._L.bhmm_ctx_set_observations_lagged(
+            self._h, code, flat.ctypes.data_as(ctypes.c_void_p), _lib.lp(off), len(observations),
+            int(lag), _lib.ip(vt), _lib.ip(vs), len(views), int(nstates), int(nsymbols), int(chunk), 0))
+        vlen = np.array([max(0, -(-(int(lens[k]) - int(s)) // int(lag))) for k, s in views],
+                        dtype=np.int64)
+        self._adopt(kind, nstates, nsymbols, vlen)
+
     def set_observations_device(self, kind, dev_ptr, offsets, nstates, nsymbols=0, chunk=0):
         """Same, for a trajectory-concatenated buffer already resident on this GPU
         (dev_ptr: integer device address, e.g. torch.Tensor.data_ptr())."""

@@ -105,8 +105,9 @@ class BayesianHMMSampler(object):
         M = self.model.output_model.nsymbols if self._output == 'discrete' else 0
         self._nsymbols = M
         if self._mine:
-            self._engine.set_observations(self._output, [self.observations[k] for k in self._mine],
-                                          nstates, nsymbols=M)
+            from .maximum_likelihood import _load_observations
+            _load_observations(self._engine, self._output, observations, self.observations,
+                               self._mine, self._comm, nstates, M)
             if self._comm.active:
                 # uniforms are addressed by the position in the UNSHARDED concatenation of all
                 # trajectories: the sampled paths do not depend on the partition over ranks

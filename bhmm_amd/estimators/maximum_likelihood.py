@@ -38,6 +38,20 @@ def default_device(comm):
     return comm.rank % ndev if ndev > 0 else comm.rank
 
 
+def _load_observations(engine, kind, given, copied, mine, comm, nstates, nsymbols):
+    """Hand this rank's trajectories to the engine.  Lagged views made by lag_observations
+    (bhmm/api.py:70-94) are not uploaded piece by piece: the original trajectories go up once and
+    the views are cut on the GPU (bhmm_ctx_set_observations_lagged) -- single process only, a
+    sharded run uploads each rank's own pieces."""
+    views = getattr(given, 'views', None)
+    if (views is not None and not comm.active and hasattr(engine, 'set_observations_lagged')
+            and len(views) == len(copied)):
+        engine.set_observations_lagged(kind, given.base, given.lag, views, nstates,
+                                       nsymbols=nsymbols)
+    else:
+        engine.set_observations(kind, [copied[k] for k in mine], nstates, nsymbols=nsymbols)
+
+
 def packed_stats_size(kind, n, M):
     """Length of the packed E-step statistics vector (include/bhmm_amd.h, bhmm_ctx_stats_size)."""
     return 1 + n + n * n + n + (2 * n if kind == 'gaussian' else (n * M if kind == 'discrete' else 0))
@@ -107,9 +121,8 @@ class MaximumLikelihoodEstimator(object):
         M = self._hmm.output_model.nsymbols if self._output == 'discrete' else 0
         self._nsymbols = M
         if self._mine:
-            self._engine.set_observations(self._output,
-                                          [self._observations[k] for k in self._mine],
-                                          nstates, nsymbols=M)
+            _load_observations(self._engine, self._output, observations, self._observations,
+                               self._mine, self._comm, nstates, M)
 
     # ---- properties (maximum_likelihood.py:145-219) -------------------------------------
     @property

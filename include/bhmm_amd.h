@@ -104,6 +104,16 @@ int bhmm_ctx_destroy(bhmm_ctx *ctx);
 int bhmm_ctx_set_observations(bhmm_ctx *ctx, int kind, const void *obs, const int64_t *offsets,
                               int K, int nstates, int nsymbols, int chunk, int obs_on_device);
 
+/* Lagged views of the observations (bhmm/api.py:70-94, lag_observations): view v is the
+ * sub-sampled trajectory obs_k[shift::lag] with k = view_traj[v], shift = view_shift[v], and
+ * becomes trajectory v of the context.  The ORIGINAL observations (obs, offsets[K+1], as for
+ * bhmm_ctx_set_observations) are uploaded once and the views are cut on the device by strided
+ * reads, instead of lag host-side copies uploaded one by one. */
+int bhmm_ctx_set_observations_lagged(bhmm_ctx *ctx, int kind, const void *obs,
+                                     const int64_t *offsets, int K, int lag,
+                                     const int32_t *view_traj, const int32_t *view_shift, int V,
+                                     int nstates, int nsymbols, int chunk, int obs_on_device);
+
 /* Number of doubles in the packed statistics vector produced by bhmm_estep for the loaded
  * observations:  [0] sum_k logL_k | [1..N] sum_k gamma_k[0] | N*N transition counts C |
  * N state counts sum_t gamma | emission block:

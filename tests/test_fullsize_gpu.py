@@ -286,3 +286,62 @@ def test_gibbs_full_size_sweep():
         ref = orc.sample_path(alpha, m["A_eval"], u=device_uniforms(123, k * T, T))
         assert np.array_equal(paths[k], ref)
     eng.close()
+
+
+# ---- lagged views cut on the device --------------------------------------------------------
+@pytest.mark.parametrize("kind", ["gaussian", "discrete", "explicit"])
+def test_lagged_views_on_device_equal_host_slices(kind):
+    """bhmm_ctx_set_observations_lagged (bhmm/api.py:70-94): the views obs_k[shift::lag] cut on
+    the GPU from one upload give the E-step, Viterbi paths and statistics of the same views
+    uploaded as separate host arrays -- ragged lengths, a trajectory shorter than the lag (its
+    pieces are dropped), stride > 1."""
+    import bhmm_amd
+    rng = np.random.default_rng(5)
+    n, M = 4, 6
+    A = rng.random((n, n)) + 2 * np.eye(n)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    lens = (1000, 333, 7, 2, 4001)
+    if kind == "gaussian":
+        base = [rng.normal(0, 2, T) for T in lens]
+        margs = (A, pi, np.linspace(-2, 2, n), np.full(n, 0.9))
+    elif kind == "discrete":
+        base = [rng.integers(0, M, T).astype(np.int32) for T in lens]
+        margs = (A, pi, rng.dirichlet(np.ones(M), size=n))
+    else:
+        base = [rng.random((T, n)) + 0.05 for T in lens]
+        margs = (A, pi)
+    for lag, stride in ((5, 1), (7, 3), (1, 1)):
+        lagged = bhmm_amd.lag_observations(base, lag, stride)
+        assert all(len(v) > 1 for v in lagged) and len(lagged.views) == len(lagged)
+        a, b = _engine(), _engine()
+        a.set_observations_lagged(kind, lagged.base, lag, lagged.views, n, nsymbols=M if kind == "discrete" else 0)
+        b.set_observations(kind, [np.ascontiguousarray(v) for v in lagged], n,
+                           nsymbols=M if kind == "discrete" else 0)
+        assert np.array_equal(a.lengths, b.lengths)
+        ra, rb = a.estep(*margs), b.estep(*margs)
+        assert np.array_equal(ra.packed, rb.packed) and np.array_equal(ra.logL_k, rb.logL_k)
+        assert all(np.array_equal(x, y) for x, y in zip(a.viterbi(*margs), b.viterbi(*margs)))
+        a.close()
+        b.close()
+
+
+def test_estimate_hmm_with_lag_uses_device_views():
+    """estimate_hmm(observations, n, lag=...) (bhmm/api.py:309-372): same fit whether the lagged
+    views are cut on the GPU or uploaded as host copies."""
+    import bhmm_amd
+    from bhmm_amd.estimators.maximum_likelihood import MaximumLikelihoodEstimator
+    rs = np.random.RandomState(1)
+    model, O, S = bhmm_amd.testsystems.generate_synthetic_observations(nstates=3, ntrajectories=4,
+                                                                       length=5000, rng=rs)
+    lagged = bhmm_amd.lag_observations(O, 4)
+    init = bhmm_amd.gaussian_hmm(np.full(3, 1 / 3.), np.full((3, 3), 0.1) + 0.7 * np.eye(3),
+                                 np.array([-1.5, 0.0, 1.5]), np.ones(3))
+    e1 = MaximumLikelihoodEstimator(lagged, 3, initial_model=init, maxit=10, accuracy=1e-9)
+    e2 = MaximumLikelihoodEstimator(list(lagged), 3, initial_model=init, maxit=10, accuracy=1e-9)
+    h1, h2 = e1.fit(), e2.fit()
+    np.testing.assert_array_equal(e1.likelihoods, e2.likelihoods)
+    np.testing.assert_array_equal(h1.transition_matrix, h2.transition_matrix)
+    assert len(h1.hidden_state_trajectories) == len(lagged) == 16
+    assert all(np.array_equal(p, q) for p, q in zip(h1.hidden_state_trajectories,
+                                                    h2.hidden_state_trajectories))
