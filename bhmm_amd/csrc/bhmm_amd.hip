@@ -63,6 +63,8 @@ static int disc_copies(int M)
 }
 
 static int stats_size(const bhmm_ctx *c);
+// symbols whose tables live in the LDS of the sweep kernels: all of them, or none (big alphabets)
+static int lds_symbols(const bhmm_ctx *c) { return c->bt_global ? 0 : c->M; }
 static int64_t ci_records(const bhmm_ctx *c) { return (int64_t)(c->Gp / 64) * c->Lmax; }
 
 #ifndef ESTEP_SPLIT
@@ -79,7 +81,7 @@ struct Runner {
     static int prescan_stitch(bhmm_ctx *c, const Model<N> &m)
     {
         const Chunks ch = chunks_of(c);
-        const size_t sm0 = (size_t)(N * N + 64 * N + (KIND == EMIT_DISC ? c->M * N : 0)) *
+        const size_t sm0 = (size_t)(N * N + 64 * N + (KIND == EMIT_DISC ? lds_symbols(c) * N : 0)) *
                            sizeof(double);
         if (sm0 > 64 * 1024)
             BHMM_HIP(hipFuncSetAttribute((const void *)(k_prescan<N, KIND>),
@@ -130,7 +132,10 @@ struct Runner {
             flag_words = c->d_specres.p;
         const Chunks ch = chunks_of(c);
         const int nblk = c->Gp / 64; // one workgroup per CI record group (64 chunks)
-        const size_t sm = smem_fwdbwd<N, KIND>(c->M, KIND == EMIT_DISC ? m.dcopies : 1);
+        const size_t sm = smem_fwdbwd<N, KIND>(lds_symbols(c), KIND == EMIT_DISC ? m.dcopies : 1);
+        if (KIND == EMIT_DISC && c->bt_global && MODE == MODE_ESTEP) // the global count tables
+            BHMM_HIP(hipMemsetAsync(c->d_dpartials.p, 0,
+                                    (size_t)DISC_GLOBAL_TABLES * c->M * N * sizeof(double), c->stream));
         if constexpr (MODE == MODE_ESTEP) {
             // the exact fallback always uses the gamma-capable, careful instantiation
             auto launch = [&](auto kern) -> int {
@@ -189,7 +194,7 @@ struct Runner {
                 return rc;
         } else {
             static_assert(MODE == MODE_ESTEP || !SPEC, "row passes take exact boundaries");
-            const size_t smr = (size_t)(KIND == EMIT_DISC ? c->M * N : 0) * sizeof(double);
+            const size_t smr = (size_t)(KIND == EMIT_DISC ? lds_symbols(c) * N : 0) * sizeof(double);
             if (smr > 64 * 1024)
                 BHMM_HIP(hipFuncSetAttribute((const void *)(k_rows<N, KIND, MODE>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr));
@@ -408,8 +413,10 @@ struct Runner {
     {
         Model<N> m;
         fill_model<N>(m, c->n, c->kind, c->M, A, pi, par0, par1);
-        if (c->kind == EMIT_DISC)
+        if (c->kind == EMIT_DISC) {
             m.dcopies = disc_copies<N>(c->M);
+            m.bt_global = c->bt_global ? 1 : 0;
+        }
         switch (c->kind) {
         case EMIT_GAUSS:
             return estep_kind<EMIT_GAUSS>(c, m, stats_dev, flags);
@@ -560,7 +567,7 @@ struct Runner {
     static int forward_launch(bhmm_ctx *c, const Model<N> &m)
     {
         const Chunks ch = chunks_of(c);
-        const size_t sm = smem_fwdbwd<N, KIND>(c->M, KIND == EMIT_DISC ? m.dcopies : 1);
+        const size_t sm = smem_fwdbwd<N, KIND>(lds_symbols(c), KIND == EMIT_DISC ? m.dcopies : 1);
         auto kern = k_estep_light<N, KIND, true, false, CAREFUL, PH_FWDROWS>;
         if (sm > 64 * 1024)
             BHMM_HIP(hipFuncSetAttribute((const void *)kern,
@@ -624,8 +631,10 @@ struct Runner {
     {
         Model<N> m;
         fill_model<N>(m, c->n, c->kind, c->M, A, pi, par0, par1);
-        if (c->kind == EMIT_DISC)
+        if (c->kind == EMIT_DISC) {
             m.dcopies = disc_copies<N>(c->M);
+            m.bt_global = c->bt_global ? 1 : 0;
+        }
         switch (c->kind) {
         case EMIT_GAUSS:
             return forward_kind<EMIT_GAUSS>(c, m);
@@ -805,7 +814,8 @@ static int alloc_work(bhmm_ctx *c)
         (rc = c->d_stats.ensure(stats_size(c))))
         return rc;
     if (c->kind == EMIT_DISC) {
-        if ((rc = c->d_dpartials.ensure((size_t)(c->Gp / 64) * c->M * N)) ||
+        const size_t ntab = c->bt_global ? (size_t)DISC_GLOBAL_TABLES : (size_t)(c->Gp / 64);
+        if ((rc = c->d_dpartials.ensure(ntab * c->M * N)) ||
             (rc = c->d_Bt.ensure((size_t)c->M * N)))
             return rc;
     }
@@ -1051,11 +1061,10 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     c->wide_replans = 0;
     c->wseg_given_up = false;
     c->wide_careful = false;
-    if (kind == BHMM_EMIT_DISCRETE) {
-        const size_t sm = smem_fwdbwd<8, EMIT_DISC>(c->M);
-        if (sm > 160 * 1024)
-            return invalid("discrete alphabet too large for the LDS-resident tables");
-    }
+    // discrete alphabets whose emission / count tables do not fit the LDS of the sweep kernels
+    // (M above ~1200 at 8 states) keep them in global memory instead (estep_sweep.hpp, BtSrc)
+    c->bt_global = kind == BHMM_EMIT_DISCRETE && !c->wide &&
+                   smem_fwdbwd<8, EMIT_DISC>(c->M) > (size_t)150 * 1024;
     int rc;
     if (c->wide) {
         // 9..64 states: trajectory-parallel kernels on trajectory-major data, no chunk plan

@@ -64,6 +64,7 @@ struct bhmm_ctx {
     int n = 0;    // real number of states
     int N = 0;    // padded (2, 4, 8)
     int M = 0;    // symbols
+    bool bt_global = false; // discrete alphabet too large for the LDS tables (global / L2 instead)
     int K = 0;    // trajectories
     int64_t total = 0;
     int L = 0, Lmax = 0, G = 0, Gp = 0;

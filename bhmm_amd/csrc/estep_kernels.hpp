@@ -50,7 +50,11 @@ struct Model {
     int nreal;
     int M; // number of symbols (discrete)
     int dcopies; // k_estep, discrete: LDS count tables per workgroup (one per wavefront, or 1)
+    int bt_global; // discrete, alphabet too large for the LDS: B^T is read from global memory
+                   // (L2-resident) and the emission counts go to DISC_GLOBAL_TABLES global tables
 };
+// big alphabets: number of replicated global count tables (workgroup b uses table b % this)
+constexpr int DISC_GLOBAL_TABLES = 8;
 
 // Chunk table (device pointers), one entry per lane of the launch; padded entries have
 // len == 0.
@@ -222,11 +226,15 @@ __global__ __launch_bounds__(64 * N) void k_prescan(const Model<N> m, const Chun
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *sA = smem;             // [N][N]
     double *sP = smem + N * N;     // [64 chunks][N] emission exchange
-    double *sBt = sP + 64 * N;     // [M][N] (discrete)
+    const double *sBt = sP + 64 * N; // [M][N] (discrete)
     for (int i = threadIdx.x; i < N * N; i += blockDim.x)
         sA[i] = m.A[i];
-    if constexpr (KIND == EMIT_DISC)
-        stage_Bt<N>(sBt, Bt_g, m.M);
+    if constexpr (KIND == EMIT_DISC) {
+        if (m.bt_global)
+            sBt = Bt_g;
+        else
+            stage_Bt<N>(sP + 64 * N, Bt_g, m.M);
+    }
     __syncthreads();
     const int cl = threadIdx.x / N; // chunk within the record group == CI lane
     const int r = threadIdx.x % N;
@@ -677,10 +685,14 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
     static_assert(MODE == MODE_FWD || MODE == MODE_BWD, "row passes only");
     constexpr int H = N / 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *Bt = smem; // [M][N]
+    const double *Bt = smem; // [M][N]
     if constexpr (KIND == EMIT_DISC) {
-        stage_Bt<N>(Bt, Bt_g, m.M);
-        __syncthreads();
+        if (m.bt_global) {
+            Bt = Bt_g;
+        } else {
+            stage_Bt<N>(smem, Bt_g, m.M);
+            __syncthreads();
+        }
     }
     const int cl = threadIdx.x / H; // chunk within the record group == CI lane
     const int q = threadIdx.x % H;  // my state pair
@@ -941,7 +953,8 @@ __device__ __forceinline__ void finalize_one(int e, const Model<N> &m, int K, in
     }
     e -= SL::S;
     if (e < MN) {
-        for (int b = lane; b < nblocks; b += 64)
+        const int ndisc = m.bt_global ? DISC_GLOBAL_TABLES : nblocks;
+        for (int b = lane; b < ndisc; b += 64)
             s += disc_partials[(int64_t)b * MN + e];
         s = wave_sum(s);
         const int sym = e / N, r = e % N;

@@ -130,8 +130,16 @@ struct ObsCursor {
 };
 
 // emission probabilities of my two states WITHOUT the outlier rule; d = o - mu (gaussian)
+// where the transposed emission matrix B^T [M][N] of the discrete model lives: staged in LDS, or
+// -- alphabets too large for that -- in global memory (two pointers, so that the LDS accesses
+// stay LDS instructions)
+struct BtSrc {
+    const double *lds;
+    const double *glb;
+    bool big;
+};
 template <int N, int KIND>
-__device__ __forceinline__ void emit_raw(const ObsIn &in, const double *Bt, int q,
+__device__ __forceinline__ void emit_raw(const ObsIn &in, const BtSrc &Bt, int q,
                                          const EmisPair &em, double (&p)[2], double (&d)[2])
 {
     if constexpr (KIND == EMIT_GAUSS) {
@@ -141,7 +149,9 @@ __device__ __forceinline__ void emit_raw(const ObsIn &in, const double *Bt, int 
             p[b] = em.cn[b] * exp_nonpos(d[b] * d[b] * em.nh[b]);
         }
     } else if constexpr (KIND == EMIT_DISC) {
-        const double2 x = *reinterpret_cast<const double2 *>(Bt + (int64_t)in.sym * N + 2 * q);
+        const int64_t e = (int64_t)in.sym * N + 2 * q;
+        const double2 x = Bt.big ? *reinterpret_cast<const double2 *>(Bt.glb + e)
+                                 : *reinterpret_cast<const double2 *>(Bt.lds + e);
         p[0] = x.x;
         p[1] = x.y;
         d[0] = d[1] = 0.0;
@@ -432,26 +442,35 @@ __device__ __forceinline__ void estep_body(
     const bool role_b = PHASE != PH_P1 || blockIdx.x >= gridDim.x / 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *red = smem;                                     // [NW][S]
-    double *Bt = smem + NW * SL::S;                         // [M][N]
     // discrete emission counts (_discrete.c:22-30) by LDS atomics: one table per wavefront where
     // LDS allows (m.dcopies == NW), so that the order of the additions -- hence the last bits of
-    // the result -- does not depend on how the wavefronts of a workgroup interleave
-    double *dstat0 = Bt + (KIND == EMIT_DISC ? m.M * N : 0); // [dcopies][M][N]
-    const int dcopies = KIND == EMIT_DISC ? m.dcopies : 0;
+    // the result -- does not depend on how the wavefronts of a workgroup interleave.
+    // Alphabets whose tables do not fit the LDS (m.bt_global): B^T is read from global memory
+    // (M N 8 bytes, L2-resident) and the counts are added with global fp64 atomics to one of
+    // DISC_GLOBAL_TABLES replicated tables in disc_partials (zeroed by the host; their sums are
+    // then no longer bit-reproducible from run to run).
+    const bool big = KIND == EMIT_DISC && m.bt_global;
+    const int Mlds = (KIND == EMIT_DISC && !big) ? m.M : 0;
+    const BtSrc Bt = {smem + NW * SL::S, Bt_g, big};        // [M][N]
+    double *dstat0 = smem + NW * SL::S + Mlds * N;          // [dcopies][M][N]
+    const int dcopies = (KIND == EMIT_DISC && !big) ? m.dcopies : 0;
     double *dstat = dstat0 + (dcopies > 1 ? (threadIdx.x >> 6) * (m.M * N) : 0);
+    double *dstat_g = disc_partials + (int64_t)(blockIdx.x % DISC_GLOBAL_TABLES) * (m.M * N);
     // the discrete kind keeps its LDS unit busy with the emission table and the count atomics:
     // its all-gather runs on DPP instead (measured: 13 % faster there, equal for the gaussian)
-    const Gather<N, ESTEP_LDS_GATHER && KIND != EMIT_DISC> gather(dstat0 + dcopies * m.M * N);
+    const Gather<N, ESTEP_LDS_GATHER && KIND != EMIT_DISC> gather(dstat0 + dcopies * Mlds * N);
     int hmin = 0x7fffffff;
 #ifdef ESTEP_CLOCKPROBE
     const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = wall_clock64();
     unsigned long long pr1 = pr0, pr2 = pr0, pr3 = pr0;
 #endif
     if constexpr (KIND == EMIT_DISC) {
-        stage_Bt<N>(Bt, Bt_g, m.M);
-        for (int i = threadIdx.x; i < dcopies * m.M * N; i += blockDim.x)
-            dstat0[i] = 0.0;
-        __syncthreads();
+        if (!big) {
+            stage_Bt<N>(smem + NW * SL::S, Bt_g, m.M);
+            for (int i = threadIdx.x; i < dcopies * m.M * N; i += blockDim.x)
+                dstat0[i] = 0.0;
+            __syncthreads();
+        }
     }
     const int cl = threadIdx.x / H; // chunk within the record group == CI lane
     const int q = threadIdx.x % H;  // my state pair
@@ -823,8 +842,12 @@ __device__ __forceinline__ void estep_body(
                     sd[b] += gd;
                     sdd[b] = fma(gd, d[b], sdd[b]);
                 }
-                if constexpr (KIND == EMIT_DISC) // _discrete.c:22-30
-                    atomicAdd(&dstat[in.sym * N + 2 * q + b], gam[b]);
+                if constexpr (KIND == EMIT_DISC) { // _discrete.c:22-30
+                    if (big)
+                        atomicAdd(&dstat_g[(int64_t)in.sym * N + 2 * q + b], gam[b]);
+                    else
+                        atomicAdd(&dstat[in.sym * N + 2 * q + b], gam[b]);
+                }
             }
             if constexpr (GAMMA)
                 if (gamma_ci)
@@ -1103,7 +1126,7 @@ __device__ __forceinline__ void estep_body(
             partials[(int64_t)blockIdx.x * SL::S + i] = v;
         }
         if constexpr (KIND == EMIT_DISC)
-            for (int i = threadIdx.x; i < m.M * N; i += blockDim.x)
+            for (int i = threadIdx.x; i < Mlds * N; i += blockDim.x)
             {
                 double v = dstat0[i];
                 for (int w = 1; w < dcopies; ++w)

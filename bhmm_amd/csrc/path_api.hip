@@ -84,12 +84,17 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     uint32_t *gw = nib + (size_t)W8 * c->Gp * P;
     const int64_t Gp64 = c->Gp;
     // scratch: counts | emission partials | reduced emission | u
-    const size_t dbl = nstat + (size_t)nblk * esz + esz + (u ? (size_t)c->total : 0) + 8;
+    // emission partials: one table per workgroup, or (big discrete alphabets) a few global ones
+    const bool bigM = c->kind == EMIT_DISC && c->bt_global;
+    const size_t ntab = bigM ? (size_t)DISC_GLOBAL_TABLES : (size_t)nblk;
+    const size_t dbl = nstat + ntab * esz + esz + (u ? (size_t)c->total : 0) + 8;
     if ((rc = c->d_scratch.ensure(dbl * sizeof(double))))
         return rc;
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(c->d_scratch.p);
     double *epart = reinterpret_cast<double *>(c->d_scratch.p) + nstat;
-    double *ered = epart + (size_t)nblk * esz;
+    double *ered = epart + ntab * esz;
+    if (bigM)
+        BHMM_HIP(hipMemsetAsync(epart, 0, ntab * esz * sizeof(double), c->stream));
     double *udev = nullptr;
     if (u) {
         udev = ered + esz;
@@ -102,6 +107,7 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipMemsetAsync(ered, 0, esz * sizeof(double), c->stream));
     Model<N> m;
     fill_model_pub<N>(m, n, c->kind, c->M, A, pi, par0, par1);
+    m.bt_global = bigM ? 1 : 0;
     {
         // exact chunk-parallel sampling: maps per part, stitch, apply + statistics
         const Chunks chs = chunks_pub(c);
@@ -133,17 +139,21 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         if (c->kind == EMIT_GAUSS)
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
                                chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
-        else if (c->kind == EMIT_DISC)
-            hipLaunchKernelGGL((k_smp_apply<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK),
-                               (size_t)c->M * N * sizeof(double), c->stream, m, chs, offd, obs_ci, P, ns,
-                               path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
+        else if (c->kind == EMIT_DISC) {
+            const size_t smd = bigM ? 0 : (size_t)c->M * N * sizeof(double);
+            if (smd > 64 * 1024)
+                BHMM_HIP(hipFuncSetAttribute((const void *)(k_smp_apply<N, EMIT_DISC>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smd));
+            hipLaunchKernelGGL((k_smp_apply<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK), smd, c->stream, m,
+                               chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
+        }
         else
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
                                chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
         BHMM_HIP(hipGetLastError());
         if (esz) {
             hipLaunchKernelGGL(k_add_partials, dim3((unsigned)esz), dim3(64), 0,
-                               c->stream, (const double *)epart, nblk, (int)esz, ered);
+                               c->stream, (const double *)epart, (int)ntab, (int)esz, ered);
             BHMM_HIP(hipGetLastError());
         }
     }

@@ -521,11 +521,17 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
     extern __shared__ __attribute__((aligned(16))) double lds[]; // discrete: [M][N] counts
     __shared__ unsigned int cnt[N * N + N];
     __shared__ double red[4][3 * N];
+    // alphabets too large for an LDS table (m.bt_global): the symbol counts go to one of
+    // DISC_GLOBAL_TABLES global tables in epartials (zeroed by the host) -- integer-valued, so
+    // the sums stay exact and order-independent
+    const bool big = KIND == EMIT_DISC && m.bt_global;
+    double *gtab = epartials + (int64_t)(blockIdx.x % DISC_GLOBAL_TABLES) * (m.M * N);
     for (int e = threadIdx.x; e < N * N + N; e += blockDim.x)
         cnt[e] = 0u;
     if constexpr (KIND == EMIT_DISC)
-        for (int e = threadIdx.x; e < m.M * N; e += blockDim.x)
-            lds[e] = 0.0;
+        if (!big)
+            for (int e = threadIdx.x; e < m.M * N; e += blockDim.x)
+                lds[e] = 0.0;
     __syncthreads();
     const int part = blockIdx.x % P;
     const int64_t g = (int64_t)(blockIdx.x / P) * 256 + threadIdx.x;
@@ -606,7 +612,10 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
             }
             if constexpr (KIND == EMIT_DISC) {
                 const int sym = y_cur;
-                atomicAdd(&lds[sym * N + st], 1.0); // integer-valued: exact, order-independent
+                if (big)
+                    atomicAdd(&gtab[(int64_t)sym * N + st], 1.0);
+                else
+                    atomicAdd(&lds[sym * N + st], 1.0); // integer-valued: exact, order-independent
             }
             nxt = st;
         }
@@ -633,8 +642,9 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
                 ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
     }
     if constexpr (KIND == EMIT_DISC)
-        for (int e = threadIdx.x; e < m.M * N; e += blockDim.x)
-            epartials[(int64_t)blockIdx.x * m.M * N + e] = lds[e];
+        if (!big)
+            for (int e = threadIdx.x; e < m.M * N; e += blockDim.x)
+                epartials[(int64_t)blockIdx.x * m.M * N + e] = lds[e];
 }
 
 // ---- small reference-shaped kernels on row-major arrays ------------------------------------

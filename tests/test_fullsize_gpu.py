@@ -345,3 +345,51 @@ def test_estimate_hmm_with_lag_uses_device_views():
     assert len(h1.hidden_state_trajectories) == len(lagged) == 16
     assert all(np.array_equal(p, q) for p, q in zip(h1.hidden_state_trajectories,
                                                     h2.hidden_state_trajectories))
+
+
+# ---- discrete alphabets beyond the LDS --------------------------------------------------------
+@pytest.mark.parametrize("n,M", [(8, 5000), (3, 40000)])
+def test_large_discrete_alphabet(n, M):
+    """bhmm/output_models/discrete.py:130-157 has no limit on the number of symbols (discrete HMMs
+    on thousands of microstates are the usual case).  Beyond the LDS capacity (M above ~1200 at
+    8 states) the emission table and the count tables live in global memory: E-step (incl. the
+    weighted symbol counts of _discrete.c:1-32), Viterbi and the Gibbs step against the oracle."""
+    rng = np.random.default_rng(M)
+    A = rng.random((n, n)) + 3 * np.eye(n)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    B = rng.dirichlet(np.full(M, 0.05), size=n) + 1e-9          # sparse-ish rows, no exact zeros
+    B /= B.sum(axis=1, keepdims=True)
+    obs = [rng.integers(0, M, T).astype(np.int32) for T in (20000, 3001, 1, 777)]
+    ref = orc.estep("discrete", obs, A, pi, B, want_gamma=True)
+    for chunk in (0, 100):
+        eng = _engine()
+        eng.set_observations("discrete", obs, n, nsymbols=M, chunk=chunk)
+        res = eng.estep(A, pi, B)
+        np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-9)
+        np.testing.assert_allclose(res.C, ref["C"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-9)
+        cnt = np.zeros((n, M))
+        for o, g in zip(obs, ref["gammas"]):
+            orc.update_pout(o, g, cnt)
+        np.testing.assert_allclose(res.symbol_counts, cnt, rtol=1e-9, atol=1e-12)
+        # gamma export and a second E-step (the global tables are cleared every time)
+        res2 = eng.estep(A, pi, B, store_gamma=True)
+        np.testing.assert_allclose(res2.symbol_counts, cnt, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(eng.gamma(1), ref["gammas"][1], rtol=1e-8, atol=1e-13)
+        # Viterbi, bit-exact
+        pobs = [orc.pobs_discrete(o, B) for o in obs]
+        for p, pb in zip(eng.viterbi(A, pi, B), pobs):
+            assert np.array_equal(p, orc.viterbi(A, pb, pi))
+        # Gibbs step: paths given the uniforms, integer statistics
+        u = [rng.random(len(o)) for o in obs]
+        sp, C, n0, emis = eng.sample_paths(A, pi, B, u=u)
+        refp = [orc.sample_path(orc.forward(A, pb, pi)[1], A, u=uu) for pb, uu in zip(pobs, u)]
+        assert all(np.array_equal(a, b) for a, b in zip(sp, refp))
+        Cr, n0r = orc.path_counts(refp, n)
+        assert np.array_equal(C, Cr) and np.array_equal(n0, n0r)
+        er = np.zeros((n, M))
+        for p, o in zip(refp, obs):
+            np.add.at(er, (p, o), 1.0)
+        assert np.array_equal(emis, er)
+        eng.close()
