@@ -412,7 +412,7 @@ __device__ __forceinline__ void beta_step(const G &gather, const ObsIn &in, int 
 #endif
 enum { PH_ALL = 0, PH_FWDROWS = 1, PH_P1 = 2, PH_P2 = 3 };
 
-template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE>
+template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE, bool BIGM = false>
 __device__ __forceinline__ void estep_body(
     const Model<N> m, const Chunks ch, const void *obs_ci, const void *obs_rm,
     const int64_t *toff,   // [K+1] trajectory offsets (time steps)
@@ -449,7 +449,7 @@ __device__ __forceinline__ void estep_body(
     // (M N 8 bytes, L2-resident) and the counts are added with global fp64 atomics to one of
     // DISC_GLOBAL_TABLES replicated tables in disc_partials (zeroed by the host; their sums are
     // then no longer bit-reproducible from run to run).
-    const bool big = KIND == EMIT_DISC && m.bt_global;
+    constexpr bool big = KIND == EMIT_DISC && BIGM; // (compile-time: the LDS path pays nothing)
     const int Mlds = (KIND == EMIT_DISC && !big) ? m.M : 0;
     const BtSrc Bt = {smem + NW * SL::S, Bt_g, big};        // [M][N]
     double *dstat0 = smem + NW * SL::S + Mlds * N;          // [dcopies][M][N]
@@ -1151,6 +1151,12 @@ __global__ __launch_bounds__(32 * N)
     __attribute__((amdgpu_waves_per_eu(ESTEP_WAVES, ESTEP_WAVES))) void k_estep(ESTEP_ARGS)
 {
     static_assert(PHASE == PH_ALL || PHASE == PH_P2, "use k_estep_light");
+    if constexpr (KIND == EMIT_DISC) {
+        if (m.bt_global) { // alphabet beyond the LDS: tables in global memory (uniform branch)
+            estep_body<N, KIND, SPEC, GAMMA, CAREFUL, PHASE, true>(ESTEP_PASS);
+            return;
+        }
+    }
     estep_body<N, KIND, SPEC, GAMMA, CAREFUL, PHASE>(ESTEP_PASS);
 }
 
@@ -1160,6 +1166,12 @@ __global__ __launch_bounds__(32 * N) __attribute__((amdgpu_waves_per_eu(4))) voi
     ESTEP_ARGS)
 {
     static_assert(PHASE == PH_P1 || PHASE == PH_FWDROWS, "use k_estep");
+    if constexpr (KIND == EMIT_DISC) {
+        if (m.bt_global) {
+            estep_body<N, KIND, SPEC, GAMMA, CAREFUL, PHASE, true>(ESTEP_PASS);
+            return;
+        }
+    }
     estep_body<N, KIND, SPEC, GAMMA, CAREFUL, PHASE>(ESTEP_PASS);
 }
 #undef ESTEP_ARGS

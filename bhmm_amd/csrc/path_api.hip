@@ -63,7 +63,10 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     const size_t nstat = (size_t)N * N + N;
     // parts per chunk for the map kernels (BHMM_AMD_SMP_PARTS overrides: kernel experiments)
     static const int parts_env = getenv("BHMM_AMD_SMP_PARTS") ? atoi(getenv("BHMM_AMD_SMP_PARTS")) : 0;
-    const int P = parts_env > 0 ? parts_env : (c->Lmax >= 256 ? 4 : 1);
+    // (k_smp_maps keeps within 128 VGPRs, i.e. four wavefronts per SIMD: 8 parts per chunk fill
+    // them on the default plan of 32768 chunks; measured on configs[4]: P = 4 0.56, 8 0.48, 16 0.52 ms
+    // for maps + stitch + apply)
+    const int P = parts_env > 0 ? parts_env : (c->Lmax >= 512 ? 8 : (c->Lmax >= 256 ? 4 : 1));
     const int nblk = (c->Gp / BLOCK) * P;
     const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)N : (c->kind == EMIT_DISC ? (size_t)c->M * N : 0);
     // scratch2: [path] | status | part maps | next-part states | lowest non-final step per part |
@@ -244,12 +247,36 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         if (hipMemGetInfo(&freeb, &totb) == hipSuccess && need + ((size_t)1 << 30) < freeb + c->d_alpha_rm.n * sizeof(double) &&
             c->d_alpha_rm.ensure((size_t)c->total * n) == BHMM_OK) {
             const dim3 pg((unsigned)((c->total + 255) / 256)), pb(256);
-            if (c->kind == EMIT_GAUSS)
+            const dim3 pl((unsigned)(((size_t)c->total * n + 255) / 256));
+#define BHMM_POBS_LANES(NLV)                                                                        \
+    do {                                                                                            \
+        if (c->kind == EMIT_GAUSS)                                                                  \
+            hipLaunchKernelGGL((k_pobs_lanes<EMIT_GAUSS, NLV>), pl, pb, 0, c->stream, m, obs,       \
+                               c->total, c->d_alpha_rm.p);                                          \
+        else                                                                                        \
+            hipLaunchKernelGGL((k_pobs_lanes<EMIT_DISC, NLV>), pl, pb, 0, c->stream, m, obs,        \
+                               c->total, c->d_alpha_rm.p);                                          \
+    } while (0)
+            // one thread per element where n is a power of two (coalesced stores), else per step
+            if (n == 2)
+                BHMM_POBS_LANES(2);
+            else if (n == 4)
+                BHMM_POBS_LANES(4);
+            else if (n == 8)
+                BHMM_POBS_LANES(8);
+            else if (n == 16)
+                BHMM_POBS_LANES(16);
+            else if (n == 32)
+                BHMM_POBS_LANES(32);
+            else if (n == 64)
+                BHMM_POBS_LANES(64);
+            else if (c->kind == EMIT_GAUSS)
                 hipLaunchKernelGGL((k_pobs_all<EMIT_GAUSS>), pg, pb, 0, c->stream, m, obs, c->total,
                                    c->d_alpha_rm.p);
             else
                 hipLaunchKernelGGL((k_pobs_all<EMIT_DISC>), pg, pb, 0, c->stream, m, obs, c->total,
                                    c->d_alpha_rm.p);
+#undef BHMM_POBS_LANES
             BHMM_HIP(hipGetLastError());
             obs = c->d_alpha_rm.p;
             vkind = EMIT_EXPL;

@@ -299,7 +299,7 @@ __device__ __forceinline__ int pick_clear(const double (&a)[N], const double *co
 // failed speculation wrote them) and is used directly.
 constexpr double SMP_TOL32 = 1e-6;
 template <int N, int KIND>
-__global__ __launch_bounds__(256, 2) void k_smp_maps(const Model<N> m, const Chunks ch,
+__global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chunks ch,
                                                      const int64_t *off, const int64_t *soff,
                                                      const double *alpha_ci, const float *rows32,
                                                      const void *obs_ci, const double *Bt_g,
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void k_smp_maps(const Model<N> m, const Chu
     // The walk is a dependent chain (the column of A a step needs is known only after the previous
     // draw) and its alpha rows come straight from HBM: they are requested SMP_MPF steps ahead.
     uint32_t alive_set = (1u << n) - 1u; // the part may be entered with any real state
-    constexpr int SMP_MPF = 4;
+    constexpr int SMP_MPF = 1;
     constexpr int NF = N / 2; // float2 per fp32 row
     const int nst = s_hi - s_lo;
     float2 ring[SMP_MPF][NF];
@@ -1245,6 +1245,36 @@ __global__ void k_pobs_all(const WideModel m, const void *obs_rm, int64_t total,
         const int sym = static_cast<const int32_t *>(obs_rm)[t];
         for (int j = 0; j < n; ++j)
             pobs[t * n + j] = m.B[(int64_t)j * m.M + sym];
+    }
+}
+
+// The same rows with one thread per ELEMENT (step, state): consecutive lanes write consecutive
+// doubles, so every store instruction of a wavefront is one contiguous 512-byte segment (the
+// thread-per-step form above writes 64 lines of which it fills an eighth each, and runs at a
+// quarter of the write rate).  NL = n must be a power of two: the outlier rule (all n
+// probabilities zero, outputmodel.py:126-130) is a ballot over the aligned group of n lanes.
+template <int KIND, int NL>
+__global__ __launch_bounds__(256) void k_pobs_lanes(const WideModel m, const void *obs_rm,
+                                                    int64_t total, double *pobs)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total * NL)
+        return;
+    const int64_t t = e / NL;
+    const int j = (int)(e % NL);
+    if constexpr (KIND == EMIT_GAUSS) {
+        const double o = static_cast<const double *>(obs_rm)[t];
+        const double d = (o - m.mu[j]) / m.sigma[j];
+        double p = m.cnorm[j] * exp(-0.5 * d * d);
+        const unsigned long long nzm = __ballot(p != 0.0);
+        const int lane = threadIdx.x & 63;
+        const unsigned long long grp = (NL == 64 ? ~0ull : ((1ull << NL) - 1)) << (lane / NL * NL);
+        if ((nzm & grp) == 0ull)
+            p = 1.0;
+        pobs[e] = p;
+    } else {
+        const int sym = static_cast<const int32_t *>(obs_rm)[t];
+        pobs[e] = m.B[(int64_t)j * m.M + sym];
     }
 }
 

@@ -1,5 +1,5 @@
-for P in 2 4 8; do
+for P in 4 8 16; do
   export BHMM_AMD_SMP_PARTS=$P
-  bash tools/ktrace.sh tools/c5_once.py > gpurun_out/r02h_parts$P.txt 2>&1
-  echo "P=$P"; grep -E "k_smp|k_estep_light" gpurun_out/r02h_parts$P.txt
+  bash tools/ktrace.sh tools/c5_once.py > gpurun_out/r02n_parts$P.txt 2>&1
+  echo "P=$P"; grep -E "k_smp|k_estep_light" gpurun_out/r02n_parts$P.txt
 done
