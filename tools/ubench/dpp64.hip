@@ -51,24 +51,29 @@ int main()
             printf(" %g", h[r * 64 + l]);
         printf("\n");
     }
+    // issue rate per SIMD with 1, 2 and 4 wavefronts per SIMD (1024 SIMDs): is one wavefront's
+    // stream of (DPP) fp64 FMAs enough to keep the VALU busy?
     for (int mode = 0; mode < 2; ++mode) {
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0);
-        hipEventCreate(&e1);
-        const int iters = 20000, blocks = 1024; // one wave per SIMD
-        for (int rep = 0; rep < 2; ++rep) {
-            hipEventRecord(e0);
-            if (mode == 0)
-                hipLaunchKernelGGL(k_rate<0>, dim3(blocks), dim3(64), 0, 0, d, iters);
-            else
-                hipLaunchKernelGGL(k_rate<1>, dim3(blocks), dim3(64), 0, 0, d, iters);
-            hipEventRecord(e1);
-            hipEventSynchronize(e1);
+        for (int wps = 1; wps <= 4; wps *= 2) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            const int iters = 20000, blocks = 1024 * wps;
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                if (mode == 0)
+                    hipLaunchKernelGGL(k_rate<0>, dim3(blocks), dim3(64), 0, 0, d, iters);
+                else
+                    hipLaunchKernelGGL(k_rate<1>, dim3(blocks), dim3(64), 0, 0, d, iters);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+            }
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("%s, %d wave(s) per SIMD: %.1f instr/us/SIMD\n",
+                   mode ? "v_fmac_f64_dpp row_newbcast" : "v_fmac_f64", wps,
+                   16.0 * iters * wps / (ms * 1e3));
         }
-        float ms;
-        hipEventElapsedTime(&ms, e0, e1);
-        printf("%s: %.1f instr/us/wave (1 wave per SIMD)\n", mode ? "v_fmac_f64_dpp row_newbcast" : "v_fmac_f64",
-               16.0 * iters / (ms * 1e3));
     }
     return 0;
 }
