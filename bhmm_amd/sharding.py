@@ -6,6 +6,8 @@ maximum_likelihood.py:271-282.  On GPUs the all-reduce runs over RCCL/xGMI on th
 buffer the E-step wrote (torch.distributed backend "nccl"); the message is ~1 KB-35 KB, i.e.
 latency-bound, so it is a single un-bucketed call.
 """
+import os
+
 import numpy as np
 
 
@@ -50,7 +52,10 @@ class Comm(object):
 
     @property
     def active(self):
-        return self.world > 1
+        """Several ranks -- or one rank with BHMM_AMD_FORCE_COMM=1, which sends a single process
+        through the same collectives (how the RCCL code path is exercised on a one-GPU box)."""
+        return self.world > 1 or (self.dist is not None and
+                                  os.environ.get("BHMM_AMD_FORCE_COMM") == "1")
 
     def bind_device(self, device):
         self.device = None if device is None else int(device)

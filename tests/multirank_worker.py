@@ -1,6 +1,6 @@
 """One rank of the multi-process GPU test (tests/test_multirank_gpu.py) -- run as a child process:
 
-    python tests/multirank_worker.py RANK WORLD PORT OUTDIR
+    python tests/multirank_worker.py RANK WORLD PORT OUTDIR [BACKEND]
 
 WORLD ranks over gloo, ALL on GPU 0 (the test box has one GPU; RCCL refuses two ranks on one
 device, so the collective runs over gloo on the host copy of the device statistics buffer --
@@ -35,12 +35,20 @@ def problem():
 
 def main():
     rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
     import bhmm_amd
-    if world > 1:
+    tag = "w%d" % world
+    if world > 1 or backend == "nccl":
+        # BACKEND nccl with WORLD 1: one rank, but through the RCCL collectives
+        # (BHMM_AMD_FORCE_COMM=1): all-reduce / broadcast on the engine's device buffers
         import torch.distributed as dist
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = port
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":
+            os.environ["BHMM_AMD_FORCE_COMM"] = "1"
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            tag = "rccl%d" % world
+        dist.init_process_group(backend, rank=rank, world_size=world)
     obs, n = problem()
     init = bhmm_amd.gaussian_hmm(np.full(n, 1.0 / n), np.full((n, n), 0.1) + 0.7 * np.eye(n),
                                  np.array([-1.0, 0.0, 2.0]), np.ones(n))
@@ -53,7 +61,7 @@ def main():
     np.random.seed(7 if rank == 0 else 500 + rank)
     sampler = bhmm_amd.BayesianHMMSampler(obs, n, initial_model=hmm, reversible=False, device=0)
     chain = sampler.sample(3, save_hidden_state_trajectory=True, seed=3)
-    np.savez(os.path.join(outdir, "w%d_r%d.npz" % (world, rank)),
+    np.savez(os.path.join(outdir, "%s_r%d.npz" % (tag, rank)),
              L=est.likelihoods, A=hmm.transition_matrix, pi=hmm.initial_distribution,
              mu=hmm.output_model.means, sig=hmm.output_model.sigmas, C=est.count_matrix,
              nlocal=len(est.local_trajectories),
@@ -62,8 +70,9 @@ def main():
              chain_mu=np.array([m.output_model.means for m in chain]),
              chain_sig=np.array([m.output_model.sigmas for m in chain]),
              chain_paths=np.concatenate(chain[-1].hidden_state_trajectories))
-    if world > 1:
+    if world > 1 or backend == "nccl":
         import torch.distributed as dist
+        assert est._comm.active and est._comm.backend == backend
         dist.destroy_process_group()
     print("rank %d/%d done" % (rank, world))
 

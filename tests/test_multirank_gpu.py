@@ -57,6 +57,26 @@ def test_two_ranks_on_the_gpu_equal_one_process(launcher):
 
 
 @pytest.mark.gpu
+def test_rccl_collectives_one_rank(launcher):
+    """The RCCL code path of the estimators (device statistics buffer -> dist.all_reduce on the
+    engine's GPU -> one copy; rank-0 parameter broadcast) with the one rank a one-GPU box allows:
+    backend "nccl", world size 1, collectives forced on.  Same results as without a process group."""
+    with tempfile.TemporaryDirectory() as d:
+        r = launcher.run([[sys.executable, WORKER, "0", "1", "0", d],
+                          [sys.executable, WORKER, "0", "1", str(_free_port()), d, "nccl"]], timeout=600)
+        for x in r:
+            assert x["rc"] == 0, x["out"]
+        ref = np.load(os.path.join(d, "w1_r0.npz"))
+        got = np.load(os.path.join(d, "rccl1_r0.npz"))
+    np.testing.assert_array_equal(got["L"], ref["L"])
+    np.testing.assert_array_equal(got["A"], ref["A"])
+    assert np.array_equal(got["v"], ref["v"])
+    np.testing.assert_array_equal(got["chain_A"], ref["chain_A"])
+    np.testing.assert_array_equal(got["chain_mu"], ref["chain_mu"])
+    assert np.array_equal(got["chain_paths"], ref["chain_paths"])
+
+
+@pytest.mark.gpu
 def test_bench_starts_its_own_ranks(launcher):
     """`python bench.py --gpus 2` without a launcher environment starts two ranks itself and
     reports n_gpus = 2 (here both ranks share the box's one GPU: --oversubscribe, gloo)."""
