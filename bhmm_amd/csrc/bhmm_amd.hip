@@ -273,15 +273,23 @@ struct Runner {
         if (rc)
             return rc;
         const int nfin = StatLayout<N, KIND>::S + (KIND == EMIT_DISC ? c->M * N : 0) + N + 1;
-        hipLaunchKernelGGL((k_tail<N, KIND>), dim3(nfin + c->K + (c->G + 63) / 64), dim3(64), 0,
+        const int nTB = (c->K + TAIL_TPB - 1) / TAIL_TPB;
+        if ((rc = c->d_tbpart.ensure((size_t)nTB * (1 + N))))
+            return rc;
+        hipLaunchKernelGGL((k_tail<N, KIND>), dim3(nfin + nTB + (c->G + 63) / 64), dim3(64), 0,
                            c->stream, m, chunks_of(c), c->K, c->G, c->Gp / 64, nfin,
                            (const int32_t *)c->d_traj_c0.p, (const double *)c->d_partials.p,
                            (const double *)c->d_dpartials.p, (const double *)c->d_logLc.p,
                            (const double *)c->d_gamma0.p, (const double *)c->d_aentry.p,
                            (const double *)c->d_aexit.p, (const double *)c->d_bexit.p,
                            (const double *)c->d_bentry.p, SPEC_TOL, stats_dev, c->d_logLk.p,
-                           c->d_tail.p + 4, S, words, words_next);
+                           c->d_tail.p + 4, S, words, words_next, c->d_tbpart.p, nTB <= 64);
         BHMM_HIP(hipGetLastError());
+        if (nTB > 64) { // (a fence + ticket per trajectory block costs more than this launch)
+            hipLaunchKernelGGL((k_tail_total<N>), dim3(1), dim3(64), 0, c->stream, c->n, nTB,
+                               (const double *)c->d_tbpart.p, stats_dev, c->d_tail.p + 4);
+            BHMM_HIP(hipGetLastError());
+        }
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
         c->ev_lean = true;
         BHMM_HIP(hipMemcpyAsync(c->h_raw, c->d_tail.p, ntail * sizeof(double), hipMemcpyDeviceToHost,
@@ -1010,6 +1018,7 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     if (c->h_raw)
         (void)hipHostFree(c->h_raw);
     c->d_tail.release();
+    c->d_tbpart.release();
     c->d_ea.release();
     c->d_probe.release();
     for (auto &ev : c->ev)
@@ -1369,6 +1378,8 @@ int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
         memcpy(stats, c->h_pinned, S * sizeof(double));
     if (logL_k)
         memcpy(logL_k, c->h_pinned + S, c->K * sizeof(double));
+    // a non-finite trajectory makes the total non-finite: look for it only then (K can be 1e6)
+    if (!std::isfinite(c->h_pinned[0]))
     for (int k = 0; k < c->K; ++k)
         if (!std::isfinite(c->h_pinned[S + k])) {
             g_err = "log-likelihood of trajectory " + std::to_string(k) + " is not finite";

@@ -105,6 +105,7 @@ struct bhmm_ctx {
     bhmm::DevBuf<unsigned int> d_specres;
     bhmm::DevBuf<int32_t> d_ea;       // exponents of the stored alpha rows (k_estep PH_P1 -> PH_P2)
     bhmm::DevBuf<double> d_tail;      // same layout as h_raw, written by k_tail (one D2H copy)
+    bhmm::DevBuf<double> d_tbpart;    // k_tail: per trajectory block [sum logL | sum gamma_0 (N)]
     int tail_slot = 0;                // verdict word set of the next E-step
     unsigned int viterbi_close = 0;   // ... number of lanes that met a close decision
     bool viterbi_chunked = false;     // last bhmm_viterbi_batch ran chunk-parallel (verified)

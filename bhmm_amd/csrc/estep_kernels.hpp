@@ -964,6 +964,8 @@ __device__ __forceinline__ void finalize_one(int e, const Model<N> &m, int K, in
     }
     e -= MN;
     if (e < N) {
+        if (!logL_k)
+            return; // fused tail: summed over trajectory blocks there (k_tail), not by one wavefront
         for (int k = lane; k < K; k += 64)
             s += gamma0[(int64_t)k * N + e];
         s = wave_sum(s);
@@ -992,10 +994,62 @@ __global__ __launch_bounds__(64) void k_finalize(const Model<N> m, int K, int nb
 }
 
 // k_tail: everything after the sweep of a speculative E-step in one launch of 64-thread
-// workgroups -- [0, nfin) finalisation entries, [nfin, nfin + K) per-trajectory log-likelihoods,
-// then one thread per chunk boundary of the check.  The workgroups are independent of each other.
+// workgroups -- [0, nfin) finalisation entries, [nfin, nfin + nTB) trajectory blocks, then one
+// thread per chunk boundary of the check.  The workgroups are independent of each other.
+// A trajectory block owns TAIL_TPB consecutive trajectories: their log-likelihoods (the sum of
+// each one's chunk logs, same summation tree whatever the number of trajectories), and the block's
+// partial sums of logL and of gamma_0.  The block that finishes last adds the partials up in block
+// order (word 3 of the verdict set counts finished blocks; it is cleared with the set) -- so the
+// tail costs K / 64 short workgroups and two sums of K / 64 terms, not K workgroups and sums of K
+// terms by one wavefront (1e6 short trajectories: 40 ms -> < 1 ms).
 // flags_next: the verdict words of the NEXT E-step (the two sets alternate), cleared here so
 // that no memset sits between E-steps.
+constexpr int TAIL_TPB = 64;
+// sum of the trajectory blocks' partials -> stats[0] (total log-likelihood) and stats[1..n]
+// (sum_k gamma_k[0]); one wavefront: every lane takes whole records (1 + N independent loads in
+// flight per record), then one wave sum per entry -- fixed order, no chain of load latencies
+template <int N>
+__device__ __forceinline__ void tail_total(int n, int nTB, const double *tb_part, double *stats,
+                                           double *mirror)
+{
+    const int lane = threadIdx.x;
+    double acc[1 + N];
+#pragma unroll
+    for (int e = 0; e <= N; ++e)
+        acc[e] = 0.0;
+    for (int t = lane; t < nTB; t += 64) {
+        double v[1 + N];
+#pragma unroll
+        for (int e = 0; e <= N; ++e)
+            v[e] = __hip_atomic_load(tb_part + (int64_t)t * (1 + N) + e, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int e = 0; e <= N; ++e)
+            acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e <= N; ++e) {
+        const double sacc = wave_sum(acc[e]);
+        if (lane == 0) {
+            if (e == 0) {
+                stats[0] = sacc;
+                mirror[0] = sacc;
+            } else if (e - 1 < n) {
+                stats[1 + (e - 1)] = sacc; // packed offset of sum_k gamma_k[0]
+                mirror[1 + (e - 1)] = sacc;
+            }
+        }
+    }
+}
+// the same as its own (one-wavefront) launch, for batches with many trajectory blocks: a kernel
+// boundary orders it behind k_tail without a fence and a ticket per block
+template <int N>
+__global__ __launch_bounds__(64) void k_tail_total(int n, int nTB, const double *tb_part,
+                                                   double *stats, double *mirror)
+{
+    tail_total<N>(n, nTB, tb_part, stats, mirror);
+}
+
 template <int N, int KIND>
 __global__ __launch_bounds__(64) void k_tail(const Model<N> m, const Chunks ch, int K, int G,
                                              int nblocks, int nfin, const int32_t *traj_c0,
@@ -1005,36 +1059,70 @@ __global__ __launch_bounds__(64) void k_tail(const Model<N> m, const Chunks ch, 
                                              const double *beta_exit, const double *b_entry,
                                              double tol, double *stats, double *logL_k,
                                              double *mirror, // [S stats | K logL_k], contiguous
-                                             int S, unsigned int *flags, unsigned int *flags_next)
+                                             int S, unsigned int *flags, unsigned int *flags_next,
+                                             double *tb_part, // [nTB][1 + N] block partials
+                                             bool fused_total)
 {
     const int b = blockIdx.x;
+    const int nTB = (K + TAIL_TPB - 1) / TAIL_TPB;
+    const int lane = threadIdx.x;
     if (b < nfin) {
         finalize_one<N, KIND>(b, m, K, nblocks, partials, disc_partials, nullptr, logL_chunk, G,
                               gamma0, stats, mirror);
         if (b == 0 && threadIdx.x < 4)
             flags_next[threadIdx.x] = 0u;
-    } else if (b < nfin + K) {
-        logl_one(b - nfin, traj_c0, logL_chunk, logL_k, mirror + S);
-        // the workgroup that finishes last adds up all trajectories in index order (word 3 of
-        // the verdict set counts finished workgroups; it is cleared with the set)
-        __threadfence();
-        unsigned int ticket = 0;
-        if (threadIdx.x == 0)
-            ticket = atomicAdd(&flags[3], 1u);
-        ticket = __shfl(ticket, 0, 64);
-        if (ticket == (unsigned int)(K - 1)) {
-            __threadfence();
-            double s = 0.0;
-            for (int k = threadIdx.x; k < K; k += 64)
-                s += __hip_atomic_load(logL_k + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s = wave_sum(s);
-            if (threadIdx.x == 0) {
-                stats[0] = s;
-                mirror[0] = s;
+    } else if (b < nfin + nTB) {
+        const int tb = b - nfin;
+        const int k0 = tb * TAIL_TPB;
+        const int kn = K - k0 < TAIL_TPB ? K - k0 : TAIL_TPB;
+        // chunk ranges of my trajectories: lane j holds the first chunk of trajectory k0 + j
+        const int c_lo = traj_c0[k0 + (lane < kn ? lane : kn)];
+        const int c_hi = __shfl_down(c_lo, 1, 64);
+        const int c_end = traj_c0[k0 + kn];
+        const int my_hi = lane == kn - 1 ? c_end : c_hi;
+        const bool single = __all(lane >= kn || my_hi - c_lo <= 1);
+        double mine = 0.0; // log-likelihood of trajectory k0 + lane
+        if (single) {
+            if (lane < kn && my_hi > c_lo)
+                mine = logL_chunk[c_lo];
+        } else {
+            for (int j = 0; j < kn; ++j) {
+                const int a0 = __shfl(c_lo, j, 64), a1 = j == kn - 1 ? c_end : __shfl(c_lo, j + 1, 64);
+                double sacc = 0.0;
+                for (int c = a0 + lane; c < a1; c += 64)
+                    sacc += logL_chunk[c];
+                sacc = wave_sum(sacc);
+                if (lane == j)
+                    mine = sacc;
             }
         }
+        if (lane < kn) {
+            logL_k[k0 + lane] = mine;
+            mirror[S + k0 + lane] = mine;
+        }
+        const double bsum = wave_sum(lane < kn ? mine : 0.0);
+        double *mypart = tb_part + (int64_t)tb * (1 + N);
+        if (lane == 0)
+            mypart[0] = bsum;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const double g = wave_sum(lane < kn ? gamma0[(int64_t)(k0 + lane) * N + e] : 0.0);
+            if (lane == 0)
+                mypart[1 + e] = g;
+        }
+        if (!fused_total)
+            return; // many trajectory blocks: k_tail_total adds the partials up after this launch
+        __threadfence();
+        unsigned int ticket = 0;
+        if (lane == 0)
+            ticket = atomicAdd(&flags[3], 1u);
+        ticket = __shfl(ticket, 0, 64);
+        if (ticket == (unsigned int)(nTB - 1)) {
+            __threadfence();
+            tail_total<N>(m.nreal, nTB, tb_part, stats, mirror);
+        }
     } else {
-        spec_check_one<N>(ch, G, (int64_t)(b - nfin - K) * 64 + threadIdx.x, alpha_entry, a_exit,
+        spec_check_one<N>(ch, G, (int64_t)(b - nfin - nTB) * 64 + threadIdx.x, alpha_entry, a_exit,
                           beta_exit, b_entry, tol, flags);
     }
 }

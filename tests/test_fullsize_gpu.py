@@ -393,3 +393,34 @@ def test_large_discrete_alphabet(n, M):
             np.add.at(er, (p, o), 1.0)
         assert np.array_equal(emis, er)
         eng.close()
+
+
+def test_many_short_trajectories():
+    """5000 ragged trajectories of 1..40 steps (the other extreme of the BASELINE shapes: many
+    independent short trajectories): per-trajectory log-likelihoods, transition counts, gamma_0 sums
+    against the oracle.  More than 64 trajectory blocks: the totals come from k_tail_total."""
+    rng = np.random.default_rng(77)
+    n = 8
+    A = rng.random((n, n)) + 2 * np.eye(n)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    mu, sig = np.linspace(-4, 4, n), rng.uniform(0.5, 1.5, n)
+    lens = rng.integers(1, 41, 5000)
+    obs = [rng.normal(0, 3, T) for T in lens]
+    ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+    eng = _engine()
+    eng.set_observations("gaussian", obs, n)
+    for _ in range(2):
+        res = eng.estep(A, pi, mu, sig)
+        np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-9)
+        np.testing.assert_allclose(res.loglik, ref["logL"].sum(), rtol=1e-11)
+        np.testing.assert_allclose(res.C, ref["C"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res.gamma0_sum, ref["gamma0_sum"], rtol=1e-9)
+        np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-9)
+    # a non-finite trajectory is still found and reported (maximum_likelihood.py:385)
+    bad = [o.copy() for o in obs]
+    bad[4321][0] = np.nan
+    eng.set_observations("gaussian", bad, n)
+    with pytest.raises(AssertionError):
+        eng.estep(A, pi, mu, sig)
+    eng.close()
