@@ -407,6 +407,12 @@ __device__ __forceinline__ void beta_step(const G &gather, const ObsIn &in, int 
 #ifndef ESTEP_WAVES
 #define ESTEP_WAVES 2
 #endif
+// E-step: every ESTEP_CK_OF(kind)-th alpha row reaches HBM, the backward sweep rebuilds the others.
+// Two for the gaussian kind.  Four for the discrete kind: without the exponentials its forward
+// launch (P1) is bound by HBM WRITES (3.2-3.8 TB/s is what the memory system sustains) with half of
+// the VALU idle, while the backward launch (P2) is VALU-bound -- a quarter of the rows halves P1's
+// bytes for one more rebuilt row per four steps in P2 (configs[2]: 24.6 -> see DESIGN.md section 9).
+#define ESTEP_CK_OF(KINDV) ((KINDV) == EMIT_DISC ? 4 : 2)
 #ifndef FWD_CKPT
 #define FWD_CKPT 16 // forward-only pass (Gibbs step): fp64 alpha rows of the steps s % FWD_CKPT == 0
 #endif
@@ -414,7 +420,7 @@ enum { PH_ALL = 0, PH_FWDROWS = 1, PH_P1 = 2, PH_P2 = 3 };
 
 template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE, bool BIGM = false>
 __device__ __forceinline__ void estep_body(
-    const Model<N> m, const Chunks ch, const void *obs_ci, const void *obs_rm,
+    const Model<N> &m, const Chunks &ch, const void *obs_ci, const void *obs_rm,
     const int64_t *toff,   // [K+1] trajectory offsets (time steps)
     const double *Bt_g, double *alpha_entry, double *beta_exit,
     double *a_exit,        // SPEC: [G][N] alpha at each chunk's last step (any scale)
@@ -634,8 +640,8 @@ __device__ __forceinline__ void estep_body(
             // rows in fp32, see PH_FWDROWS above)
             constexpr int PF = ESTEP_PF_F;
             constexpr bool CKPT = ESTEP_CKPT && !FWDONLY;
-            constexpr int CKS = FWDONLY ? FWD_CKPT : (CKPT ? 2 : 1);
-            constexpr int ALIGN = FWDONLY ? 2 * PF : 2;
+            constexpr int CKS = FWDONLY ? FWD_CKPT : (CKPT ? ESTEP_CK_OF(KIND) : 1);
+            constexpr int ALIGN = FWDONLY ? 2 * PF : (CKS > 2 ? CKS : 2);
             static_assert(PF % 2 == 0 && (FWDONLY ? CKS % (2 * PF) == 0 : (2 * PF) % CKS == 0),
                           "stored rows sit at fixed positions inside the unrolled groups");
             [[maybe_unused]] float2 *pw32 = nullptr;
@@ -711,13 +717,15 @@ __device__ __forceinline__ void estep_body(
                         }
                     });
                     if constexpr (CKPT) {
-                        // the backward sweep reads the last (len-1) % 4 + 1 rows directly: if the
-                        // single steps below do not cover them, the odd rows of the last group do
-                        if (rem == 2 * PF && tail < 4) {
+                        // the backward sweep reads the last (len-1) % (2 CKS) + 1 rows directly: if
+                        // the single steps below do not cover them, all rows of the last group are kept
+                        if (rem == 2 * PF && tail < 2 * CKS) {
 #pragma unroll
-                            for (int j = 1; j < PF; j += 2) {
-                                pw[j * RS] = ox[j];
-                                pw[(PF + j) * RS] = oy[j];
+                            for (int j = 0; j < PF; ++j) {
+                                if (j % CKS != 0)
+                                    pw[j * RS] = ox[j];
+                                if ((PF + j) % CKS != 0)
+                                    pw[(PF + j) * RS] = oy[j];
                             }
                         }
                     }
@@ -960,6 +968,47 @@ __device__ __forceinline__ void estep_body(
                 bfinish(bf, alo, ea, sc_lo);
             }
         };
+        // Four steps s .. s-3 from the stored row alpha_{s-4} (ESTEP_CK_OF == 4): the three rows in
+        // between are rebuilt first, forwards (each needs the emission row of its own step, which
+        // the backward steps below use again), then the four backward steps run as in bpair.
+        [[maybe_unused]] auto bquad = [&](const ObsIn &x3, const ObsIn &x2, const ObsIn &x1,
+                                          const ObsIn &x0, const double2 &alo, int ea, double2 *gdst,
+                                          auto sc3, auto sc2, auto sc1, auto sc0) {
+            double p3[2], d3[2], p2[2], d2[2], p1[2], d1[2], p0[2], d0[2], sv[2];
+            double a1[2], a2[2], a3[2], af[N], bf[N];
+            const double al[2] = {alo.x, alo.y};
+            gather(al, af); // alpha_{s-4}
+            sched_fence();
+            emit_raw<N, KIND>(x0, Bt, q, em, p0, d0);
+            emit_raw<N, KIND>(x1, Bt, q, em, p1, d1);
+            sched_fence();
+            fwd_dot<N>(af, Ac, sv);
+            a1[0] = sv[0] * p0[0]; // alpha_{s-3}
+            a1[1] = sv[1] * p0[1];
+            gather(a1, af);
+            sched_fence();
+            emit_raw<N, KIND>(x2, Bt, q, em, p2, d2);
+            emit_raw<N, KIND>(x3, Bt, q, em, p3, d3);
+            sched_fence();
+            fwd_dot<N>(af, Ac, sv);
+            a2[0] = sv[0] * p1[0]; // alpha_{s-2}
+            a2[1] = sv[1] * p1[1];
+            gather(a2, af);
+            fwd_dot<N>(af, Ac, sv);
+            a3[0] = sv[0] * p2[0]; // alpha_{s-1}
+            a3[1] = sv[1] * p2[1];
+            auto back = [&](const ObsIn &in, const double (&p)[2], const double (&d)[2],
+                            const double2 &apv, double2 *gd, auto sc) {
+                consume(in, d, gd);
+                const double bb[2] = {p[0] * b2[0], p[1] * b2[1]};
+                gather(bb, bf);
+                bfinish(bf, apv, ea, sc);
+            };
+            back(x3, p3, d3, make_double2(a3[0], a3[1]), gdst, sc3);
+            back(x2, p2, d2, make_double2(a2[0], a2[1]), gdst - RS, sc2);
+            back(x1, p1, d1, make_double2(a1[0], a1[1]), gdst - 2 * RS, sc1);
+            back(x0, p0, d0, alo, gdst - 3 * RS, sc0);
+        };
         // the observation of step 0 is needed last: fetch it now
         const ObsIn in0 = ObsCursor<N, KIND>(obs_ci, rec0, cl, q).at(0);
         double2 *const pg0 = GAMMA && gamma_ci ? ci_pair(gamma_ci, rec0, N, q, cl) : nullptr;
@@ -969,7 +1018,51 @@ __device__ __forceinline__ void estep_body(
             const double2 *pa = ci_pair(ws, rec0 + len - 1, N, q, cl);
             double2 *pg = pg0 + (int64_t)(len - 1) * RS;
             int rem = len - 1;
-            if constexpr (ESTEP_CKPT != 0) {
+            if constexpr (ESTEP_CKPT != 0 && ESTEP_CK_OF(KIND) == 4 &&
+                          !(CAREFUL && KIND == EMIT_GAUSS)) {
+                // (len-1) % 8 single steps on stored rows, then groups of two quads: two register
+                // sets {obs_s .. obs_{s-3}, alpha_{s-4}}, each loaded 4..7 steps before its use
+                for (int i = rem % 8; i > 0; --i) {
+                    bstep(po.at(0), pa[-RS], pg, std::true_type());
+                    po.move(-1);
+                    pa -= RS;
+                    pg -= RS;
+                }
+                rem -= rem % 8;
+                if (rem > 0) {
+                    const int32_t *pea = ea_rows + (rec0 + rem) * 64 + cl;
+                    ObsIn x[4], y[4];
+                    double2 xa = pa[-4 * RS], ya;
+                    int xe = EXPO ? pea[-4 * 64] : 0, ye = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        x[j] = po.at(-j);
+                    for (; rem > 0; rem -= 8) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            y[j] = po.at(-4 - j);
+                        ya = pa[-8 * RS];
+                        if constexpr (EXPO)
+                            ye = pea[-8 * 64];
+                        bquad(x[0], x[1], x[2], x[3], xa, xe, pg, sc_at<0>(), sc_at<1>(), sc_at<2>(),
+                              sc_at<3>());
+                        if (rem > 8) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                x[j] = po.at(-8 - j);
+                            xa = pa[-12 * RS];
+                            if constexpr (EXPO)
+                                xe = pea[-12 * 64];
+                        }
+                        bquad(y[0], y[1], y[2], y[3], ya, ye, pg - 4 * RS, sc_at<0>(), sc_at<1>(),
+                              sc_at<2>(), sc_at<3>());
+                        po.move(-8);
+                        pa -= 8 * RS;
+                        pg -= 8 * RS;
+                        pea -= 8 * 64;
+                    }
+                }
+            } else if constexpr (ESTEP_CKPT != 0) {
                 // (len-1) % 4 single steps on stored rows, then groups of two pairs: two register
                 // sets {obs_s, obs_{s-1}, alpha_{s-2}}, each loaded 2..3 steps before its use
                 for (int i = rem % 4; i > 0; --i) {
