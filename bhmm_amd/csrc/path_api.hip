@@ -133,9 +133,13 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
                                chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
                                fmap, status, dmark, nib, W8, Gp64, gw, Lp);
         BHMM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_smp_stitch, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB), dim3(64), 0,
-                           c->stream,
-                           (const int32_t *)c->d_traj_c0.p, K, P, (const uint32_t *)fmap, nstate);
+        if ((int64_t)c->G * P >= (int64_t)32 * K) // long chains: one wavefront per trajectory
+            hipLaunchKernelGGL(k_smp_stitch, dim3(K), dim3(64), 0, c->stream,
+                               (const int32_t *)c->d_traj_c0.p, K, P, (const uint32_t *)fmap, nstate);
+        else
+            hipLaunchKernelGGL(k_smp_stitch_serial, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB),
+                               dim3(64), 0, c->stream, (const int32_t *)c->d_traj_c0.p, K, P,
+                               (const uint32_t *)fmap, nstate);
         BHMM_HIP(hipGetLastError());
         const int32_t *ns = nstate, *dmk = dmark;
         const uint32_t *nb = nib, *gwc = gw;
@@ -348,9 +352,14 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         const dim3 wg((c->G + 7) / 8);
         hipLaunchKernelGGL((k_vit_walk<8, false>), wg, dim3(64), 0, c->stream, chs, c->G, n,
                            (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, (int32_t *)nullptr);
-        hipLaunchKernelGGL(k_smp_stitch, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB), dim3(64), 0,
-                           c->stream, (const int32_t *)c->d_traj_c0.p, K, 1, (const uint32_t *)vmaps,
-                           vend, (const int32_t *)last);
+        if ((int64_t)c->G >= (int64_t)32 * K)
+            hipLaunchKernelGGL(k_smp_stitch, dim3(K), dim3(64), 0, c->stream,
+                               (const int32_t *)c->d_traj_c0.p, K, 1, (const uint32_t *)vmaps, vend,
+                               (const int32_t *)last);
+        else
+            hipLaunchKernelGGL(k_smp_stitch_serial, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB),
+                               dim3(64), 0, c->stream, (const int32_t *)c->d_traj_c0.p, K, 1,
+                               (const uint32_t *)vmaps, vend, (const int32_t *)last);
         if (out_fmt == 0)
             hipLaunchKernelGGL((k_vit_walk<8, true, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
                                (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path);

@@ -472,9 +472,73 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
 }
 
 // state at the first step of the NEXT part, for every (chunk, part) (0 behind a trajectory's
-// last part, whose map is constant)
-constexpr int SMP_STITCH_TPB = 8;
+// last part, whose map is constant): walking a trajectory's maps from its end, next_state[i] = x,
+// x <- F_i(x).  One wavefront per trajectory; the chain is not walked serially: every lane
+// composes SMP_STITCH_SEG consecutive maps into one (8 nibbles: y -> F(y)), a wave-wide scan of
+// those composites gives every lane the state its segment is entered with, and the lane re-walks
+// its own segment.  (1024 maps per trajectory on configs[4]: 65 -> a few microseconds.)
+constexpr int SMP_STITCH_SEG = 16;
+__device__ __forceinline__ uint32_t smp_compose(uint32_t first, uint32_t then)
+{
+    uint32_t c = 0; // c(y) = then(first(y))
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+        c |= ((then >> (4 * ((first >> (4 * y)) & 7u))) & 7u) << (4 * y);
+    return c;
+}
 static __global__ __launch_bounds__(64) void k_smp_stitch(const int32_t *traj_c0, int K, int P,
+                                                          const uint32_t *Fmap, int32_t *next_state,
+                                                          const int32_t *start = nullptr)
+{
+    const int k = blockIdx.x;
+    if (k >= K)
+        return;
+    const int lane = threadIdx.x;
+    uint32_t x0 = start ? (uint32_t)start[k] : 0u; // Viterbi: the final state of the trajectory
+    const int64_t lo = (int64_t)traj_c0[k] * P;
+    int64_t hi = (int64_t)traj_c0[k + 1] * P - 1;
+    constexpr int TILE = 64 * SMP_STITCH_SEG;
+    while (hi >= lo) {
+        const int64_t cnt = hi - lo + 1 < TILE ? hi - lo + 1 : TILE;
+        // my segment: maps hi - (lane * SEG + j), j = 0 .. SEG-1 (walked in this order)
+        uint32_t f[SMP_STITCH_SEG];
+        uint32_t comp = 0x76543210u; // identity
+#pragma unroll
+        for (int j = 0; j < SMP_STITCH_SEG; ++j) {
+            const int64_t i = (int64_t)lane * SMP_STITCH_SEG + j;
+            f[j] = i < cnt ? Fmap[hi - i] : 0x76543210u;
+        }
+#pragma unroll
+        for (int j = 0; j < SMP_STITCH_SEG; ++j)
+            comp = smp_compose(comp, f[j]);
+        // inclusive scan over lanes: M_l = comp_l o ... o comp_0 (comp_0 applied first)
+        uint32_t M = comp;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t other = (uint32_t)__shfl_up((int)M, d, 64);
+            if (lane >= d)
+                M = smp_compose(other, M);
+        }
+        const uint32_t Mprev = (uint32_t)__shfl_up((int)M, 1, 64);
+        uint32_t x = lane == 0 ? x0 : ((Mprev >> (4 * x0)) & 7u);
+#pragma unroll
+        for (int j = 0; j < SMP_STITCH_SEG; ++j) {
+            const int64_t i = (int64_t)lane * SMP_STITCH_SEG + j;
+            if (i < cnt) {
+                next_state[hi - i] = (int32_t)x;
+                x = (f[j] >> (4 * x)) & 7u;
+            }
+        }
+        const uint32_t Mall = (uint32_t)__shfl((int)M, 63, 64);
+        x0 = (Mall >> (4 * x0)) & 7u; // state entering the next tile
+        hi -= cnt;
+    }
+}
+
+// The same chain walked by ONE lane per trajectory: for batches of many short trajectories (a
+// few maps each), where a wavefront per trajectory would be mostly idle.
+constexpr int SMP_STITCH_TPB = 8;
+static __global__ __launch_bounds__(64) void k_smp_stitch_serial(const int32_t *traj_c0, int K, int P,
                                                           const uint32_t *Fmap, int32_t *next_state,
                                                           const int32_t *start = nullptr)
 {
