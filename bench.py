@@ -393,7 +393,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     obs_dev = torch.from_numpy(obs_host.reshape(-1)).to(dev)
-    stream = torch.cuda.current_stream(dev)
+    torch.cuda.synchronize(dev)
+    # a dedicated (non-default) stream shared by the engine and the collective: the legacy default
+    # stream would serialise against every other stream of the process
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng = Engine(local, stream=stream.cuda_stream)
     eng.set_observations_device("gaussian", obs_dev.data_ptr(), off, NSTATES, chunk=args.chunk)
     S = eng.stats_size

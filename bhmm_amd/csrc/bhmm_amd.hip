@@ -273,7 +273,9 @@ struct Runner {
         if (rc)
             return rc;
         const int nfin = StatLayout<N, KIND>::S + (KIND == EMIT_DISC ? c->M * N : 0) + N + 1;
-        const int nTB = (c->K + TAIL_TPB - 1) / TAIL_TPB;
+        const int tpb = tail_tpb(c->G, c->K);
+        const int nTB = (c->K + tpb - 1) / tpb;
+        const bool fused_total = nTB <= 1024; // beyond: a fence + ticket per block costs more than a launch
         if ((rc = c->d_tbpart.ensure((size_t)nTB * (1 + N))))
             return rc;
         hipLaunchKernelGGL((k_tail<N, KIND>), dim3(nfin + nTB + (c->G + 63) / 64), dim3(64), 0,
@@ -283,9 +285,9 @@ struct Runner {
                            (const double *)c->d_gamma0.p, (const double *)c->d_aentry.p,
                            (const double *)c->d_aexit.p, (const double *)c->d_bexit.p,
                            (const double *)c->d_bentry.p, SPEC_TOL, stats_dev, c->d_logLk.p,
-                           c->d_tail.p + 4, S, words, words_next, c->d_tbpart.p, nTB <= 64);
+                           c->d_tail.p + 4, S, words, words_next, c->d_tbpart.p, fused_total, tpb);
         BHMM_HIP(hipGetLastError());
-        if (nTB > 64) { // (a fence + ticket per trajectory block costs more than this launch)
+        if (!fused_total) {
             hipLaunchKernelGGL((k_tail_total<N>), dim3(1), dim3(64), 0, c->stream, c->n, nTB,
                                (const double *)c->d_tbpart.p, stats_dev, c->d_tail.p + 4);
             BHMM_HIP(hipGetLastError());

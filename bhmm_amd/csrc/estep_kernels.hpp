@@ -1004,7 +1004,11 @@ __global__ __launch_bounds__(64) void k_finalize(const Model<N> m, int K, int nb
 // terms by one wavefront (1e6 short trajectories: 40 ms -> < 1 ms).
 // flags_next: the verdict words of the NEXT E-step (the two sets alternate), cleared here so
 // that no memset sits between E-steps.
-constexpr int TAIL_TPB = 64;
+constexpr int TAIL_TPB = 64; // trajectories per block when they are short (else one: tail_tpb())
+// A block walks its trajectories one after the other, each with a wave-wide sum over its chunks:
+// 64 per block is right for trajectories of a few chunks, one per block for long ones (configs[1]:
+// 128 chunks per trajectory -- 64 of them in sequence per block cost 80 us instead of 25).
+inline int tail_tpb(int64_t G, int K) { return G >= (int64_t)16 * K ? 1 : TAIL_TPB; }
 // sum of the trajectory blocks' partials -> stats[0] (total log-likelihood) and stats[1..n]
 // (sum_k gamma_k[0]); one wavefront: every lane takes whole records (1 + N independent loads in
 // flight per record), then one wave sum per entry -- fixed order, no chain of load latencies
@@ -1061,10 +1065,10 @@ __global__ __launch_bounds__(64) void k_tail(const Model<N> m, const Chunks ch, 
                                              double *mirror, // [S stats | K logL_k], contiguous
                                              int S, unsigned int *flags, unsigned int *flags_next,
                                              double *tb_part, // [nTB][1 + N] block partials
-                                             bool fused_total)
+                                             bool fused_total, int tpb)
 {
     const int b = blockIdx.x;
-    const int nTB = (K + TAIL_TPB - 1) / TAIL_TPB;
+    const int nTB = (K + tpb - 1) / tpb;
     const int lane = threadIdx.x;
     if (b < nfin) {
         finalize_one<N, KIND>(b, m, K, nblocks, partials, disc_partials, nullptr, logL_chunk, G,
@@ -1073,8 +1077,8 @@ __global__ __launch_bounds__(64) void k_tail(const Model<N> m, const Chunks ch, 
             flags_next[threadIdx.x] = 0u;
     } else if (b < nfin + nTB) {
         const int tb = b - nfin;
-        const int k0 = tb * TAIL_TPB;
-        const int kn = K - k0 < TAIL_TPB ? K - k0 : TAIL_TPB;
+        const int k0 = tb * tpb;
+        const int kn = K - k0 < tpb ? K - k0 : tpb;
         // chunk ranges of my trajectories: lane j holds the first chunk of trajectory k0 + j
         const int c_lo = traj_c0[k0 + (lane < kn ? lane : kn)];
         const int c_hi = __shfl_down(c_lo, 1, 64);
