@@ -605,6 +605,14 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
 #pragma unroll
     for (int i = 0; i < N; ++i)
         s0[i] = s1[i] = s2[i] = 0.0;
+    // common shift of the gaussian moments: the mean of the state means (keeps |o - shift| of the
+    // order of the spread of the means: the re-centring below loses nothing that matters)
+    double cshift = 0.0;
+    if constexpr (KIND == EMIT_GAUSS) {
+        for (int i = 0; i < m.nreal; ++i)
+            cshift += m.e0[i];
+        cshift /= (double)m.nreal;
+    }
     if (len > 0) {
         const int k = ch.traj[g];
         const int64_t t0 = ch.t0[g], base = ch.goff[g];
@@ -664,14 +672,15 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
             if (t0 + s == 0)
                 atomicAdd(&cnt[N * N + st], 1u);
             if constexpr (KIND == EMIT_GAUSS) {
-                const double o = o_cur;
+                // moments about the common shift cshift (one subtraction and one square per step,
+                // an exact 0/1 weight per state); re-centred on the state means after the walk
+                const double dc = o_cur - cshift, dd = dc * dc;
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    const double d = o - m.e0[i];
-                    const bool hit = (st == i);
-                    s0[i] += hit ? 1.0 : 0.0;
-                    s1[i] += hit ? d : 0.0;
-                    s2[i] += hit ? d * d : 0.0;
+                    const double w = (st == i) ? 1.0 : 0.0;
+                    s0[i] += w;
+                    s1[i] = fma(w, dc, s1[i]);
+                    s2[i] = fma(w, dd, s2[i]);
                 }
             }
             if constexpr (KIND == EMIT_DISC) {
@@ -693,6 +702,10 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
         const int wv = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
+            // sum (o - mu_i)^k from the moments about cshift: e = mu_i - cshift
+            const double e = m.e0[i] - cshift;
+            s2[i] = s2[i] - 2.0 * e * s1[i] + e * e * s0[i];
+            s1[i] = s1[i] - e * s0[i];
             const double a = wave_sum(s0[i]), b = wave_sum(s1[i]), c = wave_sum(s2[i]);
             if (lane == 0) {
                 red[wv][i] = a;
