@@ -620,7 +620,23 @@ struct Runner {
                 if ((rc = spec_prepare(c)))
                     return rc;
                 rc = fast ? forward_launch<KIND, false>(c, m) : forward_launch<KIND, true>(c, m);
-                if (rc || (rc = spec_verdict(c, false, &ok)))
+                if (rc)
+                    return rc;
+                if (c->fwd_defer && attempt == 0) {
+                    // the caller keeps launching on the stream and reads the verdict with its own
+                    // results (forward_ci_verdict): one host round trip less per Gibbs sweep
+                    hipLaunchKernelGGL((k_spec_check<N>), dim3((c->G + 255) / 256), dim3(256), 0,
+                                       c->stream, chunks_of(c), c->G, (const double *)c->d_aentry.p,
+                                       (const double *)c->d_aexit.p, (const double *)nullptr,
+                                       (const double *)c->d_bentry.p, SPEC_TOL, c->d_specres.p);
+                    BHMM_HIP(hipGetLastError());
+                    BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
+                                            hipMemcpyDeviceToHost, c->stream));
+                    c->prefetched = false;
+                    c->fwd_pending = true;
+                    return BHMM_OK;
+                }
+                if ((rc = spec_verdict(c, false, &ok)))
                     return rc;
                 if (ok)
                     return BHMM_OK;
@@ -653,6 +669,12 @@ struct Runner {
         default:
             return forward_kind<EMIT_EXPL>(c, m);
         }
+    }
+
+    // verdict of a deferred forward-only pass, after the caller synchronised the stream
+    static int forward_verdict(bhmm_ctx *c, bool *ok)
+    {
+        return apply_verdict(c, c->h_specres, ok, false);
     }
 
     static int pack_rows(bhmm_ctx *c, const double *src_dev)
@@ -773,6 +795,7 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
 
 int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1);
+int forward_ci_verdict(bhmm_ctx *c, bool *ok);
 int unpack_ws_rows(bhmm_ctx *c, double *dst_dev);
 // wide_api.hip (9..64 states)
 int wide_alloc(bhmm_ctx *c);
@@ -856,6 +879,11 @@ int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par
     if (c->kind == BHMM_EMIT_DISCRETE && (rc = upload_Bt(c, par0)))
         return rc;
     return BHMM_DISPATCH_N(c, forward_only(c, A, pi, par0, par1));
+}
+
+int forward_ci_verdict(bhmm_ctx *c, bool *ok)
+{
+    return BHMM_DISPATCH_N(c, forward_verdict(c, ok));
 }
 
 int unpack_ws_rows(bhmm_ctx *c, double *dst_dev)

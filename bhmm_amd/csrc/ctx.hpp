@@ -81,6 +81,8 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_aentry, d_bexit, d_ws, d_gamma_ci;
     bhmm::DevBuf<float> d_ws32;      // Gibbs step: CI alpha rows rounded to fp32 (forward-only pass)
     bool rows32_valid = false;       // ... written by the last forward-only pass
+    bool fwd_defer = false;          // forward-only pass: enqueue the boundary check, do not wait for it
+    bool fwd_pending = false;        // ... its verdict is still to be read (forward_ci_verdict)
     bhmm::DevBuf<double> d_logLc, d_logLk, d_gamma0, d_partials, d_dpartials, d_stats;
     bhmm::DevBuf<char> d_scratch;    // paths, uniforms, pointer tables ...
     bhmm::DevBuf<char> d_scratch2;

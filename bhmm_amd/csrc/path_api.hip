@@ -23,6 +23,7 @@ int wide_transition_counts(double *C, const double *A, const double *pobs, const
                            const double *beta, int n, int64_t T);
 int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1);
+int forward_ci_verdict(bhmm_ctx *c, bool *ok);
 int unpack_ws_rows(bhmm_ctx *c, double *dst_dev);
 Chunks chunks_pub(const bhmm_ctx *c);
 
@@ -54,9 +55,15 @@ struct Tmp { // scoped raw device allocations for the context-free entry points
 template <int N>
 int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1, const double *u, uint64_t seed, int32_t *paths, int64_t *counts,
-               int64_t *n0, double *emis, double *stats_dev)
+               int64_t *n0, double *emis, double *stats_dev, bool defer_check = true)
 {
-    int rc = forward_ci(c, A, pi, par0, par1); // alpha -> CI workspace
+    // alpha -> CI workspace.  The boundary check of a speculative forward pass is only enqueued:
+    // its verdict comes back with the results below, and a failed check repeats the call with the
+    // waiting form (which then lengthens the warm-up / falls back to the exact pass).
+    static const bool no_defer = getenv("BHMM_AMD_NO_DEFER") != nullptr; // (kernel experiments)
+    c->fwd_defer = defer_check && !no_defer;
+    int rc = forward_ci(c, A, pi, par0, par1);
+    c->fwd_defer = false;
     if (rc)
         return rc;
     const int K = c->K, n = c->n;
@@ -185,6 +192,15 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipMemcpyAsync(paths, path, (size_t)c->total * sizeof(int32_t),
                                 hipMemcpyDeviceToHost, c->stream));
     BHMM_HIP(hipStreamSynchronize(c->stream));
+    if (c->fwd_pending) {
+        c->fwd_pending = false;
+        bool ok = false;
+        if ((rc = forward_ci_verdict(c, &ok)))
+            return rc;
+        if (!ok) // boundaries did not verify: everything above ran on wrong alpha rows
+            return sample_run<N>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, stats_dev,
+                                 false);
+    }
     if (hstatus) {
         set_error("random choice found no state: alpha/A not normalisable (_hidden.c:299-304)");
         return hstatus;

@@ -424,3 +424,27 @@ def test_many_short_trajectories():
     with pytest.raises(AssertionError):
         eng.estep(A, pi, mu, sig)
     eng.close()
+
+
+def test_gibbs_step_with_failing_boundary_check(golden):
+    """The Gibbs step launches its sampling kernels without waiting for the boundary check of the
+    speculative forward pass; a failed check (warm-up far too short) must be noticed afterwards
+    and the step repeated on exact alpha rows -- same paths as the oracle."""
+    from conftest import split
+    g = golden("g8_ragged")
+    obs = split(g["obs"], g["lengths"])
+    margs = (g["A"], g["pi"], g["mu"], g["sigma"])
+    rng = np.random.default_rng(3)
+    u = [rng.random(len(o)) for o in obs]
+    ref = [orc.sample_path(orc.forward(g["A"], orc.pobs_gaussian(o, g["mu"], g["sigma"]), g["pi"])[1],
+                           g["A"], u=uu) for o, uu in zip(obs, u)]
+    eng = _engine()
+    eng.set_observations("gaussian", obs, 8, chunk=16)
+    eng.set_option("spec_W", 2)
+    for _ in range(3):
+        paths, C, n0, _ = eng.sample_paths(*margs, u=u)
+        assert all(np.array_equal(a, b) for a, b in zip(paths, ref))
+    assert eng.get_option("spec_fail") >= 1
+    Cr, n0r = orc.path_counts(ref, 8)
+    assert np.array_equal(C, Cr) and np.array_equal(n0, n0r)
+    eng.close()
