@@ -261,7 +261,9 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     // emission probabilities in a separate, fully parallel pass when the (total, n) matrix
     // fits (it is what the reference materialises anyway, maximum_likelihood.py:345-347)
     int vkind = c->kind;
-    if (c->kind != EMIT_EXPL) {
+    // discrete, n <= 8 with a chunk plan: the chunk-parallel kernel gathers from B itself
+    const bool disc_direct = !c->wide && c->kind == EMIT_DISC && c->spec_enabled && c->G > K;
+    if (c->kind != EMIT_EXPL && !disc_direct) {
         size_t freeb = 0, totb = 0;
         const size_t need = (size_t)c->total * n * sizeof(double);
         if (hipMemGetInfo(&freeb, &totb) == hipSuccess && need + ((size_t)1 << 30) < freeb + c->d_alpha_rm.n * sizeof(double) &&
@@ -319,7 +321,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     // n <= 8 with a chunk plan: the chunk-parallel run first; its back-pointers are accepted only
     // if every chunk boundary verifies and no decision was close (k_viterbi_chunks)
     bool done = false;
-    if (!c->wide && vkind == EMIT_EXPL && c->spec_enabled && c->G > K) {
+    if (!c->wide && (vkind == EMIT_EXPL || disc_direct) && c->spec_enabled && c->G > K) {
         int maxchunks = 1;
         for (int k = 0; k < K; ++k)
             maxchunks = std::max(maxchunks, c->traj_c0[k + 1] - c->traj_c0[k]);
@@ -332,9 +334,14 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                                    hipHostMallocDefault));
         BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
         const Chunks chs = chunks_pub(c);
-        hipLaunchKernelGGL((k_viterbi_chunks<8>), dim3((c->G + 7) / 8), dim3(64), 0, c->stream, m, chs,
-                           c->G, off, static_cast<const double *>(obs), c->spec_W, margin, ptr, last,
-                           c->d_aentry.p, c->d_aexit.p, c->d_specres.p);
+        if (disc_direct)
+            hipLaunchKernelGGL((k_viterbi_chunks<8, EMIT_DISC>), dim3((c->G + 7) / 8), dim3(64), 0,
+                               c->stream, m, chs, c->G, off, obs, c->spec_W, margin, ptr, last,
+                               c->d_aentry.p, c->d_aexit.p, c->d_specres.p);
+        else
+            hipLaunchKernelGGL((k_viterbi_chunks<8, EMIT_EXPL>), dim3((c->G + 7) / 8), dim3(64), 0,
+                               c->stream, m, chs, c->G, off, obs, c->spec_W, margin, ptr, last,
+                               c->d_aentry.p, c->d_aexit.p, c->d_specres.p);
         BHMM_HIP(hipGetLastError());
         hipLaunchKernelGGL((k_viterbi_check<8>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
                            chs, c->G, (const double *)c->d_aentry.p, (const double *)c->d_aexit.p, tol,

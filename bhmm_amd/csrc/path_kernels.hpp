@@ -1089,13 +1089,20 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
 // BIT-IDENTICAL (k_viterbi_check); then the run is the serial run outright and close decisions
 // are irrelevant.  Otherwise the host runs k_wide_viterbi_fwd.  Emission rows: k_pobs_all.
 // =========================================================================================
-template <int NP>
+// KIND: EMIT_EXPL -- `src` is the (total, n) emission matrix (k_pobs_lanes / k_pobs_all, or the
+// caller's pobs); EMIT_DISC -- `src` is the int32 symbol stream and the probability is read from
+// B directly (discrete.py:150-153: pobs = B[:, obs].T is a gather, there is nothing to precompute
+// -- for BASELINE configs[2] the materialised matrix would be 65 GB written and read again).
+template <int NP, int KIND = EMIT_EXPL>
 __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const Chunks ch, int G,
-                                                       const int64_t *toff, const double *pobs,
+                                                       const int64_t *toff, const void *src,
                                                        int W, double margin, uint8_t *ptr,
                                                        int32_t *last_state, double *v_entry,
                                                        double *v_exit, unsigned int *flags)
 {
+    static_assert(KIND == EMIT_EXPL || KIND == EMIT_DISC, "gaussian rows are precomputed");
+    [[maybe_unused]] const double *pobs = static_cast<const double *>(src);
+    [[maybe_unused]] const int32_t *syms = static_cast<const int32_t *>(src);
     constexpr int GP = 64 / NP;
     static_assert(NP <= 16, "one argmax tile");
     __shared__ __attribute__((aligned(16))) double xv[GP][NP];
@@ -1120,11 +1127,17 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
         const int64_t gs = goff - nw;
         const int steps = nw + len;
         double v = real ? 1.0 / (double)n : 0.0;
-        double p_next = real ? pobs[gs * n + j] : 0.0;
+        auto emission = [&](int64_t t) -> double {
+            if constexpr (KIND == EMIT_DISC)
+                return real ? m.B[(int64_t)j * m.M + syms[t]] : 0.0;
+            else
+                return real ? pobs[t * n + j] : 0.0;
+        };
+        double p_next = emission(gs);
         for (int s = 0; s < steps; ++s) {
             const double p = p_next;
             if (s + 1 < steps)
-                p_next = real ? pobs[(gs + s + 1) * n + j] : 0.0; // independent of the recursion
+                p_next = emission(gs + s + 1); // independent of the recursion
             double vn;
             if (exact && s == 0) {
                 vn = p * pi_j; // _hidden.c:232

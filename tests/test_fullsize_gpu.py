@@ -448,3 +448,23 @@ def test_gibbs_step_with_failing_boundary_check(golden):
     Cr, n0r = orc.path_counts(ref, 8)
     assert np.array_equal(C, Cr) and np.array_equal(n0, n0r)
     eng.close()
+
+
+def test_discrete_viterbi_one_million_steps():
+    """Discrete Viterbi at T = 1e6 (configs[2]'s trajectory length; the chunk-parallel kernel reads
+    B directly, no (T, n) emission matrix is materialised): bit-exact against the oracle."""
+    import torch
+    from bhmm_amd.engine import synth_observations
+    n, M, A, pi, B, A_eval, B_eval = _c3_model()
+    K, T = 8, 1000000
+    obs = torch.empty(K * T, dtype=torch.int32, device="cuda:0")
+    synth_observations("discrete", obs.data_ptr(), A, pi, B, None, K, T, seed=41)
+    eng = _engine()
+    eng.set_observations_device("discrete", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, n,
+                                nsymbols=M)
+    paths = eng.viterbi_u8(A_eval, pi, B_eval).reshape(K, T)
+    assert eng.get_option("viterbi_chunked") == 1
+    for k in (0, 7):
+        o = obs[k * T:(k + 1) * T].cpu().numpy()
+        assert np.array_equal(paths[k], orc.viterbi(A_eval, orc.pobs_discrete(o, B_eval), pi))
+    eng.close()
