@@ -92,6 +92,8 @@ SIGNATURES = {
                                                ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                                c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int64, ctypes.c_uint64]),
+    "bhmm_mle_reversible": (ctypes.c_int, [c_double_p, c_int64_p, c_double_p, ctypes.c_int,
+                                           ctypes.c_int64, ctypes.c_double]),
     "bhmm_diag_exp_nonpos": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int64]),
 }
 

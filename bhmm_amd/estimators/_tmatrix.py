@@ -74,10 +74,26 @@ def stationary_vector(P):
     return pi / pi.sum()
 
 
-def mle_reversible(C, maxiter=1000000, maxerr=1e-8):
+def mle_reversible(C, maxiter=1000000, maxerr=1e-8, native=True):
     """Reversible maximum-likelihood transition matrix of a strongly connected count matrix.
-    Fixed point  x_ij <- (c_ij + c_ji) / (c_i / x_i + c_j / x_j),  P_ij = x_ij / x_i."""
+    Fixed point  x_ij <- (c_ij + c_ji) / (c_i / x_i + c_j / x_j),  P_ij = x_ij / x_i.
+    native=True runs the same iteration in the library (bhmm_mle_reversible, host code: thousands
+    of O(n^2) iterations cost tens of milliseconds in numpy); the numpy loop below is the
+    restatement it is tested against, and what runs if the library is not built."""
     C = np.asarray(C, dtype=np.float64)
+    if native and C.ndim == 2 and C.shape[0] == C.shape[1] and np.all(np.isfinite(C)) \
+            and C.sum() > 0:
+        try:
+            from .. import _lib
+            L = _lib.load()
+        except (ImportError, OSError, AttributeError):
+            L = None
+        if L is not None:
+            Cc = np.ascontiguousarray(C)
+            P = np.empty_like(Cc)
+            _lib.check(L.bhmm_mle_reversible(_lib.dp(P), None, _lib.dp(Cc), int(Cc.shape[0]),
+                                             int(maxiter), float(maxerr)))
+            return P
     C2 = C + C.T
     csum = C.sum(axis=1)
     X = C2 / C2.sum()

@@ -496,3 +496,30 @@ def test_multi_start_recovers_overlapping_states():
     np.testing.assert_allclose(h.output_model.means, model.output_model.means, atol=0.1)
     np.testing.assert_allclose(h.output_model.sigmas, model.output_model.sigmas, atol=0.1)
     np.testing.assert_allclose(h.transition_matrix, model.transition_matrix, atol=0.03)
+
+
+def test_native_reversible_mle_equals_numpy_restatement():
+    """bhmm_mle_reversible (host code of the library, no GPU) runs the same fixed-point iteration
+    as the numpy restatement _tmatrix.mle_reversible: same matrices to rounding, detailed balance,
+    structural zeros kept, and the two-state closed form."""
+    from bhmm_amd.estimators import _tmatrix
+    rng = np.random.default_rng(4)
+    for n in (2, 3, 8, 20, 64):
+        C = rng.random((n, n)) * rng.integers(1, 1000, (n, n))
+        C[rng.random((n, n)) < 0.2] = 0.0
+        C += np.diag(rng.random(n) + 0.1)
+        C[0, 1] += 1.0                                   # keep it connected
+        C[np.arange(1, n), np.arange(n - 1)] += 0.5
+        C[np.arange(n - 1), np.arange(1, n)] += 0.5
+        P1 = _tmatrix.mle_reversible(C, maxiter=200000, maxerr=1e-13)
+        P0 = _tmatrix.mle_reversible(C, maxiter=200000, maxerr=1e-13, native=False)
+        np.testing.assert_allclose(P1, P0, rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(P1.sum(axis=1), 1.0, rtol=1e-13)
+        pi = _tmatrix.stationary_vector(P1)
+        F = pi[:, None] * P1
+        np.testing.assert_allclose(F, F.T, atol=1e-10)   # detailed balance
+        assert np.all(P1[(C + C.T) == 0] == 0.0)
+    # every two-state chain is reversible: the reversible MLE is the plain row-normalised one
+    C = np.array([[4.0, 1.0], [2.0, 4.0]])
+    P = _tmatrix.mle_reversible(C, maxerr=1e-15)
+    np.testing.assert_allclose(P, [[0.8, 0.2], [1.0 / 3.0, 2.0 / 3.0]], atol=1e-9)
