@@ -1107,7 +1107,13 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
     static_assert(NP <= 16, "one argmax tile");
     __shared__ __attribute__((aligned(16))) double xv[GP][NP];
     __shared__ __attribute__((aligned(16))) double xn[GP][NP];
+    // A for the winner's factor: the select tree below carries only (product, index); v[i^] and
+    // A[i^][j] are looked up afterwards (two LDS reads instead of four more registers per select)
+    __shared__ double sA[NP * NP];
     const int lane = threadIdx.x;
+    for (int e = lane; e < NP * NP; e += 64)
+        sA[e] = (e / NP < m.n && e % NP < m.n) ? m.A[(int64_t)(e / NP) * m.n + e % NP] : 0.0;
+    __syncthreads();
     const int gi = lane / NP, j = lane % NP;
     const int64_t g = (int64_t)blockIdx.x * GP + gi;
     const int len = g < G ? ch.len[g] : 0;
@@ -1145,7 +1151,7 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
                 xv[gi][j] = v;
                 // first-maximum argmax (_hidden.c:186-200) as a select tree, see
                 // k_wide_viterbi_fwd
-                double vv[NP], hh[NP], h0[NP], aa[NP];
+                double vv[NP], hh[NP], h0[NP];
                 int ii[NP];
 #pragma unroll
                 for (int i = 0; i < NP; i += 2) {
@@ -1155,8 +1161,7 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
                 }
 #pragma unroll
                 for (int i = 0; i < NP; ++i) {
-                    aa[i] = Acol[i];
-                    hh[i] = vv[i] * aa[i]; // _hidden.c:249
+                    hh[i] = vv[i] * Acol[i]; // _hidden.c:249
                     h0[i] = hh[i];
                     ii[i] = i;
                 }
@@ -1166,8 +1171,6 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
         {                                                              \
             const bool take = hh[i + Wd] > hh[i];                      \
             hh[i] = take ? hh[i + Wd] : hh[i];                         \
-            vv[i] = take ? vv[i + Wd] : vv[i];                         \
-            aa[i] = take ? aa[i + Wd] : aa[i];                         \
             ii[i] = take ? ii[i + Wd] : ii[i];                         \
         }                                                              \
     }
@@ -1187,7 +1190,7 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
                         cnt += (h0[i] >= thr) ? 1 : 0;
                     low |= real && cnt != 1;
                 }
-                vn = p * vv[0] * aa[0]; // _hidden.c:253
+                vn = p * xv[gi][ii[0]] * sA[ii[0] * NP + j]; // _hidden.c:253: (p v[i^]) A[i^][j]
             }
             xn[gi][j] = vn;
             double S = 0.0;
