@@ -332,24 +332,37 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         if (!c->h_specres)
             BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
                                    hipHostMallocDefault));
-        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
         const Chunks chs = chunks_pub(c);
-        if (disc_direct)
-            hipLaunchKernelGGL((k_viterbi_chunks<8, EMIT_DISC>), dim3((c->G + 7) / 8), dim3(64), 0,
-                               c->stream, m, chs, c->G, off, obs, c->spec_W, margin, ptr, last,
-                               c->d_aentry.p, c->d_aexit.p, c->d_specres.p);
-        else
-            hipLaunchKernelGGL((k_viterbi_chunks<8, EMIT_EXPL>), dim3((c->G + 7) / 8), dim3(64), 0,
-                               c->stream, m, chs, c->G, off, obs, c->spec_W, margin, ptr, last,
-                               c->d_aentry.p, c->d_aexit.p, c->d_specres.p);
-        BHMM_HIP(hipGetLastError());
-        hipLaunchKernelGGL((k_viterbi_check<8>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
-                           chs, c->G, (const double *)c->d_aentry.p, (const double *)c->d_aexit.p, tol,
-                           c->d_specres.p);
-        BHMM_HIP(hipGetLastError());
-        BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
-                                hipMemcpyDeviceToHost, c->stream));
-        BHMM_HIP(hipStreamSynchronize(c->stream));
+        // first without the close-decision count; bit-identical boundaries make it irrelevant
+        for (int pass = 0; pass < 2; ++pass) {
+            BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+#define BHMM_VC(KINDV, MARGINV)                                                                     \
+    hipLaunchKernelGGL((k_viterbi_chunks<8, KINDV, MARGINV>), dim3((c->G + 7) / 8), dim3(64), 0,    \
+                       c->stream, m, chs, c->G, off, obs, c->spec_W, margin, ptr, last,             \
+                       c->d_aentry.p, c->d_aexit.p, c->d_specres.p)
+            if (disc_direct) {
+                if (pass == 0)
+                    BHMM_VC(EMIT_DISC, false);
+                else
+                    BHMM_VC(EMIT_DISC, true);
+            } else {
+                if (pass == 0)
+                    BHMM_VC(EMIT_EXPL, false);
+                else
+                    BHMM_VC(EMIT_EXPL, true);
+            }
+#undef BHMM_VC
+            BHMM_HIP(hipGetLastError());
+            hipLaunchKernelGGL((k_viterbi_check<8>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
+                               chs, c->G, (const double *)c->d_aentry.p, (const double *)c->d_aexit.p,
+                               tol, c->d_specres.p);
+            BHMM_HIP(hipGetLastError());
+            BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
+                                    hipMemcpyDeviceToHost, c->stream));
+            BHMM_HIP(hipStreamSynchronize(c->stream));
+            if (c->h_specres[3] == 0 || c->h_specres[0] != 0)
+                break; // the serial run outright / out of tolerance: the count cannot help
+        }
         // all boundaries bit-identical: it is the serial run; else within tolerance and no
         // close decision
         done = c->h_specres[3] == 0 || (c->h_specres[0] == 0 && c->h_specres[2] == 0);

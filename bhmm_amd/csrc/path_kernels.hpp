@@ -1093,7 +1093,11 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
 // caller's pobs); EMIT_DISC -- `src` is the int32 symbol stream and the probability is read from
 // B directly (discrete.py:150-153: pobs = B[:, obs].T is a gather, there is nothing to precompute
 // -- for BASELINE configs[2] the materialised matrix would be 65 GB written and read again).
-template <int NP, int KIND = EMIT_EXPL>
+// MARGIN = false: the close-decision count is left out (a sixth of the step's instructions).  The
+// host runs this form first -- when every boundary vector comes out bit-identical to the
+// predecessor's, which is the normal case, the run IS the serial run and the count is not looked at
+// -- and repeats with MARGIN = true only otherwise.
+template <int NP, int KIND = EMIT_EXPL, bool MARGIN = true>
 __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const Chunks ch, int G,
                                                        const int64_t *toff, const void *src,
                                                        int W, double margin, uint8_t *ptr,
@@ -1182,13 +1186,15 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
                 if (s >= nw) {
                     if (real)
                         ptr[(gs + s) * n + j] = (uint8_t)ii[0];
-                    // candidates within `margin` of the winner: must be the winner alone
-                    const double thr = hh[0] - margin * hh[0];
-                    int cnt = 0;
+                    if constexpr (MARGIN) {
+                        // candidates within `margin` of the winner: must be the winner alone
+                        const double thr = hh[0] - margin * hh[0];
+                        int cnt = 0;
 #pragma unroll
-                    for (int i = 0; i < NP; ++i)
-                        cnt += (h0[i] >= thr) ? 1 : 0;
-                    low |= real && cnt != 1;
+                        for (int i = 0; i < NP; ++i)
+                            cnt += (h0[i] >= thr) ? 1 : 0;
+                        low |= real && cnt != 1;
+                    }
                 }
                 vn = p * xv[gi][ii[0]] * sA[ii[0] * NP + j]; // _hidden.c:253: (p v[i^]) A[i^][j]
             }
