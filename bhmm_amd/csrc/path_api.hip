@@ -333,13 +333,16 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
             BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
                                    hipHostMallocDefault));
         const Chunks chs = chunks_pub(c);
+        // discrete: B in LDS when it is small enough to leave four wavefronts per SIMD their room
+        const size_t smB = (disc_direct && (size_t)n * c->M * sizeof(double) <= 16 * 1024)
+                               ? (size_t)n * c->M * sizeof(double) : 0;
         // first without the close-decision count; bit-identical boundaries make it irrelevant
         for (int pass = 0; pass < 2; ++pass) {
             BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
 #define BHMM_VC(KINDV, MARGINV)                                                                     \
-    hipLaunchKernelGGL((k_viterbi_chunks<8, KINDV, MARGINV>), dim3((c->G + 7) / 8), dim3(64), 0,    \
+    hipLaunchKernelGGL((k_viterbi_chunks<8, KINDV, MARGINV>), dim3((c->G + 7) / 8), dim3(64), smB,  \
                        c->stream, m, chs, c->G, off, obs, c->spec_W, margin, ptr, last,             \
-                       c->d_aentry.p, c->d_aexit.p, c->d_specres.p)
+                       c->d_aentry.p, c->d_aexit.p, c->d_specres.p, smB ? 1 : 0)
             if (disc_direct) {
                 if (pass == 0)
                     BHMM_VC(EMIT_DISC, false);

@@ -1102,7 +1102,8 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
                                                        const int64_t *toff, const void *src,
                                                        int W, double margin, uint8_t *ptr,
                                                        int32_t *last_state, double *v_entry,
-                                                       double *v_exit, unsigned int *flags)
+                                                       double *v_exit, unsigned int *flags,
+                                                       int b_in_lds)
 {
     static_assert(KIND == EMIT_EXPL || KIND == EMIT_DISC, "gaussian rows are precomputed");
     [[maybe_unused]] const double *pobs = static_cast<const double *>(src);
@@ -1114,9 +1115,18 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
     // A for the winner's factor: the select tree below carries only (product, index); v[i^] and
     // A[i^][j] are looked up afterwards (two LDS reads instead of four more registers per select)
     __shared__ double sA[NP * NP];
+    extern __shared__ double sBdyn[]; // discrete: B [n][M] when the launch provides the room
     const int lane = threadIdx.x;
     for (int e = lane; e < NP * NP; e += 64)
         sA[e] = (e / NP < m.n && e % NP < m.n) ? m.A[(int64_t)(e / NP) * m.n + e % NP] : 0.0;
+    [[maybe_unused]] const double *sBd = nullptr;
+    if constexpr (KIND == EMIT_DISC) {
+        if (b_in_lds) {
+            for (int e = lane; e < m.n * m.M; e += 64)
+                sBdyn[e] = m.B[e];
+            sBd = sBdyn;
+        }
+    }
     __syncthreads();
     const int gi = lane / NP, j = lane % NP;
     const int64_t g = (int64_t)blockIdx.x * GP + gi;
@@ -1137,17 +1147,39 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
         const int64_t gs = goff - nw;
         const int steps = nw + len;
         double v = real ? 1.0 / (double)n : 0.0;
-        auto emission = [&](int64_t t) -> double {
+        // what a step reads from memory is requested VPF steps ahead (it does not depend on the
+        // recursion): the emission probability itself, or -- discrete -- the symbol, whose
+        // probability then comes from B in LDS (or, for alphabets too large for it, from L2)
+        constexpr int VPF = 4;
+        double pring[VPF];
+        int sring[VPF];
+        auto request = [&](int q, int sidx) {
+            const int64_t t = gs + (sidx < steps ? sidx : steps - 1);
             if constexpr (KIND == EMIT_DISC)
-                return real ? m.B[(int64_t)j * m.M + syms[t]] : 0.0;
+                sring[q] = syms[t];
             else
-                return real ? pobs[t * n + j] : 0.0;
+                pring[q] = real ? pobs[t * n + j] : 0.0;
         };
-        double p_next = emission(gs);
-        for (int s = 0; s < steps; ++s) {
-            const double p = p_next;
-            if (s + 1 < steps)
-                p_next = emission(gs + s + 1); // independent of the recursion
+#pragma unroll
+        for (int q = 0; q < VPF; ++q) {
+            pring[q] = 0.0;
+            sring[q] = 0;
+            request(q, q);
+        }
+        for (int sb = 0; sb < steps; sb += VPF) {
+#pragma unroll
+        for (int qq = 0; qq < VPF; ++qq) {
+            const int s = sb + qq;
+            if (s >= steps)
+                break;
+            double p;
+            if constexpr (KIND == EMIT_DISC) {
+                const int sym = sring[qq];
+                p = !real ? 0.0 : (sBd ? sBd[j * m.M + sym] : m.B[(int64_t)j * m.M + sym]);
+            } else {
+                p = pring[qq];
+            }
+            request(qq, s + VPF);
             double vn;
             if (exact && s == 0) {
                 vn = p * pi_j; // _hidden.c:232
@@ -1215,6 +1247,7 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
             v = vn / S;
             if (s == nw - 1)
                 v_entry[g * NP + j] = v; // the vector this chunk starts from
+        }
         }
         v_exit[g * NP + j] = v;
         if (t0 + len == toff[k + 1] - toff[k]) { // last chunk of the trajectory: final state
