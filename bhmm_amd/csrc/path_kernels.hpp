@@ -948,7 +948,7 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
         if constexpr (KIND == EMIT_GAUSS) {
             const double o = static_cast<const double *>(obs_rm)[gt];
             const double d = (o - mu_j) / sg_j;
-            p = real ? cn_j * exp(-0.5 * d * d) : 0.0; // _gaussian.c:18-20
+            p = real ? cn_j * exp_nonpos(-0.5 * d * d) : 0.0; // _gaussian.c:18-20
             if ((__ballot(p != 0.0) & gmask) == 0ull)
                 p = real ? 1.0 : 0.0;
         } else if constexpr (KIND == EMIT_DISC) {
@@ -1366,7 +1366,7 @@ __global__ void k_pobs_all(const WideModel m, const void *obs_rm, int64_t total,
         double s = 0.0;
         for (int j = 0; j < n; ++j) {
             const double d = (o - m.mu[j]) / m.sigma[j];
-            const double p = m.cnorm[j] * exp(-0.5 * d * d);
+            const double p = m.cnorm[j] * exp_nonpos(-0.5 * d * d);
             pobs[t * n + j] = p;
             s = (p != 0.0) ? 1.0 : s;
         }
@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_pobs_lanes(const WideModel m, const voi
     if constexpr (KIND == EMIT_GAUSS) {
         const double o = static_cast<const double *>(obs_rm)[t];
         const double d = (o - m.mu[j]) / m.sigma[j];
-        double p = m.cnorm[j] * exp(-0.5 * d * d);
+        double p = m.cnorm[j] * exp_nonpos(-0.5 * d * d);
         const unsigned long long nzm = __ballot(p != 0.0);
         const int lane = threadIdx.x & 63;
         const unsigned long long grp = (NL == 64 ? ~0ull : ((1ull << NL) - 1)) << (lane / NL * NL);
