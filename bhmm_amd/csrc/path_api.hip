@@ -261,8 +261,9 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     // emission probabilities in a separate, fully parallel pass when the (total, n) matrix
     // fits (it is what the reference materialises anyway, maximum_likelihood.py:345-347)
     int vkind = c->kind;
-    // discrete, n <= 8 with a chunk plan: the chunk-parallel kernel gathers from B itself
-    const bool disc_direct = !c->wide && c->kind == EMIT_DISC && c->spec_enabled && c->G > K;
+    // n <= 8 with a chunk plan: the chunk-parallel kernel evaluates the emission itself (gathers
+    // from B / evaluates the gaussian density): no (total, n) emission matrix is written and re-read
+    const bool disc_direct = !c->wide && c->kind != EMIT_EXPL && c->spec_enabled && c->G > K;
     if (c->kind != EMIT_EXPL && !disc_direct) {
         size_t freeb = 0, totb = 0;
         const size_t need = (size_t)c->total * n * sizeof(double);
@@ -334,7 +335,8 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                                    hipHostMallocDefault));
         const Chunks chs = chunks_pub(c);
         // discrete: B in LDS when it is small enough to leave four wavefronts per SIMD their room
-        const size_t smB = (disc_direct && (size_t)n * c->M * sizeof(double) <= 16 * 1024)
+        const size_t smB = (disc_direct && c->kind == EMIT_DISC &&
+                            (size_t)n * c->M * sizeof(double) <= 16 * 1024)
                                ? (size_t)n * c->M * sizeof(double) : 0;
         // first without the close-decision count; bit-identical boundaries make it irrelevant
         for (int pass = 0; pass < 2; ++pass) {
@@ -343,11 +345,16 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     hipLaunchKernelGGL((k_viterbi_chunks<8, KINDV, MARGINV>), dim3((c->G + 7) / 8), dim3(64), smB,  \
                        c->stream, m, chs, c->G, off, obs, c->spec_W, margin, ptr, last,             \
                        c->d_aentry.p, c->d_aexit.p, c->d_specres.p, smB ? 1 : 0)
-            if (disc_direct) {
+            if (disc_direct && c->kind == EMIT_DISC) {
                 if (pass == 0)
                     BHMM_VC(EMIT_DISC, false);
                 else
                     BHMM_VC(EMIT_DISC, true);
+            } else if (disc_direct) {
+                if (pass == 0)
+                    BHMM_VC(EMIT_GAUSS, false);
+                else
+                    BHMM_VC(EMIT_GAUSS, true);
             } else {
                 if (pass == 0)
                     BHMM_VC(EMIT_EXPL, false);

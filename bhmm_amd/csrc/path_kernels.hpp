@@ -1105,7 +1105,8 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
                                                        double *v_exit, unsigned int *flags,
                                                        int b_in_lds)
 {
-    static_assert(KIND == EMIT_EXPL || KIND == EMIT_DISC, "gaussian rows are precomputed");
+    // EMIT_GAUSS: `src` is the observation stream, the density of the lane's state is evaluated in
+    // the step (same arithmetic as k_pobs_lanes, outlier rule by a ballot over the chunk's lanes)
     [[maybe_unused]] const double *pobs = static_cast<const double *>(src);
     [[maybe_unused]] const int32_t *syms = static_cast<const int32_t *>(src);
     constexpr int GP = 64 / NP;
@@ -1157,9 +1158,16 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
             const int64_t t = gs + (sidx < steps ? sidx : steps - 1);
             if constexpr (KIND == EMIT_DISC)
                 sring[q] = syms[t];
+            else if constexpr (KIND == EMIT_GAUSS)
+                pring[q] = pobs[t]; // the observation
             else
                 pring[q] = real ? pobs[t * n + j] : 0.0;
         };
+        [[maybe_unused]] const double mu_j = (KIND == EMIT_GAUSS && real) ? m.mu[j] : 0.0;
+        [[maybe_unused]] const double sg_j = (KIND == EMIT_GAUSS && real) ? m.sigma[j] : 1.0;
+        [[maybe_unused]] const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
+        [[maybe_unused]] const unsigned long long grp =
+            (NP == 64 ? ~0ull : ((1ull << NP) - 1)) << (lane / NP * NP);
 #pragma unroll
         for (int q = 0; q < VPF; ++q) {
             pring[q] = 0.0;
@@ -1176,6 +1184,11 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
             if constexpr (KIND == EMIT_DISC) {
                 const int sym = sring[qq];
                 p = !real ? 0.0 : (sBd ? sBd[j * m.M + sym] : m.B[(int64_t)j * m.M + sym]);
+            } else if constexpr (KIND == EMIT_GAUSS) {
+                const double d = (pring[qq] - mu_j) / sg_j; // _gaussian.c:18-20
+                p = real ? cn_j * exp_nonpos(-0.5 * d * d) : 0.0;
+                if ((__ballot(p != 0.0) & grp) == 0ull)
+                    p = real ? 1.0 : 0.0; // outputmodel.py:126-130
             } else {
                 p = pring[qq];
             }
