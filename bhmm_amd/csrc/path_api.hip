@@ -497,17 +497,25 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
                            (const int64_t *)c->d_soff.p);
     BHMM_HIP(hipGetLastError());
     if (counts || n0 || emis || stats_dev) {
-        const size_t sm = esz * sizeof(double) + nstat * sizeof(unsigned int);
+        // the per-trajectory emission table in LDS, or -- alphabets too large for it -- in epart itself
+        const bool gtab = c->kind == EMIT_DISC &&
+                          esz * sizeof(double) + nstat * sizeof(unsigned int) > (size_t)150 * 1024;
+        const size_t sm = (gtab ? 0 : esz * sizeof(double)) + nstat * sizeof(unsigned int);
+        if (gtab)
+            BHMM_HIP(hipMemsetAsync(epart, 0, (size_t)K * esz * sizeof(double), c->stream));
         const void *obs = c->d_obs_rm.p;
         if (c->kind == EMIT_GAUSS)
             hipLaunchKernelGGL((k_wide_path_stats<EMIT_GAUSS>), dim3(K), dim3(256), sm, c->stream, m,
-                               off, obs, (const int32_t *)path, cnt, epart);
-        else if (c->kind == EMIT_DISC)
+                               off, obs, (const int32_t *)path, cnt, epart, 0);
+        else if (c->kind == EMIT_DISC) {
+            if (sm > 64 * 1024)
+                BHMM_HIP(hipFuncSetAttribute((const void *)(k_wide_path_stats<EMIT_DISC>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
             hipLaunchKernelGGL((k_wide_path_stats<EMIT_DISC>), dim3(K), dim3(256), sm, c->stream, m,
-                               off, obs, (const int32_t *)path, cnt, epart);
-        else
+                               off, obs, (const int32_t *)path, cnt, epart, gtab ? 1 : 0);
+        } else
             hipLaunchKernelGGL((k_wide_path_stats<EMIT_EXPL>), dim3(K), dim3(256), sm, c->stream, m,
-                               off, obs, (const int32_t *)path, cnt, epart);
+                               off, obs, (const int32_t *)path, cnt, epart, 0);
         BHMM_HIP(hipGetLastError());
         if (esz) {
             hipLaunchKernelGGL(k_add_partials, dim3((unsigned)esz), dim3(64), 0,

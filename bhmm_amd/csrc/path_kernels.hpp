@@ -1524,13 +1524,16 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_wide_path_stats(const WideModel m, const int64_t *off,
                                                          const void *obs_rm, const int32_t *path,
                                                          unsigned long long *counts, // [n*n+n]
-                                                         double *epart)             // [K][esz]
+                                                         double *epart,             // [K][esz]
+                                                         int table_global) // the emission table of
+                                                         // a big alphabet: epart itself (zeroed)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = m.n;
     const int esz = (KIND == EMIT_GAUSS) ? 3 * n : (KIND == EMIT_DISC ? n * m.M : 0);
-    unsigned int *cnt = reinterpret_cast<unsigned int *>(lds + esz);
-    for (int e = threadIdx.x; e < esz; e += blockDim.x)
+    const int elds = table_global ? 0 : esz;
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(lds + elds);
+    for (int e = threadIdx.x; e < elds; e += blockDim.x)
         lds[e] = 0.0;
     for (int e = threadIdx.x; e < n * n + n; e += blockDim.x)
         cnt[e] = 0u;
@@ -1550,14 +1553,19 @@ __global__ __launch_bounds__(256) void k_wide_path_stats(const WideModel m, cons
             atomicAdd(&lds[n + st], d);
             atomicAdd(&lds[2 * n + st], d * d);
         }
-        if constexpr (KIND == EMIT_DISC)
-            atomicAdd(&lds[(int64_t)st * m.M + static_cast<const int32_t *>(obs_rm)[o0 + t]], 1.0);
+        if constexpr (KIND == EMIT_DISC) {
+            const int64_t e = (int64_t)st * m.M + static_cast<const int32_t *>(obs_rm)[o0 + t];
+            if (table_global)
+                atomicAdd(&epart[(int64_t)blockIdx.x * esz + e], 1.0); // integer-valued: exact
+            else
+                atomicAdd(&lds[e], 1.0);
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n * n + n; e += blockDim.x)
         if (cnt[e])
             atomicAdd(&counts[e], (unsigned long long)cnt[e]);
-    for (int e = threadIdx.x; e < esz; e += blockDim.x)
+    for (int e = threadIdx.x; e < elds; e += blockDim.x)
         epart[(int64_t)k * esz + e] = lds[e];
 }
 

@@ -468,3 +468,38 @@ def test_discrete_viterbi_one_million_steps():
         o = obs[k * T:(k + 1) * T].cpu().numpy()
         assert np.array_equal(paths[k], orc.viterbi(A_eval, orc.pobs_discrete(o, B_eval), pi))
     eng.close()
+
+
+def test_wide_family_large_alphabet():
+    """16 states (the 9..64-state kernels) with 5000 symbols: E-step, Viterbi and the Gibbs step
+    with its symbol-count table beyond the LDS (per-trajectory tables in global memory)."""
+    rng = np.random.default_rng(16)
+    n, M = 16, 5000
+    A = rng.random((n, n)) + 4 * np.eye(n)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    B = rng.dirichlet(np.full(M, 0.05), size=n) + 1e-9
+    B /= B.sum(axis=1, keepdims=True)
+    obs = [rng.integers(0, M, T).astype(np.int32) for T in (3000, 777, 1)]
+    ref = orc.estep("discrete", obs, A, pi, B, want_gamma=True)
+    eng = _engine()
+    eng.set_observations("discrete", obs, n, nsymbols=M)
+    res = eng.estep(A, pi, B)
+    np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-9)
+    np.testing.assert_allclose(res.C, ref["C"], rtol=1e-9, atol=1e-12)
+    cnt = np.zeros((n, M))
+    for o, g in zip(obs, ref["gammas"]):
+        orc.update_pout(o, g, cnt)
+    np.testing.assert_allclose(res.symbol_counts, cnt, rtol=1e-9, atol=1e-12)
+    pobs = [orc.pobs_discrete(o, B) for o in obs]
+    for p, pb in zip(eng.viterbi(A, pi, B), pobs):
+        assert np.array_equal(p, orc.viterbi(A, pb, pi))
+    u = [rng.random(len(o)) for o in obs]
+    sp, C, n0, emis = eng.sample_paths(A, pi, B, u=u)
+    refp = [orc.sample_path(orc.forward(A, pb, pi)[1], A, u=uu) for pb, uu in zip(pobs, u)]
+    assert all(np.array_equal(a, b) for a, b in zip(sp, refp))
+    er = np.zeros((n, M))
+    for p, o in zip(refp, obs):
+        np.add.at(er, (p, o), 1.0)
+    assert np.array_equal(emis, er)
+    eng.close()
