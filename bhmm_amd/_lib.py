@@ -95,6 +95,8 @@ SIGNATURES = {
     "bhmm_mle_reversible": (ctypes.c_int, [c_double_p, c_int64_p, c_double_p, ctypes.c_int,
                                            ctypes.c_int64, ctypes.c_double]),
     "bhmm_diag_exp_nonpos": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int64]),
+    "bhmm_diag_gauss_pdf": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int64, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_int]),
 }
 
 _lib = None

@@ -1152,18 +1152,21 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     const size_t ci_elems = (size_t)ci_records(c) * 64;
     const Chunks ch = chunks_of(c);
     const int nblk = c->Gp / BLOCK;
+    if ((rc = c->d_obsnan.ensure(1)))
+        return rc;
+    BHMM_HIP(hipMemsetAsync(c->d_obsnan.p, 0, sizeof(int32_t), c->stream));
     if (kind == BHMM_EMIT_GAUSSIAN) {
         if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(double))))
             return rc;
         hipLaunchKernelGGL((k_pack_scalar<double>), dim3(nblk), dim3(BLOCK), 0, c->stream, ch,
                            reinterpret_cast<const double *>(src_dev),
-                           reinterpret_cast<double *>(c->d_obs_ci.p));
+                           reinterpret_cast<double *>(c->d_obs_ci.p), c->d_obsnan.p);
     } else if (kind == BHMM_EMIT_DISCRETE) {
         if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(int32_t))))
             return rc;
         hipLaunchKernelGGL((k_pack_scalar<int32_t>), dim3(nblk), dim3(BLOCK), 0, c->stream, ch,
                            reinterpret_cast<const int32_t *>(src_dev),
-                           reinterpret_cast<int32_t *>(c->d_obs_ci.p));
+                           reinterpret_cast<int32_t *>(c->d_obs_ci.p), c->d_obsnan.p);
     } else {
         if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(double) * c->N)))
             return rc;
@@ -1178,7 +1181,12 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
             return rc;
         BHMM_HIP(hipMemcpyAsync(c->d_obs_rm.p, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
     }
+    int32_t has_nan = 0;
+    BHMM_HIP(hipMemcpyAsync(&has_nan, c->d_obsnan.p, sizeof(int32_t), hipMemcpyDeviceToHost,
+                            c->stream));
     BHMM_HIP(hipStreamSynchronize(c->stream));
+    if (kind == BHMM_EMIT_GAUSSIAN && has_nan)
+        c->careful = true; // gauss_pdf(): the branch-free kernels take NaN for a perfect hit
     return BHMM_OK;
 }
 
@@ -1259,6 +1267,32 @@ int bhmm_ctx_set_observations_lagged(bhmm_ctx *c, int kind, const void *obs, con
     BHMM_HIP(hipGetLastError());
     BHMM_HIP(hipStreamSynchronize(c->stream)); // the host tables are temporaries
     return bhmm_ctx_set_observations(c, kind, d_dst.p, dst_off.data(), V, nstates, nsymbols, chunk, 1);
+}
+
+int bhmm_diag_gauss_pdf(double *y, const double *o, int64_t n, double mu, double sigma,
+                        int nansafe)
+{
+    if (!y || !o || n < 0)
+        return invalid("bhmm_diag_gauss_pdf: bad arguments");
+    Model<2> m;
+    const double A[1] = {1.0}, pi[1] = {1.0};
+    fill_model<2>(m, 1, EMIT_GAUSS, 0, A, pi, &mu, &sigma);
+    double *dx = nullptr, *dy = nullptr;
+    hipError_t e = hipMalloc(&dx, n * sizeof(double));
+    if (e == hipSuccess)
+        e = hipMalloc(&dy, n * sizeof(double));
+    if (e == hipSuccess)
+        e = hipMemcpy(dx, o, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gauss_pdf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, dy,
+                           n, m.e0[0], m.e4[0], m.e5[0], m.emg, nansafe);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(y, dy, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    return e == hipSuccess ? BHMM_OK : hip_fail(e, "bhmm_diag_gauss_pdf");
 }
 
 int bhmm_diag_exp_nonpos(double *y, const double *x, int64_t n)

@@ -87,6 +87,7 @@ struct bhmm_ctx {
     bhmm::DevBuf<char> d_scratch;    // paths, uniforms, pointer tables ...
     bhmm::DevBuf<char> d_scratch2;
     bhmm::DevBuf<int64_t> d_offsets; // [K+1] trajectory offsets (time steps)
+    bhmm::DevBuf<int32_t> d_obsnan;  // [1] set by the upload if a gaussian observation is NaN
     bhmm::DevBuf<int64_t> d_soff;    // [K] position of each trajectory in the device random stream
                                      // (unset: its offset here; a sharded caller sets global ones)
     bhmm::DevBuf<double> d_Brm;      // [n][M] emission matrix, row-major (path kernels)

@@ -47,6 +47,10 @@ struct Model {
     double e1[N]; // gaussian: 1/sigma
     double e2[N]; // gaussian: 1/(sqrt(2 pi) sigma)      (_gaussian.c:18)
     double e3[N]; // gaussian: sigma (the bit-exact path kernels divide by it)
+    double e4[N]; // gaussian, gauss_pdf(): log2(e) / (2 sigma^2) / 4096
+    double e5[N]; // gaussian, gauss_pdf(): (emg_s - log2 e2) / 4096 >= 0; 1 for a padded state
+    double emg;   // gaussian, gauss_pdf(): 1.5 * 2^40 + emg_s / 4096, emg_s = ceil(log2(max e2)); NaN if a
+                  // sigma is not a positive finite number
     int nreal;
     int M; // number of symbols (discrete)
     int dcopies; // k_estep, discrete: LDS count tables per workgroup (one per wavefront, or 1)
@@ -1234,15 +1238,23 @@ __global__ __launch_bounds__(64) void k_forget_probe(const Model<N> m, const voi
 // =========================================================================================
 // layout conversion kernels (one lane per chunk; CI side is coalesced)
 // =========================================================================================
+// has_nan (gaussian observations): set to 1 if some observation is NaN -- the context then stays on
+// the CAREFUL kernels, whose densities keep NaN apart from a perfect hit (gauss_pdf, estep_sweep.hpp)
 template <typename T>
-__global__ void k_pack_scalar(const Chunks ch, const T *src, T *dst_ci)
+__global__ void k_pack_scalar(const Chunks ch, const T *src, T *dst_ci, int32_t *has_nan)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int len = ch.len[g];
     const int64_t off = ch.goff[g];
-    for (int s = 0; s < len; ++s)
-        dst_ci[ci_rec(g, s, ch.Lmax) * 64 + lane] = src[off + s];
+    bool nan = false;
+    for (int s = 0; s < len; ++s) {
+        const T v = src[off + s];
+        nan |= v != v;
+        dst_ci[ci_rec(g, s, ch.Lmax) * 64 + lane] = v;
+    }
+    if (nan)
+        *has_nan = 1;
 }
 
 // rows of nreal doubles (row-major) -> CI records of N doubles (zero padded)

@@ -59,6 +59,72 @@ __device__ __forceinline__ double exp_nonpos(double x)
         y[i] = exp_nonpos(x[i]);
 }
 
+// Gaussian density of one state, cn exp(-(o - mu)^2 / (2 sigma^2)), in 7 + GAUSS_PDF_DEG VALU
+// instructions (cn * exp_nonpos(d * d * nh) takes 23; the two densities per lane and step were 57 %
+// of the forward sweep's instruction stream).  With v = log2 of the density and s the integer
+// emg_s >= log2 of the largest cn (host_common.hpp: fill_model):
+//   u = clamp(a d^2 + b)        = (s - v) / 4096 in [0, 1]; the clamp is an output modifier
+//   t = MG - u                  MG = 1.5 2^40 + s / 4096: t rounds to a multiple of 2^-12, the low
+//                               dword of its mantissa is s + k', k' = rint(v - s), and
+//                               t - MG = k' / 4096 exactly
+//   w = u + (t - MG)            = -(v - s - k') / 4096 = -f / 4096 exactly, |f| <= 1/2
+//   p = 2^(s + k') P(w)         P(w) = 2^f: minimax polynomial of tools/gen_exp2_poly.py in the
+//                               exactly rescaled variable (max. relative error 2.8e-16)
+// u above 1 (density below 2^(s - 4096), +-inf observations) gives 0 like exp(); a padded state
+// has a = 0, b = 1.  The clamp modifier turns NaN into 0 (DX10_CLAMP), which would make a NaN
+// observation a perfect hit: observations containing NaN put the context on the CAREFUL kernels at
+// upload, where NANSAFE uses an IEEE minimum instead (NaN -> u = 1 -> p = 0 -> fix_outlier turns the
+// row back into NaN).  An invalid sigma makes MG NaN and with it every density.
+#ifndef GAUSS_PDF_DEG
+#define GAUSS_PDF_DEG 10
+#endif
+template <bool NANSAFE>
+__device__ __forceinline__ double gauss_pdf(double d, double a, double b, double MG)
+{
+    const double dd = d * d;
+    double u;
+    if constexpr (NANSAFE)
+        u = fmin(fma(dd, a, b), 1.0);
+    else
+        u = fmin(fmax(fma(dd, a, b), 0.0), 1.0); // folded into the fma's clamp modifier
+    const double t = MG - u;
+    const double w = (t - MG) + u;
+#if GAUSS_PDF_DEG == 10
+    double q = 0x1.e3991e644e6abp+92;
+    q = fma(q, w, -0x1.b6740fc28f781p+84);
+    q = fma(q, w, 0x1.62c157ee59177p+76);
+    q = fma(q, w, -0x1.ffcb55e82f22cp+67);
+    q = fma(q, w, 0x1.4309126056718p+59);
+    q = fma(q, w, -0x1.5d87fe9cc5d6fp+50);
+    q = fma(q, w, 0x1.3b2ab6fbde0f7p+41);
+    q = fma(q, w, -0x1.c6b08d703d48ap+31);
+    q = fma(q, w, 0x1.ebfbdff82c3b9p+21);
+    q = fma(q, w, -0x1.62e42fefa3a17p+11);
+#else
+    double q = -0x1.e7aa0f6005d3cp+100;
+    q = fma(q, w, 0x1.e620fb765be15p+92);
+    q = fma(q, w, -0x1.b526788b3b73dp+84);
+    q = fma(q, w, 0x1.62bfc3c1c8a7cp+76);
+    q = fma(q, w, -0x1.ffcbfba7b89b6p+67);
+    q = fma(q, w, 0x1.43091310bf6b0p+59);
+    q = fma(q, w, -0x1.5d87fe78cf26dp+50);
+    q = fma(q, w, 0x1.3b2ab6fb9f413p+41);
+    q = fma(q, w, -0x1.c6b08d7049fd1p+31);
+    q = fma(q, w, 0x1.ebfbdff82c5adp+21);
+    q = fma(q, w, -0x1.62e42fefa39efp+11);
+#endif
+    q = fma(q, w, 1.0);
+    return ldexp(q, __double2loint(t));
+}
+
+[[maybe_unused]] static __global__ void k_gauss_pdf(const double *o, double *y, int64_t n, double mu,
+                                                    double a, double b, double MG, int nansafe)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        y[i] = nansafe ? gauss_pdf<true>(o[i] - mu, a, b, MG) : gauss_pdf<false>(o[i] - mu, a, b, MG);
+}
+
 // compile-time loop index helpers: unrolled<K>(f) calls f(integral_constant<int, 0..K-1>);
 // sc_at<J> says whether step J of an unrolled group rescales (the last one of every
 // ESTEP_SCALE_EVERY)
@@ -76,8 +142,9 @@ using sc_at = std::integral_constant<bool, (J % ESTEP_SCALE_EVERY) == ESTEP_SCAL
 // my two states' slice of the emission model
 struct EmisPair {
     double mu[2]; // gaussian: mean
-    double nh[2]; // gaussian: -1/(2 sigma^2)
-    double cn[2]; // gaussian: 1/(sqrt(2 pi) sigma)
+    double a[2];  // gaussian: gauss_pdf() constants of the state
+    double b[2];
+    double MG;
 };
 
 // observation at position pos of the trajectory-major copy (same concatenation as the input)
@@ -138,7 +205,7 @@ struct BtSrc {
     const double *glb;
     bool big;
 };
-template <int N, int KIND>
+template <int N, int KIND, bool NANSAFE>
 __device__ __forceinline__ void emit_raw(const ObsIn &in, const BtSrc &Bt, int q,
                                          const EmisPair &em, double (&p)[2], double (&d)[2])
 {
@@ -146,7 +213,7 @@ __device__ __forceinline__ void emit_raw(const ObsIn &in, const BtSrc &Bt, int q
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             d[b] = in.o - em.mu[b];
-            p[b] = em.cn[b] * exp_nonpos(d[b] * d[b] * em.nh[b]);
+            p[b] = gauss_pdf<NANSAFE>(d[b], em.a[b], em.b[b], em.MG);
         }
     } else if constexpr (KIND == EMIT_DISC) {
         const int64_t e = (int64_t)in.sym * N + 2 * q;
@@ -497,10 +564,11 @@ __device__ __forceinline__ void estep_body(
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         em.mu[b] = m.e0[2 * q + b];
-        em.nh[b] = -0.5 * m.e1[2 * q + b] * m.e1[2 * q + b];
-        em.cn[b] = m.e2[2 * q + b];
+        em.a[b] = m.e4[2 * q + b];
+        em.b[b] = m.e5[2 * q + b];
         pi2[b] = m.pi[2 * q + b];
     }
+    em.MG = m.emg;
     const double u0 = (2 * q < nreal) ? 1.0 / (double)nreal : 0.0;
     const double u1 = (2 * q + 1 < nreal) ? 1.0 / (double)nreal : 0.0;
 
@@ -538,7 +606,7 @@ __device__ __forceinline__ void estep_body(
                 // alpha_0 = pi o p_0, _hidden.c:28-39
                 const ObsIn in = load_obs<N, KIND>(obs_ci, rec0, cl, q);
                 double p[2], d[2];
-                emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
                 eP = scaled_emit<N, KIND, CAREFUL, true>(in, q, nreal, gmask, pi2, p, a, hmin);
                 *ci_pair(ws, rec0, N, q, cl) = make_double2(a[0], a[1]);
                 if constexpr (PHASE == PH_P1)
@@ -554,7 +622,7 @@ __device__ __forceinline__ void estep_body(
                         double p[2], d[2], sv[2], af[N];
                         gather(a, af);
                         sched_fence();
-                        emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                        emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
                         sched_fence();
                         fwd_dot<N>(af, Ac, sv);
                         (void)scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask,
@@ -563,7 +631,7 @@ __device__ __forceinline__ void estep_body(
                     if ((int64_t)nw == t0) {
                         const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
                         double p[2], d[2];
-                        emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                        emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
                         (void)scaled_emit<N, KIND, CAREFUL, true>(in, q, nreal, gmask, pi2, p, a, hmin);
                         ++pos;
                         --nw;
@@ -625,7 +693,7 @@ __device__ __forceinline__ void estep_body(
                 double p[2], d[2], sv[2], af[N];
                 gather(a, af);
                 sched_fence();
-                emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
                 sched_fence();
                 fwd_dot<N>(af, Ac, sv);
                 eP += scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask, sv, p,
@@ -774,7 +842,7 @@ __device__ __forceinline__ void estep_body(
             b2[1] = u1;
             auto wstep = [&](const ObsIn &in, auto sc) {
                 double p[2], d[2], bf[N], r[2], bn[2];
-                emit_raw<N, KIND>(in, Bt, q, em, p, d);
+                emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
                 int unused = 0;
                 beta_step<N, KIND, CAREFUL, decltype(sc)::value>(gather, in, q, nreal, gmask, Ar, p,
                                                                  b2, bf, r, bn, hmin, unused);
@@ -884,7 +952,7 @@ __device__ __forceinline__ void estep_body(
         };
         auto bstep = [&](const ObsIn &in, const double2 &apv, double2 *gdst, auto sc) {
             double p[2], d[2];
-            emit_raw<N, KIND>(in, Bt, q, em, p, d);
+            emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
             bcore(in, p, d, apv, gdst, sc);
         };
         // steps s and s-1 from the stored row alpha_{s-2}: alpha_{s-1} = (alpha_{s-2} A) o p_{s-1}
@@ -934,8 +1002,8 @@ __device__ __forceinline__ void estep_body(
             double p_hi[2], d_hi[2], p_lo[2], d_lo[2], sv[2], ah[2];
             const double al[2] = {alo.x, alo.y};
             if constexpr (CAREFUL && KIND == EMIT_GAUSS) {
-                emit_raw<N, KIND>(hi, Bt, q, em, p_hi, d_hi);
-                emit_raw<N, KIND>(lo, Bt, q, em, p_lo, d_lo);
+                emit_raw<N, KIND, CAREFUL>(hi, Bt, q, em, p_hi, d_hi);
+                emit_raw<N, KIND, CAREFUL>(lo, Bt, q, em, p_lo, d_lo);
                 fwd_matvec<N>(gather, al, Ac, sv);
                 int unused = 0x7fffffff;
                 (void)scaled_emit<N, KIND, CAREFUL, false>(lo, q, nreal, gmask, sv, p_lo, ah,
@@ -946,7 +1014,7 @@ __device__ __forceinline__ void estep_body(
                 double afl[N], bf[N];
                 gather(al, afl); // (1) alpha_{s-2}, for the rebuild
                 sched_fence();
-                emit_raw<N, KIND>(hi, Bt, q, em, p_hi, d_hi);
+                emit_raw<N, KIND, CAREFUL>(hi, Bt, q, em, p_hi, d_hi);
                 sched_fence();
                 fwd_dot<N>(afl, Ac, sv);
                 consume(hi, d_hi, gdst);
@@ -955,7 +1023,7 @@ __device__ __forceinline__ void estep_body(
                     gather(bb, bf); // (2) p o beta of step s
                 }
                 sched_fence();
-                emit_raw<N, KIND>(lo, Bt, q, em, p_lo, d_lo);
+                emit_raw<N, KIND, CAREFUL>(lo, Bt, q, em, p_lo, d_lo);
                 sched_fence();
                 ah[0] = sv[0] * p_lo[0];
                 ah[1] = sv[1] * p_lo[1];
@@ -979,16 +1047,16 @@ __device__ __forceinline__ void estep_body(
             const double al[2] = {alo.x, alo.y};
             gather(al, af); // alpha_{s-4}
             sched_fence();
-            emit_raw<N, KIND>(x0, Bt, q, em, p0, d0);
-            emit_raw<N, KIND>(x1, Bt, q, em, p1, d1);
+            emit_raw<N, KIND, CAREFUL>(x0, Bt, q, em, p0, d0);
+            emit_raw<N, KIND, CAREFUL>(x1, Bt, q, em, p1, d1);
             sched_fence();
             fwd_dot<N>(af, Ac, sv);
             a1[0] = sv[0] * p0[0]; // alpha_{s-3}
             a1[1] = sv[1] * p0[1];
             gather(a1, af);
             sched_fence();
-            emit_raw<N, KIND>(x2, Bt, q, em, p2, d2);
-            emit_raw<N, KIND>(x3, Bt, q, em, p3, d3);
+            emit_raw<N, KIND, CAREFUL>(x2, Bt, q, em, p2, d2);
+            emit_raw<N, KIND, CAREFUL>(x3, Bt, q, em, p3, d3);
             sched_fence();
             fwd_dot<N>(af, Ac, sv);
             a2[0] = sv[0] * p1[0]; // alpha_{s-2}

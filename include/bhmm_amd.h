@@ -240,6 +240,10 @@ int bhmm_mle_reversible(double *P, int64_t *iterations, const double *C, int n, 
 /* diagnostics: y[i] = the E-step kernels' exp() for non-positive arguments (the exponential
  * of the gaussian density, _gaussian.c:18), so that tests can bound its error in ulps */
 int bhmm_diag_exp_nonpos(double *y, const double *x, int64_t n);
+/* y[i] = the E-step kernels' gaussian density of observation o[i] for one state (mu, sigma)
+ * (_gaussian.c:18-20); nansafe = the variant of the per-step-checked kernels */
+int bhmm_diag_gauss_pdf(double *y, const double *o, int64_t n, double mu, double sigma,
+                        int nansafe);
 
 #ifdef __cplusplus
 }

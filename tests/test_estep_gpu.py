@@ -285,6 +285,68 @@ def test_exp_of_gaussian_density_is_ulp_accurate():
     assert y[0 + np.flatnonzero(x == 0.0)[0]] == 1.0
 
 
+@pytest.mark.parametrize("mu,sigma", [(0.3, 1.7), (-5.0, 1e-3), (100.0, 25.0), (1.0, 1e3), (0.0, 1.0)])
+def test_gaussian_density_of_the_sweep(mu, sigma):
+    """gauss_pdf (estep_sweep.hpp): the density of _gaussian.c:18-20 with constant, exponent and
+    range reduction fused.  Against 80-bit arithmetic: a few 1e-16 plus the rounding of the
+    exponent's argument (which libm's exp(-z*z/2) carries as well); exact zeros far out and for
+    infinite observations; NaN is kept apart from a hit by the variant of the checked kernels."""
+    from bhmm_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(11)
+    z = np.concatenate([rng.uniform(-8, 8, 200000), rng.uniform(-38.6, 38.6, 100000),
+                        rng.normal(0, 1e-6, 1000), rng.uniform(-47, 47, 20000),
+                        np.array([0.0, 1e-160, 39.0, 45.0, 60.0, 91.0, 1e5, 1e9, 1e150, 1e200])])
+    o = mu + sigma * z
+    for nansafe in (0, 1):
+        y = np.empty_like(o)
+        _lib.check(L.bhmm_diag_gauss_pdf(_lib.dp(y), _lib.dp(o), o.size, mu, sigma, nansafe))
+        ol, ml, sl = o.astype(np.longdouble), np.longdouble(mu), np.longdouble(sigma)
+        x = ((ol - ml) / sl) ** 2 / 2
+        ref = np.exp(-x) / (np.sqrt(2 * np.pi * np.longdouble(1)) * sl)
+        normal = ref > 2.3e-308
+        rel = np.abs((y[normal] - ref[normal]) / ref[normal]).astype(float)
+        bound = 6e-16 + 4e-16 * x[normal].astype(float)
+        assert np.all(rel <= bound), (rel / bound).max()
+        sub = ref[~normal].astype(float)
+        assert np.all(np.abs(y[~normal] - sub) <= 4.95e-324 * 2 + 3e-13 * sub)
+        assert np.all(y[np.abs(z) > 50] == 0.0)
+        special = np.array([np.inf, -np.inf, np.nan])
+        ys = np.empty(3)
+        _lib.check(L.bhmm_diag_gauss_pdf(_lib.dp(ys), _lib.dp(special), 3, mu, sigma, nansafe))
+        assert ys[0] == 0.0 and ys[1] == 0.0
+        if nansafe:
+            assert ys[2] == 0.0  # -> all-zero row -> fix_outlier restores the NaN
+    # an invalid sigma poisons every density
+    for bad in (0.0, -1.0, np.nan, np.inf):
+        yb = np.empty(4)
+        _lib.check(L.bhmm_diag_gauss_pdf(_lib.dp(yb), _lib.dp(np.array([0.0, 1.0, -3.0, 1e9])), 4, mu, bad, 0))
+        assert np.all(np.isnan(yb))
+
+
+def test_nan_observation_is_not_a_hit(golden):
+    """A NaN observation must poison its trajectory (the reference's pobs row is NaN) on every
+    path that evaluates the density with the clamp modifier: the upload finds it and keeps the
+    context on the checked kernels."""
+    g = golden("g8_ragged")
+    obs = split(g["obs"], g["lengths"])
+    obs = [o.copy() for o in obs]
+    obs[1][len(obs[1]) // 2] = np.nan
+    eng = _engine()
+    eng.set_observations("gaussian", obs, 8, chunk=16)
+    assert eng.get_option("careful") == 1.0
+    margs = (g["A"], g["pi"], g["mu"], g["sigma"])
+    with pytest.raises(AssertionError):
+        eng.estep(*margs)
+    ok = [o for i, o in enumerate(obs) if i != 1]
+    eng.set_observations("gaussian", ok, 8, chunk=16)
+    assert eng.get_option("careful") == 0.0
+    res = eng.estep(*margs)
+    ref = orc.estep("gaussian", ok, *margs)
+    np.testing.assert_allclose(res.loglik, ref["logL"].sum(), rtol=1e-11)
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # The statistics-only E-step (no gamma rows) runs the branch-free instantiation of k_estep: every
 # second alpha row in HBM, rescaling every 4th step, zero / tiny vectors only reported.  The tests
