@@ -14,6 +14,34 @@ namespace bhmm {
 
 inline int pad_states(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : 8); }
 
+// Constants of gauss_pdf() (estep_sweep.hpp): p = 2^(s - 4096 u), u = a (o - mu)^2 + b, for n real
+// states (npad >= n entries are written: padded states get a = 0, b = 1, i.e. p = 0); computed in
+// extended precision and rounded once.  An invalid sigma makes MG NaN (every density NaN).
+inline void gauss_pdf_constants(int n, int npad, const double *sigma, double *a, double *b, double *MG)
+{
+    const long double sqrt2pi = sqrtl(2.0L * 3.14159265358979323846264338327950288L);
+    bool valid = true;
+    long double cmax = 0.0L;
+    for (int i = 0; i < n; ++i) {
+        const long double sg = sigma[i];
+        valid = valid && sg > 0.0L && std::isfinite(sigma[i]) && std::isfinite((double)(1.0L / (sqrt2pi * sg)));
+        if (valid)
+            cmax = std::max(cmax, 1.0L / (sqrt2pi * sg));
+    }
+    const long double s = valid ? ceill(log2l(cmax)) : 0.0L;
+    for (int i = 0; i < npad; ++i) {
+        if (i < n && valid) {
+            const long double sg = sigma[i];
+            a[i] = (double)(1.44269504088896340735992468100189214L / (2.0L * sg * sg) / 4096.0L);
+            b[i] = (double)((s - log2l(1.0L / (sqrt2pi * sg))) / 4096.0L);
+        } else {
+            a[i] = 0.0;
+            b[i] = 1.0;
+        }
+    }
+    *MG = valid ? (double)(1649267441664.0L + s / 4096.0L) : std::numeric_limits<double>::quiet_NaN();
+}
+
 // ---- model marshalling -----------------------------------------------------------------
 template <int N>
 inline void fill_model(Model<N> &m, int n, int kind, int M, const double *A, const double *pi,
@@ -35,32 +63,8 @@ inline void fill_model(Model<N> &m, int n, int kind, int M, const double *A, con
             m.e2[i] = 1.0 / (sqrt(2.0 * M_PI) * par1[i]); // _gaussian.c:18
             m.e3[i] = par1[i];
         }
-    if (kind == EMIT_GAUSS) {
-        // gauss_pdf() (estep_sweep.hpp): p = 2^(s - 4096 u), u = e4 (o - mu)^2 + e5 -- the constants in
-        // extended precision, rounded once
-        bool valid = true;
-        long double cmax = 0.0L;
-        for (int i = 0; i < n; ++i) {
-            const long double sg = par1[i];
-            valid = valid && sg > 0.0L && std::isfinite(par1[i]) && std::isfinite(m.e2[i]) &&
-                    m.e2[i] > 0.0;
-            if (valid)
-                cmax = std::max(cmax, 1.0L / (sqrtl(2.0L * 3.14159265358979323846264338327950288L) * sg));
-        }
-        const long double s = valid ? ceill(log2l(cmax)) : 0.0L;
-        for (int i = 0; i < N; ++i) {
-            if (i < n && valid) {
-                const long double sg = par1[i];
-                const long double cn = 1.0L / (sqrtl(2.0L * 3.14159265358979323846264338327950288L) * sg);
-                m.e4[i] = (double)(1.44269504088896340735992468100189214L / (2.0L * sg * sg) / 4096.0L);
-                m.e5[i] = (double)((s - log2l(cn)) / 4096.0L);
-            } else {
-                m.e4[i] = 0.0;
-                m.e5[i] = 1.0;
-            }
-        }
-        m.emg = valid ? (double)(1649267441664.0L + s / 4096.0L) : std::numeric_limits<double>::quiet_NaN();
-    }
+    if (kind == EMIT_GAUSS)
+        gauss_pdf_constants(n, N, par1, m.e4, m.e5, &m.emg);
 }
 
 

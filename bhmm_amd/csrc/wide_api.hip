@@ -19,7 +19,7 @@ static int wide_model(bhmm_ctx *c, int kind, const double *A, const double *pi, 
                       const double *par1, WideModel &m)
 {
     const int n = c->n;
-    std::vector<double> h((size_t)n * n + 5 * n, 0.0);
+    std::vector<double> h((size_t)n * n + 7 * n, 0.0);
     memcpy(h.data(), A, sizeof(double) * n * n);
     double *hp = h.data() + (size_t)n * n;
     for (int i = 0; i < n; ++i) {
@@ -31,6 +31,9 @@ static int wide_model(bhmm_ctx *c, int kind, const double *A, const double *pi, 
             hp[4 * n + i] = par1[i];
         }
     }
+    m.gmg = 0.0;
+    if (kind == EMIT_GAUSS)
+        gauss_pdf_constants(n, n, par1, hp + 5 * n, hp + 6 * n, &m.gmg);
     int rc = c->d_wmodel.ensure(h.size());
     if (rc)
         return rc;
@@ -42,6 +45,8 @@ static int wide_model(bhmm_ctx *c, int kind, const double *A, const double *pi, 
     m.isig = m.mu + n;
     m.cnorm = m.isig + n;
     m.sigma = m.cnorm + n;
+    m.ga = m.sigma + n;
+    m.gb = m.ga + n;
     m.n = n;
     m.M = c->M;
     m.B = nullptr;

@@ -22,16 +22,18 @@
 namespace bhmm {
 
 // model parameters of the wide family live in one device buffer:
-//   A[n*n] | pi[n] | mu[n] | 1/sigma[n] | 1/(sqrt(2pi) sigma)[n] | sigma[n]
+//   A[n*n] | pi[n] | mu[n] | 1/sigma[n] | 1/(sqrt(2pi) sigma)[n] | sigma[n] | ga[n] | gb[n]
 struct WideModel {
     const double *A, *pi, *mu, *isig, *cnorm, *sigma;
+    const double *ga, *gb; // gauss_pdf_issue(): per-state constants (host_common.hpp: gauss_pdf_constants)
+    double gmg;            // ... and the common magic constant
     const double *B; // [n][M] row-major (discrete)
     int n, M;
 };
 
-// exp_nonpos (estep_sweep.hpp) with the Horner steps pinned to the three-address v_fma_f64: the
-// compiler otherwise picks the two-address v_fmac_f64 and copies every coefficient into the
-// accumulator first (10 extra moves per call), and these kernels are bound by instruction issue.
+// Horner step pinned to the three-address v_fma_f64: the compiler otherwise picks the two-address
+// v_fmac_f64 and copies every coefficient into the accumulator first (10 extra moves per call),
+// and these kernels are bound by instruction issue.
 __device__ __forceinline__ double horner_step(double q, double r, double c)
 {
     double o;
@@ -39,25 +41,26 @@ __device__ __forceinline__ double horner_step(double q, double r, double c)
     return o;
 }
 
-__device__ __forceinline__ double exp_nonpos_issue(double x)
+// gauss_pdf<NANSAFE = true> (estep_sweep.hpp: the gaussian density with constant, exponent and range
+// reduction fused, 18 instructions where cn * exp(-z*z/2) by range reduction took 24), Horner steps pinned
+// like above.  A NaN observation gives 0 here, as it always did in this family (-> outlier row).
+__device__ __forceinline__ double gauss_pdf_issue(double d, double a, double b, double MG)
 {
-    x = fmax(x, -750.0);
-    const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
-    double r = fma(k, -0x1.62e42fefa39efp-1, x);
-    r = fma(k, -0x1.abc9e3b39803fp-56, r);
-    double q = 0x1.ad7e38e167506p-26;
-    q = horner_step(q, r, 0x1.28ae7908135d8p-22);
-    q = horner_step(q, r, 0x1.71df27c33abefp-19);
-    q = horner_step(q, r, 0x1.a01998fd42e01p-16);
-    q = horner_step(q, r, 0x1.a01a012882c92p-13);
-    q = horner_step(q, r, 0x1.6c16c184889e3p-10);
-    q = horner_step(q, r, 0x1.111111112836cp-7);
-    q = horner_step(q, r, 0x1.55555555506eap-5);
-    q = horner_step(q, r, 0x1.55555555554f7p-3);
-    q = horner_step(q, r, 0x1.000000000000ap-1);
-    q = fma(q, r, 1.0);
-    q = fma(q, r, 1.0);
-    return ldexp(q, (int)k);
+    const double u = fmin(fma(d * d, a, b), 1.0);
+    const double t = MG - u;
+    const double w = (t - MG) + u;
+    double q = 0x1.e3991e644e6abp+92;
+    q = horner_step(q, w, -0x1.b6740fc28f781p+84);
+    q = horner_step(q, w, 0x1.62c157ee59177p+76);
+    q = horner_step(q, w, -0x1.ffcb55e82f22cp+67);
+    q = horner_step(q, w, 0x1.4309126056718p+59);
+    q = horner_step(q, w, -0x1.5d87fe9cc5d6fp+50);
+    q = horner_step(q, w, 0x1.3b2ab6fbde0f7p+41);
+    q = horner_step(q, w, -0x1.c6b08d703d48ap+31);
+    q = horner_step(q, w, 0x1.ebfbdff82c3b9p+21);
+    q = horner_step(q, w, -0x1.62e42fefa3a17p+11);
+    q = fma(q, w, 1.0);
+    return ldexp(q, __double2loint(t));
 }
 
 // ---- 64 states, one trajectory segment per wavefront: cross-lane forms of gfx950 ----------------
@@ -280,13 +283,12 @@ __device__ __forceinline__ WideIn wide_load(const WideModel &m, int j, bool real
 // emission probability of MY state (+ outlier rule over the group)
 template <int NP, int KIND>
 __device__ __forceinline__ double wide_emit(const WideModel &m, int j, bool real, const WideIn &in,
-                                            double mu_j, double is_j, double cn_j,
+                                            double mu_j, double ga_j, double gb_j,
                                             unsigned long long gmask)
 {
     double p = 0.0;
     if constexpr (KIND == EMIT_GAUSS) {
-        const double z = (in.o - mu_j) * is_j;
-        p = real ? cn_j * exp_nonpos_issue(-0.5 * z * z) : 0.0;
+        p = gauss_pdf_issue(in.o - mu_j, ga_j, gb_j, m.gmg); // lanes without a state: (0, 1) -> 0
         if ((__ballot(p != 0.0) & gmask) == 0ull)
             p = real ? 1.0 : 0.0; // outputmodel.py:126-130
     } else if constexpr (KIND == EMIT_DISC) {
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
     for (int i = 0; i < NP; ++i)
         Acol[i] = (real && i < n) ? m.A[(int64_t)i * n + j] : 0.0;
     const double mu_j = (KIND == EMIT_GAUSS && real) ? m.mu[j] : 0.0;
-    const double is_j = (KIND == EMIT_GAUSS && real) ? m.isig[j] : 0.0;
-    const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
+    const double ga_j = (KIND == EMIT_GAUSS && real) ? m.ga[j] : 0.0; // gauss_pdf_issue() constants
+    const double gb_j = (KIND == EMIT_GAUSS && real) ? m.gb[j] : 1.0;
     const double pi_j = real ? m.pi[j] : 0.0;
 
     const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0; // warm-up start (0: exact start)
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
                 const int rn = r + WIDE_PF < nsteps ? r + WIDE_PF : nsteps - 1;
                 ring[u] = wide_load<KIND>(m, j, real, o0 + tw + rn, obs_rm);
             }
-            const double p = wide_emit<NP, KIND>(m, j, real, in, mu_j, is_j, cn_j, gmask);
+            const double p = wide_emit<NP, KIND>(m, j, real, in, mu_j, ga_j, gb_j, gmask);
             double nj;
             if (from_start && r == 0) {
                 nj = pi_j * p;
@@ -523,8 +525,8 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
     if (t1 > t0) {
         const unsigned long long gmask = wgroup_mask<NP>(lane);
         const double mu_i = (KIND == EMIT_GAUSS && real) ? m.mu[i] : 0.0;
-        const double is_i = (KIND == EMIT_GAUSS && real) ? m.isig[i] : 0.0;
-        const double cn_i = (KIND == EMIT_GAUSS && real) ? m.cnorm[i] : 0.0;
+        const double ga_i = (KIND == EMIT_GAUSS && real) ? m.ga[i] : 0.0; // gauss_pdf_issue() constants
+        const double gb_i = (KIND == EMIT_GAUSS && real) ? m.gb[i] : 1.0;
         const double *arow = sA + i * PITCH;
         // one backward step: b <- A (p o b), rescaled by a power of two; returns A (p o b)[i]
         double xcur = 0.0; // p o b of the current step (back() sets it)
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                         const int rn = r + WIDE_PF < nwarm ? r + WIDE_PF : nwarm - 1;
                         ring[u] = wide_load<KIND>(m, i, real, o0 + te - rn, obs_rm);
                     }
-                    const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, is_i, cn_i, gmask);
+                    const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
                     b = back(p, b);
                     if (!LAZY || (u & 3) == 3)
                         b = rescale(b);
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                 const WideIn in = ro[u];
                 const double ap = ra[u];
                 fetch(u, r + WIDE_PF);
-                const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, is_i, cn_i, gmask);
+                const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
                 // consume gamma_t
                 sgm += gam;
                 if constexpr (KIND == EMIT_GAUSS) {
@@ -749,8 +751,8 @@ __global__ __launch_bounds__(64) void k_wide_probe(const WideModel m, const void
     for (int c = 0; c < NP; ++c)
         Areg[c] = (real && c < n) ? (dir == 0 ? m.A[(int64_t)c * n + j] : m.A[(int64_t)j * n + c]) : 0.0;
     const double mu_j = (KIND == EMIT_GAUSS && real) ? m.mu[j] : 0.0;
-    const double is_j = (KIND == EMIT_GAUSS && real) ? m.isig[j] : 0.0;
-    const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
+    const double ga_j = (KIND == EMIT_GAUSS && real) ? m.ga[j] : 0.0; // gauss_pdf_issue() constants
+    const double gb_j = (KIND == EMIT_GAUSS && real) ? m.gb[j] : 1.0;
     double x = real ? 1.0 / (double)n : 0.0, y = (j == idx % n) ? 1.0 : 0.0;
     auto matvec = [&](double v) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(64) void k_wide_probe(const WideModel m, const void
     for (int w = 0; w < Wmax; ++w) {
         const int64_t t = dir == 0 ? pos0 + w : pos0 + Wmax - 1 - w;
         const WideIn in = wide_load<KIND>(m, j, real, t, obs_rm);
-        const double p = wide_emit<NP, KIND>(m, j, real, in, mu_j, is_j, cn_j, gmask);
+        const double p = wide_emit<NP, KIND>(m, j, real, in, mu_j, ga_j, gb_j, gmask);
         auto step = [&](double v) {
             const double r = dir == 0 ? matvec(v) * p : matvec(p * v);
             return r * fast_rcp(wgroup_sum<NP>(r));

@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../bhmm_amd/csrc"
 name=$1; shift
 mkdir -p ../lib/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -c -o /tmp/bhmm_var_$name.o bhmm_amd.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libbhmm_amd_$name.so /tmp/bhmm_var_$name.o ../lib/obj/path_api.o ../lib/obj/wide_api.o ../lib/obj/synth_api.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libbhmm_amd_$name.so /tmp/bhmm_var_$name.o ../lib/obj/path_api.o ../lib/obj/wide_api.o ../lib/obj/synth_api.o ../lib/obj/host_mstep.o
 echo built $name
