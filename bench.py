@@ -10,7 +10,7 @@ Workload at N GPUs: BASELINE.json configs[1] per GPU -- 8-state Gaussian HMM,
 256 trajectories x 1e5 time steps of synthetic observations (weak scaling: every rank holds
 its own 256 trajectories; the packed sufficient statistics are all-reduced over RCCL).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 50    # the defaults (steady state)
     python bench.py --gpus N ...        # WORLD_SIZE unset: starts N ranks itself (torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -328,8 +328,8 @@ def secondary_c4(torch, dev, local, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--ntraj", type=int, default=256)
     ap.add_argument("--length", type=int, default=100000)
     ap.add_argument("--chunk", type=int, default=0)
