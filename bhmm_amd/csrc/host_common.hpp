@@ -15,7 +15,7 @@ namespace bhmm {
 inline int pad_states(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : 8); }
 
 // Constants of gauss_pdf() (estep_sweep.hpp): p = 2^(s - 4096 u), u = a (o - mu)^2 + b, for n real
-// states (npad >= n entries are written: padded states get a = 0, b = 1, i.e. p = 0); computed in
+// states (npad >= n entries are written: padded states get a tiny a and b = 1, i.e. u >= 1, p = 0); computed in
 // extended precision and rounded once.  An invalid sigma makes MG NaN (every density NaN).
 inline void gauss_pdf_constants(int n, int npad, const double *sigma, double *a, double *b, double *MG)
 {
@@ -35,7 +35,7 @@ inline void gauss_pdf_constants(int n, int npad, const double *sigma, double *a,
             a[i] = (double)(1.44269504088896340735992468100189214L / (2.0L * sg * sg) / 4096.0L);
             b[i] = (double)((s - log2l(1.0L / (sqrt2pi * sg))) / 4096.0L);
         } else {
-            a[i] = 0.0;
+            a[i] = 1e-300; // (not 0: an infinite observation must give u = inf, not inf * 0 = NaN)
             b[i] = 1.0;
         }
     }

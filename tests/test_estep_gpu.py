@@ -324,6 +324,31 @@ def test_gaussian_density_of_the_sweep(mu, sigma):
         assert np.all(np.isnan(yb))
 
 
+@pytest.mark.parametrize("want_gamma", [False, True])
+def test_infinite_observations_are_outliers(want_gamma):
+    """+-inf observations have density 0 for every state: the outlier rule (outputmodel.py:126-130)
+    makes the row all ones, on the padded 3-state model (4 lanes) as on the 8-state one, in the
+    branch-free and in the checked kernels."""
+    rng = np.random.default_rng(21)
+    for n in (3, 8):
+        A = rng.random((n, n)) + 2 * np.eye(n)
+        A /= A.sum(axis=1, keepdims=True)
+        pi = rng.dirichlet(np.ones(n))
+        mu, sig = np.linspace(-2, 2, n), rng.uniform(0.5, 1.5, n)
+        obs = [rng.normal(0, 2, T) for T in (300, 171, 64)]
+        obs[0][17] = np.inf
+        obs[1][5] = -np.inf
+        obs[1][170] = np.inf
+        ref = orc.estep("gaussian", obs, A, pi, mu, sig, want_gamma=want_gamma)
+        eng = _engine()
+        eng.set_observations("gaussian", obs, n, chunk=32)
+        for _ in range(2):
+            res = eng.estep(A, pi, mu, sig, store_gamma=want_gamma)
+            np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-11)
+            np.testing.assert_allclose(res.C, ref["C"], rtol=1e-9, atol=1e-12)
+        eng.close()
+
+
 def test_nan_observation_is_not_a_hit(golden):
     """A NaN observation must poison its trajectory (the reference's pobs row is NaN) on every
     path that evaluates the density with the clamp modifier: the upload finds it and keeps the
