@@ -166,12 +166,18 @@ struct Runner {
                 if constexpr (SPEC && ESTEP_SPLIT) {
                     // two launches: forward sweeps + backward warm-ups side by side (four
                     // wavefronts per SIMD), then the backward sweeps
-                    auto launch2 = [&](auto kern, int grid) -> int {
-                        if (sm > 64 * 1024)
+                    // P1 keeps no emission counts: without the count tables its workgroups need
+                    // less LDS (discrete kind: four of them fit a CU again) and the exchange area of
+                    // the all-gather sits right behind B^T
+                    Model<N> m1 = m;
+                    m1.dcopies = 0;
+                    const size_t sm1 = KIND == EMIT_DISC ? smem_fwdbwd<N, KIND>(lds_symbols(c), 0) : sm;
+                    auto launch2 = [&](auto kern, int grid, const Model<N> &mm, size_t smem) -> int {
+                        if (smem > 64 * 1024)
                             BHMM_HIP(hipFuncSetAttribute((const void *)kern,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         (int)sm));
-                        hipLaunchKernelGGL(kern, dim3(grid), dim3(32 * N), sm, c->stream, m, ch,
+                                                         (int)smem));
+                        hipLaunchKernelGGL(kern, dim3(grid), dim3(32 * N), smem, c->stream, mm, ch,
                                            (const void *)c->d_obs_ci.p, (const void *)c->d_obs_rm.p,
                                            (const int64_t *)c->d_offsets.p,
                                            (const double *)c->d_Bt.p, c->d_aentry.p, c->d_bexit.p,
@@ -180,10 +186,10 @@ struct Runner {
                                            c->d_partials.p, c->d_dpartials.p, flag_words, c->d_ea.p);
                         return BHMM_OK;
                     };
-                    if ((rc = launch2(k_estep_light<N, KIND, SPEC, false, false, PH_P1>, 2 * nblk)))
+                    if ((rc = launch2(k_estep_light<N, KIND, SPEC, false, false, PH_P1>, 2 * nblk, m1, sm1)))
                         return rc;
                     BHMM_HIP(hipGetLastError());
-                    rc = launch2(k_estep<N, KIND, SPEC, false, false, PH_P2>, nblk);
+                    rc = launch2(k_estep<N, KIND, SPEC, false, false, PH_P2>, nblk, m, sm);
                 } else {
                     rc = launch(k_estep<N, KIND, SPEC, false, false>);
                 }
@@ -574,10 +580,12 @@ struct Runner {
 
     // forward sweep only with k_estep<..., FWDONLY> (alpha rows up to a power of two)
     template <int KIND, bool CAREFUL>
-    static int forward_launch(bhmm_ctx *c, const Model<N> &m)
+    static int forward_launch(bhmm_ctx *c, const Model<N> &m_in)
     {
         const Chunks ch = chunks_of(c);
-        const size_t sm = smem_fwdbwd<N, KIND>(lds_symbols(c), KIND == EMIT_DISC ? m.dcopies : 1);
+        Model<N> m = m_in; // no emission counts in this pass: no count tables in LDS
+        m.dcopies = 0;
+        const size_t sm = smem_fwdbwd<N, KIND>(lds_symbols(c), KIND == EMIT_DISC ? 0 : 1);
         auto kern = k_estep_light<N, KIND, true, false, CAREFUL, PH_FWDROWS>;
         if (sm > 64 * 1024)
             BHMM_HIP(hipFuncSetAttribute((const void *)kern,
@@ -713,6 +721,14 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
         // configs[1]: profiles/r01).
         const int64_t target = 32768 * 4 / std::max(1, c->N / 2); // N/2 lanes per chunk
         int64_t l = (c->total + target - 1) / target;
+        // Very long chunks: two or three times as many.  The sweeps without xi accumulators (P1,
+        // the forward-only pass) then have four to six long wavefronts per SIMD instead of two
+        // (configs[2], 1024 x 1e6: P1 7.2 -> 5.9 ms, E-step 20.2 -> 18.7 ms), while the warm-up
+        // stays below a few per cent of the chunk even if it calibrates to four times the default.
+        if (l >= 3 * 9216)
+            l = (l + 2) / 3;
+        else if (l >= 2 * 9216)
+            l = (l + 1) / 2;
         L = (int)std::min<int64_t>(std::max<int64_t>(l, 32), (int64_t)1 << 20);
     }
     c->L = L;

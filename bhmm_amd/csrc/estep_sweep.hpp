@@ -313,6 +313,9 @@ __device__ __forceinline__ int scaled_emit(const ObsIn &in, int q, int nreal,
 #ifndef ESTEP_LDS_GATHER
 #define ESTEP_LDS_GATHER 1
 #endif
+#ifndef ESTEP_DISC_P1_LDS
+#define ESTEP_DISC_P1_LDS 0 // measured on configs[2]: P1 7.98 ms through LDS, 7.24 ms on DPP (the B lookup already sits in the LDS latency chain)
+#endif
 template <int N, bool USE_LDS>
 struct Gather {
     static constexpr int H = N / 2;
@@ -531,7 +534,9 @@ __device__ __forceinline__ void estep_body(
     double *dstat_g = disc_partials + (int64_t)(blockIdx.x % DISC_GLOBAL_TABLES) * (m.M * N);
     // the discrete kind keeps its LDS unit busy with the emission table and the count atomics:
     // its all-gather runs on DPP instead (measured: 13 % faster there, equal for the gaussian)
-    const Gather<N, ESTEP_LDS_GATHER && KIND != EMIT_DISC> gather(dstat0 + dcopies * Mlds * N);
+    // (P1 and the forward-only pass keep no counts: there the discrete kind exchanges through LDS too)
+    const Gather<N, ESTEP_LDS_GATHER && (KIND != EMIT_DISC || ESTEP_DISC_P1_LDS * (PHASE == PH_P1 || PHASE == PH_FWDROWS))>
+        gather(dstat0 + dcopies * Mlds * N);
     int hmin = 0x7fffffff;
 #ifdef ESTEP_CLOCKPROBE
     const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = wall_clock64();

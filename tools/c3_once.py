@@ -13,7 +13,7 @@ B = rng.dirichlet(np.ones(M), size=n)
 obs = torch.empty(K * T, dtype=torch.int32, device="cuda:0")
 synth_observations("discrete", obs.data_ptr(), A, pi, B, None, K, T, seed=3000)
 eng = Engine(0)
-eng.set_observations_device("discrete", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, n, nsymbols=M)
+eng.set_observations_device("discrete", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, n, nsymbols=M, chunk=int(os.environ.get("C3_CHUNK", "0")))
 args = (0.9 * A + 0.1 / n, pi, 0.8 * B + 0.2 / M)
 for _ in range(4):
     r = eng.estep(*args)
