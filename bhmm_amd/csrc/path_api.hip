@@ -86,35 +86,34 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
                                    sizeof(int32_t))))
         return rc;
     int32_t *path = paths ? reinterpret_cast<int32_t *>(c->d_scratch2.p) : nullptr;
-    int *status = reinterpret_cast<int *>(reinterpret_cast<int32_t *>(c->d_scratch2.p) + npath);
-    uint32_t *fmap = reinterpret_cast<uint32_t *>(status + 4);
+    int *status = nullptr; // (lives behind the counts, see below)
+    uint32_t *fmap = reinterpret_cast<uint32_t *>(reinterpret_cast<int32_t *>(c->d_scratch2.p) + npath + 4);
     int32_t *nstate = reinterpret_cast<int32_t *>(fmap + (size_t)c->Gp * P);
     int32_t *dmark = nstate + (size_t)c->Gp * P;
     uint32_t *nib = reinterpret_cast<uint32_t *>(dmark + (size_t)c->Gp * P);
     uint32_t *gw = nib + (size_t)W8 * c->Gp * P;
     const int64_t Gp64 = c->Gp;
-    // scratch: counts | emission partials | reduced emission | u
+    // scratch: counts | reduced emission | status | emission partials | u   (the first three are
+    // zeroed by ONE fill: every fill is a dispatch of its own, ~5 us on the stream)
     // emission partials: one table per workgroup, or (big discrete alphabets) a few global ones
     const bool bigM = c->kind == EMIT_DISC && c->bt_global;
     const size_t ntab = bigM ? (size_t)DISC_GLOBAL_TABLES : (size_t)nblk;
-    const size_t dbl = nstat + ntab * esz + esz + (u ? (size_t)c->total : 0) + 8;
+    const size_t dbl = nstat + esz + 1 + ntab * esz + (u ? (size_t)c->total : 0) + 8;
     if ((rc = c->d_scratch.ensure(dbl * sizeof(double))))
         return rc;
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(c->d_scratch.p);
-    double *epart = reinterpret_cast<double *>(c->d_scratch.p) + nstat;
-    double *ered = epart + ntab * esz;
+    double *ered = reinterpret_cast<double *>(c->d_scratch.p) + nstat;
+    status = reinterpret_cast<int *>(ered + esz);
+    double *epart = ered + esz + 1;
+    BHMM_HIP(hipMemsetAsync(cnt, 0, (nstat + esz + 1) * sizeof(double), c->stream));
     if (bigM)
         BHMM_HIP(hipMemsetAsync(epart, 0, ntab * esz * sizeof(double), c->stream));
     double *udev = nullptr;
     if (u) {
-        udev = ered + esz;
+        udev = epart + ntab * esz;
         BHMM_HIP(hipMemcpyAsync(udev, u, (size_t)c->total * sizeof(double), hipMemcpyHostToDevice,
                                 c->stream));
     }
-    BHMM_HIP(hipMemsetAsync(cnt, 0, nstat * sizeof(unsigned long long), c->stream));
-    BHMM_HIP(hipMemsetAsync(status, 0, sizeof(int), c->stream));
-    if (esz)
-        BHMM_HIP(hipMemsetAsync(ered, 0, esz * sizeof(double), c->stream));
     Model<N> m;
     fill_model_pub<N>(m, n, c->kind, c->M, A, pi, par0, par1);
     m.bt_global = bigM ? 1 : 0;
