@@ -111,8 +111,8 @@ __device__ __forceinline__ void emit(const Model<N> &m, const void *obs_ci, cons
         double mx = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const double z = (o - m.e0[i]) * m.e1[i];
-            p[i] = m.e2[i] * exp(-0.5 * z * z);
+            const double z = i < m.nreal ? (o - m.e0[i]) / m.e3[i] : 0.0; // (_gaussian.c:5-21, see k_prescan)
+            p[i] = i < m.nreal ? m.e2[i] * exp(-0.5 * z * z) : 0.0;
             mx = fmax(mx, p[i]);
         }
         if (mx == 0.0) {
@@ -131,6 +131,19 @@ __device__ __forceinline__ void emit(const Model<N> &m, const void *obs_ci, cons
         }
     } else {
         ci_load<N>(static_cast<const double *>(obs_ci), rec, lane, p);
+    }
+    // a row in the denormal range (cf. emit_raw, estep_sweep.hpp): times 2^900, exactly.  These
+    // kernels only produce boundary vectors, which carry no scale.
+    if constexpr (KIND != EMIT_DISC) {
+        double mx = p[0];
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+            mx = fmax(mx, p[i]);
+        if (mx < 0x1p-959) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                p[i] = ldexp(p[i], 900);
+        }
     }
 }
 
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(64 * N) void k_prescan(const Model<N> m, const Chun
             A[k][j] = x.x;
             A[k][j + 1] = x.y;
         }
-    const double mu_r = m.e0[r], is_r = m.e1[r], cn_r = m.e2[r];
+    const double mu_r = m.e0[r], sg_r = m.e3[r], cn_r = m.e2[r];
     const bool real = r < m.nreal;
     double *slot = sP + cl * N;
     const unsigned long long gmask = ((N == 64) ? ~0ull : ((1ull << N) - 1))
@@ -288,14 +301,21 @@ __global__ __launch_bounds__(64 * N) void k_prescan(const Model<N> m, const Chun
             load_in(rec + 1, o_n, sym_n, pv_n);
         double pr;
         if constexpr (KIND == EMIT_GAUSS) {
-            const double z = (o - mu_r) * is_r;
-            pr = cn_r * exp(-0.5 * z * z);
+            // the reference's own operation order (_gaussian.c:5-21): at the bottom of the
+            // denormal range this decides between "all zero" (outlier rule) and a last non-zero
+            // entry, and the sweeps (emit_raw) decide it the same way
+            const double z = real ? (o - mu_r) / sg_r : 0.0;
+            pr = real ? cn_r * exp(-0.5 * z * z) : 0.0;
             if ((__ballot(pr != 0.0) & gmask) == 0ull) // outlier row, outputmodel.py:126-130
                 pr = real ? 1.0 : 0.0;
+            else if ((__ballot(pr >= 0x1p-959) & gmask) == 0ull) // denormal range: times 2^900, exactly
+                pr = ldexp(pr, 900);
         } else if constexpr (KIND == EMIT_DISC) {
             pr = sBt[sym * N + r];
         } else {
             pr = pv;
+            if ((__ballot(pr >= 0x1p-959) & gmask) == 0ull && (__ballot(pr != 0.0) & gmask) != 0ull)
+                pr = ldexp(pr, 900);
         }
         slot[r] = pr;
         double p[N];

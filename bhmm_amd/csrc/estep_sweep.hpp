@@ -205,9 +205,18 @@ struct BtSrc {
     const double *glb;
     bool big;
 };
+// NANSAFE (the per-step-checked kernels) additionally rescues rows in the denormal range: if no
+// state of the chunk has a probability of 2^-959 or more -- an observation ~38 sigma from every state,
+// caller-supplied rows of 1e-320 -- sums over the row are denormal, their reciprocals infinite, and
+// the fused density no longer rounds like the reference's exp-then-scale.  Such a row (rare: one
+// divergent branch) is re-evaluated in the reference's own operation order (_gaussian.c:5-21) and
+// returned times 2^900; the return value is that exponent (else 0).  gamma and xi do not see the
+// factor, the forward sweep takes it off its exponent count.  An all-zero row is left to the
+// outlier rule.
 template <int N, int KIND, bool NANSAFE>
-__device__ __forceinline__ void emit_raw(const ObsIn &in, const BtSrc &Bt, int q,
-                                         const EmisPair &em, double (&p)[2], double (&d)[2])
+__device__ __forceinline__ int emit_raw(const Model<N> &m, unsigned long long gmask, int nreal,
+                                        const ObsIn &in, const BtSrc &Bt, int q,
+                                        const EmisPair &em, double (&p)[2], double (&d)[2])
 {
     if constexpr (KIND == EMIT_GAUSS) {
 #pragma unroll
@@ -227,6 +236,26 @@ __device__ __forceinline__ void emit_raw(const ObsIn &in, const BtSrc &Bt, int q
         p[1] = in.pp.y;
         d[0] = d[1] = 0.0;
     }
+    if constexpr (NANSAFE) {
+        const bool big = p[0] >= 0x1p-959 || p[1] >= 0x1p-959;
+        if (__builtin_expect((__ballot(big) & gmask) == 0ull, 0)) {
+            if constexpr (KIND == EMIT_GAUSS) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int st = 2 * q + b;
+                    const double z = (in.o - m.e0[st]) / m.e3[st];
+                    p[b] = st < nreal ? m.e2[st] * exp(-0.5 * z * z) : 0.0;
+                }
+            }
+            const bool nz = p[0] != 0.0 || p[1] != 0.0;
+            if ((__ballot(nz) & gmask) != 0ull) {
+                p[0] = ldexp(p[0], 900);
+                p[1] = ldexp(p[1], 900);
+                return 900;
+            }
+        }
+    }
+    return 0;
 }
 
 // The outlier rule, outputmodel.py:126-130: a row of pobs that is zero for every state becomes a
@@ -611,8 +640,8 @@ __device__ __forceinline__ void estep_body(
                 // alpha_0 = pi o p_0, _hidden.c:28-39
                 const ObsIn in = load_obs<N, KIND>(obs_ci, rec0, cl, q);
                 double p[2], d[2];
-                emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
-                eP = scaled_emit<N, KIND, CAREFUL, true>(in, q, nreal, gmask, pi2, p, a, hmin);
+                const int pe = emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, in, Bt, q, em, p, d);
+                eP = scaled_emit<N, KIND, CAREFUL, true>(in, q, nreal, gmask, pi2, p, a, hmin) - pe;
                 *ci_pair(ws, rec0, N, q, cl) = make_double2(a[0], a[1]);
                 if constexpr (PHASE == PH_P1)
                     ea_rows[rec0 * 64 + cl] = eP;
@@ -627,7 +656,7 @@ __device__ __forceinline__ void estep_body(
                         double p[2], d[2], sv[2], af[N];
                         gather(a, af);
                         sched_fence();
-                        emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
+                        emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, in, Bt, q, em, p, d);
                         sched_fence();
                         fwd_dot<N>(af, Ac, sv);
                         (void)scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask,
@@ -636,7 +665,7 @@ __device__ __forceinline__ void estep_body(
                     if ((int64_t)nw == t0) {
                         const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
                         double p[2], d[2];
-                        emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
+                        emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, in, Bt, q, em, p, d);
                         (void)scaled_emit<N, KIND, CAREFUL, true>(in, q, nreal, gmask, pi2, p, a, hmin);
                         ++pos;
                         --nw;
@@ -698,11 +727,11 @@ __device__ __forceinline__ void estep_body(
                 double p[2], d[2], sv[2], af[N];
                 gather(a, af);
                 sched_fence();
-                emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
+                const int pe = emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, in, Bt, q, em, p, d);
                 sched_fence();
                 fwd_dot<N>(af, Ac, sv);
                 eP += scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask, sv, p,
-                                                                        a, hmin);
+                                                                        a, hmin) - pe;
                 out = make_double2(a[0], a[1]);
             };
             // PH_P1: with every stored row goes the exponent removed so far (eP), one int per chunk;
@@ -847,7 +876,7 @@ __device__ __forceinline__ void estep_body(
             b2[1] = u1;
             auto wstep = [&](const ObsIn &in, auto sc) {
                 double p[2], d[2], bf[N], r[2], bn[2];
-                emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
+                emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, in, Bt, q, em, p, d);
                 int unused = 0;
                 beta_step<N, KIND, CAREFUL, decltype(sc)::value>(gather, in, q, nreal, gmask, Ar, p,
                                                                  b2, bf, r, bn, hmin, unused);
@@ -957,7 +986,7 @@ __device__ __forceinline__ void estep_body(
         };
         auto bstep = [&](const ObsIn &in, const double2 &apv, double2 *gdst, auto sc) {
             double p[2], d[2];
-            emit_raw<N, KIND, CAREFUL>(in, Bt, q, em, p, d);
+            emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, in, Bt, q, em, p, d);
             bcore(in, p, d, apv, gdst, sc);
         };
         // steps s and s-1 from the stored row alpha_{s-2}: alpha_{s-1} = (alpha_{s-2} A) o p_{s-1}
@@ -1007,8 +1036,8 @@ __device__ __forceinline__ void estep_body(
             double p_hi[2], d_hi[2], p_lo[2], d_lo[2], sv[2], ah[2];
             const double al[2] = {alo.x, alo.y};
             if constexpr (CAREFUL && KIND == EMIT_GAUSS) {
-                emit_raw<N, KIND, CAREFUL>(hi, Bt, q, em, p_hi, d_hi);
-                emit_raw<N, KIND, CAREFUL>(lo, Bt, q, em, p_lo, d_lo);
+                emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, hi, Bt, q, em, p_hi, d_hi);
+                emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, lo, Bt, q, em, p_lo, d_lo);
                 fwd_matvec<N>(gather, al, Ac, sv);
                 int unused = 0x7fffffff;
                 (void)scaled_emit<N, KIND, CAREFUL, false>(lo, q, nreal, gmask, sv, p_lo, ah,
@@ -1019,7 +1048,7 @@ __device__ __forceinline__ void estep_body(
                 double afl[N], bf[N];
                 gather(al, afl); // (1) alpha_{s-2}, for the rebuild
                 sched_fence();
-                emit_raw<N, KIND, CAREFUL>(hi, Bt, q, em, p_hi, d_hi);
+                emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, hi, Bt, q, em, p_hi, d_hi);
                 sched_fence();
                 fwd_dot<N>(afl, Ac, sv);
                 consume(hi, d_hi, gdst);
@@ -1028,7 +1057,7 @@ __device__ __forceinline__ void estep_body(
                     gather(bb, bf); // (2) p o beta of step s
                 }
                 sched_fence();
-                emit_raw<N, KIND, CAREFUL>(lo, Bt, q, em, p_lo, d_lo);
+                emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, lo, Bt, q, em, p_lo, d_lo);
                 sched_fence();
                 ah[0] = sv[0] * p_lo[0];
                 ah[1] = sv[1] * p_lo[1];
@@ -1052,16 +1081,16 @@ __device__ __forceinline__ void estep_body(
             const double al[2] = {alo.x, alo.y};
             gather(al, af); // alpha_{s-4}
             sched_fence();
-            emit_raw<N, KIND, CAREFUL>(x0, Bt, q, em, p0, d0);
-            emit_raw<N, KIND, CAREFUL>(x1, Bt, q, em, p1, d1);
+            emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, x0, Bt, q, em, p0, d0);
+            emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, x1, Bt, q, em, p1, d1);
             sched_fence();
             fwd_dot<N>(af, Ac, sv);
             a1[0] = sv[0] * p0[0]; // alpha_{s-3}
             a1[1] = sv[1] * p0[1];
             gather(a1, af);
             sched_fence();
-            emit_raw<N, KIND, CAREFUL>(x2, Bt, q, em, p2, d2);
-            emit_raw<N, KIND, CAREFUL>(x3, Bt, q, em, p3, d3);
+            emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, x2, Bt, q, em, p2, d2);
+            emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, x3, Bt, q, em, p3, d3);
             sched_fence();
             fwd_dot<N>(af, Ac, sv);
             a2[0] = sv[0] * p1[0]; // alpha_{s-2}

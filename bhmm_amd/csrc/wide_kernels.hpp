@@ -281,20 +281,41 @@ __device__ __forceinline__ WideIn wide_load(const WideModel &m, int j, bool real
 }
 
 // emission probability of MY state (+ outlier rule over the group)
-template <int NP, int KIND>
+// RESCUE (the kernels that normalise by a sum and its reciprocal every step): a row whose entries
+// all lie below 2^-959 -- densities in the denormal range, an observation ~38 sigma from every
+// state -- is returned times 2^900, *pexp = 900 (else 0): the reciprocal of a denormal sum is
+// infinite.  The backward recursion does not see the factor; the forward pass takes it off its
+// exponent count.
+template <int NP, int KIND, bool RESCUE = false>
 __device__ __forceinline__ double wide_emit(const WideModel &m, int j, bool real, const WideIn &in,
                                             double mu_j, double ga_j, double gb_j,
-                                            unsigned long long gmask)
+                                            unsigned long long gmask, int *pexp = nullptr)
 {
     double p = 0.0;
     if constexpr (KIND == EMIT_GAUSS) {
         p = gauss_pdf_issue(in.o - mu_j, ga_j, gb_j, m.gmg); // lanes without a state: (0, 1) -> 0
+        if constexpr (RESCUE) {
+            // a row in the denormal range: the reference's own operation order (_gaussian.c:5-21)
+            if (__builtin_expect((__ballot(p >= 0x1p-959) & gmask) == 0ull, 0)) {
+                const double z = real ? (in.o - mu_j) / m.sigma[j] : 0.0;
+                p = real ? m.cnorm[j] * exp(-0.5 * z * z) : 0.0;
+            }
+        }
         if ((__ballot(p != 0.0) & gmask) == 0ull)
             p = real ? 1.0 : 0.0; // outputmodel.py:126-130
     } else if constexpr (KIND == EMIT_DISC) {
         p = real ? m.B[(int64_t)j * m.M + in.sym] : 0.0;
     } else {
         p = in.o;
+    }
+    if constexpr (RESCUE) {
+        int e = 0;
+        if ((__ballot(p >= 0x1p-959) & gmask) == 0ull && (__ballot(p != 0.0) & gmask) != 0ull) {
+            p = ldexp(p, 900);
+            e = 900;
+        }
+        if (pexp)
+            *pexp = e;
     }
     return p;
 }
@@ -377,7 +398,8 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
                 const int rn = r + WIDE_PF < nsteps ? r + WIDE_PF : nsteps - 1;
                 ring[u] = wide_load<KIND>(m, j, real, o0 + tw + rn, obs_rm);
             }
-            const double p = wide_emit<NP, KIND>(m, j, real, in, mu_j, ga_j, gb_j, gmask);
+            int pexp = 0;
+            const double p = wide_emit<NP, KIND, !LAZY>(m, j, real, in, mu_j, ga_j, gb_j, gmask, &pexp);
             double nj;
             if (from_start && r == 0) {
                 nj = pi_j * p;
@@ -417,7 +439,7 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
                 if (r >= r0) {
                     int e;
                     P = frexp(P * c, &e);
-                    eP += e;
+                    eP += e - pexp;
                     if (real)
                         alpha_rm[(o0 + t) * n + j] = a;
                 } else if (r == r0 - 1 && real) {
@@ -587,7 +609,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                         const int rn = r + WIDE_PF < nwarm ? r + WIDE_PF : nwarm - 1;
                         ring[u] = wide_load<KIND>(m, i, real, o0 + te - rn, obs_rm);
                     }
-                    const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
+                    const double p = wide_emit<NP, KIND, !LAZY>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
                     b = back(p, b);
                     if (!LAZY || (u & 3) == 3)
                         b = rescale(b);
@@ -631,7 +653,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                 const WideIn in = ro[u];
                 const double ap = ra[u];
                 fetch(u, r + WIDE_PF);
-                const double p = wide_emit<NP, KIND>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
+                const double p = wide_emit<NP, KIND, !LAZY>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
                 // consume gamma_t
                 sgm += gam;
                 if constexpr (KIND == EMIT_GAUSS) {
@@ -768,7 +790,7 @@ __global__ __launch_bounds__(64) void k_wide_probe(const WideModel m, const void
     for (int w = 0; w < Wmax; ++w) {
         const int64_t t = dir == 0 ? pos0 + w : pos0 + Wmax - 1 - w;
         const WideIn in = wide_load<KIND>(m, j, real, t, obs_rm);
-        const double p = wide_emit<NP, KIND>(m, j, real, in, mu_j, ga_j, gb_j, gmask);
+        const double p = wide_emit<NP, KIND, true>(m, j, real, in, mu_j, ga_j, gb_j, gmask);
         auto step = [&](double v) {
             const double r = dir == 0 ? matvec(v) * p : matvec(p * v);
             return r * fast_rcp(wgroup_sum<NP>(r));

@@ -349,6 +349,40 @@ def test_infinite_observations_are_outliers(want_gamma):
         eng.close()
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 12, 64])
+def test_densities_in_the_denormal_range(n):
+    """Observations 37-39 sigma from every state: densities of 1e-310 .. 1e-324.  The reference divides
+    by the (denormal) row sums; a reciprocal of such a sum is infinite, and a density with constant
+    and exponential fused rounds differently from exp-then-scale down there.  The checked kernels
+    re-evaluate such rows in the reference's operation order and carry them times 2^900: results
+    stay finite, every step still contributes unit mass to the counts, and with one state (where the
+    reference's own arithmetic is exact) the log-likelihood is the reference's."""
+    rng = np.random.default_rng(5)
+    mu = np.linspace(-3.2, -2.2, n) if n > 1 else np.array([-2.9472305])
+    sig = np.full(n, 0.3) if n > 1 else np.array([0.32470804])
+    A = rng.random((n, n)) + np.eye(n)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = np.full(n, 1.0 / n)
+    obs = [rng.normal(0, 3, T) for T in (26419, 15186, 3754)]
+    with np.errstate(all="ignore"):
+        ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+    for chunk in (7, 0):
+        eng = _engine()
+        eng.set_observations("gaussian", obs, n, chunk=chunk)
+        for _ in range(2):
+            res = eng.estep(A, pi, mu, sig)
+            assert np.all(np.isfinite(res.logL_k)) and np.all(np.isfinite(res.C))
+            np.testing.assert_allclose(res.C.sum(), sum(len(o) - 1 for o in obs), rtol=1e-10)
+            np.testing.assert_allclose(res.state_counts.sum(), sum(len(o) for o in obs), rtol=1e-10)
+            # the reference's own sums are coarsely rounded denormals there: 1e-6 is its noise
+            if np.all(np.isfinite(ref["logL"])):
+                np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-6)
+            if n == 1:
+                np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-13)
+                assert res.C[0, 0] == sum(len(o) - 1 for o in obs)
+        eng.close()
+
+
 def test_nan_observation_is_not_a_hit(golden):
     """A NaN observation must poison its trajectory (the reference's pobs row is NaN) on every
     path that evaluates the density with the clamp modifier: the upload finds it and keeps the

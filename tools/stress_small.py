@@ -1,0 +1,64 @@
+"""Random parity sweep against the oracle (E-step statistics, Viterbi, sampled paths) over small random
+shapes: 1..8 states, gaussian / discrete (alphabets on both sides of the LDS limits), ragged trajectories,
+default and odd chunk lengths.  Prints one line per failure and a summary; exit code 1 on failure."""
+import os, sys
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+from bhmm_amd.engine import Engine
+from oracle import oracle as orc
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+bad = 0
+for case in range(ncase):
+    n = int(rng.integers(1, 9))
+    kind = "gaussian" if rng.random() < 0.5 else "discrete"
+    K = int(rng.integers(1, 7))
+    lens = [int(x) for x in rng.integers(1, int(rng.choice([40, 400, 3000, 40000])), K)]
+    chunk = int(rng.choice([0, 0, 1, 7, 16, 33, 100]))
+    A = rng.random((n, n)) + rng.choice([0.0, 2.0, 10.0]) * np.eye(n)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    if kind == "gaussian":
+        mu, sig = np.sort(rng.normal(0, 3, n)), rng.uniform(0.3, 2.0, n)
+        obs = [rng.normal(0, 3, T) for T in lens]
+        par = (mu, sig)
+        M = 0
+    else:
+        M = int(rng.choice([2, 17, 64, 300, 1150, 1300, 4000]))
+        B = rng.dirichlet(np.ones(M) * 0.5, size=n) * 0.98 + 0.02 / M
+        obs = [rng.integers(0, M, T).astype(np.int32) for T in lens]
+        par = (B, None)
+    tag = "case %d: %s n=%d M=%d K=%d lens=%s chunk=%d" % (case, kind, n, M, K, lens, chunk)
+    try:
+        ref = orc.estep(kind, obs, A, pi, *par)
+        eng = Engine(0)
+        eng.set_observations(kind, obs, n, nsymbols=M, chunk=chunk)
+        for rep in range(2):
+            res = eng.estep(A, pi, *par)
+            ok = np.allclose(res.logL_k, ref["logL"], rtol=1e-10, atol=1e-10) and np.allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10)
+            if not ok:
+                bad += 1
+                print("ESTEP MISMATCH", tag, "rep", rep, np.abs(res.logL_k - ref["logL"]).max(), np.abs(res.C - ref["C"]).max())
+                if os.environ.get("VERBOSE"):
+                    print("  gpu logL", res.logL_k, "ref", ref["logL"], "gpu C", res.C, "ref C", ref["C"], "par", par,
+                          "careful", eng.get_option("careful"), "spec ok/fail", eng.get_option("spec_ok"), eng.get_option("spec_fail"),
+                          "W", eng.get_option("spec_W"), "nan obs", [int(np.isnan(o).sum()) for o in obs])
+        pobs = [orc.pobs_gaussian(o, *par) if kind == "gaussian" else orc.pobs_discrete(o, B) for o in obs]
+        vp = eng.viterbi(A, pi, *par)
+        for k, (p, po) in enumerate(zip(vp, pobs)):
+            if not np.array_equal(p, orc.viterbi(A, po, pi)):
+                bad += 1
+                print("VITERBI MISMATCH", tag, "traj", k)
+        u = [rng.random(T) for T in lens]
+        sp = eng.sample_paths(A, pi, *par, u=u)[0]
+        for k, (p, po, uu) in enumerate(zip(sp, pobs, u)):
+            if not np.array_equal(p, orc.sample_path(orc.forward(A, po, pi)[1], A, u=uu)):
+                bad += 1
+                print("SAMPLE MISMATCH", tag, "traj", k)
+        eng.close()
+    except Exception as e:  # noqa
+        bad += 1
+        print("EXCEPTION", tag, repr(e)[:300])
+print("stress: %d cases, %d failures" % (ncase, bad))
+sys.exit(1 if bad else 0)
