@@ -366,6 +366,9 @@ def test_densities_in_the_denormal_range(n):
     obs = [rng.normal(0, 3, T) for T in (26419, 15186, 3754)]
     with np.errstate(all="ignore"):
         ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+    if n <= 12:
+        from ld_reference import estep_longdouble
+        ld_logL, ld_C = estep_longdouble(A, pi, [orc.pobs_gaussian(o, mu, sig) for o in obs])
     for chunk in (7, 0):
         eng = _engine()
         eng.set_observations("gaussian", obs, n, chunk=chunk)
@@ -374,9 +377,14 @@ def test_densities_in_the_denormal_range(n):
             assert np.all(np.isfinite(res.logL_k)) and np.all(np.isfinite(res.C))
             np.testing.assert_allclose(res.C.sum(), sum(len(o) - 1 for o in obs), rtol=1e-10)
             np.testing.assert_allclose(res.state_counts.sum(), sum(len(o) for o in obs), rtol=1e-10)
-            # the reference's own sums are coarsely rounded denormals there: 1e-6 is its noise
+            # the reference's own sums are coarsely rounded denormals there: 1e-6 is its noise ...
             if np.all(np.isfinite(ref["logL"])):
                 np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-6)
+            # ... so the comparison that is tight is the one with the reference's recursions carried
+            # out in 80-bit arithmetic on the reference's own double-precision emission rows
+            if n <= 12:
+                np.testing.assert_allclose(res.logL_k, ld_logL, rtol=1e-11)
+                np.testing.assert_allclose(res.C, ld_C, rtol=1e-8, atol=1e-9)
             if n == 1:
                 np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-13)
                 assert res.C[0, 0] == sum(len(o) - 1 for o in obs)
