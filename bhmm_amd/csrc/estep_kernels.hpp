@@ -147,6 +147,9 @@ __device__ __forceinline__ void emit(const Model<N> &m, const void *obs_ci, cons
     }
 }
 
+// exponent of an all-zero row of a transfer matrix (k_prescan, k_compose, k_stitch)
+constexpr int ROW_EXP_NONE = -(1 << 28);
+
 // exact power-of-two renormalisation of one row; returns the exponent removed
 template <int N>
 __device__ __forceinline__ int renorm_row(const double (&nr)[N], double (&dst)[N])
@@ -343,10 +346,16 @@ __global__ __launch_bounds__(64 * N) void k_prescan(const Model<N> m, const Chun
         ex += renorm_row<N>(nr, row);
     }
     double *out = Mbuf + g * (int64_t)(N * N + N);
+    bool zero_row = true;
 #pragma unroll
-    for (int j = 0; j < N; j += 2)
+    for (int j = 0; j < N; j += 2) {
         *reinterpret_cast<double2 *>(out + r * N + j) = make_double2(row[j], row[j + 1]);
-    out[N * N + r] = (double)ex;
+        zero_row = zero_row && row[j] == 0.0 && row[j + 1] == 0.0;
+    }
+    // a zero row (no path from state r explains the chunk: sparse A, exact zeros among the emission
+    // probabilities) carries the exponent "minus infinity": it must not take part when the rows'
+    // exponents are aligned downstream (the others would be shifted out of range)
+    out[N * N + r] = zero_row ? (double)ROW_EXP_NONE : (double)ex;
 }
 
 // =========================================================================================
@@ -384,13 +393,13 @@ __global__ __launch_bounds__(64) void k_compose(const int32_t *grp_c0, const int
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             ek[k] = (int)src[N * N + k];
-            if (row[k] > 0.0)
+            if (row[k] > 0.0 && ek[k] > ROW_EXP_NONE / 2)
                 E = max(E, ek[k] + exponent_of(row[k]));
         }
         double w[N];
 #pragma unroll
         for (int k = 0; k < N; ++k)
-            w[k] = ldexp(row[k], ek[k] - E);
+            w[k] = ek[k] > ROW_EXP_NONE / 2 ? ldexp(row[k], ek[k] - E) : 0.0;
         double nr[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -403,10 +412,17 @@ __global__ __launch_bounds__(64) void k_compose(const int32_t *grp_c0, const int
         ex += (E == NEG ? 0 : E) + renorm_row<N>(nr, row);
     }
     double *out = Pbuf + (int64_t)gidx * MS;
+    bool zero_row = ex <= ROW_EXP_NONE / 2;
+    {
+        bool all0 = true;
 #pragma unroll
-    for (int j = 0; j < N; ++j)
-        out[r * N + j] = row[j];
-    out[N * N + r] = (double)ex;
+        for (int j = 0; j < N; ++j) {
+            out[r * N + j] = row[j];
+            all0 = all0 && row[j] == 0.0;
+        }
+        zero_row = zero_row || all0;
+    }
+    out[N * N + r] = zero_row ? (double)ROW_EXP_NONE : (double)ex;
 }
 
 // =========================================================================================
@@ -476,8 +492,9 @@ __global__ __launch_bounds__(64) void k_stitch(const int32_t *seg_c0, const int3
                 if (ci < nc) {
                     alpha_entry[(int64_t)(c0 + ci) * N + r] = a;
                     const int e = (int)er[u];
-                    const int E = group_max<N>(a > 0.0 ? e + exponent_of(a) : NEG);
-                    const double w = ldexp(a, e - E);
+                    const bool use = a > 0.0 && e > ROW_EXP_NONE / 2; // (a zero row of M: see k_prescan)
+                    const int E = group_max<N>(use ? e + exponent_of(a) : NEG);
+                    const double w = use ? ldexp(a, e - E) : 0.0;
                     double buf[N];
 #pragma unroll
                     for (int j = 0; j < N; ++j)
@@ -550,8 +567,9 @@ __global__ __launch_bounds__(64) void k_stitch(const int32_t *seg_c0, const int3
                         const int e = (int)er[u];
                         if (ci + PD < nc - 1)
                             fetch(u, c - PD);
-                        const int E = group_max<N>(s > 0.0 ? e + exponent_of(s) : NEG);
-                        b = ldexp(s, e - E); // largest entry of the group in [0.5, 1)
+                        const bool use = s > 0.0 && e > ROW_EXP_NONE / 2;
+                        const int E = group_max<N>(use ? e + exponent_of(s) : NEG);
+                        b = use ? ldexp(s, e - E) : 0.0; // largest entry of the group in [0.5, 1)
                     }
                 }
             }

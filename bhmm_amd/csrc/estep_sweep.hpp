@@ -439,6 +439,19 @@ __device__ __forceinline__ void beta_step(const G &gather, const ObsIn &in, int 
 {
     constexpr int H = N / 2;
     int hm;
+    if constexpr (CAREFUL) {
+        // p o beta in the denormal range although neither factor is (a state that explains this
+        // observation well but the future badly): the sums formed from it would be denormal and
+        // their reciprocals infinite.  gamma, xi and the rescaled beta only see the vector up to
+        // a factor, so p is brought up by 2^900 first (exact; rare: one uniform branch).
+        const int hb = grp_max_i32<H>(max(__double2hiint(p[0] * b[0]), __double2hiint(p[1] * b[1])));
+        if (__builtin_expect(__ballot(hb < (64 << 20)) != 0ull, 0)) {
+            if (hb < (64 << 20)) {
+                p[0] = ldexp(p[0], 900);
+                p[1] = ldexp(p[1], 900);
+            }
+        }
+    }
     if constexpr (CAREFUL && KIND == EMIT_GAUSS) {
         for (;;) { // runs once; a second time only after the outlier rule replaced p
             const double bb[2] = {p[0] * b[0], p[1] * b[1]};

@@ -151,18 +151,18 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         const uint32_t *nb = nib, *gwc = gw;
         if (c->kind == EMIT_GAUSS)
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
-                               chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
+                               chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp, status);
         else if (c->kind == EMIT_DISC) {
             const size_t smd = bigM ? 0 : (size_t)c->M * N * sizeof(double);
             if (smd > 64 * 1024)
                 BHMM_HIP(hipFuncSetAttribute((const void *)(k_smp_apply<N, EMIT_DISC>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smd));
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK), smd, c->stream, m,
-                               chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
+                               chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp, status);
         }
         else
             hipLaunchKernelGGL((k_smp_apply<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
-                               chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp);
+                               chs, offd, obs_ci, P, ns, path, cnt, epart, dmk, nb, W8, Gp64, gwc, Lp, status);
         BHMM_HIP(hipGetLastError());
         if (esz) {
             hipLaunchKernelGGL(k_add_partials, dim3((unsigned)esz), dim3(64), 0,

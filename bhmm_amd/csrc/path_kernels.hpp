@@ -109,7 +109,10 @@ __global__ __launch_bounds__(64) void k_sample_path(const Model<N> m, const int6
 // arithmetic -- and falls back to exactly that arithmetic (IEEE division, ascending sums)
 // otherwise, so the sampled path is identical to the reference's for the same uniforms.
 // =========================================================================================
-template <int N>
+// SPEC (the map kernels, which also draw for next states the path may never take): a draw whose
+// weights are all zero -- an impossible next state under a sparse transition matrix -- returns -1
+// instead of raising; the caller marks that map entry, and only a walk that really uses it fails.
+template <int N, bool SPEC = false>
 __device__ __forceinline__ int pick_state(const double (&a)[N], const double *col, double r, int n,
                                           int *status)
 {
@@ -142,6 +145,10 @@ __device__ __forceinline__ int pick_state(const double (&a)[N], const double *co
         }
     }
     if (pick < 0) {
+        if constexpr (SPEC) {
+            if (!(S > 0.0))
+                return -1;
+        }
         *status = BHMM_ERR_CHOICE;
         pick = n - 1;
     }
@@ -431,7 +438,9 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
             while (todo) {
                 const int x = __ffs(todo) - 1;
                 todo &= todo - 1;
-                G |= (uint32_t)pick_state<N>(a, last ? nullptr : sAt + x * N, r, n, status) << (4 * x);
+                const int y = pick_state<N, true>(a, last ? nullptr : sAt + x * N, r, n, status);
+                // (bit 3 of a nibble: no state can precede next state x here)
+                G |= (y < 0 ? (8u | (uint32_t)(n - 1)) : (uint32_t)y) << (4 * x);
             }
         }
         // the images of the next step down: G over the alive set
@@ -445,7 +454,9 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
             alive_set = nset;
         }
         if (one) {
-            const uint32_t x1 = (G >> (4 * (__ffs(alive) - 1))) & 7u;
+            const uint32_t e1 = (G >> (4 * (__ffs(alive) - 1))) & 15u, x1 = e1 & 7u;
+            if (e1 & 8u) // the path itself has no possible predecessor (_hidden.c:299-304)
+                *status = BHMM_ERR_CHOICE;
             cur = x1 * 0x11111111u;
             if (last) {
                 dm = s; // no successor state: k_smp_apply takes this step (a constant map)
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
                                                    const int32_t *next_state, int32_t *path,
                                                    unsigned long long *counts, double *epartials,
                                                    const int32_t *dmark, const uint32_t *nib, int W8,
-                                                   int64_t Gp, const uint32_t *gw, int Lp)
+                                                   int64_t Gp, const uint32_t *gw, int Lp, int *status = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[]; // discrete: [M][N] counts
     __shared__ unsigned int cnt[N * N + N];
@@ -665,6 +676,8 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
             (void)y_cur;
             const bool last = (t0 + s == Tk - 1);
             const int st = (int)((g_cur >> (4 * (s >= dm ? nxt : (j & 7)))) & 7u);
+            if (s >= dm && ((g_cur >> (4 * nxt)) & 8u) && status) // entry marked by k_smp_maps:
+                *status = BHMM_ERR_CHOICE;                        // no state can precede nxt here
             if (path)
                 path[base + s] = st;
             if (!last)

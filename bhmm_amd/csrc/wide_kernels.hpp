@@ -320,6 +320,19 @@ __device__ __forceinline__ double wide_emit(const WideModel &m, int j, bool real
     return p;
 }
 
+// p o beta in the denormal range although neither factor is (a state that explains this observation
+// well but the future badly): sums formed from it would be denormal, their reciprocals infinite.
+// The kernels that normalise every step only see the vector up to a factor: p times 2^900 (exact).
+template <int NP>
+__device__ __forceinline__ double rescue_product(double p, double b, unsigned long long gmask)
+{
+    const double x = p * b;
+    if (__builtin_expect((__ballot(x >= 0x1p-959) & gmask) == 0ull, 0))
+        if ((__ballot(x != 0.0) & gmask) != 0ull)
+            return ldexp(p, 900);
+    return p;
+}
+
 // Segments: a trajectory may be cut into time segments that are processed by different lane
 // groups (one segment per trajectory = the plain serial recursion).  With several segments the
 // boundary vectors come from warm-ups over the W steps before / after the segment and are
@@ -609,7 +622,9 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                         const int rn = r + WIDE_PF < nwarm ? r + WIDE_PF : nwarm - 1;
                         ring[u] = wide_load<KIND>(m, i, real, o0 + te - rn, obs_rm);
                     }
-                    const double p = wide_emit<NP, KIND, !LAZY>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
+                    double p = wide_emit<NP, KIND, !LAZY>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
+                    if constexpr (!LAZY)
+                        p = rescue_product<NP>(p, b, gmask);
                     b = back(p, b);
                     if (!LAZY || (u & 3) == 3)
                         b = rescale(b);
@@ -653,7 +668,9 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                 const WideIn in = ro[u];
                 const double ap = ra[u];
                 fetch(u, r + WIDE_PF);
-                const double p = wide_emit<NP, KIND, !LAZY>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
+                double p = wide_emit<NP, KIND, !LAZY>(m, i, real, in, mu_i, ga_i, gb_i, gmask);
+                if constexpr (!LAZY)
+                    p = rescue_product<NP>(p, b, gmask);
                 // consume gamma_t
                 sgm += gam;
                 if constexpr (KIND == EMIT_GAUSS) {

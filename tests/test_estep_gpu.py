@@ -391,6 +391,55 @@ def test_densities_in_the_denormal_range(n):
         eng.close()
 
 
+@pytest.mark.parametrize("case", ["stress_case_53_204", "stress_case_51_278", "stress_case_55_240"])
+def test_cases_found_by_the_random_sweep(case):
+    """Inputs on which tools/stress_small.py (random parity sweep against the oracle) found defects:
+    sparse transition matrices with very narrow states -- p o beta in the denormal range although
+    neither factor is (NaN counts; 6 and 12 states) -- and an absorbing state among far outliers
+    (zero rows of the chunk transfer matrices took part in the exponent alignment of the exact
+    boundary pass: non-finite likelihood whenever the speculation gave up)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "stress", case + ".npz"))
+    A, pi, mu, sig = d["A"], d["pi"], d["par0"], d["par1"]
+    obs = np.split(d["obs"], np.cumsum(d["lens"])[:-1])
+    ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+    for chunk in (int(d["chunk"]), 0):
+        for sg in (False, True):
+            eng = _engine()
+            eng.set_observations("gaussian", obs, len(mu), chunk=chunk)
+            for _ in range(2):
+                res = eng.estep(A, pi, mu, sig, store_gamma=sg)
+                np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-10)
+                np.testing.assert_allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10)
+                np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-8, atol=1e-10)
+            eng.close()
+
+
+def test_sampled_paths_with_a_sparse_transition_matrix():
+    """The map kernels of the Gibbs step also draw for next states the path cannot take; with zeros
+    in A such a draw has no possible predecessor.  It must not raise (only a walk that really uses
+    such an entry fails): same paths as the reference for the same uniforms."""
+    rng = np.random.default_rng(8)
+    n = 6
+    for trial in range(6):
+        A = rng.random((n, n)) * (rng.random((n, n)) < 0.4)
+        A[np.arange(n), np.arange(n)] = rng.random(n) + 0.5
+        A /= A.sum(axis=1, keepdims=True)
+        pi = rng.dirichlet(np.ones(n))
+        mu, sig = np.linspace(-4, 4, n), rng.uniform(0.5, 1.5, n)
+        obs = [rng.normal(0, 3, T) for T in (700, 33, 1500)]
+        u = [rng.random(len(o)) for o in obs]
+        ref = [orc.sample_path(orc.forward(A, orc.pobs_gaussian(o, mu, sig), pi)[1], A, u=uu)
+               for o, uu in zip(obs, u)]
+        eng = _engine()
+        eng.set_observations("gaussian", obs, n, chunk=int(rng.choice([0, 16, 100])))
+        paths, C, n0, _ = eng.sample_paths(A, pi, mu, sig, u=u)
+        assert all(np.array_equal(a, b) for a, b in zip(paths, ref))
+        Cr, n0r = orc.path_counts(ref, n)
+        assert np.array_equal(C, Cr) and np.array_equal(n0, n0r)
+        eng.close()
+
+
 def test_nan_observation_is_not_a_hit(golden):
     """A NaN observation must poison its trajectory (the reference's pobs row is NaN) on every
     path that evaluates the density with the clamp modifier: the upload finds it and keeps the

@@ -27,8 +27,15 @@ for case in range(ncase):
     lens = [int(x) for x in rng.integers(1, int(rng.choice([40, 400, 3000, 12000])), K)]
     chunk = int(rng.choice([0, 0, 1, 7, 16, 33, 100]))
     A = rng.random((n, n)) + rng.choice([0.0, 2.0, 10.0]) * np.eye(n)
+    if n > 1 and rng.random() < 0.3:  # sparse transitions (every row keeps its diagonal)
+        mask = rng.random((n, n)) < 0.5
+        np.fill_diagonal(mask, True)
+        A = A * mask + 1e-300 * np.eye(n)
     A /= A.sum(axis=1, keepdims=True)
     pi = rng.dirichlet(np.ones(n))
+    if n > 1 and rng.random() < 0.2:
+        pi[rng.integers(0, n)] = 0.0
+        pi /= pi.sum()
     if kind == "gaussian":
         regime = rng.choice(["plain", "far", "narrow"])
         mu, sig = np.sort(rng.normal(0, 3, n)), rng.uniform(0.3, 2.0, n)
@@ -40,6 +47,11 @@ for case in range(ncase):
     else:
         M = int(rng.choice([2, 17, 64, 300, 1150, 1300, 4000]))
         B = rng.dirichlet(np.ones(M) * 0.5, size=n) * 0.98 + 0.02 / M
+        if rng.random() < 0.3:  # symbols some states cannot emit (never a whole column)
+            zero = rng.random((n, M)) < 0.3
+            zero[rng.integers(0, n, M), np.arange(M)] = False
+            B = np.where(zero, 0.0, B)
+            B /= B.sum(axis=1, keepdims=True)
         obs = [rng.integers(0, M, T).astype(np.int32) for T in lens]
         par = (B, None)
     tag = "case %d: %s n=%d M=%d K=%d lens=%s chunk=%d" % (case, kind, n, M, K, lens, chunk)
@@ -70,6 +82,10 @@ for case in range(ncase):
             if not ok:
                 bad += 1
                 print("ESTEP MISMATCH", tag, "rep", rep, np.abs(res.logL_k - ref["logL"]).max(), np.abs(res.C - ref["C"]).max())
+                if os.environ.get("SAVE") and rep == 0:
+                    np.savez(os.path.join(os.environ["SAVE"], "stress_case_%d_%d.npz" % (int(sys.argv[1]) if len(sys.argv) > 1 else 7, case)),
+                             A=A, pi=pi, par0=par[0], par1=par[1] if par[1] is not None else np.zeros(0), kind=kind, chunk=chunk,
+                             obs=np.concatenate(obs), lens=np.array(lens))
                 if os.environ.get("VERBOSE"):
                     print("  gpu logL", res.logL_k, "ref", ref["logL"], "gpu C", res.C, "ref C", ref["C"], "par", par,
                           "careful", eng.get_option("careful"), "spec ok/fail", eng.get_option("spec_ok"), eng.get_option("spec_fail"),
@@ -91,6 +107,10 @@ for case in range(ncase):
                 print("SAMPLE MISMATCH", tag, "traj", k)
         eng.close()
     except Exception as e:  # noqa
+        if os.environ.get("SAVE"):
+            np.savez(os.path.join(os.environ["SAVE"], "stress_case_%d_%d.npz" % (int(sys.argv[1]) if len(sys.argv) > 1 else 7, case)),
+                     A=A, pi=pi, par0=par[0], par1=par[1] if par[1] is not None else np.zeros(0), kind=kind, chunk=chunk,
+                     obs=np.concatenate(obs), lens=np.array(lens))
         bad += 1
         print("EXCEPTION", tag, repr(e)[:300])
 print("stress: %d cases, %d failures" % (ncase, bad))
