@@ -677,18 +677,24 @@ __device__ __forceinline__ ObsIn load_obs(const void *obs_ci, int64_t rec, int c
     return in;
 }
 
-// emission probabilities of MY two states (+ the outlier rule)
+// emission probabilities of MY two states (+ the outlier rule).  `is` holds sigma: the gaussian
+// density is evaluated in the reference's own operation order (_gaussian.c:5-21; cf. k_prescan).
+// A row without any entry of 2^-959 or more (densities / caller-supplied rows in the denormal range)
+// is returned times 2^900 and the function returns 900 (else 0): the callers normalise by sums and
+// their reciprocals, which are infinite for denormal sums; the forward rows take the exponent off
+// their likelihood count.
 template <int N, int KIND>
-__device__ __forceinline__ void emit_pair(const Model<N> &m, const ObsIn &in, const double *Bt,
-                                          int q, const double (&mu)[2], const double (&is)[2],
-                                          const double (&cn)[2], unsigned long long gmask,
-                                          double (&p)[2])
+__device__ __forceinline__ int emit_pair(const Model<N> &m, const ObsIn &in, const double *Bt,
+                                         int q, const double (&mu)[2], const double (&is)[2],
+                                         const double (&cn)[2], unsigned long long gmask,
+                                         double (&p)[2])
 {
     if constexpr (KIND == EMIT_GAUSS) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const double z = (in.o - mu[b]) * is[b];
-            p[b] = cn[b] * exp(-0.5 * z * z);
+            const bool real = 2 * q + b < m.nreal;
+            const double z = real ? (in.o - mu[b]) / is[b] : 0.0;
+            p[b] = real ? cn[b] * exp(-0.5 * z * z) : 0.0;
         }
         if ((__ballot(p[0] != 0.0 || p[1] != 0.0) & gmask) == 0ull) {
             p[0] = (2 * q < m.nreal) ? 1.0 : 0.0; // outlier row, outputmodel.py:126-130
@@ -702,6 +708,13 @@ __device__ __forceinline__ void emit_pair(const Model<N> &m, const ObsIn &in, co
         p[0] = in.pp.x;
         p[1] = in.pp.y;
     }
+    if ((__ballot(p[0] >= 0x1p-959 || p[1] >= 0x1p-959) & gmask) == 0ull &&
+        (__ballot(p[0] != 0.0 || p[1] != 0.0) & gmask) != 0ull) {
+        p[0] = ldexp(p[0], 900);
+        p[1] = ldexp(p[1], 900);
+        return 900;
+    }
+    return 0;
 }
 
 __device__ __forceinline__ double2 *ci_pair(double *base, int64_t rec, int N_, int q, int cl)
@@ -748,7 +761,7 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         mu[b] = m.e0[2 * q + b];
-        is[b] = m.e1[2 * q + b];
+        is[b] = m.e3[2 * q + b]; // sigma (emit_pair)
         cn[b] = m.e2[2 * q + b];
         pi2[b] = m.pi[2 * q + b];
     }
@@ -765,7 +778,7 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
         ObsIn nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, 0, ch.Lmax), cl, q);
         if (first) {
             double p[2];
-            emit_pair<N, KIND>(m, nxt, Bt, q, mu, is, cn, gmask, p);
+            const int pe0 = emit_pair<N, KIND>(m, nxt, Bt, q, mu, is, cn, gmask, p);
             if (len > 1)
                 nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, 1, ch.Lmax), cl, q);
             a[0] = pi2[0] * p[0];
@@ -775,6 +788,7 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
             a[0] *= rc;
             a[1] *= rc;
             P = frexp(c, &eP);
+            eP -= pe0;
             *ci_pair(ws, ci_rec(g, 0, ch.Lmax), N, q, cl) = make_double2(a[0], a[1]);
             s = 1;
         } else {
@@ -790,7 +804,7 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
             const ObsIn cur = nxt;
             if (s + 1 < len) // issue the next step's load before this step's arithmetic
                 nxt = load_obs<N, KIND>(obs_ci, rec + 1, cl, q);
-            emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
+            const int pe = emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
             double af[N];
             grp_gather<N>(a, af);
             double n0 = af[0] * Ac[0][0], n1 = af[0] * Ac[0][1];
@@ -807,7 +821,7 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
             a[1] = n1 * rc;
             int e;
             P = frexp(P * c, &e);
-            eP += e;
+            eP += e - pe;
             *ci_pair(ws, rec, N, q, cl) = make_double2(a[0], a[1]);
         }
         if (q == 0)
@@ -829,7 +843,14 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
         for (int s = len - 1; s >= 1; --s) {
             double p[2];
             const ObsIn cur = load_obs<N, KIND>(obs_ci, ci_rec(g, s, ch.Lmax), cl, q);
-            emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
+            (void)emit_pair<N, KIND>(m, cur, Bt, q, mu, is, cn, gmask, p);
+            {   // p o beta in the denormal range although neither factor is: p times 2^900
+                const int hb = grp_max_i32<H>(max(__double2hiint(p[0] * b2[0]), __double2hiint(p[1] * b2[1])));
+                if (hb < (64 << 20)) {
+                    p[0] = ldexp(p[0], 900);
+                    p[1] = ldexp(p[1], 900);
+                }
+            }
             const double bb2[2] = {p[0] * b2[0], p[1] * b2[1]};
             double bf[N];
             grp_gather<N>(bb2, bf);

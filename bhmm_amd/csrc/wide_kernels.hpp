@@ -945,7 +945,8 @@ __global__ __launch_bounds__(64) void k_wide_beta(const WideModel m, const int64
     if (real)
         beta_rm[(o0 + T - 1) * n + i] = b;
     for (int64_t t = T - 1; t >= 1; --t) {
-        const double p = real ? pobs_rm[(o0 + t) * n + i] : 0.0;
+        const double p = rescue_product<NP>(real ? pobs_rm[(o0 + t) * n + i] : 0.0, b,
+                                            wgroup_mask<NP>(lane));
         xg[i] = p * b;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -993,7 +994,8 @@ __global__ __launch_bounds__(64) void k_wide_xi(const double *A, const double *p
     for (int c = 0; c < NP; ++c)
         Crow[c] = 0.0;
     for (int64_t t = t0; t < t1; ++t) {
-        xg[i] = real ? pobs[(t + 1) * n + i] * beta[(t + 1) * n + i] : 0.0;
+        xg[i] = real ? rescue_product<NP>(pobs[(t + 1) * n + i], beta[(t + 1) * n + i],
+                                           wgroup_mask<NP>(lane)) * beta[(t + 1) * n + i] : 0.0;
         const double a = real ? alpha[t * n + i] : 0.0;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

@@ -1,0 +1,95 @@
+"""Random parity sweep of the single-trajectory kernel API (bhmm_amd.hidden: forward, backward,
+state_probabilities, transition_counts, viterbi, sample_path on caller-supplied pobs) against the
+oracle: 1..64 states, lengths 1..5000, dense and sparse A, pobs rows with exact zeros and with
+entries spread over hundreds of decades.  The values are compared with the reference's recursions in
+80-bit arithmetic (tests/ld_reference.py): where relative weights leave the double range (below
+1e-308 of the row) the double-precision reference loses states for good -- an exact zero stays zero
+under a transition matrix that does not refill it -- while the chunk-parallel kernels carry separate
+exponents; paths are compared with the oracle's where its rows agree with the 80-bit ones.
+usage: python tools/stress_hidden.py [seed [cases]]"""
+import os, sys
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+import bhmm_amd.hidden as hidden
+from oracle import oracle as orc
+from ld_reference import hidden_longdouble
+hidden.set_implementation("hip")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+bad = unreliable = 0
+for case in range(ncase):
+    n = int(rng.choice([1, 2, 3, 5, 8, 9, 13, 16, 24, 33, 64]))
+    T = int(rng.choice([1, 2, 7, 50, 700, 5000]))
+    A = rng.random((n, n)) + rng.choice([0.0, 3.0]) * np.eye(n)
+    if n > 1 and rng.random() < 0.3:
+        mask = rng.random((n, n)) < 0.5
+        np.fill_diagonal(mask, True)
+        A *= mask
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    spread = rng.choice([1.0, 30.0, 200.0, 720.0])
+    pobs = np.exp(-spread * rng.random((T, n)))
+    if rng.random() < 0.3:
+        z = rng.random((T, n)) < 0.3
+        z[np.arange(T), rng.integers(0, n, T)] = False
+        pobs[z] = 0.0
+    tag = "case %d: n=%d T=%d spread=%g" % (case, n, T, spread)
+    try:
+        with np.errstate(all="ignore"):
+            lr, ar = orc.forward(A, pobs, pi)
+            br = orc.backward(A, pobs)
+            Cr = orc.transition_counts(ar, br, A, pobs)
+            vr = orc.viterbi(A, pobs, pi)
+        if not (np.isfinite(lr) and np.all(np.isfinite(ar)) and np.all(np.isfinite(br)) and np.all(np.isfinite(Cr))):
+            continue
+        lg, ag = hidden.forward(A, pobs, pi)
+        bg = hidden.backward(A, pobs)
+        gg = hidden.state_probabilities(ag, bg)
+        Cg = hidden.transition_counts(ag, bg, A, pobs)
+        vg = hidden.viterbi(A, pobs, pi)
+        u = rng.random(T)
+        try:
+            sg = hidden.sample_path(ag, A, pobs, u=u)
+            sr = orc.sample_path(ar, A, u=u)
+        except Exception:
+            sg = sr = None
+        with np.errstate(all="ignore"):
+            l_ld, a_ld, b_ld, g_ld, C_ld = hidden_longdouble(A, pobs, pi)
+        ref_ok = (np.allclose(ar, a_ld, rtol=1e-6, atol=1e-250) and np.allclose(br, b_ld, rtol=1e-6, atol=1e-250)
+                  and np.isclose(lr, l_ld, rtol=1e-9))
+        if ref_ok:
+            checks = {"logL": np.isclose(lg, lr, rtol=1e-11, atol=1e-11), "alpha": np.allclose(ag, ar, rtol=1e-9, atol=1e-250),
+                      "beta": np.allclose(bg, br, rtol=1e-9, atol=1e-250), "gamma": np.allclose(gg, orc.gamma(ar, br), rtol=1e-9, atol=1e-250),
+                      "C": np.allclose(Cg, Cr, rtol=1e-8, atol=1e-12), "viterbi": np.array_equal(vg, vr),
+                      "sample": sg is not None and np.array_equal(sg, sr)}
+        else:
+            # the double-precision reference has lost states the 80-bit recursion keeps (relative
+            # weights below 1e-308 that matter again later: reducible / sparse A): no parity claim
+            # there, the outputs only have to be finite and normalised
+            unreliable += 1
+            checks = {"finite": bool(np.isfinite(lg) and np.all(np.isfinite(ag)) and np.all(np.isfinite(bg))),
+                      "alpha rows sum to one": np.allclose(ag.sum(axis=1), 1.0, rtol=1e-12)}
+        for k, ok in checks.items():
+            if not ok:
+                bad += 1
+                print("MISMATCH", k, tag)
+                if os.environ.get("VERBOSE") and k in ("alpha", "beta", "gamma"):
+                    g_, r_ = {"alpha": (ag, ar), "beta": (bg, br), "gamma": (gg, orc.gamma(ar, br))}[k]
+                    with np.errstate(all="ignore"):
+                        rel = np.abs(g_ - r_) / np.abs(r_)
+                    rel[~np.isfinite(rel)] = 0
+                    t, i = np.unravel_index(np.argmax(rel), rel.shape)
+                    print("   worst at t=%d state %d: gpu %r ref %r (row gpu %s ref %s, pobs row %s)" % (t, i, g_[t, i], r_[t, i], g_[t], r_[t], pobs[t]))
+                    print("   non-finite gpu entries:", int((~np.isfinite(g_)).sum()))
+    except Exception as e:  # noqa
+        if os.environ.get("SAVE"):
+            np.savez(os.path.join(os.environ["SAVE"], "hidden_case_%s_%d.npz" % (sys.argv[1] if len(sys.argv) > 1 else "3", case)), A=A, pi=pi, pobs=pobs, u=u, ag=ag, ar=ar)
+        if os.environ.get("VERBOSE"):
+            import traceback; traceback.print_exc()
+            print("   alpha gpu finite:", bool(np.all(np.isfinite(ag))), "row sums min/max", ag.sum(1).min(), ag.sum(1).max())
+            print("   alpha ref row sums min/max", ar.sum(1).min(), ar.sum(1).max())
+        bad += 1
+        print("EXCEPTION", tag, repr(e)[:200])
+print("stress_hidden: %d cases, %d failures (%d cases where the double-precision reference itself is off the 80-bit recursion)" % (ncase, bad, unreliable))
+sys.exit(1 if bad else 0)
