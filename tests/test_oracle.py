@@ -206,3 +206,28 @@ def test_bit_identical_to_compiled_reference(N, T, seed):
     o_int = rng.integers(0, 5, T).astype(np.int32)
     assert np.array_equal(orc.update_pout(o_int, w, np.zeros((N, 5))),
                           orc.ref_update_pout(o_int, w, np.zeros((N, 5))))
+
+
+def test_longdouble_recursions_agree_with_the_oracle_in_the_normal_range():
+    """tests/ld_reference.py (the reference's recursions in 80-bit arithmetic: the arbiter where the
+    double-precision reference loses precision in the denormal range) is itself pinned here: on
+    ordinary inputs it reproduces the oracle to rounding."""
+    from ld_reference import estep_longdouble, hidden_longdouble
+    rng = np.random.default_rng(3)
+    for n in (1, 3, 8, 13):
+        A = rng.random((n, n)) + np.eye(n)
+        A /= A.sum(axis=1, keepdims=True)
+        pi = rng.dirichlet(np.ones(n))
+        mu, sig = np.linspace(-2, 2, n), rng.uniform(0.5, 1.5, n)
+        obs = [rng.normal(0, 2, T) for T in (120, 33)]
+        ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+        pobs = [orc.pobs_gaussian(o, mu, sig) for o in obs]
+        logL, C = estep_longdouble(A, pi, pobs)
+        np.testing.assert_allclose(logL, ref["logL"], rtol=1e-13)
+        np.testing.assert_allclose(C, ref["C"], rtol=1e-11, atol=1e-13)
+        l, a, b, g, C1 = hidden_longdouble(A, pobs[0], pi)
+        lr, ar = orc.forward(A, pobs[0], pi)
+        np.testing.assert_allclose(l, lr, rtol=1e-13)
+        np.testing.assert_allclose(a, ar, rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(b, orc.backward(A, pobs[0]), rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(g, orc.gamma(ar, orc.backward(A, pobs[0])), rtol=1e-11, atol=1e-300)
