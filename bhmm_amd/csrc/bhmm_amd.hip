@@ -1047,11 +1047,12 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     c->d_bgrp.release();
     c->d_aexit.release();
     c->d_bentry.release();
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < 3; ++w) {
         c->d_wseg_traj[w].release();
         c->d_wseg_len[w].release();
         c->d_wseg_traj0[w].release();
         c->d_wseg_t0[w].release();
+        c->d_wseg_fmid.release();
     }
     c->d_wlogLseg.release();
     c->d_waentry.release();
@@ -1349,6 +1350,8 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
         c->wseg_enabled = value != 0.0;
     else if (n == "wide_segment_len")
         c->wseg_len = std::max(0, (int)value); // takes effect at the next set_observations
+    else if (n == "wide_split")
+        c->wseg_split = value != 0.0; // 64 states: own, finer segment plan for the forward pass
     else
         return invalid("unknown or read-only option: " + n);
     return BHMM_OK;
@@ -1377,6 +1380,9 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->viterbi_close;
     else if (n == "wide_segments")
         *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
+    else if (n == "wide_fwd_segments") // the forward pass's own, finer plan (64 states), 0 if none
+        *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0] &&
+                  c->w_nseg[2] > c->w_nseg[1]) ? c->w_nseg[2] : 0;
     else
         return invalid("unknown option: " + n);
     return BHMM_OK;

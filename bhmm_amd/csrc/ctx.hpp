@@ -124,11 +124,15 @@ struct bhmm_ctx {
     bool wide = false;               // nstates > 8: wide_kernels.hpp family
     // wide family: segment tables.  [0] = one segment per trajectory (exact serial recursion),
     // [1] = time-segmented plan with verified warm-up boundaries (optional)
-    int w_nseg[2] = {0, 0};
-    bhmm::DevBuf<int32_t> d_wseg_traj[2], d_wseg_len[2], d_wseg_traj0[2];
-    bhmm::DevBuf<int64_t> d_wseg_t0[2];
+    // plans: 0 = one segment per trajectory, 1 = time segments (both passes), 2 = the forward pass's
+    // own, finer time segments (64 states: it fits two wavefronts per SIMD, the backward pass one)
+    int w_nseg[3] = {0, 0, 0};
+    bhmm::DevBuf<int32_t> d_wseg_traj[3], d_wseg_len[3], d_wseg_traj0[3];
+    bhmm::DevBuf<int64_t> d_wseg_t0[3];
+    bhmm::DevBuf<int64_t> d_wseg_fmid;  // plan 1: start of the forward pass's second segment inside each
     bhmm::DevBuf<double> d_wlogLseg, d_waentry, d_waexit, d_wbexit, d_wbentry;
     bool wseg_enabled = true;
+    bool wseg_split = true;     // 64 states: own, finer plan for the forward pass (wide_plan_segments)
     int64_t wseg_cur_len = 0;   // segment length of plan 1 (re-plans only lengthen: buffers are sized once)
     int wseg_len = 0;                // 0 = automatic
     double *h_raw = nullptr;         // pinned: [verdict words, 2 sets (4 doubles) | stats | logL_k]

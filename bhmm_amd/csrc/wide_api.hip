@@ -68,14 +68,24 @@ static Segs segs_of(bhmm_ctx *c, int which)
     sg.t0 = c->d_wseg_t0[which].p;
     sg.len = c->d_wseg_len[which].p;
     sg.nseg = c->w_nseg[which];
-    sg.W = c->spec_W;
+    // (segment starts and the warm-up are multiples of four: the lazily scaled passes then rescale on
+    // the steps t % 4 == 3 whatever plan each of them runs on)
+    sg.W = (c->spec_W + 3) & ~3;
+    sg.fmid = (which == 1 && c->w_nseg[2] > c->w_nseg[1]) ? c->d_wseg_fmid.p : nullptr;
     return sg;
+}
+
+// the plan the forward pass runs on when the backward pass runs on `which`
+static int wide_fwd_plan(const bhmm_ctx *c, int which)
+{
+    return (which == 1 && c->w_nseg[2] > c->w_nseg[1]) ? 2 : which;
 }
 
 template <int NP, int KIND>
 static int wide_launch_fwd(bhmm_ctx *c, const WideModel &m, int which, bool lazy = false)
 {
     constexpr int GP = 64 / NP;
+    which = wide_fwd_plan(c, which);
     const Segs sg = segs_of(c, which);
     if (lazy && NP == 64 && c->n == 64) // the shape of BASELINE configs[3]
         hipLaunchKernelGGL((k_wide_fwd<NP, KIND, true, NP == 64>), dim3((sg.nseg + GP - 1) / GP),
@@ -155,7 +165,7 @@ static int64_t wide_fill_len(const bhmm_ctx *c)
 }
 
 // segment plan `which` with segments of at most seglen steps (seglen <= 0: one per trajectory)
-static int wide_plan(bhmm_ctx *c, int which, int64_t seglen)
+static int wide_plan(bhmm_ctx *c, int which, int64_t seglen, int mult = 1)
 {
     std::vector<int32_t> st, sl, s0(c->K + 1, 0);
     std::vector<int64_t> stt;
@@ -164,12 +174,17 @@ static int wide_plan(bhmm_ctx *c, int which, int64_t seglen)
         const int64_t T = c->offsets[k + 1] - c->offsets[k];
         if (T <= 0)
             continue;
-        const int64_t ns = seglen > 0 ? (T + seglen - 1) / seglen : 1;
-        const int64_t base = T / ns, rem = T % ns;
-        for (int64_t q = 0; q < ns; ++q) {
+        const int64_t ns = (seglen > 0 ? (T + seglen - 1) / seglen : 1) * mult;
+        // boundaries at multiples of four (see segs_of)
+        int64_t prev = 0;
+        for (int64_t q = 1; q <= ns; ++q) {
+            int64_t b = q == ns ? T : ((q * T) / ns) & ~(int64_t)3;
+            if (b <= prev)
+                continue;
             st.push_back(k);
-            sl.push_back((int32_t)(base + (q < rem ? 1 : 0)));
-            stt.push_back(q * base + std::min(q, rem));
+            sl.push_back((int32_t)(b - prev));
+            stt.push_back(prev);
+            prev = b;
         }
     }
     s0[c->K] = (int32_t)st.size();
@@ -187,6 +202,45 @@ static int wide_plan(bhmm_ctx *c, int which, int64_t seglen)
     BHMM_HIP(hipMemcpy(c->d_wseg_traj0[which].p, s0.data(), (c->K + 1) * sizeof(int32_t),
                        hipMemcpyHostToDevice));
     return BHMM_OK;
+}
+
+// plan 1 with segments of seglen steps and, for 64 states, the forward pass's own plan 2 with half
+// of that (its kernel fits two wavefronts per SIMD; measured on configs[3]: 4.6 instead of 5.1 ms)
+// as long as its segments stay four warm-ups long
+static int wide_plan_segments(bhmm_ctx *c, int64_t seglen)
+{
+    int rc = wide_plan(c, 1, seglen);
+    if (rc)
+        return rc;
+    c->w_nseg[2] = 0;
+    // (every segment of plan 1 cut in two: the segment count stays a multiple of the SIMD count)
+    if (c->N == 64 && c->wseg_split && seglen / 2 >= 4 * (int64_t)c->spec_W && seglen >= 128) {
+        if ((rc = wide_plan(c, 2, seglen, 2)))
+            return rc;
+        // for every segment of plan 1: the start of a plan-2 segment strictly inside it (-1: none)
+        std::vector<int64_t> mid;
+        for (int k = 0; k < c->K; ++k) {
+            const int64_t T = c->offsets[k + 1] - c->offsets[k];
+            if (T <= 0)
+                continue;
+            const int64_t ns = (T + seglen - 1) / seglen;
+            int64_t prev = 0;
+            for (int64_t q = 1; q <= ns; ++q) {
+                const int64_t b = q == ns ? T : ((q * T) / ns) & ~(int64_t)3;
+                if (b <= prev)
+                    continue;
+                const int64_t m2 = (((2 * q - 1) * T) / (2 * ns)) & ~(int64_t)3;
+                mid.push_back(m2 > prev && m2 < b ? m2 : -1);
+                prev = b;
+            }
+        }
+        if ((int)mid.size() != c->w_nseg[1])
+            return BHMM_ERR_INVALID; // (cannot happen: both loops cut the trajectories the same way)
+        if ((rc = c->d_wseg_fmid.ensure(std::max<size_t>(mid.size(), 1))))
+            return rc;
+        BHMM_HIP(hipMemcpy(c->d_wseg_fmid.p, mid.data(), mid.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    return rc;
 }
 
 int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, const double *par0,
@@ -213,10 +267,11 @@ int wide_alloc(bhmm_ctx *c)
         for (int k = 0; k < c->K; ++k)
             maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
         c->wseg_cur_len = seglen;
-        if (c->wseg_enabled && maxT > seglen && (rc = wide_plan(c, 1, seglen)))
+        if (c->wseg_enabled && maxT > seglen && (rc = wide_plan_segments(c, seglen)))
             return rc;
     }
-    const int nsmax = std::max(std::max(c->w_nseg[0], c->w_nseg[1]), 1);
+    // (buffers sized for the finest plan there can be: plan 2 has at most twice the segments of plan 1)
+    const int nsmax = std::max(std::max(c->w_nseg[0], 2 * c->w_nseg[1] + c->K), 1);
     if ((rc = c->d_alpha_rm.ensure((size_t)c->total * n)) ||
         (rc = c->d_logLk.ensure(std::max(c->K, 1))) || (rc = c->d_wlogLseg.ensure(nsmax)) ||
         (rc = c->d_gamma0.ensure((size_t)std::max(c->K, 1) * n)) ||
@@ -379,7 +434,7 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
                 c->wseg_given_up = true;
             } else if (seglen > c->wseg_cur_len) {
                 c->wseg_cur_len = seglen;
-                if ((rc = wide_plan(c, 1, seglen)))
+                if ((rc = wide_plan_segments(c, seglen)))
                     return rc;
                 if (c->w_nseg[1] <= c->w_nseg[0])
                     c->wseg_given_up = true;
@@ -393,9 +448,12 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 3 * sizeof(unsigned int), c->stream));
         if ((rc = run(1, lazy)))
             return rc;
-        const Segs sgs = segs_of(c, 1);
-        hipLaunchKernelGGL(k_wide_check, dim3((sgs.nseg + 255) / 256), dim3(256), 0, c->stream, sgs,
+        const Segs sgs = segs_of(c, 1), sgf = segs_of(c, wide_fwd_plan(c, 1));
+        hipLaunchKernelGGL(k_wide_check, dim3((sgf.nseg + 255) / 256), dim3(256), 0, c->stream, sgf,
                            c->n, (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
+                           (const double *)nullptr, (const double *)nullptr, 1e-11, c->d_specres.p);
+        hipLaunchKernelGGL(k_wide_check, dim3((sgs.nseg + 255) / 256), dim3(256), 0, c->stream, sgs,
+                           c->n, (const double *)nullptr, (const double *)nullptr,
                            (const double *)c->d_wbexit.p, (const double *)c->d_wbentry.p, 1e-11,
                            c->d_specres.p);
         BHMM_HIP(hipGetLastError());
@@ -439,7 +497,7 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
             c->spec_W = (int)Wn;
             if (seglen > c->wseg_cur_len) {
                 c->wseg_cur_len = seglen;
-                if ((rc = wide_plan(c, 1, seglen)))
+                if ((rc = wide_plan_segments(c, seglen)))
                     return rc;
             }
             if (c->w_nseg[1] <= c->w_nseg[0])

@@ -344,6 +344,9 @@ struct Segs {
     const int32_t *len;
     int nseg;
     int W;
+    // backward pass only: where the forward pass, if it runs on a finer plan, starts a segment of
+    // its own inside this one (-1: nowhere) -- alpha there continues another chain of rescalings
+    const int64_t *fmid = nullptr;
 };
 
 // LAZY (E-step only): alpha is carried un-normalised, up to a power of two that is refreshed every
@@ -646,6 +649,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         constexpr bool SPARSE_SUM = LAZY && NP == 64;
         // alpha_t was rescaled by the forward pass where (t - tw) % 4 == 3, tw its warm-up start
         const int phase = (int)((t1 - 1 - ((t0 - sg.W > 0) ? t0 - sg.W : 0)) & 3);
+        const int64_t tmid = sg.fmid ? sg.fmid[s] : -1;
         double rS_keep = 0.0;
         auto fetch = [&](int u, int r) {
             const int64_t tt = t1 - 1 - (r < nmain ? r : nmain - 1);
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                     // the reciprocal (64 states; the chain restarts after four steps: no drift).
                     bool need = true;
                     if constexpr (SPARSE_SUM)
-                        need = r == 0 || last || ((phase - r) & 3) == 3;
+                        need = r == 0 || last || ((phase - r) & 3) == 3 || t == tmid;
                     if (need)
                         rS_keep = fast_rcp(wgroup_sum<NP>(q));
                     const double rS = rS_keep;
@@ -853,8 +857,10 @@ __global__ __launch_bounds__(64) void k_wide_probe(const WideModel m, const void
             dev = fmax(dev, r);
         }
     };
-    cmp(a_entry + (int64_t)s * n, a_exit + (int64_t)(s - 1) * n);
-    cmp(b_exit + (int64_t)(s - 1) * n, b_entry + (int64_t)s * n);
+    if (a_entry) // (the two passes may run on different segment plans: one launch per plan)
+        cmp(a_entry + (int64_t)s * n, a_exit + (int64_t)(s - 1) * n);
+    if (b_exit)
+        cmp(b_exit + (int64_t)(s - 1) * n, b_entry + (int64_t)s * n);
     if (!(dev <= tol))
         atomicAdd(&result[0], 1u);
     atomicMax(&result[1], __float_as_uint((float)fmin(dev, 1.0)));

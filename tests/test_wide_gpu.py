@@ -358,3 +358,39 @@ def test_wide_probe_sets_warmup_before_first_estep():
     r2 = eng.estep(A, pi, mu + 0.05, sig)
     assert np.array_equal(res.packed, r2.packed) and eng.get_option("spec_W") == W
     eng.close()
+
+
+def test_forward_pass_on_its_own_finer_segments():
+    """64 states: the forward kernel fits two wavefronts per SIMD, the backward kernel one, so the
+    forward pass runs on a plan with every segment cut in two.  The backward pass then meets a change
+    of alpha's rescaling chain in the middle of its segments (it must not reuse the gamma normaliser
+    across it): same statistics as the serial plan and as the common plan, odd lengths included."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(12)
+    n = 64
+    A = rng.random((n, n)) + 8 * np.eye(n)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    mu, sig = np.linspace(-6, 6, n), rng.uniform(0.4, 1.0, n)
+    obs = [rng.normal(0, 4, T) for T in (6001, 2503, 4099)]
+    res = {}
+    for tag, opts in (("serial", {"wide_segments": 0}), ("common", {"wide_split": 0}), ("split", {"wide_split": 1})):
+        eng = Engine(0)
+        eng.set_option("spec_W", 32)
+        eng.set_option("wide_segment_len", 1000)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.set_observations("gaussian", obs, n)
+        for _ in range(2):
+            r = eng.estep(A, pi, mu, sig)
+        res[tag] = (r, eng.get_option("wide_segments"), eng.get_option("wide_fwd_segments"), eng.get_option("spec_fail"))
+        eng.close()
+    assert res["serial"][1] == 0 and res["common"][1] > 3 and res["common"][2] == 0
+    assert res["split"][2] == 2 * res["split"][1] and res["split"][3] == 0
+    ref = res["serial"][0]
+    for tag in ("common", "split"):
+        r = res[tag][0]
+        np.testing.assert_allclose(r.logL_k, ref.logL_k, rtol=1e-12)
+        np.testing.assert_allclose(r.C, ref.C, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(r.state_counts, ref.state_counts, rtol=1e-10)
+        np.testing.assert_allclose(r.state_counts.sum(), sum(len(o) for o in obs), rtol=1e-12)

@@ -16,6 +16,8 @@ s = hidden_paths_gpu(A, pi, K, T, 12).long()
 obs = (torch.tensor(mu, device=dev)[s] + torch.tensor(sig, device=dev)[s] * torch.randn((K, T), device=dev, dtype=torch.float64)).reshape(-1)
 args = (0.9 * A + 0.1 / n, pi, mu + 0.05, sig)
 eng = Engine(0)
+if os.environ.get("C4_SPLIT") is not None:
+    eng.set_option("wide_split", int(os.environ["C4_SPLIT"]))
 if len(sys.argv) > 1:
     eng.set_option("spec_W", int(sys.argv[1]))
 if len(sys.argv) > 2:
