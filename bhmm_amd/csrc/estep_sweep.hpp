@@ -984,8 +984,25 @@ __device__ __forceinline__ void estep_body(
             consume(in, d, gdst);
             beta_step<N, KIND, CAREFUL, decltype(sc)::value>(gather, in, q, nreal, gmask, Ar, p, b2,
                                                              bf, r, bn, hmin, Eb);
-            const double q0 = apv.x * r[0], q1 = apv.y * r[1];
-            const double rS = fast_rcp(grp_sum<H>(q0 + q1));
+            double q0 = apv.x * r[0], q1 = apv.y * r[1];
+            double S = grp_sum<H>(q0 + q1);
+            if constexpr (CAREFUL) {
+                // alpha concentrated on states whose (A (p o beta)) is in the denormal range although
+                // p o beta as a whole is not (sparse A, narrow states): S is denormal, 1 / S infinite.
+                // The vectors are brought up by 2^900 (exact), which gamma and xi do not see.
+                if (__builtin_expect(__ballot(!(S >= 0x1p-959) && S > 0.0) != 0ull, 0)) {
+                    const int kk = (!(S >= 0x1p-959) && S > 0.0) ? 900 : 0;
+                    r[0] = ldexp(r[0], kk);
+                    r[1] = ldexp(r[1], kk);
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        bf[j] = ldexp(bf[j], kk);
+                    q0 = apv.x * r[0];
+                    q1 = apv.y * r[1];
+                    S = grp_sum<H>(q0 + q1);
+                }
+            }
+            const double rS = fast_rcp(S);
             gam[0] = q0 * rS;
             gam[1] = q1 * rS;
             const double w0 = apv.x * rS, w1 = apv.y * rS;

@@ -639,8 +639,12 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
         double a = real ? alpha_rm[(o0 + t1 - 1) * n + i] : 0.0;
         double gam;
         {
-            const double g = a * b;
-            gam = g * fast_rcp(wgroup_sum<NP>(g));
+            double g = a * b, Sg = wgroup_sum<NP>(g);
+            if (!(Sg >= 0x1p-959) && Sg > 0.0) { // (as in the step below)
+                g = a * ldexp(b, 900);
+                Sg = wgroup_sum<NP>(g);
+            }
+            gam = g * fast_rcp(Sg);
         }
         // rings: observation of step t and alpha of step t - 1, WIDE_PF steps ahead
         WideIn ro[WIDE_PF];
@@ -692,8 +696,8 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                     if (real)
                         gamma0[(int64_t)k * n + i] = gam;
                 } else {
-                    const double br = back(p, b);
-                    const double q = ap * br;
+                    double br = back(p, b);
+                    double q = ap * br;
                     // sum_i alpha_{t-1}[i] (A (p_t o beta_t))[i] = sum_j alpha_t[j] beta_t[j]: as long as
                     // neither vector has been rescaled, the normaliser of gamma is the one of the
                     // step before.  The lazily scaled forward pass rescales every fourth step (known
@@ -702,8 +706,23 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                     bool need = true;
                     if constexpr (SPARSE_SUM)
                         need = r == 0 || last || ((phase - r) & 3) == 3 || t == tmid;
-                    if (need)
-                        rS_keep = fast_rcp(wgroup_sum<NP>(q));
+                    if (need) {
+                        double Ssum = wgroup_sum<NP>(q);
+                        // alpha concentrated on states whose (A (p o beta)) is in the denormal range
+                        // although p o beta as a whole is not (sparse A, narrow states): the sum is
+                        // denormal, its reciprocal infinite.  Lazy kernels report it (the host
+                        // repeats the E-step with this instantiation's non-lazy twin); here the
+                        // product is redone with p times 2^900 (exact), which gamma, xi and the
+                        // rescaled beta do not see.
+                        if constexpr (LAZY) {
+                            trouble |= !(Ssum >= 0x1p-959);
+                        } else if (__builtin_expect(!(Ssum >= 0x1p-959) && Ssum > 0.0, 0)) {
+                            br = back(ldexp(p, 900), b);
+                            q = ap * br;
+                            Ssum = wgroup_sum<NP>(q);
+                        }
+                        rS_keep = fast_rcp(Ssum);
+                    }
                     const double rS = rS_keep;
                     gam = q * rS;
                     const double w = ap * rS;

@@ -391,13 +391,15 @@ def test_densities_in_the_denormal_range(n):
         eng.close()
 
 
-@pytest.mark.parametrize("case", ["stress_case_53_204", "stress_case_51_278", "stress_case_55_240"])
+@pytest.mark.parametrize("case", ["stress_case_53_204", "stress_case_51_278", "stress_case_55_240",
+                                  "stress_case_72_35"])
 def test_cases_found_by_the_random_sweep(case):
     """Inputs on which tools/stress_small.py (random parity sweep against the oracle) found defects:
     sparse transition matrices with very narrow states -- p o beta in the denormal range although
     neither factor is (NaN counts; 6 and 12 states) -- and an absorbing state among far outliers
     (zero rows of the chunk transfer matrices took part in the exponent alignment of the exact
-    boundary pass: non-finite likelihood whenever the speculation gave up)."""
+    boundary pass: non-finite likelihood whenever the speculation gave up); alpha concentrated on a
+    state whose A (p o beta) is denormal while p o beta as a whole is not (24 states: NaN counts)."""
     import os
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "stress", case + ".npz"))
     A, pi, mu, sig = d["A"], d["pi"], d["par0"], d["par1"]
