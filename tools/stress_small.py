@@ -25,6 +25,9 @@ for case in range(ncase):
     kind = "gaussian" if rng.random() < 0.5 else "discrete"
     K = int(rng.integers(1, 7))
     lens = [int(x) for x in rng.integers(1, int(rng.choice([40, 400, 3000, 12000])), K)]
+    if os.environ.get("LARGE"):  # few, long trajectories: default chunk plans, the branch-free kernels
+        K = int(rng.integers(1, 40))
+        lens = [int(x) for x in rng.integers(20000, 200000, K)]
     chunk = int(rng.choice([0, 0, 1, 7, 16, 33, 100]))
     A = rng.random((n, n)) + rng.choice([0.0, 2.0, 10.0]) * np.eye(n)
     if n > 1 and rng.random() < 0.3:  # sparse transitions (every row keeps its diagonal)
