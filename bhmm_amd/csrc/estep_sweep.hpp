@@ -1287,6 +1287,15 @@ __device__ __forceinline__ void estep_body(
             if constexpr (SPEC) // beta one step before this chunk: what the previous chunk assumed
                 *reinterpret_cast<double2 *>(b_entry + g * N + 2 * q) = make_double2(b2[0], b2[1]);
         }
+        if constexpr (!CAREFUL) {
+            // Self-check of the branch-free sweep: every step contributes unit gamma mass.  A chunk
+            // that does not come out at its length (an intermediate product in the denormal range
+            // that the scale tracking did not see, anything non-finite) is reported like a tiny
+            // vector: the host repeats the E-step with the per-step-checked kernels.
+            const double mass = grp_sum<H>(sg[0] + sg[1]);
+            if (!(fabs(mass - (double)len) <= 1e-8 * (double)len))
+                hmin = 0;
+        }
         } // HAS_BWD
         } // role_b
         } // !FWDONLY

@@ -751,9 +751,13 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                         xi_flush(); // slots of steps that did not run hold w = 0
             }
         }
-        if constexpr (LAZY)
+        if constexpr (LAZY) {
+            // self-check of the lazily scaled pass: unit gamma mass per step (else: non-lazy rerun)
+            const double mass = wgroup_sum<NP>(sgm);
+            trouble |= !(fabs(mass - (double)nmain) <= 1e-8 * (double)nmain);
             if (trouble && i == 0)
                 atomicOr(&flags[2], 1u);
+        }
     }
     if constexpr (NP == 64) {
         // C / D layout of v_mfma_f64_16x16x4: column = lane & 15, row = (lane >> 4) + 4 r
