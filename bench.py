@@ -479,7 +479,7 @@ def main():
                        "chunk_len": eng.chunk_len, "chunks": eng.num_chunks,
                        "speculative_boundaries": {k: eng.get_option(k) for k in
                                                   ("spec_enabled", "spec_W", "spec_ok", "spec_fail",
-                                                   "spec_last_dev")},
+                                                   "spec_last_dev", "careful")},
                        "collective": ("RCCL all-reduce" if backend == "nccl" else
                                       "gloo all-reduce (--oversubscribe test aid: ranks share GPUs)")
                                      if distributed else "none (one process)",
