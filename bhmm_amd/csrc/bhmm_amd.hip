@@ -67,6 +67,8 @@ static int stats_size(const bhmm_ctx *c);
 static int lds_symbols(const bhmm_ctx *c) { return c->bt_global ? 0 : c->M; }
 static int64_t ci_records(const bhmm_ctx *c) { return (int64_t)(c->Gp / 64) * c->Lmax; }
 
+int replan_coarse(bhmm_ctx *c); // (defined with bhmm_ctx_set_observations)
+
 #ifndef ESTEP_SPLIT
 #define ESTEP_SPLIT 1 // statistics-only speculative E-step in two launches (PH_P1, PH_P2)
 #endif
@@ -378,6 +380,8 @@ struct Runner {
                 return rc;
             if (W > 0)
                 c->spec_W = W;
+            if (c->chunk_mult > 1 && (int64_t)c->spec_W * 16 > c->L && (rc = replan_coarse(c)))
+                return rc;
         }
         if (c->spec_enabled) {
             for (int attempt = 0; attempt < 2; ++attempt) {
@@ -617,6 +621,8 @@ struct Runner {
                 return rc;
             if (W > 0)
                 c->spec_W = W;
+            if (c->chunk_mult > 1 && (int64_t)c->spec_W * 16 > c->L && (rc = replan_coarse(c)))
+                return rc;
         }
         if (c->spec_enabled) {
             for (int attempt = 0; attempt < 2; ++attempt) {
@@ -710,8 +716,10 @@ struct Runner {
 
 // ---- chunk planning ----------------------------------------------------------------------
 // Every trajectory is cut into ceil(T/L) chunks whose lengths differ by at most one.
-static int plan_chunks(bhmm_ctx *c, int chunk)
+static int plan_chunks(bhmm_ctx *c, int chunk, bool allow_mult = true)
 {
+    if (chunk > 0)
+        c->chunk_mult = 1;
     const int K = c->K;
     int L = chunk;
     if (L <= 0) {
@@ -725,10 +733,14 @@ static int plan_chunks(bhmm_ctx *c, int chunk)
         // the forward-only pass) then have four to six long wavefronts per SIMD instead of two
         // (configs[2], 1024 x 1e6: P1 7.2 -> 5.9 ms, E-step 20.2 -> 18.7 ms), while the warm-up
         // stays below a few per cent of the chunk even if it calibrates to four times the default.
-        if (l >= 3 * 9216)
+        c->chunk_mult = 1;
+        if (l >= 3 * 9216 && allow_mult) {
             l = (l + 2) / 3;
-        else if (l >= 2 * 9216)
+            c->chunk_mult = 3;
+        } else if (l >= 2 * 9216 && allow_mult) {
             l = (l + 1) / 2;
+            c->chunk_mult = 2;
+        }
         L = (int)std::min<int64_t>(std::max<int64_t>(l, 32), (int64_t)1 << 20);
     }
     c->L = L;
@@ -1077,6 +1089,61 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     return BHMM_OK;
 }
 
+extern "C++" {
+// re-lay the trajectory-major observations at src_dev (device) out chunk-interleaved for the
+// current chunk plan
+static int pack_observations(bhmm_ctx *c, const char *src_dev)
+{
+    const int kind = c->kind;
+    int rc;
+    const size_t ci_elems = (size_t)ci_records(c) * 64;
+    const Chunks ch = chunks_of(c);
+    const int nblk = c->Gp / BLOCK;
+    if ((rc = c->d_obsnan.ensure(1)))
+        return rc;
+    BHMM_HIP(hipMemsetAsync(c->d_obsnan.p, 0, sizeof(int32_t), c->stream));
+    if (kind == BHMM_EMIT_GAUSSIAN) {
+        if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(double))))
+            return rc;
+        hipLaunchKernelGGL((k_pack_scalar<double>), dim3(nblk), dim3(BLOCK), 0, c->stream, ch,
+                           reinterpret_cast<const double *>(src_dev),
+                           reinterpret_cast<double *>(c->d_obs_ci.p), c->d_obsnan.p);
+    } else if (kind == BHMM_EMIT_DISCRETE) {
+        if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(int32_t))))
+            return rc;
+        hipLaunchKernelGGL((k_pack_scalar<int32_t>), dim3(nblk), dim3(BLOCK), 0, c->stream, ch,
+                           reinterpret_cast<const int32_t *>(src_dev),
+                           reinterpret_cast<int32_t *>(c->d_obs_ci.p), c->d_obsnan.p);
+    } else {
+        if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(double) * c->N)))
+            return rc;
+        rc = BHMM_DISPATCH_N(c, pack_rows(c, reinterpret_cast<const double *>(src_dev)));
+        if (rc)
+            return rc;
+    }
+    return BHMM_OK;
+}
+
+// The automatic plan took two or three times the default chunk count because the chunks were very
+// long (plan_chunks), assuming a warm-up of a few hundred steps.  The model turned out to forget
+// slowly (the calibrated warm-up exceeds 1/16 of the chunk): back to the default count -- the
+// observations are re-laid out from the trajectory-major copy on the device.
+int bhmm::replan_coarse(bhmm_ctx *c)
+{
+    int rc;
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = plan_chunks(c, 0, false)) || (rc = alloc_work(c)))
+        return rc;
+    if ((rc = pack_observations(c, c->d_obs_rm.p)))
+        return rc;
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    c->gamma_valid = false;
+    c->rows32_valid = false;
+    return BHMM_OK;
+}
+} // extern "C++"
+
 int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int64_t *offsets, int K,
                               int nstates, int nsymbols, int chunk, int obs_on_device)
 {
@@ -1166,31 +1233,8 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         BHMM_HIP(hipMemcpyAsync(c->d_obs_rm.p, base, bytes, hipMemcpyHostToDevice, c->stream));
         src_dev = c->d_obs_rm.p;
     }
-    const size_t ci_elems = (size_t)ci_records(c) * 64;
-    const Chunks ch = chunks_of(c);
-    const int nblk = c->Gp / BLOCK;
-    if ((rc = c->d_obsnan.ensure(1)))
+    if ((rc = pack_observations(c, src_dev)))
         return rc;
-    BHMM_HIP(hipMemsetAsync(c->d_obsnan.p, 0, sizeof(int32_t), c->stream));
-    if (kind == BHMM_EMIT_GAUSSIAN) {
-        if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(double))))
-            return rc;
-        hipLaunchKernelGGL((k_pack_scalar<double>), dim3(nblk), dim3(BLOCK), 0, c->stream, ch,
-                           reinterpret_cast<const double *>(src_dev),
-                           reinterpret_cast<double *>(c->d_obs_ci.p), c->d_obsnan.p);
-    } else if (kind == BHMM_EMIT_DISCRETE) {
-        if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(int32_t))))
-            return rc;
-        hipLaunchKernelGGL((k_pack_scalar<int32_t>), dim3(nblk), dim3(BLOCK), 0, c->stream, ch,
-                           reinterpret_cast<const int32_t *>(src_dev),
-                           reinterpret_cast<int32_t *>(c->d_obs_ci.p), c->d_obsnan.p);
-    } else {
-        if ((rc = c->d_obs_ci.ensure(ci_elems * sizeof(double) * c->N)))
-            return rc;
-        rc = BHMM_DISPATCH_N(c, pack_rows(c, reinterpret_cast<const double *>(src_dev)));
-        if (rc)
-            return rc;
-    }
     BHMM_HIP(hipGetLastError());
     if (obs_on_device) {
         // keep a trajectory-major copy for the path kernels

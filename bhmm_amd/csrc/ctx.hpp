@@ -68,6 +68,7 @@ struct bhmm_ctx {
     int K = 0;    // trajectories
     int64_t total = 0;
     int L = 0, Lmax = 0, G = 0, Gp = 0;
+    int chunk_mult = 1; // automatic plan: 2 / 3 times the default chunk count (very long chunks)
     std::vector<int64_t> offsets;  // [K+1]
     std::vector<int32_t> traj_c0;  // [K+1] first chunk of each trajectory
 

@@ -503,3 +503,49 @@ def test_wide_family_large_alphabet():
         np.add.at(er, (p, o), 1.0)
     assert np.array_equal(emis, er)
     eng.close()
+
+
+def test_very_long_chunks_replan_for_a_slowly_forgetting_model():
+    """Automatic plans take two or three times the default chunk count when chunks are very long,
+    assuming a warm-up of a few hundred steps.  A model that forgets over thousands of steps (dwell
+    times of 1e4 steps, strongly overlapping emissions) goes back to the default count at the
+    calibration of its first E-step: same log-likelihoods as an explicit coarse plan, unit gamma mass,
+    and for one trajectory the oracle's value."""
+    import torch
+    from bhmm_amd.engine import synth_observations
+    n, K, T = 8, 512, 1_190_000                    # 6.1e8 steps: chunks of 18 600 steps at 32 768 chunks
+    A = np.full((n, n), 1e-4 / (n - 1))
+    np.fill_diagonal(A, 1.0 - 1e-4)
+    pi = np.full(n, 1.0 / n)
+    mu, sig = np.linspace(-0.7, 0.7, n), np.full(n, 1.0)
+    obs = torch.empty(K * T, dtype=torch.float64, device="cuda:0")
+    synth_observations("gaussian", obs.data_ptr(), A, pi, mu, sig, K, T, seed=11)
+    off = np.arange(K + 1, dtype=np.int64) * T
+    eng = _engine()
+    eng.set_observations_device("gaussian", obs.data_ptr(), off, n)
+    fine = eng.chunk_len
+    assert fine < 12000                            # the plan with the tripled / doubled chunk count
+    res = eng.estep(A, pi, mu, sig)
+    W = eng.get_option("spec_W")
+    assert W * 16 > fine and eng.chunk_len > 1.9 * fine, (W, fine, eng.chunk_len)   # re-planned
+    np.testing.assert_allclose(res.state_counts.sum(), K * T, rtol=1e-10)
+    np.testing.assert_allclose(res.C.sum(), K * (T - 1), rtol=1e-10)
+    res_b = eng.estep(A, pi, mu, sig)
+    np.testing.assert_allclose(res_b.logL_k, res.logL_k, rtol=1e-13)
+    coarse = eng.chunk_len
+    eng.close()
+    sub = obs[:2 * T]
+    eng2 = _engine()
+    eng2.set_observations_device("gaussian", sub.data_ptr(), off[:3], n, chunk=2 * coarse + 17)
+    res2 = eng2.estep(A, pi, mu, sig)
+    np.testing.assert_allclose(res2.logL_k, res.logL_k[:2], rtol=1e-11)
+    eng2.close()
+    o = obs[:2_000_000].cpu().numpy()
+    eng3 = _engine()
+    eng3.set_observations("gaussian", [o], n)
+    r3 = eng3.estep(A, pi, mu, sig)
+    ref = orc.estep("gaussian", [o], A, pi, mu, sig)
+    np.testing.assert_allclose(r3.logL_k, ref["logL"], rtol=1e-11)
+    eng3.close()
+    del obs, sub
+    torch.cuda.empty_cache()
