@@ -41,9 +41,12 @@ for case in range(ncase):
             B0 = 0.7 * B + 0.3 / M
             init = bhmm_amd.discrete_hmm(pi0, A0, B0 / B0.sum(axis=1, keepdims=True))
         kw = dict(initial_model=init, reversible=rev, accuracy=1e-4, maxit=12)
-        ref = bhmm_amd.MaximumLikelihoodEstimator(obs, n, engine_factory=OracleEngine, **kw)
+        lag = int(rng.choice([1, 1, 2, 3, 5]))
+        lobs = bhmm_amd.lag_observations(obs, lag) if lag > 1 else obs   # GPU: views cut on the device
+        tag += " lag=%d" % lag
+        ref = bhmm_amd.MaximumLikelihoodEstimator(lobs, n, engine_factory=OracleEngine, **kw)
         href = ref.fit()
-        est = bhmm_amd.MaximumLikelihoodEstimator(obs, n, **kw)
+        est = bhmm_amd.MaximumLikelihoodEstimator(lobs, n, **kw)
         hmm = est.fit()
         ok = (len(est.likelihoods) == len(ref.likelihoods) and np.allclose(est.likelihoods, ref.likelihoods, rtol=1e-9)
               and np.allclose(hmm.transition_matrix, href.transition_matrix, rtol=1e-6, atol=1e-9))
