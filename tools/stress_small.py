@@ -93,15 +93,16 @@ for case in range(ncase):
                     print("  gpu logL", res.logL_k, "ref", ref["logL"], "gpu C", res.C, "ref C", ref["C"], "par", par,
                           "careful", eng.get_option("careful"), "spec ok/fail", eng.get_option("spec_ok"), eng.get_option("spec_fail"),
                           "W", eng.get_option("spec_W"), "nan obs", [int(np.isnan(o).sum()) for o in obs])
-        if denorm:
-            eng.close()
-            continue  # (paths: the reference's forward rows are degenerate there)
         pobs = [orc.pobs_gaussian(o, *par) if kind == "gaussian" else orc.pobs_discrete(o, B) for o in obs]
         vp = eng.viterbi(A, pi, *par)
         for k, (p, po) in enumerate(zip(vp, pobs)):
-            if not np.array_equal(p, orc.viterbi(A, po, pi)):
+            vr = orc.viterbi(A, po, pi)
+            if not np.array_equal(p, vr):
                 bad += 1
-                print("VITERBI MISMATCH", tag, "traj", k)
+                print("VITERBI MISMATCH", tag, "traj", k, "differing steps", int((p != vr).sum()), "of", len(vr), "(denormal regime)" if denorm else "")
+        if denorm:
+            eng.close()
+            continue  # (sampled paths: the reference's forward rows are degenerate there)
         u = [rng.random(T) for T in lens]
         sp = eng.sample_paths(A, pi, *par, u=u)[0]
         for k, (p, po, uu) in enumerate(zip(sp, pobs, u)):
