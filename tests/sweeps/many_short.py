@@ -1,7 +1,8 @@
 """Many short trajectories (the other extreme of the BASELINE shapes): K x T = 65536 x 128 and
 8192 x 1000, 8-state Gaussian: E-step / Gibbs sweep / Viterbi time, parity of a few trajectories."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import numpy as np, torch
 from bench import make_c2_model, timeit
 from bhmm_amd.engine import Engine, synth_observations

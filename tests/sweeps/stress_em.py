@@ -1,9 +1,9 @@
-"""Random sweep of whole estimations: MaximumLikelihoodEstimator on the HIP engine against the same
+"""Test infrastructure (uses the oracle).  Random sweep of whole estimations: MaximumLikelihoodEstimator on the HIP engine against the same
 run on the oracle-backed CPU engine double (tests/oracle_engine.py): likelihood history, parameters,
 Viterbi paths -- gaussian and discrete, 2..6 states, reversible or not, a few trajectories, with and
-without an initial model.  usage: python tools/stress_em.py [seed [cases]]"""
+without an initial model.  usage: python tests/sweeps/stress_em.py [seed [cases]]"""
 import os, sys, warnings
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import bhmm_amd

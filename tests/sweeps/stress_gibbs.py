@@ -1,8 +1,8 @@
-"""Random sweep of Gibbs chains: BayesianHMMSampler on the HIP engine against the same chain on the
+"""Test infrastructure (uses the oracle).  Random sweep of Gibbs chains: BayesianHMMSampler on the HIP engine against the same chain on the
 oracle-backed CPU engine double (same numpy seed for the parameter draws, same counter-based uniforms
-for the hidden paths): the sampled models must coincide.  usage: python tools/stress_gibbs.py [seed [cases]]"""
+for the hidden paths): the sampled models must coincide.  usage: python tests/sweeps/stress_gibbs.py [seed [cases]]"""
 import os, sys, warnings
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import bhmm_amd

@@ -1,4 +1,4 @@
-"""Random parity sweep of the single-trajectory kernel API (bhmm_amd.hidden: forward, backward,
+"""Test infrastructure (uses the oracle).  Random parity sweep of the single-trajectory kernel API (bhmm_amd.hidden: forward, backward,
 state_probabilities, transition_counts, viterbi, sample_path on caller-supplied pobs) against the
 oracle: 1..64 states, lengths 1..5000, dense and sparse A, pobs rows with exact zeros and with
 entries spread over hundreds of decades.  The values are compared with the reference's recursions in
@@ -6,9 +6,9 @@ entries spread over hundreds of decades.  The values are compared with the refer
 1e-308 of the row) the double-precision reference loses states for good -- an exact zero stays zero
 under a transition matrix that does not refill it -- while the chunk-parallel kernels carry separate
 exponents; paths are compared with the oracle's where its rows agree with the 80-bit ones.
-usage: python tools/stress_hidden.py [seed [cases]]"""
+usage: python tests/sweeps/stress_hidden.py [seed [cases]]"""
 import os, sys
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import bhmm_amd.hidden as hidden

@@ -1,10 +1,10 @@
-"""One engine, many data sets: the context is re-used across random problems of changing kind, state
+"""Test infrastructure (uses the oracle).  One engine, many data sets: the context is re-used across random problems of changing kind, state
 count (1..40), alphabet, trajectory count and length, chunk length -- every E-step (with and without
 gamma rows), Viterbi and sampled path against the oracle.  Catches state that survives
 set_observations (calibration, fallback flags, buffers sized for an earlier problem).
-usage: python tools/stress_reuse.py [seed [cases]]"""
+usage: python tests/sweeps/stress_reuse.py [seed [cases]]"""
 import os, sys
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 from bhmm_amd.engine import Engine

@@ -1,4 +1,4 @@
-"""Random parity sweep against the oracle (E-step statistics, Viterbi, sampled paths) over small random
+"""Test infrastructure (uses the oracle).  Random parity sweep against the oracle (E-step statistics, Viterbi, sampled paths) over small random
 shapes: 1..24 states, gaussian / discrete (alphabets on both sides of the LDS limits), ragged
 trajectories, default and odd chunk lengths; gaussian data also with far outliers and very narrow
 states.  Where some observation has all its densities in the denormal range (< 2.3e-308) the
@@ -7,7 +7,7 @@ compared with the reference's recursions carried out in 80-bit arithmetic on the
 double-precision emission rows; everywhere else with the oracle itself, to 1e-10 / 1e-8.
 Prints one line per failure and a summary; exit code 1 on failure."""
 import os, sys
-R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 from bhmm_amd import _lib

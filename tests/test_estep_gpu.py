@@ -394,7 +394,7 @@ def test_densities_in_the_denormal_range(n):
 @pytest.mark.parametrize("case", ["stress_case_53_204", "stress_case_51_278", "stress_case_55_240",
                                   "stress_case_72_35"])
 def test_cases_found_by_the_random_sweep(case):
-    """Inputs on which tools/stress_small.py (random parity sweep against the oracle) found defects:
+    """Inputs on which tests/sweeps/stress_small.py (random parity sweep against the oracle) found defects:
     sparse transition matrices with very narrow states -- p o beta in the denormal range although
     neither factor is (NaN counts; 6 and 12 states) -- and an absorbing state among far outliers
     (zero rows of the chunk transfer matrices took part in the exponent alignment of the exact
