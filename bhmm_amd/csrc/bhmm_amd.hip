@@ -1138,7 +1138,12 @@ int bhmm::replan_coarse(bhmm_ctx *c)
         return rc;
     BHMM_HIP(hipGetLastError());
     BHMM_HIP(hipStreamSynchronize(c->stream));
+    // rows stored under the old plan are gone; an E-step in flight that stores gamma (this runs
+    // inside its first call) gets rows of the new plan's size -- bhmm_estep sets gamma_valid
+    // when that E-step has been enqueued
     c->gamma_valid = false;
+    if (c->gamma_wanted && (rc = c->d_gamma_ci.ensure((size_t)ci_records(c) * c->N * 64)))
+        return rc;
     c->rows32_valid = false;
     return BHMM_OK;
 }
@@ -1255,17 +1260,19 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
 namespace bhmm {
 // view v, element i  <-  source element src_start[v] + i * lag  (elements of `words` 4-byte words)
 static __global__ void k_lag_gather(const uint32_t *src, uint32_t *dst, const int64_t *src_start,
-                                    const int64_t *dst_off, int lag, int words)
+                                    const int64_t *dst_off, int lag, int words, int V)
 {
-    const int v = blockIdx.y;
-    const int64_t len = dst_off[v + 1] - dst_off[v];
-    const int64_t s0 = src_start[v], d0 = dst_off[v];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t *ps = src + (s0 + i * lag) * words;
-        uint32_t *pd = dst + (d0 + i) * words;
-        for (int w = 0; w < words; ++w)
-            pd[w] = ps[w];
+    // gridDim.y is capped (HIP: 65535), so a grid row serves views v, v + gridDim.y, ...
+    for (int v = blockIdx.y; v < V; v += gridDim.y) {
+        const int64_t len = dst_off[v + 1] - dst_off[v];
+        const int64_t s0 = src_start[v], d0 = dst_off[v];
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            const uint32_t *ps = src + (s0 + i * lag) * words;
+            uint32_t *pd = dst + (d0 + i) * words;
+            for (int w = 0; w < words; ++w)
+                pd[w] = ps[w];
+        }
     }
 }
 } // namespace bhmm
@@ -1321,10 +1328,17 @@ int bhmm_ctx_set_observations_lagged(bhmm_ctx *c, int kind, const void *obs, con
                             hipMemcpyHostToDevice, c->stream));
     BHMM_HIP(hipMemcpyAsync(d_tab.p + V, dst_off.data(), ((size_t)V + 1) * sizeof(int64_t),
                             hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_lag_gather, dim3(64, V), dim3(256), 0, c->stream,
+    // x covers the longest view in 256-element blocks (at most 64 of them, grid-stride beyond),
+    // y the views (at most 32768 grid rows, strided beyond): any number of views launches
+    int64_t longest = 0;
+    for (int v = 0; v < V; ++v)
+        longest = std::max(longest, dst_off[v + 1] - dst_off[v]);
+    const unsigned gx = (unsigned)std::min<int64_t>(64, (longest + 255) / 256);
+    const unsigned gy = (unsigned)std::min(V, 32768);
+    hipLaunchKernelGGL(k_lag_gather, dim3(gx, gy), dim3(256), 0, c->stream,
                        reinterpret_cast<const uint32_t *>(src_dev),
                        reinterpret_cast<uint32_t *>(d_dst.p), (const int64_t *)d_tab.p,
-                       (const int64_t *)(d_tab.p + V), lag, (int)(esz / 4));
+                       (const int64_t *)(d_tab.p + V), lag, (int)(esz / 4), V);
     BHMM_HIP(hipGetLastError());
     BHMM_HIP(hipStreamSynchronize(c->stream)); // the host tables are temporaries
     return bhmm_ctx_set_observations(c, kind, d_dst.p, dst_off.data(), V, nstates, nsymbols, chunk, 1);
@@ -1474,15 +1488,20 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         if ((rc = c->d_gamma_ci.ensure((size_t)ci_records(c) * c->N * 64)))
             return rc;
     }
-    c->gamma_valid = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
+    c->gamma_valid = false;
+    c->gamma_wanted = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
     double *sd = stats_dev ? stats_dev : c->d_stats.p;
     c->last_stats_internal = (stats_dev == nullptr);
     c->last_stats = sd;
     c->prefetched = false;
     c->ev_lean = false;
     if (c->wide)
-        return wide_estep(c, A, pi, par0, par1, sd, flags);
-    return BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
+        rc = wide_estep(c, A, pi, par0, par1, sd, flags);
+    else
+        rc = BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
+    c->gamma_valid = rc == BHMM_OK && c->gamma_wanted;
+    c->gamma_wanted = false;
+    return rc;
 }
 
 int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)

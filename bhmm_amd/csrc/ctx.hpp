@@ -141,6 +141,7 @@ struct bhmm_ctx {
     size_t h_pinned_n = 0;
 
     bool gamma_valid = false;
+    bool gamma_wanted = false;  // the E-step in flight stores gamma (a re-plan must re-size the rows)
     bool careful = false;       // E-steps use the kernel with the per-step outlier branch
     bool careful_retry = false; // the last verdict asked for a repeat with that kernel
     bool wide_careful = false;  // 9..64 states: lazily scaled kernels left their range on these data

@@ -66,6 +66,20 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     c->fwd_defer = false;
     if (rc)
         return rc;
+    // A deferred verdict must be consumed on EVERY way out (allocation failure, launch error ...):
+    // left pending, its bookkeeping is skipped and a later call reads stale verdict words.
+    struct PendingVerdict {
+        bhmm_ctx *c;
+        ~PendingVerdict()
+        {
+            if (!c->fwd_pending)
+                return;
+            c->fwd_pending = false;
+            (void)hipStreamSynchronize(c->stream);
+            bool ok = false;
+            (void)forward_ci_verdict(c, &ok); // (the call is failing anyway: outcome unused)
+        }
+    } pending_guard{c};
     const int K = c->K, n = c->n;
     const size_t nstat = (size_t)N * N + N;
     // parts per chunk for the map kernels (BHMM_AMD_SMP_PARTS overrides: kernel experiments)

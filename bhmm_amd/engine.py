@@ -100,8 +100,11 @@ class Engine(object):
         elif kind == 'discrete':
             flat = np.ascontiguousarray(np.concatenate([np.asarray(o).astype(np.int32)
                                                         for o in observations]))
-            if flat.size and (flat.min() < 0 or flat.max() >= nsymbols):
-                raise ValueError("discrete observation outside [0, nsymbols)")
+            # only what the views touch has to be a symbol (stride > 1 skips shifts)
+            for k, s in views:
+                piece = np.asarray(observations[k])[int(s)::int(lag)]
+                if piece.size and (piece.min() < 0 or piece.max() >= nsymbols):
+                    raise ValueError("discrete observation outside [0, nsymbols)")
         else:
             flat = np.ascontiguousarray(np.concatenate(
                 [np.asarray(o, dtype=np.float64).reshape(-1, nstates) for o in observations]))

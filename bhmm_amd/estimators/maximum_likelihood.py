@@ -38,6 +38,23 @@ def default_device(comm):
     return comm.rank % ndev if ndev > 0 else comm.rank
 
 
+def _views_intact(lagged):
+    """True while every entry of a LaggedObservations list still IS the recorded view
+    base[k][shift::lag] (same memory, length, stride, dtype).  A list is mutable: after
+    `obs[i] = ...`, a sort or a remove/append the recipe no longer describes the data, and the
+    estimators must upload the entries themselves."""
+    try:
+        for entry, (k, shift) in zip(lagged, lagged.views):
+            want = lagged.base[k][shift::lagged.lag]
+            if not isinstance(entry, np.ndarray) or entry.shape != want.shape \
+                    or entry.dtype != want.dtype or entry.strides != want.strides \
+                    or entry.__array_interface__['data'][0] != want.__array_interface__['data'][0]:
+                return False
+    except (AttributeError, IndexError, TypeError):
+        return False
+    return True
+
+
 def _load_observations(engine, kind, given, copied, mine, comm, nstates, nsymbols):
     """Hand this rank's trajectories to the engine.  Lagged views made by lag_observations
     (bhmm/api.py:70-94) are not uploaded piece by piece: the original trajectories go up once and
@@ -45,7 +62,7 @@ def _load_observations(engine, kind, given, copied, mine, comm, nstates, nsymbol
     sharded run uploads each rank's own pieces."""
     views = getattr(given, 'views', None)
     if (views is not None and not comm.active and hasattr(engine, 'set_observations_lagged')
-            and len(views) == len(copied)):
+            and len(views) == len(copied) and _views_intact(given)):
         engine.set_observations_lagged(kind, given.base, given.lag, views, nstates,
                                        nsymbols=nsymbols)
     else:

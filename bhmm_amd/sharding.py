@@ -74,7 +74,12 @@ class Comm(object):
         import torch
         t = self._bufs.get(n)
         if t is None:
-            t = torch.zeros(int(n), dtype=torch.float64, device=self._torch_device())
+            # empty, not zeros: a fill kernel on torch's stream would be unordered against the
+            # engine's own stream, which overwrites the whole vector (ranks without a shard call
+            # zero_() themselves); the synchronize orders the allocation against first use
+            dev = self._torch_device()
+            t = torch.empty(int(n), dtype=torch.float64, device=dev)
+            torch.cuda.current_stream(dev).synchronize()
             self._bufs[n] = t
         return t
 

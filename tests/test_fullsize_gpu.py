@@ -322,8 +322,42 @@ def test_lagged_views_on_device_equal_host_slices(kind):
         ra, rb = a.estep(*margs), b.estep(*margs)
         assert np.array_equal(ra.packed, rb.packed) and np.array_equal(ra.logL_k, rb.logL_k)
         assert all(np.array_equal(x, y) for x, y in zip(a.viterbi(*margs), b.viterbi(*margs)))
+        # ... and both are the oracle's E-step on the numpy views obs_k[shift::lag]
+        views = [np.ascontiguousarray(v) for v in lagged]
+        if kind == "explicit":
+            ll = [orc.forward(A, v, pi)[0] for v in views]
+            np.testing.assert_allclose(ra.logL_k, ll, rtol=1e-10)
+        else:
+            ref = orc.estep(kind, views, *margs)
+            np.testing.assert_allclose(ra.logL_k, ref["logL"], rtol=1e-10)
+            np.testing.assert_allclose(ra.C, ref["C"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(ra.state_counts, ref["state_counts"], rtol=1e-9)
         a.close()
         b.close()
+
+
+def test_more_lagged_views_than_a_grid_dimension():
+    """100 trajectories at lag 1000 are 1e5 views -- more than HIP's 65 535 limit on gridDim.y,
+    which the gather kernel used to map views to."""
+    import bhmm_amd
+    rng = np.random.default_rng(8)
+    n = 3
+    A = rng.random((n, n)) + 2 * np.eye(n)
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    mu, sig = np.linspace(-1, 1, n), np.full(n, 0.8)
+    base = [rng.normal(0, 1.5, 2500 + 13 * k) for k in range(100)]
+    lagged = bhmm_amd.lag_observations(base, 1000)
+    assert len(lagged) == 100_000 and len(lagged.views) == len(lagged)
+    a, b = _engine(), _engine()
+    a.set_observations_lagged("gaussian", lagged.base, 1000, lagged.views, n)
+    b.set_observations("gaussian", [np.ascontiguousarray(v) for v in lagged], n)
+    ra, rb = a.estep(A, pi, mu, sig), b.estep(A, pi, mu, sig)
+    assert np.array_equal(ra.packed, rb.packed) and np.array_equal(ra.logL_k, rb.logL_k)
+    ref = orc.estep("gaussian", [np.ascontiguousarray(v) for v in lagged[:500]], A, pi, mu, sig)
+    np.testing.assert_allclose(ra.logL_k[:500], ref["logL"], rtol=1e-10)
+    a.close()
+    b.close()
 
 
 def test_estimate_hmm_with_lag_uses_device_views():
@@ -525,13 +559,19 @@ def test_very_long_chunks_replan_for_a_slowly_forgetting_model():
     eng.set_observations_device("gaussian", obs.data_ptr(), off, n)
     fine = eng.chunk_len
     assert fine < 12000                            # the plan with the tripled / doubled chunk count
-    res = eng.estep(A, pi, mu, sig)
+    # gamma rows are stored by the very E-step that re-plans: they must be sized for the NEW plan
+    # and be reported as stored
+    res = eng.estep(A, pi, mu, sig, store_gamma=True)
     W = eng.get_option("spec_W")
     assert W * 16 > fine and eng.chunk_len > 1.9 * fine, (W, fine, eng.chunk_len)   # re-planned
     np.testing.assert_allclose(res.state_counts.sum(), K * T, rtol=1e-10)
     np.testing.assert_allclose(res.C.sum(), K * (T - 1), rtol=1e-10)
-    res_b = eng.estep(A, pi, mu, sig)
+    g_first = eng.gamma(K - 1)
+    np.testing.assert_allclose(g_first.sum(axis=1), 1.0, rtol=1e-10)
+    res_b = eng.estep(A, pi, mu, sig, store_gamma=True)
     np.testing.assert_allclose(res_b.logL_k, res.logL_k, rtol=1e-13)
+    np.testing.assert_allclose(eng.gamma(K - 1), g_first, rtol=0, atol=1e-12)
+    del g_first
     coarse = eng.chunk_len
     eng.close()
     sub = obs[:2 * T]

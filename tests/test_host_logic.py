@@ -523,3 +523,40 @@ def test_native_reversible_mle_equals_numpy_restatement():
     C = np.array([[4.0, 1.0], [2.0, 4.0]])
     P = _tmatrix.mle_reversible(C, maxerr=1e-15)
     np.testing.assert_allclose(P, [[0.8, 0.2], [1.0 / 3.0, 2.0 / 3.0]], atol=1e-9)
+
+
+def test_lagged_list_that_was_edited_is_not_taken_for_its_recipe():
+    """A LaggedObservations list is mutable; the device-side fast path (upload the originals, cut
+    the views on the GPU) may only be taken while every entry still IS the recorded view
+    (ADVICE round 2)."""
+    from bhmm_amd.estimators.maximum_likelihood import _views_intact, _load_observations
+    base = [np.arange(20.0), np.arange(7.0)]
+    lagged = bhmm_amd.lag_observations(base, 3)
+    assert _views_intact(lagged)
+    edited = bhmm_amd.lag_observations(base, 3)
+    edited[1] = edited[1].copy()                    # same values, other memory
+    assert not _views_intact(edited)
+    swapped = bhmm_amd.lag_observations(base, 3)
+    swapped[0], swapped[1] = swapped[1], swapped[0]
+    assert not _views_intact(swapped)
+    cut = bhmm_amd.lag_observations(base, 3)
+    cut[2] = cut[2][:-1]
+    assert not _views_intact(cut)
+
+    class Rec(object):
+        def __init__(self):
+            self.calls = []
+
+        def set_observations_lagged(self, *a, **k):
+            self.calls.append('lagged')
+
+        def set_observations(self, *a, **k):
+            self.calls.append('plain')
+
+    class NoComm(object):
+        active = False
+
+    for given, want in ((lagged, 'lagged'), (edited, 'plain'), (swapped, 'plain')):
+        rec = Rec()
+        _load_observations(rec, 'gaussian', given, list(given), range(len(given)), NoComm(), 2, 0)
+        assert rec.calls == [want]
