@@ -20,6 +20,8 @@ ERR_HIP = 4
 ERR_NONFINITE = 5
 ERR_CHOICE = 6
 ERR_NO_DEVICE = 7
+ERR_SIGMA = 8
+ERR_DISCONNECTED = 9
 
 EMIT_GAUSSIAN = 0
 EMIT_DISCRETE = 1
@@ -94,6 +96,26 @@ SIGNATURES = {
                                                ctypes.c_int64, ctypes.c_uint64]),
     "bhmm_mle_reversible": (ctypes.c_int, [c_double_p, c_int64_p, c_double_p, ctypes.c_int,
                                            ctypes.c_int64, ctypes.c_double]),
+    "bhmm_mstep": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                  c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p,
+                                  ctypes.c_int64, ctypes.c_double, ctypes.c_double, c_double_p,
+                                  c_double_p, c_double_p, c_double_p, c_int32_p]),
+    "bhmm_gibbs_parameters": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
+                                             c_double_p, c_double_p, c_double_p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,
+                                             ctypes.c_uint64, c_double_p, c_double_p, c_double_p,
+                                             c_double_p, c_int32_p]),
+    "bhmm_host_connected_sets": (ctypes.c_int, [c_int32_p, c_double_p, ctypes.c_int,
+                                                ctypes.c_double, ctypes.c_int]),
+    "bhmm_host_stationary_vector": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int]),
+    "bhmm_host_estimate_tmatrix": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                            c_double_p, ctypes.c_int64, ctypes.c_double,
+                                            ctypes.c_double, c_int64_p]),
+    "bhmm_host_is_reversible": (ctypes.c_int, [c_double_p, ctypes.c_int]),
+    "bhmm_host_partial_rev": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, c_int32_p,
+                                             ctypes.c_int64, ctypes.c_double]),
+    "bhmm_host_rng_draws": (ctypes.c_int, [c_double_p, ctypes.c_int64, ctypes.c_int,
+                                           ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64]),
     "bhmm_diag_exp_nonpos": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int64]),
     "bhmm_diag_gauss_pdf": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int64, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_int]),
@@ -138,6 +160,10 @@ def check(rc):
         raise ValueError(msg)
     if rc == ERR_NONFINITE:
         raise AssertionError(msg)
+    if rc == ERR_SIGMA:
+        raise RuntimeError(msg)          # gaussian.py:271-272
+    if rc == ERR_DISCONNECTED:
+        raise NotImplementedError(msg)   # bayesian_sampling.py:347-350
     raise BhmmAmdError(rc, msg)
 
 

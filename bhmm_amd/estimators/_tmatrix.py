@@ -95,13 +95,19 @@ def stationary_vector(P):
     return pi / pi.sum()
 
 
-def mle_reversible(C, maxiter=1000000, maxerr=1e-8, native=True):
+NATIVE = True      # mle_reversible: run the fixed point in the library (tests switch it off to
+                   # compare the library with the pure-numpy loop)
+
+
+def mle_reversible(C, maxiter=1000000, maxerr=1e-8, native=None):
     """Reversible maximum-likelihood transition matrix of a strongly connected count matrix.
     Fixed point  x_ij <- (c_ij + c_ji) / (c_i / x_i + c_j / x_j),  P_ij = x_ij / x_i.
     native=True runs the same iteration in the library (bhmm_mle_reversible, host code: thousands
     of O(n^2) iterations cost tens of milliseconds in numpy); the numpy loop below is the
     restatement it is tested against, and what runs if the library is not built."""
     C = np.asarray(C, dtype=np.float64)
+    if native is None:
+        native = NATIVE
     if native and C.ndim == 2 and C.shape[0] == C.shape[1] and np.all(np.isfinite(C)) \
             and C.sum() > 0:
         try:

@@ -4,9 +4,12 @@ The hot step of every sweep -- sampling all hidden paths (forward pass + backwar
 trajectory, :283-331) and collecting their statistics (generic_hmm.py:297-334,398-431) -- is
 one call into the device engine, which returns the integer transition / start counts and the
 per-state emission statistics.  The parameter updates that follow (emission parameters, p0,
-transition matrix; :333-373) are tiny host-side draws; the reversible transition-matrix
-sampler lives in msmtools in the reference and is restated from the literature here
-("parity unpinned", see _tmatrix.sample_reversible).
+transition matrix; :333-373) are ONE native host call (bhmm_gibbs_parameters, host code of the
+shared library) driven by a counter-based generator: given the all-reduced statistics every rank
+draws the SAME parameters, so a sharded chain needs no broadcast.  The reversible
+transition-matrix sampler lives in msmtools in the reference; it is restated from the
+publication (Trendelkamp-Schroer et al. 2015) and is "parity unpinned" against msmtools itself.
+`native_parameters=False` selects the numpy draws (np.random stream, rank 0 draws + broadcast).
 """
 import copy
 
@@ -40,7 +43,7 @@ class BayesianHMMSampler(object):
     def __init__(self, observations, nstates, initial_model=None, reversible=True,
                  stationary=False, transition_matrix_sampling_steps=1000, p0_prior='mixed',
                  transition_matrix_prior='mixed', output='gaussian', device=None,
-                 process_group=None, engine_factory=None):
+                 process_group=None, engine_factory=None, native_parameters=True):
         if len(observations) == 0:
             raise Exception("No observations were provided.")
         self.reversible = reversible
@@ -115,6 +118,9 @@ class BayesianHMMSampler(object):
                 self._engine.set_stream_offsets(goff[self._mine])
         self._sweep = 0
         self._rng = np.random
+        self._native = bool(native_parameters)
+        self._param_seed = None
+        self._draw = None
 
     def _generateInitialModel(self, output_model_type, device=None, process_group=None,
                               engine_factory=None):
@@ -149,9 +155,14 @@ class BayesianHMMSampler(object):
 
     def _update(self, seed=None, keep_paths=False):
         """One Gibbs sweep, bayesian_sampling.py:269-281.  With several ranks the hidden-path
-        step runs sharded; the parameters are then drawn ONCE, on rank 0, and broadcast, so the
-        chain does not depend on how the ranks' random generators were seeded."""
-        C, n0, emis = self._updateHiddenStateTrajectories(seed=seed, keep_paths=keep_paths)
+        step runs sharded and its statistics are all-reduced; the parameter draws are then a
+        deterministic function of (statistics, seed, sweep) that every rank evaluates itself
+        (native path), or are drawn on rank 0 and broadcast (numpy path)."""
+        packed = self._updateHiddenStateTrajectories(seed=seed, keep_paths=keep_paths)
+        if self._native:
+            self._update_parameters_native(packed, seed)
+            return
+        C, n0, emis = _unpack_path_stats(packed, self._output, self.nstates, self._nsymbols)
         if not self._comm.active:
             self._updateEmissionProbabilities(emis)
             self._updateTransitionMatrix(C, n0)
@@ -166,6 +177,31 @@ class BayesianHMMSampler(object):
         self._broadcast_parameters(failed=err is not None)
         if err is not None:
             raise err
+
+    def _update_parameters_native(self, packed, seed):
+        """bayesian_sampling.py:333-373 as one call of bhmm_gibbs_parameters."""
+        if self._param_seed is None or seed is not None:
+            if seed is not None:
+                base = int(seed)
+            else:
+                # no seed given: one draw from numpy's global generator (np.random.seed makes the
+                # whole chain reproducible), identical on every rank
+                base = int(self._rng.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(self._rng.randint(0, 2 ** 31 - 1))
+                base = int(self._comm.broadcast_numpy(np.array([base], dtype=np.int64), src=0)[0])
+            self._param_seed = (base * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        if self._draw is None:
+            from ._native import GibbsParameters
+            om = self.model.output_model
+            self._draw = GibbsParameters(
+                self._output, self.nstates, self._nsymbols, prior_C=self.prior_C,
+                prior_n0=self.prior_n0, prior_B=getattr(om, 'prior', None),
+                reversible=self.reversible, stationary=self.stationary,
+                nsteps=self.transition_matrix_sampling_steps)
+        om = self.model.output_model
+        par0, par1 = om.parameters()
+        Tij, p0, new0, new1 = self._draw(packed, par0, par1, self._param_seed, self._sweep)
+        om.set_parameters(new0, new1)
+        self.model.update(p0, Tij)
 
     def _broadcast_parameters(self, failed=False):
         """[ok | T (n*n) | p0 (n) | emission parameters] from rank 0 to every rank."""
@@ -192,8 +228,9 @@ class BayesianHMMSampler(object):
             self.model.update(p0, Tij)
 
     def _updateHiddenStateTrajectories(self, seed=None, keep_paths=False):
-        """bayesian_sampling.py:283-331 for all trajectories at once, plus the hidden-path
-        statistics the two parameter updates need."""
+        """bayesian_sampling.py:283-331 for all trajectories at once.  Returns the hidden-path
+        statistics the two parameter updates need as ONE packed fp64 vector
+        [C n*n | n0 n | emission block] (summed over ranks)."""
         if seed is not None:
             self._seed_base = int(seed)
         base = getattr(self, '_seed_base', 0x5EED)
@@ -206,9 +243,15 @@ class BayesianHMMSampler(object):
         n, M = self.nstates, self._nsymbols
         esz = 3 * n if self._output == 'gaussian' else (n * M if self._output == 'discrete' else 0)
         paths = []
+
+        def pack(C, n0, emis):
+            return np.concatenate([np.ravel(C).astype(np.float64), np.ravel(n0).astype(np.float64)]
+                                  + ([np.ravel(emis)] if esz else []))
+
         if not comm.active:
             paths, C, n0, emis = eng.sample_paths(A, pi, par0, par1, seed=sweep_seed,
                                                   want_paths=keep_paths)
+            packed = pack(C, n0, emis)
         elif hasattr(eng, 'sample_paths_dev'):
             # ONE packed fp64 vector [C | n0 | emission block] stays on the engine's GPU, ONE
             # all-reduce, ONE copy to the host; the integer counts are exact in fp64 (< 2^53)
@@ -218,16 +261,15 @@ class BayesianHMMSampler(object):
                                              want_paths=keep_paths)
             else:
                 buf.zero_()
-            C, n0, emis = _unpack_path_stats(comm.allreduce_stats(buf), self._output, n, M)
+            packed = comm.allreduce_stats(buf)
         else:
             # host-side engine (CPU test double): same packed vector, host all-reduce
             packed = np.zeros(n * n + n + esz)
             if self._mine:
                 paths, C, n0, emis = eng.sample_paths(A, pi, par0, par1, seed=sweep_seed,
                                                       want_paths=keep_paths)
-                packed = np.concatenate([np.ravel(C).astype(np.float64), np.ravel(n0).astype(np.float64)]
-                                        + ([np.ravel(emis)] if esz else []))
-            C, n0, emis = _unpack_path_stats(comm.allreduce_sum_numpy(packed), self._output, n, M)
+                packed = pack(C, n0, emis)
+            packed = comm.allreduce_sum_numpy(packed)
         if keep_paths:
             full = [None] * self.nobs
             if self._comm.active:
@@ -240,7 +282,7 @@ class BayesianHMMSampler(object):
             self.model.hidden_state_trajectories = full
         else:
             self.model.hidden_state_trajectories = None
-        return C, n0, emis
+        return np.asarray(packed, dtype=np.float64)
 
     def _updateEmissionProbabilities(self, emis):
         """bayesian_sampling.py:333-339 from per-state statistics instead of gathered arrays."""

@@ -122,6 +122,7 @@ class MaximumLikelihoodEstimator(object):
         self._store_gamma = store_gamma
         self._gammas = None
         self._last = None
+        self._mstep = None
         hidden.set_implementation(config.kernel)
         self._hmm.output_model.set_implementation(config.kernel)
 
@@ -256,7 +257,24 @@ class MaximumLikelihoodEstimator(object):
 
     # ---- M-step --------------------------------------------------------------------------
     def _update_model(self, res, maxiter=10000000):
-        """maximum_likelihood.py:284-330 on the reduced statistics."""
+        """maximum_likelihood.py:284-330 on the reduced statistics, as ONE native host call
+        (bhmm_mstep: transition matrix incl. connected sets / reversible fixed points, initial or
+        stationary distribution, emission parameters).  `reversible` is decided from the current
+        transition matrix, like the reference's `self._hmm.is_reversible`."""
+        om = self._hmm.output_model
+        par0, par1 = om.parameters()
+        if self._mstep is None:
+            from ._native import MStep
+            self._mstep = MStep(self._output, self._nstates, self._nsymbols)
+        fixed = (self._fixed_stationary_distribution if self._stationary
+                 else self._fixed_initial_distribution)
+        T, pi, new0, new1 = self._mstep(res.packed, self._hmm.transition_matrix, par0, par1, None,
+                                        self._stationary, fixed, maxiter, 1e-12, 1e-16)
+        self._hmm.update(pi, T)
+        om.set_parameters(new0, new1)
+
+    def _update_model_numpy(self, res, maxiter=10000000):
+        """The same M-step in numpy (_tmatrix.py): the restatement bhmm_mstep is tested against."""
         gamma0_sum, C = res.gamma0_sum, res.C
         T = _tmatrix.estimate_P(C, reversible=self._hmm.is_reversible,
                                 fixed_statdist=self._fixed_stationary_distribution,

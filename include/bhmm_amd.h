@@ -37,6 +37,9 @@ extern "C" {
 #define BHMM_ERR_NONFINITE 5   /* log-likelihood not finite (maximum_likelihood.py:385) */
 #define BHMM_ERR_CHOICE 6      /* inverse-CDF draw found no state (_hidden.c:299-304) */
 #define BHMM_ERR_NO_DEVICE 7   /* no HIP device / library built without one visible */
+#define BHMM_ERR_SIGMA 8       /* M-step: a sigma fell below eps (gaussian.py:271-272, RuntimeError) */
+#define BHMM_ERR_DISCONNECTED 9 /* reversible sampling of a disconnected count matrix
+                                  (bayesian_sampling.py:347-350, NotImplementedError) */
 
 /* emission model kinds */
 #define BHMM_EMIT_GAUSSIAN 0 /* obs: double[T];  par0 = means[N], par1 = sigmas[N]            */
@@ -236,6 +239,67 @@ int bhmm_synth_observations(void *obs_dev, uint8_t *states_dev, int device, void
  * iteration next to a 1 ms E-step. */
 int bhmm_mle_reversible(double *P, int64_t *iterations, const double *C, int n, int64_t maxiter,
                         double maxerr);
+
+/* ------------------------------------------------------------------------------------
+ * (3) host-side model updates between two passes over the trajectories (no device work).
+ *     The reference does these in Python / numpy / msmtools; next to a 0.9 ms E-step or Gibbs path
+ *     step they must not cost milliseconds, so each is ONE call.
+ * ---------------------------------------------------------------------------------- */
+
+/* The whole M-step of one EM iteration (maximum_likelihood.py:284-330) from the packed statistics
+ * vector of bhmm_estep (layout: bhmm_ctx_stats_size):
+ *   transition matrix  estimate_P (_tmatrix_disconnected.py:68-123: strongly / weakly connected
+ *                      sets, reversible fixed point, partially reversible iteration :126-190,
+ *                      row normalisation, estimator with a fixed stationary vector),
+ *   initial / stationary distribution (maximum_likelihood.py:310-320, _tmatrix_disconnected.py:229-251),
+ *   emission parameters (gaussian.py:214-272 from moments about the old means; discrete.py:202-215).
+ *   reversible : 1 / 0, or -1 = "reversible iff T_old is" (the reference passes
+ *                self._hmm.is_reversible, _tmatrix_disconnected.py:213-226)
+ *   stationary : pi_new = stationary distribution of T_new (else normalised sum_k gamma_k[0])
+ *   fixed_pi   : NULL, or the fixed stationary (stationary != 0) / initial (stationary == 0) vector
+ *   par0_old / par1_old : current emission parameters (gaussian: means, sigmas; else may be NULL)
+ *   outputs    : T_new[n*n], pi_new[n], par0_new (means[n] | B[n*M]), par1_new (sigmas[n] | unused)
+ *   info       : optional int32[2]: reversible branch taken, fixed-point iterations
+ * Returns BHMM_ERR_SIGMA if a sigma falls below machine epsilon. */
+int bhmm_mstep(int kind, int n, int M, const double *stats, const double *T_old,
+               const double *par0_old, const double *par1_old, int reversible, int stationary,
+               const double *fixed_pi, int64_t maxiter, double maxerr, double mincount,
+               double *T_new, double *pi_new, double *par0_new, double *par1_new, int32_t *info);
+
+/* The parameter draws of one Gibbs sweep (bayesian_sampling.py:333-373) from the packed path
+ * statistics of bhmm_sample_paths_dev (layout: bhmm_ctx_path_stats_size), in the reference's order:
+ *   emission parameters (gaussian.py:303-318 | discrete.py:243-251; par0 / par1 in and out),
+ *   transition matrix   reversible: start at the reversible MLE of C = counts + prior_C, zero
+ *                       pattern made consistent (:352-357), then `nsteps` FULL sweeps of the
+ *                       element-wise Gibbs sampler of Trendelkamp-Schroer et al. 2015 (what
+ *                       msmtools.estimation.sample_tmatrix(nsteps=...) counts); else independent
+ *                       Dirichlet rows,
+ *   initial distribution Dirichlet(n0 + prior_n0) over the positive entries, or (stationary != 0)
+ *                       the stationary distribution of the new matrix.
+ * Random numbers come from a counter-based generator: the result is a function of (seed, sweep)
+ * and the inputs alone, so every rank of a sharded run draws the SAME parameters from the
+ * all-reduced statistics without a broadcast.  prior_* may be NULL (zero).  info: optional
+ * int32[1], number of 64-bit draws consumed.  Returns BHMM_ERR_DISCONNECTED for reversible
+ * sampling of a count matrix that is not strongly connected. */
+int bhmm_gibbs_parameters(int kind, int n, int M, const double *path_stats, const double *prior_C,
+                          const double *prior_n0, const double *prior_B, int reversible,
+                          int stationary, int64_t nsteps, uint64_t seed, uint64_t sweep, double *T,
+                          double *p0, double *par0, double *par1, int32_t *info);
+
+/* building blocks of the two calls above, exported for the parity / property tests:
+ * component label per state (sets numbered by decreasing size, _tmatrix_disconnected.py:28-43) */
+int bhmm_host_connected_sets(int32_t *label, const double *C, int n, double mincount, int strong);
+int bhmm_host_stationary_vector(double *pi, const double *P, int n);
+int bhmm_host_estimate_tmatrix(double *P, const double *C, int n, int reversible, const double *fixed_pi,
+                         int64_t maxiter, double maxerr, double mincount, int64_t *iterations);
+int bhmm_host_is_reversible(const double *P, int n); /* 1 / 0 (-1: bad argument) */
+/* _tmatrix_disconnected.py:126-190: rows in_set != 0 of P (n x n, in/out) */
+int bhmm_host_partial_rev(double *P, const double *C, int n, const int32_t *in_set, int64_t maxiter,
+                          double maxerr);
+/* `count` draws of the counter-based generator: what = 0 uniform [0,1), 1 standard normal,
+ * 2 gamma(param), 3 uniform (0,1) */
+int bhmm_host_rng_draws(double *out, int64_t count, int what, double param, uint64_t seed,
+                        uint64_t stream);
 
 /* diagnostics: y[i] = the E-step kernels' exp() for non-positive arguments (the exponential
  * of the gaussian density, _gaussian.c:18), so that tests can bound its error in ulps */

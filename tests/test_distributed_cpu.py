@@ -28,7 +28,7 @@ def _problem():
     return _gauss_problem(seed=3, K=5, T=250)
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, native=True, reversible=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import torch.distributed as dist
@@ -43,11 +43,16 @@ def _worker(rank, world, port, outdir):
     assert est._comm.world == world and sorted(sum(est._parts, [])) == list(range(len(obs)))
     hmm = est.fit()
     # rank 0 carries the chain's random generator; the other ranks are seeded differently on
-    # purpose: parameters are drawn on rank 0 and broadcast, so it must not matter
+    # purpose.  numpy path: parameters are drawn on rank 0 and broadcast; native path:
+    # only the chain's base seed comes from rank 0's generator (one broadcast), the draws are a
+    # function of (all-reduced statistics, seed, sweep) that every rank evaluates itself
     np.random.seed(5 if rank == 0 else 1000 + rank)
-    sampler = bhmm_amd.BayesianHMMSampler(obs, 3, initial_model=hmm, reversible=False,
-                                          engine_factory=OracleEngine)
-    C, n0, emis = sampler._updateHiddenStateTrajectories(seed=1, keep_paths=True)
+    sampler = bhmm_amd.BayesianHMMSampler(obs, 3, initial_model=hmm, reversible=reversible,
+                                          engine_factory=OracleEngine, native_parameters=native,
+                                          transition_matrix_sampling_steps=20)
+    from bhmm_amd.estimators.bayesian_sampling import _unpack_path_stats
+    C, n0, emis = _unpack_path_stats(sampler._updateHiddenStateTrajectories(seed=1, keep_paths=True),
+                                     'gaussian', 3, 0)
     first_paths = [np.array(p) for p in sampler.model.hidden_state_trajectories]
     chain = sampler.sample(4, save_hidden_state_trajectory=True)
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), L=est.likelihoods,
@@ -65,7 +70,8 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_rank_em_equals_single_process():
+@pytest.mark.parametrize("native,reversible", [(True, False), (True, True), (False, False)])
+def test_two_rank_em_equals_single_process(native, reversible):
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     import bhmm_amd
@@ -75,13 +81,16 @@ def test_two_rank_em_equals_single_process():
                                               accuracy=1e-5, maxit=15, engine_factory=OracleEngine)
     ref = est.fit()
     np.random.seed(5)
-    sampler = bhmm_amd.BayesianHMMSampler(obs, 3, initial_model=ref, reversible=False,
-                                          engine_factory=OracleEngine)
-    gC, gn0, _ = sampler._updateHiddenStateTrajectories(seed=1, keep_paths=True)
+    sampler = bhmm_amd.BayesianHMMSampler(obs, 3, initial_model=ref, reversible=reversible,
+                                          engine_factory=OracleEngine, native_parameters=native,
+                                          transition_matrix_sampling_steps=20)
+    from bhmm_amd.estimators.bayesian_sampling import _unpack_path_stats
+    gC, gn0, _ = _unpack_path_stats(sampler._updateHiddenStateTrajectories(seed=1, keep_paths=True),
+                                    'gaussian', 3, 0)
     gp2 = np.array(sampler.model.hidden_state_trajectories[2])
     chain = sampler.sample(4, save_hidden_state_trajectory=True)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), d, native, reversible), nprocs=2, join=True)
         r0 = np.load(os.path.join(d, "rank0.npz"))
         r1 = np.load(os.path.join(d, "rank1.npz"))
     for r in (r0, r1):                                       # every rank holds the full result
