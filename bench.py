@@ -18,8 +18,15 @@ its own 256 trajectories; the packed sufficient statistics are all-reduced over 
 At N = 1 the same JSON line also carries `cpu_baseline` (the reference's own C kernels on one
 core, plus `all_cores`), and `secondary`: the other BASELINE configs on the same GPU -- first of
 all configs[2] on ONE GPU (8-state discrete, 1024 x 1e6: the north-star target shape, with its
-own CPU figure and the >= 50x check), then Viterbi and the Gibbs sweep at the configs[1] shape and
-configs[3] (64 states).
+own CPU figure and the >= 50x check), then Viterbi and the Gibbs sweep at the configs[1] shape,
+configs[3] (64 states), and the WHOLE iterations the estimator classes run: one EM iteration
+(E-step + native M-step) and one Gibbs sweep (path step + parameter draws + model update).
+
+At N > 1 `secondary` holds the two configs BASELINE quotes on 8 GPUs, run on all ranks:
+configs[2] STRONG-scaled (1024 / N trajectories x 1e6 per rank; the trajectories are drawn on the
+device by global index, so every N sees the same data and the summed log-likelihood is checked
+against the committed N = 1 value) and the configs[4] chain (whole Gibbs sweeps of
+BayesianHMMSampler: sharded path step, one all-reduce, parameter draws on every rank).
 """
 import argparse
 import json
@@ -221,45 +228,125 @@ def timeit(fn, reps, sync, batches=1):
 # ---------------------------------------------------------------------------------------
 # secondary measurements (N = 1): the other BASELINE configs on the same GPU
 # ---------------------------------------------------------------------------------------
-def secondary_c3(torch, dev, local, args):
-    """configs[2] on ONE GPU: 8-state discrete (M = 64), 1024 x 1e6 -- the north-star target
-    shape.  Observations are drawn on the device (bhmm_synth_observations)."""
+# log-likelihood of the configs[2] evaluation model on the default workload (1024 x 1e6, seed 3000),
+# measured at N = 1 (profiles/r03): every N must reproduce it, the trajectories being drawn by
+# GLOBAL index.  None = not recorded for this shape.
+C3_LOGLIK_N1 = {(1024, 1000000): -4043229364.929859}
+
+
+class Ranks(object):
+    """What the secondary measurements need to know about the job."""
+
+    def __init__(self, torch, dist, world, rank, local, dev, backend, distributed):
+        self.torch, self.dist = torch, dist
+        self.world, self.rank, self.local, self.dev = world, rank, local, dev
+        self.backend, self.distributed = backend, distributed
+
+    def fence(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.distributed:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, seconds):
+        if not self.distributed:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64,
+                              device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_stats(self, stats_dev_tensor):
+        """Packed statistics of all ranks on the host (ONE all-reduce + ONE copy)."""
+        if not self.distributed:
+            return stats_dev_tensor.cpu().numpy()
+        if self.backend == "nccl":
+            self.dist.all_reduce(stats_dev_tensor)
+            return stats_dev_tensor.cpu().numpy()
+        h = stats_dev_tensor.cpu()
+        self.dist.all_reduce(h)
+        return h.numpy()
+
+
+def secondary_c3(rk, args):
+    """configs[2]: 8-state discrete (M = 64), 1024 x 1e6 -- the north-star target shape -- on ONE
+    GPU, or STRONG-scaled over the ranks (1024 / N trajectories per rank, statistics all-reduced).
+    Observations are drawn on the device by global trajectory index."""
     from bhmm_amd.engine import Engine, synth_observations
+    torch, dev, local = rk.torch, rk.dev, rk.local
     rng = np.random.default_rng(3000)
     n, M, K, T = 8, 64, args.c3_ntraj, args.c3_length
+    assert K % rk.world == 0, "configs[2]: %d trajectories do not split over %d ranks" % (K, rk.world)
+    Kloc = K // rk.world
     A = metastable_matrix(n, rng)
     pi = stationary(A)
     B = rng.dirichlet(np.ones(M), size=n)
     A_eval, B_eval = 0.9 * A + 0.1 / n, 0.8 * B + 0.2 / M
-    obs = torch.empty(K * T, dtype=torch.int32, device=dev)
+    obs = torch.empty(Kloc * T, dtype=torch.int32, device=dev)
     t0 = time.perf_counter()
-    synth_observations("discrete", obs.data_ptr(), A, pi, B, None, K, T, seed=3000, device=local)
+    synth_observations("discrete", obs.data_ptr(), A, pi, B, None, Kloc, T, seed=3000, device=local,
+                       first_traj=rk.rank * Kloc)
     t_gen = time.perf_counter() - t0
     eng = Engine(local)
-    eng.set_observations_device("discrete", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T,
+    eng.set_observations_device("discrete", obs.data_ptr(), np.arange(Kloc + 1, dtype=np.int64) * T,
                                 n, nsymbols=M)
-    eng.estep(A_eval, pi, B_eval)                      # measures the warm-up length, verifies
-    dt = timeit(lambda: eng.estep(A_eval, pi, B_eval), args.c3_steps, eng.sync)
-    r = eng.estep(A_eval, pi, B_eval)
+    stats = torch.empty(eng.stats_size, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def one():
+        if not rk.distributed:
+            return eng.estep(A_eval, pi, B_eval).packed
+        eng.estep_launch(A_eval, pi, B_eval, stats_dev=stats.data_ptr())
+        eng.sync()
+        return rk.sum_stats(stats)
+
+    one()                                              # measures the warm-up length, verifies
+    rk.fence()
+    t0 = time.perf_counter()
+    for _ in range(args.c3_steps):
+        one()
+    rk.fence()
+    dt = rk.max_over_ranks(time.perf_counter() - t0) / args.c3_steps
+    packed = one()
     kms = eng.kernel_ms(2)
+    logL_k = eng.estep_fetch_logL() if rk.distributed else eng.estep_fetch().logL_k
+    coll_ms = None
+    if rk.distributed:
+        rk.fence()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            rk.sum_stats(stats)
+        coll_ms = 1e3 * (time.perf_counter() - t0) / 20
+    r = eng.unpack(packed)
     np.testing.assert_allclose(r.state_counts.sum(), K * T, rtol=1e-9)
     np.testing.assert_allclose(r.C.sum(), K * (T - 1), rtol=1e-9)
+    want = C3_LOGLIK_N1.get((K, T))
+    if want is not None:
+        assert abs(r.loglik - want) <= 1e-12 * abs(want), \
+            "configs[2]: log-likelihood %r differs from the N = 1 value %r" % (r.loglik, want)
     b_alg = 2 * 4 + 16 * n                               # 136 B / step, SURVEY.md 8(d)
-    out = {"config": "configs[2] on ONE GPU: 8-state discrete HMM (M=64), %d trajectories x %d "
-                     "timesteps, one full E-step" % (K, T),
-           "ms": 1e3 * dt, "timesteps_per_s": K * T / dt,
+    out = {"config": "configs[2]%s: 8-state discrete HMM (M=64), %d trajectories x %d timesteps, one "
+                     "full E-step%s" % (" on ONE GPU" if rk.world == 1 else " STRONG-scaled over %d GPUs"
+                                        % rk.world, K, T,
+                                        "" if rk.world == 1 else " (%d trajectories per rank, all-reduce of "
+                                        "%d statistics)" % (Kloc, eng.stats_size)),
+           "n_gpus": rk.world, "scaling": "strong",
+           "ms": 1e3 * dt, "timesteps_per_s": K * T / dt, "loglik": r.loglik,
+           "loglik_matches_n1": None if want is None else True,
+           "allreduce_plus_copy_ms": coll_ms,
            "roofline": {"bound": "hbm", "alg_bytes_per_timestep": b_alg,
-                        "achieved": b_alg * K * T / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": b_alg * K * T / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "kernel_ms": kms, "whole_estep_frac": b_alg * K * T / dt / 1e9 / HBM_PEAK_GBS},
+                        "achieved": b_alg * Kloc * T / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": b_alg * Kloc * T / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "kernel_ms": kms, "per": "GPU (rank 0's sweep launches)",
+                        "whole_estep_frac": b_alg * K * T / dt / 1e9 / HBM_PEAK_GBS / rk.world},
            "chunk_len": eng.chunk_len, "chunks": eng.num_chunks,
            "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")},
            "synth_seconds": t_gen}
-    if not args.no_cpu:
+    if rk.world == 1 and not args.no_cpu:
         kc = min(args.c3_cpu_traj, K)
         sample = obs[: kc * T].cpu().numpy().reshape(kc, T)
         cb, ll = cpu_baseline("discrete", A_eval, pi, B_eval, None, sample, threads=1)
-        rel = float(np.max(np.abs((r.logL_k[:kc] - np.array(ll)) / np.array(ll))))
+        rel = float(np.max(np.abs((logL_k[:kc] - np.array(ll)) / np.array(ll))))
         assert rel < 1e-9, "configs[2]: GPU/CPU log-likelihood mismatch %g" % rel
         cb["loglik_rel_diff_vs_gpu"] = rel
         out["cpu_baseline"] = cb
@@ -267,8 +354,83 @@ def secondary_c3(torch, dev, local, args):
         out["target_50x_met"] = bool(out["speedup_vs_1core"] >= 50.0)
         assert out["target_50x_met"], "north-star target (>= 50x the reference CPU path) missed"
     eng.close()
-    del obs
+    del obs, stats
+    torch.cuda.empty_cache()
     return out
+
+
+def secondary_whole_iterations(rk, model, args):
+    """What a user of the estimator classes pays per iteration, host side included: whole EM
+    iterations (MaximumLikelihoodEstimator.em_step: E-step + all-reduce + native M-step,
+    maximum_likelihood.py:383-399) and whole Gibbs sweeps (BayesianHMMSampler.sample: sharded path
+    step + all-reduce + parameter draws + model update + the per-sample model copy,
+    bayesian_sampling.py:206-281) on the configs[1] / configs[4] shape.  Every rank holds the same
+    global set of trajectories (drawn on the device by global index) and the classes shard it."""
+    import bhmm_amd
+    from bhmm_amd.engine import synth_observations
+    from bhmm_amd.estimators import _tmatrix
+    torch, dev, local = rk.torch, rk.dev, rk.local
+    n, K, T = NSTATES, args.ntraj, args.length
+    buf = torch.empty(K * T, dtype=torch.float64, device=dev)
+    synth_observations("gaussian", buf.data_ptr(), model["A"], model["pi"], model["mu"],
+                       model["sigma"], K, T, seed=2000, device=local, first_traj=0)
+    host = buf.cpu().numpy().reshape(K, T)
+    del buf
+    torch.cuda.empty_cache()
+    obs = [host[k] for k in range(K)]
+    pi, A_eval = model["pi"], model["A_eval"]
+    A_rev = _tmatrix.mle_reversible(pi[:, None] * A_eval, maxerr=1e-14)   # a reversible start
+    res = []
+    for rev in (True, False):
+        init = bhmm_amd.gaussian_hmm(pi, A_rev if rev else A_eval, model["mu_eval"], model["sigma"])
+        est = bhmm_amd.MaximumLikelihoodEstimator(obs, n, initial_model=init, reversible=rev,
+                                                  device=local)
+        for _ in range(max(5, args.em_iterations)):      # (also brings the GPU out of its idle clocks)
+            est.em_step()
+        rk.fence()
+        lls = []
+        t0 = time.perf_counter()
+        for _ in range(args.em_iterations):
+            lls.append(est.em_step())
+        rk.fence()
+        dt = rk.max_over_ranks(time.perf_counter() - t0) / args.em_iterations
+        assert np.all(np.diff(lls) > -1e-6 * abs(lls[0])), "EM log-likelihood decreased"
+        eng = est._engine
+        res.append({"config": "configs[1] shape, WHOLE EM iteration (E-step%s + native M-step, model "
+                              "updated every iteration), %s transition matrix, %d x %d over %d GPU(s)"
+                              % (" + all-reduce" if rk.distributed else "",
+                                 "reversible" if rev else "non-reversible", K, T, rk.world),
+                    "n_gpus": rk.world, "ms_per_iteration": 1e3 * dt,
+                    "timesteps_per_s": K * T / dt, "iterations": args.em_iterations,
+                    "loglik_first_last": [lls[0], lls[-1]],
+                    "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail")}
+                    if hasattr(eng, "get_option") and est.local_trajectories else None})
+        eng.close()
+        del est
+    for rev, nsteps in ((False, 1000), (True, 1000), (True, 30)):
+        init = bhmm_amd.gaussian_hmm(pi, A_rev if rev else A_eval, model["mu_eval"], model["sigma"])
+        smp = bhmm_amd.BayesianHMMSampler(obs, n, initial_model=init, reversible=rev,
+                                          transition_matrix_sampling_steps=nsteps, device=local)
+        smp.sample(max(3, args.chain_sweeps), seed=1)
+        rk.fence()
+        t0 = time.perf_counter()
+        models = smp.sample(args.chain_sweeps)
+        rk.fence()
+        dt = rk.max_over_ranks(time.perf_counter() - t0) / args.chain_sweeps
+        assert len(models) == args.chain_sweeps
+        res.append({"config": "configs[4] chain, WHOLE Gibbs sweep (path step%s + parameter draws + "
+                              "model update + model copy), %s, 8-state Gaussian, %d x %d over %d GPU(s)"
+                              % (" + all-reduce" if rk.distributed else "",
+                                 ("reversible, %d full sweeps of the transition-matrix sampler per "
+                                  "Gibbs sweep%s" % (nsteps, " (the reference's default)"
+                                                     if nsteps == 1000 else "")) if rev
+                                 else "non-reversible (Dirichlet rows)", K, T, rk.world),
+                    "n_gpus": rk.world, "ms_per_sweep": 1e3 * dt, "timesteps_per_s": K * T / dt,
+                    "sweeps": args.chain_sweeps, "samples_100_seconds": 100 * dt})
+        smp._engine.close()
+        del smp, models
+    torch.cuda.empty_cache()
+    return res
 
 
 def secondary_c2_paths(torch, dev, local, eng, model, K, T, args):
@@ -295,7 +457,10 @@ def secondary_c2_paths(torch, dev, local, eng, model, K, T, args):
     b_alg = 2 * 8 + 16 * 8 + 4                           # Gibbs path sweep
     res.append({"config": "configs[4] sweep: Gibbs hidden-path step (forward + backward sampling + "
                           "path statistics), 8-state Gaussian, %d x %d, one GPU" % (K, T),
-                "ms": 1e3 * dt, "timesteps_per_s": K * T / dt, "sweeps_100_seconds": 100 * dt,
+                "ms": 1e3 * dt, "timesteps_per_s": K * T / dt,
+                "path_steps_100_seconds": 100 * dt,
+                "note": "the hidden-path step alone; the whole sweep incl. parameter draws is the "
+                        "'WHOLE Gibbs sweep' entries below",
                 "roofline": {"bound": "hbm", "alg_bytes_per_timestep": b_alg,
                              "frac": b_alg * K * T / dt / 1e9 / HBM_PEAK_GBS}})
     return res
@@ -347,6 +512,10 @@ def main():
     ap.add_argument("--c3-length", type=int, default=1000000)
     ap.add_argument("--c3-steps", type=int, default=5)
     ap.add_argument("--c3-cpu-traj", type=int, default=6)
+    ap.add_argument("--traffic-json", default="profiles/traffic_current.json",
+                    help="offline PMC measurement quoted as roofline.traffic (tools/profile_round*.sh)")
+    ap.add_argument("--chain-sweeps", type=int, default=20, help="Gibbs sweeps timed per chain variant")
+    ap.add_argument("--em-iterations", type=int, default=30, help="whole EM iterations timed")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST AID for boxes with fewer GPUs than ranks: ranks share GPUs "
                          "(local rank modulo device count) and the all-reduce runs over gloo")
@@ -365,22 +534,11 @@ def main():
 
     K, T = args.ntraj, args.length
     model = make_c2_model()
-    obs_host = synth_gaussian(model, K, T, seed=1000 * 2 + rank)   # this rank's trajectories
     off = np.arange(K + 1, dtype=np.int64) * T
-
-    # CPU legs first, before this process initialises the GPU (rank 0, N = 1 only)
-    cb = cb_all = ll_cpu = None
-    if world == 1 and not args.no_cpu:
-        mcpu = (model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
-        cb, ll_cpu = cpu_baseline("gaussian", *mcpu, obs_host[: args.cpu_traj], threads=1)
-        nc = host_cores()
-        if nc > 1:
-            cb_all, ll_all = cpu_baseline("gaussian", *mcpu, obs_host, threads=nc)
-            assert np.allclose(ll_all[: args.cpu_traj], ll_cpu, rtol=1e-13)
 
     import torch
     import torch.distributed as dist
-    from bhmm_amd.engine import Engine
+    from bhmm_amd.engine import Engine, synth_observations
 
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -399,8 +557,25 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    obs_dev = torch.from_numpy(obs_host.reshape(-1)).to(dev)
+    # this rank's trajectories, drawn ON THE DEVICE (bhmm_synth_observations_at): rank r holds
+    # trajectories r*K .. (r+1)*K - 1 of one global set -- no per-rank numpy loop over 1e5 steps
+    obs_dev = torch.empty(K * T, dtype=torch.float64, device=dev)
+    synth_observations("gaussian", obs_dev.data_ptr(), model["A"], model["pi"], model["mu"],
+                       model["sigma"], K, T, seed=2000, device=local, first_traj=rank * K)
     torch.cuda.synchronize(dev)
+
+    # CPU legs (rank 0, N = 1 only) on host copies of the same trajectories
+    cb = cb_all = ll_cpu = None
+    if world == 1 and not args.no_cpu:
+        obs_host = obs_dev.cpu().numpy().reshape(K, T)
+        mcpu = (model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
+        cb, ll_cpu = cpu_baseline("gaussian", *mcpu, obs_host[: args.cpu_traj], threads=1)
+        nc = host_cores()
+        if nc > 1:
+            cb_all, ll_all = cpu_baseline("gaussian", *mcpu, obs_host, threads=nc)
+            assert np.allclose(ll_all[: args.cpu_traj], ll_cpu, rtol=1e-13)
+        del obs_host
+
     # a dedicated (non-default) stream shared by the engine and the collective: the legacy default
     # stream would serialise against every other stream of the process
     stream = torch.cuda.Stream(device=dev)
@@ -454,6 +629,7 @@ def main():
     # sanity of the reduced statistics: every step of every rank carries unit gamma mass
     np.testing.assert_allclose(res.state_counts.sum(), world * K * T, rtol=1e-9)
 
+    out = None
     if rank == 0:
         steps_total = world * K * T
         value = steps_total * args.steps / elapsed
@@ -465,15 +641,17 @@ def main():
         alg_bytes_launch = B_ALG_GAUSS * K * T
         achieved = alg_bytes_launch / (kern_ms[2] * 1e-3) / 1e9
         traffic, traffic_file = None, None
-        for cand in ("r02/r02_traffic.json", "r01/r01q_traffic.json"):
-            tj = os.path.join(ROOT, "profiles", cand)
-            if os.path.exists(tj) and (K, T) == (256, 100000):
-                # HBM bytes of the sweep launches of one E-step from the PMC counters: collected
-                # OFFLINE with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
-                # correction applied), same workload and kernels -- not re-measured by this run
-                if eng.get_option("spec_ok") > 0 and eng.get_option("spec_fail") == 0:
-                    traffic, traffic_file = json.load(open(tj))["traffic_bytes_per_launch"], cand
-                break
+        tj = args.traffic_json if os.path.isabs(args.traffic_json) else os.path.join(ROOT, args.traffic_json)
+        if os.path.exists(tj) and (K, T) == (256, 100000):
+            # HBM bytes of the sweep launches of one E-step from the PMC counters: collected
+            # OFFLINE with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction
+            # applied), same workload and kernels -- not re-measured by this run.  The file is
+            # named by --traffic-json (default: profiles/traffic_current.json, a copy of the
+            # latest round's measurement; its "source" field says which)
+            if eng.get_option("spec_ok") > 0 and eng.get_option("spec_fail") == 0:
+                tdoc = json.load(open(tj))
+                traffic = tdoc["traffic_bytes_per_launch"]
+                traffic_file = "%s (%s)" % (args.traffic_json, tdoc.get("source", "source not recorded"))
         out = {
             "metric": "timesteps/sec forward-backward (whole node), N=8 states",
             "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
@@ -497,7 +675,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_is_live": False,
                          "traffic_source": ("offline rocprofv3 PMC passes on the same workload, "
-                                            "profiles/%s" % traffic_file) if traffic_file else None,
+                                            "%s" % traffic_file) if traffic_file else None,
                          "alg_bytes_per_launch": alg_bytes_launch,
                          "alg_bytes_per_timestep": B_ALG_GAUSS,
                          "whole_estep_frac": B_ALG_GAUSS * value / world / 1e9 / HBM_PEAK_GBS},
@@ -518,14 +696,22 @@ def main():
             if cb_all is not None:
                 cb["all_cores"] = {k: cb_all[k] for k in ("value", "unit", "cores", "sample")}
             out["cpu_baseline"] = cb
-        if world == 1 and not args.no_secondary:
+    if not args.no_secondary:
+        # the secondary measurements run on ALL ranks (their collectives need everyone)
+        rk = Ranks(torch, dist, world, rank, local, dev, backend, distributed)
+        sec = []
+        if world == 1:
             sec = secondary_c2_paths(torch, dev, local, eng, model, K, T, args)
-            eng.close()
-            del obs_dev
-            torch.cuda.empty_cache()
-            sec.insert(0, secondary_c3(torch, dev, local, args))
+        eng.close()
+        del obs_dev, stats
+        torch.cuda.empty_cache()
+        sec.insert(0, secondary_c3(rk, args))
+        if world == 1:
             sec.append(secondary_c4(torch, dev, local, args))
+        sec.extend(secondary_whole_iterations(rk, model, args))
+        if out is not None:
             out["secondary"] = sec
+    if out is not None:
         print(json.dumps(out))
     eng.close()
     if distributed:

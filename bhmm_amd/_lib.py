@@ -94,12 +94,17 @@ SIGNATURES = {
                                                ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                                c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int64, ctypes.c_uint64]),
+    "bhmm_synth_observations_at": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p,
+                                                  ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                                  c_double_p, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,
+                                                  ctypes.c_int64]),
     "bhmm_mle_reversible": (ctypes.c_int, [c_double_p, c_int64_p, c_double_p, ctypes.c_int,
                                            ctypes.c_int64, ctypes.c_double]),
     "bhmm_mstep": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                   c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p,
                                   ctypes.c_int64, ctypes.c_double, ctypes.c_double, c_double_p,
-                                  c_double_p, c_double_p, c_double_p, c_int32_p]),
+                                  c_double_p, c_double_p, c_double_p, c_int32_p, c_double_p]),
     "bhmm_gibbs_parameters": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
                                              c_double_p, c_double_p, c_double_p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "host_common.hpp"
+#include "plan.hpp"
 #include "estep_sweep.hpp"
 
 namespace bhmm {
@@ -718,72 +719,27 @@ struct Runner {
 // Every trajectory is cut into ceil(T/L) chunks whose lengths differ by at most one.
 static int plan_chunks(bhmm_ctx *c, int chunk, bool allow_mult = true)
 {
-    if (chunk > 0)
-        c->chunk_mult = 1;
+    // the tables come from plan.hpp (pure host code, also built under the CPU sanitizers); here
+    // they are adopted and uploaded
     const int K = c->K;
-    int L = chunk;
-    if (L <= 0) {
-        // k_estep uses N/2 lanes per chunk: 32768 chunks (N = 8) put two 64-lane wavefronts on every
-        // SIMD of the 256 CUs.  Fewer, longer chunks amortise the warm-up of the speculative
-        // boundaries (W / L extra steps); more chunks only help occupancy (measured optimum on
-        // configs[1]: profiles/r01).
-        const int64_t target = 32768 * 4 / std::max(1, c->N / 2); // N/2 lanes per chunk
-        int64_t l = (c->total + target - 1) / target;
-        // Very long chunks: two or three times as many.  The sweeps without xi accumulators (P1,
-        // the forward-only pass) then have four to six long wavefronts per SIMD instead of two
-        // (configs[2], 1024 x 1e6: P1 7.2 -> 5.9 ms, E-step 20.2 -> 18.7 ms), while the warm-up
-        // stays below a few per cent of the chunk even if it calibrates to four times the default.
-        c->chunk_mult = 1;
-        if (l >= 3 * 9216 && allow_mult) {
-            l = (l + 2) / 3;
-            c->chunk_mult = 3;
-        } else if (l >= 2 * 9216 && allow_mult) {
-            l = (l + 1) / 2;
-            c->chunk_mult = 2;
-        }
-        L = (int)std::min<int64_t>(std::max<int64_t>(l, 32), (int64_t)1 << 20);
-    }
-    c->L = L;
-    std::vector<int32_t> ctraj, clen;
-    std::vector<int64_t> ct0, cgoff;
-    c->traj_c0.assign(K + 1, 0);
-    int Lmax = 1;
-    for (int k = 0; k < K; ++k) {
-        const int64_t T = c->offsets[k + 1] - c->offsets[k];
-        c->traj_c0[k] = (int32_t)ctraj.size();
-        if (T <= 0)
-            continue;
-        const int64_t nck = (T + L - 1) / L;
-        const int64_t base = T / nck, rem = T % nck;
-        if ((int64_t)ctraj.size() + nck > (int64_t)1 << 30)
-            return invalid("too many chunks");
-        for (int64_t q = 0; q < nck; ++q) {
-            const int64_t len = base + (q < rem ? 1 : 0);
-            const int64_t t0 = q * base + std::min(q, rem);
-            ctraj.push_back(k);
-            clen.push_back((int32_t)len);
-            ct0.push_back(t0);
-            cgoff.push_back(c->offsets[k] + t0);
-            Lmax = std::max<int>(Lmax, (int)len);
-        }
-    }
-    c->traj_c0[K] = (int32_t)ctraj.size();
-    c->G = (int)ctraj.size();
-    c->Gp = std::max(BLOCK, (c->G + BLOCK - 1) / BLOCK * BLOCK);
-    c->Lmax = Lmax;
-    ctraj.resize(c->Gp, 0);
-    clen.resize(c->Gp, 0);
-    ct0.resize(c->Gp, 1);
-    cgoff.resize(c->Gp, 0);
+    plan::ChunkPlan p;
+    if (!plan::plan_chunks(c->offsets, K, c->N, c->total, chunk, allow_mult, BLOCK, p))
+        return invalid("too many chunks");
+    c->chunk_mult = p.chunk_mult;
+    c->L = p.L;
+    c->traj_c0 = p.traj_c0;
+    c->G = p.G;
+    c->Gp = p.Gp;
+    c->Lmax = p.Lmax;
     int rc;
     if ((rc = c->d_ctraj.ensure(c->Gp)) || (rc = c->d_clen.ensure(c->Gp)) ||
         (rc = c->d_ct0.ensure(c->Gp)) || (rc = c->d_cgoff.ensure(c->Gp)) ||
         (rc = c->d_traj_c0.ensure(K + 1)))
         return rc;
-    BHMM_HIP(hipMemcpy(c->d_ctraj.p, ctraj.data(), c->Gp * sizeof(int32_t), hipMemcpyHostToDevice));
-    BHMM_HIP(hipMemcpy(c->d_clen.p, clen.data(), c->Gp * sizeof(int32_t), hipMemcpyHostToDevice));
-    BHMM_HIP(hipMemcpy(c->d_ct0.p, ct0.data(), c->Gp * sizeof(int64_t), hipMemcpyHostToDevice));
-    BHMM_HIP(hipMemcpy(c->d_cgoff.p, cgoff.data(), c->Gp * sizeof(int64_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_ctraj.p, p.ctraj.data(), c->Gp * sizeof(int32_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_clen.p, p.clen.data(), c->Gp * sizeof(int32_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_ct0.p, p.ct0.data(), c->Gp * sizeof(int64_t), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(c->d_cgoff.p, p.cgoff.data(), c->Gp * sizeof(int64_t), hipMemcpyHostToDevice));
     BHMM_HIP(hipMemcpy(c->d_traj_c0.p, c->traj_c0.data(), (K + 1) * sizeof(int32_t),
                        hipMemcpyHostToDevice));
     if ((rc = c->d_offsets.ensure(K + 1)))
@@ -791,31 +747,17 @@ static int plan_chunks(bhmm_ctx *c, int chunk, bool allow_mult = true)
     BHMM_HIP(hipMemcpy(c->d_offsets.p, c->offsets.data(), (K + 1) * sizeof(int64_t),
                        hipMemcpyHostToDevice));
     // two-level stitch: groups of R consecutive chunks; serial depth 2R + n/R instead of n
-    int nmax = 0;
-    for (int k = 0; k < K; ++k)
-        nmax = std::max(nmax, c->traj_c0[k + 1] - c->traj_c0[k]);
-    c->nG = 0;
-    if (nmax > 48) {
-        const int R = std::max(4, std::min(256, (int)lround(sqrt(0.5 * nmax))));
-        std::vector<int32_t> g0, g1, gt(K + 1, 0);
-        for (int k = 0; k < K; ++k) {
-            gt[k] = (int32_t)g0.size();
-            for (int cc = c->traj_c0[k]; cc < c->traj_c0[k + 1]; cc += R) {
-                g0.push_back(cc);
-                g1.push_back(std::min(cc + R, c->traj_c0[k + 1]));
-            }
-        }
-        gt[K] = (int32_t)g0.size();
-        c->nG = (int)g0.size();
+    c->nG = p.nG;
+    if (c->nG > 0) {
         const size_t MSz = (size_t)c->N * c->N + c->N;
         if ((rc = c->d_grp_c0.ensure(c->nG)) || (rc = c->d_grp_c1.ensure(c->nG)) ||
             (rc = c->d_grp_traj0.ensure(K + 1)) || (rc = c->d_P.ensure((size_t)c->nG * MSz)) ||
             (rc = c->d_agrp.ensure((size_t)c->nG * c->N)) ||
             (rc = c->d_bgrp.ensure((size_t)c->nG * c->N)))
             return rc;
-        BHMM_HIP(hipMemcpy(c->d_grp_c0.p, g0.data(), c->nG * sizeof(int32_t), hipMemcpyHostToDevice));
-        BHMM_HIP(hipMemcpy(c->d_grp_c1.p, g1.data(), c->nG * sizeof(int32_t), hipMemcpyHostToDevice));
-        BHMM_HIP(hipMemcpy(c->d_grp_traj0.p, gt.data(), (K + 1) * sizeof(int32_t),
+        BHMM_HIP(hipMemcpy(c->d_grp_c0.p, p.g0.data(), c->nG * sizeof(int32_t), hipMemcpyHostToDevice));
+        BHMM_HIP(hipMemcpy(c->d_grp_c1.p, p.g1.data(), c->nG * sizeof(int32_t), hipMemcpyHostToDevice));
+        BHMM_HIP(hipMemcpy(c->d_grp_traj0.p, p.gt.data(), (K + 1) * sizeof(int32_t),
                            hipMemcpyHostToDevice));
     }
     return BHMM_OK;

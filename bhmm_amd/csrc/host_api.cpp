@@ -116,7 +116,7 @@ extern "C" int bhmm_mstep(int kind, int n, int M, const double *stats, const dou
                           const double *par0_old, const double *par1_old, int reversible,
                           int stationary, const double *fixed_pi, int64_t maxiter, double maxerr,
                           double mincount, double *T_new, double *pi_new, double *par0_new,
-                          double *par1_new, int32_t *info)
+                          double *par1_new, int32_t *info, double *warm_state)
 {
     if (!stats || !T_new || !pi_new || n < 1)
         return bhmm::invalid_arg("bhmm_mstep: NULL argument or no states");
@@ -128,7 +128,7 @@ extern "C" int bhmm_mstep(int kind, int n, int M, const double *stats, const dou
     const bool rev = reversible < 0 ? is_reversible(T_old, n) : reversible != 0;
     int64_t its = 0;
     int rc = estimate_P(C, n, rev, stationary ? fixed_pi : nullptr, maxiter, maxerr, mincount, T_new,
-                        &its);
+                        &its, warm_state);
     if (rc)
         return rc;
     if (stationary) {

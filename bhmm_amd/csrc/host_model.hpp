@@ -26,7 +26,9 @@ Sets connected_sets(const double *C, int n, double mincount, bool strong);
 void stationary_vector(const double *P, int n, double *pi);
 
 // the fixed point of bhmm_mle_reversible (host_mstep.cpp); returns the iteration count
-int64_t mle_reversible(const double *C, int n, int64_t maxiter, double maxerr, double *P);
+// xsum_state (optional, 1 + n doubles, in/out): warm start / final state of the row sums
+int64_t mle_reversible(const double *C, int n, int64_t maxiter, double maxerr, double *P,
+                       double *xsum_state = nullptr);
 // reversible MLE with a given stationary vector
 void mle_reversible_fixed_pi(const double *C, const double *pi, int n, int64_t maxiter,
                              double maxerr, double *P);
@@ -34,8 +36,10 @@ void mle_reversible_fixed_pi(const double *C, const double *pi, int n, int64_t m
 int64_t partial_rev(const double *C, int n, const std::vector<char> &in_S, int64_t maxiter,
                     double maxerr, double *P);
 // _tmatrix_disconnected.py:68-123.  fixed_pi may be NULL.  Returns BHMM_OK / error code.
+// warm (optional, 1 + n doubles, in/out): state of the reversible fixed point carried from call to call
 int estimate_P(const double *C, int n, bool reversible, const double *fixed_pi, int64_t maxiter,
-               double maxerr, double mincount, double *P, int64_t *iterations);
+               double maxerr, double mincount, double *P, int64_t *iterations,
+               double *warm = nullptr);
 // _tmatrix_disconnected.py:229-251 with a count matrix
 void stationary_distribution(const double *P, const double *C, int n, double mincount, double *pi);
 // _tmatrix_disconnected.py:213-226

@@ -45,12 +45,13 @@ __device__ __forceinline__ int cdf_pick(const double *cdf, int n, double u)
 // One thread per trajectory (serial in t: the hidden path is a Markov chain), 64 trajectories
 // per workgroup, 64 steps buffered per thread in LDS and written out as whole 256-byte rows so
 // that the stores are coalesced although every thread walks its own trajectory.
-//   stream position of step t of trajectory k: 2 * (k * T + t) (state), + 1 (emission)
+//   stream position of step t of trajectory k: 2 * ((k0 + k) * T + t) (state), + 1 (emission);
+//   k0 = index of this call's first trajectory in a larger (sharded) set
 template <bool GAUSS>
 __global__ __launch_bounds__(64) void k_synth(const double *cdfA, const double *cdfpi,
                                               const double *par0, const double *par1, int n, int M,
                                               int K, int64_t T, uint64_t seed, void *obs_out,
-                                              uint8_t *states_out)
+                                              uint8_t *states_out, int64_t k0)
 {
     extern __shared__ double sm[];
     double *sA = sm;              // [n*n] row CDFs of A
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(64) void k_synth(const double *cdfA, const double *
         if (live) {
             for (int q = 0; q < cnt; ++q) {
                 const int64_t t = tb + q;
-                const uint64_t pos = 2 * (uint64_t)(k * T + t);
+                const uint64_t pos = 2 * (uint64_t)((k0 + k) * T + t);
                 const double us = synth_uniform(seed, pos);
                 s = t == 0 ? cdf_pick(cdfpi, n, us) : cdf_pick(sA + s * n, n, us);
                 const double ue = synth_uniform(seed, pos + 1);
@@ -110,12 +111,26 @@ __global__ __launch_bounds__(64) void k_synth(const double *cdfA, const double *
 
 using namespace bhmm;
 
+extern "C" int bhmm_synth_observations_at(void *obs_dev, uint8_t *states_dev, int device,
+                                          void *stream, int kind, const double *A, const double *pi,
+                                          const double *par0, const double *par1, int N, int M,
+                                          int K, int64_t T, uint64_t seed, int64_t first_traj);
+
 extern "C" int bhmm_synth_observations(void *obs_dev, uint8_t *states_dev, int device, void *stream,
                                        int kind, const double *A, const double *pi,
                                        const double *par0, const double *par1, int N, int M, int K,
                                        int64_t T, uint64_t seed)
 {
-    if (!obs_dev || !A || !pi || !par0 || N < 1 || N > 255 || K < 1 || T < 1)
+    return bhmm_synth_observations_at(obs_dev, states_dev, device, stream, kind, A, pi, par0, par1, N,
+                                      M, K, T, seed, 0);
+}
+
+extern "C" int bhmm_synth_observations_at(void *obs_dev, uint8_t *states_dev, int device,
+                                          void *stream, int kind, const double *A, const double *pi,
+                                          const double *par0, const double *par1, int N, int M,
+                                          int K, int64_t T, uint64_t seed, int64_t first_traj)
+{
+    if (!obs_dev || !A || !pi || !par0 || N < 1 || N > 255 || K < 1 || T < 1 || first_traj < 0)
         return invalid_arg("bad argument");
     if (kind != BHMM_EMIT_GAUSSIAN && kind != BHMM_EMIT_DISCRETE)
         return invalid_arg("kind must be gaussian or discrete");
@@ -174,7 +189,7 @@ extern "C" int bhmm_synth_observations(void *obs_dev, uint8_t *states_dev, int d
             if (rc == hipSuccess)
                 hipLaunchKernelGGL(k_synth<true>, grid, blk, sm, st, (const double *)dA,
                                    (const double *)dpi, (const double *)d0, (const double *)d1, N, M, K,
-                                   T, seed, obs_dev, states_dev);
+                                   T, seed, obs_dev, states_dev, first_traj);
         } else {
             if (sm > 64 * 1024)
                 rc = hipFuncSetAttribute((const void *)k_synth<false>,
@@ -182,7 +197,7 @@ extern "C" int bhmm_synth_observations(void *obs_dev, uint8_t *states_dev, int d
             if (rc == hipSuccess)
                 hipLaunchKernelGGL(k_synth<false>, grid, blk, sm, st, (const double *)dA,
                                    (const double *)dpi, (const double *)d0, (const double *)nullptr, N,
-                                   M, K, T, seed, obs_dev, states_dev);
+                                   M, K, T, seed, obs_dev, states_dev, first_traj);
         }
         if (rc == hipSuccess)
             rc = hipGetLastError();

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "host_common.hpp"
+#include "plan.hpp"
 #include "wide_kernels.hpp"
 
 namespace bhmm {
@@ -167,26 +168,10 @@ static int64_t wide_fill_len(const bhmm_ctx *c)
 // segment plan `which` with segments of at most seglen steps (seglen <= 0: one per trajectory)
 static int wide_plan(bhmm_ctx *c, int which, int64_t seglen, int mult = 1)
 {
-    std::vector<int32_t> st, sl, s0(c->K + 1, 0);
-    std::vector<int64_t> stt;
-    for (int k = 0; k < c->K; ++k) {
-        s0[k] = (int32_t)st.size();
-        const int64_t T = c->offsets[k + 1] - c->offsets[k];
-        if (T <= 0)
-            continue;
-        const int64_t ns = (seglen > 0 ? (T + seglen - 1) / seglen : 1) * mult;
-        // boundaries at multiples of four (see segs_of)
-        int64_t prev = 0;
-        for (int64_t q = 1; q <= ns; ++q) {
-            int64_t b = q == ns ? T : ((q * T) / ns) & ~(int64_t)3;
-            if (b <= prev)
-                continue;
-            st.push_back(k);
-            sl.push_back((int32_t)(b - prev));
-            stt.push_back(prev);
-            prev = b;
-        }
-    }
+    plan::SegPlan sp; // (plan.hpp: pure host code, also built under the CPU sanitizers)
+    plan::plan_segments(c->offsets, c->K, seglen, mult, sp);
+    std::vector<int32_t> &st = sp.traj, &sl = sp.len, &s0 = sp.traj0;
+    std::vector<int64_t> &stt = sp.t0;
     s0[c->K] = (int32_t)st.size();
     const int ns = (int)st.size();
     c->w_nseg[which] = ns;
@@ -219,21 +204,7 @@ static int wide_plan_segments(bhmm_ctx *c, int64_t seglen)
             return rc;
         // for every segment of plan 1: the start of a plan-2 segment strictly inside it (-1: none)
         std::vector<int64_t> mid;
-        for (int k = 0; k < c->K; ++k) {
-            const int64_t T = c->offsets[k + 1] - c->offsets[k];
-            if (T <= 0)
-                continue;
-            const int64_t ns = (T + seglen - 1) / seglen;
-            int64_t prev = 0;
-            for (int64_t q = 1; q <= ns; ++q) {
-                const int64_t b = q == ns ? T : ((q * T) / ns) & ~(int64_t)3;
-                if (b <= prev)
-                    continue;
-                const int64_t m2 = (((2 * q - 1) * T) / (2 * ns)) & ~(int64_t)3;
-                mid.push_back(m2 > prev && m2 < b ? m2 : -1);
-                prev = b;
-            }
-        }
+        plan::plan_forward_mids(c->offsets, c->K, seglen, mid);
         if ((int)mid.size() != c->w_nseg[1])
             return BHMM_ERR_INVALID; // (cannot happen: both loops cut the trajectories the same way)
         if ((rc = c->d_wseg_fmid.ensure(std::max<size_t>(mid.size(), 1))))

@@ -317,10 +317,12 @@ class Engine(object):
 
 
 def synth_observations(kind, obs_dev, A, pi, par0, par1, K, T, seed, device=0, stream=None,
-                       states_dev=None):
+                       states_dev=None, first_traj=0):
     """Draw K synthetic trajectories of T steps on the GPU into the device buffer at address
     `obs_dev` (K*T doubles for 'gaussian', int32 for 'discrete'); see bhmm_synth_observations in
-    include/bhmm_amd.h.  states_dev: optional device address of K*T bytes for the hidden paths."""
+    include/bhmm_amd.h.  states_dev: optional device address of K*T bytes for the hidden paths.
+    first_traj: index of this call's first trajectory in a larger (sharded) set -- the slice is then
+    exactly what one call for the whole set would have drawn for these trajectories."""
     L = _lib.load()
     _lib.require_device()
     A = _lib.f64(A)
@@ -328,8 +330,8 @@ def synth_observations(kind, obs_dev, A, pi, par0, par1, K, T, seed, device=0, s
     p0 = _lib.f64(par0)
     p1 = _lib.f64(par1) if par1 is not None else None
     M = p0.shape[1] if kind == 'discrete' else 0
-    _lib.check(L.bhmm_synth_observations(
+    _lib.check(L.bhmm_synth_observations_at(
         ctypes.c_void_p(int(obs_dev)), ctypes.c_void_p(int(states_dev)) if states_dev else None,
         int(device), ctypes.c_void_p(stream) if stream else None, _KINDS[kind], _lib.dp(A),
         _lib.dp(_lib.f64(pi)), _lib.dp(p0), _lib.dp(p1), int(n), int(M), int(K), int(T),
-        ctypes.c_uint64(int(seed))))
+        ctypes.c_uint64(int(seed)), int(first_traj)))

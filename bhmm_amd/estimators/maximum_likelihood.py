@@ -296,6 +296,16 @@ class MaximumLikelihoodEstimator(object):
         else:
             om.estimate_from_statistics(res.symbol_counts)
 
+    def em_step(self):
+        """ONE whole EM iteration -- E-step over all trajectories (every rank's shard on its GPU,
+        statistics all-reduced), then the M-step -- as `fit` performs it (maximum_likelihood.py:383-399
+        without the convergence bookkeeping).  Returns the log-likelihood of the model the E-step
+        was evaluated with."""
+        res = self._estep()
+        self._update_model(res, maxiter=self._maxit_P)
+        self._last = res
+        return res.loglik
+
     def compute_viterbi_paths(self):
         """maximum_likelihood.py:332-352.  Paths of the local trajectories; with several
         ranks they are gathered so that every rank returns the full list."""

@@ -34,6 +34,24 @@ class HMM(object):
     def __repr__(self):
         return 'HMM(%r, %r, %r)' % (self._Pi, self._Tij, self.output_model)
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) -- what the Gibbs sampler stores per posterior sample
+        (bayesian_sampling.py:259) -- without the generic object walk (150 us per sample): arrays
+        are copied, hidden paths too, cached spectral data is dropped."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if isinstance(v, np.ndarray):
+                new.__dict__[k] = v.copy()
+            elif k == '_spectral':
+                new.__dict__[k] = None
+            elif k == 'hidden_state_trajectories' and v is not None:
+                new.__dict__[k] = [None if p is None else np.array(p) for p in v]
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     @property
     def lag(self):
         return self._lag

@@ -15,6 +15,14 @@ class OutputModel(object):
     def nstates(self):
         return self._nstates
 
+    def __deepcopy__(self, memo):
+        """Array attributes copied, the rest by reference semantics of copy.copy (scalars, flags)."""
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = v.copy() if isinstance(v, np.ndarray) else v
+        return new
+
     def set_implementation(self, impl):
         """outputmodel.py:69-86.  Only 'hip' exists here; other names warn and keep it."""
         if impl.lower() != 'hip':

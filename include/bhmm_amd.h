@@ -230,6 +230,14 @@ int bhmm_synth_observations(void *obs_dev, uint8_t *states_dev, int device, void
                             const double *A, const double *pi, const double *par0,
                             const double *par1, int N, int M, int K, int64_t T, uint64_t seed);
 
+/* The same for a SLICE of a larger set: this call's trajectory k is trajectory first_traj + k of
+ * the set (stream positions 2 * ((first_traj + k) * T + t)), so ranks that each draw their own shard
+ * hold exactly the trajectories one process would draw for the whole set. */
+int bhmm_synth_observations_at(void *obs_dev, uint8_t *states_dev, int device, void *stream, int kind,
+                               const double *A, const double *pi, const double *par0,
+                               const double *par1, int N, int M, int K, int64_t T, uint64_t seed,
+                               int64_t first_traj);
+
 /* Host-side M-step helper (no device work): the reversible maximum-likelihood transition matrix
  * of a strongly connected count matrix C[n*n] -- the estimator bhmm takes from msmtools
  * (bhmm/estimators/_tmatrix_disconnected.py:94-105, maximum_likelihood.py:306-320) -- by the
@@ -260,11 +268,16 @@ int bhmm_mle_reversible(double *P, int64_t *iterations, const double *C, int n, 
  *   par0_old / par1_old : current emission parameters (gaussian: means, sigmas; else may be NULL)
  *   outputs    : T_new[n*n], pi_new[n], par0_new (means[n] | B[n*M]), par1_new (sigmas[n] | unused)
  *   info       : optional int32[2]: reversible branch taken, fixed-point iterations
+ *   warm_state : optional, 1 + n doubles owned by the caller, zero-initialised and handed to every
+ *                call of one EM run: the reversible fixed point then starts from the previous
+ *                iteration's solution (same fixed point, same stopping rule, far fewer iterations;
+ *                only while all states form one closed connected set).  NULL: cold start.
  * Returns BHMM_ERR_SIGMA if a sigma falls below machine epsilon. */
 int bhmm_mstep(int kind, int n, int M, const double *stats, const double *T_old,
                const double *par0_old, const double *par1_old, int reversible, int stationary,
                const double *fixed_pi, int64_t maxiter, double maxerr, double mincount,
-               double *T_new, double *pi_new, double *par0_new, double *par1_new, int32_t *info);
+               double *T_new, double *pi_new, double *par0_new, double *par1_new, int32_t *info,
+               double *warm_state);
 
 /* The parameter draws of one Gibbs sweep (bayesian_sampling.py:333-373) from the packed path
  * statistics of bhmm_sample_paths_dev (layout: bhmm_ctx_path_stats_size), in the reference's order:

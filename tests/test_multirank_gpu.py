@@ -79,17 +79,39 @@ def test_rccl_collectives_one_rank(launcher):
 @pytest.mark.gpu
 def test_bench_starts_its_own_ranks(launcher):
     """`python bench.py --gpus 2` without a launcher environment starts two ranks itself and
-    reports n_gpus = 2 (here both ranks share the box's one GPU: --oversubscribe, gloo)."""
+    reports n_gpus = 2 (here both ranks share the box's one GPU: --oversubscribe, gloo).  Its
+    `secondary` carries the two configs BASELINE quotes on 8 GPUs -- configs[2] strong-scaled and
+    the configs[4] chain as whole sweeps -- and, the trajectories being drawn by global index, the
+    2-rank run sees the data of the 1-rank run: same configs[2] log-likelihood."""
     import json
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    r = launcher.run([[sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
-                       "--oversubscribe", "--steps", "3", "--warmup", "1", "--ntraj", "16",
-                       "--length", "20000", "--no-cpu"]], timeout=600, env=env)[0]
-    assert r["rc"] == 0, r["out"]
-    line = [ln for ln in r["out"].splitlines() if ln.startswith('{"metric"')]
-    assert len(line) == 1, r["out"]
-    out = json.loads(line[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
-    assert abs(out["value"] - 2 * 16 * 20000 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    small = ["--steps", "3", "--warmup", "1", "--ntraj", "16", "--length", "20000", "--no-cpu",
+             "--c3-ntraj", "8", "--c3-length", "50000", "--c3-steps", "2", "--chain-sweeps", "3",
+             "--em-iterations", "3"]
+    outs = []
+    for gpus in (1, 2):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + small
+        if gpus > 1:
+            cmd.append("--oversubscribe")
+        r = launcher.run([cmd], timeout=900, env=env)[0]
+        assert r["rc"] == 0, r["out"]
+        line = [ln for ln in r["out"].splitlines() if ln.startswith('{"metric"')]
+        assert len(line) == 1, r["out"]
+        outs.append(json.loads(line[0]))
+    one, two = outs
+    assert two["n_gpus"] == 2 and two["steps"] == 3 and two["scaling"] == "weak"
+    assert abs(two["value"] - 2 * 16 * 20000 * 3 / (two["ms_per_step"] * 3e-3)) < 1e-6 * two["value"]
+    c3 = [[e for e in o["secondary"] if e["config"].startswith("configs[2]")][0] for o in outs]
+    assert c3[0]["n_gpus"] == 1 and c3[1]["n_gpus"] == 2 and c3[1]["scaling"] == "strong"
+    assert abs(c3[1]["loglik"] - c3[0]["loglik"]) <= 1e-12 * abs(c3[0]["loglik"])
+    assert c3[1]["allreduce_plus_copy_ms"] > 0
+    for o in outs:
+        whole = [e for e in o["secondary"] if "WHOLE" in e["config"]]
+        assert len(whole) == 5 and all(e["n_gpus"] == o["n_gpus"] for e in whole)
+        assert all(e.get("ms_per_iteration", e.get("ms_per_sweep")) > 0 for e in whole)
+    # the EM sequence of the sharded run is the single-process sequence
+    em = [[e for e in o["secondary"] if "WHOLE EM" in e["config"]] for o in outs]
+    for a, b in zip(*em):
+        np.testing.assert_allclose(a["loglik_first_last"], b["loglik_first_last"], rtol=1e-12)
