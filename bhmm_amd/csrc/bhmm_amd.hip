@@ -774,6 +774,13 @@ int wide_forward(bhmm_ctx *c, const double *A, const double *pi, const double *p
 int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1, double *stats_dev, int flags);
 int wide_backward(bhmm_ctx *c, const double *A);
+// gen_api.hip (more than 64 states)
+int gen_alloc(bhmm_ctx *c);
+int gen_forward(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                const double *par1);
+int gen_backward(bhmm_ctx *c, const double *A);
+int gen_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0, const double *par1,
+              double *stats_dev, int flags);
 
 
 static int stats_size(const bhmm_ctx *c)
@@ -1098,8 +1105,8 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         return invalid("bad context / offsets / K");
     if (kind < 0 || kind > 2)
         return invalid("unknown emission kind");
-    if (nstates < 1 || nstates > 64)
-        return invalid("1..64 hidden states are supported");
+    if (nstates < 1 || nstates > 4096)
+        return invalid("1..4096 hidden states are supported");
     if (kind == BHMM_EMIT_DISCRETE && nsymbols < 1)
         return invalid("nsymbols must be >= 1 for discrete emissions");
     BHMM_HIP(hipSetDevice(c->device));
@@ -1108,7 +1115,8 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     c->last_stats = nullptr;
     c->kind = kind;
     c->n = nstates;
-    c->wide = nstates > 8;
+    c->gen = nstates > 64; // any-N family (gen_kernels.hpp); 9..64: the wide family
+    c->wide = nstates > 8 && !c->gen;
     c->N = pad_states(nstates);
     c->M = kind == BHMM_EMIT_DISCRETE ? nsymbols : 0;
     c->K = K;
@@ -1133,10 +1141,10 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     c->wide_careful = false;
     // discrete alphabets whose emission / count tables do not fit the LDS of the sweep kernels
     // (M above ~1200 at 8 states) keep them in global memory instead (estep_sweep.hpp, BtSrc)
-    c->bt_global = kind == BHMM_EMIT_DISCRETE && !c->wide &&
+    c->bt_global = kind == BHMM_EMIT_DISCRETE && !c->wide && !c->gen &&
                    smem_fwdbwd<8, EMIT_DISC>(c->M) > (size_t)150 * 1024;
     int rc;
-    if (c->wide) {
+    if (c->wide || c->gen) {
         // 9..64 states: trajectory-parallel kernels on trajectory-major data, no chunk plan
         const size_t esz_w = kind == BHMM_EMIT_GAUSSIAN ? sizeof(double)
                              : kind == BHMM_EMIT_DISCRETE ? sizeof(int32_t)
@@ -1152,7 +1160,7 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
                                 hipMemcpyHostToDevice, c->stream));
         c->G = c->Gp = 0;
         c->Lmax = 0;
-        if ((rc = wide_alloc(c)))
+        if ((rc = c->gen ? gen_alloc(c) : wide_alloc(c)))
             return rc;
         if ((rc = ensure_pinned(c, (size_t)stats_size(c) + c->K)))
             return rc;
@@ -1424,9 +1432,9 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         return invalid("discrete emissions need B");
     BHMM_HIP(hipSetDevice(c->device));
     int rc;
-    if (!c->wide && c->kind == BHMM_EMIT_DISCRETE && (rc = upload_Bt(c, par0)))
+    if (!c->wide && !c->gen && c->kind == BHMM_EMIT_DISCRETE && (rc = upload_Bt(c, par0)))
         return rc;
-    if (!c->wide && (flags & BHMM_FLAG_STORE_GAMMA)) {
+    if (!c->wide && !c->gen && (flags & BHMM_FLAG_STORE_GAMMA)) {
         if ((rc = c->d_gamma_ci.ensure((size_t)ci_records(c) * c->N * 64)))
             return rc;
     }
@@ -1437,7 +1445,9 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     c->last_stats = sd;
     c->prefetched = false;
     c->ev_lean = false;
-    if (c->wide)
+    if (c->gen)
+        rc = gen_estep(c, A, pi, par0, par1, sd, flags);
+    else if (c->wide)
         rc = wide_estep(c, A, pi, par0, par1, sd, flags);
     else
         rc = BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
@@ -1491,7 +1501,7 @@ int bhmm_get_gamma(bhmm_ctx *c, int k, double *gamma)
     const int64_t T = c->offsets[k + 1] - c->offsets[k];
     if (T == 0)
         return BHMM_OK;
-    if (c->wide) { // already trajectory-major
+    if (c->wide || c->gen) { // already trajectory-major
         BHMM_HIP(hipMemcpyAsync(gamma, c->d_gamma_ci.p + c->offsets[k] * c->n,
                                 (size_t)T * c->n * sizeof(double), hipMemcpyDeviceToHost,
                                 c->stream));
@@ -1564,8 +1574,9 @@ int bhmm_forward(double *alpha, double *logprob, const double *A, const double *
     if (rc)
         return rc;
     bhmm_ctx *c = t.c;
-    if (c->wide) {
-        if ((rc = wide_forward(c, A, pi, nullptr, nullptr)))
+    if (c->wide || c->gen) {
+        if ((rc = c->gen ? gen_forward(c, A, pi, nullptr, nullptr)
+                         : wide_forward(c, A, pi, nullptr, nullptr)))
             return rc;
         BHMM_HIP(hipMemcpyAsync(alpha, c->d_alpha_rm.p, (size_t)T * N * sizeof(double),
                                 hipMemcpyDeviceToHost, c->stream));
@@ -1594,8 +1605,8 @@ int bhmm_backward(double *beta, const double *A, const double *pobs, int N, int6
     if (rc)
         return rc;
     bhmm_ctx *c = t.c;
-    if (c->wide) {
-        if ((rc = wide_backward(c, A)))
+    if (c->wide || c->gen) {
+        if ((rc = c->gen ? gen_backward(c, A) : wide_backward(c, A)))
             return rc;
         BHMM_HIP(hipMemcpyAsync(beta, c->d_alpha_rm.p, (size_t)T * N * sizeof(double),
                                 hipMemcpyDeviceToHost, c->stream));

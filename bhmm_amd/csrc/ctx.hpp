@@ -123,6 +123,9 @@ struct bhmm_ctx {
     bhmm::DevBuf<int32_t> d_grp_c0, d_grp_c1, d_grp_traj0; // [nG], [nG], [K+1]
     bhmm::DevBuf<double> d_P, d_agrp, d_bgrp;              // group products / boundary vectors
     bool wide = false;               // nstates > 8: wide_kernels.hpp family
+    bool gen = false;                // nstates > 64: gen_kernels.hpp family (any N, trajectory-major,
+                                     // one workgroup per trajectory; `wide` is false then)
+    bhmm::DevBuf<double> d_gpobs, d_gW, d_gAt, d_gxipart, d_gpart, d_gsym;
     // wide family: segment tables.  [0] = one segment per trajectory (exact serial recursion),
     // [1] = time-segmented plan with verified warm-up boundaries (optional)
     // plans: 0 = one segment per trajectory, 1 = time segments (both passes), 2 = the forward pass's

@@ -1,0 +1,441 @@
+// gen_api.hip -- host side of the any-N family (gen_kernels.hpp): contexts with more than 64 hidden
+// states.  bhmm/hidden/impl_c/_hidden.c:16-378 has no limit on N; neither has the C ABI.  Everything
+// is trajectory-major and materialised like the reference does (pobs, alpha, beta / W rows); one
+// workgroup per trajectory, no time decomposition.  Compiled with -ffp-contract=off.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "host_common.hpp"
+#include "gen_kernels.hpp"
+
+namespace bhmm {
+int invalid_arg(const std::string &msg);
+int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, const double *par0,
+                   const double *par1, WideModel &m);
+
+namespace {
+
+size_t gen_smem(int n, int vectors, int extra) { return ((size_t)vectors * n + extra) * sizeof(double); }
+
+template <typename F>
+int gen_set_smem(F *fn, size_t sm)
+{
+    if (sm > 64 * 1024)
+        BHMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    return BHMM_OK;
+}
+
+// emission rows of all steps (the reference materialises them too, maximum_likelihood.py:249-252)
+int gen_pobs(bhmm_ctx *c, const WideModel &m, const double **pobs)
+{
+    if (c->kind == EMIT_EXPL) {
+        *pobs = reinterpret_cast<const double *>(c->d_obs_rm.p);
+        return BHMM_OK;
+    }
+    int rc = c->d_gpobs.ensure((size_t)c->total * c->n);
+    if (rc)
+        return rc;
+    const dim3 pg((unsigned)((c->total + 255) / 256)), pb(256);
+    if (c->kind == EMIT_GAUSS)
+        hipLaunchKernelGGL((k_pobs_all<EMIT_GAUSS>), pg, pb, 0, c->stream, m, (const void *)c->d_obs_rm.p,
+                           c->total, c->d_gpobs.p);
+    else
+        hipLaunchKernelGGL((k_pobs_all<EMIT_DISC>), pg, pb, 0, c->stream, m, (const void *)c->d_obs_rm.p,
+                           c->total, c->d_gpobs.p);
+    BHMM_HIP(hipGetLastError());
+    *pobs = c->d_gpobs.p;
+    return BHMM_OK;
+}
+
+int gen_transposed(bhmm_ctx *c, const WideModel &m)
+{
+    const int n = c->n;
+    int rc = c->d_gAt.ensure((size_t)n * n);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k_gen_transpose, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0,
+                       c->stream, m.A, n, c->d_gAt.p);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+int gen_launch_forward(bhmm_ctx *c, const WideModel &m, const double *pobs)
+{
+    const size_t sm = gen_smem(c->n, 2, 2);
+    int rc = gen_set_smem(k_gen_forward, sm);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k_gen_forward, dim3(c->K), dim3(GEN_TPB), sm, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, c->K, pobs, c->d_alpha_rm.p, c->d_logLk.p);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+// xi GEMM + reduction geometry
+int gen_nsplit(const bhmm_ctx *c)
+{
+    const int tiles = (c->n + 31) / 32;
+    const int64_t want = 4096 / ((int64_t)tiles * tiles) + 1;
+    return (int)std::max<int64_t>(1, std::min<int64_t>({want, (c->total + 63) / 64, (int64_t)256}));
+}
+
+} // namespace
+
+int gen_alloc(bhmm_ctx *c)
+{
+    const int n = c->n;
+    const size_t rows = (size_t)c->total * n;
+    const int K = std::max(c->K, 1);
+    const size_t S = 1 + (size_t)n + (size_t)n * n + n + std::max<size_t>(2 * (size_t)n, (size_t)n * c->M);
+    int rc;
+    if ((rc = c->d_alpha_rm.ensure(rows)) || (rc = c->d_logLk.ensure(K)) ||
+        (rc = c->d_gamma0.ensure((size_t)K * n)) || (rc = c->d_stats.ensure(S)))
+        return rc;
+    return BHMM_OK;
+}
+
+int gen_forward(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                const double *par1)
+{
+    WideModel m;
+    int rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m);
+    if (rc)
+        return rc;
+    const double *pobs = nullptr;
+    if ((rc = gen_pobs(c, m, &pobs)))
+        return rc;
+    return gen_launch_forward(c, m, pobs);
+}
+
+// beta rows of _hidden.c:69-110 (explicit pobs) into d_alpha_rm
+int gen_backward(bhmm_ctx *c, const double *A)
+{
+    WideModel m;
+    std::vector<double> pi(c->n, 1.0 / c->n);
+    int rc = wide_model_pub(c, EMIT_EXPL, A, pi.data(), nullptr, nullptr, m);
+    if (rc || (rc = gen_transposed(c, m)))
+        return rc;
+    const double *pobs = reinterpret_cast<const double *>(c->d_obs_rm.p);
+    const size_t sm = gen_smem(c->n, 3, 1 + GEN_TPB);
+    if ((rc = gen_set_smem(k_gen_backward<EMIT_EXPL, false>, sm)))
+        return rc;
+    hipLaunchKernelGGL((k_gen_backward<EMIT_EXPL, false>), dim3(c->K), dim3(GEN_TPB), sm, c->stream, m,
+                       (const double *)c->d_gAt.p, (const int64_t *)c->d_offsets.p, c->K, pobs,
+                       (const void *)nullptr, (const double *)nullptr, c->d_alpha_rm.p,
+                       (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr,
+                       (double *)nullptr);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+int gen_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0, const double *par1,
+              double *stats_dev, int flags)
+{
+    WideModel m;
+    int rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m);
+    if (rc)
+        return rc;
+    const int n = c->n, K = c->K;
+    const bool sg = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
+    const int nsplit = gen_nsplit(c);
+    if ((rc = gen_transposed(c, m)) || (rc = c->d_gW.ensure((size_t)c->total * n)) ||
+        (rc = c->d_gpart.ensure((size_t)std::max(K, 1) * 3 * n)) ||
+        (rc = c->d_gxipart.ensure((size_t)nsplit * n * n)) ||
+        (c->kind == EMIT_DISC && (rc = c->d_gsym.ensure((size_t)n * c->M))) ||
+        (sg && (rc = c->d_gamma_ci.ensure((size_t)c->total * n))))
+        return rc;
+    BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
+    const double *pobs = nullptr;
+    if ((rc = gen_pobs(c, m, &pobs)))
+        return rc;
+    BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
+    if ((rc = gen_launch_forward(c, m, pobs)))
+        return rc;
+    BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
+    if (c->kind == EMIT_DISC)
+        BHMM_HIP(hipMemsetAsync(c->d_gsym.p, 0, (size_t)n * c->M * sizeof(double), c->stream));
+    const size_t sm = gen_smem(n, 3, 1 + GEN_TPB);
+    double *gam = sg ? c->d_gamma_ci.p : nullptr;
+#define BHMM_GEN_BWD(KINDV)                                                                          \
+    do {                                                                                             \
+        if ((rc = gen_set_smem(k_gen_backward<KINDV, true>, sm)))                                    \
+            return rc;                                                                               \
+        hipLaunchKernelGGL((k_gen_backward<KINDV, true>), dim3(K), dim3(GEN_TPB), sm, c->stream, m,  \
+                           (const double *)c->d_gAt.p, (const int64_t *)c->d_offsets.p, K, pobs,     \
+                           (const void *)c->d_obs_rm.p, (const double *)c->d_alpha_rm.p,             \
+                           (double *)nullptr, c->d_gW.p, gam, c->d_gpart.p, c->d_gamma0.p,           \
+                           c->d_gsym.p);                                                             \
+    } while (0)
+    if (c->kind == EMIT_GAUSS)
+        BHMM_GEN_BWD(EMIT_GAUSS);
+    else if (c->kind == EMIT_DISC)
+        BHMM_GEN_BWD(EMIT_DISC);
+    else
+        BHMM_GEN_BWD(EMIT_EXPL);
+#undef BHMM_GEN_BWD
+    BHMM_HIP(hipGetLastError());
+    const int tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(k_gen_xi_gemm, dim3(tiles * tiles, nsplit), dim3(256), 0, c->stream,
+                       (const double *)c->d_alpha_rm.p, (const double *)c->d_gW.p, c->total, n, nsplit,
+                       c->d_gxipart.p);
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
+    const dim3 fg(256), fb(256);
+#define BHMM_GEN_FIN(KINDV)                                                                          \
+    hipLaunchKernelGGL((k_gen_finalize<KINDV>), fg, fb, 0, c->stream, m, K, nsplit,                  \
+                       (const double *)c->d_gxipart.p, (const double *)c->d_gpart.p,                 \
+                       (const double *)c->d_gamma0.p, (const double *)c->d_logLk.p,                  \
+                       (const double *)c->d_gsym.p, stats_dev)
+    if (c->kind == EMIT_GAUSS)
+        BHMM_GEN_FIN(EMIT_GAUSS);
+    else if (c->kind == EMIT_DISC)
+        BHMM_GEN_FIN(EMIT_DISC);
+    else
+        BHMM_GEN_FIN(EMIT_EXPL);
+#undef BHMM_GEN_FIN
+    BHMM_HIP(hipGetLastError());
+    BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
+    c->ev_pending = true;
+    return BHMM_OK;
+}
+
+// out_fmt as wide_viterbi_run: 0 int32 host, 1 uint8 host, 2 uint8 device (N <= 256 for the bytes)
+int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                    const double *par1, void *paths_out, int out_fmt)
+{
+    const int n = c->n, K = c->K;
+    if (out_fmt != 0 && n > 256)
+        return invalid_arg("one byte per step holds at most 256 states: use bhmm_viterbi_batch (int32)");
+    WideModel m;
+    int rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m);
+    if (rc)
+        return rc;
+    c->viterbi_chunked = false;
+    const double *pobs = nullptr;
+    if ((rc = gen_pobs(c, m, &pobs)) ||
+        (rc = c->d_scratch.ensure((size_t)c->total * n * sizeof(uint16_t))) ||
+        (rc = c->d_scratch2.ensure(((size_t)c->total + K) * sizeof(int32_t))))
+        return rc;
+    uint16_t *ptr = reinterpret_cast<uint16_t *>(c->d_scratch.p);
+    int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
+    int32_t *path = last + K;
+    const size_t sm = gen_smem(n, 2, 2);
+    if ((rc = gen_set_smem(k_gen_viterbi_fwd, sm)))
+        return rc;
+    hipLaunchKernelGGL(k_gen_viterbi_fwd, dim3(K), dim3(GEN_TPB), sm, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, K, pobs, ptr, last);
+    BHMM_HIP(hipGetLastError());
+    const dim3 tg((K + 63) / 64), tb(64);
+    if (out_fmt == 0) {
+        hipLaunchKernelGGL(k_gen_viterbi_trace<int32_t>, tg, tb, 0, c->stream,
+                           (const int64_t *)c->d_offsets.p, K, n, (const uint16_t *)ptr,
+                           (const int32_t *)last, path);
+        BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipMemcpyAsync(paths_out, path, (size_t)c->total * sizeof(int32_t),
+                                hipMemcpyDeviceToHost, c->stream));
+    } else {
+        uint8_t *p8 = out_fmt == 2 ? static_cast<uint8_t *>(paths_out) : reinterpret_cast<uint8_t *>(path);
+        hipLaunchKernelGGL(k_gen_viterbi_trace<uint8_t>, tg, tb, 0, c->stream,
+                           (const int64_t *)c->d_offsets.p, K, n, (const uint16_t *)ptr,
+                           (const int32_t *)last, p8);
+        BHMM_HIP(hipGetLastError());
+        if (out_fmt == 1)
+            BHMM_HIP(hipMemcpyAsync(paths_out, p8, (size_t)c->total, hipMemcpyDeviceToHost, c->stream));
+    }
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    return BHMM_OK;
+}
+
+// alpha_dev: rows to sample from (the context's own forward pass when NULL)
+int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                   const double *par1, const double *u, uint64_t seed, int32_t *paths,
+                   int64_t *counts, int64_t *n0, double *emis, double *stats_dev)
+{
+    int rc = gen_forward(c, A, pi, par0, par1); // alpha rows in d_alpha_rm
+    if (rc)
+        return rc;
+    WideModel m;
+    if ((rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m)))
+        return rc;
+    const int n = c->n, K = c->K;
+    const size_t nstat = (size_t)n * n + n;
+    const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)n : (c->kind == EMIT_DISC ? (size_t)n * c->M : 0);
+    const size_t nsym = c->kind == EMIT_DISC ? (size_t)n * c->M : 0;
+    if ((rc = c->d_scratch2.ensure(((size_t)c->total + 4) * sizeof(int32_t))) ||
+        (rc = c->d_scratch.ensure((nstat + nsym + (size_t)std::max(K, 1) * 3 * n + nstat + esz +
+                                   (u ? (size_t)c->total : 0) + 8) * sizeof(double))))
+        return rc;
+    int32_t *path = reinterpret_cast<int32_t *>(c->d_scratch2.p);
+    int *status = reinterpret_cast<int *>(path + c->total);
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(c->d_scratch.p);
+    unsigned long long *symcnt = cnt + nstat;
+    double *epart = reinterpret_cast<double *>(symcnt + nsym);
+    double *packed = epart + (size_t)std::max(K, 1) * 3 * n;
+    double *udev = nullptr;
+    if (u) {
+        udev = packed + nstat + esz;
+        BHMM_HIP(hipMemcpyAsync(udev, u, (size_t)c->total * sizeof(double), hipMemcpyHostToDevice,
+                                c->stream));
+    }
+    BHMM_HIP(hipMemsetAsync(cnt, 0, (nstat + nsym) * sizeof(unsigned long long), c->stream));
+    BHMM_HIP(hipMemsetAsync(status, 0, sizeof(int), c->stream));
+    const size_t sm = gen_smem(n, 1, 4);
+    if ((rc = gen_set_smem(k_gen_sample, sm)))
+        return rc;
+    hipLaunchKernelGGL(k_gen_sample, dim3(K), dim3(GEN_TPB), sm, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, K, (const double *)c->d_alpha_rm.p,
+                       (const double *)udev, seed, (const int64_t *)c->d_soff.p, path, status);
+    BHMM_HIP(hipGetLastError());
+    int hstatus = 0;
+    BHMM_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    if (hstatus) {
+        set_error("random choice found no state: alpha/A not normalisable (_hidden.c:299-304)");
+        return hstatus;
+    }
+    const void *obs = c->d_obs_rm.p;
+    const dim3 pg(256), pb(256);
+#define BHMM_GEN_PS(KINDV)                                                                          \
+    do {                                                                                            \
+        hipLaunchKernelGGL((k_gen_path_stats<KINDV>), dim3(K), dim3(GEN_TPB), 0, c->stream, m,      \
+                           (const int64_t *)c->d_offsets.p, K, obs, (const int32_t *)path, cnt,     \
+                           epart, symcnt);                                                          \
+        hipLaunchKernelGGL((k_gen_pack_path_stats<KINDV>), pg, pb, 0, c->stream, m, K,              \
+                           (const unsigned long long *)cnt, (const double *)epart,                  \
+                           (const unsigned long long *)symcnt, stats_dev ? stats_dev : packed);     \
+    } while (0)
+    if (c->kind == EMIT_GAUSS)
+        BHMM_GEN_PS(EMIT_GAUSS);
+    else if (c->kind == EMIT_DISC)
+        BHMM_GEN_PS(EMIT_DISC);
+    else
+        BHMM_GEN_PS(EMIT_EXPL);
+#undef BHMM_GEN_PS
+    BHMM_HIP(hipGetLastError());
+    std::vector<double> hp;
+    if (!stats_dev && (counts || n0 || emis)) {
+        hp.resize(nstat + esz);
+        BHMM_HIP(hipMemcpyAsync(hp.data(), packed, hp.size() * sizeof(double), hipMemcpyDeviceToHost,
+                                c->stream));
+    }
+    if (paths)
+        BHMM_HIP(hipMemcpyAsync(paths, path, (size_t)c->total * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    if (!hp.empty()) {
+        if (counts)
+            for (size_t e = 0; e < (size_t)n * n; ++e)
+                counts[e] = (int64_t)llround(hp[e]);
+        if (n0)
+            for (int i = 0; i < n; ++i)
+                n0[i] = (int64_t)llround(hp[(size_t)n * n + i]);
+        if (emis && esz)
+            memcpy(emis, hp.data() + nstat, esz * sizeof(double));
+    }
+    return BHMM_OK;
+}
+
+// single-trajectory entry points with host arrays and more than 64 states ---------------------------
+int gen_transition_counts(double *C, const double *A, const double *pobs, const double *alpha,
+                          const double *beta, int N, int64_t T)
+{
+    if (N > GEN_MAXN)
+        return invalid_arg("more than 4096 hidden states are not supported");
+    double *d = nullptr;
+    const size_t rows = (size_t)T * N, nn = (size_t)N * N;
+    const int tiles = (N + 31) / 32;
+    const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>({4096 / ((int64_t)tiles * tiles) + 1,
+                                                                    (T + 63) / 64, (int64_t)256}));
+    const size_t need = 4 * rows + 2 * nn + (size_t)nsplit * nn + nn;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), need * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc failed");
+        return BHMM_ERR_NO_MEM;
+    }
+    struct Free {
+        double *p;
+        ~Free() { (void)hipFree(p); }
+    } guard{d};
+    double *dp = d, *da = dp + rows, *db = da + rows, *dW = db + rows, *dA = dW + rows, *dAt = dA + nn,
+           *dpart = dAt + nn, *dC = dpart + (size_t)nsplit * nn;
+    BHMM_HIP(hipMemcpy(dp, pobs, rows * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(da, alpha, rows * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(db, beta, rows * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(dA, A, nn * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_gen_transpose, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, 0,
+                       (const double *)dA, N, dAt);
+    const size_t sm = ((size_t)N + GEN_TPB) * sizeof(double);
+    hipLaunchKernelGGL(k_gen_w_rows, dim3((unsigned)T), dim3(GEN_TPB), sm, 0, (const double *)dAt, N, T,
+                       (const double *)dp, (const double *)da, (const double *)db, dW);
+    hipLaunchKernelGGL(k_gen_xi_gemm, dim3(tiles * tiles, nsplit), dim3(256), 0, 0, (const double *)da,
+                       (const double *)dW, T, N, nsplit, dpart);
+    BHMM_HIP(hipGetLastError());
+    std::vector<double> hpart((size_t)nsplit * nn);
+    BHMM_HIP(hipMemcpy(hpart.data(), dpart, hpart.size() * sizeof(double), hipMemcpyDeviceToHost));
+    (void)dC;
+    for (size_t ij = 0; ij < nn; ++ij) {
+        double v = 0.0;
+        for (int s = 0; s < nsplit; ++s)
+            v += hpart[(size_t)s * nn + ij];
+        C[ij] = v * A[ij];
+    }
+    return BHMM_OK;
+}
+
+int gen_sample_path(int32_t *path, const double *alpha, const double *A, const double *u, int N,
+                    int64_t T)
+{
+    if (N > GEN_MAXN)
+        return invalid_arg("more than 4096 hidden states are not supported");
+    double *d = nullptr;
+    const size_t rows = (size_t)T * N, nn = (size_t)N * N;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), (rows + nn + (size_t)T + 8) * sizeof(double) +
+                                                                ((size_t)T + 4) * sizeof(int32_t));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc failed");
+        return BHMM_ERR_NO_MEM;
+    }
+    struct Free {
+        double *p;
+        ~Free() { (void)hipFree(p); }
+    } guard{d};
+    double *da = d, *dA = da + rows, *du = dA + nn;
+    int64_t *doff = reinterpret_cast<int64_t *>(du + T);
+    int32_t *dpath = reinterpret_cast<int32_t *>(doff + 2);
+    int *status = reinterpret_cast<int *>(dpath + T);
+    const int64_t off[2] = {0, T};
+    BHMM_HIP(hipMemcpy(da, alpha, rows * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(dA, A, nn * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(du, u, (size_t)T * sizeof(double), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemcpy(doff, off, sizeof(off), hipMemcpyHostToDevice));
+    BHMM_HIP(hipMemset(status, 0, sizeof(int)));
+    WideModel m;
+    memset(&m, 0, sizeof(m));
+    m.A = dA;
+    m.n = N;
+    const size_t sm = ((size_t)N + 4) * sizeof(double);
+    int rc = gen_set_smem(k_gen_sample, sm);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k_gen_sample, dim3(1), dim3(GEN_TPB), sm, 0, m, (const int64_t *)doff, 1,
+                       (const double *)da, (const double *)du, (uint64_t)0, (const int64_t *)nullptr,
+                       dpath, status);
+    BHMM_HIP(hipGetLastError());
+    int hstatus = 0;
+    BHMM_HIP(hipMemcpy(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost));
+    if (hstatus) {
+        set_error("random choice found no state: alpha/A not normalisable (_hidden.c:299-304)");
+        return hstatus;
+    }
+    BHMM_HIP(hipMemcpy(path, dpath, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return BHMM_OK;
+}
+
+} // namespace bhmm

@@ -1,0 +1,501 @@
+// gen_kernels.hpp -- hidden kernels for ANY number of states (the family behind N > 64): the C ABI
+// must not refuse what bhmm/hidden/impl_c/_hidden.c:16-378 accepts.  Slow by design -- one workgroup
+// per trajectory, serial in t, the transition matrix read from global memory (L2) in every step --
+// but order-faithful: compiled with -ffp-contract=off, every product and every sum below is taken in
+// the order of the reference's scalar C, so forward / backward rows, Viterbi
+// paths and sampled paths (given the uniforms) are those of the reference to the last bit wherever
+// the reference's libm exp / log is not involved.  The xi counts, the one O(N^2) statistic, are a true
+// dense GEMM here -- C' = alpha^T W over all time steps, W_t = p_{t+1} o beta_{t+1} / S_t -- and run
+// on the matrix cores (v_mfma_f64_16x16x4), the case BASELINE.json's north_star reserves them for.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "path_kernels.hpp"
+
+namespace bhmm {
+
+constexpr int GEN_TPB = 256;   // threads per workgroup; thread q owns states q, q + 256, ...
+constexpr int GEN_MAXPT = 16;  // states per thread: up to 4096 states
+constexpr int GEN_MAXN = GEN_TPB * GEN_MAXPT;
+
+// sum of x[0 .. n) in ascending index order (the reference's loops), the same value in every thread
+__device__ __forceinline__ double gen_ordered_sum(const double *x, int n, double *slot)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i)
+            s += x[i];
+        *slot = s;
+    }
+    __syncthreads();
+    return *slot;
+}
+
+// _hidden.c:16-66.  alpha rows (total, n) row-major, logL per trajectory.
+__global__ __launch_bounds__(GEN_TPB) void k_gen_forward(const WideModel m, const int64_t *off, int K,
+                                                          const double *pobs, double *alpha,
+                                                          double *logL)
+{
+    extern __shared__ double gsm[];
+    const int n = m.n, tid = threadIdx.x;
+    double *xa = gsm, *ya = gsm + n, *slot = gsm + 2 * n;
+    const int k = blockIdx.x;
+    const int64_t t0 = off[k], T = off[k + 1] - t0;
+    double ll = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+        const double *p = pobs + (t0 + t) * n;
+        for (int j = tid; j < n; j += GEN_TPB) {
+            double a;
+            if (t == 0) {
+                a = m.pi[j] * p[j];
+            } else {
+                double s = 0.0;
+                for (int i = 0; i < n; ++i)
+                    s += xa[i] * m.A[(int64_t)i * n + j];
+                a = s * p[j];
+            }
+            ya[j] = a;
+        }
+        const double c = gen_ordered_sum(ya, n, slot);
+        if (tid == 0)
+            ll += log(c);
+        double *out = alpha + (t0 + t) * n;
+        for (int j = tid; j < n; j += GEN_TPB) {
+            double a = ya[j];
+            if (c != 0)
+                a /= c;
+            out[j] = a;
+            xa[j] = a;
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+        logL[k] = ll;
+}
+
+// _hidden.c:69-110 and, with STATS, everything else the E-step takes from the backward pass:
+//   gamma_t = alpha_t o beta_t / sum (hidden/api.py:176-186)  -> sum_t gamma, gamma_0, emission
+//   statistics (gaussian: moments about the old means; discrete: weighted symbol counts), optional
+//   gamma rows;  W_t = p_{t+1} o beta_{t+1} / S_t with S_t = sum_i alpha_t[i] (A (p o beta))[i], the
+//   xi normaliser of _hidden.c:168-179, for the GEMM C' = alpha^T W.
+// At = A transposed (coalesced reads of a row of A by the thread that owns it).
+template <int KIND, bool STATS>
+__global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
+    const WideModel m, const double *At, const int64_t *off, int K, const double *pobs,
+    const void *obs_rm, const double *alpha, double *beta_out, double *W, double *gamma_out,
+    double *part /* [K][3][n] */, double *g0 /* [K][n] */, double *symtab /* [n][M] */)
+{
+    extern __shared__ double gsm[];
+    const int n = m.n, tid = threadIdx.x;
+    double *nb = gsm, *np = gsm + n, *cur = gsm + 2 * n, *slot = gsm + 3 * n;
+    const int k = blockIdx.x;
+    const int64_t t0 = off[k], T = off[k + 1] - t0;
+    double sc[GEN_MAXPT], sd[GEN_MAXPT], sdd[GEN_MAXPT];
+#pragma unroll
+    for (int q = 0; q < GEN_MAXPT; ++q)
+        sc[q] = sd[q] = sdd[q] = 0.0;
+    for (int64_t t = T - 1; t >= 0; --t) {
+        double Snorm = 1.0;
+        if (t == T - 1) {
+            for (int i = tid; i < n; i += GEN_TPB)
+                cur[i] = 1.0;
+        } else {
+            for (int i = tid; i < n; i += GEN_TPB) {
+                double s = 0.0;
+                for (int j = 0; j < n; ++j)
+                    s += At[(int64_t)j * n + i] * np[j] * nb[j];
+                cur[i] = s;
+            }
+        }
+        const double c = gen_ordered_sum(cur, n, slot);
+        if constexpr (STATS) {
+            if (t < T - 1) {
+                // S_t = sum_i alpha_t[i] cur[i] (cur still unnormalised), then W_t from the row t+1
+                const double *a = alpha + (t0 + t) * n;
+                double loc = 0.0;
+                for (int i = tid; i < n; i += GEN_TPB)
+                    loc += a[i] * cur[i];
+                // tree sum over the workgroup through LDS (slot area: GEN_TPB doubles behind slot)
+                double *red = slot + 1;
+                red[tid] = loc;
+                __syncthreads();
+                for (int w = GEN_TPB / 2; w > 0; w >>= 1) {
+                    if (tid < w)
+                        red[tid] += red[tid + w];
+                    __syncthreads();
+                }
+                Snorm = red[0];
+                __syncthreads();
+                double *wr = W + (t0 + t) * n;
+                for (int j = tid; j < n; j += GEN_TPB)
+                    wr[j] = np[j] * nb[j] / Snorm;
+            } else {
+                double *wr = W + (t0 + t) * n;
+                for (int j = tid; j < n; j += GEN_TPB)
+                    wr[j] = 0.0; // the last step of a trajectory has no transition
+            }
+        }
+        // normalise (reference: divide by the row sum unless it is zero), publish as "next" row
+        const double *p = pobs + (t0 + t) * n;
+        double gl = 0.0;
+        for (int i = tid; i < n; i += GEN_TPB) {
+            double b = cur[i];
+            if (c != 0)
+                b /= c;
+            nb[i] = b;
+            np[i] = p[i];
+            if (beta_out)
+                beta_out[(t0 + t) * n + i] = b;
+            if constexpr (STATS)
+                gl += alpha[(t0 + t) * n + i] * b;
+        }
+        if constexpr (STATS) {
+            double *red = slot + 1;
+            __syncthreads();
+            red[tid] = gl;
+            __syncthreads();
+            for (int w = GEN_TPB / 2; w > 0; w >>= 1) {
+                if (tid < w)
+                    red[tid] += red[tid + w];
+                __syncthreads();
+            }
+            const double gs = red[0];
+            __syncthreads();
+            [[maybe_unused]] double o = 0.0;
+            [[maybe_unused]] int sym = 0;
+            if constexpr (KIND == EMIT_GAUSS)
+                o = static_cast<const double *>(obs_rm)[t0 + t];
+            if constexpr (KIND == EMIT_DISC)
+                sym = static_cast<const int32_t *>(obs_rm)[t0 + t];
+            int q = 0;
+            for (int i = tid; i < n; i += GEN_TPB, ++q) {
+                const double g = alpha[(t0 + t) * n + i] * nb[i] / gs;
+                sc[q] += g;
+                if constexpr (KIND == EMIT_GAUSS) {
+                    const double d = o - m.mu[i];
+                    sd[q] += g * d;
+                    sdd[q] += g * (d * d);
+                }
+                if constexpr (KIND == EMIT_DISC)
+                    atomicAdd(&symtab[(int64_t)i * m.M + sym], g);
+                if (gamma_out)
+                    gamma_out[(t0 + t) * n + i] = g;
+                if (t == 0)
+                    g0[(int64_t)k * n + i] = g;
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (STATS) {
+        int q = 0;
+        for (int i = tid; i < n; i += GEN_TPB, ++q) {
+            part[((int64_t)k * 3 + 0) * n + i] = sc[q];
+            part[((int64_t)k * 3 + 1) * n + i] = sd[q];
+            part[((int64_t)k * 3 + 2) * n + i] = sdd[q];
+        }
+        if (T <= 0)
+            for (int i = tid; i < n; i += GEN_TPB)
+                g0[(int64_t)k * n + i] = 0.0;
+    }
+}
+
+// xi as a GEMM on the matrix cores:  part[split] (n x n) = sum over this split's steps of
+// alpha_t^T W_t.  One wavefront per 16 x 16 tile of the output, four per workgroup (a 32 x 32 tile),
+// v_mfma_f64_16x16x4: lane = 16 k + i holds A-operand element (i, k) and B-operand element (k, i);
+// result register r of lane l is element (row (l >> 4) + 4 r, column l & 15).
+typedef double gen_v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_gen_xi_gemm(const double *alpha, const double *W,
+                                                     int64_t total, int n, int nsplit, double *part)
+{
+    const int tiles = (n + 31) / 32;
+    const int ti = blockIdx.x / tiles, tj = blockIdx.x % tiles;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i0 = ti * 32 + (wave >> 1) * 16, j0 = tj * 32 + (wave & 1) * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t per = ((total + nsplit - 1) / nsplit + 3) / 4 * 4;
+    const int64_t tb = (int64_t)blockIdx.y * per, te = tb + per < total ? tb + per : total;
+    const bool ia = i0 + li < n, jb = j0 + li < n;
+    gen_v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t t = tb; t < te; t += 4) {
+        const int64_t tt = t + lk;
+        const double a = (ia && tt < te) ? alpha[tt * n + i0 + li] : 0.0;
+        const double b = (jb && tt < te) ? W[tt * n + j0 + li] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r, col = j0 + li;
+        if (row < n && col < n)
+            part[((int64_t)blockIdx.y * n + row) * n + col] = acc[r];
+    }
+}
+
+// Packed statistics vector of the E-step (include/bhmm_amd.h: bhmm_ctx_stats_size), fixed summation
+// order: [logL | gamma_0 sums (n) | C = A o sum_splits C' (n*n) | sum gamma (n) | emission block]
+template <int KIND>
+__global__ void k_gen_finalize(const WideModel m, int K, int nsplit, const double *xipart,
+                               const double *part, const double *g0, const double *logLk,
+                               const double *symtab, double *stats)
+{
+    const int n = m.n;
+    const int64_t nn = (int64_t)n * n;
+    const int64_t nout = 1 + n + nn + n + (KIND == EMIT_GAUSS ? 2 * n : (KIND == EMIT_DISC ? (int64_t)n * m.M : 0));
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nout;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (e == 0) {
+            for (int k = 0; k < K; ++k)
+                v += logLk[k];
+        } else if (e < 1 + n) {
+            for (int k = 0; k < K; ++k)
+                v += g0[(int64_t)k * n + (e - 1)];
+        } else if (e < 1 + n + nn) {
+            const int64_t ij = e - 1 - n;
+            for (int s = 0; s < nsplit; ++s)
+                v += xipart[(int64_t)s * nn + ij];
+            v *= m.A[ij];
+        } else if (e < 1 + 2 * n + nn) {
+            const int64_t i = e - 1 - n - nn;
+            for (int k = 0; k < K; ++k)
+                v += part[((int64_t)k * 3 + 0) * n + i];
+        } else if (KIND == EMIT_GAUSS) {
+            const int64_t r = e - 1 - 2 * n - nn;
+            const int which = (int)(r / n) + 1;
+            const int64_t i = r % n;
+            for (int k = 0; k < K; ++k)
+                v += part[((int64_t)k * 3 + which) * n + i];
+        } else {
+            v = symtab[e - 1 - 2 * n - nn];
+        }
+        stats[e] = v;
+    }
+}
+
+// W rows from GIVEN alpha / beta / pobs (single-trajectory bhmm_transition_counts, _hidden.c:148-183):
+// one workgroup per step t < T - 1.
+__global__ __launch_bounds__(GEN_TPB) void k_gen_w_rows(const double *At, int n, int64_t T,
+                                                        const double *pobs, const double *alpha,
+                                                        const double *beta, double *W)
+{
+    extern __shared__ double gsm[];
+    double *pb = gsm, *red = gsm + n;
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (t >= T - 1) {
+        for (int j = tid; j < n; j += GEN_TPB)
+            W[t * n + j] = 0.0;
+        return;
+    }
+    for (int j = tid; j < n; j += GEN_TPB)
+        pb[j] = pobs[(t + 1) * n + j] * beta[(t + 1) * n + j];
+    __syncthreads();
+    double loc = 0.0;
+    for (int i = tid; i < n; i += GEN_TPB) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j)
+            s += At[(int64_t)j * n + i] * pb[j];
+        loc += alpha[t * n + i] * s;
+    }
+    red[tid] = loc;
+    __syncthreads();
+    for (int w = GEN_TPB / 2; w > 0; w >>= 1) {
+        if (tid < w)
+            red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    const double S = red[0];
+    for (int j = tid; j < n; j += GEN_TPB)
+        W[t * n + j] = pb[j] / S;
+}
+
+// _hidden.c:203-281, forward part: back-pointers (one uint16 per (t, j)) and the final state
+__global__ __launch_bounds__(GEN_TPB) void k_gen_viterbi_fwd(const WideModel m, const int64_t *off,
+                                                              int K, const double *pobs,
+                                                              uint16_t *ptr, int32_t *last_state)
+{
+    extern __shared__ double gsm[];
+    const int n = m.n, tid = threadIdx.x;
+    double *v = gsm, *vn = gsm + n, *slot = gsm + 2 * n;
+    const int k = blockIdx.x;
+    const int64_t t0 = off[k], T = off[k + 1] - t0;
+    if (T <= 0)
+        return;
+    for (int64_t t = 0; t < T; ++t) {
+        const double *p = pobs + (t0 + t) * n;
+        for (int j = tid; j < n; j += GEN_TPB) {
+            if (t == 0) {
+                vn[j] = p[j] * m.pi[j];
+            } else {
+                int best = 0;
+                double hm = v[0] * m.A[j];
+                for (int i = 1; i < n; ++i) {
+                    const double h = v[i] * m.A[(int64_t)i * n + j];
+                    if (h > hm) {
+                        hm = h;
+                        best = i;
+                    }
+                }
+                ptr[(t0 + t) * n + j] = (uint16_t)best;
+                vn[j] = p[j] * v[best] * m.A[(int64_t)best * n + j];
+            }
+        }
+        const double S = gen_ordered_sum(vn, n, slot);
+        for (int j = tid; j < n; j += GEN_TPB)
+            v[j] = vn[j] / S;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int a = 0;
+        double mx = v[0];
+        for (int i = 1; i < n; ++i)
+            if (v[i] > mx) {
+                mx = v[i];
+                a = i;
+            }
+        last_state[k] = a;
+    }
+}
+
+// back-trace (_hidden.c:269-272): one thread per trajectory chases the pointers
+template <typename PT>
+__global__ void k_gen_viterbi_trace(const int64_t *off, int K, int n, const uint16_t *ptr,
+                                    const int32_t *last_state, PT *path)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K)
+        return;
+    const int64_t t0 = off[k], T = off[k + 1] - t0;
+    if (T <= 0)
+        return;
+    int s = last_state[k];
+    path[t0 + T - 1] = (PT)s;
+    for (int64_t t = T - 2; t >= 0; --t) {
+        s = ptr[(t0 + t + 1) * n + s];
+        path[t0 + t] = (PT)s;
+    }
+}
+
+// _hidden.c:330-378 (+ _normalize :307-319, _random_choice :283-305): backward sampling from alpha
+__global__ __launch_bounds__(GEN_TPB) void k_gen_sample(const WideModel m, const int64_t *off, int K,
+                                                        const double *alpha, const double *u,
+                                                        uint64_t seed, const int64_t *soff,
+                                                        int32_t *path, int *status)
+{
+    extern __shared__ double gsm[];
+    const int n = m.n, tid = threadIdx.x;
+    double *ps = gsm, *slot = gsm + n;
+    int *pick = reinterpret_cast<int *>(gsm + n + 1);
+    const int k = blockIdx.x;
+    const int64_t t0 = off[k], T = off[k + 1] - t0;
+    const int64_t s0 = soff ? soff[k] : t0;
+    int nxt = 0;
+    for (int64_t t = T - 1; t >= 0; --t) {
+        const double *a = alpha + (t0 + t) * n;
+        for (int i = tid; i < n; i += GEN_TPB)
+            ps[i] = (t == T - 1) ? a[i] : a[i] * m.A[(int64_t)i * n + nxt];
+        const double S = gen_ordered_sum(ps, n, slot);
+        if (tid == 0) {
+            const double r = u ? u[t0 + t] : uniform01(seed, (uint64_t)(s0 + t));
+            double acc = 0.0;
+            int pk = -1;
+            for (int i = 0; i < n; ++i) {
+                acc += ps[i] / S;
+                if (acc >= r) {
+                    pk = i;
+                    break;
+                }
+            }
+            *pick = pk;
+        }
+        __syncthreads();
+        nxt = *pick;
+        if (nxt < 0) {
+            if (tid == 0)
+                atomicExch(status, BHMM_ERR_CHOICE);
+            return;
+        }
+        if (tid == 0)
+            path[t0 + t] = nxt;
+        __syncthreads();
+    }
+}
+
+// hidden-path statistics (generic_hmm.py:297-334,398-431): transition / start counts by integer
+// atomics (exact, order-free); per-state emission statistics without atomics -- thread q walks the
+// trajectory once per state it owns (O(n T) per trajectory, small against the O(n^2 T) forward pass)
+// and leaves per-trajectory partials that are added in trajectory order.
+template <int KIND>
+__global__ __launch_bounds__(GEN_TPB) void k_gen_path_stats(const WideModel m, const int64_t *off,
+                                                            int K, const void *obs_rm,
+                                                            const int32_t *path,
+                                                            unsigned long long *cnt /* n*n + n */,
+                                                            double *epart /* gauss [K][3][n] */,
+                                                            unsigned long long *symcnt /* [n][M] */)
+{
+    const int n = m.n, tid = threadIdx.x;
+    const int k = blockIdx.x;
+    const int64_t t0 = off[k], T = off[k + 1] - t0;
+    if (T > 0 && tid == 0)
+        atomicAdd(&cnt[(int64_t)n * n + path[t0]], 1ull);
+    for (int64_t t = tid; t + 1 < T; t += GEN_TPB)
+        atomicAdd(&cnt[(int64_t)path[t0 + t] * n + path[t0 + t + 1]], 1ull);
+    if constexpr (KIND == EMIT_DISC) {
+        const int32_t *sym = static_cast<const int32_t *>(obs_rm);
+        for (int64_t t = tid; t < T; t += GEN_TPB)
+            atomicAdd(&symcnt[(int64_t)path[t0 + t] * m.M + sym[t0 + t]], 1ull);
+    }
+    if constexpr (KIND == EMIT_GAUSS) {
+        const double *o = static_cast<const double *>(obs_rm);
+        for (int i = tid; i < n; i += GEN_TPB) {
+            double c = 0.0, s = 0.0, ss = 0.0;
+            const double mu = m.mu[i];
+            for (int64_t t = 0; t < T; ++t)
+                if (path[t0 + t] == i) {
+                    const double d = o[t0 + t] - mu;
+                    c += 1.0;
+                    s += d;
+                    ss += d * d;
+                }
+            epart[((int64_t)k * 3 + 0) * n + i] = c;
+            epart[((int64_t)k * 3 + 1) * n + i] = s;
+            epart[((int64_t)k * 3 + 2) * n + i] = ss;
+        }
+    }
+}
+
+// [counts n*n | n0 n | emission block] as fp64 (bhmm_sample_paths_dev) or raw tables for the host
+template <int KIND>
+__global__ void k_gen_pack_path_stats(const WideModel m, int K, const unsigned long long *cnt,
+                                      const double *epart, const unsigned long long *symcnt,
+                                      double *out)
+{
+    const int n = m.n;
+    const int64_t nn = (int64_t)n * n + n;
+    const int64_t esz = KIND == EMIT_GAUSS ? 3 * (int64_t)n : (KIND == EMIT_DISC ? (int64_t)n * m.M : 0);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nn + esz;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        double v;
+        if (e < nn) {
+            v = (double)cnt[e];
+        } else if (KIND == EMIT_GAUSS) {
+            const int64_t r = e - nn;
+            v = 0.0;
+            for (int k = 0; k < K; ++k)
+                v += epart[((int64_t)k * 3 + r / n) * n + r % n];
+        } else {
+            v = (double)symcnt[e - nn];
+        }
+        out[e] = v;
+    }
+}
+
+__global__ void k_gen_transpose(const double *A, int n, double *At)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int64_t)n * n)
+        At[(e % n) * n + e / n] = A[e];
+}
+
+} // namespace bhmm

@@ -24,6 +24,16 @@ int wide_transition_counts(double *C, const double *A, const double *pobs, const
 int forward_ci(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1);
 int forward_ci_verdict(bhmm_ctx *c, bool *ok);
+// gen_api.hip (more than 64 states)
+int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                    const double *par1, void *paths_out, int out_fmt);
+int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                   const double *par1, const double *u, uint64_t seed, int32_t *paths,
+                   int64_t *counts, int64_t *n0, double *emis, double *stats_dev);
+int gen_transition_counts(double *C, const double *A, const double *pobs, const double *alpha,
+                          const double *beta, int N, int64_t T);
+int gen_sample_path(int32_t *path, const double *alpha, const double *A, const double *u, int N,
+                    int64_t T);
 int unpack_ws_rows(bhmm_ctx *c, double *dst_dev);
 Chunks chunks_pub(const bhmm_ctx *c);
 
@@ -607,7 +617,9 @@ int bhmm_viterbi_batch(bhmm_ctx *c, const double *A, const double *pi, const dou
     if (c->kind == BHMM_EMIT_DISCRETE && !par0)
         return invalid_arg("discrete emissions need B");
     BHMM_HIP(hipSetDevice(c->device));
-    // all state counts use the LDS-exchange kernels (k_wide_viterbi_*)
+    if (c->gen)
+        return gen_viterbi_run(c, A, pi, par0, par1, paths, 0);
+    // all state counts up to 64 use the LDS-exchange kernels (k_wide_viterbi_*)
     return wide_viterbi_run(c, A, pi, par0, par1, paths, 0);
 }
 
@@ -623,6 +635,8 @@ int bhmm_viterbi_batch_u8(bhmm_ctx *c, const double *A, const double *pi, const 
     if (c->kind == BHMM_EMIT_DISCRETE && !par0)
         return invalid_arg("discrete emissions need B");
     BHMM_HIP(hipSetDevice(c->device));
+    if (c->gen)
+        return gen_viterbi_run(c, A, pi, par0, par1, paths, paths_on_device ? 2 : 1);
     return wide_viterbi_run(c, A, pi, par0, par1, paths, paths_on_device ? 2 : 1);
 }
 
@@ -635,6 +649,8 @@ int bhmm_sample_paths(bhmm_ctx *c, const double *A, const double *pi, const doub
     if (!A || !pi)
         return invalid_arg("NULL argument");
     BHMM_HIP(hipSetDevice(c->device));
+    if (c->gen)
+        return gen_sample_run(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, nullptr);
     if (c->wide)
         return wide_sample_run(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, nullptr);
     switch (c->N) {
@@ -680,6 +696,9 @@ int bhmm_sample_paths_dev(bhmm_ctx *c, const double *A, const double *pi, const 
     if (!A || !pi || !stats_dev)
         return invalid_arg("NULL argument");
     BHMM_HIP(hipSetDevice(c->device));
+    if (c->gen)
+        return gen_sample_run(c, A, pi, par0, par1, u, seed, paths, nullptr, nullptr, nullptr,
+                              stats_dev);
     if (c->wide)
         return wide_sample_run(c, A, pi, par0, par1, u, seed, paths, nullptr, nullptr, nullptr,
                                stats_dev);
@@ -715,7 +734,7 @@ int bhmm_sample_path(int32_t *path, const double *alpha, const double *A, const 
     if (!path || !alpha || !A || !u || N < 1 || T < 1)
         return invalid_arg("NULL argument or empty problem");
     if (N > 64)
-        return invalid_arg("1..64 hidden states are supported");
+        return gen_sample_path(path, alpha, A, u, N, T);
     Tmp tmp;
     double *d_alpha, *d_u;
     int64_t *d_off;
@@ -826,7 +845,7 @@ int bhmm_transition_counts(double *C, const double *A, const double *pobs, const
     if (!C || !A || !pobs || !alpha || !beta || N < 1 || T < 1)
         return invalid_arg("NULL argument or empty problem");
     if (N > 64)
-        return invalid_arg("1..64 hidden states are supported");
+        return gen_transition_counts(C, A, pobs, alpha, beta, N, T);
     if (N > 8)
         return wide_transition_counts(C, A, pobs, alpha, beta, N, T);
     Tmp tmp;

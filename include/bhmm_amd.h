@@ -101,7 +101,9 @@ int bhmm_ctx_destroy(bhmm_ctx *ctx);
 
 /* Upload K trajectories.  obs is the concatenation of all trajectories (element type per
  * `kind`), offsets[K+1] the element offsets of each trajectory in time steps.
- * nstates = N, nsymbols = M (discrete only).  chunk = time-chunk length used for the
+ * nstates = N (1 .. 4096: N <= 8 chunk-parallel kernels, 9 .. 64 the lane-per-state family, above
+ * that the any-N family of gen_kernels.hpp -- the reference's _hidden.c has no limit either),
+ * nsymbols = M (discrete only).  chunk = time-chunk length used for the
  * parallel-in-time decomposition (0 = choose automatically).  obs_on_device != 0 means
  * `obs` is already a device pointer on the context's device (offsets stay on the host). */
 int bhmm_ctx_set_observations(bhmm_ctx *ctx, int kind, const void *obs, const int64_t *offsets,
@@ -146,7 +148,8 @@ int bhmm_get_gamma(bhmm_ctx *ctx, int k, double *gamma);
 int bhmm_viterbi_batch(bhmm_ctx *ctx, const double *A, const double *pi, const double *par0,
                        const double *par1, int32_t *paths);
 
-/* Same paths as bhmm_viterbi_batch, one byte per step (N <= 64 states fit a byte; the int32 form
+/* Same paths as bhmm_viterbi_batch, one byte per step (for N <= 256 states -- more return
+ * BHMM_ERR_INVALID here and use the int32 form; the int32 form
  * above is the reference's return type, hidden.pyx:161-162, and costs four times the copy).
  * paths_on_device == 0: paths is a host buffer of sum_k T_k bytes -- pass pinned memory
  * (hipHostMalloc / torch pin_memory) for the full link rate, a pageable buffer is pinned for the
