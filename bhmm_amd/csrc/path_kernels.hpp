@@ -1085,6 +1085,31 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
     }
 }
 
+// exp_nonpos() with its Horner steps pinned to the three-address v_fma_f64 (horner_step,
+// wide_kernels.hpp): the same twelve fused multiply-adds, hence the same bits, without the ten
+// coefficient moves the two-address v_fmac_f64 form costs -- the Viterbi kernels are bound by the
+// length of their instruction stream.
+__device__ __forceinline__ double exp_nonpos_issue(double x)
+{
+    x = fmax(x, -750.0);
+    const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma(k, -0x1.62e42fefa39efp-1, x);
+    r = fma(k, -0x1.abc9e3b39803fp-56, r);
+    double q = 0x1.ad7e38e167506p-26;
+    q = horner_step(q, r, 0x1.28ae7908135d8p-22);
+    q = horner_step(q, r, 0x1.71df27c33abefp-19);
+    q = horner_step(q, r, 0x1.a01998fd42e01p-16);
+    q = horner_step(q, r, 0x1.a01a012882c92p-13);
+    q = horner_step(q, r, 0x1.6c16c184889e3p-10);
+    q = horner_step(q, r, 0x1.111111112836cp-7);
+    q = horner_step(q, r, 0x1.55555555506eap-5);
+    q = horner_step(q, r, 0x1.55555555554f7p-3);
+    q = horner_step(q, r, 0x1.000000000000ap-1);
+    q = horner_step(q, r, 1.0);
+    q = horner_step(q, r, 1.0);
+    return ldexp(q, (int)k);
+}
+
 // =========================================================================================
 // k_viterbi_chunks: the same order-faithful recursion, parallel over the time chunks of the
 // E-step plan, and still bit-identical to the serial run -- verified, not assumed:
@@ -1199,7 +1224,7 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
                 p = !real ? 0.0 : (sBd ? sBd[j * m.M + sym] : m.B[(int64_t)j * m.M + sym]);
             } else if constexpr (KIND == EMIT_GAUSS) {
                 const double d = (pring[qq] - mu_j) / sg_j; // _gaussian.c:18-20
-                p = real ? cn_j * exp_nonpos(-0.5 * d * d) : 0.0;
+                p = real ? cn_j * exp_nonpos_issue(-0.5 * d * d) : 0.0;
                 if ((__ballot(p != 0.0) & grp) == 0ull)
                     p = real ? 1.0 : 0.0; // outputmodel.py:126-130
             } else {
