@@ -1,5 +1,6 @@
 // wide_api.hip -- host side of the 9..64-state kernel family (wide_kernels.hpp).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -120,7 +121,26 @@ static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
     // A's rows in LDS for fewer than 64 lanes per segment; the 64-lane kernel keeps them in VGPRs
     const size_t sm = NP == 64 ? 0 : (size_t)(NP * wide_pitch(NP)) * sizeof(double);
     double *gam = store_gamma ? c->d_gamma_ci.p : (double *)nullptr;
-    if (lazy && NP == 64 && c->n == 64)
+    // control experiment: xi counts as a separate time-parallel GEMM
+    static const bool xi_gemm = getenv("BHMM_AMD_WIDE_XI_GEMM") != nullptr;
+    if (lazy && NP == 64 && c->n == 64 && xi_gemm) {
+        const int nsplit = 4096;
+        int rc;
+        if ((rc = c->d_gW.ensure((size_t)c->total * 64)) || (rc = c->d_gxipart.ensure((size_t)nsplit * 4096)))
+            return rc;
+        hipLaunchKernelGGL(k_wide_zero_last_rows, dim3(c->K), dim3(64), 0, c->stream,
+                           (const int64_t *)c->d_offsets.p, c->K, 64, c->d_gW.p);
+        hipLaunchKernelGGL((k_wide_bwd<NP, KIND, true, NP == 64, NP == 64>), dim3((sg.nseg + GP - 1) / GP),
+                           dim3(64), sm, c->stream, m, (const int64_t *)c->d_offsets.p, sg,
+                           (const void *)c->d_obs_rm.p, (const double *)c->d_alpha_rm.p, gam,
+                           c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p,
+                           c->d_wbentry.p, c->d_specres.p, c->d_gW.p);
+        hipLaunchKernelGGL(k_wide_xi_gemm64, dim3(nsplit), dim3(64), 0, c->stream,
+                           (const double *)c->d_alpha_rm.p, (const double *)c->d_gW.p, c->total, nsplit,
+                           c->d_gxipart.p);
+        hipLaunchKernelGGL(k_wide_xi_reduce, dim3(16), dim3(256), 0, c->stream,
+                           (const double *)c->d_gxipart.p, nsplit, c->d_partials.p);
+    } else if (lazy && NP == 64 && c->n == 64)
         hipLaunchKernelGGL((k_wide_bwd<NP, KIND, true, NP == 64>), dim3((sg.nseg + GP - 1) / GP),
                            dim3(64), sm, c->stream, m, (const int64_t *)c->d_offsets.p, sg,
                            (const void *)c->d_obs_rm.p, (const double *)c->d_alpha_rm.p, gam,

@@ -483,12 +483,15 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
 // statistics per segment: [n*n C' rows | n sum gamma | (gauss) n sum gamma d | n sum gamma d^2]
 // discrete symbol table: [nseg][n][M] (dstat)
 // LAZY: beta is refreshed to a power of two every fourth step instead of every step (see k_wide_fwd)
-template <int NP, int KIND, bool LAZY = false, bool FULL = false>
+// XIG (64 states, control experiment of round 3, BHMM_AMD_WIDE_XI_GEMM=1): no xi accumulators in this
+// kernel; it stores the rows W_{t-1} = p_t o beta_t / S_t instead and the counts are the
+// time-parallel GEMM C' = alpha^T W of k_wide_xi_gemm64.
+template <int NP, int KIND, bool LAZY = false, bool FULL = false, bool XIG = false>
 __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_t *off, const Segs sg,
                                                  const void *obs_rm, const double *alpha_rm,
                                                  double *gamma_rm, double *gamma0, double *part,
                                                  double *dstat, double *b_exit, double *b_entry,
-                                                 unsigned int *flags = nullptr)
+                                                 unsigned int *flags = nullptr, double *Wg = nullptr)
 {
     constexpr int GP = 64 / NP;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
             Arow[c] = (real && c < n) ? m.A[(int64_t)i * n + c] : 0.0;
     }
     auto xi_flush = [&]() {
-        if constexpr (NP == 64) {
+        if constexpr (NP == 64 && !XIG) {
             double ow[4] = {wq[0], wq[1], wq[2], wq[3]}, ox[4] = {xq[0], xq[1], xq[2], xq[3]};
             rows_transpose4(ow);
             rows_transpose4(ox);
@@ -726,7 +729,11 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                     const double rS = rS_keep;
                     gam = q * rS;
                     const double w = ap * rS;
-                    if constexpr (NP == 64) {
+                    if constexpr (NP == 64 && XIG) {
+                        if (real)
+                            Wg[(o0 + t - 1) * n + i] = xcur * rS;
+                        (void)w;
+                    } else if constexpr (NP == 64) {
                         wq[u & 3] = w;
                         xq[u & 3] = xcur;
                     } else {
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * I + (lane >> 4) + 4 * r, col = 16 * J + (lane & 15);
                     if (FULL || (row < n && col < n))
-                        mypart[(int64_t)row * n + col] = Cacc[I][J][r];
+                        mypart[(int64_t)row * n + col] = XIG ? 0.0 : Cacc[I][J][r];
                 }
     }
     if (real) {
@@ -785,6 +792,75 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
             mypart[n * n + 2 * n + i] = sdd;
         }
     }
+}
+
+// xi counts of 64 states as a time-parallel GEMM (control experiment, see k_wide_bwd<.., XIG>):
+// every wavefront owns a stretch of time steps and the full 64 x 64 tile -- 16 v_mfma_f64_16x16x4
+// per four steps on eight 512-byte loads, accumulators in 128 registers -- and leaves its partial
+// sum in xipart[split]; k_wide_xi_reduce adds them in split order into segment 0's block of `part`.
+static __global__ __launch_bounds__(64) void k_wide_xi_gemm64(const double *alpha, const double *W,
+                                                        int64_t total, int nsplit, double *xipart)
+{
+    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+    const int64_t per = ((total + nsplit - 1) / nsplit + 3) / 4 * 4;
+    const int64_t tb = (int64_t)blockIdx.x * per, te = tb + per < total ? tb + per : total;
+    wide_d4 acc[4][4];
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+            acc[I][J] = wide_d4{0.0, 0.0, 0.0, 0.0};
+    double a[4], b[4], an[4], bn[4];
+    auto load = [&](int64_t t, double (&x)[4], double (&y)[4]) {
+        const int64_t tt = t + lk;
+        const bool ok = tt < te;
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            x[I] = ok ? alpha[tt * 64 + 16 * I + li] : 0.0;
+            y[I] = ok ? W[tt * 64 + 16 * I + li] : 0.0;
+        }
+    };
+    load(tb, a, b);
+    for (int64_t t = tb; t < te; t += 4) {
+        load(t + 4, an, bn); // (beyond te: zeros)
+#pragma unroll
+        for (int I = 0; I < 4; ++I)
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+                acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            a[I] = an[I];
+            b[I] = bn[I];
+        }
+    }
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                xipart[((int64_t)blockIdx.x * 64 + 16 * I + lk + 4 * r) * 64 + 16 * J + li] = acc[I][J][r];
+}
+
+static __global__ void k_wide_xi_reduce(const double *xipart, int nsplit, double *part)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 64 * 64)
+        return;
+    double v = 0.0;
+    for (int s = 0; s < nsplit; ++s)
+        v += xipart[(int64_t)s * 4096 + e];
+    part[e] = v; // segment 0's C' block (the backward kernel wrote zeros there)
+}
+
+// rows W_{T-1} of every trajectory: no transition leaves the last step
+static __global__ void k_wide_zero_last_rows(const int64_t *off, int K, int n, double *Wg)
+{
+    const int k = blockIdx.x;
+    if (k < K && off[k + 1] > off[k])
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            Wg[(off[k + 1] - 1) * n + i] = 0.0;
 }
 
 // =========================================================================================
