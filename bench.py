@@ -388,14 +388,17 @@ def secondary_whole_iterations(rk, model, args):
         for _ in range(max(5, args.em_iterations)):      # (also brings the GPU out of its idle clocks)
             est.em_step()
         rk.fence()
-        lls = []
+        lls, sweep_ms, carried = [], [], []
+        eng = est._engine
         t0 = time.perf_counter()
         for _ in range(args.em_iterations):
             lls.append(est.em_step())
+            if est.local_trajectories and hasattr(eng, "kernel_ms"):
+                sweep_ms.append(eng.kernel_ms(2))
+                carried.append(int(eng.get_option("carry_W")))
         rk.fence()
         dt = rk.max_over_ranks(time.perf_counter() - t0) / args.em_iterations
         assert np.all(np.diff(lls) > -1e-6 * abs(lls[0])), "EM log-likelihood decreased"
-        eng = est._engine
         res.append({"config": "configs[1] shape, WHOLE EM iteration (E-step%s + native M-step, model "
                               "updated every iteration), %s transition matrix, %d x %d over %d GPU(s)"
                               % (" + all-reduce" if rk.distributed else "",
@@ -403,7 +406,17 @@ def secondary_whole_iterations(rk, model, args):
                     "n_gpus": rk.world, "ms_per_iteration": 1e3 * dt,
                     "timesteps_per_s": K * T / dt, "iterations": args.em_iterations,
                     "loglik_first_last": [lls[0], lls[-1]],
-                    "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail")}
+                    "sweep_kernel_ms_mean": float(np.mean(sweep_ms)) if sweep_ms else None,
+                    "warmup_steps_used": {"full": eng.get_option("spec_W"),
+                                          "carried_min_median_max": [int(np.min(carried)),
+                                                                     int(np.median(carried)),
+                                                                     int(np.max(carried))],
+                                          "note": "0 = full warm-up from the uniform vector; > 0 = "
+                                                  "warm-up of that many steps from the previous "
+                                                  "E-step's boundary vectors (verified like every "
+                                                  "warm-up)"} if carried else None,
+                    "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail",
+                                                            "carry_ok", "carry_fail")}
                     if hasattr(eng, "get_option") and est.local_trajectories else None})
         eng.close()
         del est
@@ -624,6 +637,14 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # a second, untimed-by-the-contract window right behind the requested steps: what an EM loop of
+    # hundreds of iterations sees once the GPU's power management has settled
+    steady = []
+    for _ in range(100):
+        t1 = time.perf_counter()
+        one_step()
+        steady.append(time.perf_counter() - t1)
+    steady_ms = 1e3 * float(np.median(steady[50:]))
     res = eng.unpack(host_stats.numpy().copy())
     assert np.isfinite(res.loglik)
     # sanity of the reduced statistics: every step of every rank carries unit gamma mass
@@ -656,6 +677,7 @@ def main():
             "metric": "timesteps/sec forward-backward (whole node), N=8 states",
             "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "steady_state_ms": steady_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[1]: 8-state Gaussian HMM, %d trajectories x %d "

@@ -153,7 +153,7 @@ struct Runner {
                                    c->spec_W, c->d_ws.p,
                                    store_gamma ? c->d_gamma_ci.p : (double *)nullptr, c->d_logLc.p,
                                    c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p, flag_words,
-                                   c->d_ea.p);
+                                   c->d_ea.p, Carry());
                 return BHMM_OK;
             };
             // the branch-free instantiation needs the verdict round trip of the speculative
@@ -175,7 +175,8 @@ struct Runner {
                     Model<N> m1 = m;
                     m1.dcopies = 0;
                     const size_t sm1 = KIND == EMIT_DISC ? smem_fwdbwd<N, KIND>(lds_symbols(c), 0) : sm;
-                    auto launch2 = [&](auto kern, int grid, const Model<N> &mm, size_t smem) -> int {
+                    auto launch2 = [&](auto kern, int grid, const Model<N> &mm, size_t smem,
+                                       const Carry &cy) -> int {
                         if (smem > 64 * 1024)
                             BHMM_HIP(hipFuncSetAttribute((const void *)kern,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -186,17 +187,44 @@ struct Runner {
                                            (const double *)c->d_Bt.p, c->d_aentry.p, c->d_bexit.p,
                                            c->d_aexit.p, c->d_bentry.p, c->spec_W, c->d_ws.p,
                                            (double *)nullptr, c->d_logLc.p, c->d_gamma0.p,
-                                           c->d_partials.p, c->d_dpartials.p, flag_words, c->d_ea.p);
+                                           c->d_partials.p, c->d_dpartials.p, flag_words, c->d_ea.p,
+                                           cy);
                         return BHMM_OK;
                     };
-                    if ((rc = launch2(k_estep_light<N, KIND, SPEC, false, false, PH_P1>, 2 * nblk, m1, sm1)))
+                    // boundary vectors carried between E-steps (decided by estep_kind): P1 starts its
+                    // warm-ups from them, P2 captures beta for the next E-step
+                    Carry c1, c2;
+                    if (c->carry_use > 0) {
+                        c1.a_in = c->d_carry_a.p;
+                        c1.b_in = c->d_carry_b.p;
+                        c1.da = c->d_carry_da.p;
+                        c1.db = c->d_carry_db.p;
+                    }
+                    if ((rc = launch2(k_estep_light<N, KIND, SPEC, false, false, PH_P1>, 2 * nblk, m1,
+                                      sm1, c1)))
                         return rc;
                     BHMM_HIP(hipGetLastError());
-                    rc = launch2(k_estep<N, KIND, SPEC, false, false, PH_P2>, nblk, m, sm);
+                    if (c->carry_cap > 0) {
+                        // (P1 has consumed the old vectors: the same buffers take the new ones)
+                        BHMM_HIP(hipMemsetAsync(c->d_carry_db.p, 0, (size_t)c->Gp * sizeof(int32_t),
+                                                c->stream));
+                        c2.b_out = c->d_carry_b.p;
+                        c2.db_out = c->d_carry_db.p;
+                        c2.cap = c->carry_cap;
+                    }
+                    rc = launch2(k_estep<N, KIND, SPEC, false, false, PH_P2>, nblk, m, sm, c2);
+                    if (rc == BHMM_OK && c->carry_cap > 0) {
+                        BHMM_HIP(hipGetLastError());
+                        hipLaunchKernelGGL((k_carry_alpha<N>), dim3((c->G + 255) / 256), dim3(256), 0,
+                                           c->stream, ch, c->G, (const double *)c->d_ws.p,
+                                           c->carry_Wout, c->d_carry_a.p, c->d_carry_da.p);
+                    }
                 } else {
+                    c->carry_cap = 0;
                     rc = launch(k_estep<N, KIND, SPEC, false, false>);
                 }
             } else {
+                c->carry_cap = 0; // (no capture outside the split launches)
                 rc = launch(k_estep<N, KIND, SPEC, true, true>);
             }
             if (rc)
@@ -385,13 +413,67 @@ struct Runner {
                 return rc;
         }
         if (c->spec_enabled) {
-            for (int attempt = 0; attempt < 2; ++attempt) {
+            // ---- boundary vectors carried from the previous E-step (estep_sweep.hpp: Carry) ----
+            // decades of forgetting per step, from the calibrated warm-up (1e-13 after W / 1.15 steps)
+            const double rdec = 13.0 * 1.15 / std::max(c->spec_W, 16);
+            bool eligible = c->carry_enabled && ESTEP_SPLIT && KIND != EMIT_EXPL && !c->careful &&
+                            !(flags & BHMM_FLAG_STORE_GAMMA) && c->G > c->K;
+            if (KIND == EMIT_GAUSS) // (the branch-free split launches only, see fwdbwd)
+                for (int i = 0; i < c->n; ++i)
+                    eligible = eligible && m.e2[i] < 1048576.0;
+            const double delta = c->carry_delta;
+            c->carry_use = 0;
+            if (eligible && c->carry_valid && delta > 0.0 && delta <= 0.05) {
+                // predicted boundary deviation of a warm-up of carry_Wc steps from vectors that are
+                // off by kappa * delta
+                const double pred = c->carry_kappa * delta * pow(10.0, -rdec * c->carry_Wc);
+                if (pred <= 0.3 * SPEC_TOL)
+                    c->carry_use = c->carry_Wc;
+            }
+            auto plan_capture = [&]() {
+                // capture for the NEXT E-step, sized for twice this step's model change
+                c->carry_cap = c->carry_Wout = 0;
+                if (!eligible || (c->d_carry_a.ensure((size_t)c->Gp * N)) ||
+                    (c->d_carry_b.ensure((size_t)c->Gp * N)) || (c->d_carry_da.ensure(c->Gp)) ||
+                    (c->d_carry_db.ensure(c->Gp)))
+                    return;
+                const double dn = delta > 0.0 ? 2.0 * delta : 1e-3;
+                const double need = (log10(c->carry_kappa * dn) - log10(0.1 * SPEC_TOL)) / rdec;
+                int Wc = ((int)ceil(std::max(need, 16.0)) + 7) / 8 * 8;
+                if (Wc > (int)(0.85 * c->spec_W) || Wc + 16 > c->L)
+                    return; // not worth it / chunks too short
+                c->carry_Wout = Wc;
+                c->carry_cap = Wc; // beta at local step Wc: Wc + 1 warm-up steps
+            };
+            for (int attempt = 0; attempt < 3; ++attempt) {
                 bool ok = false;
                 const int W_tried = c->spec_W;
+                const int carried = c->carry_use;
+                plan_capture();
                 if ((rc = estep_spec<KIND>(c, m, stats_dev, flags, &ok)))
                     return rc;
-                if (ok)
+                if (ok) {
+                    if (carried > 0) {
+                        // what the check measured bounds the sensitivity for the next prediction
+                        const double keff = (double)c->spec_last_dev /
+                                            (delta * pow(10.0, -rdec * carried));
+                        c->carry_kappa = std::min(std::max(std::max(0.5 * c->carry_kappa, 8.0 * keff), 1.0), 1e8);
+                        c->carry_ok++;
+                    }
+                    c->carry_last_W = carried;
+                    c->carry_valid = c->carry_cap > 0;
+                    c->carry_Wc = c->carry_Wout;
+                    c->carry_use = 0;
                     return BHMM_OK;
+                }
+                c->carry_valid = false;
+                if (carried > 0 && !c->careful_retry) {
+                    // shortened warm-ups did not verify: same call again with full ones
+                    c->carry_kappa = std::min(c->carry_kappa * 30.0, 1e8);
+                    c->carry_use = 0;
+                    continue;
+                }
+                c->carry_use = 0;
                 if (!c->careful_retry) {
                     // boundaries did not verify: exact pipeline now; for the next call measure
                     // the curve again (the model has moved), never below +25 %
@@ -548,6 +630,10 @@ struct Runner {
         if (*verified) {
             c->prefetched = results_on_host;
             c->spec_ok++;
+        } else if (c->carry_use > 0) {
+            // the shortened warm-ups from carried vectors did not verify: the caller repeats with
+            // full warm-ups; this says nothing about the warm-up length itself
+            c->carry_fail++;
         } else {
             // lengthen the warm-up for the next call; give up once it would cost more than the
             // prescan (slowly mixing model / uninformative data)
@@ -604,7 +690,7 @@ struct Runner {
                            (const int64_t *)c->d_offsets.p, (const double *)c->d_Bt.p, c->d_aentry.p,
                            c->d_bexit.p, c->d_aexit.p, c->d_bentry.p, c->spec_W, c->d_ws.p,
                            reinterpret_cast<double *>(c->d_ws32.p), c->d_logLc.p, c->d_gamma0.p,
-                           c->d_partials.p, c->d_dpartials.p, c->d_specres.p, c->d_ea.p);
+                           c->d_partials.p, c->d_dpartials.p, c->d_specres.p, c->d_ea.p, Carry());
         BHMM_HIP(hipGetLastError());
         c->rows32_valid = true;
         return BHMM_OK;
@@ -939,6 +1025,8 @@ int bhmm_ctx_create(bhmm_ctx **out, int device, void *stream)
             c->num_simd = 4 * cus;
         (void)hipGetLastError();
     }
+    if (const char *e = getenv("BHMM_AMD_CARRY"))
+        c->carry_enabled = atoi(e) != 0;
     if (const char *e = getenv("BHMM_AMD_SPEC"))
         c->spec_enabled = atoi(e) != 0;
     if (const char *e = getenv("BHMM_AMD_SPEC_W")) {
@@ -1093,6 +1181,7 @@ int bhmm::replan_coarse(bhmm_ctx *c)
     c->gamma_valid = false;
     if (c->gamma_wanted && (rc = c->d_gamma_ci.ensure((size_t)ci_records(c) * c->N * 64)))
         return rc;
+    c->carry_valid = false; // (vectors of the old plan's chunks)
     c->rows32_valid = false;
     return BHMM_OK;
 }
@@ -1133,6 +1222,10 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         return invalid("obs == NULL");
     c->gamma_valid = false;
     c->careful = c->careful_retry = false;
+    c->carry_valid = false;
+    c->carry_use = c->carry_cap = 0;
+    c->carry_kappa = 100.0;
+    c->prev_model.clear();
     c->spec_calibrated = c->spec_W_fixed;
     if (!c->spec_W_fixed)
         c->spec_W = 288;
@@ -1350,7 +1443,13 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
     const std::string n(name);
     if (n == "spec_enabled")
         c->spec_enabled = value != 0.0;
-    else if (n == "spec_W") {
+    else if (n == "carry") { // warm-ups from the previous E-step's boundary vectors (EM sequences)
+        c->carry_enabled = value != 0.0;
+        c->carry_valid = false;
+    } else if (n == "carry_kappa") { // (tests: the sensitivity bound that sizes the carried warm-ups)
+        c->carry_kappa = value;
+    } else if (n == "spec_W") {
+        c->carry_valid = false;
         c->spec_W = std::max(1, (int)value);
         c->spec_W_fixed = c->spec_calibrated = true; // the caller's choice: no probe
     }
@@ -1386,6 +1485,16 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->viterbi_chunked ? 1.0 : 0.0;
     else if (n == "viterbi_close")
         *value = c->viterbi_close;
+    else if (n == "carry")
+        *value = c->carry_enabled ? 1.0 : 0.0;
+    else if (n == "carry_W") // warm-up steps of the last E-step's carried starts (0: full warm-ups)
+        *value = c->carry_last_W;
+    else if (n == "carry_ok")
+        *value = c->carry_ok;
+    else if (n == "carry_fail")
+        *value = c->carry_fail;
+    else if (n == "carry_kappa")
+        *value = c->carry_kappa;
     else if (n == "wide_segments")
         *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
     else if (n == "wide_fwd_segments") // the forward pass's own, finer plan (64 states), 0 if none
@@ -1440,6 +1549,34 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     }
     c->gamma_valid = false;
     c->gamma_wanted = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
+    if (!c->wide && !c->gen) {
+        // how far the model moved since the previous E-step on these observations (max norm;
+        // emission parameters in units of sigma): sizes the warm-ups from carried boundary vectors
+        const int n = c->n;
+        const size_t ne = c->kind == BHMM_EMIT_GAUSSIAN ? 2 * (size_t)n
+                          : (c->kind == BHMM_EMIT_DISCRETE ? (size_t)n * c->M : 0);
+        std::vector<double> cur((size_t)n * n + ne);
+        memcpy(cur.data(), A, (size_t)n * n * sizeof(double));
+        if (c->kind == BHMM_EMIT_GAUSSIAN) {
+            memcpy(cur.data() + (size_t)n * n, par0, n * sizeof(double));
+            memcpy(cur.data() + (size_t)n * n + n, par1, n * sizeof(double));
+        } else if (c->kind == BHMM_EMIT_DISCRETE) {
+            memcpy(cur.data() + (size_t)n * n, par0, ne * sizeof(double));
+        }
+        double delta = -1.0;
+        if (c->prev_model.size() == cur.size()) {
+            delta = 0.0;
+            for (size_t e = 0; e < cur.size(); ++e) {
+                double d = fabs(cur[e] - c->prev_model[e]);
+                if (c->kind == BHMM_EMIT_GAUSSIAN && e >= (size_t)n * n)
+                    d /= fabs(par1[(e - (size_t)n * n) % n]);
+                if (!(d <= delta))
+                    delta = d == d ? d : 1e300;
+            }
+        }
+        c->carry_delta = delta;
+        c->prev_model.swap(cur);
+    }
     double *sd = stats_dev ? stats_dev : c->d_stats.p;
     c->last_stats_internal = (stats_dev == nullptr);
     c->last_stats = sd;

@@ -106,6 +106,19 @@ struct bhmm_ctx {
     int spec_fail = 0, spec_ok = 0;
     float spec_last_dev = 0.f;
     bhmm::DevBuf<double> d_aexit, d_bentry;
+    // boundary vectors carried from one E-step to the next (estep_sweep.hpp: Carry)
+    bool carry_enabled = true;    // option "carry" / BHMM_AMD_CARRY=0
+    bool carry_valid = false;     // d_carry_* hold vectors of the previous (verified) E-step
+    int carry_Wc = 0;             // ... captured for warm-ups of about this many steps
+    int carry_use = 0;            // this launch: warm-ups start from the carried vectors (their Wc)
+    int carry_cap = 0;            // this launch: capture beta when this many steps remain (0: none)
+    int carry_Wout = 0;           // this launch: capture alpha this many steps before the chunks
+    double carry_kappa = 100.0;   // boundary deviation per unit of model change, running bound
+    double carry_delta = -1.0;    // model change against the previous E-step (-1: unknown)
+    int carry_ok = 0, carry_fail = 0, carry_last_W = 0;
+    std::vector<double> prev_model; // [A | par0 | par1] of the previous E-step
+    bhmm::DevBuf<double> d_carry_a, d_carry_b;
+    bhmm::DevBuf<int32_t> d_carry_da, d_carry_db;
     bhmm::DevBuf<unsigned int> d_specres;
     bhmm::DevBuf<int32_t> d_ea;       // exponents of the stored alpha rows (k_estep PH_P1 -> PH_P2)
     bhmm::DevBuf<double> d_tail;      // same layout as h_raw, written by k_tail (one D2H copy)

@@ -943,6 +943,32 @@ __global__ void k_spec_check(const Chunks ch, int G, const double *alpha_entry, 
                       beta_exit, b_entry, tol, result);
 }
 
+// alpha for the next E-step's shortened warm-ups (estep_sweep.hpp: Carry): for chunk g (not the first
+// of its trajectory) the stored workspace row of chunk g - 1 closest below `Wc` steps before its end
+// (rows at multiples of four are stored by every instantiation), and the number of warm-up steps
+// from there to the row just before chunk g.
+template <int N>
+__global__ void k_carry_alpha(const Chunks ch, int G, const double *ws, int Wc, double *a_out,
+                              int32_t *da_out)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G)
+        return;
+    int d = 0;
+    if (ch.len[g] > 0 && ch.t0[g] != 0) {
+        const int lp = ch.len[g - 1];
+        const int idx = (lp - Wc) & ~3;
+        if (lp - Wc >= 0 && idx >= 0) {
+            d = lp - 1 - idx;
+            const double *src = ws + ci_rec(g - 1, idx, ch.Lmax) * (int64_t)(N * 64) + ((g - 1) & 63) * N;
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                a_out[g * N + j] = src[j];
+        }
+    }
+    da_out[g] = d;
+}
+
 // =========================================================================================
 // k_logl: per-trajectory log-likelihood = sum of its chunks' logs (one wavefront per
 // trajectory, fixed summation tree -> run-to-run identical).

@@ -530,6 +530,23 @@ __device__ __forceinline__ void beta_step(const G &gather, const ObsIn &in, int 
 #endif
 enum { PH_ALL = 0, PH_FWDROWS = 1, PH_P1 = 2, PH_P2 = 3 };
 
+// Boundary vectors carried from one E-step to the next (round 3).  In an EM sequence the model moves
+// little per iteration, so a chunk's warm-up need not start from the uniform vector W steps out: it
+// starts from the PREVIOUS E-step's alpha (beta) da (db) steps before (after) the chunk -- off by
+// the effect of the model change instead of by O(1) -- and runs only that many steps.  The boundary
+// check afterwards is the same, so the result is as exact as before; a failed check repeats the
+// E-step with full warm-ups.  alpha comes from the stored workspace rows (k_carry_alpha after the
+// sweep), beta is captured by the backward sweep itself when `cap` steps remain.
+struct Carry {
+    const double *a_in = nullptr;  // [Gp][N] alpha da[g] + 1 steps before chunk g's first step
+    const double *b_in = nullptr;  // [Gp][N] beta db[g] steps after chunk g's last step
+    const int32_t *da = nullptr;   // [Gp] warm-up steps from a_in (0: none, full warm-up)
+    const int32_t *db = nullptr;   // [Gp]
+    double *b_out = nullptr;       // PH_P2: capture for the next E-step, [Gp][N] (entry g - 1)
+    int32_t *db_out = nullptr;     // ... and its distance
+    int cap = 0;                   // ... taken when `cap` steps of the chunk remain (multiple of 8)
+};
+
 template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE, bool BIGM = false>
 __device__ __forceinline__ void estep_body(
     const Model<N> &m, const Chunks &ch, const void *obs_ci, const void *obs_rm,
@@ -545,8 +562,9 @@ __device__ __forceinline__ void estep_body(
     double *partials,      // [gridDim.x][S] register statistics per workgroup
     double *disc_partials, // [gridDim.x][M*N] discrete emission statistics per workgroup
     unsigned int *flags,   // !CAREFUL: flags[2] counts chunks that met a zero / denormal vector
-    int32_t *ea_ci)        // PH_P1 -> PH_P2: [Gp] exponent of each chunk's last alpha row, then CI
+    int32_t *ea_ci,        // PH_P1 -> PH_P2: [Gp] exponent of each chunk's last alpha row, then CI
                            // [record][64] cumulative exponents of the stored alpha rows
+    const Carry &carry)    // PH_P1 / PH_P2: boundary vectors carried between E-steps (or all null)
 {
     using SL = StatLayout<N, KIND>;
     constexpr int H = N / 2;
@@ -664,6 +682,14 @@ __device__ __forceinline__ void estep_body(
                     // warm-up over the nw steps before the chunk, from the uniform vector or
                     // -- where that reaches the start of the trajectory -- exactly from pi
                     int nw = (int)(t0 < (int64_t)W ? t0 : (int64_t)W);
+                    // carried start (only where the full warm-up would not reach the trajectory's
+                    // start, which is exact and stays)
+                    int dca = 0;
+                    if constexpr (PHASE == PH_P1)
+                        if (carry.a_in && t0 > (int64_t)W)
+                            dca = carry.da[g];
+                    if (dca > 0)
+                        nw = dca;
                     int64_t pos = goff - nw;
                     auto wstep = [&](const ObsIn &in, auto sc) {
                         double p[2], d[2], sv[2], af[N];
@@ -675,7 +701,11 @@ __device__ __forceinline__ void estep_body(
                         (void)scaled_emit<N, KIND, CAREFUL, decltype(sc)::value>(in, q, nreal, gmask,
                                                                                  sv, p, a, hmin);
                     };
-                    if ((int64_t)nw == t0) {
+                    if (dca > 0) {
+                        const double2 x = *reinterpret_cast<const double2 *>(carry.a_in + g * N + 2 * q);
+                        a[0] = x.x;
+                        a[1] = x.y;
+                    } else if ((int64_t)nw == t0) {
                         const ObsIn in = load_obs_rm<N, KIND>(obs_rm, pos, q, nreal);
                         double p[2], d[2];
                         emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, in, Bt, q, em, p, d);
@@ -884,9 +914,20 @@ __device__ __forceinline__ void estep_body(
             // same start vector where the warm-up reaches the end of the trajectory
             const int64_t after = (toff[k + 1] - toff[k]) - (t0 + len);
             int nw = (int)(after < (int64_t)W ? after : (int64_t)W);
-            int64_t pos = goff + len + nw - 1;
             b2[0] = u0;
             b2[1] = u1;
+            if constexpr (PHASE == PH_P1) {
+                // carried start (only where the warm-up would not reach the trajectory's end, whose
+                // constant vector is exact and stays)
+                const int dcb = (carry.b_in && after > (int64_t)W) ? carry.db[g] : 0;
+                if (dcb > 0) {
+                    nw = dcb;
+                    const double2 x = *reinterpret_cast<const double2 *>(carry.b_in + g * N + 2 * q);
+                    b2[0] = x.x;
+                    b2[1] = x.y;
+                }
+            }
+            int64_t pos = goff + len + nw - 1;
             auto wstep = [&](const ObsIn &in, auto sc) {
                 double p[2], d[2], bf[N], r[2], bn[2];
                 emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, in, Bt, q, em, p, d);
@@ -1169,7 +1210,13 @@ __device__ __forceinline__ void estep_body(
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         x[j] = po.at(-j);
-                    for (; rem > 0; rem -= 8) {
+                    // (PH_P2 with a capture request: the same loop runs in two stretches, down to
+                    // `cap` remaining steps and then to the end; in between b2 -- beta at my local
+                    // step cap, cap + 1 steps after the last step of the chunk before me -- is
+                    // left for that chunk's next warm-up.  No instruction is added to the loop.)
+                    int stop = (PHASE == PH_P2 && carry.b_out && rem > carry.cap) ? carry.cap : 0;
+                    for (int stretch = 0; stretch < 2; ++stretch) {
+                    for (; rem > stop; rem -= 8) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             y[j] = po.at(-4 - j);
@@ -1193,6 +1240,16 @@ __device__ __forceinline__ void estep_body(
                         pg -= 8 * RS;
                         pea -= 8 * 64;
                     }
+                    if (stop == 0)
+                        break;
+                    if (!first) {
+                        *reinterpret_cast<double2 *>(carry.b_out + (g - 1) * N + 2 * q) =
+                            make_double2(b2[0], b2[1]);
+                        if (q == 0)
+                            carry.db_out[g - 1] = stop + 1;
+                    }
+                    stop = 0;
+                    }
                 }
             } else if constexpr (ESTEP_CKPT != 0) {
                 // (len-1) % 4 single steps on stored rows, then groups of two pairs: two register
@@ -1210,7 +1267,9 @@ __device__ __forceinline__ void estep_body(
                     ObsIn xh = po.at(0), xl = po.at(-1), yh, yl;
                     double2 xa = pa[-2 * RS], ya;
                     int xe = EXPO ? pea[-2 * 64] : 0, ye = 0;
-                    for (; rem > 0; rem -= 4) {
+                    int stop = (PHASE == PH_P2 && carry.b_out && rem > carry.cap) ? carry.cap : 0;
+                    for (int stretch = 0; stretch < 2; ++stretch) { // (see the quad loop above)
+                    for (; rem > stop; rem -= 4) {
                         yh = po.at(-2);
                         yl = po.at(-3);
                         ya = pa[-4 * RS];
@@ -1229,6 +1288,16 @@ __device__ __forceinline__ void estep_body(
                         pa -= 4 * RS;
                         pg -= 4 * RS;
                         pea -= 4 * 64;
+                    }
+                    if (stop == 0)
+                        break;
+                    if (!first) {
+                        *reinterpret_cast<double2 *>(carry.b_out + (g - 1) * N + 2 * q) =
+                            make_double2(b2[0], b2[1]);
+                        if (q == 0)
+                            carry.db_out[g - 1] = stop + 1;
+                    }
+                    stop = 0;
                     }
                 }
             } else {
@@ -1374,10 +1443,11 @@ __device__ __forceinline__ void estep_body(
     const Model<N> m, const Chunks ch, const void *obs_ci, const void *obs_rm, const int64_t *toff, \
         const double *Bt_g, double *alpha_entry, double *beta_exit, double *a_exit,              \
         double *b_entry, int W, double *ws, double *gamma_ci, double *logL_chunk, double *gamma0, \
-        double *partials, double *disc_partials, unsigned int *flags, int32_t *ea_ci
+        double *partials, double *disc_partials, unsigned int *flags, int32_t *ea_ci,          \
+        const Carry carry
 #define ESTEP_PASS                                                                               \
     m, ch, obs_ci, obs_rm, toff, Bt_g, alpha_entry, beta_exit, a_exit, b_entry, W, ws, gamma_ci,   \
-        logL_chunk, gamma0, partials, disc_partials, flags, ea_ci
+        logL_chunk, gamma0, partials, disc_partials, flags, ea_ci, carry
 
 // the sweeps that carry the xi accumulators: two wavefronts per SIMD, up to 256 VGPRs
 template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE = PH_ALL>

@@ -199,6 +199,15 @@ int bhmm_sample_paths_dev(bhmm_ctx *ctx, const double *A, const double *pi, cons
  *   "wide_segments" 1/0  (9..64 states) cut trajectories into time segments with the same
  *                        verified warm-up boundaries; reading it returns the segment count in use
  *   "wide_segment_len"   segment length for the next bhmm_ctx_set_observations (0 = automatic)
+ *   "carry"         1/0  (N <= 8) in a sequence of E-steps on slowly changing models (EM) start the
+ *                        warm-ups from the PREVIOUS E-step's boundary vectors, a shorter distance
+ *                        out, sized from the model change and the measured sensitivity; verified
+ *                        like every warm-up, repeated with full warm-ups if the check fails.  Not
+ *                        used when the model is identical to the previous call's (default 1;
+ *                        BHMM_AMD_CARRY=0)
+ *   "carry_W", "carry_ok", "carry_fail"  (read-only) warm-up steps of the last E-step's carried
+ *                        starts (0: full warm-ups), E-steps that verified on carried starts /
+ *                        had to be repeated
  *   "spec_ok", "spec_fail"  (read-only) E-steps whose boundaries verified / fell back
  *   "spec_last_dev" (read-only) largest relative boundary deviation of the last check
  *   "careful"       (read-only) 1 after an E-step met an all-zero emission row (gaussian

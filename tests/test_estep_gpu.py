@@ -642,3 +642,56 @@ def test_randomised_models_and_shapes(seed):
                         ((A, pi, B) if kind == "discrete" else (A, pi))))
     assert np.array_equal(res.packed, again.packed)
     eng.close()
+
+
+def test_em_sequence_on_carried_boundary_vectors():
+    """Round 3: in a sequence of E-steps on slowly changing models the warm-ups start from the
+    PREVIOUS E-step's boundary vectors, a shorter distance out (estep_sweep.hpp: Carry).  Same
+    statistics as with full warm-ups (both verified to 1e-11) and as the oracle; never used when the
+    model did not change; a deliberately wrong sensitivity bound makes the check fail, the E-step is
+    repeated with full warm-ups and still returns the right statistics."""
+    rng = np.random.default_rng(77)
+    n, K, T = 8, 24, 40000
+    A0 = rng.random((n, n)) + 6 * np.eye(n)
+    A0 /= A0.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    mu0, sig0 = np.linspace(-4, 4, n), np.linspace(0.6, 1.4, n)
+    obs = [rng.normal(mu0[rng.integers(0, n, T)], 1.0) for _ in range(K)]
+    a, b = _engine(), _engine()
+    a.set_observations("gaussian", obs, n, chunk=2048)      # (chunks long against the warm-up)
+    b.set_observations("gaussian", obs, n, chunk=2048)
+    b.set_option("carry", 0)
+    used = []
+    for it in range(14):
+        drift = 3e-3 * 0.6 ** it
+        A = A0 * (1 + drift * rng.normal(size=(n, n)))
+        A /= A.sum(axis=1, keepdims=True)
+        mu = mu0 + drift * rng.normal(size=n)
+        sig = sig0 * (1 + drift * rng.normal(size=n))
+        ra, rb = a.estep(A, pi, mu, sig), b.estep(A, pi, mu, sig)
+        used.append(int(a.get_option("carry_W")))
+        np.testing.assert_allclose(ra.packed, rb.packed, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(ra.logL_k, rb.logL_k, rtol=1e-12)
+    W = a.get_option("spec_W")
+    assert a.get_option("carry_ok") >= 6 and a.get_option("carry_fail") == 0, used
+    assert 0 < min(u for u in used if u > 0) < 0.8 * W, (used, W)
+    assert b.get_option("carry_ok") == 0 and b.get_option("carry_W") == 0
+    ref = orc.estep("gaussian", obs[:3], A, pi, mu, sig)
+    np.testing.assert_allclose(ra.logL_k[:3], ref["logL"], rtol=1e-10)
+    # the same model again: nothing to gain from carried vectors that are exact -- full warm-ups
+    a.estep(A, pi, mu, sig)
+    assert a.get_option("carry_W") == 0
+    # a sensitivity bound that is far too optimistic: the short warm-up fails the check, the
+    # E-step is repeated with full warm-ups
+    a.set_option("carry_kappa", 1e-12)
+    a.estep(A, pi, mu, sig)               # (captures for a warm-up of the minimum length)
+    fails = a.get_option("carry_fail")
+    A2 = A * (1 + 2e-2 * rng.random((n, n)))
+    A2 /= A2.sum(axis=1, keepdims=True)
+    r2 = a.estep(A2, pi, mu + 0.02, sig)
+    assert a.get_option("carry_fail") == fails + 1
+    ref = orc.estep("gaussian", obs[:3], A2, pi, mu + 0.02, sig)
+    np.testing.assert_allclose(r2.logL_k[:3], ref["logL"], rtol=1e-10)
+    np.testing.assert_allclose(r2.state_counts.sum(), K * T, rtol=1e-10)
+    a.close()
+    b.close()
