@@ -644,6 +644,36 @@ def test_randomised_models_and_shapes(seed):
     eng.close()
 
 
+def test_carried_boundary_vectors_discrete_kind():
+    """The same for discrete emissions (the backward sweep runs in groups of eight steps there)."""
+    rng = np.random.default_rng(78)
+    n, M, K, T = 8, 40, 16, 60000
+    A0 = rng.random((n, n)) + 5 * np.eye(n)
+    A0 /= A0.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    B0 = rng.dirichlet(np.ones(M) * 0.5, size=n)
+    obs = [rng.integers(0, M, T).astype(np.int32) for _ in range(K)]
+    a, b = _engine(), _engine()
+    a.set_observations("discrete", obs, n, nsymbols=M, chunk=2048)
+    b.set_observations("discrete", obs, n, nsymbols=M, chunk=2048)
+    b.set_option("carry", 0)
+    used = []
+    for it in range(12):
+        drift = 2e-3 * 0.6 ** it
+        A = A0 * (1 + drift * rng.normal(size=(n, n)))
+        A /= A.sum(axis=1, keepdims=True)
+        B = B0 * (1 + drift * rng.normal(size=(n, M)))
+        B /= B.sum(axis=1, keepdims=True)
+        ra, rb = a.estep(A, pi, B), b.estep(A, pi, B)
+        used.append(int(a.get_option("carry_W")))
+        np.testing.assert_allclose(ra.packed, rb.packed, rtol=1e-9, atol=1e-9)
+    assert a.get_option("carry_ok") >= 5 and a.get_option("carry_fail") == 0, used
+    ref = orc.estep("discrete", obs[:2], A, pi, B)
+    np.testing.assert_allclose(ra.logL_k[:2], ref["logL"], rtol=1e-10)
+    a.close()
+    b.close()
+
+
 def test_em_sequence_on_carried_boundary_vectors():
     """Round 3: in a sequence of E-steps on slowly changing models the warm-ups start from the
     PREVIOUS E-step's boundary vectors, a shorter distance out (estep_sweep.hpp: Carry).  Same

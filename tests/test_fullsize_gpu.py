@@ -589,3 +589,74 @@ def test_very_long_chunks_replan_for_a_slowly_forgetting_model():
     eng3.close()
     del obs, sub
     torch.cuda.empty_cache()
+
+
+# ---- BASELINE configs[4] at its full size: the 100-sample chain ---------------------------------
+@pytest.mark.parametrize("reversible", [False, True])
+def test_configs4_chain_of_100_samples_full_size(reversible):
+    """BASELINE configs[4]: BayesianHMM Gibbs sampler, 8 states, 100 posterior samples x 256
+    trajectories (x 1e5 steps) through `bayesian_hmm`'s sampler class, native parameter draws.  With
+    2.56e7 observations the posterior is narrow: every sample must be a valid model within a few
+    posterior standard deviations of the generating one, the chain must MOVE (no frozen sampler),
+    and the samples' spread must have the right order of magnitude (~ 1 / sqrt(counts))."""
+    import torch
+    import bhmm_amd
+    from bench import make_c2_model
+    from bhmm_amd.engine import synth_observations
+    from bhmm_amd.estimators import _tmatrix
+    m = make_c2_model()
+    n, K, T = 8, 256, 100000
+    buf = torch.empty(K * T, dtype=torch.float64, device="cuda:0")
+    synth_observations("gaussian", buf.data_ptr(), m["A"], m["pi"], m["mu"], m["sigma"], K, T, seed=2000)
+    host = buf.cpu().numpy().reshape(K, T)
+    del buf
+    obs = [host[k] for k in range(K)]
+    A0 = _tmatrix.mle_reversible(m["pi"][:, None] * m["A"], maxerr=1e-14) if reversible else m["A"]
+    init = bhmm_amd.gaussian_hmm(m["pi"], A0, m["mu"], m["sigma"])
+    smp = bhmm_amd.BayesianHMMSampler(obs, n, initial_model=init, reversible=reversible,
+                                      transition_matrix_sampling_steps=30)
+    models = smp.sample(100, nburn=5, seed=11)
+    assert len(models) == 100
+    A = np.array([h.transition_matrix for h in models])
+    mu = np.array([h.output_model.means for h in models])
+    sg = np.array([h.output_model.sigmas for h in models])
+    np.testing.assert_allclose(A.sum(axis=2), 1.0, rtol=1e-12)
+    assert np.all(A >= 0) and np.all(sg > 0)
+    # near the generating model (the metastable matrix of the bench is itself reversible up to the
+    # rescaling of its rows; 1e-2 is hundreds of posterior standard deviations of slack for A)
+    assert np.abs(A.mean(axis=0) - m["A"]).max() < 1e-2
+    assert np.abs(mu.mean(axis=0) - m["mu"]).max() < 2e-2 and np.abs(sg.mean(axis=0) - m["sigma"]).max() < 2e-2
+    # the chain moves, with the spread a posterior of 2.56e7 observations has
+    assert np.all(mu.std(axis=0) > 1e-5) and np.all(mu.std(axis=0) < 5e-3)
+    assert np.all(A.std(axis=0)[m["A"] > 1e-3] > 1e-6) and A.std(axis=0).max() < 5e-3
+    assert len({h.transition_matrix.tobytes() for h in models}) == 100
+    if reversible:
+        pi_s = _tmatrix.stationary_vector(models[-1].transition_matrix)
+        X = pi_s[:, None] * models[-1].transition_matrix
+        np.testing.assert_allclose(X, X.T, atol=1e-12)
+    smp._engine.close()
+
+
+def test_gamma_rows_at_full_size_against_the_oracle():
+    """gamma export at BASELINE configs[1]'s full size (256 x 1e5): rows of three trajectories against
+    the oracle, not only their sums."""
+    import torch
+    from bench import make_c2_model
+    from bhmm_amd.engine import synth_observations
+    m = make_c2_model()
+    n, K, T = 8, 256, 100000
+    buf = torch.empty(K * T, dtype=torch.float64, device="cuda:0")
+    synth_observations("gaussian", buf.data_ptr(), m["A"], m["pi"], m["mu"], m["sigma"], K, T, seed=2000)
+    eng = _engine()
+    eng.set_observations_device("gaussian", buf.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, n)
+    margs = (m["A_eval"], m["pi"], m["mu_eval"], m["sigma"])
+    res = eng.estep(*margs, store_gamma=True)
+    np.testing.assert_allclose(res.state_counts.sum(), K * T, rtol=1e-10)
+    for k in (0, 131, 255):
+        o = buf[k * T:(k + 1) * T].cpu().numpy()
+        ref = orc.estep("gaussian", [o], *margs, want_gamma=True)
+        g = eng.gamma(k)
+        np.testing.assert_allclose(g, ref["gammas"][0], rtol=1e-8, atol=1e-13)
+        np.testing.assert_allclose(g.sum(axis=1), 1.0, rtol=1e-12)
+        np.testing.assert_allclose(res.logL_k[k], ref["logL"][0], rtol=1e-12)
+    eng.close()
