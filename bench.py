@@ -678,6 +678,10 @@ def main():
             "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "steady_state_ms": steady_ms,
+            "timing_note": "ms_per_step covers exactly the requested steps; with few warm-up steps "
+                           "they fall into the GPU's power ramp after idling (first ~30 E-steps run "
+                           "~10 % slower, DESIGN.md section 7); steady_state_ms is the median of steps "
+                           "51-100 of an extra window right behind them",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[1]: 8-state Gaussian HMM, %d trajectories x %d "

@@ -415,7 +415,11 @@ struct Runner {
         if (c->spec_enabled) {
             // ---- boundary vectors carried from the previous E-step (estep_sweep.hpp: Carry) ----
             // decades of forgetting per step, from the calibrated warm-up (1e-13 after W / 1.15 steps)
-            const double rdec = 13.0 * 1.15 / std::max(c->spec_W, 16);
+            // (the calibration is conservative -- 1e-13 on 256 sampled stretches plus 15 % --; what the
+            // boundary check of a full warm-up actually measured is the better estimate, when known)
+            double rdec = 13.0 * 1.15 / std::max(c->spec_W, 16);
+            if (c->carry_rdec > 0.0)
+                rdec = std::min(rdec, c->carry_rdec);
             bool eligible = c->carry_enabled && ESTEP_SPLIT && KIND != EMIT_EXPL && !c->careful &&
                             !(flags & BHMM_FLAG_STORE_GAMMA) && c->G > c->K;
             if (KIND == EMIT_GAUSS) // (the branch-free split launches only, see fwdbwd)
@@ -459,6 +463,12 @@ struct Runner {
                                             (delta * pow(10.0, -rdec * carried));
                         c->carry_kappa = std::min(std::max(std::max(0.5 * c->carry_kappa, 8.0 * keff), 1.0), 1e8);
                         c->carry_ok++;
+                    }
+                    if (carried == 0 && c->spec_last_dev > 0.f && c->spec_last_dev < 1e-6f) {
+                        // a full warm-up of spec_W steps from the uniform vector (start error O(1))
+                        // left this deviation at the worst boundary
+                        const double rr = -log10((double)c->spec_last_dev) / std::max(c->spec_W, 16);
+                        c->carry_rdec = c->carry_rdec > 0.0 ? std::min(c->carry_rdec, rr) : rr;
                     }
                     c->carry_last_W = carried;
                     c->carry_valid = c->carry_cap > 0;
@@ -1225,6 +1235,7 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     c->carry_valid = false;
     c->carry_use = c->carry_cap = 0;
     c->carry_kappa = 100.0;
+    c->carry_rdec = 0.0;
     c->prev_model.clear();
     c->spec_calibrated = c->spec_W_fixed;
     if (!c->spec_W_fixed)

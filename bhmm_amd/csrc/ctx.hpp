@@ -115,6 +115,8 @@ struct bhmm_ctx {
     int carry_Wout = 0;           // this launch: capture alpha this many steps before the chunks
     double carry_kappa = 100.0;   // boundary deviation per unit of model change, running bound
     double carry_delta = -1.0;    // model change against the previous E-step (-1: unknown)
+    double carry_rdec = 0.0;      // decades of forgetting per warm-up step, measured: the deviation the
+                                  // check found after a FULL warm-up from the uniform vector (0: unknown)
     int carry_ok = 0, carry_fail = 0, carry_last_W = 0;
     std::vector<double> prev_model; // [A | par0 | par1] of the previous E-step
     bhmm::DevBuf<double> d_carry_a, d_carry_b;
