@@ -521,6 +521,9 @@ def main():
     ap.add_argument("--cpu-traj", type=int, default=200, help="trajectories in the 1-core CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-steady", action="store_true",
+                    help="skip the extra steady-state window (profiling runs: the kernel statistics then "
+                         "cover exactly the warm-up and timed launches)")
     ap.add_argument("--c3-ntraj", type=int, default=1024)
     ap.add_argument("--c3-length", type=int, default=1000000)
     ap.add_argument("--c3-steps", type=int, default=5)
@@ -640,11 +643,11 @@ def main():
     # a second, untimed-by-the-contract window right behind the requested steps: what an EM loop of
     # hundreds of iterations sees once the GPU's power management has settled
     steady = []
-    for _ in range(100):
+    for _ in range(0 if args.no_steady else 100):
         t1 = time.perf_counter()
         one_step()
         steady.append(time.perf_counter() - t1)
-    steady_ms = 1e3 * float(np.median(steady[50:]))
+    steady_ms = 1e3 * float(np.median(steady[50:])) if steady else None
     res = eng.unpack(host_stats.numpy().copy())
     assert np.isfinite(res.loglik)
     # sanity of the reduced statistics: every step of every rank carries unit gamma mass

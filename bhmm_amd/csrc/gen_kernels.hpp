@@ -24,8 +24,20 @@ __device__ __forceinline__ double gen_ordered_sum(const double *x, int n, double
 {
     __syncthreads();
     if (threadIdx.x == 0) {
+        // same additions in the same order; the loads of eight entries are issued together (one
+        // LDS round trip per eight additions instead of one per addition)
         double s = 0.0;
-        for (int i = 0; i < n; ++i)
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = x[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += v[u];
+        }
+        for (; i < n; ++i)
             s += x[i];
         *slot = s;
     }
@@ -52,8 +64,21 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_forward(const WideModel m, cons
                 a = m.pi[j] * p[j];
             } else {
                 double s = 0.0;
-                for (int i = 0; i < n; ++i)
-                    s += xa[i] * m.A[(int64_t)i * n + j];
+                const double *Ac = m.A + j;
+                int i = 0;
+                for (; i + 8 <= n; i += 8) { // eight loads in flight, then the products in order
+                    double av[8], xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        av[u] = Ac[(int64_t)(i + u) * n];
+                        xv[u] = xa[i + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        s += xv[u] * av[u];
+                }
+                for (; i < n; ++i)
+                    s += xa[i] * Ac[(int64_t)i * n];
                 a = s * p[j];
             }
             ya[j] = a;
@@ -104,8 +129,22 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
         } else {
             for (int i = tid; i < n; i += GEN_TPB) {
                 double s = 0.0;
-                for (int j = 0; j < n; ++j)
-                    s += At[(int64_t)j * n + i] * np[j] * nb[j];
+                const double *Ar = At + i;
+                int j = 0;
+                for (; j + 8 <= n; j += 8) {
+                    double av[8], pv[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        av[u] = Ar[(int64_t)(j + u) * n];
+                        pv[u] = np[j + u];
+                        bv[u] = nb[j + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        s += av[u] * pv[u] * bv[u];
+                }
+                for (; j < n; ++j)
+                    s += Ar[(int64_t)j * n] * np[j] * nb[j];
                 cur[i] = s;
             }
         }
@@ -329,9 +368,27 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_viterbi_fwd(const WideModel m, 
                 vn[j] = p[j] * m.pi[j];
             } else {
                 int best = 0;
-                double hm = v[0] * m.A[j];
-                for (int i = 1; i < n; ++i) {
-                    const double h = v[i] * m.A[(int64_t)i * n + j];
+                const double *Ac = m.A + j;
+                double hm = v[0] * Ac[0];
+                int i = 1;
+                for (; i + 8 <= n; i += 8) {
+                    double av[8], xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        av[u] = Ac[(int64_t)(i + u) * n];
+                        xv[u] = v[i + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double h = xv[u] * av[u];
+                        if (h > hm) {
+                            hm = h;
+                            best = i + u;
+                        }
+                    }
+                }
+                for (; i < n; ++i) {
+                    const double h = v[i] * Ac[(int64_t)i * n];
                     if (h > hm) {
                         hm = h;
                         best = i;

@@ -9,7 +9,7 @@ O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/${tag}_bench_5_20.json 2> /tmp/b.err || tail -5 /tmp/b.err
 rm -rf /tmp/prof_d
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_d -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-secondary > $O/${tag}_bench_5_20_under_rocprof.json 2> /tmp/prof_d.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_d -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-secondary --no-steady > $O/${tag}_bench_5_20_under_rocprof.json 2> /tmp/prof_d.err
 cp $(find /tmp/prof_d -name "*kernel_stats.csv" | head -1) $O/${tag}_kernel_stats_5_20.csv
 python3 - $O/${tag}_bench_5_20.json $O/${tag}_bench_5_20_under_rocprof.json $O/${tag}_kernel_stats_5_20.csv <<'PY'
 import json, sys, csv

@@ -16,6 +16,11 @@ python3 $R/bench.py > $O/${tag}_bench.json 2> /tmp/bench.err || tail -5 /tmp/ben
 rm -rf /tmp/prof_k
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -- python3 $R/bench.py --no-cpu > $O/${tag}_bench_under_rocprof.json 2> /tmp/prof_k.err
 cp $(find /tmp/prof_k -name "*kernel_stats.csv" | head -1) $O/${tag}_kernel_stats.csv
+# the headline loop alone (50 + 200 launches of the sweep pair, nothing else): the averages that
+# roofline.achieved of the bench line must agree with
+rm -rf /tmp/prof_h
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_h -- python3 $R/bench.py --no-cpu --no-secondary --no-steady > $O/${tag}_bench_headline_under_rocprof.json 2> /tmp/prof_h.err
+cp $(find /tmp/prof_h -name "*kernel_stats.csv" | head -1) $O/${tag}_kernel_stats_headline.csv
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_$ctr
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/prof_$ctr -- python3 $R/tools/pmc_traffic2.py > /tmp/prof_$ctr.log 2>&1
