@@ -601,12 +601,13 @@ def main():
     S = eng.stats_size
     stats = torch.zeros(S, dtype=torch.float64, device=dev)
     host_stats = torch.zeros(S, dtype=torch.float64).pin_memory()
+    host_np = host_stats.numpy()                    # (same memory)
 
     def one_step():
         if not distributed:
             # single GPU: the library lands the statistics in pinned host memory itself
             eng.estep_launch(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
-            host_stats.copy_(torch.from_numpy(eng.estep_fetch().packed))
+            eng.estep_fetch_packed(host_np)         # reduced statistics, on the host
             return host_stats
         eng.estep_launch(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"],
                          stats_dev=stats.data_ptr())

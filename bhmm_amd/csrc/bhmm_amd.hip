@@ -204,16 +204,16 @@ struct Runner {
                                       sm1, c1)))
                         return rc;
                     BHMM_HIP(hipGetLastError());
-                    if (c->carry_cap > 0) {
+                    c2.cap = c->carry_cap;
+                    if (c->carry_cap > 0 && c->carry_store) {
                         // (P1 has consumed the old vectors: the same buffers take the new ones)
                         BHMM_HIP(hipMemsetAsync(c->d_carry_db.p, 0, (size_t)c->Gp * sizeof(int32_t),
                                                 c->stream));
                         c2.b_out = c->d_carry_b.p;
                         c2.db_out = c->d_carry_db.p;
-                        c2.cap = c->carry_cap;
                     }
                     rc = launch2(k_estep<N, KIND, SPEC, false, false, PH_P2>, nblk, m, sm, c2);
-                    if (rc == BHMM_OK && c->carry_cap > 0) {
+                    if (rc == BHMM_OK && c->carry_cap > 0 && c->carry_store) {
                         BHMM_HIP(hipGetLastError());
                         hipLaunchKernelGGL((k_carry_alpha<N>), dim3((c->G + 255) / 256), dim3(256), 0,
                                            c->stream, ch, c->G, (const double *)c->d_ws.p,
@@ -437,6 +437,7 @@ struct Runner {
             auto plan_capture = [&]() {
                 // capture for the NEXT E-step, sized for twice this step's model change
                 c->carry_cap = c->carry_Wout = 0;
+                c->carry_store = false;
                 if (!eligible || (c->d_carry_a.ensure((size_t)c->Gp * N)) ||
                     (c->d_carry_b.ensure((size_t)c->Gp * N)) || (c->d_carry_da.ensure(c->Gp)) ||
                     (c->d_carry_db.ensure(c->Gp)))
@@ -448,6 +449,11 @@ struct Runner {
                     return; // not worth it / chunks too short
                 c->carry_Wout = Wc;
                 c->carry_cap = Wc; // beta at local step Wc: Wc + 1 warm-up steps
+                // a model identical to the previous call's: the sweep is split at the same place (it
+                // must round like the call before, see Carry::cap) but nothing is stored -- carried
+                // starts are only used after a change, and a caller that repeats E-steps on a fixed
+                // model should not pay for the two small launches
+                c->carry_store = delta != 0.0;
             };
             for (int attempt = 0; attempt < 3; ++attempt) {
                 bool ok = false;
@@ -471,7 +477,7 @@ struct Runner {
                         c->carry_rdec = c->carry_rdec > 0.0 ? std::min(c->carry_rdec, rr) : rr;
                     }
                     c->carry_last_W = carried;
-                    c->carry_valid = c->carry_cap > 0;
+                    c->carry_valid = c->carry_cap > 0 && c->carry_store;
                     c->carry_Wc = c->carry_Wout;
                     c->carry_use = 0;
                     return BHMM_OK;

@@ -113,6 +113,7 @@ struct bhmm_ctx {
     int carry_use = 0;            // this launch: warm-ups start from the carried vectors (their Wc)
     int carry_cap = 0;            // this launch: capture beta when this many steps remain (0: none)
     int carry_Wout = 0;           // this launch: capture alpha this many steps before the chunks
+    bool carry_store = false;     // this launch: store the captures (else the sweep is only split there)
     double carry_kappa = 100.0;   // boundary deviation per unit of model change, running bound
     double carry_delta = -1.0;    // model change against the previous E-step (-1: unknown)
     double carry_rdec = 0.0;      // decades of forgetting per warm-up step, measured: the deviation the

@@ -544,7 +544,11 @@ struct Carry {
     const int32_t *db = nullptr;   // [Gp]
     double *b_out = nullptr;       // PH_P2: capture for the next E-step, [Gp][N] (entry g - 1)
     int32_t *db_out = nullptr;     // ... and its distance
-    int cap = 0;                   // ... taken when `cap` steps of the chunk remain (multiple of 8)
+    int cap = 0;                   // ... taken when `cap` steps of the chunk remain (multiple of 8).
+                                   // The sweep is split there whether or not b_out is set: the split
+                                   // changes how the lanes of a wavefront line up in time, hence the
+                                   // order of the discrete kind's count atomics -- a call that does
+                                   // not capture must round like one that does
 };
 
 template <int N, int KIND, bool SPEC, bool GAMMA, bool CAREFUL, int PHASE, bool BIGM = false>
@@ -1214,7 +1218,10 @@ __device__ __forceinline__ void estep_body(
                     // `cap` remaining steps and then to the end; in between b2 -- beta at my local
                     // step cap, cap + 1 steps after the last step of the chunk before me -- is
                     // left for that chunk's next warm-up.  No instruction is added to the loop.)
-                    int stop = (PHASE == PH_P2 && carry.b_out && rem > carry.cap) ? carry.cap : 0;
+                    int stop = (PHASE == PH_P2 && carry.cap > 0 && rem > carry.cap) ? carry.cap : 0;
+                    // (a real loop, not two copies of the body: both stretches must execute the SAME
+                    // instructions, or a run with a capture would round differently from one without)
+#pragma clang loop unroll(disable)
                     for (int stretch = 0; stretch < 2; ++stretch) {
                     for (; rem > stop; rem -= 8) {
 #pragma unroll
@@ -1242,7 +1249,7 @@ __device__ __forceinline__ void estep_body(
                     }
                     if (stop == 0)
                         break;
-                    if (!first) {
+                    if (carry.b_out && !first) {
                         *reinterpret_cast<double2 *>(carry.b_out + (g - 1) * N + 2 * q) =
                             make_double2(b2[0], b2[1]);
                         if (q == 0)
@@ -1267,7 +1274,8 @@ __device__ __forceinline__ void estep_body(
                     ObsIn xh = po.at(0), xl = po.at(-1), yh, yl;
                     double2 xa = pa[-2 * RS], ya;
                     int xe = EXPO ? pea[-2 * 64] : 0, ye = 0;
-                    int stop = (PHASE == PH_P2 && carry.b_out && rem > carry.cap) ? carry.cap : 0;
+                    int stop = (PHASE == PH_P2 && carry.cap > 0 && rem > carry.cap) ? carry.cap : 0;
+#pragma clang loop unroll(disable)
                     for (int stretch = 0; stretch < 2; ++stretch) { // (see the quad loop above)
                     for (; rem > stop; rem -= 4) {
                         yh = po.at(-2);
@@ -1291,7 +1299,7 @@ __device__ __forceinline__ void estep_body(
                     }
                     if (stop == 0)
                         break;
-                    if (!first) {
+                    if (carry.b_out && !first) {
                         *reinterpret_cast<double2 *>(carry.b_out + (g - 1) * N + 2 * q) =
                             make_double2(b2[0], b2[1]);
                         if (q == 0)

@@ -194,6 +194,14 @@ class Engine(object):
         _lib.check(self._L.bhmm_estep_fetch(self._h, _lib.dp(packed), _lib.dp(logL_k)))
         return EStepResult(self.kind, self.nstates, self.nsymbols, packed, logL_k)
 
+    def estep_fetch_packed(self, out=None):
+        """Wait for the last E-step and return only its packed statistics vector (layout:
+        include/bhmm_amd.h, bhmm_ctx_stats_size) -- no per-field copies, no logL_k."""
+        if out is None:
+            out = np.empty(self.stats_size)
+        _lib.check(self._L.bhmm_estep_fetch(self._h, _lib.dp(out), None))
+        return out
+
     def estep_fetch_logL(self):
         """Per-trajectory log-likelihoods of the last E-step only (waits for it).  Used when the
         packed statistics stay on the device for an all-reduce."""

@@ -714,7 +714,8 @@ def test_em_sequence_on_carried_boundary_vectors():
     # a sensitivity bound that is far too optimistic: the short warm-up fails the check, the
     # E-step is repeated with full warm-ups
     a.set_option("carry_kappa", 1e-12)
-    a.estep(A, pi, mu, sig)               # (captures for a warm-up of the minimum length)
+    a.estep(A, pi, mu + 1e-7, sig)        # (full warm-ups; captures for a warm-up of the minimum length)
+    assert a.get_option("carry_W") == 0
     fails = a.get_option("carry_fail")
     A2 = A * (1 + 2e-2 * rng.random((n, n)))
     A2 /= A2.sum(axis=1, keepdims=True)
