@@ -111,6 +111,44 @@ def fit_gmm1d(x, ncomp, maxit=300, tol=1e-9, min_sigma=None, nbins=4096):
     return weights[order], means[order], sigmas[order]
 
 
+def fit_gmm1d_from_centers(x, centers, n_iter=100, tol=1e-3, min_covar=1e-3):
+    """The reference's own mixture fit from GIVEN starting centres: the EM of its vendored
+    `GMM(n_components)` (bhmm/_external/sklearn/mixture/gmm.py:414-527, diagonal covariances) --
+    uniform starting weights, every variance started at var(x) + min_covar, at most 100 iterations,
+    stopped when the mean log-likelihood moves by less than 1e-3, M-step with the 10 eps / eps
+    guards and the min_covar floor of :511-527, 684-690.  The reference draws the centres with a
+    k-means++ seeding that is seeded from the clock (kmeans.c:273), so its initial model differs
+    from run to run; with the centres given, this function returns the weights / means / sigmas
+    its fit arrives at (pinned by tests/golden/init_refs.npz).  Components are NOT reordered."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    means = np.array(centers, dtype=np.float64).ravel()
+    k = means.size
+    if x.size < k:
+        raise ValueError('GMM estimation with %s components, but got only %s samples' % (k, x.size))
+    eps = np.finfo(float).eps
+    weights = np.full(k, 1.0 / k)
+    covars = np.full(k, np.cov(x) + min_covar)
+    x2 = x * x
+    last = None
+    for _ in range(n_iter):
+        lpr = -0.5 * (np.log(2.0 * np.pi) + np.log(covars) + means * means / covars
+                      - 2.0 * np.outer(x, means / covars) + np.outer(x2, 1.0 / covars)) + np.log(weights)
+        vmax = lpr.max(axis=1)
+        logprob = np.log(np.exp(lpr - vmax[:, None]).sum(axis=1)) + vmax
+        cur = logprob.mean()
+        if last is not None and abs(cur - last) < tol:
+            break
+        last = cur
+        resp = np.exp(lpr - logprob[:, None])
+        w = resp.sum(axis=0)
+        wx = resp.T @ x
+        inv = 1.0 / (w + 10.0 * eps)
+        weights = w / (w.sum() + 10.0 * eps) + eps
+        means = wx * inv
+        covars = (resp.T @ x2) * inv - 2.0 * means * wx * inv + means * means + min_covar
+    return weights, means, np.sqrt(covars)
+
+
 def fractional_counts(observations, means, sigmas):
     """N[i, j] = sum over trajectories and t of w_t[i] * w_{t+1}[j] with w_t the normalised
     emission densities of step t (init/gaussian.py:66-78)."""
@@ -140,10 +178,18 @@ def _few_million_steps(observations, limit=4000000):
     return [observations[k] for k in sorted(keep)]
 
 
-def init_model_gaussian1d(observations, nstates, reversible=True):
-    observations = _few_million_steps(observations)
-    pooled = np.concatenate([np.asarray(o, dtype=np.float64).ravel() for o in observations])
-    weights, means, sigmas = fit_gmm1d(pooled, nstates)
+def init_model_gaussian1d(observations, nstates, reversible=True, centers=None):
+    """centers: None -- the reproducible mixture fit described above; `nstates` starting centres --
+    the reference's mixture fit from exactly those (`fit_gmm1d_from_centers`), on all observations."""
+    if centers is not None:
+        if len(np.ravel(centers)) != nstates:
+            raise ValueError('need one starting centre per state')
+        pooled = np.concatenate([np.asarray(o, dtype=np.float64).ravel() for o in observations])
+        weights, means, sigmas = fit_gmm1d_from_centers(pooled, centers)
+    else:
+        observations = _few_million_steps(observations)
+        pooled = np.concatenate([np.asarray(o, dtype=np.float64).ravel() for o in observations])
+        weights, means, sigmas = fit_gmm1d(pooled, nstates)
     N = fractional_counts(observations, means, sigmas)
     P = _tmatrix.estimate_P(N, reversible=reversible)
     pi = _tmatrix.stationary_distribution(P, C=N)
