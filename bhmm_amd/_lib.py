@@ -88,6 +88,7 @@ SIGNATURES = {
     "bhmm_ctx_num_chunks": (ctypes.c_int, [c_void_p]),
     "bhmm_ctx_chunk_len": (ctypes.c_int, [c_void_p]),
     "bhmm_ctx_last_kernel_ms": (ctypes.c_double, [c_void_p, ctypes.c_int]),
+    "bhmm_ctx_last_kernel_ms_all": (ctypes.c_int, [c_void_p, c_double_p]),
     "bhmm_ctx_stream": (c_void_p, [c_void_p]),
     "bhmm_ctx_sync": (ctypes.c_int, [c_void_p]),
     "bhmm_synth_observations": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p,

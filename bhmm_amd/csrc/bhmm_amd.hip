@@ -241,7 +241,6 @@ struct Runner {
                                c->d_logLc.p);
         }
         BHMM_HIP(hipGetLastError());
-        if (!getenv("BHMM_X_NOEV"))
         BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
         return BHMM_OK;
     }
@@ -306,9 +305,6 @@ struct Runner {
         c->tail_slot ^= 1;
         unsigned int *words = reinterpret_cast<unsigned int *>(c->d_tail.p) + 4 * slot;
         unsigned int *words_next = reinterpret_cast<unsigned int *>(c->d_tail.p) + 4 * (slot ^ 1);
-        static const bool x_noev = getenv("BHMM_X_NOEV") != nullptr;
-        static const bool x_spin = getenv("BHMM_X_SPIN") != nullptr;
-        if (!x_noev)
         BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
         rc = fwdbwd<KIND, MODE_ESTEP, true>(c, m, (flags & BHMM_FLAG_STORE_GAMMA) != 0, words);
         if (rc)
@@ -333,15 +329,10 @@ struct Runner {
                                (const double *)c->d_tbpart.p, stats_dev, c->d_tail.p + 4);
             BHMM_HIP(hipGetLastError());
         }
-        if (!x_noev)
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
         c->ev_lean = true;
         BHMM_HIP(hipMemcpyAsync(c->h_raw, c->d_tail.p, ntail * sizeof(double), hipMemcpyDeviceToHost,
                                 c->stream));
-        if (x_spin) {
-            while (hipStreamQuery(c->stream) == hipErrorNotReady) {
-            }
-        } else
         BHMM_HIP(hipStreamSynchronize(c->stream));
         if ((rc = apply_verdict(c, reinterpret_cast<const unsigned int *>(c->h_raw) + 4 * slot,
                                 verified, true)))
@@ -1552,6 +1543,15 @@ double bhmm_ctx_last_kernel_ms(bhmm_ctx *c, int which)
     if (!c || which < 0 || which > 4)
         return -1.0;
     return c->last_ms[which];
+}
+
+int bhmm_ctx_last_kernel_ms_all(bhmm_ctx *c, double *out)
+{
+    if (!c || !out)
+        return invalid("bad arguments");
+    for (int i = 0; i < 5; ++i)
+        out[i] = c->last_ms[i];
+    return BHMM_OK;
 }
 
 int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0,

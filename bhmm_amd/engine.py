@@ -47,6 +47,10 @@ class Engine(object):
         self._h = h
         self.device = int(device)
         self.kind = None
+        self._stage = None
+        self._keep = {}
+        self._fetch = None
+        self._kms = None
         self.nstates = 0
         self.nsymbols = 0
         self.lengths = None
@@ -132,6 +136,8 @@ class Engine(object):
         self.nsymbols = int(nsymbols)
         self.lengths = lengths
         self.offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        self._stage = None
+        self._fetch = None
 
     @property
     def stats_size(self):
@@ -167,23 +173,54 @@ class Engine(object):
     def kernel_ms(self, which):
         return self._L.bhmm_ctx_last_kernel_ms(self._h, which)
 
+    def kernel_ms_all(self):
+        """The five HIP-event intervals of the last E-step (prescan, stitch, sweep, finalise, whole)
+        in an array owned by the engine (overwritten by the next call)."""
+        k = self._kms
+        if k is None:
+            buf = np.zeros(5)
+            k = self._kms = (buf, _lib.dp(buf))
+        _lib.check(self._L.bhmm_ctx_last_kernel_ms_all(self._h, k[1]))
+        return k[0]
+
     # -- E-step --------------------------------------------------------------------------
+    _STAGE_LIMIT = 1 << 16   # elements: larger emission tables are passed as they are
+
     def _model_ptrs(self, A, pi, par0, par1):
-        A = _lib.f64(A)
-        pi = _lib.f64(pi)
-        p0 = _lib.f64(par0) if par0 is not None else None
-        p1 = _lib.f64(par1) if par1 is not None else None
+        """ctypes pointers (A, pi, par0, par1) for one call.  The model is copied into arrays owned
+        by the engine whose pointers are made once per set of observations: building four ctypes
+        pointers from numpy arrays costs ~13 us per call, a sixtieth of an E-step of configs[1]."""
         n = self.nstates
-        if A.shape != (n, n) or pi.shape != (n,):
+        if np.shape(A) != (n, n) or np.shape(pi) != (n,):
             raise ValueError("model shape does not match nstates=%d" % n)
-        return A, pi, p0, p1
+        st = self._stage
+        if st is None:
+            st = self._stage = {}
+        out = []
+        for key, a in (("A", A), ("pi", pi), ("p0", par0), ("p1", par1)):
+            if a is None:
+                out.append(None)
+                continue
+            shp = np.shape(a)
+            ent = st.get(key)
+            if ent is None or ent[0].shape != shp:
+                if int(np.prod(shp, dtype=np.int64)) > self._STAGE_LIMIT:
+                    a = _lib.f64(a)
+                    self._keep[key] = a             # alive until the call returns
+                    out.append(_lib.dp(a))
+                    continue
+                buf = np.empty(shp, dtype=np.float64)
+                ent = st[key] = (buf, _lib.dp(buf))
+            np.copyto(ent[0], a)
+            out.append(ent[1])
+        return out
 
     def estep_launch(self, A, pi, par0=None, par1=None, stats_dev=None, store_gamma=False):
         """Enqueue one E-step.  stats_dev: optional device address receiving the packed
         statistics (e.g. a torch tensor that is all-reduced across ranks afterwards)."""
         A, pi, p0, p1 = self._model_ptrs(A, pi, par0, par1)
         flags = _lib.FLAG_STORE_GAMMA if store_gamma else 0
-        _lib.check(self._L.bhmm_estep(self._h, _lib.dp(A), _lib.dp(pi), _lib.dp(p0), _lib.dp(p1),
+        _lib.check(self._L.bhmm_estep(self._h, A, pi, p0, p1,
                                       ctypes.c_void_p(int(stats_dev)) if stats_dev else None,
                                       flags))
 
@@ -199,7 +236,10 @@ class Engine(object):
         include/bhmm_amd.h, bhmm_ctx_stats_size) -- no per-field copies, no logL_k."""
         if out is None:
             out = np.empty(self.stats_size)
-        _lib.check(self._L.bhmm_estep_fetch(self._h, _lib.dp(out), None))
+        f = self._fetch
+        if f is None or f[0] is not out:            # the pointer of a re-used `out` is made once
+            f = self._fetch = (out, _lib.dp(out))
+        _lib.check(self._L.bhmm_estep_fetch(self._h, f[1], None))
         return out
 
     def estep_fetch_logL(self):
@@ -226,8 +266,7 @@ class Engine(object):
     def viterbi(self, A, pi, par0=None, par1=None):
         A, pi, p0, p1 = self._model_ptrs(A, pi, par0, par1)
         paths = np.empty(int(self.offsets[-1]), dtype=np.int32)
-        _lib.check(self._L.bhmm_viterbi_batch(self._h, _lib.dp(A), _lib.dp(pi), _lib.dp(p0),
-                                              _lib.dp(p1), _lib.ip(paths)))
+        _lib.check(self._L.bhmm_viterbi_batch(self._h, A, pi, p0, p1, _lib.ip(paths)))
         return [paths[self.offsets[k]:self.offsets[k + 1]] for k in range(len(self.lengths))]
 
     def viterbi_u8(self, A, pi, par0=None, par1=None, out=None):
@@ -251,8 +290,7 @@ class Engine(object):
             if on_dev and out.device.index != self.device:
                 raise ValueError("out lives on another GPU than this engine")
             ptr = out.data_ptr()
-        _lib.check(self._L.bhmm_viterbi_batch_u8(self._h, _lib.dp(A), _lib.dp(pi), _lib.dp(p0),
-                                                 _lib.dp(p1), ctypes.c_void_p(int(ptr)), on_dev))
+        _lib.check(self._L.bhmm_viterbi_batch_u8(self._h, A, pi, p0, p1, ctypes.c_void_p(int(ptr)), on_dev))
         return out
 
     def set_stream_offsets(self, soff):
@@ -277,8 +315,7 @@ class Engine(object):
         total = int(self.offsets[-1])
         paths = np.empty(total, dtype=np.int32) if want_paths else None
         uu = _lib.f64(np.concatenate(u)) if u is not None else None
-        _lib.check(self._L.bhmm_sample_paths_dev(self._h, _lib.dp(A), _lib.dp(pi), _lib.dp(p0),
-                                                 _lib.dp(p1), _lib.dp(uu), ctypes.c_uint64(int(seed)),
+        _lib.check(self._L.bhmm_sample_paths_dev(self._h, A, pi, p0, p1, _lib.dp(uu), ctypes.c_uint64(int(seed)),
                                                  _lib.ip(paths), ctypes.c_void_p(int(stats_dev))))
         if not want_paths:
             return None
@@ -314,8 +351,7 @@ class Engine(object):
         else:
             emis = None
         uu = _lib.f64(np.concatenate(u)) if u is not None else None
-        _lib.check(self._L.bhmm_sample_paths(self._h, _lib.dp(A), _lib.dp(pi), _lib.dp(p0),
-                                             _lib.dp(p1), _lib.dp(uu), ctypes.c_uint64(int(seed)),
+        _lib.check(self._L.bhmm_sample_paths(self._h, A, pi, p0, p1, _lib.dp(uu), ctypes.c_uint64(int(seed)),
                                              _lib.ip(paths), _lib.lp(C), _lib.lp(n0),
                                              _lib.dp(emis)))
         plist = None

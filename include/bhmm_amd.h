@@ -227,6 +227,8 @@ int bhmm_ctx_chunk_len(const bhmm_ctx *ctx);
  * HIP events on the context's stream.  which: 0 prescan, 1 stitch, 2 forward-backward,
  * 3 finalize, 4 whole E-step. Valid after bhmm_estep_fetch (or a stream sync). */
 double bhmm_ctx_last_kernel_ms(bhmm_ctx *ctx, int which);
+/* all five at once: out[5] (one call inside a timed loop instead of five) */
+int bhmm_ctx_last_kernel_ms_all(bhmm_ctx *ctx, double *out);
 void *bhmm_ctx_stream(bhmm_ctx *ctx);
 int bhmm_ctx_sync(bhmm_ctx *ctx);
 /* Measurement / test support: K synthetic trajectories of T steps each, drawn ON
