@@ -1085,29 +1085,119 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
     }
 }
 
-// exp_nonpos() with its Horner steps pinned to the three-address v_fma_f64 (horner_step,
-// wide_kernels.hpp): the same twelve fused multiply-adds, hence the same bits, without the ten
-// coefficient moves the two-address v_fmac_f64 form costs -- the Viterbi kernels are bound by the
-// length of their instruction stream.
-__device__ __forceinline__ double exp_nonpos_issue(double x)
+// ---- instruction-count diet of the chunked Viterbi step (round 3) ------------------------------
+// The chunked Viterbi kernel is bound by the length of its instruction stream (four wavefronts per
+// SIMD at ~0.9 of the issue ceiling), so what follows removes instructions without touching a
+// single rounding:
+//  * exp_nonpos() as ONE assembly block: the same range reduction and the same twelve fused
+//    multiply-adds (hence the same bits), coefficients in scalar registers, the constant of the
+//    density multiplied in the block.  As separate statements the compiler protects every inline
+//    v_fma_f64 against its successor with an s_nop (its hazard model does not look inside assembly),
+//    eleven wasted issue slots per density; dependent v_fma_f64 need no wait state.
+//  * the first-maximum argmax over eight products as one block: compares into scalar pairs,
+//    v_max_f64 for the values, v_cndmask for the indices, ordered so that every select finds its
+//    mask two wait states old (the gfx950 rule for a VALU read of a VALU-written SGPR) -- 21
+//    instructions where the compiler's select tree took 26 plus five s_nop.  take = b > a, value
+//    max(a, b): identical to `take ? b : a` for the non-negative finite products of this recursion.
+//  * the division by sigma of _gaussian.c:18 as q0 = x r, d = q0 + r (x - q0 sigma) with
+//    r = RN(1 / sigma): three instructions instead of the thirteen of an IEEE division by a
+//    run-time value, and the correctly rounded quotient all the same (Markstein's theorem for a
+//    correctly rounded reciprocal; checked here against x / sigma on 1.5e9 random and
+//    special-mantissa pairs without a mismatch).  An infinite observation gives NaN instead of inf,
+//    which the clamp of the exponent turns into the same exact zero.
+__device__ __forceinline__ double gauss_exp_block(double x, double cn)
 {
     x = fmax(x, -750.0);
     const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
     double r = fma(k, -0x1.62e42fefa39efp-1, x);
     r = fma(k, -0x1.abc9e3b39803fp-56, r);
-    double q = 0x1.ad7e38e167506p-26;
-    q = horner_step(q, r, 0x1.28ae7908135d8p-22);
-    q = horner_step(q, r, 0x1.71df27c33abefp-19);
-    q = horner_step(q, r, 0x1.a01998fd42e01p-16);
-    q = horner_step(q, r, 0x1.a01a012882c92p-13);
-    q = horner_step(q, r, 0x1.6c16c184889e3p-10);
-    q = horner_step(q, r, 0x1.111111112836cp-7);
-    q = horner_step(q, r, 0x1.55555555506eap-5);
-    q = horner_step(q, r, 0x1.55555555554f7p-3);
-    q = horner_step(q, r, 0x1.000000000000ap-1);
-    q = horner_step(q, r, 1.0);
-    q = horner_step(q, r, 1.0);
-    return ldexp(q, (int)k);
+    const int ki = (int)k;
+    double q;
+    asm("v_fma_f64 %0, %2, %1, %3\n\t"
+        "v_fma_f64 %0, %0, %1, %4\n\t"
+        "v_fma_f64 %0, %0, %1, %5\n\t"
+        "v_fma_f64 %0, %0, %1, %6\n\t"
+        "v_fma_f64 %0, %0, %1, %7\n\t"
+        "v_fma_f64 %0, %0, %1, %8\n\t"
+        "v_fma_f64 %0, %0, %1, %9\n\t"
+        "v_fma_f64 %0, %0, %1, %10\n\t"
+        "v_fma_f64 %0, %0, %1, %11\n\t"
+        "v_fma_f64 %0, %0, %1, 1.0\n\t"
+        "v_fma_f64 %0, %0, %1, 1.0\n\t"
+        "v_ldexp_f64 %0, %0, %12\n\t"
+        "v_mul_f64 %0, %13, %0"
+        : "=&v"(q)
+        : "v"(r), "v"(0x1.ad7e38e167506p-26), "s"(0x1.28ae7908135d8p-22), "s"(0x1.71df27c33abefp-19),
+          "s"(0x1.a01998fd42e01p-16), "s"(0x1.a01a012882c92p-13), "s"(0x1.6c16c184889e3p-10),
+          "s"(0x1.111111112836cp-7), "s"(0x1.55555555506eap-5), "s"(0x1.55555555554f7p-3),
+          "s"(0x1.000000000000ap-1), "v"(ki), "v"(cn));
+    return q;
+}
+
+// index of the FIRST maximum of h[0..7] (_hidden.c:186-200: `if (h > best)`), and the maximum when
+// WANT_MAX.  h is destroyed.
+template <bool WANT_MAX>
+__device__ __forceinline__ int argmax8_block(double (&h)[8], double &mx)
+{
+    int i0, i1, i2, i3;
+    unsigned long long s0, s1, s2, s3;
+    if constexpr (WANT_MAX) {
+        asm("v_cmp_gt_f64 %[s0], %[h1], %[h0]\n\t"
+            "v_cmp_gt_f64 %[s1], %[h3], %[h2]\n\t"
+            "v_cmp_gt_f64 %[s2], %[h5], %[h4]\n\t"
+            "v_cmp_gt_f64 %[s3], %[h7], %[h6]\n\t"
+            "v_max_f64 %[h0], %[h0], %[h1]\n\t"
+            "v_max_f64 %[h2], %[h2], %[h3]\n\t"
+            "v_max_f64 %[h4], %[h4], %[h5]\n\t"
+            "v_max_f64 %[h6], %[h6], %[h7]\n\t"
+            "v_cndmask_b32 %[i0], 0, 1, %[s0]\n\t"
+            "v_cndmask_b32 %[i1], 2, 3, %[s1]\n\t"
+            "v_cndmask_b32 %[i2], 4, 5, %[s2]\n\t"
+            "v_cndmask_b32 %[i3], 6, 7, %[s3]\n\t"
+            "v_cmp_gt_f64 %[s0], %[h2], %[h0]\n\t"
+            "v_cmp_gt_f64 %[s1], %[h6], %[h4]\n\t"
+            "v_max_f64 %[h0], %[h0], %[h2]\n\t"
+            "v_max_f64 %[h4], %[h4], %[h6]\n\t"
+            "v_cndmask_b32 %[i0], %[i0], %[i1], %[s0]\n\t"
+            "v_cndmask_b32 %[i2], %[i2], %[i3], %[s1]\n\t"
+            "v_cmp_gt_f64 %[s0], %[h4], %[h0]\n\t"
+            "v_max_f64 %[h0], %[h0], %[h4]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32 %[i0], %[i0], %[i2], %[s0]"
+            : [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3), [s0] "=&s"(s0),
+              [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [h0] "+v"(h[0]), [h2] "+v"(h[2]),
+              [h4] "+v"(h[4]), [h6] "+v"(h[6])
+            : [h1] "v"(h[1]), [h3] "v"(h[3]), [h5] "v"(h[5]), [h7] "v"(h[7]));
+        mx = h[0];
+    } else {
+        asm("v_cmp_gt_f64 %[s0], %[h1], %[h0]\n\t"
+            "v_cmp_gt_f64 %[s1], %[h3], %[h2]\n\t"
+            "v_cmp_gt_f64 %[s2], %[h5], %[h4]\n\t"
+            "v_cmp_gt_f64 %[s3], %[h7], %[h6]\n\t"
+            "v_max_f64 %[h0], %[h0], %[h1]\n\t"
+            "v_max_f64 %[h2], %[h2], %[h3]\n\t"
+            "v_max_f64 %[h4], %[h4], %[h5]\n\t"
+            "v_max_f64 %[h6], %[h6], %[h7]\n\t"
+            "v_cndmask_b32 %[i0], 0, 1, %[s0]\n\t"
+            "v_cndmask_b32 %[i1], 2, 3, %[s1]\n\t"
+            "v_cndmask_b32 %[i2], 4, 5, %[s2]\n\t"
+            "v_cndmask_b32 %[i3], 6, 7, %[s3]\n\t"
+            "v_cmp_gt_f64 %[s0], %[h2], %[h0]\n\t"
+            "v_cmp_gt_f64 %[s1], %[h6], %[h4]\n\t"
+            "v_max_f64 %[h0], %[h0], %[h2]\n\t"
+            "v_max_f64 %[h4], %[h4], %[h6]\n\t"
+            "v_cndmask_b32 %[i0], %[i0], %[i1], %[s0]\n\t"
+            "v_cndmask_b32 %[i2], %[i2], %[i3], %[s1]\n\t"
+            "v_cmp_gt_f64 %[s0], %[h4], %[h0]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %[i0], %[i0], %[i2], %[s0]"
+            : [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3), [s0] "=&s"(s0),
+              [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [h0] "+v"(h[0]), [h2] "+v"(h[2]),
+              [h4] "+v"(h[4]), [h6] "+v"(h[6])
+            : [h1] "v"(h[1]), [h3] "v"(h[3]), [h5] "v"(h[5]), [h7] "v"(h[7]));
+        mx = 0.0;
+    }
+    return i0;
 }
 
 // =========================================================================================
@@ -1135,6 +1225,11 @@ __device__ __forceinline__ double exp_nonpos_issue(double x)
 // host runs this form first -- when every boundary vector comes out bit-identical to the
 // predecessor's, which is the normal case, the run IS the serial run and the count is not looked at
 // -- and repeats with MARGIN = true only otherwise.
+// The steps run in blocks of VPF.  A block in which every chunk of the wavefront is in its warm-up,
+// or every chunk is past it and at least two blocks from its end, takes a form without per-step
+// conditions (no back-pointer store / an unconditional one, no clamp of the prefetch address, the
+// outlier rule looked at only when a normalising sum is exactly zero); the first block of a
+// trajectory, the block in which a warm-up ends and the last two blocks take the general form.
 template <int NP, int KIND = EMIT_EXPL, bool MARGIN = true>
 __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const Chunks ch, int G,
                                                        const int64_t *toff, const void *src,
@@ -1148,10 +1243,10 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
     [[maybe_unused]] const double *pobs = static_cast<const double *>(src);
     [[maybe_unused]] const int32_t *syms = static_cast<const int32_t *>(src);
     constexpr int GP = 64 / NP;
-    static_assert(NP <= 16, "one argmax tile");
+    static_assert(NP == 8, "argmax8_block");
     __shared__ __attribute__((aligned(16))) double xv[GP][NP];
     __shared__ __attribute__((aligned(16))) double xn[GP][NP];
-    // A for the winner's factor: the select tree below carries only (product, index); v[i^] and
+    // A for the winner's factor: the argmax carries only (product, index); v[i^] and
     // A[i^][j] are looked up afterwards (two LDS reads instead of four more registers per select)
     __shared__ double sA[NP * NP];
     extern __shared__ double sBdyn[]; // discrete: B [n][M] when the launch provides the room
@@ -1174,6 +1269,7 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
     if (len > 0) {
         const int n = m.n;
         const bool real = j < n;
+        const bool allreal = n == NP; // (uniform) every lane stores a back-pointer
         double Acol[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i)
@@ -1201,11 +1297,99 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
             else
                 pring[q] = real ? pobs[t * n + j] : 0.0;
         };
+        // the same without the clamp, for blocks at least VPF steps from the end of the chunk
+        auto request_inside = [&](int q, int sidx) {
+            const int64_t t = gs + sidx;
+            if constexpr (KIND == EMIT_DISC)
+                sring[q] = syms[t];
+            else if constexpr (KIND == EMIT_GAUSS)
+                pring[q] = pobs[t];
+            else
+                pring[q] = real ? pobs[t * n + j] : 0.0;
+        };
         [[maybe_unused]] const double mu_j = (KIND == EMIT_GAUSS && real) ? m.mu[j] : 0.0;
         [[maybe_unused]] const double sg_j = (KIND == EMIT_GAUSS && real) ? m.sigma[j] : 1.0;
+        [[maybe_unused]] const double rs_j = 1.0 / sg_j; // correctly rounded: IEEE division
         [[maybe_unused]] const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
         [[maybe_unused]] const unsigned long long grp =
             (NP == 64 ? ~0ull : ((1ull << NP) - 1)) << (lane / NP * NP);
+        // emission probability of the lane's state from ring slot q (outlier rule not applied)
+        auto emission = [&](int q) -> double {
+            if constexpr (KIND == EMIT_DISC) {
+                const int sym = sring[q];
+                return !real ? 0.0 : (sBd ? sBd[j * m.M + sym] : m.B[(int64_t)j * m.M + sym]);
+            } else if constexpr (KIND == EMIT_GAUSS) {
+                const double x = pring[q] - mu_j;
+                const double q0 = x * rs_j;
+                const double d = fma(fma(-q0, sg_j, x), rs_j, q0); // == x / sigma, _gaussian.c:18
+                return gauss_exp_block(-0.5 * d * d, cn_j); // cn_j = 0 on padding lanes
+            } else {
+                return pring[q];
+            }
+        };
+        auto ordered_sum = [&]() -> double {
+            double xs[NP];
+#pragma unroll
+            for (int i = 0; i < NP; i += 2) {
+                const double2 x = *reinterpret_cast<const double2 *>(&xn[gi][i]);
+                xs[i] = x.x;
+                xs[i + 1] = x.y;
+            }
+            double S = 0.0 + xs[0]; // (the reference's sum starts from zero: -0 becomes +0)
+#pragma unroll
+            for (int i = 1; i < NP; ++i)
+                S += xs[i]; // ascending order; padded states add exact zeros
+            return S;
+        };
+        // one step without conditions on the step number.  MAIN: back-pointer stored at pq.
+        auto fast_step = [&](auto main_tag, auto allreal_tag, double p, uint8_t *pq) {
+            constexpr bool MAIN = decltype(main_tag)::value;
+            constexpr bool ALLREAL = decltype(allreal_tag)::value;
+            xv[gi][j] = v;
+            double hh[NP];
+            [[maybe_unused]] double h0[NP];
+#pragma unroll
+            for (int i = 0; i < NP; i += 2) {
+                const double2 x = *reinterpret_cast<const double2 *>(&xv[gi][i]);
+                hh[i] = x.x * Acol[i]; // _hidden.c:249
+                hh[i + 1] = x.y * Acol[i + 1];
+            }
+            if constexpr (MAIN && MARGIN) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    h0[i] = hh[i];
+            }
+            double mx;
+            const int ib = argmax8_block<MAIN && MARGIN>(hh, mx);
+            if constexpr (MAIN) {
+                if (ALLREAL || real)
+                    *pq = (uint8_t)ib;
+                if constexpr (MARGIN) {
+                    const double thr = mx - margin * mx;
+                    int cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        cnt += (h0[i] >= thr) ? 1 : 0;
+                    low |= real && cnt != 1;
+                }
+            }
+            const double bv = xv[gi][ib], bA = sA[ib * NP + j];
+            double vn = p * bv * bA; // _hidden.c:253: (p v[i^]) A[i^][j]
+            xn[gi][j] = vn;
+            double S = ordered_sum();
+            if constexpr (KIND == EMIT_GAUSS) {
+                // outputmodel.py:126-130 (an all-zero emission row counts as all ones): such a row
+                // makes every product of its chunk zero, so it is looked for only then
+                if (__any(S == 0.0)) {
+                    if ((__ballot(p != 0.0) & grp) == 0ull)
+                        p = real ? 1.0 : 0.0;
+                    vn = p * bv * bA;
+                    xn[gi][j] = vn;
+                    S = ordered_sum();
+                }
+            }
+            v = vn / S;
+        };
 #pragma unroll
         for (int q = 0; q < VPF; ++q) {
             pring[q] = 0.0;
@@ -1213,22 +1397,48 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
             request(q, q);
         }
         for (int sb = 0; sb < steps; sb += VPF) {
+            // (per wavefront: the chunks of a wavefront differ in nw at the start of a trajectory
+            // and by one step in length)
+            const bool inside = sb + 2 * VPF <= steps && (sb > 0 || !exact);
+            if (__all(inside && sb + VPF <= nw)) {
+#pragma unroll
+                for (int qq = 0; qq < VPF; ++qq) {
+                    const double p = emission(qq);
+                    request_inside(qq, sb + qq + VPF);
+                    fast_step(std::false_type{}, std::false_type{}, p, nullptr);
+                }
+                if (sb + VPF == nw)
+                    v_entry[g * NP + j] = v; // the vector this chunk starts from
+                continue;
+            }
+            if (__all(inside && sb >= nw)) {
+                uint8_t *pq = ptr + (gs + sb) * n + j;
+                if (allreal) {
+#pragma unroll
+                    for (int qq = 0; qq < VPF; ++qq) {
+                        const double p = emission(qq);
+                        request_inside(qq, sb + qq + VPF);
+                        fast_step(std::true_type{}, std::true_type{}, p, pq + qq * NP);
+                    }
+                } else {
+#pragma unroll
+                    for (int qq = 0; qq < VPF; ++qq) {
+                        const double p = emission(qq);
+                        request_inside(qq, sb + qq + VPF);
+                        fast_step(std::true_type{}, std::false_type{}, p, pq + qq * n);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
         for (int qq = 0; qq < VPF; ++qq) {
             const int s = sb + qq;
             if (s >= steps)
                 break;
-            double p;
-            if constexpr (KIND == EMIT_DISC) {
-                const int sym = sring[qq];
-                p = !real ? 0.0 : (sBd ? sBd[j * m.M + sym] : m.B[(int64_t)j * m.M + sym]);
-            } else if constexpr (KIND == EMIT_GAUSS) {
-                const double d = (pring[qq] - mu_j) / sg_j; // _gaussian.c:18-20
-                p = real ? cn_j * exp_nonpos_issue(-0.5 * d * d) : 0.0;
+            double p = emission(qq);
+            if constexpr (KIND == EMIT_GAUSS) {
                 if ((__ballot(p != 0.0) & grp) == 0ull)
                     p = real ? 1.0 : 0.0; // outputmodel.py:126-130
-            } else {
-                p = pring[qq];
             }
             request(qq, s + VPF);
             double vn;
@@ -1282,19 +1492,7 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
                 vn = p * xv[gi][ii[0]] * sA[ii[0] * NP + j]; // _hidden.c:253: (p v[i^]) A[i^][j]
             }
             xn[gi][j] = vn;
-            double S = 0.0;
-            {
-                double xs[NP];
-#pragma unroll
-                for (int i = 0; i < NP; i += 2) {
-                    const double2 x = *reinterpret_cast<const double2 *>(&xn[gi][i]);
-                    xs[i] = x.x;
-                    xs[i + 1] = x.y;
-                }
-#pragma unroll
-                for (int i = 0; i < NP; ++i)
-                    S += xs[i]; // ascending order; padded states add exact zeros
-            }
+            const double S = ordered_sum();
             v = vn / S;
             if (s == nw - 1)
                 v_entry[g * NP + j] = v; // the vector this chunk starts from
