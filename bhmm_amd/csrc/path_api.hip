@@ -265,7 +265,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     c->viterbi_chunked = false;
     const size_t gpad = c->wide ? 0 : (size_t)c->Gp;
     if ((rc = c->d_scratch.ensure((size_t)c->total * n)) ||
-        (rc = c->d_scratch2.ensure(((size_t)c->total + K + 2 * gpad) * sizeof(int32_t))))
+        (rc = c->d_scratch2.ensure(((size_t)c->total + K + 3 * gpad) * sizeof(int32_t))))
         return rc;
     uint8_t *ptr = reinterpret_cast<uint8_t *>(c->d_scratch.p);
     int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
@@ -273,6 +273,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     uint8_t *path8 = out_fmt == 2 ? static_cast<uint8_t *>(paths_out) : reinterpret_cast<uint8_t *>(path);
     uint32_t *vmaps = reinterpret_cast<uint32_t *>(path + c->total); // chunked run: chunk maps,
     int32_t *vend = reinterpret_cast<int32_t *>(vmaps + gpad);       // state at each chunk's end
+    int32_t *vcoal = vend + gpad; // step below which the map pass wrote the path itself (k_vit_walk)
     // U trajectories per lane group.  Measured on configs[1] (256 trajectories): the kernel is
     // bound by the instruction stream of each wavefront, not by latency, and SIMDs are plentiful
     // (32 of 1024 busy), so U = 1 is fastest (U = 4 was 3.5x slower); the parameter stays for
@@ -419,8 +420,12 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     if (done) {
         const Chunks chs = chunks_pub(c);
         const dim3 wg((c->G + 7) / 8);
-        hipLaunchKernelGGL((k_vit_walk<8, false>), wg, dim3(64), 0, c->stream, chs, c->G, n,
-                           (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, (int32_t *)nullptr);
+        if (out_fmt == 0)
+            hipLaunchKernelGGL((k_vit_walk<8, false, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                               (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, path, vcoal);
+        else
+            hipLaunchKernelGGL((k_vit_walk<8, false, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                               (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, path8, vcoal);
         if ((int64_t)c->G >= (int64_t)32 * K)
             hipLaunchKernelGGL(k_smp_stitch, dim3(K), dim3(64), 0, c->stream,
                                (const int32_t *)c->d_traj_c0.p, K, 1, (const uint32_t *)vmaps, vend,
@@ -431,10 +436,10 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                                (const uint32_t *)vmaps, vend, (const int32_t *)last);
         if (out_fmt == 0)
             hipLaunchKernelGGL((k_vit_walk<8, true, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
-                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path);
+                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path, vcoal);
         else
             hipLaunchKernelGGL((k_vit_walk<8, true, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
-                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path8);
+                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path8, vcoal);
     } else if (out_fmt == 0) {
         hipLaunchKernelGGL(k_wide_viterbi_trace<int32_t>, dim3(K), dim3(64), 0, c->stream, off, K, n,
                            (const uint8_t *)ptr, (const int32_t *)last, path);

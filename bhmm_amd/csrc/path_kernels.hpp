@@ -1551,10 +1551,15 @@ __global__ void k_viterbi_check(const Chunks ch, int G, const double *v_entry, c
 // trajectory from its final state, k_vit_walk<true> re-walks every chunk from its known last state
 // and writes the path (_hidden.c:269-272).  Back-pointer rows are staged through LDS 64 steps at
 // a time; a dependent chain of global byte loads would be latency bound.
+// The survivors of a Viterbi recursion coalesce: a few dozen steps below the end of a chunk all
+// eight candidates have walked into the same state, and from there down the path does not depend
+// on what follows the chunk.  The map pass notices that at a tile boundary (step coal[g]), writes
+// the path below it itself, and the second pass walks only the steps above -- one walk over the
+// back-pointers instead of two.
 template <int NP, bool APPLY, typename PT = int32_t>
 __global__ __launch_bounds__(64) void k_vit_walk(const Chunks ch, int G, int n, const uint8_t *ptr,
                                                  const int32_t *end_state, uint32_t *maps,
-                                                 PT *path)
+                                                 PT *path, int32_t *coal)
 {
     constexpr int GP = 64 / NP;
     __shared__ uint8_t tile[GP][64 * NP];
@@ -1571,23 +1576,40 @@ __global__ __launch_bounds__(64) void k_vit_walk(const Chunks ch, int G, int n, 
         // chunk that does not start its trajectory leads into the previous chunk (maps only)
         const int s_lo = (APPLY || first) ? 1 : 0;
         int cur = APPLY ? end_state[g] : e;
+        // APPLY: the path below step `stop` is there already.  Maps: `agreed` once the candidates
+        // have met; -1 = they never did (then the second pass walks the whole chunk)
+        const int stop = APPLY ? coal[g] : -1;
+        bool agreed = false;
+        int met = -1;
         if (APPLY && e == 0)
             path[goff + len - 1] = (PT)cur;
-        for (int hi = len - 1; hi >= s_lo; hi -= 64) {
+        for (int hi = len - 1; hi >= s_lo && hi > stop; hi -= 64) {
             const int lo = hi - 63 > s_lo ? hi - 63 : s_lo;
             const int cnt = hi - lo + 1;
             const int64_t base = (goff + lo) * n;
             for (int b = e; b < cnt * n; b += NP)
                 tile[gi][b] = ptr[base + b];
+            const bool writing = APPLY || agreed;
             for (int q = cnt - 1; q >= 0; --q) {
                 cur = tile[gi][q * n + cur];
-                if (APPLY && e == 0)
+                if (writing && e == 0)
                     outp[gi][q] = cur; // path at step lo + q - 1
             }
-            if constexpr (APPLY)
+            if (writing) {
                 for (int q = e; q < cnt; q += NP)
-                    path[goff + lo - 1 + q] = (PT)outp[gi][q];
+                    if (lo - 1 + q >= 0) // (row 0 of a later chunk points into its predecessor)
+                        path[goff + lo - 1 + q] = (PT)outp[gi][q];
+            } else {
+                const int c0 = __shfl(cur, 0, NP);
+                const unsigned long long same = __ballot(cur == c0);
+                if (((same >> (gi * NP)) & ((1ull << NP) - 1)) == ((1ull << NP) - 1)) {
+                    agreed = true;
+                    met = lo - 1; // every candidate is in the same state at this step
+                }
+            }
         }
+        if (!APPLY && e == 0)
+            coal[g] = met;
         packed = (unsigned int)cur << (4 * e);
     }
     if constexpr (!APPLY) {
