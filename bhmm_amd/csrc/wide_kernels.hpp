@@ -49,18 +49,26 @@ __device__ __forceinline__ double gauss_pdf_issue(double d, double a, double b, 
     const double u = fmin(fma(d * d, a, b), 1.0);
     const double t = MG - u;
     const double w = (t - MG) + u;
-    double q = 0x1.e3991e644e6abp+92;
-    q = horner_step(q, w, -0x1.b6740fc28f781p+84);
-    q = horner_step(q, w, 0x1.62c157ee59177p+76);
-    q = horner_step(q, w, -0x1.ffcb55e82f22cp+67);
-    q = horner_step(q, w, 0x1.4309126056718p+59);
-    q = horner_step(q, w, -0x1.5d87fe9cc5d6fp+50);
-    q = horner_step(q, w, 0x1.3b2ab6fbde0f7p+41);
-    q = horner_step(q, w, -0x1.c6b08d703d48ap+31);
-    q = horner_step(q, w, 0x1.ebfbdff82c3b9p+21);
-    q = horner_step(q, w, -0x1.62e42fefa3a17p+11);
-    q = fma(q, w, 1.0);
-    return ldexp(q, __double2loint(t));
+    // the polynomial and the exponent as ONE block (separate statements: an s_nop between every two
+    // of them, see dot16); same ten fused multiply-adds, coefficients in scalar registers
+    double q;
+    asm("v_fma_f64 %0, %2, %1, %3\n\t"
+        "v_fma_f64 %0, %0, %1, %4\n\t"
+        "v_fma_f64 %0, %0, %1, %5\n\t"
+        "v_fma_f64 %0, %0, %1, %6\n\t"
+        "v_fma_f64 %0, %0, %1, %7\n\t"
+        "v_fma_f64 %0, %0, %1, %8\n\t"
+        "v_fma_f64 %0, %0, %1, %9\n\t"
+        "v_fma_f64 %0, %0, %1, %10\n\t"
+        "v_fma_f64 %0, %0, %1, %11\n\t"
+        "v_fma_f64 %0, %0, %1, 1.0\n\t"
+        "v_ldexp_f64 %0, %0, %12"
+        : "=&v"(q)
+        : "v"(w), "v"(0x1.e3991e644e6abp+92), "s"(-0x1.b6740fc28f781p+84), "s"(0x1.62c157ee59177p+76),
+          "s"(-0x1.ffcb55e82f22cp+67), "s"(0x1.4309126056718p+59), "s"(-0x1.5d87fe9cc5d6fp+50),
+          "s"(0x1.3b2ab6fbde0f7p+41), "s"(-0x1.c6b08d703d48ap+31), "s"(0x1.ebfbdff82c3b9p+21),
+          "s"(-0x1.62e42fefa3a17p+11), "v"(__double2loint(t)));
+    return q;
 }
 
 // ---- 64 states, one trajectory segment per wavefront: cross-lane forms of gfx950 ----------------
@@ -163,14 +171,37 @@ __device__ __forceinline__ void fmac_bcast(double &acc, const double &src, const
                      : "v"(src), "v"(w), "n"(I));
 }
 
-// acc[i & 3] += v[16 ROW + i] * w(i), i = 0..15, with v given as its row copy `src`
+// acc[i & 3] += v[16 ROW + i] * w(i), i = 0..15, with v given as its row copy `src`.
+// ONE assembly block: as sixteen statements the compiler separates every fourth from its
+// predecessor with an s_nop (its hazard model counts an inline statement as zero wait states, so the
+// accumulator written four instructions earlier looks freshly written) -- a seventh of the forward
+// kernel's instruction stream was such padding.
 template <typename WF>
 __device__ __forceinline__ void dot16(double (&acc)[4], const double &src, WF &&w)
 {
-    unrolled<16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        fmac_bcast<i, i == 0>(acc[i & 3], src, w(ic));
-    });
+#define BHMM_W(I) "v"(w(std::integral_constant<int, I>{}))
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                 : "v"(src), BHMM_W(0), BHMM_W(1), BHMM_W(2), BHMM_W(3), BHMM_W(4), BHMM_W(5), BHMM_W(6),
+                   BHMM_W(7), BHMM_W(8), BHMM_W(9), BHMM_W(10), BHMM_W(11), BHMM_W(12), BHMM_W(13),
+                   BHMM_W(14), BHMM_W(15));
+#undef BHMM_W
 }
 
 // sum / max over all 64 lanes, result in every lane (fixed order)
