@@ -497,7 +497,7 @@ __device__ __forceinline__ uint32_t smp_compose(uint32_t first, uint32_t then)
         c |= ((then >> (4 * ((first >> (4 * y)) & 7u))) & 7u) << (4 * y);
     return c;
 }
-static __global__ __launch_bounds__(64) void k_smp_stitch(const int32_t *traj_c0, int K, int P,
+[[maybe_unused]] static __global__ __launch_bounds__(64) void k_smp_stitch(const int32_t *traj_c0, int K, int P,
                                                           const uint32_t *Fmap, int32_t *next_state,
                                                           const int32_t *start = nullptr)
 {
@@ -549,7 +549,7 @@ static __global__ __launch_bounds__(64) void k_smp_stitch(const int32_t *traj_c0
 // The same chain walked by ONE lane per trajectory: for batches of many short trajectories (a
 // few maps each), where a wavefront per trajectory would be mostly idle.
 constexpr int SMP_STITCH_TPB = 8;
-static __global__ __launch_bounds__(64) void k_smp_stitch_serial(const int32_t *traj_c0, int K, int P,
+[[maybe_unused]] static __global__ __launch_bounds__(64) void k_smp_stitch_serial(const int32_t *traj_c0, int K, int P,
                                                           const uint32_t *Fmap, int32_t *next_state,
                                                           const int32_t *start = nullptr)
 {
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) void k_smp_apply(const Model<N> m, const Chunk
 
 // ---- small reference-shaped kernels on row-major arrays ------------------------------------
 // gamma_t = alpha_t o beta_t / sum (hidden/api.py:176-186); one thread per time step.
-static __global__ void k_gamma_rows(const double *alpha, const double *beta, double *gamma, int n,
+[[maybe_unused]] static __global__ void k_gamma_rows(const double *alpha, const double *beta, double *gamma, int n,
                              int64_t T)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,7 +756,7 @@ static __global__ void k_gamma_rows(const double *alpha, const double *beta, dou
 }
 
 // Gaussian pdf rows (_gaussian.c:45-70) + outlier rule; one thread per time step.
-static __global__ void k_pobs_gaussian(const double *obs, const double *mu, const double *sigma,
+[[maybe_unused]] static __global__ void k_pobs_gaussian(const double *obs, const double *mu, const double *sigma,
                                 double *pobs, int n, int64_t T, int ignore_outliers)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -851,7 +851,7 @@ __global__ void k_sum_partials(const double *partials, int nblocks, int n, doubl
 
 // weighted symbol counts pout[i][obs[t]] += w[t][i] (_discrete.c:1-32): one block per
 // state-row slab; fp64 atomics into an LDS histogram, then one ordered flush.
-static __global__ void k_update_pout(const int32_t *obs, const double *w, int64_t T, int n, int M,
+[[maybe_unused]] static __global__ void k_update_pout(const int32_t *obs, const double *w, int64_t T, int n, int M,
                               double *pout_partials)
 {
     extern __shared__ double hist[]; // [n][M]
@@ -871,7 +871,7 @@ static __global__ void k_update_pout(const int32_t *obs, const double *w, int64_
 
 // dst[e] += sum_b partials[b][e]: one wavefront per entry (a single thread walking all blocks
 // is bound by the latency of its dependent loads), fixed summation tree
-static __global__ __launch_bounds__(64) void k_add_partials(const double *partials, int nblocks, int count,
+[[maybe_unused]] static __global__ __launch_bounds__(64) void k_add_partials(const double *partials, int nblocks, int count,
                                                      double *dst)
 {
     const int e = blockIdx.x;
@@ -890,7 +890,7 @@ static __global__ __launch_bounds__(64) void k_add_partials(const double *partia
 // all-reduce.  Counts are integers below 2^53: their fp64 sums are exact in any order.
 //   cnt  : [Ns*Ns + Ns] integer counts with row stride Ns (the padded state count)
 //   ered : gaussian [3][Ns]; discrete [M][Ns] when `transposed`, else [n][M]
-static __global__ void k_pack_path_stats(const unsigned long long *cnt, const double *ered, int n, int Ns,
+[[maybe_unused]] static __global__ void k_pack_path_stats(const unsigned long long *cnt, const double *ered, int n, int Ns,
                                   int M, int kind, int transposed, double *out)
 {
     const int nn = n * n;

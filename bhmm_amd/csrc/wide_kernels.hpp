@@ -829,7 +829,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const WideModel m, const int64_
 // every wavefront owns a stretch of time steps and the full 64 x 64 tile -- 16 v_mfma_f64_16x16x4
 // per four steps on eight 512-byte loads, accumulators in 128 registers -- and leaves its partial
 // sum in xipart[split]; k_wide_xi_reduce adds them in split order into segment 0's block of `part`.
-static __global__ __launch_bounds__(64) void k_wide_xi_gemm64(const double *alpha, const double *W,
+[[maybe_unused]] static __global__ __launch_bounds__(64) void k_wide_xi_gemm64(const double *alpha, const double *W,
                                                         int64_t total, int nsplit, double *xipart)
 {
     const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
@@ -874,7 +874,7 @@ static __global__ __launch_bounds__(64) void k_wide_xi_gemm64(const double *alph
                 xipart[((int64_t)blockIdx.x * 64 + 16 * I + lk + 4 * r) * 64 + 16 * J + li] = acc[I][J][r];
 }
 
-static __global__ void k_wide_xi_reduce(const double *xipart, int nsplit, double *part)
+[[maybe_unused]] static __global__ void k_wide_xi_reduce(const double *xipart, int nsplit, double *part)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 64 * 64)
@@ -886,7 +886,7 @@ static __global__ void k_wide_xi_reduce(const double *xipart, int nsplit, double
 }
 
 // rows W_{T-1} of every trajectory: no transition leaves the last step
-static __global__ void k_wide_zero_last_rows(const int64_t *off, int K, int n, double *Wg)
+[[maybe_unused]] static __global__ void k_wide_zero_last_rows(const int64_t *off, int K, int n, double *Wg)
 {
     const int k = blockIdx.x;
     if (k < K && off[k + 1] > off[k])
