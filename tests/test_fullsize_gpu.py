@@ -122,6 +122,48 @@ def test_viterbi_full_size_chunked_and_bit_exact():
     eng.close()
 
 
+def test_chunked_viterbi_with_outliers_infinities_and_odd_sigmas():
+    """The condition-free step blocks of k_viterbi_chunks (path_kernels.hpp) on data that exercise what
+    they skip: observations 40 sigma from every state (all-zero emission rows -> outputmodel.py:126-130,
+    found there through a zero normalising sum), +-inf observations (the reciprocal form of the division
+    by sigma gives NaN where the quotient is inf; the clamp of the exponent must turn both into the same
+    zero), an observation exactly on a mean, sigmas with all-ones / power-of-two mantissas, fewer than 8
+    states (padding lanes) and ragged lengths whose warm-ups end inside a block.  Paths bit for bit."""
+    rng = np.random.default_rng(40)
+    for n in (8, 5, 2):
+        A = rng.random((n, n)) + np.eye(n) * 6.0
+        A /= A.sum(axis=1)[:, None]
+        pi = np.full(n, 1.0 / n)
+        mu = np.linspace(-3.0, 3.0, n)
+        sig = rng.uniform(0.4, 1.2, n)
+        sig[0] = np.nextafter(1.0, 0.0)             # mantissa all ones
+        sig[-1] = 0.5                               # power of two
+        lengths = (30011, 20000, 5003, 997)
+        obs = []
+        for T in lengths:
+            s = np.zeros(T, dtype=np.int64)
+            for t in range(1, T):
+                s[t] = s[t - 1] if rng.random() < 0.97 else rng.integers(0, n)
+            o = rng.normal(mu[s], sig[s])
+            bad = rng.choice(np.arange(600, T - 5), size=12, replace=False)
+            o[bad[:4]] = 80.0                       # density 0 for every state
+            o[bad[4:6]] = np.inf
+            o[bad[6:8]] = -np.inf
+            o[bad[8]] = mu[n // 2]                  # exactly on a mean
+            o[bad[9]] = 45.0 * sig.max() + mu[-1]   # in the last state's far tail only
+            o[bad[10]:bad[10] + 3] = -90.0          # three outliers in a row
+            obs.append(o)
+        eng = _engine()
+        eng.set_observations("gaussian", obs, n, chunk=640)
+        eng.estep(A, pi, mu, sig)                   # (calibrates the warm-up)
+        vp = eng.viterbi(A, pi, mu, sig)
+        assert eng.get_option("viterbi_chunked") == 1
+        for o, p in zip(obs, vp):
+            ref = orc.viterbi(A, orc.pobs_gaussian(o, mu, sig), pi)   # (outlier rule included)
+            assert np.array_equal(p, ref)
+        eng.close()
+
+
 # ---- E-step at T = 1e6 and at the configs[2] batch -----------------------------------------
 def test_one_million_step_discrete_trajectory_vs_oracle():
     """One T = 1e6 discrete trajectory (64-bit offsets inside a long trajectory, 1e6-term
