@@ -1246,6 +1246,7 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     c->spec_calibrated = c->spec_W_fixed;
     if (!c->spec_W_fixed)
         c->spec_W = 288;
+    c->vit_W = 0;
     c->wide_replans = 0;
     c->wseg_given_up = false;
     c->wide_careful = false;
@@ -1468,6 +1469,7 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
     } else if (n == "spec_W") {
         c->carry_valid = false;
         c->spec_W = std::max(1, (int)value);
+        c->vit_W = 0;
         c->spec_W_fixed = c->spec_calibrated = true; // the caller's choice: no probe
     }
     else if (n == "wide_segments")

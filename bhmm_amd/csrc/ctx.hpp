@@ -127,6 +127,7 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_tail;      // same layout as h_raw, written by k_tail (one D2H copy)
     bhmm::DevBuf<double> d_tbpart;    // k_tail: per trajectory block [sum logL | sum gamma_0 (N)]
     int tail_slot = 0;                // verdict word set of the next E-step
+    int vit_W = 0;                    // warm-up the chunked Viterbi last verified with (0: spec_W)
     unsigned int viterbi_close = 0;   // ... number of lanes that met a close decision
     bool viterbi_chunked = false;     // last bhmm_viterbi_batch ran chunk-parallel (verified)
     int wide_replans = 0;             // 9..64 states: segment plans re-made after failed checks

@@ -362,12 +362,17 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         const size_t smB = (disc_direct && c->kind == EMIT_DISC &&
                             (size_t)n * c->M * sizeof(double) <= 16 * 1024)
                                ? (size_t)n * c->M * sizeof(double) : 0;
+        // A warm-up too short for some boundary (the survivors of that stretch had not met yet) shows
+        // as a boundary out of tolerance: the run is repeated with twice, then four times the warm-up
+        // (one more pass of ~1 ms each) before the serial kernel (tens of ms) has to decide.
+        int W_try = std::max(c->spec_W, c->vit_W);
+        for (int attempt = 0; attempt < 3; ++attempt, W_try *= 2) {
         // first without the close-decision count; bit-identical boundaries make it irrelevant
         for (int pass = 0; pass < 2; ++pass) {
             BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
 #define BHMM_VC(KINDV, MARGINV)                                                                     \
     hipLaunchKernelGGL((k_viterbi_chunks<8, KINDV, MARGINV>), dim3((c->G + 7) / 8), dim3(64), smB,  \
-                       c->stream, m, chs, c->G, off, obs, c->spec_W, margin, ptr, last,             \
+                       c->stream, m, chs, c->G, off, obs, W_try, margin, ptr, last,             \
                        c->d_aentry.p, c->d_aexit.p, c->d_specres.p, smB ? 1 : 0)
             if (disc_direct && c->kind == EMIT_DISC) {
                 if (pass == 0)
@@ -396,6 +401,11 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
             BHMM_HIP(hipStreamSynchronize(c->stream));
             if (c->h_specres[3] == 0 || c->h_specres[0] != 0)
                 break; // the serial run outright / out of tolerance: the count cannot help
+        }
+        if (c->h_specres[0] == 0) {
+            c->vit_W = W_try; // (what worked is where the next call on these observations starts)
+            break; // every boundary within tolerance: a longer warm-up changes nothing
+        }
         }
         // all boundaries bit-identical: it is the serial run; else within tolerance and no
         // close decision

@@ -164,6 +164,45 @@ def test_chunked_viterbi_with_outliers_infinities_and_odd_sigmas():
         eng.close()
 
 
+def test_chunked_viterbi_recovers_from_a_warm_up_that_is_too_short():
+    """A warm-up of 32 steps does not bring the survivors of every chunk boundary together at the
+    configs[1] model (tools/viterbi_w.py: 96 is still too short, 128 suffices): the boundary check sees
+    it, the run is repeated with 64 and 128 steps and accepted -- the same paths, no serial kernel; the
+    next call starts from the length that worked."""
+    import time
+    import torch
+    from bench import make_c2_model
+    from bhmm_amd.engine import synth_observations
+    K, T = 64, 50000
+    m = make_c2_model()
+    obs = torch.empty(K * T, dtype=torch.float64, device="cuda:0")
+    synth_observations("gaussian", obs.data_ptr(), m["A"], m["pi"], m["mu"], m["sigma"], K, T, seed=5)
+    margs = (m["A_eval"], m["pi"], m["mu_eval"], m["sigma"])
+    ref = None
+    for W in (0, 32):
+        eng = _engine()
+        eng.set_observations_device("gaussian", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, 8,
+                                    chunk=782)
+        if W:
+            eng.set_option("spec_W", W)
+        paths = torch.empty(K * T, dtype=torch.uint8, device="cuda:0")
+        eng.viterbi_u8(*margs, out=paths)
+        assert eng.get_option("viterbi_chunked") == 1
+        if ref is None:
+            ref = paths.cpu().numpy().copy()
+            o = obs[:T].cpu().numpy()
+            assert np.array_equal(ref[:T], orc.viterbi(m["A_eval"], orc.pobs_gaussian(o, m["mu_eval"], m["sigma"]),
+                                                       m["pi"]))
+        else:
+            assert np.array_equal(paths.cpu().numpy(), ref)
+            t0 = time.perf_counter()
+            eng.viterbi_u8(*margs, out=paths)       # second call: no failed attempts any more
+            torch.cuda.synchronize()
+            assert time.perf_counter() - t0 < 0.02
+            assert np.array_equal(paths.cpu().numpy(), ref)
+        eng.close()
+
+
 # ---- E-step at T = 1e6 and at the configs[2] batch -----------------------------------------
 def test_one_million_step_discrete_trajectory_vs_oracle():
     """One T = 1e6 discrete trajectory (64-bit offsets inside a long trajectory, 1e6-term
