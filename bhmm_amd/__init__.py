@@ -24,3 +24,4 @@ MaximumLikelihoodHMM = MaximumLikelihoodEstimator   # name used by BASELINE.json
 BayesianHMM = BayesianHMMSampler                    # name used by BASELINE.json
 
 __version__ = "0.1"
+version = __version__          # (bhmm/__init__.py exposes `version` as well)
