@@ -1,0 +1,85 @@
+"""Test infrastructure (uses the oracle).  Random parity sweep for the two kernel families that the small-
+shape sweep does not reach: 9..64 states (lane-per-state kernels, wide_kernels.hpp) and 65..200 states
+(any-N family, gen_kernels.hpp) -- gaussian / discrete, ragged trajectories (lengths 1, 2, ... included),
+sparse transition matrices, zero entries in pi, far-away observations.  E-step statistics against the
+oracle (logL 1e-10, counts 1e-8), Viterbi and sampled paths (given the uniforms) bit for bit.
+Prints one line per failure and a summary; exit code 1 on failure."""
+import os, sys
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+from bhmm_amd.engine import Engine
+from oracle import oracle as orc
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 11)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = skipped = nbig = 0
+for case in range(ncase):
+    big = rng.random() < 0.35
+    n = int(rng.integers(65, 201)) if big else int(rng.integers(9, 65))
+    kind = "gaussian" if rng.random() < 0.5 else "discrete"
+    K = int(rng.integers(1, 6))
+    tmax = int(rng.choice([30, 300, 700])) if big else int(rng.choice([40, 500, 4000]))
+    lens = [int(x) for x in rng.integers(1, tmax, K)]
+    chunk = int(rng.choice([0, 0, 0, 17, 64, 250]))
+    A = rng.random((n, n)) ** 2 + rng.choice([0.0, 3.0, 20.0]) * np.eye(n)
+    if rng.random() < 0.4:
+        mask = rng.random((n, n)) < 0.4
+        np.fill_diagonal(mask, True)
+        A = A * mask
+    A /= A.sum(axis=1, keepdims=True)
+    pi = rng.dirichlet(np.ones(n))
+    if rng.random() < 0.3:
+        pi[rng.integers(0, n, 3)] = 0.0
+        pi /= pi.sum()
+    if kind == "gaussian":
+        mu, sig = np.sort(rng.normal(0, 0.15 * n, n)), rng.uniform(0.3, 2.0, n)
+        spread = 0.2 * n * (4.0 if rng.random() < 0.3 else 1.0)
+        obs = [rng.normal(0, spread, T) for T in lens]
+        par, M = (mu, sig), 0
+    else:
+        M = int(rng.choice([3, 40, 257, 1200]))
+        B = rng.dirichlet(np.ones(M) * 0.5, size=n) * 0.98 + 0.02 / M
+        obs = [rng.integers(0, M, T).astype(np.int32) for T in lens]
+        par = (B, None)
+    tag = "case %d: %s n=%d M=%d lens=%s chunk=%d" % (case, kind, n, M, lens, chunk)
+    try:
+        with np.errstate(all="ignore"):
+            ref = orc.estep(kind, obs, A, pi, *par)
+        if not (np.all(np.isfinite(ref["logL"])) and np.all(np.isfinite(ref["C"]))):
+            skipped += 1
+            continue
+        pobs = [orc.pobs_gaussian(o, *par) if kind == "gaussian" else orc.pobs_discrete(o, B) for o in obs]
+        if kind == "gaussian" and any(np.any((po.max(axis=1) < 1e-290)) for po in pobs):
+            skipped += 1
+            continue  # denormal emission rows: covered by stress_small against the 80-bit recursion
+        nbig += int(big)
+        eng = Engine(0)
+        eng.set_observations(kind, obs, n, nsymbols=M, chunk=chunk)
+        for rep in range(2):
+            res = eng.estep(A, pi, *par)
+            ok = (np.allclose(res.logL_k, ref["logL"], rtol=1e-10, atol=1e-10) and
+                  np.allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10) and
+                  np.allclose(res.gamma0_sum, ref["gamma0_sum"], rtol=1e-8, atol=1e-12) and
+                  np.allclose(res.state_counts, ref["state_counts"], rtol=1e-8, atol=1e-10))
+            if not ok:
+                bad += 1
+                print("ESTEP MISMATCH", tag, "rep", rep, np.abs(res.logL_k - ref["logL"]).max(), np.abs(res.C - ref["C"]).max())
+        vp = eng.viterbi(A, pi, *par)
+        for k, (p, po) in enumerate(zip(vp, pobs)):
+            vr = orc.viterbi(A, po, pi)
+            if not np.array_equal(p, vr):
+                bad += 1
+                print("VITERBI MISMATCH", tag, "traj", k, "differing steps", int((p != vr).sum()), "of", len(vr))
+        u = [rng.random(T) for T in lens]
+        sp = eng.sample_paths(A, pi, *par, u=u)[0]
+        for k, (p, po, uu) in enumerate(zip(sp, pobs, u)):
+            if not np.array_equal(p, orc.sample_path(orc.forward(A, po, pi)[1], A, u=uu)):
+                bad += 1
+                print("SAMPLE MISMATCH", tag, "traj", k)
+        eng.close()
+    except Exception as e:  # noqa
+        bad += 1
+        print("EXCEPTION", tag, repr(e)[:300])
+print("stress_many_states: %d cases (%d skipped: the reference itself leaves the floating-point range; %d with more than 64 states), %d failures" % (ncase, skipped, nbig, bad))
+sys.exit(1 if bad else 0)
