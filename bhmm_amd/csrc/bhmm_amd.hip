@@ -331,8 +331,13 @@ struct Runner {
         }
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
         c->ev_lean = true;
-        BHMM_HIP(hipMemcpyAsync(c->h_raw, c->d_tail.p, ntail * sizeof(double), hipMemcpyDeviceToHost,
-                                c->stream));
+        // many trajectories: their log-likelihoods (K doubles) stay on the device until somebody asks
+        // for them (bhmm_estep_fetch) -- a million of them are 8 MB over the host link per E-step,
+        // and an EM loop needs only their sum
+        c->logLk_prefetched = c->K <= 4096;
+        BHMM_HIP(hipMemcpyAsync(c->h_raw, c->d_tail.p,
+                                (c->logLk_prefetched ? ntail : 4 + (size_t)S) * sizeof(double),
+                                hipMemcpyDeviceToHost, c->stream));
         BHMM_HIP(hipStreamSynchronize(c->stream));
         if ((rc = apply_verdict(c, reinterpret_cast<const unsigned int *>(c->h_raw) + 4 * slot,
                                 verified, true)))
@@ -582,6 +587,7 @@ struct Runner {
         c->prefetched = false;
         if (stats_src) { // the results ride on the same synchronisation as the verdict
             const int S = stats_size(c);
+            c->logLk_prefetched = true;
             BHMM_HIP(hipMemcpyAsync(c->h_pinned, stats_src, S * sizeof(double),
                                     hipMemcpyDeviceToHost, c->stream));
             BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, c->K * sizeof(double),
@@ -1629,6 +1635,7 @@ int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
     const int S = stats_size(c);
     // statistics come from the buffer the E-step wrote (the caller's, if it gave one: a caller that
     // all-reduces that buffer in place fetches before reducing, or asks for logL_k only)
+    bool have_logLk = true;
     if (!c->prefetched) {
         if (!c->last_stats)
             return invalid("no E-step has run on these observations");
@@ -1637,15 +1644,23 @@ int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
         BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, c->K * sizeof(double),
                                 hipMemcpyDeviceToHost, c->stream));
         BHMM_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        have_logLk = c->logLk_prefetched;
     }
     c->prefetched = false;
     collect_timing(c);
     if (stats)
         memcpy(stats, c->h_pinned, S * sizeof(double));
+    // a non-finite trajectory makes the total non-finite: look for it only then (K can be 1e6)
+    const bool scan = !std::isfinite(c->h_pinned[0]);
+    if (!have_logLk && (logL_k || scan)) {
+        BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, c->K * sizeof(double),
+                                hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+    }
     if (logL_k)
         memcpy(logL_k, c->h_pinned + S, c->K * sizeof(double));
-    // a non-finite trajectory makes the total non-finite: look for it only then (K can be 1e6)
-    if (!std::isfinite(c->h_pinned[0]))
+    if (scan)
     for (int k = 0; k < c->K; ++k)
         if (!std::isfinite(c->h_pinned[S + k])) {
             g_err = "log-likelihood of trajectory " + std::to_string(k) + " is not finite";

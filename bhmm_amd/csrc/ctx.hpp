@@ -166,6 +166,7 @@ struct bhmm_ctx {
     bool careful_retry = false; // the last verdict asked for a repeat with that kernel
     bool wide_careful = false;  // 9..64 states: lazily scaled kernels left their range on these data
     bool prefetched = false;          // stats + logL_k of the last E-step already sit in h_pinned
+    bool logLk_prefetched = true;     // ... logL_k included (not for many trajectories: on demand)
     bool last_stats_internal = true;
     double *last_stats = nullptr;     // device buffer the last E-step wrote its statistics to
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -225,7 +225,12 @@ class MaximumLikelihoodEstimator(object):
         par0, par1 = om.parameters()
         eng, comm = self._engine, self._comm
         A, pi = self._hmm.transition_matrix, self._hmm.initial_distribution
-        if not comm.active:
+        if not comm.active and hasattr(eng, 'estep_fetch_packed'):
+            # (the per-trajectory log-likelihoods stay on the device: the EM loop needs their sum,
+            # which is packed[0]; with 1e6 short trajectories they would be 8 MB per iteration)
+            eng.estep_launch(A, pi, par0, par1, store_gamma=self._store_gamma)
+            res = EStepResult(self._output, self._nstates, self._nsymbols, eng.estep_fetch_packed(), None)
+        elif not comm.active:
             res = eng.estep(A, pi, par0, par1, store_gamma=self._store_gamma)
         elif hasattr(eng, 'estep_launch'):
             # the E-step leaves its packed statistics in a device buffer on the engine's GPU; ONE

@@ -203,6 +203,39 @@ def test_chunked_viterbi_recovers_from_a_warm_up_that_is_too_short():
         eng.close()
 
 
+def test_many_trajectories_fetch_their_log_likelihoods_on_demand():
+    """More than 4096 trajectories: the E-step brings only the packed statistics to the host; the
+    per-trajectory log-likelihoods are copied when bhmm_estep_fetch is asked for them (before or after a
+    statistics-only fetch), and a non-finite one is still found and named."""
+    rng = np.random.default_rng(4096)
+    n, K = 4, 6000
+    A = rng.random((n, n)) + np.eye(n) * 3
+    A /= A.sum(axis=1)[:, None]
+    pi = np.full(n, 0.25)
+    mu, sig = np.array([-2.0, -0.5, 0.5, 2.0]), np.array([0.6, 0.5, 0.5, 0.7])
+    obs = [rng.normal(0, 1.5, int(T)) for T in rng.integers(1, 40, K)]
+    ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+    eng = _engine()
+    eng.set_observations("gaussian", obs, n)
+    res = eng.estep(A, pi, mu, sig)
+    np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(res.loglik, ref["logL"].sum(), rtol=1e-12)
+    eng.estep_launch(A, pi, mu, sig)
+    packed = eng.estep_fetch_packed().copy()
+    np.testing.assert_allclose(packed[0], ref["logL"].sum(), rtol=1e-12)
+    np.testing.assert_allclose(eng.estep_fetch_logL(), ref["logL"], rtol=1e-11, atol=1e-12)
+    # an impossible start for one trajectory: its log-likelihood is -inf, the call says which
+    pi0 = np.array([1.0, 0.0, 0.0, 0.0])
+    A0 = A.copy()
+    obs2 = list(obs)
+    obs2[4321] = np.array([np.nan, 0.1, 0.2])
+    eng.set_observations("gaussian", obs2, n)
+    with pytest.raises(AssertionError, match="4321"):
+        eng.estep_launch(A0, pi0, mu, sig)
+        eng.estep_fetch_packed()
+    eng.close()
+
+
 # ---- E-step at T = 1e6 and at the configs[2] batch -----------------------------------------
 def test_one_million_step_discrete_trajectory_vs_oracle():
     """One T = 1e6 discrete trajectory (64-bit offsets inside a long trajectory, 1e6-term
