@@ -315,17 +315,40 @@ struct Runner {
         const bool fused_total = nTB <= 1024; // beyond: a fence + ticket per block costs more than a launch
         if ((rc = c->d_tbpart.ensure((size_t)nTB * (1 + N))))
             return rc;
-        hipLaunchKernelGGL((k_tail<N, KIND>), dim3(nfin + nTB + (c->G + 63) / 64), dim3(64), 0,
-                           c->stream, m, chunks_of(c), c->K, c->G, c->Gp / 64, nfin,
-                           (const int32_t *)c->d_traj_c0.p, (const double *)c->d_partials.p,
-                           (const double *)c->d_dpartials.p, (const double *)c->d_logLc.p,
+        // very many sweep workgroups: fold their partial statistics 128 rows at a time first
+        int nrows = c->Gp / 64;
+        const double *part_src = c->d_partials.p, *dpart_src = c->d_dpartials.p;
+        if (nrows > 2048) {
+            constexpr int SS = StatLayout<N, KIND>::S;
+            const int MN = (KIND == EMIT_DISC && !m.bt_global) ? c->M * N : 0;
+            const int nf = (nrows + FOLD_ROWS - 1) / FOLD_ROWS;
+            if ((rc = c->d_fold.ensure((size_t)nf * (SS + MN))))
+                return rc;
+            hipLaunchKernelGGL(k_fold_rows, dim3(nf), dim3(256), 0, c->stream,
+                               (const double *)c->d_partials.p, nrows, SS, c->d_fold.p);
+            part_src = c->d_fold.p;
+            if (MN) {
+                hipLaunchKernelGGL(k_fold_rows, dim3(nf), dim3(256), 0, c->stream,
+                                   (const double *)c->d_dpartials.p, nrows, MN,
+                                   c->d_fold.p + (size_t)nf * SS);
+                dpart_src = c->d_fold.p + (size_t)nf * SS;
+            }
+            BHMM_HIP(hipGetLastError());
+            nrows = nf;
+        }
+        hipLaunchKernelGGL((k_tail<N, KIND>),
+                           dim3((nfin + nTB + (c->G + 63) / 64 + TAIL_WAVES - 1) / TAIL_WAVES),
+                           dim3(64 * TAIL_WAVES), 0,
+                           c->stream, m, chunks_of(c), c->K, c->G, nrows, nfin,
+                           (const int32_t *)c->d_traj_c0.p, part_src,
+                           dpart_src, (const double *)c->d_logLc.p,
                            (const double *)c->d_gamma0.p, (const double *)c->d_aentry.p,
                            (const double *)c->d_aexit.p, (const double *)c->d_bexit.p,
                            (const double *)c->d_bentry.p, SPEC_TOL, stats_dev, c->d_logLk.p,
                            c->d_tail.p + 4, S, words, words_next, c->d_tbpart.p, fused_total, tpb);
         BHMM_HIP(hipGetLastError());
         if (!fused_total) {
-            hipLaunchKernelGGL((k_tail_total<N>), dim3(1), dim3(64), 0, c->stream, c->n, nTB,
+            hipLaunchKernelGGL((k_tail_total<N>), dim3(1 + N), dim3(64), 0, c->stream, c->n, nTB,
                                (const double *)c->d_tbpart.p, stats_dev, c->d_tail.p + 4);
             BHMM_HIP(hipGetLastError());
         }
@@ -1136,6 +1159,7 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     if (c->h_raw)
         (void)hipHostFree(c->h_raw);
     c->d_tail.release();
+    c->d_fold.release();
     c->d_tbpart.release();
     c->d_ea.release();
     c->d_probe.release();

@@ -125,6 +125,7 @@ struct bhmm_ctx {
     bhmm::DevBuf<unsigned int> d_specres;
     bhmm::DevBuf<int32_t> d_ea;       // exponents of the stored alpha rows (k_estep PH_P1 -> PH_P2)
     bhmm::DevBuf<double> d_tail;      // same layout as h_raw, written by k_tail (one D2H copy)
+    bhmm::DevBuf<double> d_fold;      // partial statistics folded 128 rows at a time (k_fold_rows)
     bhmm::DevBuf<double> d_tbpart;    // k_tail: per trajectory block [sum logL | sum gamma_0 (N)]
     int tail_slot = 0;                // verdict word set of the next E-step
     int vit_W = 0;                    // warm-up the chunked Viterbi last verified with (0: spec_W)

@@ -921,7 +921,10 @@ __device__ __forceinline__ void spec_commit(double dev, double tol, unsigned int
     if ((threadIdx.x & 63) == 0) {
         if (bad)
             atomicAdd(&result[0], (unsigned int)__popcll(bad));
-        atomicMax(&result[1], __float_as_uint(m));
+        // (nothing to report from a wavefront of first chunks: a million short trajectories are
+        // 15 625 such wavefronts, and their atomics on this one word were 0.15 ms)
+        if (m > 0.f)
+            atomicMax(&result[1], __float_as_uint(m));
     }
 }
 
@@ -1014,15 +1017,30 @@ __device__ __forceinline__ void finalize_one(int e, const Model<N> &m, int K, in
             mirror[idx] = v;
     };
     const int n = m.nreal;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63; // one wavefront per entry (k_tail: four entries per workgroup)
     const int MN = (KIND == EMIT_DISC) ? m.M * N : 0;
     // packed offsets
     const int oG0 = 1, oC = 1 + n, oSG = oC + n * n, oE = oSG + n;
     double s = 0.0;
+    // column sums over many rows: four independent partial sums per lane keep four loads in flight
+    // (a million short trajectories are 15 625 rows: one dependent add per load was 0.27 ms)
+    auto column_sum = [&](const double *col, int64_t stride, int rows) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = lane;
+        for (; b + 192 < rows; b += 256) {
+            const double v0 = col[(int64_t)b * stride], v1 = col[(int64_t)(b + 64) * stride];
+            const double v2 = col[(int64_t)(b + 128) * stride], v3 = col[(int64_t)(b + 192) * stride];
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
+        }
+        for (; b < rows; b += 64)
+            s0 += col[(int64_t)b * stride];
+        return wave_sum((s0 + s1) + (s2 + s3));
+    };
     if (e < SL::S) {
-        for (int b = lane; b < nblocks; b += 64)
-            s += partials[(int64_t)b * SL::S + e];
-        s = wave_sum(s);
+        s = column_sum(partials + e, SL::S, nblocks);
         if (lane != 0)
             return;
         if (e < SL::NC) {
@@ -1043,9 +1061,7 @@ __device__ __forceinline__ void finalize_one(int e, const Model<N> &m, int K, in
     e -= SL::S;
     if (e < MN) {
         const int ndisc = m.bt_global ? DISC_GLOBAL_TABLES : nblocks;
-        for (int b = lane; b < ndisc; b += 64)
-            s += disc_partials[(int64_t)b * MN + e];
-        s = wave_sum(s);
+        s = column_sum(disc_partials + e, MN, ndisc);
         const int sym = e / N, r = e % N;
         if (lane == 0 && r < n)
             put(oE + r * m.M + sym, s);
@@ -1055,18 +1071,14 @@ __device__ __forceinline__ void finalize_one(int e, const Model<N> &m, int K, in
     if (e < N) {
         if (!logL_k)
             return; // fused tail: summed over trajectory blocks there (k_tail), not by one wavefront
-        for (int k = lane; k < K; k += 64)
-            s += gamma0[(int64_t)k * N + e];
-        s = wave_sum(s);
+        s = column_sum(gamma0 + e, N, K);
         if (lane == 0 && e < n)
             put(oG0 + e, s);
         return;
     }
     if (!logL_k)
         return; // fused tail: the total is formed by the last trajectory workgroup (k_tail)
-    for (int k = lane; k < K; k += 64)
-        s += logL_k[k];
-    s = wave_sum(s);
+    s = column_sum(logL_k, 1, K);
     if (lane == 0)
         put(0, s);
 }
@@ -1101,11 +1113,36 @@ inline int tail_tpb(int64_t G, int K) { return G >= (int64_t)16 * K ? 1 : TAIL_T
 // sum of the trajectory blocks' partials -> stats[0] (total log-likelihood) and stats[1..n]
 // (sum_k gamma_k[0]); one wavefront: every lane takes whole records (1 + N independent loads in
 // flight per record), then one wave sum per entry -- fixed order, no chain of load latencies
+// entry e of the same sums by one wavefront of its own (k_tail_total: many trajectory blocks)
+template <int N>
+__device__ __forceinline__ void tail_total_entry(int e, int n, int nTB, const double *tb_part,
+                                                 double *stats, double *mirror)
+{
+    const int lane = threadIdx.x & 63;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int t = lane;
+    for (; t + 192 < nTB; t += 256) {
+        const double v0 = tb_part[(int64_t)t * (1 + N) + e], v1 = tb_part[(int64_t)(t + 64) * (1 + N) + e];
+        const double v2 = tb_part[(int64_t)(t + 128) * (1 + N) + e], v3 = tb_part[(int64_t)(t + 192) * (1 + N) + e];
+        s0 += v0;
+        s1 += v1;
+        s2 += v2;
+        s3 += v3;
+    }
+    for (; t < nTB; t += 64)
+        s0 += tb_part[(int64_t)t * (1 + N) + e];
+    const double sacc = wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0 && (e == 0 || e - 1 < n)) {
+        stats[e] = sacc; // packed offsets: [0] total log-likelihood, [1 + i] sum_k gamma_k[0][i]
+        mirror[e] = sacc;
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void tail_total(int n, int nTB, const double *tb_part, double *stats,
                                            double *mirror)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     double acc[1 + N];
 #pragma unroll
     for (int e = 0; e <= N; ++e)
@@ -1140,11 +1177,40 @@ template <int N>
 __global__ __launch_bounds__(64) void k_tail_total(int n, int nTB, const double *tb_part,
                                                    double *stats, double *mirror)
 {
-    tail_total<N>(n, nTB, tb_part, stats, mirror);
+    tail_total_entry<N>(blockIdx.x, n, nTB, tb_part, stats, mirror); // grid: 1 + N workgroups
 }
 
+// k_fold_rows: rows [b R, (b + 1) R) of a [rows][cols] table summed into row b of `out` (fixed order),
+// one thread per column -- consecutive threads read consecutive doubles.  The finalisation sums a
+// column per wavefront, which is a strided walk over the whole table: fine for the few hundred rows
+// of a usual batch, 0.2 ms for the 15 625 rows a million short trajectories leave behind.  Folding
+// first leaves it ~120 rows.
+constexpr int FOLD_ROWS = 128;
+[[maybe_unused]] static __global__ __launch_bounds__(256) void k_fold_rows(const double *tab, int rows, int cols,
+                                                                           double *out)
+{
+    const int r0 = blockIdx.x * FOLD_ROWS;
+    const int r1 = r0 + FOLD_ROWS < rows ? r0 + FOLD_ROWS : rows;
+    for (int e = threadIdx.x; e < cols; e += 256) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            const double v0 = tab[(int64_t)r * cols + e], v1 = tab[(int64_t)(r + 1) * cols + e];
+            const double v2 = tab[(int64_t)(r + 2) * cols + e], v3 = tab[(int64_t)(r + 3) * cols + e];
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
+        }
+        for (; r < r1; ++r)
+            s0 += tab[(int64_t)r * cols + e];
+        out[(int64_t)blockIdx.x * cols + e] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+constexpr int TAIL_WAVES = 4; // wavefronts per workgroup of k_tail, each with a role of its own
 template <int N, int KIND>
-__global__ __launch_bounds__(64) void k_tail(const Model<N> m, const Chunks ch, int K, int G,
+__global__ __launch_bounds__(64 * TAIL_WAVES) void k_tail(const Model<N> m, const Chunks ch, int K, int G,
                                              int nblocks, int nfin, const int32_t *traj_c0,
                                              const double *partials, const double *disc_partials,
                                              const double *logL_chunk, const double *gamma0,
@@ -1156,14 +1222,16 @@ __global__ __launch_bounds__(64) void k_tail(const Model<N> m, const Chunks ch, 
                                              double *tb_part, // [nTB][1 + N] block partials
                                              bool fused_total, int tpb)
 {
-    const int b = blockIdx.x;
+    // (workgroups of four wavefronts: a million short trajectories are 31 000 roles, and as
+    // one-wavefront workgroups their dispatch alone took 0.24 ms)
+    const int b = blockIdx.x * TAIL_WAVES + (threadIdx.x >> 6);
     const int nTB = (K + tpb - 1) / tpb;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     if (b < nfin) {
         finalize_one<N, KIND>(b, m, K, nblocks, partials, disc_partials, nullptr, logL_chunk, G,
                               gamma0, stats, mirror);
-        if (b == 0 && threadIdx.x < 4)
-            flags_next[threadIdx.x] = 0u;
+        if (b == 0 && lane < 4)
+            flags_next[lane] = 0u;
     } else if (b < nfin + nTB) {
         const int tb = b - nfin;
         const int k0 = tb * tpb;
@@ -1215,7 +1283,8 @@ __global__ __launch_bounds__(64) void k_tail(const Model<N> m, const Chunks ch, 
             tail_total<N>(m.nreal, nTB, tb_part, stats, mirror);
         }
     } else {
-        spec_check_one<N>(ch, G, (int64_t)(b - nfin - nTB) * 64 + threadIdx.x, alpha_entry, a_exit,
+        // (roles beyond the last boundary: spec_dev_one ignores g >= G)
+        spec_check_one<N>(ch, G, (int64_t)(b - nfin - nTB) * 64 + lane, alpha_entry, a_exit,
                           beta_exit, b_entry, tol, flags);
     }
 }
