@@ -68,7 +68,8 @@ static int stats_size(const bhmm_ctx *c);
 static int lds_symbols(const bhmm_ctx *c) { return c->bt_global ? 0 : c->M; }
 static int64_t ci_records(const bhmm_ctx *c) { return (int64_t)(c->Gp / 64) * c->Lmax; }
 
-int replan_coarse(bhmm_ctx *c); // (defined with bhmm_ctx_set_observations)
+int replan_coarse(bhmm_ctx *c, bool half = false); // (defined with bhmm_ctx_set_observations)
+int replan_for_warmup(bhmm_ctx *c);
 
 #ifndef ESTEP_SPLIT
 #define ESTEP_SPLIT 1 // statistics-only speculative E-step in two launches (PH_P1, PH_P2)
@@ -439,6 +440,8 @@ struct Runner {
                 c->spec_W = W;
             if (c->chunk_mult > 1 && (int64_t)c->spec_W * 16 > c->L && (rc = replan_coarse(c)))
                 return rc;
+            if ((rc = replan_for_warmup(c)))
+                return rc;
         }
         if (c->spec_enabled) {
             // ---- boundary vectors carried from the previous E-step (estep_sweep.hpp: Carry) ----
@@ -755,6 +758,8 @@ struct Runner {
                 c->spec_W = W;
             if (c->chunk_mult > 1 && (int64_t)c->spec_W * 16 > c->L && (rc = replan_coarse(c)))
                 return rc;
+            if ((rc = replan_for_warmup(c)))
+                return rc;
         }
         if (c->spec_enabled) {
             for (int attempt = 0; attempt < 2; ++attempt) {
@@ -848,13 +853,13 @@ struct Runner {
 
 // ---- chunk planning ----------------------------------------------------------------------
 // Every trajectory is cut into ceil(T/L) chunks whose lengths differ by at most one.
-static int plan_chunks(bhmm_ctx *c, int chunk, bool allow_mult = true)
+static int plan_chunks(bhmm_ctx *c, int chunk, bool allow_mult = true, bool half = false)
 {
     // the tables come from plan.hpp (pure host code, also built under the CPU sanitizers); here
     // they are adopted and uploaded
     const int K = c->K;
     plan::ChunkPlan p;
-    if (!plan::plan_chunks(c->offsets, K, c->N, c->total, chunk, allow_mult, BLOCK, p))
+    if (!plan::plan_chunks(c->offsets, K, c->N, c->total, chunk, allow_mult, BLOCK, p, half))
         return invalid("too many chunks");
     c->chunk_mult = p.chunk_mult;
     c->L = p.L;
@@ -1211,11 +1216,25 @@ static int pack_observations(bhmm_ctx *c, const char *src_dev)
 // long (plan_chunks), assuming a warm-up of a few hundred steps.  The model turned out to forget
 // slowly (the calibrated warm-up exceeds 1/16 of the chunk): back to the default count -- the
 // observations are re-laid out from the trajectory-major copy on the device.
-int bhmm::replan_coarse(bhmm_ctx *c)
+// The automatic plan cuts every batch into the default number of chunks.  Once the warm-up of the
+// model is known: if those chunks are shorter than about 1.6 warm-ups, half as many are faster
+// (plan.hpp).  Only for a plan that did reach the default count -- below it the device is not full
+// and more chunks mean more parallelism -- and only once per set of observations.
+int bhmm::replan_for_warmup(bhmm_ctx *c)
+{
+    if (!c->chunk_auto || c->replanned_half || c->chunk_mult > 1 || c->wide || c->gen)
+        return BHMM_OK;
+    if ((int64_t)c->G * 10 < plan::default_chunk_count(c->N) * 9 || (double)c->L >= 1.6 * c->spec_W)
+        return BHMM_OK;
+    c->replanned_half = true;
+    return replan_coarse(c, true);
+}
+
+int bhmm::replan_coarse(bhmm_ctx *c, bool half)
 {
     int rc;
     BHMM_HIP(hipStreamSynchronize(c->stream));
-    if ((rc = plan_chunks(c, 0, false)) || (rc = alloc_work(c)))
+    if ((rc = plan_chunks(c, 0, false, half)) || (rc = alloc_work(c)))
         return rc;
     if ((rc = pack_observations(c, c->d_obs_rm.p)))
         return rc;
@@ -1308,6 +1327,8 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         BHMM_HIP(hipStreamSynchronize(c->stream));
         return BHMM_OK;
     }
+    c->chunk_auto = chunk <= 0;
+    c->replanned_half = false;
     rc = plan_chunks(c, chunk);
     if (rc)
         return rc;

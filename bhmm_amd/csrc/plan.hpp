@@ -26,9 +26,11 @@ struct ChunkPlan {
 //   chunk         chunk length, or <= 0 for the automatic plan
 //   allow_mult    automatic plan may take two / three times the default chunk count
 //   block         chunks per workgroup (the tables are padded to a multiple of it)
+//   half          automatic plan with half the default chunk count (see default_chunk_count)
 // Returns false if the plan would exceed 2^30 chunks.
+inline int64_t default_chunk_count(int N) { return 32768 * 4 / std::max(1, N / 2); } // N/2 lanes per chunk
 inline bool plan_chunks(const std::vector<int64_t> &offsets, int K, int N, int64_t total, int chunk,
-                        bool allow_mult, int block, ChunkPlan &p)
+                        bool allow_mult, int block, ChunkPlan &p, bool half = false)
 {
     p = ChunkPlan();
     int L = chunk;
@@ -37,7 +39,12 @@ inline bool plan_chunks(const std::vector<int64_t> &offsets, int K, int N, int64
         // SIMD of the 256 CUs.  Fewer, longer chunks amortise the warm-up of the speculative
         // boundaries (W / L extra steps); more chunks only help occupancy (measured optimum on
         // configs[1]: profiles/r01).
-        const int64_t target = 32768 * 4 / std::max(1, N / 2); // N/2 lanes per chunk
+        // `half`: 16384 chunks -- ONE wavefront per SIMD in the backward sweep, which issues at 0.85-0.9
+        // of the rate of two.  The better plan when the default one's chunks come out shorter than
+        // about 1.6 warm-ups (a batch of a few million steps): each chunk's two warm-ups then cost
+        // more than the lost occupancy (tools/chunk_scan.py; the host re-plans once the warm-up of
+        // the model has been measured, bhmm_amd.hip: replan_for_warmup)
+        const int64_t target = default_chunk_count(N) / (half ? 2 : 1);
         int64_t l = (total + target - 1) / target;
         // Very long chunks: two or three times as many.  The sweeps without xi accumulators (P1,
         // the forward-only pass) then have four to six long wavefronts per SIMD instead of two

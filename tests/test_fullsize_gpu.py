@@ -236,6 +236,44 @@ def test_many_trajectories_fetch_their_log_likelihoods_on_demand():
     eng.close()
 
 
+def test_automatic_plan_halves_its_chunk_count_when_chunks_are_shorter_than_the_warm_up():
+    """A batch of 1.2e6 steps: the default plan (32768 chunks of 37 steps) would spend most of its
+    time in warm-ups of a few hundred steps; once the warm-up is calibrated (first E-step) the library
+    re-plans with 16384 chunks (plan.hpp, tools/chunk_scan.py).  Results against the oracle before and
+    after, E-step / Viterbi / Gibbs statistics on the new plan; a caller's own chunk length is kept."""
+    import torch
+    from bench import make_c2_model
+    from bhmm_amd.engine import synth_observations
+    K, T = 12, 100000
+    m = make_c2_model()
+    obs = torch.empty(K * T, dtype=torch.float64, device="cuda:0")
+    synth_observations("gaussian", obs.data_ptr(), m["A"], m["pi"], m["mu"], m["sigma"], K, T, seed=12)
+    margs = (m["A_eval"], m["pi"], m["mu_eval"], m["sigma"])
+    host = obs.cpu().numpy().reshape(K, T)
+    ref = orc.estep("gaussian", list(host), *margs)
+    eng = _engine()
+    eng.set_observations_device("gaussian", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, 8)
+    g0 = eng.num_chunks
+    assert g0 > 30000
+    for _ in range(2):
+        res = eng.estep(*margs)
+        np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-11)
+        np.testing.assert_allclose(res.C, ref["C"], rtol=1e-9, atol=1e-9)
+    assert 15000 < eng.num_chunks < 17000 and eng.chunk_len > 1.9 * (T * K / g0)
+    vp = eng.viterbi(*margs)
+    assert eng.get_option("viterbi_chunked") == 1
+    assert np.array_equal(vp[5], orc.viterbi(m["A_eval"], orc.pobs_gaussian(host[5], m["mu_eval"], m["sigma"]), m["pi"]))
+    paths, C, n0, emis = eng.sample_paths(*margs, seed=3)
+    assert C.sum() == K * (T - 1) and n0.sum() == K
+    eng.close()
+    eng = _engine()
+    eng.set_observations_device("gaussian", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, 8, chunk=40)
+    g1 = eng.num_chunks
+    eng.estep(*margs)
+    assert eng.num_chunks == g1
+    eng.close()
+
+
 # ---- E-step at T = 1e6 and at the configs[2] batch -----------------------------------------
 def test_one_million_step_discrete_trajectory_vs_oracle():
     """One T = 1e6 discrete trajectory (64-bit offsets inside a long trajectory, 1e6-term
