@@ -982,10 +982,20 @@ __device__ __forceinline__ void logl_one(int k, const int32_t *traj_c0, const do
                                          double *logL_k, double *mirror = nullptr)
 {
     const int lane = threadIdx.x;
-    double s = 0.0;
-    for (int c = traj_c0[k] + lane; c < traj_c0[k + 1]; c += 64)
-        s += logL_chunk[c];
-    s = wave_sum(s);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int a1 = traj_c0[k + 1];
+    int c = traj_c0[k] + lane;
+    for (; c + 192 < a1; c += 256) {
+        const double v0 = logL_chunk[c], v1 = logL_chunk[c + 64];
+        const double v2 = logL_chunk[c + 128], v3 = logL_chunk[c + 192];
+        s0 += v0;
+        s1 += v1;
+        s2 += v2;
+        s3 += v3;
+    }
+    for (; c < a1; c += 64)
+        s0 += logL_chunk[c];
+    double s = wave_sum((s0 + s1) + (s2 + s3));
     if (lane == 0) {
         logL_k[k] = s;
         if (mirror)
@@ -1249,10 +1259,21 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_tail(const Model<N> m, cons
         } else {
             for (int j = 0; j < kn; ++j) {
                 const int a0 = __shfl(c_lo, j, 64), a1 = j == kn - 1 ? c_end : __shfl(c_lo, j + 1, 64);
-                double sacc = 0.0;
-                for (int c = a0 + lane; c < a1; c += 64)
-                    sacc += logL_chunk[c];
-                sacc = wave_sum(sacc);
+                // (one trajectory of a million steps is 31 250 chunks: four loads in flight per lane,
+                // a dependent add per load took 0.15 ms)
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int c = a0 + lane;
+                for (; c + 192 < a1; c += 256) {
+                    const double v0 = logL_chunk[c], v1 = logL_chunk[c + 64];
+                    const double v2 = logL_chunk[c + 128], v3 = logL_chunk[c + 192];
+                    s0 += v0;
+                    s1 += v1;
+                    s2 += v2;
+                    s3 += v3;
+                }
+                for (; c < a1; c += 64)
+                    s0 += logL_chunk[c];
+                double sacc = wave_sum((s0 + s1) + (s2 + s3));
                 if (lane == j)
                     mine = sacc;
             }
