@@ -923,7 +923,10 @@ __device__ __forceinline__ void spec_commit(double dev, double tol, unsigned int
             atomicAdd(&result[0], (unsigned int)__popcll(bad));
         // (nothing to report from a wavefront of first chunks: a million short trajectories are
         // 15 625 such wavefronts, and their atomics on this one word were 0.15 ms)
-        if (m > 0.f)
+        // ... nor one whose largest deviation is below what the word holds already (a plain look
+        // first: hundreds of atomics on one address serialise)
+        if (m > 0.f && __float_as_uint(m) > __hip_atomic_load(&result[1], __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(&result[1], __float_as_uint(m));
     }
 }
