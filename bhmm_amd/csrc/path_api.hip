@@ -343,6 +343,32 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         else                                              \
             BHMM_WV(NPV, EMIT_EXPL);                      \
     } while (0)
+    // back-trace of an accepted chunk-parallel run (k_vit_walk, maps -> stitch -> paths)
+    auto launch_walks = [&]() {
+        const Chunks chs = chunks_pub(c);
+        const dim3 wg((c->G + 7) / 8);
+        if (out_fmt == 0)
+            hipLaunchKernelGGL((k_vit_walk<8, false, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                               (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, path, vcoal);
+        else
+            hipLaunchKernelGGL((k_vit_walk<8, false, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                               (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, path8, vcoal);
+        if ((int64_t)c->G >= (int64_t)32 * K)
+            hipLaunchKernelGGL(k_smp_stitch, dim3(K), dim3(64), 0, c->stream,
+                               (const int32_t *)c->d_traj_c0.p, K, 1, (const uint32_t *)vmaps, vend,
+                               (const int32_t *)last);
+        else
+            hipLaunchKernelGGL(k_smp_stitch_serial, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB),
+                               dim3(64), 0, c->stream, (const int32_t *)c->d_traj_c0.p, K, 1,
+                               (const uint32_t *)vmaps, vend, (const int32_t *)last);
+        if (out_fmt == 0)
+            hipLaunchKernelGGL((k_vit_walk<8, true, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path, vcoal);
+        else
+            hipLaunchKernelGGL((k_vit_walk<8, true, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path8, vcoal);
+    };
+    bool walks_in_flight = false;
     // n <= 8 with a chunk plan: the chunk-parallel run first; its back-pointers are accepted only
     // if every chunk boundary verifies and no decision was close (k_viterbi_chunks)
     bool done = false;
@@ -398,7 +424,15 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
             BHMM_HIP(hipGetLastError());
             BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
                                     hipMemcpyDeviceToHost, c->stream));
+            // the normal case is "all boundaries bit-identical": the back-trace is enqueued behind
+            // the first pass before its verdict is known (one host round trip less); the walks only
+            // read back-pointers, which are valid state indices whatever the verdict, and are
+            // repeated after any further pass
+            const bool speculative = attempt == 0 && pass == 0;
+            if (speculative)
+                launch_walks();
             BHMM_HIP(hipStreamSynchronize(c->stream));
+            walks_in_flight = speculative && c->h_specres[3] == 0;
             if (c->h_specres[3] == 0 || c->h_specres[0] != 0)
                 break; // the serial run outright / out of tolerance: the count cannot help
         }
@@ -428,28 +462,8 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         BHMM_WV_KIND(64);
     BHMM_HIP(hipGetLastError());
     if (done) {
-        const Chunks chs = chunks_pub(c);
-        const dim3 wg((c->G + 7) / 8);
-        if (out_fmt == 0)
-            hipLaunchKernelGGL((k_vit_walk<8, false, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
-                               (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, path, vcoal);
-        else
-            hipLaunchKernelGGL((k_vit_walk<8, false, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
-                               (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, path8, vcoal);
-        if ((int64_t)c->G >= (int64_t)32 * K)
-            hipLaunchKernelGGL(k_smp_stitch, dim3(K), dim3(64), 0, c->stream,
-                               (const int32_t *)c->d_traj_c0.p, K, 1, (const uint32_t *)vmaps, vend,
-                               (const int32_t *)last);
-        else
-            hipLaunchKernelGGL(k_smp_stitch_serial, dim3((K + SMP_STITCH_TPB - 1) / SMP_STITCH_TPB),
-                               dim3(64), 0, c->stream, (const int32_t *)c->d_traj_c0.p, K, 1,
-                               (const uint32_t *)vmaps, vend, (const int32_t *)last);
-        if (out_fmt == 0)
-            hipLaunchKernelGGL((k_vit_walk<8, true, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
-                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path, vcoal);
-        else
-            hipLaunchKernelGGL((k_vit_walk<8, true, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
-                               (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path8, vcoal);
+        if (!walks_in_flight)
+            launch_walks();
     } else if (out_fmt == 0) {
         hipLaunchKernelGGL(k_wide_viterbi_trace<int32_t>, dim3(K), dim3(64), 0, c->stream, off, K, n,
                            (const uint8_t *)ptr, (const int32_t *)last, path);
