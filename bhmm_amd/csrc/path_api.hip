@@ -344,14 +344,17 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
             BHMM_WV(NPV, EMIT_EXPL);                      \
     } while (0)
     // back-trace of an accepted chunk-parallel run (k_vit_walk, maps -> stitch -> paths)
-    auto launch_walks = [&]() {
+    // (models of up to four states: four lanes per chunk, 16 chunks per wavefront)
+    const bool vit4 = !c->wide && n <= 4;
+    auto launch_walks_np = [&](auto npc) {
+        constexpr int VNP = decltype(npc)::value;
         const Chunks chs = chunks_pub(c);
-        const dim3 wg((c->G + 7) / 8);
+        const dim3 wg((c->G + 64 / VNP - 1) / (64 / VNP));
         if (out_fmt == 0)
-            hipLaunchKernelGGL((k_vit_walk<8, false, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+            hipLaunchKernelGGL((k_vit_walk<VNP, false, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
                                (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, path, vcoal);
         else
-            hipLaunchKernelGGL((k_vit_walk<8, false, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+            hipLaunchKernelGGL((k_vit_walk<VNP, false, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
                                (const uint8_t *)ptr, (const int32_t *)nullptr, vmaps, path8, vcoal);
         if ((int64_t)c->G >= (int64_t)32 * K)
             hipLaunchKernelGGL(k_smp_stitch, dim3(K), dim3(64), 0, c->stream,
@@ -362,11 +365,17 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                                dim3(64), 0, c->stream, (const int32_t *)c->d_traj_c0.p, K, 1,
                                (const uint32_t *)vmaps, vend, (const int32_t *)last);
         if (out_fmt == 0)
-            hipLaunchKernelGGL((k_vit_walk<8, true, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+            hipLaunchKernelGGL((k_vit_walk<VNP, true, int32_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
                                (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path, vcoal);
         else
-            hipLaunchKernelGGL((k_vit_walk<8, true, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
+            hipLaunchKernelGGL((k_vit_walk<VNP, true, uint8_t>), wg, dim3(64), 0, c->stream, chs, c->G, n,
                                (const uint8_t *)ptr, (const int32_t *)vend, (uint32_t *)nullptr, path8, vcoal);
+    };
+    auto launch_walks = [&]() {
+        if (vit4)
+            launch_walks_np(std::integral_constant<int, 4>{});
+        else
+            launch_walks_np(std::integral_constant<int, 8>{});
     };
     bool walks_in_flight = false;
     // n <= 8 with a chunk plan: the chunk-parallel run first; its back-pointers are accepted only
@@ -396,10 +405,18 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         // first without the close-decision count; bit-identical boundaries make it irrelevant
         for (int pass = 0; pass < 2; ++pass) {
             BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
-#define BHMM_VC(KINDV, MARGINV)                                                                     \
-    hipLaunchKernelGGL((k_viterbi_chunks<8, KINDV, MARGINV>), dim3((c->G + 7) / 8), dim3(64), smB,  \
-                       c->stream, m, chs, c->G, off, obs, W_try, margin, ptr, last,             \
-                       c->d_aentry.p, c->d_aexit.p, c->d_specres.p, smB ? 1 : 0)
+#define BHMM_VC_NP(VNP, KINDV, MARGINV)                                                             \
+    hipLaunchKernelGGL((k_viterbi_chunks<VNP, KINDV, MARGINV>),                                     \
+                       dim3((c->G + 64 / VNP - 1) / (64 / VNP)), dim3(64), smB, c->stream, m, chs,   \
+                       c->G, off, obs, W_try, margin, ptr, last, c->d_aentry.p, c->d_aexit.p,       \
+                       c->d_specres.p, smB ? 1 : 0)
+#define BHMM_VC(KINDV, MARGINV)                 \
+    do {                                        \
+        if (vit4)                               \
+            BHMM_VC_NP(4, KINDV, MARGINV);      \
+        else                                    \
+            BHMM_VC_NP(8, KINDV, MARGINV);      \
+    } while (0)
             if (disc_direct && c->kind == EMIT_DISC) {
                 if (pass == 0)
                     BHMM_VC(EMIT_DISC, false);
@@ -417,10 +434,16 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                     BHMM_VC(EMIT_EXPL, true);
             }
 #undef BHMM_VC
+#undef BHMM_VC_NP
             BHMM_HIP(hipGetLastError());
-            hipLaunchKernelGGL((k_viterbi_check<8>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
-                               chs, c->G, (const double *)c->d_aentry.p, (const double *)c->d_aexit.p,
-                               tol, c->d_specres.p);
+            if (vit4)
+                hipLaunchKernelGGL((k_viterbi_check<4>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
+                                   chs, c->G, (const double *)c->d_aentry.p,
+                                   (const double *)c->d_aexit.p, tol, c->d_specres.p);
+            else
+                hipLaunchKernelGGL((k_viterbi_check<8>), dim3((c->G + 255) / 256), dim3(256), 0, c->stream,
+                                   chs, c->G, (const double *)c->d_aentry.p,
+                                   (const double *)c->d_aexit.p, tol, c->d_specres.p);
             BHMM_HIP(hipGetLastError());
             BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
                                     hipMemcpyDeviceToHost, c->stream));

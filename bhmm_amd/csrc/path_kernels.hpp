@@ -1200,6 +1200,55 @@ __device__ __forceinline__ int argmax8_block(double (&h)[8], double &mx)
     return i0;
 }
 
+// the same for four products (models of up to four states: 16 chunks per wavefront instead of 8)
+template <bool WANT_MAX>
+__device__ __forceinline__ int argmax4_block(double (&h)[4], double &mx)
+{
+    int i0, i1;
+    unsigned long long s0, s1;
+    if constexpr (WANT_MAX) {
+        asm("v_cmp_gt_f64 %[s0], %[h1], %[h0]\n\t"
+            "v_cmp_gt_f64 %[s1], %[h3], %[h2]\n\t"
+            "v_max_f64 %[h0], %[h0], %[h1]\n\t"
+            "v_max_f64 %[h2], %[h2], %[h3]\n\t"
+            "v_cndmask_b32 %[i0], 0, 1, %[s0]\n\t"
+            "v_cndmask_b32 %[i1], 2, 3, %[s1]\n\t"
+            "v_cmp_gt_f64 %[s0], %[h2], %[h0]\n\t"
+            "v_max_f64 %[h0], %[h0], %[h2]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32 %[i0], %[i0], %[i1], %[s0]"
+            : [i0] "=&v"(i0), [i1] "=&v"(i1), [s0] "=&s"(s0), [s1] "=&s"(s1), [h0] "+v"(h[0]),
+              [h2] "+v"(h[2])
+            : [h1] "v"(h[1]), [h3] "v"(h[3]));
+        mx = h[0];
+    } else {
+        asm("v_cmp_gt_f64 %[s0], %[h1], %[h0]\n\t"
+            "v_cmp_gt_f64 %[s1], %[h3], %[h2]\n\t"
+            "v_max_f64 %[h0], %[h0], %[h1]\n\t"
+            "v_max_f64 %[h2], %[h2], %[h3]\n\t"
+            "v_cndmask_b32 %[i0], 0, 1, %[s0]\n\t"
+            "v_cndmask_b32 %[i1], 2, 3, %[s1]\n\t"
+            "v_cmp_gt_f64 %[s0], %[h2], %[h0]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %[i0], %[i0], %[i1], %[s0]"
+            : [i0] "=&v"(i0), [i1] "=&v"(i1), [s0] "=&s"(s0), [s1] "=&s"(s1), [h0] "+v"(h[0]),
+              [h2] "+v"(h[2])
+            : [h1] "v"(h[1]), [h3] "v"(h[3]));
+        mx = 0.0;
+    }
+    return i0;
+}
+
+template <int NP, bool WANT_MAX>
+__device__ __forceinline__ int argmax_block(double (&h)[NP], double &mx)
+{
+    static_assert(NP == 4 || NP == 8, "argmax blocks for 4 and 8 products");
+    if constexpr (NP == 8)
+        return argmax8_block<WANT_MAX>(h, mx);
+    else
+        return argmax4_block<WANT_MAX>(h, mx);
+}
+
 // =========================================================================================
 // k_viterbi_chunks: the same order-faithful recursion, parallel over the time chunks of the
 // E-step plan, and still bit-identical to the serial run -- verified, not assumed:
@@ -1243,7 +1292,7 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
     [[maybe_unused]] const double *pobs = static_cast<const double *>(src);
     [[maybe_unused]] const int32_t *syms = static_cast<const int32_t *>(src);
     constexpr int GP = 64 / NP;
-    static_assert(NP == 8, "argmax8_block");
+    static_assert(NP == 4 || NP == 8, "argmax_block");
     __shared__ __attribute__((aligned(16))) double xv[GP][NP];
     __shared__ __attribute__((aligned(16))) double xn[GP][NP];
     // A for the winner's factor: the argmax carries only (product, index); v[i^] and
@@ -1360,7 +1409,7 @@ __global__ __launch_bounds__(64) void k_viterbi_chunks(const WideModel m, const 
                     h0[i] = hh[i];
             }
             double mx;
-            const int ib = argmax8_block<MAIN && MARGIN>(hh, mx);
+            const int ib = argmax_block<NP, MAIN && MARGIN>(hh, mx);
             if constexpr (MAIN) {
                 if (ALLREAL || real)
                     *pq = (uint8_t)ib;
