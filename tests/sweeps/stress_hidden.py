@@ -59,9 +59,16 @@ for case in range(ncase):
         ref_ok = (np.allclose(ar, a_ld, rtol=1e-6, atol=1e-250) and np.allclose(br, b_ld, rtol=1e-6, atol=1e-250)
                   and np.isclose(lr, l_ld, rtol=1e-9))
         if ref_ok:
-            checks = {"logL": np.isclose(lg, lr, rtol=1e-11, atol=1e-11), "alpha": np.allclose(ag, ar, rtol=1e-9, atol=1e-250),
-                      "beta": np.allclose(bg, br, rtol=1e-9, atol=1e-250), "gamma": np.allclose(gg, orc.gamma(ar, br), rtol=1e-9, atol=1e-250),
-                      "C": np.allclose(Cg, Cr, rtol=1e-8, atol=1e-12), "viterbi": np.array_equal(vg, vr),
+            # values against the 80-bit recursion (a denormal emission entry costs the double-precision
+            # reference a few 1e-9 of a beta row, seed 557 case 242; the kernels are closer to the
+            # 80-bit values than it is), paths against the reference's
+            f = lambda x: np.asarray(x, dtype=np.float64)
+            checks = {"logL": np.isclose(lg, float(l_ld), rtol=1e-11, atol=1e-11) or np.isclose(lg, lr, rtol=1e-11, atol=1e-11),
+                      "alpha": np.allclose(ag, f(a_ld), rtol=1e-9, atol=1e-250) or np.allclose(ag, ar, rtol=1e-9, atol=1e-250),
+                      "beta": np.allclose(bg, f(b_ld), rtol=1e-9, atol=1e-250) or np.allclose(bg, br, rtol=1e-9, atol=1e-250),
+                      "gamma": np.allclose(gg, f(g_ld), rtol=1e-9, atol=1e-250) or np.allclose(gg, orc.gamma(ar, br), rtol=1e-9, atol=1e-250),
+                      "C": np.allclose(Cg, f(C_ld), rtol=1e-8, atol=1e-12) or np.allclose(Cg, Cr, rtol=1e-8, atol=1e-12),
+                      "viterbi": np.array_equal(vg, vr),
                       "sample": sg is not None and np.array_equal(sg, sr)}
         else:
             # the double-precision reference has lost states the 80-bit recursion keeps (relative
