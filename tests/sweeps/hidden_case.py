@@ -1,6 +1,7 @@
-"""Replay one case of tests/sweeps/stress_hidden.py verbosely: python tools/hidden_case.py SEED CASE"""
+"""Test infrastructure (uses the oracle).  Replay one case of tests/sweeps/stress_hidden.py verbosely:
+python tests/sweeps/hidden_case.py SEED CASE"""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import bhmm_amd.hidden as hidden

@@ -78,3 +78,15 @@ def test_product_never_imports_the_oracle():
                         or "bhmm_oracle" in src:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_tools_do_not_use_the_oracle_either():
+    """tools/ holds measurement scripts for the GPU box; whatever needs the oracle lives under tests/."""
+    bad = []
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        path = os.path.join(ROOT, "tools", f)
+        if os.path.isfile(path) and f.endswith((".py", ".sh")):
+            src = open(path).read()
+            if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "liboracle" in src:
+                bad.append(f)
+    assert not bad, bad
