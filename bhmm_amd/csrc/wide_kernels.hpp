@@ -31,16 +31,6 @@ struct WideModel {
     int n, M;
 };
 
-// Horner step pinned to the three-address v_fma_f64: the compiler otherwise picks the two-address
-// v_fmac_f64 and copies every coefficient into the accumulator first (10 extra moves per call),
-// and these kernels are bound by instruction issue.
-__device__ __forceinline__ double horner_step(double q, double r, double c)
-{
-    double o;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(q), "v"(r), "v"(c));
-    return o;
-}
-
 // gauss_pdf<NANSAFE = true> (estep_sweep.hpp: the gaussian density with constant, exponent and range
 // reduction fused, 18 instructions where cn * exp(-z*z/2) by range reduction took 24), Horner steps pinned
 // like above.  A NaN observation gives 0 here, as it always did in this family (-> outlier row).
