@@ -783,12 +783,21 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
                 nxt = load_obs<N, KIND>(obs_ci, ci_rec(g, 1, ch.Lmax), cl, q);
             a[0] = pi2[0] * p[0];
             a[1] = pi2[1] * p[1];
+            int pex = pe0;
+            // the whole row in the denormal range (an explicit emission row may hold denormals: the
+            // reciprocal of its sum would be infinite) although the factors are not zero: times 2^900,
+            // exactly, and 900 off the exponent count -- the reference divides by the denormal sum
+            if (grp_max_i32<H>(max(__double2hiint(a[0]), __double2hiint(a[1]))) < (64 << 20)) {
+                a[0] = pi2[0] * ldexp(p[0], 900);
+                a[1] = pi2[1] * ldexp(p[1], 900);
+                pex += 900;
+            }
             const double c = grp_sum<H>(a[0] + a[1]);
             const double rc = fast_rcp(c);
             a[0] *= rc;
             a[1] *= rc;
             P = frexp(c, &eP);
-            eP -= pe0;
+            eP -= pex;
             *ci_pair(ws, ci_rec(g, 0, ch.Lmax), N, q, cl) = make_double2(a[0], a[1]);
             s = 1;
         } else {
@@ -813,6 +822,12 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
                 n0 = fma(af[i], Ac[i][0], n0);
                 n1 = fma(af[i], Ac[i][1], n1);
             }
+            int pex = pe;
+            if (grp_max_i32<H>(max(__double2hiint(n0 * p[0]), __double2hiint(n1 * p[1]))) < (64 << 20)) {
+                p[0] = ldexp(p[0], 900); // (see the first step)
+                p[1] = ldexp(p[1], 900);
+                pex += 900;
+            }
             n0 *= p[0];
             n1 *= p[1];
             const double c = grp_sum<H>(n0 + n1);
@@ -821,7 +836,7 @@ __global__ __launch_bounds__(32 * N) void k_rows(const Model<N> m, const Chunks 
             a[1] = n1 * rc;
             int e;
             P = frexp(P * c, &e);
-            eP += e - pe;
+            eP += e - pex;
             *ci_pair(ws, rec, N, q, cl) = make_double2(a[0], a[1]);
         }
         if (q == 0)

@@ -37,6 +37,31 @@ for case in range(want + 1):
     with np.errstate(all="ignore"):
         lr, ar = orc.forward(A, pobs, pi); br = orc.backward(A, pobs)
         l_ld, a_ld, b_ld, g_ld, C_ld = hidden_longdouble(A, pobs, pi)
+    lg, ag = hidden.forward(A, pobs, pi)
+    bg = hidden.backward(A, pobs)
+    gg = hidden.state_probabilities(ag, bg)
+    f = lambda x: np.asarray(x, dtype=np.float64)
+    print("logL gpu %r ref %r 80-bit %r" % (lg, lr, float(l_ld)))
+    for name, g_, r_, l_ in (("alpha", ag, ar, f(a_ld)), ("beta", bg, br, f(b_ld)), ("gamma", gg, orc.gamma(ar, br), f(g_ld))):
+        nf = ~np.isfinite(g_)
+        print(name, "non-finite gpu entries:", int(nf.sum()), "first bad row", int(np.argmax(nf.any(axis=1))) if nf.any() else None,
+              "| row sums min/max", np.nanmin(g_.sum(axis=1)), np.nanmax(g_.sum(axis=1)))
+        with np.errstate(all="ignore"):
+            rel = np.abs(g_ - l_) / np.abs(l_)
+        rel[~np.isfinite(rel)] = 0
+        rel[np.abs(l_) < 1e-250] = 0
+        t, i = np.unravel_index(np.argmax(rel), rel.shape)
+        print("   worst vs 80-bit at t=%d state %d: rel %.3e gpu %r ref %r 80-bit %r; rows off by > 1e-9: %d" % (
+            t, i, rel[t, i], g_[t, i], r_[t, i], l_[t, i], int((rel.max(axis=1) > 1e-9).sum())))
+        for tt in range(max(0, t - 2), min(T, t + 3)):
+            print("     t", tt, "gpu", g_[tt], "ref", r_[tt], "ld", l_[tt], "pobs", pobs[tt])
+    nf = ~np.isfinite(ag)
+    if nf.any():
+        t = int(np.argmax(nf.any(axis=1)))
+        print("first non-finite alpha row", t)
+        for tt in range(max(0, t - 6), min(T, t + 3)):
+            print("     t", tt, "gpu", ag[tt], "ref", ar[tt], "ld", f(a_ld)[tt], "pobs", pobs[tt])
+    sys.exit(0)
     bg = hidden.backward(A, pobs)
     with np.errstate(all="ignore"):
         rel = np.abs(bg - br) / np.abs(br)
