@@ -471,7 +471,16 @@ __global__ __launch_bounds__(64) void k_wide_fwd(const WideModel m, const int64_
                     S_start = wgroup_sum<NP>(a);
                 }
             } else {
-                const double c = wgroup_sum<NP>(nj);
+                double c = wgroup_sum<NP>(nj);
+                // the new row in the denormal range although the emission row is not (narrow states:
+                // the mass sits where this observation is all but impossible): its sum's reciprocal
+                // would be infinite -- times 2^900, exactly, and 900 off the exponent count (the
+                // backward pass: rescue_product; found by tests/sweeps/stress_small.py 2001 / 2860)
+                if (__builtin_expect(!(c >= 0x1p-959) && c > 0.0, 0)) {
+                    nj = ldexp(nj, 900);
+                    c = wgroup_sum<NP>(nj);
+                    pexp += 900;
+                }
                 a = nj * fast_rcp(c);
                 if (r >= r0) {
                     int e;

@@ -394,3 +394,25 @@ def test_forward_pass_on_its_own_finer_segments():
         np.testing.assert_allclose(r.C, ref.C, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(r.state_counts, ref.state_counts, rtol=1e-10)
         np.testing.assert_allclose(r.state_counts.sum(), sum(len(o) for o in obs), rtol=1e-12)
+
+
+def test_row_in_the_denormal_range_in_the_non_lazy_forward_pass():
+    """tests/sweeps/stress_small.py seed 2001 case 2860 (saved under tests/golden/cases): 20 narrow states,
+    an observation that is all but impossible where the mass sits -- the new alpha row is denormal although
+    the emission row is not, the reciprocal of its sum was infinite and the log-likelihood NaN.  The
+    reference divides by the denormal sum and stays finite."""
+    import os
+    from bhmm_amd.engine import Engine
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cases", "wide20_denormal_row_2001_2860.npz"),
+                allow_pickle=True)
+    A, pi, mu, sig, lens = d["A"], d["pi"], d["par0"], d["par1"], d["lens"]
+    obs = np.split(d["obs"], np.cumsum(lens)[:-1])
+    ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+    assert np.all(np.isfinite(ref["logL"]))
+    eng = Engine(0)
+    eng.set_observations("gaussian", obs, A.shape[0], chunk=int(d["chunk"]))
+    for _ in range(2):
+        res = eng.estep(A, pi, mu, sig)
+        np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-10)
+        np.testing.assert_allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10)
+    eng.close()
