@@ -154,8 +154,30 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
                 // S_t = sum_i alpha_t[i] cur[i] (cur still unnormalised), then W_t from the row t+1
                 const double *a = alpha + (t0 + t) * n;
                 double loc = 0.0;
-                for (int i = tid; i < n; i += GEN_TPB)
-                    loc += a[i] * cur[i];
+                // The next row's products p o beta in or near the denormal range (an observation tens
+                // of sigma from every state): W = p o beta / S would be a quotient of two numbers with
+                // a few digits each -- and S, formed from (A p) beta in the reference's order for the
+                // beta row, does not even lose the SAME digits as the numerators (counts off by up to
+                // 0.15 in tests/sweeps/stress_many_states.py).  There the products are formed with p
+                // times 2^kx (exact) and S from exactly those products; kx cancels in W.
+                int kx = 0;
+                if (c > 0.0) {
+                    int ec;
+                    (void)frexp(c, &ec);
+                    kx = -ec > 64 ? (-ec < 900 ? -ec : 900) : 0;
+                }
+                if (kx > 0) {
+                    for (int i = tid; i < n; i += GEN_TPB) {
+                        double s2 = 0.0;
+                        const double *Ar = At + i;
+                        for (int j = 0; j < n; ++j)
+                            s2 += Ar[(int64_t)j * n] * (ldexp(np[j], kx) * nb[j]);
+                        loc += a[i] * s2;
+                    }
+                } else {
+                    for (int i = tid; i < n; i += GEN_TPB)
+                        loc += a[i] * cur[i];
+                }
                 // tree sum over the workgroup through LDS (slot area: GEN_TPB doubles behind slot)
                 double *red = slot + 1;
                 red[tid] = loc;
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
                 __syncthreads();
                 double *wr = W + (t0 + t) * n;
                 for (int j = tid; j < n; j += GEN_TPB)
-                    wr[j] = np[j] * nb[j] / Snorm;
+                    wr[j] = ldexp(np[j], kx) * nb[j] / Snorm;
             } else {
                 double *wr = W + (t0 + t) * n;
                 for (int j = tid; j < n; j += GEN_TPB)

@@ -10,9 +10,11 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 from bhmm_amd.engine import Engine
 from oracle import oracle as orc
+from ld_reference import estep_longdouble
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 11)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+ONLY = int(os.environ["ONLY"]) if os.environ.get("ONLY") else -1   # replay one case (same random stream)
 bad = skipped = nbig = 0
 for case in range(ncase):
     big = rng.random() < 0.35
@@ -50,21 +52,63 @@ for case in range(ncase):
             skipped += 1
             continue
         pobs = [orc.pobs_gaussian(o, *par) if kind == "gaussian" else orc.pobs_discrete(o, B) for o in obs]
-        if kind == "gaussian" and any(np.any((po.max(axis=1) < 1e-290)) for po in pobs):
-            skipped += 1
-            continue  # denormal emission rows: covered by stress_small against the 80-bit recursion
+        # emission rows whose entries reach into the denormal range: the double-precision reference loses
+        # digits there (seed 3007 case 894: its counts are off the 80-bit recursion by 1.5e-6, the kernels
+        # by 1e-14) -- compared with the reference's recursions carried out in 80-bit arithmetic instead
+        denorm = kind == "gaussian" and any(np.any((po.max(axis=1) < 1e-250)) for po in pobs)
+        if denorm:
+            with np.errstate(all="ignore"):
+                ld_logL, ld_C = estep_longdouble(A, pi, pobs)
+            if not (np.all(np.isfinite(ld_logL)) and np.all(np.isfinite(ld_C))):
+                skipped += 1
+                continue
         nbig += int(big)
+        if ONLY >= 0 and case != ONLY:
+            for T in lens:
+                rng.random(T)
+            continue
+        if ONLY >= 0 and os.environ.get("SAVE"):
+            np.savez(os.path.join(os.environ["SAVE"], "many_states_case_%s_%d.npz" % (sys.argv[1], case)), A=A, pi=pi,
+                     par0=par[0], par1=par[1] if par[1] is not None else np.zeros(0), kind=kind, chunk=chunk,
+                     obs=np.concatenate(obs), lens=np.array(lens), M=M)
         eng = Engine(0)
         eng.set_observations(kind, obs, n, nsymbols=M, chunk=chunk)
         for rep in range(2):
             res = eng.estep(A, pi, *par)
-            ok = (np.allclose(res.logL_k, ref["logL"], rtol=1e-10, atol=1e-10) and
-                  np.allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10) and
-                  np.allclose(res.gamma0_sum, ref["gamma0_sum"], rtol=1e-8, atol=1e-12) and
-                  np.allclose(res.state_counts, ref["state_counts"], rtol=1e-8, atol=1e-10))
+            ok = False
+            if denorm:
+                # The lane-per-state kernels stay with the 80-bit values (1e-14 where the reference is off
+                # by 1e-6); the any-N family is order-faithful -- its rows and log-likelihoods are the
+                # reference's bit for bit -- but forms the counts as a GEMM over W = p o beta / S, and
+                # where those products are denormal neither it nor the reference keeps its digits (the
+                # reference is off the 80-bit counts by up to 7e-2 in this sweep): there the counts only
+                # have to be as good as the reference's own, or within 1e-5.
+                ok = (np.allclose(res.logL_k, ld_logL, rtol=1e-10, atol=1e-9) and
+                      np.allclose(res.C, ld_C, rtol=1e-8, atol=1e-9))
+                if not ok and big:
+                    ok = (np.allclose(res.logL_k, ref["logL"], rtol=1e-10, atol=1e-10) and
+                          np.abs(res.C - ld_C).max() <= max(10.0 * np.abs(ref["C"] - ld_C).max(), 1e-5))
+            if not ok:
+                ok = (np.allclose(res.logL_k, ref["logL"], rtol=1e-10, atol=1e-10) and
+                      np.allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10) and
+                      np.allclose(res.gamma0_sum, ref["gamma0_sum"], rtol=1e-8, atol=1e-12) and
+                      np.allclose(res.state_counts, ref["state_counts"], rtol=1e-8, atol=1e-10))
             if not ok:
                 bad += 1
-                print("ESTEP MISMATCH", tag, "rep", rep, np.abs(res.logL_k - ref["logL"]).max(), np.abs(res.C - ref["C"]).max())
+                print("ESTEP MISMATCH", tag, "rep", rep, np.abs(res.logL_k - ref["logL"]).max(), np.abs(res.C - ref["C"]).max(),
+                      ("| denormal regime: C gpu-80bit %.2e, ref-80bit %.2e" % (np.abs(res.C - ld_C).max(), np.abs(ref["C"] - ld_C).max())) if denorm else "")
+                if ONLY >= 0:
+                    d = np.abs(res.C - ref["C"])
+                    i, j = np.unravel_index(np.argmax(d), d.shape)
+                    print("   worst C entry", (i, j), "gpu", res.C[i, j], "ref", ref["C"][i, j], "| C sums", res.C.sum(), ref["C"].sum(),
+                          "| gamma0", np.abs(res.gamma0_sum - ref["gamma0_sum"]).max(), "state_counts", np.abs(res.state_counts - ref["state_counts"]).max(),
+                          "| careful", eng.get_option("careful"), "spec ok/fail", eng.get_option("spec_ok"), eng.get_option("spec_fail"),
+                          "segments", eng.get_option("wide_segments"))
+        if denorm:
+            eng.close()
+            for T in lens:
+                rng.random(T)
+            continue  # (paths: the reference's own rows are degenerate there, stress_small)
         vp = eng.viterbi(A, pi, *par)
         for k, (p, po) in enumerate(zip(vp, pobs)):
             vr = orc.viterbi(A, po, pi)
