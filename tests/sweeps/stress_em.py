@@ -45,8 +45,21 @@ for case in range(ncase):
         lobs = bhmm_amd.lag_observations(obs, lag) if lag > 1 else obs   # GPU: views cut on the device
         tag += " lag=%d" % lag
         ref = bhmm_amd.MaximumLikelihoodEstimator(lobs, n, engine_factory=OracleEngine, **kw)
-        href = ref.fit()
         est = bhmm_amd.MaximumLikelihoodEstimator(lobs, n, **kw)
+        try:
+            href = ref.fit()
+        except RuntimeError as e_ref:
+            # a state collapsed onto a single observation (gaussian.py:271-272 raises there): the run
+            # on the HIP engine has to end the same way
+            try:
+                est.fit()
+                bad += 1
+                print("MISMATCH", tag, "the oracle-engine run raised", repr(e_ref)[:80], "the HIP run did not")
+            except RuntimeError as e_gpu:
+                if str(e_gpu) != str(e_ref):
+                    bad += 1
+                    print("MISMATCH", tag, "different errors", repr(e_ref)[:80], repr(e_gpu)[:80])
+            continue
         hmm = est.fit()
         ok = (len(est.likelihoods) == len(ref.likelihoods) and np.allclose(est.likelihoods, ref.likelihoods, rtol=1e-9)
               and np.allclose(hmm.transition_matrix, href.transition_matrix, rtol=1e-6, atol=1e-9))
