@@ -63,9 +63,13 @@ for case in range(ncase):
             # reference a few 1e-9 of a beta row, seed 557 case 242; the kernels are closer to the
             # 80-bit values than it is), paths against the reference's
             f = lambda x: np.asarray(x, dtype=np.float64)
+            # entry by entry: a row behind a denormal emission entry may carry the reference's rounding
+            # (seed 4002 case 1395: kernels == reference there, 3e-9 off the 80-bit value) while other
+            # rows of the same call are the 80-bit ones
+            either = lambda g, l, r: bool(np.all(np.isclose(g, l, rtol=1e-9, atol=1e-250) | np.isclose(g, r, rtol=1e-9, atol=1e-250)))
             checks = {"logL": np.isclose(lg, float(l_ld), rtol=1e-11, atol=1e-11) or np.isclose(lg, lr, rtol=1e-11, atol=1e-11),
-                      "alpha": np.allclose(ag, f(a_ld), rtol=1e-9, atol=1e-250) or np.allclose(ag, ar, rtol=1e-9, atol=1e-250),
-                      "beta": np.allclose(bg, f(b_ld), rtol=1e-9, atol=1e-250) or np.allclose(bg, br, rtol=1e-9, atol=1e-250),
+                      "alpha": either(ag, f(a_ld), ar),
+                      "beta": either(bg, f(b_ld), br),
                       # gamma and the counts are functions of the rows they are GIVEN: the reference's
                       # routines on the very same rows (the kernels' alpha may be the double-precision
                       # reference's and their beta the 80-bit one's -- each within its own check)
