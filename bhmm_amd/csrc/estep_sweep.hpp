@@ -1110,7 +1110,11 @@ __device__ __forceinline__ void estep_body(
                          double2 *gdst, auto sc_hi, auto sc_lo) {
             double p_hi[2], d_hi[2], p_lo[2], d_lo[2], sv[2], ah[2];
             const double al[2] = {alo.x, alo.y};
-            if constexpr (CAREFUL && KIND == EMIT_GAUSS) {
+            // (per-step-checked kernels, every emission kind: the rebuilt alpha row is RESCALED.  Left
+            // at the magnitude of its emission row -- explicit rows of 1e-222 -- its product with
+            // A (p o beta) underflowed to zero, S = 0, gamma and the counts NaN: found by the explicit
+            // E-step check of tests/sweeps/stress_small.py, tests/golden/cases/explicit2_nan_counts_*)
+            if constexpr (CAREFUL) {
                 emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, hi, Bt, q, em, p_hi, d_hi);
                 emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, lo, Bt, q, em, p_lo, d_lo);
                 fwd_matvec<N>(gather, al, Ac, sv);

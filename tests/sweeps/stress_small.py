@@ -94,6 +94,29 @@ for case in range(ncase):
                           "careful", eng.get_option("careful"), "spec ok/fail", eng.get_option("spec_ok"), eng.get_option("spec_fail"),
                           "W", eng.get_option("spec_W"), "nan obs", [int(np.isnan(o).sum()) for o in obs])
         pobs = [orc.pobs_gaussian(o, *par) if kind == "gaussian" else orc.pobs_discrete(o, B) for o in obs]
+        if not denorm and not os.environ.get("LARGE") and case % 3 == 0:
+            # gamma rows of a stored-gamma E-step, and the same E-step through explicit emission rows
+            res_g = eng.estep(A, pi, *par, store_gamma=True)
+            kk = int(case // 3) % len(obs)
+            al, be = orc.forward(A, pobs[kk], pi)[1], orc.backward(A, pobs[kk])
+            with np.errstate(all="ignore"):
+                g_ref = orc.gamma(al, be)
+            if np.all(np.isfinite(g_ref)) and not np.allclose(eng.gamma(kk), g_ref, rtol=1e-8, atol=1e-12):
+                bad += 1
+                print("GAMMA MISMATCH", tag, "traj", kk, np.abs(eng.gamma(kk) - g_ref).max())
+            if not np.allclose(res_g.logL_k, ref["logL"], rtol=1e-10, atol=1e-10):
+                bad += 1
+                print("STORE-GAMMA ESTEP MISMATCH", tag)
+            e2 = Engine(0)
+            e2.set_observations("explicit", pobs, n, chunk=chunk)
+            r2 = e2.estep(A, pi, None, None)
+            if not (np.allclose(r2.logL_k, ref["logL"], rtol=1e-10, atol=1e-10) and np.allclose(r2.C, ref["C"], rtol=1e-8, atol=1e-10)):
+                bad += 1
+                print("EXPLICIT ESTEP MISMATCH", tag, np.abs(r2.logL_k - ref["logL"]).max(), np.abs(r2.C - ref["C"]).max())
+                if os.environ.get("SAVE"):
+                    np.savez(os.path.join(os.environ["SAVE"], "explicit_case_%d_%d.npz" % (int(sys.argv[1]) if len(sys.argv) > 1 else 7, case)),
+                             A=A, pi=pi, chunk=chunk, pobs=np.concatenate(pobs), lens=np.array(lens))
+            e2.close()
         vp = eng.viterbi(A, pi, *par)
         for k, (p, po) in enumerate(zip(vp, pobs)):
             vr = orc.viterbi(A, po, pi)

@@ -726,3 +726,34 @@ def test_em_sequence_on_carried_boundary_vectors():
     np.testing.assert_allclose(r2.state_counts.sum(), K * T, rtol=1e-10)
     a.close()
     b.close()
+
+
+def test_explicit_rows_of_1e_minus_222_do_not_underflow_the_rebuilt_alpha_row():
+    """tests/sweeps/stress_small.py seed 7 case 921 (saved under tests/golden/cases): explicit emission rows
+    like [0, 1e-222] followed by [9e-126, 1e-198].  The per-step-checked backward sweep rebuilds every
+    second alpha row from its predecessor; left at the magnitude of its emission row, its product with
+    A (p o beta) underflowed to zero and gamma / the counts were NaN where the reference is finite."""
+    import os
+    from bhmm_amd.engine import Engine
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cases", "explicit2_nan_counts_7_921.npz"))
+    A, pi, lens = d["A"], d["pi"], d["lens"]
+    pobs = np.split(d["pobs"], np.cumsum(lens)[:-1])
+    n = A.shape[0]
+    Cref = np.zeros((n, n))
+    lls = []
+    for p in pobs:
+        ll, al = orc.forward(A, p, pi)
+        be = orc.backward(A, p)
+        Cref += orc.transition_counts(al, be, A, p)
+        lls.append(ll)
+    assert np.all(np.isfinite(Cref))
+    for chunk in (int(d["chunk"]), 0):
+        eng = Engine(0)
+        eng.set_observations("explicit", pobs, n, chunk=chunk)
+        res = eng.estep(A, pi, None, None, store_gamma=True)
+        np.testing.assert_allclose(res.logL_k, lls, rtol=1e-11)
+        np.testing.assert_allclose(res.C, Cref, rtol=1e-8, atol=1e-10)
+        g = eng.gamma(0)
+        np.testing.assert_allclose(g, orc.gamma(orc.forward(A, pobs[0], pi)[1], orc.backward(A, pobs[0])),
+                                   rtol=1e-8, atol=1e-12)
+        eng.close()
