@@ -109,6 +109,24 @@ for case in range(ncase):
             for T in lens:
                 rng.random(T)
             continue  # (paths: the reference's own rows are degenerate there, stress_small)
+        if case % 3 == 0:
+            # stored gamma rows, and the same E-step through explicit emission rows
+            res_g = eng.estep(A, pi, *par, store_gamma=True)
+            kk = int(case // 3) % len(obs)
+            g_ref = orc.gamma(orc.forward(A, pobs[kk], pi)[1], orc.backward(A, pobs[kk]))
+            if np.all(np.isfinite(g_ref)) and not np.allclose(eng.gamma(kk), g_ref, rtol=1e-8, atol=1e-12):
+                bad += 1
+                print("GAMMA MISMATCH", tag, "traj", kk, np.abs(eng.gamma(kk) - g_ref).max())
+            if not np.allclose(res_g.logL_k, ref["logL"], rtol=1e-10, atol=1e-10):
+                bad += 1
+                print("STORE-GAMMA ESTEP MISMATCH", tag)
+            e2 = Engine(0)
+            e2.set_observations("explicit", pobs, n, chunk=chunk)
+            r2 = e2.estep(A, pi, None, None)
+            if not (np.allclose(r2.logL_k, ref["logL"], rtol=1e-10, atol=1e-10) and np.allclose(r2.C, ref["C"], rtol=1e-8, atol=1e-10)):
+                bad += 1
+                print("EXPLICIT ESTEP MISMATCH", tag, np.abs(r2.logL_k - ref["logL"]).max(), np.abs(r2.C - ref["C"]).max())
+            e2.close()
         vp = eng.viterbi(A, pi, *par)
         for k, (p, po) in enumerate(zip(vp, pobs)):
             vr = orc.viterbi(A, po, pi)
