@@ -1158,6 +1158,31 @@ __device__ __forceinline__ void estep_body(
             double p3[2], d3[2], p2[2], d2[2], p1[2], d1[2], p0[2], d0[2], sv[2];
             double a1[2], a2[2], a3[2], af[N], bf[N];
             const double al[2] = {alo.x, alo.y};
+            if constexpr (CAREFUL) {
+                // per-step-checked kernels: every rebuilt row is RESCALED (three steps of emission
+                // probabilities of 1e-150 took the unscaled rows to zero, S = 0, gamma and the counts
+                // NaN -- tests/golden/cases/disc5_tiny_B_8001_1411.npz) and the backward steps are the
+                // checked ones of bcore
+                int unused = 0x7fffffff;
+                emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, x0, Bt, q, em, p0, d0);
+                emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, x1, Bt, q, em, p1, d1);
+                emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, x2, Bt, q, em, p2, d2);
+                emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, x3, Bt, q, em, p3, d3);
+                fwd_matvec<N>(gather, al, Ac, sv);
+                (void)scaled_emit<N, KIND, CAREFUL, false>(x0, q, nreal, gmask, sv, p0, a1, unused);
+                fwd_matvec<N>(gather, a1, Ac, sv);
+                (void)scaled_emit<N, KIND, CAREFUL, false>(x1, q, nreal, gmask, sv, p1, a2, unused);
+                fwd_matvec<N>(gather, a2, Ac, sv);
+                (void)scaled_emit<N, KIND, CAREFUL, false>(x2, q, nreal, gmask, sv, p2, a3, unused);
+                bcore(x3, p3, d3, make_double2(a3[0], a3[1]), gdst, sc3);
+                bcore(x2, p2, d2, make_double2(a2[0], a2[1]), gdst - RS, sc2);
+                bcore(x1, p1, d1, make_double2(a1[0], a1[1]), gdst - 2 * RS, sc1);
+                bcore(x0, p0, d0, alo, gdst - 3 * RS, sc0);
+                (void)ea;
+                (void)af;
+                (void)bf;
+                return;
+            }
             gather(al, af); // alpha_{s-4}
             sched_fence();
             emit_raw<N, KIND, CAREFUL>(m, gmask, nreal, x0, Bt, q, em, p0, d0);

@@ -50,6 +50,9 @@ for case in range(ncase):
     else:
         M = int(rng.choice([2, 17, 64, 300, 1150, 1300, 4000]))
         B = rng.dirichlet(np.ones(M) * 0.5, size=n) * 0.98 + 0.02 / M
+        if rng.random() < 0.2:  # emission probabilities spread over hundreds of decades
+            B = np.exp(-float(rng.choice([50.0, 300.0, 700.0])) * rng.random((n, M)))
+            B /= B.sum(axis=1, keepdims=True)
         if rng.random() < 0.3:  # symbols some states cannot emit (never a whole column)
             zero = rng.random((n, M)) < 0.3
             zero[rng.integers(0, n, M), np.arange(M)] = False

@@ -757,3 +757,32 @@ def test_explicit_rows_of_1e_minus_222_do_not_underflow_the_rebuilt_alpha_row():
         np.testing.assert_allclose(g, orc.gamma(orc.forward(A, pobs[0], pi)[1], orc.backward(A, pobs[0])),
                                    rtol=1e-8, atol=1e-12)
         eng.close()
+
+
+@pytest.mark.parametrize("spec,store_gamma", [(1, False), (1, True), (0, False)])
+def test_discrete_emission_probabilities_spread_over_hundreds_of_decades(spec, store_gamma):
+    """tests/sweeps/stress_small.py seed 8001 case 1411 (saved): B with entries down to 2e-294.  The discrete
+    kind keeps every fourth alpha row and rebuilds three from each; unscaled, three steps of probabilities
+    of 1e-150 took the rebuilt rows to zero (S = 0: NaN counts) in the branch-free AND the per-step-checked
+    kernel.  The checked kernel now rescales every rebuilt row; the branch-free one reports and is repeated."""
+    import os
+    from bhmm_amd.engine import Engine
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cases", "disc5_tiny_B_8001_1411.npz"),
+                allow_pickle=True)
+    A, pi, B, lens = d["A"], d["pi"], d["par0"], d["lens"]
+    obs = [o.astype(np.int32) for o in np.split(d["obs"], np.cumsum(lens)[:-1])]
+    ref = orc.estep("discrete", obs, A, pi, B, None, want_gamma=True)
+    assert np.all(np.isfinite(ref["C"]))
+    eng = Engine(0)
+    eng.set_option("spec_enabled", spec)
+    eng.set_observations("discrete", obs, A.shape[0], nsymbols=B.shape[1], chunk=int(d["chunk"]))
+    for _ in range(2):
+        res = eng.estep(A, pi, B, store_gamma=store_gamma)
+        np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-10)
+        np.testing.assert_allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-8, atol=1e-10)
+        Bn = orc.estimate_discrete(obs, ref["gammas"], B.shape[1])       # discrete.py:202-215 on the reference's gammas
+        np.testing.assert_allclose(res.symbol_counts / res.symbol_counts.sum(axis=1)[:, None], Bn, rtol=1e-8, atol=1e-12)
+    if store_gamma:
+        np.testing.assert_allclose(eng.gamma(0), ref["gammas"][0], rtol=1e-8, atol=1e-12)
+    eng.close()
