@@ -42,6 +42,9 @@ for case in range(ncase):
     else:
         M = int(rng.choice([3, 40, 257, 1200]))
         B = rng.dirichlet(np.ones(M) * 0.5, size=n) * 0.98 + 0.02 / M
+        if rng.random() < 0.25:  # emission probabilities spread over hundreds of decades
+            B = np.exp(-float(rng.choice([50.0, 300.0, 700.0])) * rng.random((n, M)))
+            B /= B.sum(axis=1, keepdims=True)
         obs = [rng.integers(0, M, T).astype(np.int32) for T in lens]
         par = (B, None)
     tag = "case %d: %s n=%d M=%d lens=%s chunk=%d" % (case, kind, n, M, lens, chunk)
