@@ -1705,6 +1705,21 @@ int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
     }
     if (logL_k)
         memcpy(logL_k, c->h_pinned + S, c->K * sizeof(double));
+    if (!scan) {
+        // finite log-likelihoods but a non-finite statistic: fail loudly rather than hand NaN counts
+        // to an M-step.  Known to happen only for reducible transition matrices (A = I) with
+        // emission probabilities hundreds of decades apart, where the blocks' likelihood ratio
+        // leaves the double range inside one chunk and the transfer matrices of the exact pipeline
+        // (one exponent per matrix) lose a block.
+        // (log-likelihood, sum gamma_0, counts, sum gamma -- not the emission sums: an infinite
+        // observation that the outlier rule lets through makes those infinite in the reference too)
+        const int ncheck = std::min(S, 1 + c->n + c->n * c->n + c->n);
+        for (int e = 0; e < ncheck; ++e)
+            if (!std::isfinite(c->h_pinned[e])) {
+                g_err = "sufficient statistic " + std::to_string(e) + " of the E-step is not finite";
+                return BHMM_ERR_NONFINITE;
+            }
+    }
     if (scan)
     for (int k = 0; k < c->K; ++k)
         if (!std::isfinite(c->h_pinned[S + k])) {

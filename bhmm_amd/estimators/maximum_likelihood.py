@@ -258,6 +258,9 @@ class MaximumLikelihoodEstimator(object):
             packed = comm.allreduce_sum_numpy(packed)
             res = EStepResult(self._output, self._nstates, self._nsymbols, packed, logL_k)
         assert np.isfinite(res.loglik)       # maximum_likelihood.py:385
+        nn = self._nstates
+        assert np.all(np.isfinite(res.packed[:1 + 2 * nn + nn * nn])), \
+            'counts of the E-step are not finite'
         return res
 
     # ---- M-step --------------------------------------------------------------------------

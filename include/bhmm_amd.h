@@ -139,7 +139,10 @@ int bhmm_estep(bhmm_ctx *ctx, const double *A, const double *pi, const double *p
 /* Wait for the last E-step and copy results to the host.  stats (packed vector) and/or
  * logL_k[K] may be NULL.  Returns BHMM_ERR_NONFINITE if any logL_k is not finite.  With more than
  * 4096 trajectories the K log-likelihoods cross the host link only when logL_k is asked for (or the
- * total is not finite and the offending trajectory has to be named): an EM loop needs stats[0]. */
+ * total is not finite and the offending trajectory has to be named): an EM loop needs stats[0].
+ * BHMM_ERR_NONFINITE also if the log-likelihoods are finite but a count (sum gamma_0, C, sum gamma) is
+ * not: known only for reducible transition matrices with emission probabilities hundreds of decades
+ * apart -- refused loudly instead of handing NaN counts to an M-step. */
 int bhmm_estep_fetch(bhmm_ctx *ctx, double *stats, double *logL_k);
 /* After an E-step run with BHMM_FLAG_STORE_GAMMA: copy gamma of trajectory k, (T_k,N)
  * row-major, to the host. */

@@ -38,6 +38,10 @@ for case in range(ncase):
         mu, sig = np.sort(rng.normal(0, 0.15 * n, n)), rng.uniform(0.3, 2.0, n)
         spread = 0.2 * n * (4.0 if rng.random() < 0.3 else 1.0)
         obs = [rng.normal(0, spread, T) for T in lens]
+        if rng.random() < 0.15:  # a few extreme values: huge, infinite, exactly on a mean
+            for o in obs:
+                for _ in range(int(rng.integers(1, 4))):
+                    o[rng.integers(0, len(o))] = rng.choice([1e200, -1e200, np.inf, -np.inf, 1e-300, float(mu[rng.integers(0, n)])])
         par, M = (mu, sig), 0
     else:
         M = int(rng.choice([3, 40, 257, 1200]))

@@ -19,7 +19,7 @@ from ld_reference import estep_longdouble
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-bad = 0
+bad = limited = 0
 for case in range(ncase):
     n = int(rng.integers(1, 9)) if rng.random() < 0.7 else int(rng.integers(9, 25))
     kind = "gaussian" if rng.random() < 0.5 else "discrete"
@@ -45,6 +45,10 @@ for case in range(ncase):
         if regime == "narrow":
             sig = sig * 0.05
         obs = [rng.normal(0, 12.0 if regime == "far" else 3.0, T) for T in lens]
+        if rng.random() < 0.15:  # a few extreme values: huge, infinite, exactly on a mean
+            for o in obs:
+                for _ in range(int(rng.integers(1, 4))):
+                    o[rng.integers(0, len(o))] = rng.choice([1e200, -1e200, np.inf, -np.inf, 1e-300, float(mu[rng.integers(0, n)])])
         par = (mu, sig)
         M = 0
     else:
@@ -137,11 +141,22 @@ for case in range(ncase):
                 print("SAMPLE MISMATCH", tag, "traj", k)
         eng.close()
     except Exception as e:  # noqa
+        if "is not finite" in repr(e) and "statistic" in repr(e):
+            # the loud failure of a known limitation: a REDUCIBLE transition matrix (blocks that never
+            # mix) whose blocks' likelihood ratio leaves the double range within one chunk
+            from scipy.sparse.csgraph import connected_components
+            if connected_components(A > 0, directed=True, connection="strong")[0] > 1:
+                limited += 1
+                try:
+                    eng.close()
+                except Exception:
+                    pass
+                continue
         if os.environ.get("SAVE"):
             np.savez(os.path.join(os.environ["SAVE"], "stress_case_%d_%d.npz" % (int(sys.argv[1]) if len(sys.argv) > 1 else 7, case)),
                      A=A, pi=pi, par0=par[0], par1=par[1] if par[1] is not None else np.zeros(0), kind=kind, chunk=chunk,
                      obs=np.concatenate(obs), lens=np.array(lens))
         bad += 1
         print("EXCEPTION", tag, repr(e)[:300])
-print("stress: %d cases, %d failures" % (ncase, bad))
+print("stress: %d cases, %d failures%s" % (ncase, bad, (" (%d reducible models refused loudly: non-finite statistics)" % limited) if limited else ""))
 sys.exit(1 if bad else 0)
