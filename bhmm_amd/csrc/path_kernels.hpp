@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(64) void k_vit_walk(const Chunks ch, int G, int n, 
                                                  PT *path, int32_t *coal)
 {
     constexpr int GP = 64 / NP;
-    __shared__ uint8_t tile[GP][64 * NP];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[GP][64 * NP];
     __shared__ int32_t outp[GP][64];
     const int lane = threadIdx.x;
     const int gi = lane / NP, e = lane % NP;
@@ -1636,8 +1636,16 @@ __global__ __launch_bounds__(64) void k_vit_walk(const Chunks ch, int G, int n, 
             const int lo = hi - 63 > s_lo ? hi - 63 : s_lo;
             const int cnt = hi - lo + 1;
             const int64_t base = (goff + lo) * n;
-            for (int b = e; b < cnt * n; b += NP)
-                tile[gi][b] = ptr[base + b];
+            if ((n & 3) == 0) {
+                // rows of 4 or 8 bytes: the tile as 32-bit words (a quarter of the loads and stores)
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(ptr + base);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(&tile[gi][0]);
+                for (int b = e; b < cnt * n / 4; b += NP)
+                    dst[b] = src[b];
+            } else {
+                for (int b = e; b < cnt * n; b += NP)
+                    tile[gi][b] = ptr[base + b];
+            }
             const bool writing = APPLY || agreed;
             for (int q = cnt - 1; q >= 0; --q) {
                 cur = tile[gi][q * n + cur];
