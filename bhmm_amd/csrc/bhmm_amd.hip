@@ -68,7 +68,7 @@ static int stats_size(const bhmm_ctx *c);
 static int lds_symbols(const bhmm_ctx *c) { return c->bt_global ? 0 : c->M; }
 static int64_t ci_records(const bhmm_ctx *c) { return (int64_t)(c->Gp / 64) * c->Lmax; }
 
-int replan_coarse(bhmm_ctx *c, bool half = false); // (defined with bhmm_ctx_set_observations)
+int replan_coarse(bhmm_ctx *c, bool half = false, int chunk = 0); // (defined with bhmm_ctx_set_observations)
 int replan_for_warmup(bhmm_ctx *c);
 
 #ifndef ESTEP_SPLIT
@@ -1230,11 +1230,11 @@ int bhmm::replan_for_warmup(bhmm_ctx *c)
     return replan_coarse(c, true);
 }
 
-int bhmm::replan_coarse(bhmm_ctx *c, bool half)
+int bhmm::replan_coarse(bhmm_ctx *c, bool half, int chunk)
 {
     int rc;
     BHMM_HIP(hipStreamSynchronize(c->stream));
-    if ((rc = plan_chunks(c, 0, false, half)) || (rc = alloc_work(c)))
+    if ((rc = plan_chunks(c, chunk, false, half)) || (rc = alloc_work(c)))
         return rc;
     if ((rc = pack_observations(c, c->d_obs_rm.p)))
         return rc;
@@ -1329,6 +1329,7 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     }
     c->chunk_auto = chunk <= 0;
     c->replanned_half = false;
+    c->serial_retry_done = false;
     rc = plan_chunks(c, chunk);
     if (rc)
         return rc;
@@ -1667,6 +1668,35 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         rc = wide_estep(c, A, pi, par0, par1, sd, flags);
     else
         rc = BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
+    if (rc == BHMM_OK && !c->wide && !c->gen && c->G > c->K && !c->serial_retry_done) {
+        // Safety net for the one situation in which a chunked evaluation cannot follow the reference
+        // (reducible transition matrices whose blocks' relative weight leaves the
+        // double range -- the reference's result depends on the order in which ITS recursions lose a
+        // block): finite log-likelihoods but non-finite counts.  The observations are re-planned with
+        // one chunk per trajectory -- the plain sequential recursions -- and the E-step is repeated,
+        // once per set of observations.
+        const int S = stats_size(c);
+        if (!c->prefetched) {
+            BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->last_stats, S * sizeof(double), hipMemcpyDeviceToHost,
+                                    c->stream));
+            BHMM_HIP(hipStreamSynchronize(c->stream));
+        }
+        const int ncheck = std::min(S, 1 + c->n + c->n * c->n + c->n);
+        bool finite = true;
+        for (int e = 0; e < ncheck; ++e)
+            finite = finite && std::isfinite(c->h_pinned[e]);
+        int64_t maxT = 0;
+        for (int k = 0; k < c->K; ++k)
+            maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+        if (!finite && std::isfinite(c->h_pinned[0]) && maxT < ((int64_t)1 << 30)) {
+            c->serial_retry_done = true;
+            c->chunk_auto = false;
+            if ((rc = replan_coarse(c, false, (int)maxT)))
+                return rc;
+            c->prefetched = false;
+            rc = BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
+        }
+    }
     c->gamma_valid = rc == BHMM_OK && c->gamma_wanted;
     c->gamma_wanted = false;
     return rc;

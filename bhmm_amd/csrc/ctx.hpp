@@ -131,6 +131,7 @@ struct bhmm_ctx {
     int vit_W = 0;                    // warm-up the chunked Viterbi last verified with (0: spec_W)
     bool chunk_auto = true;           // the caller left the chunk length to the library
     bool replanned_half = false;      // ... and it has been re-planned with half the chunks (once)
+    bool serial_retry_done = false;   // non-finite counts: re-planned with one chunk per trajectory (once)
     unsigned int viterbi_close = 0;   // ... number of lanes that met a close decision
     bool viterbi_chunked = false;     // last bhmm_viterbi_batch ran chunk-parallel (verified)
     int wide_replans = 0;             // 9..64 states: segment plans re-made after failed checks

@@ -786,3 +786,29 @@ def test_discrete_emission_probabilities_spread_over_hundreds_of_decades(spec, s
     if store_gamma:
         np.testing.assert_allclose(eng.gamma(0), ref["gammas"][0], rtol=1e-8, atol=1e-12)
     eng.close()
+
+
+def test_reducible_model_with_wide_emissions_is_repeated_on_one_chunk_per_trajectory():
+    """tests/sweeps/stress_small.py seed 9201 case 840 (saved): A = I with emission probabilities hundreds
+    of decades apart.  The reference's gamma depends on the order in which its sequential recursions lose
+    a block; the chunked evaluation came out 0/0.  The library notices the
+    non-finite counts, re-plans with one chunk per trajectory -- the sequential recursions -- and repeats
+    the E-step: finite, and equal to the reference's."""
+    import os
+    from bhmm_amd.engine import Engine
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cases", "disc2_tiny_B_9201_840.npz"),
+                allow_pickle=True)
+    A, pi, B, lens = d["A"], d["pi"], d["par0"], d["lens"]
+    obs = [o.astype(np.int32) for o in np.split(d["obs"], np.cumsum(lens)[:-1])]
+    ref = orc.estep("discrete", obs, A, pi, B, None)
+    assert np.all(np.isfinite(ref["C"]))
+    eng = Engine(0)
+    eng.set_observations("discrete", obs, 2, nsymbols=B.shape[1], chunk=int(d["chunk"]))
+    assert eng.num_chunks > len(obs)
+    for _ in range(2):
+        res = eng.estep(A, pi, B)
+        np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-10)
+        np.testing.assert_allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-8, atol=1e-10)
+    assert eng.num_chunks == len(obs)
+    eng.close()
