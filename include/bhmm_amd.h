@@ -141,8 +141,9 @@ int bhmm_estep(bhmm_ctx *ctx, const double *A, const double *pi, const double *p
  * 4096 trajectories the K log-likelihoods cross the host link only when logL_k is asked for (or the
  * total is not finite and the offending trajectory has to be named): an EM loop needs stats[0].
  * BHMM_ERR_NONFINITE also if the log-likelihoods are finite but a count (sum gamma_0, C, sum gamma) is
- * not: known only for reducible transition matrices with emission probabilities hundreds of decades
- * apart -- refused loudly instead of handing NaN counts to an M-step. */
+ * not even after bhmm_estep's own retry on one chunk per trajectory (reducible
+ * transition matrices with emission probabilities hundreds of decades apart) -- refused loudly instead
+ * of handing NaN counts to an M-step. */
 int bhmm_estep_fetch(bhmm_ctx *ctx, double *stats, double *logL_k);
 /* After an E-step run with BHMM_FLAG_STORE_GAMMA: copy gamma of trajectory k, (T_k,N)
  * row-major, to the host. */
