@@ -812,3 +812,39 @@ def test_reducible_model_with_wide_emissions_is_repeated_on_one_chunk_per_trajec
         np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-8, atol=1e-10)
     assert eng.num_chunks == len(obs)
     eng.close()
+
+
+@pytest.mark.parametrize("case,kind", [("gauss8_denormal_entries_8101_681", "gaussian"),
+                                       ("disc4_M1150_9501_20", "discrete")])
+@pytest.mark.parametrize("spec,store_gamma", [(1, False), (1, True), (0, False)])
+def test_weight_on_entries_in_the_denormal_range(case, kind, spec, store_gamma):
+    """Two saved cases of tests/sweeps/stress_small.py in which a sparse transition matrix puts the whole
+    weight of a step on a state whose emission probability (seed 8101 case 681: single entries of a Gaussian
+    row below 2^-1022 beside representable ones) or whose p o beta entry (seed 9501 case 20: beta spread over
+    more than 300 decades) is in the denormal range.  The reference multiplies alpha A p beta left to right and
+    divides by the sum of the same products, so the lost bits cancel and it stays within 2e-15 of the 80-bit
+    recursion; products formed in another order, or rounded once more in A (p o beta), left counts off by 6e-4
+    and 2e-6.  The per-step-checked kernel forms such rows times 2^900; the branch-free one notices weights
+    alpha_i / S of 2^850 and reports."""
+    import os
+    from bhmm_amd.engine import Engine
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cases", case + ".npz"), allow_pickle=True)
+    A, pi, lens = d["A"], d["pi"], d["lens"]
+    par0, par1 = d["par0"], (d["par1"] if d["par1"].size else None)
+    obs = np.split(d["obs"], np.cumsum(lens)[:-1])
+    if kind == "discrete":
+        obs = [o.astype(np.int32) for o in obs]
+    ref = orc.estep(kind, obs, A, pi, par0, par1, want_gamma=True)
+    assert np.all(np.isfinite(ref["C"]))
+    eng = Engine(0)
+    eng.set_option("spec_enabled", spec)
+    eng.set_observations(kind, obs, A.shape[0], nsymbols=par0.shape[1] if kind == "discrete" else 0,
+                         chunk=int(d["chunk"]))
+    for _ in range(2):
+        res = eng.estep(A, pi, par0, par1, store_gamma=store_gamma)
+        np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-10)
+        np.testing.assert_allclose(res.C, ref["C"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-9, atol=1e-11)
+    if store_gamma:
+        np.testing.assert_allclose(eng.gamma(0), ref["gammas"][0], rtol=1e-8, atol=1e-12)
+    eng.close()
