@@ -20,6 +20,9 @@ int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, con
 namespace {
 
 size_t gen_smem(int n, int vectors, int extra) { return ((size_t)vectors * n + extra) * sizeof(double); }
+// the workgroup's own copy of the transition matrix behind the vectors, where it fits (gen_kernels.hpp, ALDS)
+size_t gen_a_bytes(int n) { return (size_t)n * n * sizeof(double); }
+bool gen_a_in_lds(int n, size_t vectors_bytes) { return vectors_bytes + gen_a_bytes(n) <= GEN_LDS_LIMIT; }
 
 template <typename F>
 int gen_set_smem(F *fn, size_t sm)
@@ -66,12 +69,21 @@ int gen_transposed(bhmm_ctx *c, const WideModel &m)
 
 int gen_launch_forward(bhmm_ctx *c, const WideModel &m, const double *pobs)
 {
-    const size_t sm = gen_smem(c->n, 2, 2);
-    int rc = gen_set_smem(k_gen_forward, sm);
-    if (rc)
-        return rc;
-    hipLaunchKernelGGL(k_gen_forward, dim3(c->K), dim3(GEN_TPB), sm, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, c->K, pobs, c->d_alpha_rm.p, c->d_logLk.p);
+    size_t sm = gen_smem(c->n, 2, 2);
+    const bool alds = gen_a_in_lds(c->n, sm);
+    int rc;
+    if (alds) {
+        sm += gen_a_bytes(c->n);
+        if ((rc = gen_set_smem(k_gen_forward<true>, sm)))
+            return rc;
+        hipLaunchKernelGGL(k_gen_forward<true>, dim3(c->K), dim3(GEN_TPB), sm, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, c->K, pobs, c->d_alpha_rm.p, c->d_logLk.p);
+    } else {
+        if ((rc = gen_set_smem(k_gen_forward<false>, sm)))
+            return rc;
+        hipLaunchKernelGGL(k_gen_forward<false>, dim3(c->K), dim3(GEN_TPB), sm, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, c->K, pobs, c->d_alpha_rm.p, c->d_logLk.p);
+    }
     BHMM_HIP(hipGetLastError());
     return BHMM_OK;
 }
@@ -121,14 +133,24 @@ int gen_backward(bhmm_ctx *c, const double *A)
     if (rc || (rc = gen_transposed(c, m)))
         return rc;
     const double *pobs = reinterpret_cast<const double *>(c->d_obs_rm.p);
-    const size_t sm = gen_smem(c->n, 3, 1 + GEN_TPB);
-    if ((rc = gen_set_smem(k_gen_backward<EMIT_EXPL, false>, sm)))
-        return rc;
-    hipLaunchKernelGGL((k_gen_backward<EMIT_EXPL, false>), dim3(c->K), dim3(GEN_TPB), sm, c->stream, m,
-                       (const double *)c->d_gAt.p, (const int64_t *)c->d_offsets.p, c->K, pobs,
-                       (const void *)nullptr, (const double *)nullptr, c->d_alpha_rm.p,
-                       (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr,
-                       (double *)nullptr);
+    size_t sm = gen_smem(c->n, 3, 1 + GEN_TPB);
+    const bool alds = gen_a_in_lds(c->n, sm);
+    sm += alds ? gen_a_bytes(c->n) : 0;
+#define BHMM_GEN_BETA(ALDSV)                                                                         \
+    do {                                                                                             \
+        if ((rc = gen_set_smem(k_gen_backward<EMIT_EXPL, false, ALDSV>, sm)))                        \
+            return rc;                                                                               \
+        hipLaunchKernelGGL((k_gen_backward<EMIT_EXPL, false, ALDSV>), dim3(c->K), dim3(GEN_TPB), sm, \
+                           c->stream, m, (const double *)c->d_gAt.p, (const int64_t *)c->d_offsets.p, \
+                           c->K, pobs, (const void *)nullptr, (const double *)nullptr,               \
+                           c->d_alpha_rm.p, (double *)nullptr, (double *)nullptr, (double *)nullptr, \
+                           (double *)nullptr, (double *)nullptr);                                    \
+    } while (0)
+    if (alds)
+        BHMM_GEN_BETA(true);
+    else
+        BHMM_GEN_BETA(false);
+#undef BHMM_GEN_BETA
     BHMM_HIP(hipGetLastError());
     return BHMM_OK;
 }
@@ -159,17 +181,26 @@ int gen_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0
     BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
     if (c->kind == EMIT_DISC)
         BHMM_HIP(hipMemsetAsync(c->d_gsym.p, 0, (size_t)n * c->M * sizeof(double), c->stream));
-    const size_t sm = gen_smem(n, 3, 1 + GEN_TPB);
+    size_t sm = gen_smem(n, 3, 1 + GEN_TPB);
+    const bool alds = gen_a_in_lds(n, sm);
+    sm += alds ? gen_a_bytes(n) : 0;
     double *gam = sg ? c->d_gamma_ci.p : nullptr;
-#define BHMM_GEN_BWD(KINDV)                                                                          \
+#define BHMM_GEN_BWD2(KINDV, ALDSV)                                                                  \
     do {                                                                                             \
-        if ((rc = gen_set_smem(k_gen_backward<KINDV, true>, sm)))                                    \
+        if ((rc = gen_set_smem(k_gen_backward<KINDV, true, ALDSV>, sm)))                             \
             return rc;                                                                               \
-        hipLaunchKernelGGL((k_gen_backward<KINDV, true>), dim3(K), dim3(GEN_TPB), sm, c->stream, m,  \
-                           (const double *)c->d_gAt.p, (const int64_t *)c->d_offsets.p, K, pobs,     \
-                           (const void *)c->d_obs_rm.p, (const double *)c->d_alpha_rm.p,             \
+        hipLaunchKernelGGL((k_gen_backward<KINDV, true, ALDSV>), dim3(K), dim3(GEN_TPB), sm,         \
+                           c->stream, m, (const double *)c->d_gAt.p, (const int64_t *)c->d_offsets.p, \
+                           K, pobs, (const void *)c->d_obs_rm.p, (const double *)c->d_alpha_rm.p,    \
                            (double *)nullptr, c->d_gW.p, gam, c->d_gpart.p, c->d_gamma0.p,           \
                            c->d_gsym.p);                                                             \
+    } while (0)
+#define BHMM_GEN_BWD(KINDV)                                                                          \
+    do {                                                                                             \
+        if (alds)                                                                                    \
+            BHMM_GEN_BWD2(KINDV, true);                                                              \
+        else                                                                                         \
+            BHMM_GEN_BWD2(KINDV, false);                                                             \
     } while (0)
     if (c->kind == EMIT_GAUSS)
         BHMM_GEN_BWD(EMIT_GAUSS);
@@ -178,6 +209,7 @@ int gen_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0
     else
         BHMM_GEN_BWD(EMIT_EXPL);
 #undef BHMM_GEN_BWD
+#undef BHMM_GEN_BWD2
     BHMM_HIP(hipGetLastError());
     const int tiles = (n + 31) / 32;
     hipLaunchKernelGGL(k_gen_xi_gemm, dim3(tiles * tiles, nsplit), dim3(256), 0, c->stream,
@@ -224,11 +256,19 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
     uint16_t *ptr = reinterpret_cast<uint16_t *>(c->d_scratch.p);
     int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
     int32_t *path = last + K;
-    const size_t sm = gen_smem(n, 2, 2);
-    if ((rc = gen_set_smem(k_gen_viterbi_fwd, sm)))
-        return rc;
-    hipLaunchKernelGGL(k_gen_viterbi_fwd, dim3(K), dim3(GEN_TPB), sm, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, K, pobs, ptr, last);
+    size_t sm = gen_smem(n, 2, 2);
+    if (gen_a_in_lds(n, sm)) {
+        sm += gen_a_bytes(n);
+        if ((rc = gen_set_smem(k_gen_viterbi_fwd<true>, sm)))
+            return rc;
+        hipLaunchKernelGGL(k_gen_viterbi_fwd<true>, dim3(K), dim3(GEN_TPB), sm, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, K, pobs, ptr, last);
+    } else {
+        if ((rc = gen_set_smem(k_gen_viterbi_fwd<false>, sm)))
+            return rc;
+        hipLaunchKernelGGL(k_gen_viterbi_fwd<false>, dim3(K), dim3(GEN_TPB), sm, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, K, pobs, ptr, last);
+    }
     BHMM_HIP(hipGetLastError());
     const dim3 tg((K + 63) / 64), tb(64);
     if (out_fmt == 0) {
@@ -284,12 +324,21 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
     }
     BHMM_HIP(hipMemsetAsync(cnt, 0, (nstat + nsym) * sizeof(unsigned long long), c->stream));
     BHMM_HIP(hipMemsetAsync(status, 0, sizeof(int), c->stream));
-    const size_t sm = gen_smem(n, 1, 4);
-    if ((rc = gen_set_smem(k_gen_sample, sm)))
-        return rc;
-    hipLaunchKernelGGL(k_gen_sample, dim3(K), dim3(GEN_TPB), sm, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, K, (const double *)c->d_alpha_rm.p,
-                       (const double *)udev, seed, (const int64_t *)c->d_soff.p, path, status);
+    size_t sm = gen_smem(n, 2, 4);
+    if (gen_a_in_lds(n, sm)) {
+        sm += gen_a_bytes(n);
+        if ((rc = gen_set_smem(k_gen_sample<true>, sm)))
+            return rc;
+        hipLaunchKernelGGL(k_gen_sample<true>, dim3(K), dim3(GEN_TPB), sm, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, K, (const double *)c->d_alpha_rm.p,
+                           (const double *)udev, seed, (const int64_t *)c->d_soff.p, path, status);
+    } else {
+        if ((rc = gen_set_smem(k_gen_sample<false>, sm)))
+            return rc;
+        hipLaunchKernelGGL(k_gen_sample<false>, dim3(K), dim3(GEN_TPB), sm, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, K, (const double *)c->d_alpha_rm.p,
+                           (const double *)udev, seed, (const int64_t *)c->d_soff.p, path, status);
+    }
     BHMM_HIP(hipGetLastError());
     int hstatus = 0;
     BHMM_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -420,11 +469,11 @@ int gen_sample_path(int32_t *path, const double *alpha, const double *A, const d
     memset(&m, 0, sizeof(m));
     m.A = dA;
     m.n = N;
-    const size_t sm = ((size_t)N + 4) * sizeof(double);
-    int rc = gen_set_smem(k_gen_sample, sm);
+    const size_t sm = gen_smem(N, 2, 4);
+    int rc = gen_set_smem(k_gen_sample<false>, sm);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(k_gen_sample, dim3(1), dim3(GEN_TPB), sm, 0, m, (const int64_t *)doff, 1,
+    hipLaunchKernelGGL(k_gen_sample<false>, dim3(1), dim3(GEN_TPB), sm, 0, m, (const int64_t *)doff, 1,
                        (const double *)da, (const double *)du, (uint64_t)0, (const int64_t *)nullptr,
                        dpath, status);
     BHMM_HIP(hipGetLastError());

@@ -24,19 +24,40 @@ __device__ __forceinline__ double gen_ordered_sum(const double *x, int n, double
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        // same additions in the same order; the loads of eight entries are issued together (one
-        // LDS round trip per eight additions instead of one per addition)
+        // same additions in the same order; eight entries are loaded at a time and the next eight are
+        // requested before the current eight are added (the chain of additions is what bounds this:
+        // the LDS round trips hide behind it)
         double s = 0.0;
-        int i = 0;
-        for (; i + 8 <= n; i += 8) {
-            double v[8];
+        const int nb = n / 8;
+        double v[8], w[8];
+        if (nb > 0) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[u] = x[i + u];
+                v[u] = x[u];
+        }
+        int b = 0;
+        for (; b + 2 <= nb; b += 2) { // two register sets in turn: no copies that would wait for a load
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                w[u] = x[8 * (b + 1) + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += v[u];
+            if (b + 2 < nb) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = x[8 * (b + 2) + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += w[u];
+        }
+        if (b < nb) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 s += v[u];
         }
+        int i = 8 * nb;
         for (; i < n; ++i)
             s += x[i];
         *slot = s;
@@ -45,7 +66,191 @@ __device__ __forceinline__ double gen_ordered_sum(const double *x, int n, double
     return *slot;
 }
 
+// The transition matrix of a model with n^2 doubles + the vectors below 160 KB of LDS (n <= ~140) is
+// copied there once per workgroup (ALDS): every step reads all of it, and the ~600 cycles of an L2
+// round trip per eight products -- in front of a chain of dependent additions that the reference's
+// order does not allow to split -- were most of a step (3 us per step at n = 65).
+constexpr size_t GEN_LDS_LIMIT = 160 * 1024;
+// The products of a batch are all formed before its chain of additions starts: left to itself the
+// scheduler emits product, addition, product, addition, ... and every addition then waits for its own
+// product as well as for its predecessor (twice the latency per term).
+#define GEN_CHAIN_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// sum_i x[i] * Ac[i * stride], in ascending i (the reference's loop; products and additions separate:
+// -ffp-contract=off), eight products' operands loaded at a time, the next eight requested first
+template <bool PRE>
+__device__ __forceinline__ double gen_dot(const double *Ac, int64_t stride, const double *x, int n)
+{
+    double s = 0.0;
+    int i = 0;
+    if constexpr (!PRE) {
+        // the matrix in global memory (more than ~140 states; several wavefronts per SIMD hide the
+        // round trips between them, and the look-ahead below measured 10 % slower there)
+        for (; i + 8 <= n; i += 8) {
+            double av[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[u] = Ac[(int64_t)(i + u) * stride];
+                xv[u] = x[i + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                xv[u] = xv[u] * av[u];
+            GEN_CHAIN_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += xv[u];
+        }
+    } else {
+        const int nb = n / 8;
+        double av[8], xv[8], aw[8], xw[8];
+        if (nb > 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[u] = Ac[(int64_t)u * stride];
+                xv[u] = x[u];
+            }
+        }
+        int b = 0;
+        for (; b + 2 <= nb; b += 2) { // two register sets in turn (no copies that would wait for a load)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                aw[u] = Ac[(int64_t)(8 * (b + 1) + u) * stride];
+                xw[u] = x[8 * (b + 1) + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                xv[u] = xv[u] * av[u];
+            GEN_CHAIN_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += xv[u];
+            if (b + 2 < nb) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = Ac[(int64_t)(8 * (b + 2) + u) * stride];
+                    xv[u] = x[8 * (b + 2) + u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                xw[u] = xw[u] * aw[u];
+            GEN_CHAIN_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += xw[u];
+        }
+        if (b < nb) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                xv[u] = xv[u] * av[u];
+            GEN_CHAIN_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += xv[u];
+        }
+        i = 8 * nb;
+    }
+    for (; i < n; ++i)
+        s += x[i] * Ac[(int64_t)i * stride];
+    return s;
+}
+// sum_j Ar[j * stride] * p[j] * b[j], in ascending j, (A p) b as _hidden.c:92-98 multiplies
+template <bool PRE>
+__device__ __forceinline__ double gen_dot3(const double *Ar, int64_t stride, const double *p,
+                                           const double *b, int n)
+{
+    double s = 0.0;
+    int j = 0;
+    if constexpr (!PRE) {
+        for (; j + 8 <= n; j += 8) {
+            double av[8], pv[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[u] = Ar[(int64_t)(j + u) * stride];
+                pv[u] = p[j + u];
+                bv[u] = b[j + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                av[u] = av[u] * pv[u] * bv[u];
+            GEN_CHAIN_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += av[u];
+        }
+    } else {
+        const int nb = n / 8;
+        double av[8], pv[8], bv[8], aw[8], pw[8], bw[8];
+        if (nb > 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[u] = Ar[(int64_t)u * stride];
+                pv[u] = p[u];
+                bv[u] = b[u];
+            }
+        }
+        int q = 0;
+        for (; q + 2 <= nb; q += 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                aw[u] = Ar[(int64_t)(8 * (q + 1) + u) * stride];
+                pw[u] = p[8 * (q + 1) + u];
+                bw[u] = b[8 * (q + 1) + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                av[u] = av[u] * pv[u] * bv[u];
+            GEN_CHAIN_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += av[u];
+            if (q + 2 < nb) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = Ar[(int64_t)(8 * (q + 2) + u) * stride];
+                    pv[u] = p[8 * (q + 2) + u];
+                    bv[u] = b[8 * (q + 2) + u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                aw[u] = aw[u] * pw[u] * bw[u];
+            GEN_CHAIN_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += aw[u];
+        }
+        if (q < nb) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                av[u] = av[u] * pv[u] * bv[u];
+            GEN_CHAIN_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                s += av[u];
+        }
+        j = 8 * nb;
+    }
+    for (; j < n; ++j)
+        s += Ar[(int64_t)j * stride] * p[j] * b[j];
+    return s;
+}
+
+// sum over the workgroup (any order: only the tolerance-compared statistics use it): butterfly inside
+// each wavefront, the four partial sums through `red` -- one barrier; the caller alternates between two
+// areas, and every step has further barriers, so an area is never rewritten while it is still read
+__device__ __forceinline__ double gen_block_sum(double v, double *red)
+{
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // _hidden.c:16-66.  alpha rows (total, n) row-major, logL per trajectory.
+template <bool ALDS>
 __global__ __launch_bounds__(GEN_TPB) void k_gen_forward(const WideModel m, const int64_t *off, int K,
                                                           const double *pobs, double *alpha,
                                                           double *logL)
@@ -53,39 +258,42 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_forward(const WideModel m, cons
     extern __shared__ double gsm[];
     const int n = m.n, tid = threadIdx.x;
     double *xa = gsm, *ya = gsm + n, *slot = gsm + 2 * n;
+    const double *Amat;
+    if constexpr (ALDS) {
+        double *Al = gsm + 2 * n + 2;
+        for (int e = tid; e < n * n; e += GEN_TPB)
+            Al[e] = m.A[e];
+        Amat = Al;
+    } else {
+        Amat = m.A;
+    }
     const int k = blockIdx.x;
     const int64_t t0 = off[k], T = off[k + 1] - t0;
     double ll = 0.0;
+    __syncthreads();
+    // The emission row of the next step is requested a step ahead (first state of each thread; a
+    // barrier pins the load where it is written), and the logarithms are taken by the LAST thread --
+    // idle below 256 states -- so that thread 0's ordered sum is the only serial stretch of a step.
+    double pnext = (T > 0 && tid < n) ? pobs[t0 * n + tid] : 0.0, cprev = 1.0;
     for (int64_t t = 0; t < T; ++t) {
         const double *p = pobs + (t0 + t) * n;
+        const double pmine = pnext;
+        if (t + 1 < T && tid < n)
+            pnext = p[n + tid];
         for (int j = tid; j < n; j += GEN_TPB) {
+            const double pj = j == tid ? pmine : p[j];
             double a;
-            if (t == 0) {
-                a = m.pi[j] * p[j];
-            } else {
-                double s = 0.0;
-                const double *Ac = m.A + j;
-                int i = 0;
-                for (; i + 8 <= n; i += 8) { // eight loads in flight, then the products in order
-                    double av[8], xv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        av[u] = Ac[(int64_t)(i + u) * n];
-                        xv[u] = xa[i + u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        s += xv[u] * av[u];
-                }
-                for (; i < n; ++i)
-                    s += xa[i] * Ac[(int64_t)i * n];
-                a = s * p[j];
-            }
+            if (t == 0)
+                a = m.pi[j] * pj;
+            else
+                a = gen_dot<ALDS>(Amat + j, n, xa, n) * pj;
             ya[j] = a;
         }
+        // (the logarithm of the previous step's sum: in the shadow of the other wavefronts' products)
+        if (tid == GEN_TPB - 1 && t > 0)
+            ll += log(cprev);
         const double c = gen_ordered_sum(ya, n, slot);
-        if (tid == 0)
-            ll += log(c);
+        cprev = c;
         double *out = alpha + (t0 + t) * n;
         for (int j = tid; j < n; j += GEN_TPB) {
             double a = ya[j];
@@ -96,8 +304,11 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_forward(const WideModel m, cons
         }
         __syncthreads();
     }
-    if (tid == 0)
+    if (tid == GEN_TPB - 1) {
+        if (T > 0)
+            ll += log(cprev);
         logL[k] = ll;
+    }
 }
 
 // _hidden.c:69-110 and, with STATS, everything else the E-step takes from the backward pass:
@@ -106,7 +317,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_forward(const WideModel m, cons
 //   gamma rows;  W_t = p_{t+1} o beta_{t+1} / S_t with S_t = sum_i alpha_t[i] (A (p o beta))[i], the
 //   xi normaliser of _hidden.c:168-179, for the GEMM C' = alpha^T W.
 // At = A transposed (coalesced reads of a row of A by the thread that owns it).
-template <int KIND, bool STATS>
+template <int KIND, bool STATS, bool ALDS>
 __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
     const WideModel m, const double *At, const int64_t *off, int K, const double *pobs,
     const void *obs_rm, const double *alpha, double *beta_out, double *W, double *gamma_out,
@@ -115,6 +326,16 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
     extern __shared__ double gsm[];
     const int n = m.n, tid = threadIdx.x;
     double *nb = gsm, *np = gsm + n, *cur = gsm + 2 * n, *slot = gsm + 3 * n;
+    const double *Atm; // A transposed: global, or this workgroup's copy in LDS (behind slot + red)
+    if constexpr (ALDS) {
+        double *Al = gsm + 3 * n + 1 + GEN_TPB;
+        for (int e = tid; e < n * n; e += GEN_TPB)
+            Al[e] = At[e];
+        Atm = Al;
+    } else {
+        Atm = At;
+    }
+    __syncthreads();
     const int k = blockIdx.x;
     const int64_t t0 = off[k], T = off[k + 1] - t0;
     double sc[GEN_MAXPT], sd[GEN_MAXPT], sdd[GEN_MAXPT];
@@ -123,30 +344,18 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
         sc[q] = sd[q] = sdd[q] = 0.0;
     for (int64_t t = T - 1; t >= 0; --t) {
         double Snorm = 1.0;
+        // this step's rows of pobs and alpha, requested before the recursion (first state of each
+        // thread; the barriers pin the loads here) instead of where they are used
+        const double p_mine = tid < n ? pobs[(t0 + t) * n + tid] : 0.0;
+        [[maybe_unused]] double a_mine = 0.0;
+        if constexpr (STATS)
+            a_mine = tid < n ? alpha[(t0 + t) * n + tid] : 0.0;
         if (t == T - 1) {
             for (int i = tid; i < n; i += GEN_TPB)
                 cur[i] = 1.0;
         } else {
-            for (int i = tid; i < n; i += GEN_TPB) {
-                double s = 0.0;
-                const double *Ar = At + i;
-                int j = 0;
-                for (; j + 8 <= n; j += 8) {
-                    double av[8], pv[8], bv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        av[u] = Ar[(int64_t)(j + u) * n];
-                        pv[u] = np[j + u];
-                        bv[u] = nb[j + u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        s += av[u] * pv[u] * bv[u];
-                }
-                for (; j < n; ++j)
-                    s += Ar[(int64_t)j * n] * np[j] * nb[j];
-                cur[i] = s;
-            }
+            for (int i = tid; i < n; i += GEN_TPB)
+                cur[i] = gen_dot3<ALDS>(Atm + i, n, np, nb, n);
         }
         const double c = gen_ordered_sum(cur, n, slot);
         if constexpr (STATS) {
@@ -169,26 +378,16 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
                 if (kx > 0) {
                     for (int i = tid; i < n; i += GEN_TPB) {
                         double s2 = 0.0;
-                        const double *Ar = At + i;
+                        const double *Ar = Atm + i;
                         for (int j = 0; j < n; ++j)
                             s2 += Ar[(int64_t)j * n] * (ldexp(np[j], kx) * nb[j]);
                         loc += a[i] * s2;
                     }
                 } else {
                     for (int i = tid; i < n; i += GEN_TPB)
-                        loc += a[i] * cur[i];
+                        loc += (i == tid ? a_mine : a[i]) * cur[i];
                 }
-                // tree sum over the workgroup through LDS (slot area: GEN_TPB doubles behind slot)
-                double *red = slot + 1;
-                red[tid] = loc;
-                __syncthreads();
-                for (int w = GEN_TPB / 2; w > 0; w >>= 1) {
-                    if (tid < w)
-                        red[tid] += red[tid + w];
-                    __syncthreads();
-                }
-                Snorm = red[0];
-                __syncthreads();
+                Snorm = gen_block_sum(loc, slot + 1);
                 double *wr = W + (t0 + t) * n;
                 for (int j = tid; j < n; j += GEN_TPB)
                     wr[j] = ldexp(np[j], kx) * nb[j] / Snorm;
@@ -206,24 +405,14 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
             if (c != 0)
                 b /= c;
             nb[i] = b;
-            np[i] = p[i];
+            np[i] = i == tid ? p_mine : p[i];
             if (beta_out)
                 beta_out[(t0 + t) * n + i] = b;
             if constexpr (STATS)
-                gl += alpha[(t0 + t) * n + i] * b;
+                gl += (i == tid ? a_mine : alpha[(t0 + t) * n + i]) * b;
         }
         if constexpr (STATS) {
-            double *red = slot + 1;
-            __syncthreads();
-            red[tid] = gl;
-            __syncthreads();
-            for (int w = GEN_TPB / 2; w > 0; w >>= 1) {
-                if (tid < w)
-                    red[tid] += red[tid + w];
-                __syncthreads();
-            }
-            const double gs = red[0];
-            __syncthreads();
+            const double gs = gen_block_sum(gl, slot + 5);
             [[maybe_unused]] double o = 0.0;
             [[maybe_unused]] int sym = 0;
             if constexpr (KIND == EMIT_GAUSS)
@@ -232,7 +421,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
                 sym = static_cast<const int32_t *>(obs_rm)[t0 + t];
             int q = 0;
             for (int i = tid; i < n; i += GEN_TPB, ++q) {
-                const double g = alpha[(t0 + t) * n + i] * nb[i] / gs;
+                const double g = (i == tid ? a_mine : alpha[(t0 + t) * n + i]) * nb[i] / gs;
                 sc[q] += g;
                 if constexpr (KIND == EMIT_GAUSS) {
                     const double d = o - m.mu[i];
@@ -372,6 +561,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_w_rows(const double *At, int n,
 }
 
 // _hidden.c:203-281, forward part: back-pointers (one uint16 per (t, j)) and the final state
+template <bool ALDS>
 __global__ __launch_bounds__(GEN_TPB) void k_gen_viterbi_fwd(const WideModel m, const int64_t *off,
                                                               int K, const double *pobs,
                                                               uint16_t *ptr, int32_t *last_state)
@@ -383,6 +573,16 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_viterbi_fwd(const WideModel m, 
     const int64_t t0 = off[k], T = off[k + 1] - t0;
     if (T <= 0)
         return;
+    const double *Amat;
+    if constexpr (ALDS) {
+        double *Al = gsm + 2 * n + 2;
+        for (int e = tid; e < n * n; e += GEN_TPB)
+            Al[e] = m.A[e];
+        Amat = Al;
+    } else {
+        Amat = m.A;
+    }
+    __syncthreads();
     for (int64_t t = 0; t < T; ++t) {
         const double *p = pobs + (t0 + t) * n;
         for (int j = tid; j < n; j += GEN_TPB) {
@@ -390,7 +590,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_viterbi_fwd(const WideModel m, 
                 vn[j] = p[j] * m.pi[j];
             } else {
                 int best = 0;
-                const double *Ac = m.A + j;
+                const double *Ac = Amat + j;
                 double hm = v[0] * Ac[0];
                 int i = 1;
                 for (; i + 8 <= n; i += 8) {
@@ -417,7 +617,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_viterbi_fwd(const WideModel m, 
                     }
                 }
                 ptr[(t0 + t) * n + j] = (uint16_t)best;
-                vn[j] = p[j] * v[best] * m.A[(int64_t)best * n + j];
+                vn[j] = p[j] * v[best] * Amat[(int64_t)best * n + j];
             }
         }
         const double S = gen_ordered_sum(vn, n, slot);
@@ -457,6 +657,7 @@ __global__ void k_gen_viterbi_trace(const int64_t *off, int K, int n, const uint
 }
 
 // _hidden.c:330-378 (+ _normalize :307-319, _random_choice :283-305): backward sampling from alpha
+template <bool ALDS>
 __global__ __launch_bounds__(GEN_TPB) void k_gen_sample(const WideModel m, const int64_t *off, int K,
                                                         const double *alpha, const double *u,
                                                         uint64_t seed, const int64_t *soff,
@@ -464,27 +665,55 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_sample(const WideModel m, const
 {
     extern __shared__ double gsm[];
     const int n = m.n, tid = threadIdx.x;
-    double *ps = gsm, *slot = gsm + n;
-    int *pick = reinterpret_cast<int *>(gsm + n + 1);
+    double *ps = gsm, *qs = gsm + n, *slot = gsm + 2 * n;
+    int *pick = reinterpret_cast<int *>(gsm + 2 * n + 1);
+    [[maybe_unused]] double *Alt = gsm + 2 * n + 4; // ALDS: A transposed (column nxt of A contiguous)
+    if constexpr (ALDS) {
+        for (int e = tid; e < n * n; e += GEN_TPB)
+            Alt[(e % n) * n + e / n] = m.A[e];
+    }
+    __syncthreads();
     const int k = blockIdx.x;
     const int64_t t0 = off[k], T = off[k + 1] - t0;
     const int64_t s0 = soff ? soff[k] : t0;
     int nxt = 0;
     for (int64_t t = T - 1; t >= 0; --t) {
         const double *a = alpha + (t0 + t) * n;
-        for (int i = tid; i < n; i += GEN_TPB)
-            ps[i] = (t == T - 1) ? a[i] : a[i] * m.A[(int64_t)i * n + nxt];
+        for (int i = tid; i < n; i += GEN_TPB) {
+            double av;
+            if constexpr (ALDS)
+                av = Alt[nxt * n + i];
+            else
+                av = m.A[(int64_t)i * n + nxt];
+            ps[i] = (t == T - 1) ? a[i] : a[i] * av;
+        }
         const double S = gen_ordered_sum(ps, n, slot);
+        // the quotients of _normalize (:307-319) by the thread that owns the entry; the cumulative
+        // search of _random_choice (:283-305) is the serial part
+        for (int i = tid; i < n; i += GEN_TPB)
+            qs[i] = ps[i] / S;
+        __syncthreads();
         if (tid == 0) {
             const double r = u ? u[t0 + t] : uniform01(seed, (uint64_t)(s0 + t));
             double acc = 0.0;
             int pk = -1;
-            for (int i = 0; i < n; ++i) {
-                acc += ps[i] / S;
-                if (acc >= r) {
-                    pk = i;
-                    break;
+            int i = 0;
+            for (; pk < 0 && i + 8 <= n; i += 8) {
+                double v[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+                    v[w] = qs[i + w];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    acc += v[w];
+                    if (pk < 0 && acc >= r)
+                        pk = i + w;
                 }
+            }
+            for (; pk < 0 && i < n; ++i) {
+                acc += qs[i];
+                if (acc >= r)
+                    pk = i;
             }
             *pick = pk;
         }
