@@ -19,7 +19,7 @@ from ld_reference import estep_longdouble
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-bad = limited = 0
+bad = limited = needles = 0
 for case in range(ncase):
     n = int(rng.integers(1, 9)) if rng.random() < 0.7 else int(rng.integers(9, 25))
     kind = "gaussian" if rng.random() < 0.5 else "discrete"
@@ -40,11 +40,26 @@ for case in range(ncase):
         pi[rng.integers(0, n)] = 0.0
         pi /= pi.sum()
     if kind == "gaussian":
-        regime = rng.choice(["plain", "far", "narrow"])
+        regime = rng.choice(["plain", "far", "narrow", "needle"], p=[0.3, 0.3, 0.3, 0.1])
         mu, sig = np.sort(rng.normal(0, 3, n)), rng.uniform(0.3, 2.0, n)
         if regime == "narrow":
             sig = sig * 0.05
         obs = [rng.normal(0, 12.0 if regime == "far" else 3.0, T) for T in lens]
+        if regime == "needle":
+            # densities of 1e30 .. 1e75: widths far below the spacing of the means, observations drawn from a
+            # hidden path of the model itself (anything else would be an outlier row in every step)
+            sig = sig * float(rng.choice([1e-30, 1e-60, 1e-75]))
+            if n > 1 and rng.random() < 0.5:   # ... for some of the states only: rows with entries of 1e40 beside
+                wide = rng.random(n) < 0.5     # ordinary and denormal ones
+                sig = np.where(wide, rng.uniform(0.3, 30.0, n), sig)
+            obs = []
+            for T in lens:
+                st = np.zeros(T, dtype=np.int64)
+                st[0] = rng.integers(0, n)
+                for t in range(1, T):
+                    nzs = np.flatnonzero(A[st[t - 1]] > 0)
+                    st[t] = rng.choice(nzs) if rng.random() < 0.3 else st[t - 1] if A[st[t - 1], st[t - 1]] > 0 else rng.choice(nzs)
+                obs.append(mu[st] + sig[st] * rng.normal(0, 1, T))
         if rng.random() < 0.15:  # a few extreme values: huge, infinite, exactly on a mean
             for o in obs:
                 for _ in range(int(rng.integers(1, 4))):
@@ -70,6 +85,7 @@ for case in range(ncase):
             ref = orc.estep(kind, obs, A, pi, *par)
         if not (np.all(np.isfinite(ref["logL"])) and np.all(np.isfinite(ref["C"]))):
             continue  # the reference itself leaves the floating-point range here
+        needles += int(kind == "gaussian" and regime == "needle")
         eng = Engine(0)
         eng.set_observations(kind, obs, n, nsymbols=M, chunk=chunk)
         denorm = False
@@ -188,5 +204,6 @@ for case in range(ncase):
                      obs=np.concatenate(obs), lens=np.array(lens))
         bad += 1
         print("EXCEPTION", tag, repr(e)[:300])
-print("stress: %d cases, %d failures%s" % (ncase, bad, (" (%d reducible models refused loudly: non-finite statistics)" % limited) if limited else ""))
+print("stress: %d cases, %d failures%s%s" % (ncase, bad, (" (%d reducible models refused loudly: non-finite statistics)" % limited) if limited else "",
+                                             (" (%d with densities of 1e30 and more)" % needles) if needles else ""))
 sys.exit(1 if bad else 0)
