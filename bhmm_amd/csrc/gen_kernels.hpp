@@ -1,7 +1,7 @@
 // gen_kernels.hpp -- hidden kernels for ANY number of states (the family behind N > 64): the C ABI
 // must not refuse what bhmm/hidden/impl_c/_hidden.c:16-378 accepts.  Slow by design -- one workgroup
-// per trajectory, serial in t, the transition matrix read from global memory (L2) in every step --
-// but order-faithful: compiled with -ffp-contract=off, every product and every sum below is taken in
+// per trajectory, serial in t, the transition matrix in LDS up to ~140 states and read from global
+// memory (L2) in every step above that -- but order-faithful: compiled with -ffp-contract=off, every product and every sum below is taken in
 // the order of the reference's scalar C, so forward / backward rows, Viterbi
 // paths and sampled paths (given the uniforms) are those of the reference to the last bit wherever
 // the reference's libm exp / log is not involved.  The xi counts, the one O(N^2) statistic, are a true
