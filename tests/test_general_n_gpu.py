@@ -152,3 +152,28 @@ def test_estimators_run_with_more_than_64_states():
     models = smp.sample(2, seed=4)
     assert len(models) == 2
     np.testing.assert_allclose(models[-1].transition_matrix.sum(axis=1), 1.0, rtol=1e-12)
+
+
+@pytest.mark.parametrize("n", [139, 140, 141])
+def test_transition_matrix_in_lds_up_to_the_size_that_fits(n):
+    """Up to 140 states the any-N kernels keep their own copy of A in LDS (n^2 doubles + the vectors within the
+    160 KB of a CU), from 141 on they read it from global memory: both sides of the boundary launch and give
+    the oracle's log-likelihoods bit for bit (order-faithful rows), its counts, Viterbi and sampled paths."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(1000 + n)
+    A, pi, mu, sig = _model(n, rng, "gaussian")
+    obs = [rng.normal(0, 0.05 * n, T) for T in (40, 7, 1)]
+    ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+    pobs = [orc.pobs_gaussian(o, mu, sig) for o in obs]
+    eng = Engine(0)
+    eng.set_observations("gaussian", obs, n)
+    res = eng.estep(A, pi, mu, sig)
+    np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-13)
+    np.testing.assert_allclose(res.C, ref["C"], rtol=1e-9, atol=1e-12)
+    for p, po in zip(eng.viterbi(A, pi, mu, sig), pobs):
+        assert np.array_equal(p, orc.viterbi(A, po, pi))
+    u = [rng.random(len(o)) for o in obs]
+    paths = eng.sample_paths(A, pi, mu, sig, u=u)[0]
+    for p, po, uu in zip(paths, pobs, u):
+        assert np.array_equal(p, orc.sample_path(orc.forward(A, po, pi)[1], A, uu))
+    eng.close()
