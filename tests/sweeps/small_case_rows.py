@@ -26,6 +26,10 @@ for k, o in enumerate(obs):
     st = eng.estep(A, pi, par0, par1, store_gamma=True)
     g = eng.gamma(0)
     dg = np.abs(g - gr).max(axis=1) if len(o) else np.zeros(0)
+    from ld_reference import estep_longdouble
+    with np.errstate(all="ignore"):
+        ld_ll = estep_longdouble(A, pi, [po])[0][0]
+    print("   logL gpu %.10f ref %.10f 80-bit %.10f | gpu-80bit %.3e ref-80bit %.3e" % (st.loglik, ref["logL"][0], ld_ll, st.loglik - ld_ll, ref["logL"][0] - ld_ll))
     print("traj", k, "T", len(o), "dlogL %.2e dC %.2e dgamma %.2e careful" % (abs(st.loglik - ref["logL"]), np.abs(st.C - ref["C"]).max() if len(o) > 1 else 0.0, dg.max() if len(o) else 0.0), eng.get_option("careful"))
     bad = np.where(dg > 1e-10)[0]
     if len(bad):
