@@ -1079,6 +1079,10 @@ int bhmm_ctx_create(bhmm_ctx **out, int device, void *stream)
         c->carry_enabled = atoi(e) != 0;
     if (const char *e = getenv("BHMM_AMD_SPEC"))
         c->spec_enabled = atoi(e) != 0;
+    if (const char *e = getenv("BHMM_AMD_TILE"))
+        c->tile_enabled = atoi(e) != 0;
+    if (const char *e = getenv("BHMM_AMD_TILE_PER_CU"))
+        c->tile_per_cu = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("BHMM_AMD_SPEC_W")) {
         c->spec_W = std::max(1, atoi(e));
         c->spec_W_fixed = true;
@@ -1530,6 +1534,10 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
         c->wseg_len = std::max(0, (int)value); // takes effect at the next set_observations
     else if (n == "wide_split")
         c->wseg_split = value != 0.0; // 64 states: own, finer segment plan for the forward pass
+    else if (n == "tile")
+        c->tile_enabled = value != 0.0; // row-batched matrix-core recursions (next set_observations)
+    else if (n == "tile_per_cu")
+        c->tile_per_cu = std::max(1, std::min(4, (int)value)); // (next set_observations)
     else
         return invalid("unknown or read-only option: " + n);
     return BHMM_OK;
@@ -1568,6 +1576,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->carry_kappa;
     else if (n == "wide_segments")
         *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
+    else if (n == "tile") // 1: the last E-step ran on the row-batched matrix-core kernels
+        *value = c->tile_used ? 1.0 : 0.0;
     else if (n == "wide_fwd_segments") // the forward pass's own, finer plan (64 states), 0 if none
         *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0] &&
                   c->w_nseg[2] > c->w_nseg[1]) ? c->w_nseg[2] : 0;

@@ -156,6 +156,14 @@ struct bhmm_ctx {
     bhmm::DevBuf<int64_t> d_wseg_t0[3];
     bhmm::DevBuf<int64_t> d_wseg_fmid;  // plan 1: start of the forward pass's second segment inside each
     bhmm::DevBuf<double> d_wlogLseg, d_waentry, d_waexit, d_wbexit, d_wbentry;
+    // row-batched matrix-core recursions (tile_kernels.hpp): 16 segments per workgroup
+    bool tile_enabled = true;        // option "tile" / BHMM_AMD_TILE=0
+    int tile_per_cu = 1;             // tiles the segment plan aims at per compute unit (option "tile_per_cu")
+    int w_ntiles[3] = {0, 0, 0};
+    bhmm::DevBuf<int32_t> d_tile_seg[3]; // [16 * ntiles] segment of every tile row (-1: none)
+    bhmm::DevBuf<int32_t> d_wexp;    // [total] exponent the forward pass removed at every step
+    bhmm::DevBuf<int32_t> d_wePseg;  // [segments] ... summed over the main part of every segment
+    bool tile_used = false;          // the last E-step ran on the tile kernels
     bool wseg_enabled = true;
     bool wseg_split = true;     // 64 states: own, finer plan for the forward pass (wide_plan_segments)
     int64_t wseg_cur_len = 0;   // segment length of plan 1 (re-plans only lengthen: buffers are sized once)

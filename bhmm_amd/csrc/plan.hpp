@@ -139,6 +139,19 @@ inline void plan_segments(const std::vector<int64_t> &offsets, int K, int64_t se
     s.traj0[K] = (int32_t)s.traj.size();
 }
 
+// Tiles of the row-batched kernels (tile_kernels.hpp): 16 segments per workgroup, which runs as long
+// as its longest row -- segments sorted by length (stable, longest first), empty slots -1.
+inline void plan_tiles(const SegPlan &s, std::vector<int32_t> &tile_seg)
+{
+    std::vector<int32_t> order;
+    for (size_t i = 0; i < s.len.size(); ++i)
+        if (s.len[i] > 0)
+            order.push_back((int32_t)i);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return s.len[a] > s.len[b]; });
+    tile_seg.assign((order.size() + 15) / 16 * 16, -1);
+    std::copy(order.begin(), order.end(), tile_seg.begin());
+}
+
 // For every segment of the plan with `seglen`: the start of a segment of the twice-as-fine plan
 // strictly inside it (-1: none).  Cuts the trajectories exactly like plan_segments(.., 1).
 inline void plan_forward_mids(const std::vector<int64_t> &offsets, int K, int64_t seglen,

@@ -1,0 +1,849 @@
+// tile_kernels.hpp -- row-batched E-step recursions on the fp64 matrix cores, 64 states and more.
+//
+// Reference loops covered: bhmm/hidden/impl_c/_hidden.c:42-63 (forward), :91-109 (backward),
+// :148-183 (xi counts), hidden/api.py:176-186 (gamma), with the emission rows of
+// output_models/impl_c/_gaussian.c:5-21 / discrete.py:130-157 fused in.
+//
+// The 9..64-state kernels of wide_kernels.hpp run one trajectory segment per wavefront: a
+// matrix-VECTOR product per step on DPP FMAs, one or two wavefronts per SIMD, about 690 cycles per
+// step against the 256 pipe cycles its 4096 FMAs need.  Here SIXTEEN segments ("rows") form a tile
+// and one workgroup of four wavefronts advances the whole tile by one step with
+//
+//     alpha-tile [16 x N] . A [N x N]      on v_mfma_f64_16x16x4_f64
+//
+// Output column tile c (16 states) belongs to wavefront c mod 4; its block of A (all N rows, 16
+// columns) stays in that wavefront's registers as the B operand; the tile of the previous step is
+// all-gathered through LDS into the A-operand layout (lane (m, k) <- row m, state 4 kk + k).  The
+// emission row and the power-of-two rescaling are elementwise on the C/D layout
+// (lane (s, q), register r  <->  row q + 4 r, state 16 c + s).  The backward kernel does the same
+// with A transposed and adds the xi counts as a second group of matrix instructions per step:
+// C'[16 I.., 16 J..] += (alpha_{t-1} / S)[rows, 16 I..]^T (p_t o beta_t)[rows, 16 J..], K = the tile's
+// rows -- the C/D-layout registers of alpha ARE the A operand, the LDS copy of p o beta the B operand.
+//
+// Scaling.  alpha and beta are carried up to powers of two (refreshed every fourth step from the
+// row maxima the wavefronts exchange one step earlier); the normaliser of gamma and xi is the same
+// bilinear form at every step of a segment, sum_j alpha_t[j] beta_t[j] = S0 2^(exponents removed
+// since), so it is summed across the four wavefronts ONCE per segment (and once more for the
+// transition into the segment, whose alpha row belongs to the neighbour's chain).  The forward pass
+// leaves the exponent it removed at step t in exps[t].  Rows that leave the range this covers
+// (a vector below 2^-900, a denormal normaliser, a gamma mass that is off) raise flags[2] and the
+// host repeats the E-step with the per-step-normalising kernels (wide_kernels.hpp /
+// gen_kernels.hpp) -- exactly the contract of the lazily scaled 9..64-state kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wide_kernels.hpp"
+
+namespace bhmm {
+
+#ifndef TILE_PF
+#define TILE_PF 4 // steps of load-ahead (a tile step takes about half a microsecond)
+#endif
+static_assert(TILE_PF % 4 == 0, "the rescaling phase is the position inside the unrolled group");
+
+template <int NT>
+struct TileGeo {
+    static constexpr int NP = 16 * NT;                   // padded state count
+    static constexpr int TPW = (NT + 3) / 4;             // column tiles per wavefront
+    static constexpr int KK = NP / 4;                    // K steps of one product
+    static constexpr int PX = (NP + 31) / 32 * 32 + 2;   // pitch of a tile row in LDS: == 2 (mod 32)
+};
+
+// physical LDS row of tile row rho = q + 4 r.  Rows q and q + 1 of one register index lie eight
+// apart, so that both read patterns are conflict-free with the pitch above: the matvec operand
+// (lanes (m, k): row m, column 4 kk + k) and the xi operand (lanes (s, q): row q + 4 r, column 16 J + s).
+__device__ __forceinline__ int tile_prow(int rho)
+{
+    const int q = rho & 3, r = rho >> 2;
+    return 8 * (q & 1) + 4 * (q >> 1) + r;
+}
+
+__device__ __forceinline__ int row16_max_i32(int v)
+{
+    v = max(v, dpp_i32<0xB1>(v));
+    v = max(v, dpp_i32<0x4E>(v));
+    v = max(v, dpp_i32<0x141>(v)); // row_half_mirror
+    v = max(v, dpp_i32<0x140>(v)); // row_mirror
+    return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+// sum over the 16 lanes of a row, result in every lane (fixed order)
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
+
+// which segment sits in which tile row: tile_seg[16 * tile + rho] (-1: empty)
+struct TilePlan {
+    const int32_t *tile_seg;
+    int ntiles;
+};
+
+// what one step reads for my four rows
+template <int KIND, int TPW>
+struct TileIn {
+    double o[KIND == EMIT_GAUSS ? 4 : 1];
+    int sym[KIND == EMIT_DISC ? 4 : 1];
+    double p[KIND == EMIT_EXPL ? TPW : 1][4];
+};
+
+// emission probability of state (tile ct, lane s) for row r of this lane
+template <int KIND, int TPW>
+__device__ __forceinline__ double tile_emit(const WideModel &m, const TileIn<KIND, TPW> &in, int c, int r,
+                                            int j, bool real, double mu_j, double ga_j, double gb_j)
+{
+    if constexpr (KIND == EMIT_GAUSS)
+        return gauss_pdf_issue(in.o[r] - mu_j, ga_j, gb_j, m.gmg);
+    else if constexpr (KIND == EMIT_DISC)
+        return real ? m.B[(int64_t)j * m.M + in.sym[r]] : 0.0;
+    else
+        return in.p[c][r];
+}
+
+// A tile advances in groups of four steps (the rescaling phase).  Most groups are uniform over the
+// tile's 16 rows -- every row still in its warm-up, or every row in its main part -- and run without
+// any per-row predicate; the groups around segment entries and exits take the general path.
+enum { TM_WARM = 0, TM_MAIN = 1, TM_GEN = 2 };
+
+template <int V>
+using tile_ic = std::integral_constant<int, V>;
+
+__device__ __forceinline__ int tile_all_min(int v)
+{
+    v = min(v, __shfl_xor(v, 16, 64));
+    return min(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ int tile_all_max(int v)
+{
+    v = max(v, __shfl_xor(v, 16, 64));
+    return max(v, __shfl_xor(v, 32, 64));
+}
+
+// =========================================================================================
+// k_tile_fwd: alpha rows (row-major, up to a power of two per row) for the main part of every
+// segment, the exponents removed (exps[global step], eP_seg[segment]), the vectors at the segment
+// entry (after the warm-up) and exit for the boundary check and the log-likelihood.
+// FULL: n == 16 NT (no padded states).
+// =========================================================================================
+template <int NT, int KIND, int WPS, bool FULL>
+__global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const int64_t *off, const Segs sg,
+                                                       const TilePlan tp, const void *obs_rm,
+                                                       double *alpha_rm, int32_t *exps, int32_t *eP_seg,
+                                                       double *a_entry, double *a_exit, unsigned int *flags)
+{
+    using G = TileGeo<NT>;
+    constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX;
+    __shared__ __attribute__((aligned(16))) double sX[2 * 16 * PX];
+    __shared__ int sE[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const int n = FULL ? 16 * NT : m.n;
+
+    // ---- my four rows ----------------------------------------------------------------------
+    int seg[4], nst[4], r0[4];
+    int64_t ob[4]; // global step index of the row's first (warm-up) step
+    bool fs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + q + 4 * r];
+        seg[r] = sgi;
+        nst[r] = 0;
+        r0[r] = 0;
+        ob[r] = 0;
+        fs[r] = false;
+        if (sgi >= 0 && sg.len[sgi] > 0) {
+            const int64_t o0 = off[sg.traj[sgi]], t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+            const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0;
+            nst[r] = (int)(t1 - tw);
+            r0[r] = (int)(t0 - tw);
+            ob[r] = o0 + tw;
+            fs[r] = tw == 0;
+        }
+    }
+    // (every wavefront holds all 16 rows: these are uniform over the workgroup)
+    const int nmax = tile_all_max(max(max(nst[0], nst[1]), max(nst[2], nst[3])));
+    const int nstmin = tile_all_min(min(min(nst[0], nst[1]), min(nst[2], nst[3])));
+    const int r0min = tile_all_min(min(min(r0[0], r0[1]), min(r0[2], r0[3])));
+    const int r0max = tile_all_max(max(max(r0[0], r0[1]), max(r0[2], r0[3])));
+    const bool anyfs = __any(fs[0] || fs[1] || fs[2] || fs[3]);
+    // steps [0, g1): all rows warm up; [g2, g3): all rows in their main part; the rest: general
+    const int g4 = (nmax + 3) & ~3;
+    const int g1 = min(max(r0min - 1, 0) & ~3, g4);
+    const int g2 = min(max((r0max + 3) & ~3, anyfs ? 4 : 0), g4);
+    const int g3 = min(max(g2, max(nstmin - TILE_PF, 0) & ~3), g4);
+
+    // ---- the model: my blocks of A (B operand), emission constants, pi ------------------------
+    double Breg[TPW * KK];
+    double mu_j[TPW], ga_j[TPW], gb_j[TPW], pi_j[TPW];
+    bool real[TPW];
+    int64_t abase[TPW][4]; // element index of (row's first step, my state) in a [step][n] array
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const int j = 16 * (w + 4 * c) + s;
+        real[c] = (w + 4 * c < NT) && (FULL || j < n);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int i = 4 * kk + q;
+            Breg[c * KK + kk] = (real[c] && (FULL || i < n)) ? m.A[(int64_t)i * n + j] : 0.0;
+        }
+        mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[j] : 0.0;
+        ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[j] : 0.0;
+        gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[j] : 1.0;
+        pi_j[c] = real[c] ? m.pi[j] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            abase[c][r] = ob[r] * n + j;
+    }
+    for (int e = tid; e < 16 * PX; e += 256)
+        sX[e] = (e % PX) < n ? 1.0 / (double)n : 0.0; // warm-ups start from the uniform vector
+    int xw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        xw[r] = tile_prow(q + 4 * r) * PX;
+    const int xr = tile_prow(s) * PX + q;
+
+    // what step rs reads (LM == TM_GEN: rows that have ended keep reading their last step)
+    auto load = [&](TileIn<KIND, TPW> &in, int rs, auto lm) __attribute__((always_inline)) {
+        constexpr int LM = decltype(lm)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int rr = rs;
+            if constexpr (LM == TM_GEN)
+                rr = rs < nst[r] ? rs : (nst[r] > 0 ? nst[r] - 1 : 0);
+            if constexpr (KIND == EMIT_GAUSS)
+                in.o[r] = static_cast<const double *>(obs_rm)[ob[r] + rr];
+            else if constexpr (KIND == EMIT_DISC)
+                in.sym[r] = static_cast<const int32_t *>(obs_rm)[ob[r] + rr];
+            else {
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[abase[c][r] + (int64_t)rr * n] : 0.0;
+            }
+        }
+    };
+    TileIn<KIND, TPW> ring[TILE_PF];
+#pragma unroll
+    for (int u = 0; u < TILE_PF; ++u)
+        load(ring[u], u, tile_ic<TM_GEN>{});
+    __syncthreads();
+
+    int eP[4] = {0, 0, 0, 0};
+    bool trouble = false;
+    auto step = [&](int rs, auto uc, auto mc, auto lc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
+        const TileIn<KIND, TPW> in = ring[u];
+        load(ring[u], rs + TILE_PF, lc);
+        const double *X = sX + (u & 1) * 16 * PX; // (groups of four steps: the buffer is the step's parity)
+        double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
+        wide_d4 acc[TPW];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const double av = X[xr + 4 * kk];
+#pragma unroll
+            for (int c = 0; c < TPW; ++c)
+                if (w + 4 * c < NT)
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Breg[c * KK + kk],
+                                                                  kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+        }
+        // the exponent this step removes: row maxima of the step before, over the four wavefronts
+        int E[4] = {0, 0, 0, 0};
+        if constexpr (u == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rho = q + 4 * r;
+                E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
+                const bool act = MODE != TM_GEN || rs < nst[r];
+                trouble |= act && E[r] < WIDE_TROUBLE_EXP;
+                if (MODE == TM_MAIN || (MODE == TM_GEN && act && rs >= r0[r])) {
+                    eP[r] += E[r];
+                    if (w == 0 && s == 0)
+                        exps[ob[r] + rs] = E[r];
+                }
+            }
+        }
+        int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
+        const int64_t rsn = (int64_t)rs * n;
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) {
+            if (w + 4 * c < NT) {
+                const int j = 16 * (w + 4 * c) + s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double p = tile_emit<KIND, TPW>(m, in, c, r, j, real[c], mu_j[c], ga_j[c], gb_j[c]);
+                    double v = acc[c][r] * p;
+                    if constexpr (MODE == TM_GEN)
+                        if (fs[r] && rs == 0)
+                            v = pi_j[c] * p;
+                    if constexpr (u == 3)
+                        v = ldexp(v, -E[r]);
+                    Xn[xw[r] + j] = v;
+                    if constexpr (u == 2)
+                        pm[r] = max(pm[r], v > 0.0 ? exponent_of(v) : -(1 << 28));
+                    if constexpr (MODE == TM_MAIN) {
+                        if (FULL || real[c])
+                            alpha_rm[abase[c][r] + rsn] = v;
+                    } else if constexpr (MODE == TM_GEN) {
+                        if (real[c] && rs < nst[r]) {
+                            if (rs >= r0[r])
+                                alpha_rm[abase[c][r] + rsn] = v;
+                            else if (rs == r0[r] - 1)
+                                a_entry[(int64_t)seg[r] * n + j] = v;
+                            if (rs == nst[r] - 1)
+                                a_exit[(int64_t)seg[r] * n + j] = v;
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (u == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mx = row16_max_i32(pm[r]);
+                if (s == 0)
+                    sE[16 * w + q + 4 * r] = mx;
+            }
+        }
+        __syncthreads();
+    };
+    // groups [lo, hi) in mode mc; the last group prefetches with the general (clamped) loads
+    auto run = [&](int lo, int hi, auto mc) __attribute__((always_inline)) {
+        int rs = lo;
+        for (; rs + 8 <= hi; rs += 4) {
+            step(rs, tile_ic<0>{}, mc, mc);
+            step(rs + 1, tile_ic<1>{}, mc, mc);
+            step(rs + 2, tile_ic<2>{}, mc, mc);
+            step(rs + 3, tile_ic<3>{}, mc, mc);
+        }
+        for (; rs + 4 <= hi; rs += 4) {
+            step(rs, tile_ic<0>{}, mc, tile_ic<TM_GEN>{});
+            step(rs + 1, tile_ic<1>{}, mc, tile_ic<TM_GEN>{});
+            step(rs + 2, tile_ic<2>{}, mc, tile_ic<TM_GEN>{});
+            step(rs + 3, tile_ic<3>{}, mc, tile_ic<TM_GEN>{});
+        }
+    };
+    run(0, g1, tile_ic<TM_WARM>{});
+    run(g1, g2, tile_ic<TM_GEN>{});
+    run(g2, g3, tile_ic<TM_MAIN>{});
+    run(g3, g4, tile_ic<TM_GEN>{});
+    if (w == 0 && s == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (seg[r] >= 0)
+                eP_seg[seg[r]] = eP[r];
+    }
+    if (__any(trouble) && lane == 0)
+        atomicOr(&flags[2], 1u);
+}
+
+// log-likelihood of every segment from what k_tile_fwd left: log sum(exit vector) - log sum(entry
+// vector) + ln 2 * removed exponents (the entry vector of a segment that starts its trajectory is
+// exact: pi o p_0 carries the whole likelihood, nothing is subtracted)
+[[maybe_unused]] static __global__ void k_tile_logl(const Segs sg, int n, const double *a_entry,
+                                                    const double *a_exit, const int32_t *eP_seg,
+                                                    double *logL_seg, unsigned int *flags)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= sg.nseg)
+        return;
+    if (sg.len[s] <= 0) {
+        logL_seg[s] = 0.0;
+        return;
+    }
+    double se = 0.0, sx = 0.0;
+    for (int j = 0; j < n; ++j)
+        sx += a_exit[(int64_t)s * n + j];
+    const bool warm = sg.t0[s] > 0;
+    if (warm)
+        for (int j = 0; j < n; ++j)
+            se += a_entry[(int64_t)s * n + j];
+    else
+        se = 1.0;
+    if (!(sx > 0.0) || !(se > 0.0))
+        atomicOr(&flags[2], 1u);
+    logL_seg[s] = (log(sx) - log(se)) + (double)eP_seg[s] * 0.693147180559945309417232121458;
+}
+
+// =========================================================================================
+// k_tile_bwd: beta in registers only; gamma, xi counts, emission statistics per tile.
+//   part  [tile][n*n C' | n sum gamma | (gauss) n sum gamma d | n sum gamma d^2]
+//   dstat [tile][4][n][M] (discrete: one table per lane row q, so that no two lanes share an entry)
+// XIG: no xi accumulators; the rows W_{t-1} = p_t o beta_t / S are stored instead (counts by the
+// time-parallel GEMM of gen_kernels.hpp) -- for state counts whose accumulators do not fit.
+// =========================================================================================
+template <int NT, int KIND, int WPS, bool FULL, bool XIG>
+__global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const int64_t *off, const Segs sg,
+                                                       const TilePlan tp, const void *obs_rm,
+                                                       const double *alpha_rm, const int32_t *exps,
+                                                       double *gamma_rm, double *gamma0, double *part,
+                                                       double *dstat, double *b_exit, double *b_entry,
+                                                       unsigned int *flags, double *Wg)
+{
+    using G = TileGeo<NT>;
+    constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX;
+    __shared__ __attribute__((aligned(16))) double sX[2 * 16 * PX];
+    __shared__ int sE[64];
+    __shared__ double sS[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const int n = FULL ? 16 * NT : m.n;
+
+    // ---- my four rows: step us of the tile is time ttop - us of the row ------------------------
+    int seg[4], nwarm[4], nst[4], trj[4];
+    int64_t gtop[4]; // global step index of time ttop
+    int ttop[4];     // (time inside the trajectory; trajectories of up to 2^31 steps)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + q + 4 * r];
+        seg[r] = sgi;
+        nwarm[r] = 0;
+        nst[r] = 0;
+        gtop[r] = 0;
+        ttop[r] = 0;
+        trj[r] = 0;
+        if (sgi >= 0 && sg.len[sgi] > 0) {
+            const int k = sg.traj[sgi];
+            const int64_t o0 = off[k], T = off[k + 1] - o0, t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+            const int64_t te = (t1 - 1 + sg.W < T - 1) ? t1 - 1 + sg.W : T - 1;
+            nwarm[r] = t1 < T ? (int)(te - t1) + 1 : 0;
+            nst[r] = nwarm[r] + (int)(t1 - t0);
+            ttop[r] = (int)(t1 - 1 + nwarm[r]);
+            gtop[r] = o0 + ttop[r];
+            trj[r] = k;
+        }
+    }
+    const int nmax = tile_all_max(max(max(nst[0], nst[1]), max(nst[2], nst[3])));
+    const int nstmin = tile_all_min(min(min(nst[0], nst[1]), min(nst[2], nst[3])));
+    const int emin = tile_all_min(min(min(nwarm[0], nwarm[1]), min(nwarm[2], nwarm[3])));
+    const int emax = tile_all_max(max(max(nwarm[0], nwarm[1]), max(nwarm[2], nwarm[3])));
+    // steps [0, g1): all rows warm up (and none reads alpha yet); [g2, g3): all rows inside their main
+    // part (entered, not at their last step, t > 0 also for what is fetched ahead); the rest: general
+    const int g4 = (nmax + 3) & ~3;
+    const int g1 = min(max(emin - 1, 0) & ~3, g4);
+    const int g2 = min((emax + 1 + 3) & ~3, g4);
+    const int g3 = min(max(g2, max(nstmin - 1 - TILE_PF, 0) & ~3), g4);
+
+    // ---- the model: my blocks of A^T (B operand of the beta product) --------------------------
+    double Breg[TPW * KK];
+    double mu_j[TPW], ga_j[TPW], gb_j[TPW];
+    bool real[TPW];
+    int64_t abase[TPW][4]; // element index of (time ttop, my state) in a [step][n] array
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const int i = 16 * (w + 4 * c) + s; // my state: row i of A
+        real[c] = (w + 4 * c < NT) && (FULL || i < n);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int j = 4 * kk + q;
+            Breg[c * KK + kk] = (real[c] && (FULL || j < n)) ? m.A[(int64_t)i * n + j] : 0.0;
+        }
+        mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[i] : 0.0;
+        ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[i] : 0.0;
+        gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[i] : 1.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            abase[c][r] = gtop[r] * n + i;
+    }
+    int xw[4], xq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        xw[r] = tile_prow(q + 4 * r) * PX;
+        xq[r] = xw[r] + s; // xi operand: row q + 4 r, column 16 J + s
+    }
+    const int xr = tile_prow(s) * PX + q;
+
+    // xi accumulators: C'[16 (w + 4 c) .., 16 J ..]
+    wide_d4 Cacc[XIG ? 1 : TPW][XIG ? 1 : NT];
+    if constexpr (!XIG) {
+#pragma unroll
+        for (int c = 0; c < TPW; ++c)
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+                Cacc[c][J] = wide_d4{0.0, 0.0, 0.0, 0.0};
+    }
+    double sgm[TPW], sd[TPW], sdd[TPW];
+#pragma unroll
+    for (int c = 0; c < TPW; ++c)
+        sgm[c] = sd[c] = sdd[c] = 0.0;
+    double *mytab = nullptr;
+    if constexpr (KIND == EMIT_DISC) {
+        mytab = dstat + ((int64_t)blockIdx.x * 4 + q) * n * m.M;
+#pragma unroll
+        for (int c = 0; c < TPW; ++c)
+            if (real[c])
+                for (int z = 0; z < m.M; ++z)
+                    mytab[(int64_t)(16 * (w + 4 * c) + s) * m.M + z] = 0.0;
+    }
+
+    // what one step reads: the observation of time t, alpha of time t - 1, the exponent removed at t
+    struct BIn {
+        TileIn<KIND, TPW> e;
+        double ap[TPW][4];
+        int ex[4];
+    };
+    auto load = [&](BIn &in, int us, auto lm) __attribute__((always_inline)) {
+        constexpr int LM = decltype(lm)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int uu = us;
+            if constexpr (LM == TM_GEN)
+                uu = us < nst[r] ? us : (nst[r] > 0 ? nst[r] - 1 : 0);
+            const int64_t g = gtop[r] - uu; // global index of time t
+            const int t = ttop[r] - uu;
+            const int64_t un = (int64_t)uu * n;
+            if constexpr (KIND == EMIT_GAUSS)
+                in.e.o[r] = static_cast<const double *>(obs_rm)[g];
+            else if constexpr (KIND == EMIT_DISC)
+                in.e.sym[r] = static_cast<const int32_t *>(obs_rm)[g];
+            else {
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    in.e.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[abase[c][r] - un] : 0.0;
+            }
+            if constexpr (LM == TM_WARM) {
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    in.ap[c][r] = 0.0;
+                in.ex[r] = 0;
+            } else if constexpr (LM == TM_MAIN) {
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    in.ap[c][r] = (FULL || real[c]) ? alpha_rm[abase[c][r] - un - n] : 0.0;
+                const int e = exps[g];
+                in.ex[r] = (t & 3) == 3 ? e : 0;
+            } else {
+                // alpha_{t-1} from the last warm-up step on (it becomes alpha_t of the first main step)
+                const bool wanta = us + 1 >= nwarm[r] && us < nst[r] && t > 0;
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    in.ap[c][r] = (wanta && real[c]) ? alpha_rm[abase[c][r] - un - n] : 0.0;
+                in.ex[r] = (us >= nwarm[r] && us < nst[r] && (t & 3) == 3) ? exps[g] : 0;
+            }
+        }
+    };
+    BIn ring[TILE_PF];
+#pragma unroll
+    for (int u = 0; u < TILE_PF; ++u)
+        load(ring[u], u, tile_ic<TM_GEN>{});
+
+    // state of my rows
+    double beta[TPW][4], acur[TPW][4];
+    double rS0[4] = {0.0, 0.0, 0.0, 0.0}, mass[4] = {0.0, 0.0, 0.0, 0.0};
+    int cg[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < TPW; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            beta[c][r] = real[c] ? 1.0 / (double)n : 0.0; // _hidden.c:79-88 (any scale)
+            // rows without a warm-up (end of the trajectory) start in the main part: alpha_{T-1}
+            acur[c][r] = (nst[r] > 0 && nwarm[r] == 0 && real[c]) ? alpha_rm[abase[c][r]] : 0.0;
+        }
+    bool trouble = false;
+    // sum over all states of v (my states, my four rows), exchanged through sS: two barriers
+    auto rows_sum = [&](const double (&v)[4], double (&out)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double ps = row16_sum(v[r]);
+            if (s == 0)
+                sS[16 * w + q + 4 * r] = ps;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rho = q + 4 * r;
+            out[r] = (sS[rho] + sS[16 + rho]) + (sS[32 + rho] + sS[48 + rho]);
+        }
+        __syncthreads();
+    };
+
+    auto step = [&](int us, auto uc, auto mc, auto lc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
+        const BIn in = ring[u];
+        load(ring[u], us + TILE_PF, lc);
+        bool mainr[4], lastr[4];
+        int tt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            mainr[r] = MODE == TM_MAIN;
+            lastr[r] = false;
+            tt[r] = 1;
+        }
+        bool any_last = false;
+        if constexpr (MODE == TM_GEN) {
+            bool enter[4], any_enter = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mainr[r] = us >= nwarm[r] && us < nst[r];
+                enter[r] = us == nwarm[r] && nst[r] > 0;
+                tt[r] = ttop[r] - us;
+                lastr[r] = us == nst[r] - 1 && tt[r] > 0; // the transition into the segment
+                any_enter |= enter[r];
+                any_last |= lastr[r];
+            }
+            any_enter = __any(any_enter); // (every wavefront holds all 16 rows: uniform over the workgroup)
+            any_last = __any(any_last);
+            if (any_enter) {
+                // a row enters its main part: the warm-up's beta for the boundary check, and the
+                // normaliser of the whole segment, S0 = sum_j alpha_t*[j] beta_t*[j]
+                double g[4] = {0.0, 0.0, 0.0, 0.0}, S0[4];
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        g[r] += acur[c][r] * beta[c][r];
+                        if (enter[r] && nwarm[r] > 0 && real[c])
+                            b_exit[(int64_t)seg[r] * n + 16 * (w + 4 * c) + s] = beta[c][r];
+                    }
+                rows_sum(g, S0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (enter[r]) {
+                        trouble |= !(S0[r] >= 0x1p-959) || !(S0[r] < 0x1p1000);
+                        rS0[r] = fast_rcp(S0[r]);
+                        cg[r] = 0;
+                    }
+            }
+        }
+        // ---- gamma_t of the rows in their main part, x = p_t o beta_t ----------------------------
+        double x[TPW][4];
+        const int64_t usn = (int64_t)us * n;
+        if constexpr (MODE == TM_WARM) {
+#pragma unroll
+            for (int c = 0; c < TPW; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double p = (w + 4 * c < NT) ? tile_emit<KIND, TPW>(m, in.e, c, r, 16 * (w + 4 * c) + s,
+                                                                            real[c], mu_j[c], ga_j[c], gb_j[c])
+                                                      : 0.0;
+                    x[c][r] = p * beta[c][r];
+                }
+        } else {
+            double fg[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                fg[r] = mainr[r] ? ldexp(rS0[r], -cg[r]) : 0.0;
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) {
+                const int j = 16 * (w + 4 * c) + s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double p = (w + 4 * c < NT)
+                                         ? tile_emit<KIND, TPW>(m, in.e, c, r, j, real[c], mu_j[c], ga_j[c], gb_j[c])
+                                         : 0.0;
+                    const double gam = acur[c][r] * beta[c][r] * fg[r];
+                    x[c][r] = p * beta[c][r];
+                    mass[r] += gam;
+                    sgm[c] += gam;
+                    if constexpr (KIND == EMIT_GAUSS) {
+                        const double d = in.e.o[r] - mu_j[c];
+                        const double gd = gam * d;
+                        sd[c] += gd;
+                        sdd[c] = fma(gd, d, sdd[c]);
+                    }
+                    if constexpr (KIND == EMIT_DISC)
+                        if (real[c] && mainr[r])
+                            mytab[(int64_t)j * m.M + in.e.sym[r]] += gam;
+                    if (real[c] && mainr[r]) {
+                        if (gamma_rm)
+                            gamma_rm[abase[c][r] - usn] = gam;
+                        if (MODE == TM_GEN && tt[r] == 0)
+                            gamma0[(int64_t)trj[r] * n + j] = gam;
+                    }
+                }
+            }
+        }
+        double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
+#pragma unroll
+        for (int c = 0; c < TPW; ++c)
+            if (w + 4 * c < NT)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Xn[xw[r] + 16 * (w + 4 * c) + s] = x[c][r];
+        __syncthreads();
+        // ---- beta_{t-1} (raw) = A (p_t o beta_t) ------------------------------------------------
+        const double *X = Xn;
+        wide_d4 acc[TPW];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const double av = X[xr + 4 * kk];
+#pragma unroll
+            for (int c = 0; c < TPW; ++c)
+                if (w + 4 * c < NT)
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Breg[c * KK + kk],
+                                                                  kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+        }
+        // ---- xi of the transition t-1 -> t ------------------------------------------------------
+        int cx[4] = {0, 0, 0, 0};
+        if constexpr (MODE != TM_WARM) {
+            double fx[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cx[r] = cg[r] + in.ex[r];
+                fx[r] = (mainr[r] && tt[r] > 0) ? ldexp(rS0[r], -cx[r]) : 0.0;
+            }
+            if constexpr (MODE == TM_GEN) {
+                if (any_last) {
+                    // alpha_{t0-1} belongs to the neighbouring segment's chain: its own normaliser
+                    double g[4] = {0.0, 0.0, 0.0, 0.0}, SL[4];
+#pragma unroll
+                    for (int c = 0; c < TPW; ++c)
+                        if (w + 4 * c < NT)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                g[r] += in.ap[c][r] * acc[c][r];
+                    rows_sum(g, SL);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (lastr[r]) {
+                            trouble |= !(SL[r] >= 0x1p-959) || !(SL[r] < 0x1p1000);
+                            fx[r] = fast_rcp(SL[r]);
+                        }
+                }
+            }
+            if constexpr (!XIG) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double xb[NT];
+#pragma unroll
+                    for (int J = 0; J < NT; ++J)
+                        xb[J] = X[xq[r] + 16 * J];
+#pragma unroll
+                    for (int c = 0; c < TPW; ++c)
+                        if (w + 4 * c < NT) {
+                            const double aw = in.ap[c][r] * fx[r];
+#pragma unroll
+                            for (int J = 0; J < NT; ++J)
+                                Cacc[c][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, xb[J], Cacc[c][J], 0, 0, 0);
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (real[c] && mainr[r] && tt[r] > 0)
+                            Wg[abase[c][r] - usn - n] = x[c][r] * fx[r];
+            }
+        }
+        // ---- rescale (every fourth step, by the row maxima exchanged one step earlier) ------
+        int E[4] = {0, 0, 0, 0};
+        if constexpr (u == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rho = q + 4 * r;
+                E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
+                trouble |= (MODE != TM_GEN || us < nst[r]) && E[r] < WIDE_TROUBLE_EXP;
+            }
+        }
+        int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
+#pragma unroll
+        for (int c = 0; c < TPW; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double b = (w + 4 * c < NT) ? acc[c][r] : 0.0;
+                if constexpr (u == 3)
+                    b = ldexp(b, -E[r]);
+                if constexpr (u == 2)
+                    pm[r] = max(pm[r], b > 0.0 ? exponent_of(b) : -(1 << 28));
+                if constexpr (MODE == TM_GEN)
+                    if (us == nst[r] - 1 && real[c] && tt[r] > 0)
+                        b_entry[(int64_t)seg[r] * n + 16 * (w + 4 * c) + s] = b; // beta one step before the segment
+                beta[c][r] = b;
+                if constexpr (MODE != TM_WARM)
+                    acur[c][r] = in.ap[c][r];
+            }
+        if constexpr (u == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mx = row16_max_i32(pm[r]);
+                if (s == 0)
+                    sE[16 * w + q + 4 * r] = mx;
+            }
+        }
+        if constexpr (MODE != TM_WARM) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cg[r] = cx[r] - E[r];
+        }
+    };
+    auto run = [&](int lo, int hi, auto mc) __attribute__((always_inline)) {
+        int us = lo;
+        for (; us + 8 <= hi; us += 4) {
+            step(us, tile_ic<0>{}, mc, mc);
+            step(us + 1, tile_ic<1>{}, mc, mc);
+            step(us + 2, tile_ic<2>{}, mc, mc);
+            step(us + 3, tile_ic<3>{}, mc, mc);
+        }
+        for (; us + 4 <= hi; us += 4) {
+            step(us, tile_ic<0>{}, mc, tile_ic<TM_GEN>{});
+            step(us + 1, tile_ic<1>{}, mc, tile_ic<TM_GEN>{});
+            step(us + 2, tile_ic<2>{}, mc, tile_ic<TM_GEN>{});
+            step(us + 3, tile_ic<3>{}, mc, tile_ic<TM_GEN>{});
+        }
+    };
+    run(0, g1, tile_ic<TM_WARM>{});
+    run(g1, g2, tile_ic<TM_GEN>{});
+    run(g2, g3, tile_ic<TM_MAIN>{});
+    run(g3, g4, tile_ic<TM_GEN>{});
+
+    // ---- self-check: unit gamma mass per step of every row -------------------------------------
+    {
+        double tot[4];
+        rows_sum(mass, tot);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double want = (double)(nst[r] - nwarm[r]);
+            trouble |= !(fabs(tot[r] - want) <= 1e-8 * want);
+        }
+        if (__any(trouble) && lane == 0)
+            atomicOr(&flags[2], 1u);
+    }
+    // ---- the tile's partial statistics --------------------------------------------------------
+    const int S = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0);
+    double *mypart = part + (int64_t)blockIdx.x * S;
+    if constexpr (!XIG) {
+#pragma unroll
+        for (int c = 0; c < TPW; ++c)
+            if (w + 4 * c < NT)
+#pragma unroll
+                for (int J = 0; J < NT; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * (w + 4 * c) + q + 4 * r, col = 16 * J + s;
+                        if (FULL || (row < n && col < n))
+                            mypart[(int64_t)row * n + col] = Cacc[c][J][r];
+                    }
+    }
+    // emission statistics of state 16 (w + 4 c) + s: the four lane rows q hold disjoint tile rows
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        double a0 = sgm[c], a1 = sd[c], a2 = sdd[c];
+        a0 += __shfl_xor(a0, 16, 64);
+        a0 += __shfl_xor(a0, 32, 64);
+        if constexpr (KIND == EMIT_GAUSS) {
+            a1 += __shfl_xor(a1, 16, 64);
+            a1 += __shfl_xor(a1, 32, 64);
+            a2 += __shfl_xor(a2, 16, 64);
+            a2 += __shfl_xor(a2, 32, 64);
+        }
+        if (real[c] && q == 0) {
+            const int j = 16 * (w + 4 * c) + s;
+            mypart[n * n + j] = a0;
+            if constexpr (KIND == EMIT_GAUSS) {
+                mypart[n * n + n + j] = a1;
+                mypart[n * n + 2 * n + j] = a2;
+            }
+        }
+    }
+}
+
+} // namespace bhmm

@@ -10,6 +10,7 @@
 #include "host_common.hpp"
 #include "plan.hpp"
 #include "wide_kernels.hpp"
+#include "tile_kernels.hpp"
 
 namespace bhmm {
 int invalid_arg(const std::string &msg);
@@ -83,10 +84,56 @@ static int wide_fwd_plan(const bhmm_ctx *c, int which)
     return (which == 1 && c->w_nseg[2] > c->w_nseg[1]) ? 2 : which;
 }
 
+// 64 states: the lazily scaled E-step runs on the row-batched matrix-core kernels (tile_kernels.hpp)
+static bool wide_tile(const bhmm_ctx *c) { return c->tile_enabled && c->n == 64; }
+
+template <int KIND>
+static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
+{
+    const Segs sg = segs_of(c, which);
+    const TilePlan tp{c->d_tile_seg[which].p, c->w_ntiles[which]};
+    hipLaunchKernelGGL((k_tile_fwd<4, KIND, 2, true>), dim3(tp.ntiles), dim3(256), 0, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p, c->d_alpha_rm.p,
+                       c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p);
+    BHMM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_tile_logl, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg, c->n,
+                       (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
+                       (const int32_t *)c->d_wePseg.p, c->d_wlogLseg.p, c->d_specres.p);
+    hipLaunchKernelGGL(k_logl, dim3(c->K), dim3(64), 0, c->stream,
+                       (const int32_t *)c->d_wseg_traj0[which].p, c->K,
+                       (const double *)c->d_wlogLseg.p, c->d_logLk.p);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+template <int KIND>
+static int tile_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool store_gamma, double *stats_dev)
+{
+    const Segs sg = segs_of(c, which);
+    const TilePlan tp{c->d_tile_seg[which].p, c->w_ntiles[which]};
+    double *gam = store_gamma ? c->d_gamma_ci.p : (double *)nullptr;
+    hipLaunchKernelGGL((k_tile_bwd<4, KIND, 1, true, false>), dim3(tp.ntiles), dim3(256), 0, c->stream, m,
+                       (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
+                       (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
+                       c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
+                       (double *)nullptr);
+    BHMM_HIP(hipGetLastError());
+    const int n = c->n;
+    const int nfin = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0) + (KIND == EMIT_DISC ? n * c->M : 0) +
+                     n + 1;
+    hipLaunchKernelGGL((k_wide_finalize<KIND>), dim3(nfin), dim3(64), 0, c->stream, m, c->K, tp.ntiles,
+                       4 * tp.ntiles, (const double *)c->d_partials.p, (const double *)c->d_dpartials.p,
+                       (const double *)c->d_logLk.p, (const double *)c->d_gamma0.p, stats_dev);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
 template <int NP, int KIND>
 static int wide_launch_fwd(bhmm_ctx *c, const WideModel &m, int which, bool lazy = false)
 {
     constexpr int GP = 64 / NP;
+    if (lazy && wide_tile(c))
+        return tile_launch_fwd<KIND>(c, m, which);
     which = wide_fwd_plan(c, which);
     const Segs sg = segs_of(c, which);
     if (lazy && NP == 64 && c->n == 64) // the shape of BASELINE configs[3]
@@ -117,6 +164,8 @@ static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
                            double *stats_dev, bool lazy = false)
 {
     constexpr int GP = 64 / NP;
+    if (lazy && wide_tile(c))
+        return tile_launch_bwd<KIND>(c, m, which, store_gamma, stats_dev);
     const Segs sg = segs_of(c, which);
     // A's rows in LDS for fewer than 64 lanes per segment; the 64-lane kernel keeps them in VGPRs
     const size_t sm = NP == 64 ? 0 : (size_t)(NP * wide_pitch(NP)) * sizeof(double);
@@ -163,7 +212,7 @@ static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
     const int nfin = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0) + (KIND == EMIT_DISC ? n * c->M : 0) +
                      n + 1;
     hipLaunchKernelGGL((k_wide_finalize<KIND>), dim3(nfin), dim3(64), 0, c->stream, m, c->K, sg.nseg,
-                       (const double *)c->d_partials.p, (const double *)c->d_dpartials.p,
+                       sg.nseg, (const double *)c->d_partials.p, (const double *)c->d_dpartials.p,
                        (const double *)c->d_logLk.p, (const double *)c->d_gamma0.p, stats_dev);
     BHMM_HIP(hipGetLastError());
     return BHMM_OK;
@@ -181,6 +230,10 @@ static int wide_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
 static int64_t wide_fill_len(const bhmm_ctx *c)
 {
     const int64_t groups_per_wave = 64 / c->N;
+    if (wide_tile(c)) { // 16 segments per workgroup, tile_per_cu workgroups per compute unit
+        const int64_t want = 16 * (int64_t)(c->num_simd / 4) * c->tile_per_cu;
+        return ((c->total + want - 1) / want + 3) & ~(int64_t)3;
+    }
     const int64_t want = (c->N == 64) ? (int64_t)c->num_simd : 4 * (int64_t)c->num_simd * groups_per_wave;
     return (c->total + want - 1) / want;
 }
@@ -206,6 +259,16 @@ static int wide_plan(bhmm_ctx *c, int which, int64_t seglen, int mult = 1)
     BHMM_HIP(hipMemcpy(c->d_wseg_t0[which].p, stt.data(), ns * sizeof(int64_t), hipMemcpyHostToDevice));
     BHMM_HIP(hipMemcpy(c->d_wseg_traj0[which].p, s0.data(), (c->K + 1) * sizeof(int32_t),
                        hipMemcpyHostToDevice));
+    c->w_ntiles[which] = 0;
+    if (wide_tile(c)) {
+        // tiles of 16 segments of about the same number of steps (a tile runs as long as its longest row)
+        std::vector<int32_t> ts;
+        plan::plan_tiles(sp, ts);
+        c->w_ntiles[which] = (int)(ts.size() / 16);
+        if ((rc = c->d_tile_seg[which].ensure(std::max<size_t>(ts.size(), 16))))
+            return rc;
+        BHMM_HIP(hipMemcpy(c->d_tile_seg[which].p, ts.data(), ts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     return BHMM_OK;
 }
 
@@ -219,7 +282,7 @@ static int wide_plan_segments(bhmm_ctx *c, int64_t seglen)
         return rc;
     c->w_nseg[2] = 0;
     // (every segment of plan 1 cut in two: the segment count stays a multiple of the SIMD count)
-    if (c->N == 64 && c->wseg_split && seglen / 2 >= 4 * (int64_t)c->spec_W && seglen >= 128) {
+    if (c->N == 64 && !wide_tile(c) && c->wseg_split && seglen / 2 >= 4 * (int64_t)c->spec_W && seglen >= 128) {
         if ((rc = wide_plan(c, 2, seglen, 2)))
             return rc;
         // for every segment of plan 1: the start of a plan-2 segment strictly inside it (-1: none)
@@ -253,7 +316,7 @@ int wide_alloc(bhmm_ctx *c)
     {
         int64_t seglen = c->wseg_len;
         if (seglen <= 0)
-            seglen = std::max<int64_t>(wide_fill_len(c), 8 * (int64_t)c->spec_W);
+            seglen = std::max<int64_t>(wide_fill_len(c), (wide_tile(c) ? 2 : 8) * (int64_t)c->spec_W);
         int64_t maxT = 0;
         for (int k = 0; k < c->K; ++k)
             maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
@@ -272,7 +335,10 @@ int wide_alloc(bhmm_ctx *c)
         (rc = c->d_specres.ensure(4)) ||
         (rc = c->d_stats.ensure(1 + n + n * n + n + std::max(2 * n, n * c->M))))
         return rc;
-    if (c->kind == EMIT_DISC && (rc = c->d_dpartials.ensure((size_t)nsmax * n * c->M)))
+    if (c->kind == EMIT_DISC && (rc = c->d_dpartials.ensure((size_t)std::max(nsmax, 4 * (nsmax / 16 + 1)) * n * c->M)))
+        return rc;
+    if (wide_tile(c) && ((rc = c->d_wexp.ensure((size_t)std::max<int64_t>(c->total, 1))) ||
+                         (rc = c->d_wePseg.ensure(nsmax))))
         return rc;
     if (!c->h_specres)
         BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
@@ -368,25 +434,28 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         return rc;
     auto run = [&](int which, bool lazy) -> int {
         int r;
+        c->tile_used = lazy && wide_tile(c);
+        // event intervals of this family: [0] forward pass, [2] backward pass + statistics
         BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
-        BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
-        BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
+#define BHMM_WIDE_PASSES(KINDV)                                                                  \
+    do {                                                                                         \
+        if ((r = WIDE_DISPATCH(c, KINDV, wide_launch_fwd, c, m, which, lazy)))                   \
+            return r;                                                                            \
+        BHMM_HIP(hipEventRecord(c->ev[1], c->stream));                                           \
+        BHMM_HIP(hipEventRecord(c->ev[2], c->stream));                                           \
+        r = WIDE_DISPATCH(c, KINDV, wide_launch_bwd, c, m, which, sg, stats_dev, lazy);          \
+    } while (0)
         switch (c->kind) {
         case EMIT_GAUSS:
-            if ((r = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m, which, lazy)))
-                return r;
-            r = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_bwd, c, m, which, sg, stats_dev, lazy);
+            BHMM_WIDE_PASSES(EMIT_GAUSS);
             break;
         case EMIT_DISC:
-            if ((r = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m, which, lazy)))
-                return r;
-            r = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_bwd, c, m, which, sg, stats_dev, lazy);
+            BHMM_WIDE_PASSES(EMIT_DISC);
             break;
         default:
-            if ((r = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m, which, lazy)))
-                return r;
-            r = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_bwd, c, m, which, sg, stats_dev, lazy);
+            BHMM_WIDE_PASSES(EMIT_EXPL);
         }
+#undef BHMM_WIDE_PASSES
         if (r)
             return r;
         BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
@@ -419,7 +488,7 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
                 maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
             int64_t seglen = c->wseg_len;
             if (seglen <= 0)
-                seglen = std::max<int64_t>(wide_fill_len(c), 4 * (int64_t)W);
+                seglen = std::max<int64_t>(wide_fill_len(c), (wide_tile(c) ? 2 : 4) * (int64_t)W);
             seglen = std::max(seglen, c->wseg_cur_len); // never more segments than allocated for
             if (seglen >= maxT) {
                 c->wseg_given_up = true;
@@ -477,7 +546,7 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         double f = log(1e-12) / log(d);
         f = std::min(std::max(f, 1.25), 8.0);
         const int64_t Wn = ((int64_t)ceil(c->spec_W * f) + 7) / 8 * 8;
-        int64_t seglen = c->wseg_len > 0 ? (int64_t)c->wseg_len : 4 * Wn;
+        int64_t seglen = c->wseg_len > 0 ? (int64_t)c->wseg_len : (wide_tile(c) ? 2 : 4) * Wn;
         if (c->wseg_len <= 0)
             seglen = std::max(seglen, wide_fill_len(c));
         seglen = std::max(seglen, c->wseg_cur_len); // never more segments than allocated for

@@ -998,7 +998,7 @@ __global__ __launch_bounds__(64) void k_wide_probe(const WideModel m, const void
 // packed statistics (bhmm_amd.h layout) from the per-trajectory partials; one wavefront per
 // output entry, trajectory-strided partial sums + fixed shuffle tree.
 template <int KIND>
-__global__ __launch_bounds__(64) void k_wide_finalize(const WideModel m, int K, int nseg,
+__global__ __launch_bounds__(64) void k_wide_finalize(const WideModel m, int K, int nseg, int ndtab,
                                                       const double *part, const double *dstat,
                                                       const double *logL_k, const double *gamma0,
                                                       double *stats)
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(64) void k_wide_finalize(const WideModel m, int K, 
     }
     e -= S;
     if (e < MN) {
-        for (int k = lane; k < nseg; k += 64)
+        for (int k = lane; k < ndtab; k += 64) // (ndtab symbol tables: one per segment, or four per tile)
             s += dstat[(int64_t)k * MN + e];
         s = wave_sum(s);
         if (lane == 0)

@@ -1,0 +1,379 @@
+// tile_proto.hip -- prototype / microbenchmark of the row-batched MFMA forward recursion
+// (16 trajectory segments per workgroup, alpha-tile[16 x N] . A[N x N] on v_mfma_f64_16x16x4).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../bhmm_amd/csrc -o tile_proto tile_proto.hip
+// run:   ./tile_proto [steps] [tiles]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "host_common.hpp"
+#include "wide_kernels.hpp"
+
+using namespace bhmm;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define CK(x)                                                                         \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+__device__ __forceinline__ int row16_max(int v)
+{
+    v = max(v, dpp_i32<0xB1>(v));
+    v = max(v, dpp_i32<0x4E>(v));
+    v = max(v, dpp_i32<0x141>(v)); // row_half_mirror
+    v = max(v, dpp_i32<0x140>(v)); // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ void keep_alive(double x) { asm volatile("" ::"v"(x)); }
+
+// physical LDS row of tile row rho = q + 4 r
+__device__ __forceinline__ int prow(int rho)
+{
+    const int q = rho & 3, r = rho >> 2;
+    return 8 * (q & 1) + 4 * (q >> 1) + r;
+}
+
+// N states (multiple of 64 here), NACC accumulators per column tile, AREG: A's column block in VGPRs
+template <int N, int NACC, bool AREG, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict__ A, const double *__restrict__ mu,
+                                                       const double *__restrict__ ga, const double *__restrict__ gb,
+                                                       double gmg, const double *__restrict__ obs, int T,
+                                                       int nsteps, double *__restrict__ alpha, int store, unsigned long long *clk)
+{
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
+    const unsigned long long cs = __builtin_readcyclecounter(), ws = wall_clock64();
+    constexpr int NT = N / 16;       // column tiles
+    constexpr int TPW = NT / 4;      // tiles per wavefront
+    constexpr int KK = N / 4;        // K steps per product
+    constexpr int PA = N + 16;       // pitch of A in LDS: rows 4kk+q, q = 0/1 land 16 bank pairs apart
+    constexpr int PX = N + 2;        // pitch of the alpha tile: rows m -> 2 m bank pairs
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sM = smem;                       // [N][PA]   (only when !AREG)
+    double *sX = smem + (AREG ? 0 : N * PA); // [2][16][PX]
+    int *sE = reinterpret_cast<int *>(sX + 2 * 16 * PX); // [4][16]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    if constexpr (!AREG) {
+        for (int e = tid; e < N * N; e += 256)
+            sM[(e / N) * PA + (e % N)] = A[e];
+    }
+    double Breg[AREG ? TPW * KK : 1];
+    if constexpr (AREG) {
+#pragma unroll
+        for (int c = 0; c < TPW; ++c)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+                Breg[c * KK + kk] = A[(4 * kk + q) * N + 16 * (w + 4 * c) + s];
+    }
+    // initial vector: uniform
+    for (int e = tid; e < 16 * N; e += 256)
+        sX[(e / N) * PX + (e % N)] = 1.0 / N;
+    // per-lane constants of my states
+    double mu_j[TPW], ga_j[TPW], gb_j[TPW];
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const int j = 16 * (w + 4 * c) + s;
+        mu_j[c] = mu[j];
+        ga_j[c] = ga[j];
+        gb_j[c] = gb[j];
+    }
+    // my four rows (D layout): rho_r = q + 4 r; global row = 16 blockIdx + rho
+    const double *orow[4];
+    double *arow[4];
+    int xw[4]; // LDS write offsets
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = (int64_t)blockIdx.x * 16 + q + 4 * r;
+        orow[r] = obs + row * T;
+        arow[r] = alpha + row * (int64_t)T * N;
+        xw[r] = prow(q + 4 * r) * PX;
+    }
+    const int xr = prow(s) * PX + q; // A-operand read offset (+ 4 kk)
+    constexpr int PF = 4;
+    double oring[PF][4];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            oring[u][r] = orow[r][u < nsteps ? u : nsteps - 1];
+    __syncthreads();
+    int cur = 0;
+    int eP[4] = {0, 0, 0, 0};
+    for (int tb = 0; tb < nsteps; tb += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = tb + u;
+            if (t >= nsteps)
+                break;
+            double o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = oring[u][r];
+                const int tn = t + PF < nsteps ? t + PF : nsteps - 1;
+                oring[u][r] = orow[r][tn];
+            }
+            const double *X = sX + cur * 16 * PX;
+            double *Xn = sX + (cur ^ 1) * 16 * PX;
+            const unsigned long long c0 = clk ? __builtin_readcyclecounter() : 0;
+            d4 acc[TPW][NACC];
+#pragma unroll
+            for (int c = 0; c < TPW; ++c)
+#pragma unroll
+                for (int a = 0; a < NACC; ++a)
+                    acc[c][a] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const double av = X[xr + 4 * kk];
+#pragma unroll
+                for (int c = 0; c < TPW; ++c) {
+                    double bv;
+                    if constexpr (AREG)
+                        bv = Breg[c * KK + kk];
+                    else
+                        bv = sM[(4 * kk + q) * PA + 16 * (w + 4 * c) + s];
+                    acc[c][kk % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c][kk % NACC], 0, 0, 0);
+                }
+            }
+            unsigned long long c1 = 0;
+            if (clk) {
+                keep_alive(acc[0][0][0]);
+                c1 = __builtin_readcyclecounter();
+            }
+            // exponent for the rescale of this step (from the partial maxima of the step before)
+            int E[4] = {0, 0, 0, 0};
+            if ((u & 3) == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rho = q + 4 * r;
+                    E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
+                    eP[r] += E[r];
+                }
+            }
+            int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) {
+                d4 sum = acc[c][0];
+#pragma unroll
+                for (int a = 1; a < NACC; ++a)
+                    sum += acc[c][a];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double p = gauss_pdf_issue(o[r] - mu_j[c], ga_j[c], gb_j[c], gmg);
+                    double v = sum[r] * p;
+                    if ((u & 3) == 3)
+                        v = ldexp(v, -E[r]);
+                    Xn[xw[r] + 16 * (w + 4 * c) + s] = v;
+                    if (store)
+                        arow[r][(int64_t)t * N + 16 * (w + 4 * c) + s] = v;
+                    if ((u & 3) == 2)
+                        pm[r] = max(pm[r], v > 0.0 ? exponent_of(v) : -(1 << 28));
+                }
+            }
+            if ((u & 3) == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = row16_max(pm[r]);
+                    if (s == 0)
+                        sE[16 * w + q + 4 * r] = m;
+                }
+            }
+            unsigned long long c2 = 0;
+            if (clk)
+                c2 = __builtin_readcyclecounter();
+            __syncthreads();
+            if (clk) {
+                const unsigned long long c3 = __builtin_readcyclecounter();
+                tA += c1 - c0;
+                tB += c2 - c1;
+                tC += c3 - c2;
+            }
+            cur ^= 1;
+        }
+    }
+    if (clk && blockIdx.x == 0 && tid == 0) {
+        clk[0] = tA;
+        clk[1] = tB;
+        clk[2] = tC;
+        clk[3] = __builtin_readcyclecounter() - cs;
+        clk[4] = wall_clock64() - ws;
+    }
+    if (!store) { // keep the result alive: last vector + exponents
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < TPW; ++c)
+                arow[r][16 * (w + 4 * c) + s] = sX[cur * 16 * PX + xw[r] + 16 * (w + 4 * c) + s] + eP[r];
+    }
+}
+
+// naive reference: one workgroup of N threads per row, normalised every step
+template <int N>
+__global__ void k_ref_fwd(const double *A, const double *mu, const double *sig, const double *obs, int T,
+                          int nsteps, double *alpha)
+{
+    __shared__ double x[N], red[N];
+    const int j = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    x[j] = 1.0 / N;
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+        double acc = 0.0;
+        for (int i = 0; i < N; ++i)
+            acc += x[i] * A[i * N + j];
+        const double z = (obs[row * T + t] - mu[j]) / sig[j];
+        const double v = acc * exp(-0.5 * z * z) / (sqrt(2.0 * M_PI) * sig[j]);
+        red[j] = v;
+        __syncthreads();
+        double sum = 0.0;
+        for (int i = 0; i < N; ++i)
+            sum += red[i];
+        __syncthreads();
+        x[j] = v / sum;
+        alpha[(row * T + t) * N + j] = x[j];
+        __syncthreads();
+    }
+}
+
+template <int N, int NACC, bool AREG, int WPS>
+static void run(const char *name, int tiles, int T, int nsteps, const double *dA, const double *dmu,
+                const double *dga, const double *dgb, double gmg, const double *dobs, double *dalpha,
+                const std::vector<double> &ref, int refrows)
+{
+    constexpr int PA = N + 16, PX = N + 2;
+    const size_t sm = ((AREG ? 0 : (size_t)N * PA) + 2 * 16 * PX) * sizeof(double) + 64 * sizeof(int);
+    auto kern = k_tile_fwd<N, NACC, AREG, WPS>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    // correctness on the first refrows rows (store = 1, few tiles)
+    double maxdev = 0.0;
+    if (refrows > 0) {
+        const int ct = (refrows + 15) / 16;
+        hipLaunchKernelGGL(kern, dim3(ct), dim3(256), sm, 0, dA, dmu, dga, dgb, gmg, dobs, T, nsteps, dalpha, 1, (unsigned long long *)nullptr);
+        CK(hipDeviceSynchronize());
+        std::vector<double> h((size_t)refrows * T * N);
+        for (int r = 0; r < refrows; ++r)
+            CK(hipMemcpy(h.data() + (size_t)r * T * N, dalpha + (size_t)r * T * N, (size_t)nsteps * N * sizeof(double),
+                         hipMemcpyDeviceToHost));
+        for (int r = 0; r < refrows; ++r)
+            for (int t = 0; t < nsteps; ++t) {
+                double sum = 0.0;
+                for (int j = 0; j < N; ++j)
+                    sum += h[((size_t)r * T + t) * N + j];
+                for (int j = 0; j < N; ++j) {
+                    const double a = h[((size_t)r * T + t) * N + j] / sum, b = ref[((size_t)r * T + t) * N + j];
+                    const double d = fabs(a - b) / fmax(b, 1e-280);
+                    if (b > 1e-200 && d > maxdev)
+                        maxdev = d;
+                    if (!(sum > 0.0))
+                        maxdev = 1e300;
+                }
+            }
+    }
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), sm, 0, dA, dmu, dga, dgb, gmg, dobs, T, nsteps, dalpha, 0, (unsigned long long *)nullptr);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = fminf(best, ms);
+    }
+    CK(hipGetLastError());
+    // with store
+    float bests = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), sm, 0, dA, dmu, dga, dgb, gmg, dobs, T, nsteps, dalpha, 1, (unsigned long long *)nullptr);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        bests = fminf(bests, ms);
+    }
+    {
+        unsigned long long *dclk, h[5];
+        CK(hipMalloc(&dclk, 64));
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), sm, 0, dA, dmu, dga, dgb, gmg, dobs, T, nsteps, dalpha, 0, dclk);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h, dclk, sizeof(h), hipMemcpyDeviceToHost));
+        printf("    phases (cycles/step, wave 0 of tile 0): mfma-issue %.0f  emit+write %.0f  barrier %.0f  total %.0f  clock %.2f GHz\n",
+               (double)h[0] / nsteps, (double)h[1] / nsteps, (double)h[2] / nsteps, (double)h[3] / nsteps,
+               (double)h[3] / ((double)h[4] * 10.0));
+        CK(hipFree(dclk));
+    }
+    const double rowsteps = (double)tiles * 16 * nsteps;
+    printf("%-28s N=%d tiles=%d steps=%d: %.3f ms (no store) %.3f ms (store)  %.1f ns/tile-step  "
+           "%.2f TFLOP/s  maxdev %.2e\n",
+           name, N, tiles, nsteps, best, bests, 1e6 * best / nsteps, 2.0 * N * N * rowsteps / (best * 1e-3) / 1e12,
+           maxdev);
+}
+
+int main(int argc, char **argv)
+{
+    const int nsteps = argc > 1 ? atoi(argv[1]) : 2000;
+    const int T = nsteps;
+    constexpr int N = 64;
+    const int maxtiles = 1024;
+    const int64_t rows = (int64_t)maxtiles * 16;
+    std::vector<double> A(N * N), mu(N), sig(N), ga(N), gb(N);
+    srand(1);
+    for (int i = 0; i < N; ++i) {
+        double sum = 0.0;
+        for (int j = 0; j < N; ++j) {
+            A[i * N + j] = (rand() / (double)RAND_MAX) * 0.01 + (i == j ? 0.9 : 0.0) + (abs(i - j) == 1 ? 0.04 : 0.0);
+            sum += A[i * N + j];
+        }
+        for (int j = 0; j < N; ++j)
+            A[i * N + j] /= sum;
+        mu[i] = -5.0 + 10.0 * i / (N - 1);
+        sig[i] = 0.5 + 1.5 * i / (N - 1);
+    }
+    double gmg;
+    gauss_pdf_constants(N, N, sig.data(), ga.data(), gb.data(), &gmg);
+    std::vector<double> obs((size_t)rows * T);
+    for (auto &o : obs)
+        o = -6.0 + 12.0 * (rand() / (double)RAND_MAX);
+    double *dA, *dmu, *dsig, *dga, *dgb, *dobs, *dalpha, *dref;
+    CK(hipMalloc(&dA, N * N * 8));
+    CK(hipMalloc(&dmu, N * 8));
+    CK(hipMalloc(&dsig, N * 8));
+    CK(hipMalloc(&dga, N * 8));
+    CK(hipMalloc(&dgb, N * 8));
+    CK(hipMalloc(&dobs, obs.size() * 8));
+    CK(hipMalloc(&dalpha, (size_t)rows * T * N * 8));
+    const int refrows = 32;
+    CK(hipMalloc(&dref, (size_t)refrows * T * N * 8));
+    CK(hipMemcpy(dA, A.data(), N * N * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dmu, mu.data(), N * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsig, sig.data(), N * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dga, ga.data(), N * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dgb, gb.data(), N * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dobs, obs.data(), obs.size() * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ref_fwd<N>, dim3(refrows), dim3(N), 0, 0, dA, dmu, dsig, dobs, T, nsteps, dref);
+    CK(hipDeviceSynchronize());
+    std::vector<double> ref((size_t)refrows * T * N);
+    CK(hipMemcpy(ref.data(), dref, ref.size() * 8, hipMemcpyDeviceToHost));
+
+    for (int tiles : {256, 512}) {
+        run<N, 1, false, 1>("lds-A acc1 wps1", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 2, false, 2>("lds-A acc2 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 4, false, 2>("lds-A acc4 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 1, true, 2>("reg-A acc1 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 2, true, 2>("reg-A acc2 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 4, true, 2>("reg-A acc4 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 2, true, 3>("reg-A acc2 wps3", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+    }
+    return 0;
+}
