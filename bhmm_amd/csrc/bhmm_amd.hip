@@ -1576,6 +1576,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->carry_kappa;
     else if (n == "wide_segments")
         *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
+    else if (n == "wide_trouble") // which self-check of the lazily scaled kernels fired last (bit mask)
+        *value = c->wide_trouble;
     else if (n == "tile") // 1: the last E-step ran on the row-batched matrix-core kernels
         *value = c->tile_used ? 1.0 : 0.0;
     else if (n == "wide_fwd_segments") // the forward pass's own, finer plan (64 states), 0 if none

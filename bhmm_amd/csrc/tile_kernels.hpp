@@ -110,6 +110,65 @@ __device__ __forceinline__ double tile_emit(const WideModel &m, const TileIn<KIN
         return in.p[c][r];
 }
 
+// Four densities of ONE state at four observations (the four tile rows of a lane): gauss_pdf_issue with
+// the four Horner chains side by side, in plain fused multiply-adds, so that the scheduler can
+// interleave them with each other AND with the matrix instructions of the step (as four opaque
+// blocks the chains ran one after the other behind the matrix instructions: 790 cycles per step of
+// the forward recursion, measured, against 1024 for its matrix instructions).
+__device__ __forceinline__ void gauss_pdf4_issue(const double (&d)[4], double a, double b, double MG,
+                                                 double (&p)[4])
+{
+    double w[4], q[4];
+    int tl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double u = fmin(fma(d[i] * d[i], a, b), 1.0);
+        const double t = MG - u;
+        w[i] = (t - MG) + u;
+        tl[i] = __double2loint(t);
+        q[i] = 0x1.e3991e644e6abp+92;
+    }
+    constexpr double C[10] = {-0x1.b6740fc28f781p+84, 0x1.62c157ee59177p+76, -0x1.ffcb55e82f22cp+67,
+                              0x1.4309126056718p+59,  -0x1.5d87fe9cc5d6fp+50, 0x1.3b2ab6fbde0f7p+41,
+                              -0x1.c6b08d703d48ap+31, 0x1.ebfbdff82c3b9p+21,  -0x1.62e42fefa3a17p+11, 1.0};
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            q[i] = __builtin_fma(q[i], w[i], C[k]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        p[i] = ldexp(q[i], tl[i]);
+}
+
+// emission probabilities of my states (tiles c) for my four rows
+template <int NT, int KIND, int TPW>
+__device__ __forceinline__ void tile_emit4(const WideModel &m, const TileIn<KIND, TPW> &in, int w, int s,
+                                           const bool (&real)[TPW], const double (&mu_j)[TPW],
+                                           const double (&ga_j)[TPW], const double (&gb_j)[TPW],
+                                           double (&p)[TPW][4])
+{
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        if constexpr (KIND == EMIT_GAUSS) {
+            double d[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                d[r] = in.o[r] - mu_j[c];
+            gauss_pdf4_issue(d, ga_j[c], gb_j[c], m.gmg, p[c]); // (lanes without a state: a = 0, b = 1 -> 0)
+        } else if constexpr (KIND == EMIT_DISC) {
+            const int j = 16 * (w + 4 * c) + s;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                p[c][r] = real[c] ? m.B[(int64_t)j * m.M + in.sym[r]] : 0.0;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                p[c][r] = in.p[c][r];
+        }
+    }
+}
+
 // A tile advances in groups of four steps (the rescaling phase).  Most groups are uniform over the
 // tile's 16 rows -- every row still in its warm-up, or every row in its main part -- and run without
 // any per-row predicate; the groups around segment entries and exits take the general path.
@@ -134,6 +193,8 @@ __device__ __forceinline__ int tile_all_max(int v)
 // segment, the exponents removed (exps[global step], eP_seg[segment]), the vectors at the segment
 // entry (after the warm-up) and exit for the boundary check and the log-likelihood.
 // FULL: n == 16 NT (no padded states).
+// One iteration: matrix instructions of step rs | times the emission row, LDS write, HBM store |
+// emission row of step rs + 1 and the loads of step rs + 4 (in the shadow of the exchange) | barrier.
 // =========================================================================================
 template <int NT, int KIND, int WPS, bool FULL>
 __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const int64_t *off, const Segs sg,
@@ -150,7 +211,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
     const int n = FULL ? 16 * NT : m.n;
 
     // ---- my four rows ----------------------------------------------------------------------
-    int seg[4], nst[4], r0[4];
+    int seg[4], nst[4], r0[4], nlast[4];
     int64_t ob[4]; // global step index of the row's first (warm-up) step
     bool fs[4];
 #pragma unroll
@@ -169,6 +230,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
             ob[r] = o0 + tw;
             fs[r] = tw == 0;
         }
+        nlast[r] = nst[r] > 0 ? nst[r] - 1 : 0;
     }
     // (every wavefront holds all 16 rows: these are uniform over the workgroup)
     const int nmax = tile_all_max(max(max(nst[0], nst[1]), max(nst[2], nst[3])));
@@ -180,7 +242,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
     const int g4 = (nmax + 3) & ~3;
     const int g1 = min(max(r0min - 1, 0) & ~3, g4);
     const int g2 = min(max((r0max + 3) & ~3, anyfs ? 4 : 0), g4);
-    const int g3 = min(max(g2, max(nstmin - TILE_PF, 0) & ~3), g4);
+    const int g3 = min(max(g2, max(nstmin - 1, 0) & ~3), g4); // (a row's last step stores its exit vector: general)
 
     // ---- the model: my blocks of A (B operand), emission constants, pi ------------------------
     double Breg[TPW * KK];
@@ -212,14 +274,11 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
         xw[r] = tile_prow(q + 4 * r) * PX;
     const int xr = tile_prow(s) * PX + q;
 
-    // what step rs reads (LM == TM_GEN: rows that have ended keep reading their last step)
-    auto load = [&](TileIn<KIND, TPW> &in, int rs, auto lm) __attribute__((always_inline)) {
-        constexpr int LM = decltype(lm)::value;
+    // what step rs reads (rows that have ended keep reading their last step)
+    auto load = [&](TileIn<KIND, TPW> &in, int rs) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int rr = rs;
-            if constexpr (LM == TM_GEN)
-                rr = rs < nst[r] ? rs : (nst[r] > 0 ? nst[r] - 1 : 0);
+            const int rr = min(rs, nlast[r]);
             if constexpr (KIND == EMIT_GAUSS)
                 in.o[r] = static_cast<const double *>(obs_rm)[ob[r] + rr];
             else if constexpr (KIND == EMIT_DISC)
@@ -234,26 +293,46 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
     TileIn<KIND, TPW> ring[TILE_PF];
 #pragma unroll
     for (int u = 0; u < TILE_PF; ++u)
-        load(ring[u], u, tile_ic<TM_GEN>{});
+        load(ring[u], u);
+    double pcur[TPW][4]; // emission row of the step whose matrix instructions are issued next
+    tile_emit4<NT, KIND, TPW>(m, ring[0], w, s, real, mu_j, ga_j, gb_j, pcur);
+    load(ring[0], TILE_PF);
     __syncthreads();
 
     int eP[4] = {0, 0, 0, 0};
-    bool trouble = false;
-    auto step = [&](int rs, auto uc, auto mc, auto lc) __attribute__((always_inline)) {
+    unsigned int trouble = 0u; // (bit 0: a vector below 2^-900)
+    auto step = [&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
-        const TileIn<KIND, TPW> in = ring[u];
-        load(ring[u], rs + TILE_PF, lc);
         const double *X = sX + (u & 1) * 16 * PX; // (groups of four steps: the buffer is the step's parity)
         double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
         wide_d4 acc[TPW];
+        {
+            // (all operand reads first: issued one pair of matrix instructions ahead of its use, every
+            // read's latency sat in the dependent chain -- 168 instead of 128 cycles per pair)
+            double av[KK];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const double av = X[xr + 4 * kk];
+            for (int kk = 0; kk < KK; ++kk)
+                av[kk] = X[xr + 4 * kk];
 #pragma unroll
-            for (int c = 0; c < TPW; ++c)
-                if (w + 4 * c < NT)
-                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Breg[c * KK + kk],
-                                                                  kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    if (NT % 4 == 0 || w + 4 * c < NT)
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], Breg[c * KK + kk],
+                                                                      kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+        }
+        // in the shadow of the matrix instructions: the emission row of the next step, the loads of
+        // step rs + 1 + 4 (the pattern below asks the scheduler to issue them between the matrix
+        // instructions, all operand reads first)
+        double pnext[TPW][4];
+        tile_emit4<NT, KIND, TPW>(m, ring[(u + 1) & 3], w, s, real, mu_j, ga_j, gb_j, pnext);
+        load(ring[(u + 1) & 3], rs + 1 + TILE_PF);
+        __builtin_amdgcn_sched_group_barrier(0x100, KK / 2, 0); // LDS reads (pairs)
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);      // the loads
+#pragma unroll
+        for (int kk = 0; kk < KK * TPW; ++kk) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one matrix instruction
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); // ... six vector instructions behind it
         }
         // the exponent this step removes: row maxima of the step before, over the four wavefronts
         int E[4] = {0, 0, 0, 0};
@@ -263,7 +342,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
                 const int rho = q + 4 * r;
                 E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
                 const bool act = MODE != TM_GEN || rs < nst[r];
-                trouble |= act && E[r] < WIDE_TROUBLE_EXP;
+                trouble |= (act && E[r] < WIDE_TROUBLE_EXP) ? 1u : 0u;
                 if (MODE == TM_MAIN || (MODE == TM_GEN && act && rs >= r0[r])) {
                     eP[r] += E[r];
                     if (w == 0 && s == 0)
@@ -275,15 +354,14 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
         const int64_t rsn = (int64_t)rs * n;
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
-            if (w + 4 * c < NT) {
+            if (NT % 4 == 0 || w + 4 * c < NT) {
                 const int j = 16 * (w + 4 * c) + s;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double p = tile_emit<KIND, TPW>(m, in, c, r, j, real[c], mu_j[c], ga_j[c], gb_j[c]);
-                    double v = acc[c][r] * p;
+                    double v = acc[c][r] * pcur[c][r];
                     if constexpr (MODE == TM_GEN)
                         if (fs[r] && rs == 0)
-                            v = pi_j[c] * p;
+                            v = pi_j[c] * pcur[c][r];
                     if constexpr (u == 3)
                         v = ldexp(v, -E[r]);
                     Xn[xw[r] + j] = v;
@@ -302,6 +380,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
                                 a_exit[(int64_t)seg[r] * n + j] = v;
                         }
                     }
+                    pcur[c][r] = pnext[c][r];
                 }
             }
         }
@@ -315,20 +394,13 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
         }
         __syncthreads();
     };
-    // groups [lo, hi) in mode mc; the last group prefetches with the general (clamped) loads
+    // groups [lo, hi) in mode mc
     auto run = [&](int lo, int hi, auto mc) __attribute__((always_inline)) {
-        int rs = lo;
-        for (; rs + 8 <= hi; rs += 4) {
-            step(rs, tile_ic<0>{}, mc, mc);
-            step(rs + 1, tile_ic<1>{}, mc, mc);
-            step(rs + 2, tile_ic<2>{}, mc, mc);
-            step(rs + 3, tile_ic<3>{}, mc, mc);
-        }
-        for (; rs + 4 <= hi; rs += 4) {
-            step(rs, tile_ic<0>{}, mc, tile_ic<TM_GEN>{});
-            step(rs + 1, tile_ic<1>{}, mc, tile_ic<TM_GEN>{});
-            step(rs + 2, tile_ic<2>{}, mc, tile_ic<TM_GEN>{});
-            step(rs + 3, tile_ic<3>{}, mc, tile_ic<TM_GEN>{});
+        for (int rs = lo; rs + 4 <= hi; rs += 4) {
+            step(rs, tile_ic<0>{}, mc);
+            step(rs + 1, tile_ic<1>{}, mc);
+            step(rs + 2, tile_ic<2>{}, mc);
+            step(rs + 3, tile_ic<3>{}, mc);
         }
     };
     run(0, g1, tile_ic<TM_WARM>{});
@@ -341,8 +413,8 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
             if (seg[r] >= 0)
                 eP_seg[seg[r]] = eP[r];
     }
-    if (__any(trouble) && lane == 0)
-        atomicOr(&flags[2], 1u);
+    if (trouble)
+        atomicOr(&flags[2], trouble);
 }
 
 // log-likelihood of every segment from what k_tile_fwd left: log sum(exit vector) - log sum(entry
@@ -369,7 +441,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
     else
         se = 1.0;
     if (!(sx > 0.0) || !(se > 0.0))
-        atomicOr(&flags[2], 1u);
+        atomicOr(&flags[2], 2u);
     logL_seg[s] = (log(sx) - log(se)) + (double)eP_seg[s] * 0.693147180559945309417232121458;
 }
 
@@ -379,6 +451,12 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
 //   dstat [tile][4][n][M] (discrete: one table per lane row q, so that no two lanes share an entry)
 // XIG: no xi accumulators; the rows W_{t-1} = p_t o beta_t / S are stored instead (counts by the
 // time-parallel GEMM of gen_kernels.hpp) -- for state counts whose accumulators do not fit.
+//
+// One iteration (step us = time t of a row): the matrix instructions of beta_{t-1} = A (p_t o beta_t)
+// | rescale, x' = p_{t-1} o beta_{t-1} into the other LDS buffer -- the serial chain -- | then, while
+// that exchange is in flight: the xi matrix instructions of the transition t-1 -> t (operands: alpha_{t-1}
+// in registers, p_t o beta_t still in this step's LDS buffer), gamma_{t-1} and the emission statistics,
+// the emission row of time t - 2, the loads of four steps ahead | barrier.
 // =========================================================================================
 template <int NT, int KIND, int WPS, bool FULL, bool XIG>
 __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const int64_t *off, const Segs sg,
@@ -398,7 +476,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
     const int n = FULL ? 16 * NT : m.n;
 
     // ---- my four rows: step us of the tile is time ttop - us of the row ------------------------
-    int seg[4], nwarm[4], nst[4], trj[4];
+    int seg[4], nwarm[4], nst[4], trj[4], nlast[4];
     int64_t gtop[4]; // global step index of time ttop
     int ttop[4];     // (time inside the trajectory; trajectories of up to 2^31 steps)
 #pragma unroll
@@ -420,17 +498,20 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
             gtop[r] = o0 + ttop[r];
             trj[r] = k;
         }
+        nlast[r] = nst[r] > 0 ? nst[r] - 1 : 0;
     }
     const int nmax = tile_all_max(max(max(nst[0], nst[1]), max(nst[2], nst[3])));
     const int nstmin = tile_all_min(min(min(nst[0], nst[1]), min(nst[2], nst[3])));
     const int emin = tile_all_min(min(min(nwarm[0], nwarm[1]), min(nwarm[2], nwarm[3])));
     const int emax = tile_all_max(max(max(nwarm[0], nwarm[1]), max(nwarm[2], nwarm[3])));
-    // steps [0, g1): all rows warm up (and none reads alpha yet); [g2, g3): all rows inside their main
-    // part (entered, not at their last step, t > 0 also for what is fetched ahead); the rest: general
+    // Iteration us does the back half of step us and the front half of step us + 1.
+    // [0, g1): both are warm-up steps of every row, and none reads alpha yet (also not four steps
+    // ahead); [g2, g3): both are main-part steps of every row (entered, before the last step, t > 0
+    // also for what is fetched ahead); the rest: general
     const int g4 = (nmax + 3) & ~3;
-    const int g1 = min(max(emin - 1, 0) & ~3, g4);
+    const int g1 = min(max(emin - 2 - TILE_PF, 0) & ~3, g4);
     const int g2 = min((emax + 1 + 3) & ~3, g4);
-    const int g3 = min(max(g2, max(nstmin - 1 - TILE_PF, 0) & ~3), g4);
+    const int g3 = min(max(g2, max(nstmin - 2 - TILE_PF, 0) & ~3), g4);
 
     // ---- the model: my blocks of A^T (B operand of the beta product) --------------------------
     double Breg[TPW * KK];
@@ -484,56 +565,64 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
                     mytab[(int64_t)(16 * (w + 4 * c) + s) * m.M + z] = 0.0;
     }
 
-    // what one step reads: the observation of time t, alpha of time t - 1, the exponent removed at t
-    struct BIn {
-        TileIn<KIND, TPW> e;
+    // what one step reads: the observation of time t (ringE; consumed two iterations before the
+    // rest: the emission row is computed ahead), alpha of time t - 1 and the exponent removed at t (ringA)
+    struct AIn {
         double ap[TPW][4];
         int ex[4];
     };
-    auto load = [&](BIn &in, int us, auto lm) __attribute__((always_inline)) {
-        constexpr int LM = decltype(lm)::value;
+    auto loadE = [&](TileIn<KIND, TPW> &in, int us) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int uu = us;
-            if constexpr (LM == TM_GEN)
-                uu = us < nst[r] ? us : (nst[r] > 0 ? nst[r] - 1 : 0);
+            const int uu = min(us, nlast[r]);
             const int64_t g = gtop[r] - uu; // global index of time t
-            const int t = ttop[r] - uu;
-            const int64_t un = (int64_t)uu * n;
             if constexpr (KIND == EMIT_GAUSS)
-                in.e.o[r] = static_cast<const double *>(obs_rm)[g];
+                in.o[r] = static_cast<const double *>(obs_rm)[g];
             else if constexpr (KIND == EMIT_DISC)
-                in.e.sym[r] = static_cast<const int32_t *>(obs_rm)[g];
+                in.sym[r] = static_cast<const int32_t *>(obs_rm)[g];
             else {
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
-                    in.e.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[abase[c][r] - un] : 0.0;
+                    in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[abase[c][r] - (int64_t)uu * n] : 0.0;
             }
+        }
+    };
+    auto loadA = [&](AIn &in, int us, auto lm) __attribute__((always_inline)) {
+        constexpr int LM = decltype(lm)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
             if constexpr (LM == TM_WARM) {
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
                     in.ap[c][r] = 0.0;
                 in.ex[r] = 0;
             } else if constexpr (LM == TM_MAIN) {
+                const int64_t un = (int64_t)us * n;
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
                     in.ap[c][r] = (FULL || real[c]) ? alpha_rm[abase[c][r] - un - n] : 0.0;
-                const int e = exps[g];
-                in.ex[r] = (t & 3) == 3 ? e : 0;
+                const int e = exps[gtop[r] - us];
+                in.ex[r] = ((ttop[r] - us) & 3) == 3 ? e : 0;
             } else {
+                const int uu = min(us, nlast[r]);
+                const int t = ttop[r] - uu;
+                const int64_t un = (int64_t)uu * n;
                 // alpha_{t-1} from the last warm-up step on (it becomes alpha_t of the first main step)
                 const bool wanta = us + 1 >= nwarm[r] && us < nst[r] && t > 0;
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
                     in.ap[c][r] = (wanta && real[c]) ? alpha_rm[abase[c][r] - un - n] : 0.0;
-                in.ex[r] = (us >= nwarm[r] && us < nst[r] && (t & 3) == 3) ? exps[g] : 0;
+                in.ex[r] = (us >= nwarm[r] && us < nst[r] && (t & 3) == 3) ? exps[gtop[r] - uu] : 0;
             }
         }
     };
-    BIn ring[TILE_PF];
+    TileIn<KIND, TPW> ringE[TILE_PF];
+    AIn ringA[TILE_PF];
 #pragma unroll
-    for (int u = 0; u < TILE_PF; ++u)
-        load(ring[u], u, tile_ic<TM_GEN>{});
+    for (int u = 0; u < TILE_PF; ++u) {
+        loadE(ringE[u], u);
+        loadA(ringA[u], u, tile_ic<TM_GEN>{});
+    }
 
     // state of my rows
     double beta[TPW][4], acur[TPW][4];
@@ -547,9 +636,9 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
             // rows without a warm-up (end of the trajectory) start in the main part: alpha_{T-1}
             acur[c][r] = (nst[r] > 0 && nwarm[r] == 0 && real[c]) ? alpha_rm[abase[c][r]] : 0.0;
         }
-    bool trouble = false;
+    unsigned int trouble = 0u; // (bits: 4 S0, 8 entry normaliser, 16 a vector below 2^-900, 32 gamma mass)
     // sum over all states of v (my states, my four rows), exchanged through sS: two barriers
-    auto rows_sum = [&](const double (&v)[4], double (&out)[4]) {
+    auto rows_sum = [&](const double (&v)[4], double (&out)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double ps = row16_sum(v[r]);
@@ -565,35 +654,29 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
         __syncthreads();
     };
 
-    auto step = [&](int us, auto uc, auto mc, auto lc) __attribute__((always_inline)) {
+    // emission row / observation of the step whose front half comes next
+    double pcur[TPW][4];
+    TileIn<KIND, TPW> ecur;
+
+    // front half of step us (time t): [a row enters its main part: normaliser S0] ; x = p_t o beta_t
+    // into LDS buffer us & 1.  Returns through `fg` the gamma factors of the step.
+    auto front_chain = [&](int us, auto uc, auto mc, double (&fg)[4], bool (&mainr)[4]) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
-        const BIn in = ring[u];
-        load(ring[u], us + TILE_PF, lc);
-        bool mainr[4], lastr[4];
-        int tt[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r)
             mainr[r] = MODE == TM_MAIN;
-            lastr[r] = false;
-            tt[r] = 1;
-        }
-        bool any_last = false;
         if constexpr (MODE == TM_GEN) {
             bool enter[4], any_enter = false;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 mainr[r] = us >= nwarm[r] && us < nst[r];
                 enter[r] = us == nwarm[r] && nst[r] > 0;
-                tt[r] = ttop[r] - us;
-                lastr[r] = us == nst[r] - 1 && tt[r] > 0; // the transition into the segment
                 any_enter |= enter[r];
-                any_last |= lastr[r];
             }
             any_enter = __any(any_enter); // (every wavefront holds all 16 rows: uniform over the workgroup)
-            any_last = __any(any_last);
             if (any_enter) {
-                // a row enters its main part: the warm-up's beta for the boundary check, and the
-                // normaliser of the whole segment, S0 = sum_j alpha_t*[j] beta_t*[j]
+                // the warm-up's beta for the boundary check, and the normaliser of the whole
+                // segment, S0 = sum_j alpha_t*[j] beta_t*[j]
                 double g[4] = {0.0, 0.0, 0.0, 0.0}, S0[4];
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
@@ -607,84 +690,119 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (enter[r]) {
-                        trouble |= !(S0[r] >= 0x1p-959) || !(S0[r] < 0x1p1000);
+                        trouble |= (!(S0[r] >= 0x1p-959) || !(S0[r] < 0x1p1000)) ? 4u : 0u;
                         rS0[r] = fast_rcp(S0[r]);
                         cg[r] = 0;
                     }
             }
         }
-        // ---- gamma_t of the rows in their main part, x = p_t o beta_t ----------------------------
-        double x[TPW][4];
-        const int64_t usn = (int64_t)us * n;
-        if constexpr (MODE == TM_WARM) {
+        double *Xn = sX + (u & 1) * 16 * PX;
 #pragma unroll
-            for (int c = 0; c < TPW; ++c)
+        for (int c = 0; c < TPW; ++c)
+            if (w + 4 * c < NT)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double p = (w + 4 * c < NT) ? tile_emit<KIND, TPW>(m, in.e, c, r, 16 * (w + 4 * c) + s,
-                                                                            real[c], mu_j[c], ga_j[c], gb_j[c])
-                                                      : 0.0;
-                    x[c][r] = p * beta[c][r];
-                }
-        } else {
-            double fg[4];
+                for (int r = 0; r < 4; ++r)
+                    Xn[xw[r] + 16 * (w + 4 * c) + s] = pcur[c][r] * beta[c][r];
+        if constexpr (MODE != TM_WARM) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 fg[r] = mainr[r] ? ldexp(rS0[r], -cg[r]) : 0.0;
+        }
+    };
+    // ... and off the chain: gamma_t and the emission statistics of the rows in their main part
+    auto front_stats = [&](int us, auto mc, const double (&fg)[4], const bool (&mainr)[4]) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mc)::value;
+        if constexpr (MODE != TM_WARM) {
+            const int64_t usn = (int64_t)us * n;
 #pragma unroll
             for (int c = 0; c < TPW; ++c) {
                 const int j = 16 * (w + 4 * c) + s;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double p = (w + 4 * c < NT)
-                                         ? tile_emit<KIND, TPW>(m, in.e, c, r, j, real[c], mu_j[c], ga_j[c], gb_j[c])
-                                         : 0.0;
                     const double gam = acur[c][r] * beta[c][r] * fg[r];
-                    x[c][r] = p * beta[c][r];
                     mass[r] += gam;
                     sgm[c] += gam;
                     if constexpr (KIND == EMIT_GAUSS) {
-                        const double d = in.e.o[r] - mu_j[c];
+                        const double d = ecur.o[r] - mu_j[c];
                         const double gd = gam * d;
                         sd[c] += gd;
                         sdd[c] = fma(gd, d, sdd[c]);
                     }
                     if constexpr (KIND == EMIT_DISC)
                         if (real[c] && mainr[r])
-                            mytab[(int64_t)j * m.M + in.e.sym[r]] += gam;
+                            mytab[(int64_t)j * m.M + ecur.sym[r]] += gam;
                     if (real[c] && mainr[r]) {
                         if (gamma_rm)
                             gamma_rm[abase[c][r] - usn] = gam;
-                        if (MODE == TM_GEN && tt[r] == 0)
+                        if (MODE == TM_GEN && ttop[r] - us == 0)
                             gamma0[(int64_t)trj[r] * n + j] = gam;
                     }
                 }
             }
         }
-        double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
-#pragma unroll
-        for (int c = 0; c < TPW; ++c)
-            if (w + 4 * c < NT)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Xn[xw[r] + 16 * (w + 4 * c) + s] = x[c][r];
+    };
+
+    // prologue: the front half of step 0
+    {
+        tile_emit4<NT, KIND, TPW>(m, ringE[0], w, s, real, mu_j, ga_j, gb_j, pcur);
+        ecur = ringE[0];
+        loadE(ringE[0], TILE_PF);
+        double fg[4];
+        bool mainr[4];
+        front_chain(0, tile_ic<0>{}, tile_ic<TM_GEN>{}, fg, mainr);
+        front_stats(0, tile_ic<TM_GEN>{}, fg, mainr);
+        // the emission row of step 1
+        tile_emit4<NT, KIND, TPW>(m, ringE[1], w, s, real, mu_j, ga_j, gb_j, pcur);
+        ecur = ringE[1];
+        loadE(ringE[1], 1 + TILE_PF);
         __syncthreads();
-        // ---- beta_{t-1} (raw) = A (p_t o beta_t) ------------------------------------------------
-        const double *X = Xn;
+    }
+
+    auto step = [&](int us, auto uc, auto mc, auto lc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
+        const AIn in = ringA[u];
+        loadA(ringA[u], us + TILE_PF, lc);
+        // ---- back half of step us: beta_{t-1} (raw) = A (p_t o beta_t) ----------------------------
+        const double *X = sX + (u & 1) * 16 * PX;
         wide_d4 acc[TPW];
+        {
+            // (all operand reads first: issued one pair of matrix instructions ahead of its use, every
+            // read's latency sat in the dependent chain -- 168 instead of 128 cycles per pair)
+            double av[KK];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const double av = X[xr + 4 * kk];
+            for (int kk = 0; kk < KK; ++kk)
+                av[kk] = X[xr + 4 * kk];
 #pragma unroll
-            for (int c = 0; c < TPW; ++c)
-                if (w + 4 * c < NT)
-                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Breg[c * KK + kk],
-                                                                  kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    if (NT % 4 == 0 || w + 4 * c < NT)
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], Breg[c * KK + kk],
+                                                                      kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
         }
-        // ---- xi of the transition t-1 -> t ------------------------------------------------------
+        bool mainr[4], lastr[4];
+        int tt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            mainr[r] = MODE == TM_MAIN;
+            lastr[r] = false;
+            tt[r] = 1;
+        }
+        bool any_last = false;
+        if constexpr (MODE == TM_GEN) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mainr[r] = us >= nwarm[r] && us < nst[r];
+                tt[r] = ttop[r] - us;
+                lastr[r] = us == nst[r] - 1 && tt[r] > 0; // the transition into the segment
+                any_last |= lastr[r];
+            }
+            any_last = __any(any_last);
+        }
+        // factors of xi for the transition t-1 -> t
         int cx[4] = {0, 0, 0, 0};
+        double fx[4] = {0.0, 0.0, 0.0, 0.0};
         if constexpr (MODE != TM_WARM) {
-            double fx[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 cx[r] = cg[r] + in.ex[r];
@@ -704,44 +822,20 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (lastr[r]) {
-                            trouble |= !(SL[r] >= 0x1p-959) || !(SL[r] < 0x1p1000);
+                            trouble |= (!(SL[r] >= 0x1p-959) || !(SL[r] < 0x1p1000)) ? 8u : 0u;
                             fx[r] = fast_rcp(SL[r]);
                         }
                 }
             }
-            if constexpr (!XIG) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double xb[NT];
-#pragma unroll
-                    for (int J = 0; J < NT; ++J)
-                        xb[J] = X[xq[r] + 16 * J];
-#pragma unroll
-                    for (int c = 0; c < TPW; ++c)
-                        if (w + 4 * c < NT) {
-                            const double aw = in.ap[c][r] * fx[r];
-#pragma unroll
-                            for (int J = 0; J < NT; ++J)
-                                Cacc[c][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, xb[J], Cacc[c][J], 0, 0, 0);
-                        }
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < TPW; ++c)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (real[c] && mainr[r] && tt[r] > 0)
-                            Wg[abase[c][r] - usn - n] = x[c][r] * fx[r];
-            }
         }
-        // ---- rescale (every fourth step, by the row maxima exchanged one step earlier) ------
+        // rescale (every fourth step, by the row maxima exchanged one step earlier)
         int E[4] = {0, 0, 0, 0};
         if constexpr (u == 3) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rho = q + 4 * r;
                 E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
-                trouble |= (MODE != TM_GEN || us < nst[r]) && E[r] < WIDE_TROUBLE_EXP;
+                trouble |= ((MODE != TM_GEN || us < nst[r]) && E[r] < WIDE_TROUBLE_EXP) ? 16u : 0u;
             }
         }
         int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
@@ -761,6 +855,15 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
                 if constexpr (MODE != TM_WARM)
                     acur[c][r] = in.ap[c][r];
             }
+        if constexpr (MODE != TM_WARM) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cg[r] = cx[r] - E[r];
+        }
+        // ---- front half of step us + 1, the chain part: x' into the other buffer ------------------
+        double fg[4] = {0.0, 0.0, 0.0, 0.0};
+        bool mainn[4];
+        front_chain(us + 1, tile_ic<(u + 1) & 3>{}, mc, fg, mainn);
         if constexpr (u == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -769,12 +872,46 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
                     sE[16 * w + q + 4 * r] = mx;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- off the chain: xi of the transition t-1 -> t -----------------------------------------
         if constexpr (MODE != TM_WARM) {
+            if constexpr (!XIG) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                cg[r] = cx[r] - E[r];
+                for (int r = 0; r < 4; ++r) {
+                    double xb[NT];
+#pragma unroll
+                    for (int J = 0; J < NT; ++J)
+                        xb[J] = X[xq[r] + 16 * J];
+#pragma unroll
+                    for (int c = 0; c < TPW; ++c)
+                        if (w + 4 * c < NT) {
+                            const double aw = in.ap[c][r] * fx[r];
+#pragma unroll
+                            for (int J = 0; J < NT; ++J)
+                                Cacc[c][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, xb[J], Cacc[c][J], 0, 0, 0);
+                        }
+                }
+            } else {
+                const int64_t usn = (int64_t)us * n;
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    if (w + 4 * c < NT)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (real[c] && mainr[r] && tt[r] > 0)
+                                Wg[abase[c][r] - usn - n] = X[xw[r] + 16 * (w + 4 * c) + s] * fx[r];
+            }
         }
+        front_stats(us + 1, mc, fg, mainn);
+        // the emission row of step us + 2, the observation loads of four steps further
+        tile_emit4<NT, KIND, TPW>(m, ringE[(u + 2) & 3], w, s, real, mu_j, ga_j, gb_j, pcur);
+        ecur = ringE[(u + 2) & 3];
+        loadE(ringE[(u + 2) & 3], us + 2 + TILE_PF);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
     };
+    // groups [lo, hi) in mode mc; the last group of a phase takes the general path (its last
+    // iteration does the front half of the next phase's first step) and fetches for it
     auto run = [&](int lo, int hi, auto mc) __attribute__((always_inline)) {
         int us = lo;
         for (; us + 8 <= hi; us += 4) {
@@ -784,10 +921,10 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
             step(us + 3, tile_ic<3>{}, mc, mc);
         }
         for (; us + 4 <= hi; us += 4) {
-            step(us, tile_ic<0>{}, mc, tile_ic<TM_GEN>{});
-            step(us + 1, tile_ic<1>{}, mc, tile_ic<TM_GEN>{});
-            step(us + 2, tile_ic<2>{}, mc, tile_ic<TM_GEN>{});
-            step(us + 3, tile_ic<3>{}, mc, tile_ic<TM_GEN>{});
+            step(us, tile_ic<0>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
+            step(us + 1, tile_ic<1>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
+            step(us + 2, tile_ic<2>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
+            step(us + 3, tile_ic<3>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
         }
     };
     run(0, g1, tile_ic<TM_WARM>{});
@@ -802,10 +939,10 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double want = (double)(nst[r] - nwarm[r]);
-            trouble |= !(fabs(tot[r] - want) <= 1e-8 * want);
+            trouble |= !(fabs(tot[r] - want) <= 1e-8 * want) ? 32u : 0u;
         }
-        if (__any(trouble) && lane == 0)
-            atomicOr(&flags[2], 1u);
+        if (trouble)
+            atomicOr(&flags[2], trouble);
     }
     // ---- the tile's partial statistics --------------------------------------------------------
     const int S = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0);

@@ -520,6 +520,8 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 3 * sizeof(unsigned int),
                                 hipMemcpyDeviceToHost, c->stream));
         BHMM_HIP(hipStreamSynchronize(c->stream));
+        if (lazy)
+            c->wide_trouble = c->h_specres[2];
         if (lazy && c->h_specres[2] != 0) {
             // a vector left the range the lazy scaling covers: per-step normalisation from now on
             c->wide_careful = true;

@@ -42,54 +42,37 @@ __device__ __forceinline__ int prow(int rho)
     return 8 * (q & 1) + 4 * (q >> 1) + r;
 }
 
-// N states (multiple of 64 here), NACC accumulators per column tile, AREG: A's column block in VGPRs
-template <int N, int NACC, bool AREG, int WPS>
+// VAR: 0 reads next to their use, emission after the matrix instructions (four asm blocks)
+//      1 all operand reads first (sched_group_barrier), emission as in 0
+//      2 reads first; emission of the NEXT step after the LDS write (before the barrier), four chains interleaved (C++)
+//      3 reads first; emission of the next step interleaved with the matrix instructions (sched_group_barrier)
+//      4 as 2, but NO emission at all (p = 1): what the recursion alone costs
+template <int N, int VAR, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict__ A, const double *__restrict__ mu,
                                                        const double *__restrict__ ga, const double *__restrict__ gb,
                                                        double gmg, const double *__restrict__ obs, int T,
                                                        int nsteps, double *__restrict__ alpha, int store, unsigned long long *clk)
 {
-    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
+    unsigned long long tA = 0, tB = 0, tC = 0;
     const unsigned long long cs = __builtin_readcyclecounter(), ws = wall_clock64();
-    constexpr int NT = N / 16;       // column tiles
-    constexpr int TPW = NT / 4;      // tiles per wavefront
-    constexpr int KK = N / 4;        // K steps per product
-    constexpr int PA = N + 16;       // pitch of A in LDS: rows 4kk+q, q = 0/1 land 16 bank pairs apart
-    constexpr int PX = N + 2;        // pitch of the alpha tile: rows m -> 2 m bank pairs
+    constexpr int KK = N / 4;
+    constexpr int PX = N + 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *sM = smem;                       // [N][PA]   (only when !AREG)
-    double *sX = smem + (AREG ? 0 : N * PA); // [2][16][PX]
-    int *sE = reinterpret_cast<int *>(sX + 2 * 16 * PX); // [4][16]
+    double *sX = smem;
+    int *sE = reinterpret_cast<int *>(sX + 2 * 16 * PX);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int s = lane & 15, q = lane >> 4;
-    if constexpr (!AREG) {
-        for (int e = tid; e < N * N; e += 256)
-            sM[(e / N) * PA + (e % N)] = A[e];
-    }
-    double Breg[AREG ? TPW * KK : 1];
-    if constexpr (AREG) {
+    double Breg[KK];
 #pragma unroll
-        for (int c = 0; c < TPW; ++c)
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-                Breg[c * KK + kk] = A[(4 * kk + q) * N + 16 * (w + 4 * c) + s];
-    }
-    // initial vector: uniform
+    for (int kk = 0; kk < KK; ++kk)
+        Breg[kk] = A[(4 * kk + q) * N + 16 * w + s];
     for (int e = tid; e < 16 * N; e += 256)
         sX[(e / N) * PX + (e % N)] = 1.0 / N;
-    // per-lane constants of my states
-    double mu_j[TPW], ga_j[TPW], gb_j[TPW];
-#pragma unroll
-    for (int c = 0; c < TPW; ++c) {
-        const int j = 16 * (w + 4 * c) + s;
-        mu_j[c] = mu[j];
-        ga_j[c] = ga[j];
-        gb_j[c] = gb[j];
-    }
-    // my four rows (D layout): rho_r = q + 4 r; global row = 16 blockIdx + rho
+    const int j = 16 * w + s;
+    const double mu_j = mu[j], ga_j = ga[j], gb_j = gb[j];
     const double *orow[4];
     double *arow[4];
-    int xw[4]; // LDS write offsets
+    int xw[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = (int64_t)blockIdx.x * 16 + q + 4 * r;
@@ -97,7 +80,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict_
         arow[r] = alpha + row * (int64_t)T * N;
         xw[r] = prow(q + 4 * r) * PX;
     }
-    const int xr = prow(s) * PX + q; // A-operand read offset (+ 4 kk)
+    const int xr = prow(s) * PX + q;
     constexpr int PF = 4;
     double oring[PF][4];
 #pragma unroll
@@ -105,8 +88,42 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             oring[u][r] = orow[r][u < nsteps ? u : nsteps - 1];
+    double pcur[4] = {1.0, 1.0, 1.0, 1.0};
+    auto emit_c = [&](const double (&o)[4], double (&p)[4]) __attribute__((always_inline)) {
+        double d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            d[r] = o[r] - mu_j;
+        double wv[4], qv[4];
+        int tl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double u = fmin(fma(d[i] * d[i], ga_j, gb_j), 1.0);
+            const double t = gmg - u;
+            wv[i] = (t - gmg) + u;
+            tl[i] = __double2loint(t);
+            qv[i] = 0x1.e3991e644e6abp+92;
+        }
+        constexpr double C[10] = {-0x1.b6740fc28f781p+84, 0x1.62c157ee59177p+76, -0x1.ffcb55e82f22cp+67,
+                                  0x1.4309126056718p+59,  -0x1.5d87fe9cc5d6fp+50, 0x1.3b2ab6fbde0f7p+41,
+                                  -0x1.c6b08d703d48ap+31, 0x1.ebfbdff82c3b9p+21,  -0x1.62e42fefa3a17p+11, 1.0};
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                qv[i] = __builtin_fma(qv[i], wv[i], C[k]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            p[i] = ldexp(qv[i], tl[i]);
+    };
+    if constexpr (VAR == 2 || VAR == 3) {
+        double o0[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            o0[r] = oring[0][r];
+        emit_c(o0, pcur);
+    }
     __syncthreads();
-    int cur = 0;
     int eP[4] = {0, 0, 0, 0};
     for (int tb = 0; tb < nsteps; tb += PF) {
 #pragma unroll
@@ -114,41 +131,49 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict_
             const int t = tb + u;
             if (t >= nsteps)
                 break;
-            double o[4];
+            double o[4], on[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 o[r] = oring[u][r];
+                on[r] = oring[(u + 1) & 3][r];
                 const int tn = t + PF < nsteps ? t + PF : nsteps - 1;
                 oring[u][r] = orow[r][tn];
             }
-            const double *X = sX + cur * 16 * PX;
-            double *Xn = sX + (cur ^ 1) * 16 * PX;
+            const double *X = sX + (u & 1) * 16 * PX;
+            double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
             const unsigned long long c0 = clk ? __builtin_readcyclecounter() : 0;
-            d4 acc[TPW][NACC];
+            d4 acc;
+            if constexpr (VAR == 0) {
 #pragma unroll
-            for (int c = 0; c < TPW; ++c)
+                for (int kk = 0; kk < KK; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[xr + 4 * kk], Breg[kk], kk == 0 ? d4{0.0, 0.0, 0.0, 0.0} : acc, 0, 0, 0);
+            } else {
+                double av[KK];
 #pragma unroll
-                for (int a = 0; a < NACC; ++a)
-                    acc[c][a] = d4{0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk < KK; ++kk)
+                    av[kk] = X[xr + 4 * kk];
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                const double av = X[xr + 4 * kk];
+                for (int kk = 0; kk < KK; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], Breg[kk], kk == 0 ? d4{0.0, 0.0, 0.0, 0.0} : acc, 0, 0, 0);
+            }
+            double pnext[4] = {1.0, 1.0, 1.0, 1.0};
+            if constexpr (VAR == 3) {
+                emit_c(on, pnext);
+                __builtin_amdgcn_sched_group_barrier(0x100, KK / 2, 0);
 #pragma unroll
-                for (int c = 0; c < TPW; ++c) {
-                    double bv;
-                    if constexpr (AREG)
-                        bv = Breg[c * KK + kk];
-                    else
-                        bv = sM[(4 * kk + q) * PA + 16 * (w + 4 * c) + s];
-                    acc[c][kk % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c][kk % NACC], 0, 0, 0);
+                for (int kk = 0; kk < KK; ++kk) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                 }
+            } else if constexpr (VAR != 0) {
+                __builtin_amdgcn_sched_group_barrier(0x100, KK / 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, KK, 0);
             }
             unsigned long long c1 = 0;
             if (clk) {
-                keep_alive(acc[0][0][0]);
+                keep_alive(acc[0]);
                 c1 = __builtin_readcyclecounter();
             }
-            // exponent for the rescale of this step (from the partial maxima of the step before)
             int E[4] = {0, 0, 0, 0};
             if ((u & 3) == 3) {
 #pragma unroll
@@ -160,23 +185,20 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict_
             }
             int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
 #pragma unroll
-            for (int c = 0; c < TPW; ++c) {
-                d4 sum = acc[c][0];
-#pragma unroll
-                for (int a = 1; a < NACC; ++a)
-                    sum += acc[c][a];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double p = gauss_pdf_issue(o[r] - mu_j[c], ga_j[c], gb_j[c], gmg);
-                    double v = sum[r] * p;
-                    if ((u & 3) == 3)
-                        v = ldexp(v, -E[r]);
-                    Xn[xw[r] + 16 * (w + 4 * c) + s] = v;
-                    if (store)
-                        arow[r][(int64_t)t * N + 16 * (w + 4 * c) + s] = v;
-                    if ((u & 3) == 2)
-                        pm[r] = max(pm[r], v > 0.0 ? exponent_of(v) : -(1 << 28));
-                }
+            for (int r = 0; r < 4; ++r) {
+                double p;
+                if constexpr (VAR <= 1)
+                    p = gauss_pdf_issue(o[r] - mu_j, ga_j, gb_j, gmg);
+                else
+                    p = pcur[r];
+                double v = acc[r] * p;
+                if ((u & 3) == 3)
+                    v = ldexp(v, -E[r]);
+                Xn[xw[r] + j] = v;
+                if (store)
+                    arow[r][(int64_t)t * N + j] = v;
+                if ((u & 3) == 2)
+                    pm[r] = max(pm[r], v > 0.0 ? exponent_of(v) : -(1 << 28));
             }
             if ((u & 3) == 2) {
 #pragma unroll
@@ -185,6 +207,15 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict_
                     if (s == 0)
                         sE[16 * w + q + 4 * r] = m;
                 }
+            }
+            if constexpr (VAR == 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                emit_c(on, pcur);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (VAR == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pcur[r] = pnext[r];
             }
             unsigned long long c2 = 0;
             if (clk)
@@ -196,7 +227,6 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict_
                 tB += c2 - c1;
                 tC += c3 - c2;
             }
-            cur ^= 1;
         }
     }
     if (clk && blockIdx.x == 0 && tid == 0) {
@@ -206,12 +236,10 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict_
         clk[3] = __builtin_readcyclecounter() - cs;
         clk[4] = wall_clock64() - ws;
     }
-    if (!store) { // keep the result alive: last vector + exponents
+    if (!store) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < TPW; ++c)
-                arow[r][16 * (w + 4 * c) + s] = sX[cur * 16 * PX + xw[r] + 16 * (w + 4 * c) + s] + eP[r];
+            arow[r][j] = sX[xw[r] + j] + eP[r];
     }
 }
 
@@ -243,14 +271,14 @@ __global__ void k_ref_fwd(const double *A, const double *mu, const double *sig, 
     }
 }
 
-template <int N, int NACC, bool AREG, int WPS>
+template <int N, int VAR, int WPS>
 static void run(const char *name, int tiles, int T, int nsteps, const double *dA, const double *dmu,
                 const double *dga, const double *dgb, double gmg, const double *dobs, double *dalpha,
                 const std::vector<double> &ref, int refrows)
 {
-    constexpr int PA = N + 16, PX = N + 2;
-    const size_t sm = ((AREG ? 0 : (size_t)N * PA) + 2 * 16 * PX) * sizeof(double) + 64 * sizeof(int);
-    auto kern = k_tile_fwd<N, NACC, AREG, WPS>;
+    constexpr int PX = N + 2;
+    const size_t sm = ((size_t)2 * 16 * PX) * sizeof(double) + 64 * sizeof(int);
+    auto kern = k_tile_fwd<N, VAR, WPS>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -367,13 +395,11 @@ int main(int argc, char **argv)
     CK(hipMemcpy(ref.data(), dref, ref.size() * 8, hipMemcpyDeviceToHost));
 
     for (int tiles : {256, 512}) {
-        run<N, 1, false, 1>("lds-A acc1 wps1", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
-        run<N, 2, false, 2>("lds-A acc2 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
-        run<N, 4, false, 2>("lds-A acc4 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
-        run<N, 1, true, 2>("reg-A acc1 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
-        run<N, 2, true, 2>("reg-A acc2 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
-        run<N, 4, true, 2>("reg-A acc4 wps2", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
-        run<N, 2, true, 3>("reg-A acc2 wps3", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 0, 2>("v0 baseline", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 1, 2>("v1 reads first", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 2, 2>("v2 emission before barrier", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 3, 2>("v3 emission between mfma", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
+        run<N, 4, 2>("v4 no emission", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, 0 ? ref : ref, 0);
     }
     return 0;
 }
