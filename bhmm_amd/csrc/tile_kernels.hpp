@@ -111,10 +111,7 @@ __device__ __forceinline__ double tile_emit(const WideModel &m, const TileIn<KIN
 }
 
 // Four densities of ONE state at four observations (the four tile rows of a lane): gauss_pdf_issue with
-// the four Horner chains side by side, in plain fused multiply-adds, so that the scheduler can
-// interleave them with each other AND with the matrix instructions of the step (as four opaque
-// blocks the chains ran one after the other behind the matrix instructions: 790 cycles per step of
-// the forward recursion, measured, against 1024 for its matrix instructions).
+// the four Horner chains side by side, so that no fused multiply-add waits for its predecessor.
 __device__ __forceinline__ void gauss_pdf4_issue(const double (&d)[4], double a, double b, double MG,
                                                  double (&p)[4])
 {
@@ -176,6 +173,7 @@ enum { TM_WARM = 0, TM_MAIN = 1, TM_GEN = 2 };
 
 template <int V>
 using tile_ic = std::integral_constant<int, V>;
+typedef double tile_d2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int tile_all_min(int v)
 {
@@ -188,36 +186,58 @@ __device__ __forceinline__ int tile_all_max(int v)
     return max(v, __shfl_xor(v, 32, 64));
 }
 
+// Workgroup = EIGHT wavefronts on one tile.  Measured on gfx950 (tools/proto/step_lat.hip,
+// tile_proto.hip): the matrix instructions of a step are a dependent chain (1024 cycles) that
+// vector instructions of the same wavefront cannot hide behind, 16-byte LDS reads feed it at 1390
+// cycles per step where 8-byte reads need 1830, and four global stores per lane cost it another 220.
+// So the roles are split:
+//   wavefronts 0-3 ("matrix"): operand reads, matrix instructions, times the emission row, LDS write;
+//   wavefronts 4-7 ("stream"): the emission rows one step ahead (into LDS), the observation
+//       stream, alpha rows from the LDS tile to HBM in 16-byte pieces, exponent bookkeeping --
+//       wavefront 4 + w shares the SIMD of matrix wavefront w and fills the cycles its chain leaves.
+// One barrier per step for all eight.  The K index of the products is (q, kk) <-> state q * KK + kk,
+// so that the operand of lane (m, q) is 8 * KK consecutive bytes of row m of the tile.
+constexpr int TILE_THREADS = 512;
+
+// emission rows handed from the stream wavefronts to the matrix wavefronts: [slot][w][c][half][lane][2]
+template <int TPW>
+__device__ __forceinline__ int tile_p_index(int slot, int w, int c, int h, int lane)
+{
+    return ((((slot * 4 + w) * TPW + c) * 2 + h) * 64 + lane) * 2;
+}
+
 // =========================================================================================
 // k_tile_fwd: alpha rows (row-major, up to a power of two per row) for the main part of every
 // segment, the exponents removed (exps[global step], eP_seg[segment]), the vectors at the segment
 // entry (after the warm-up) and exit for the boundary check and the log-likelihood.
 // FULL: n == 16 NT (no padded states).
-// One iteration: matrix instructions of step rs | times the emission row, LDS write, HBM store |
-// emission row of step rs + 1 and the loads of step rs + 4 (in the shadow of the exchange) | barrier.
 // =========================================================================================
-template <int NT, int KIND, int WPS, bool FULL>
-__global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const int64_t *off, const Segs sg,
-                                                       const TilePlan tp, const void *obs_rm,
-                                                       double *alpha_rm, int32_t *exps, int32_t *eP_seg,
-                                                       double *a_entry, double *a_exit, unsigned int *flags)
+template <int NT, int KIND, bool FULL>
+__global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, const int64_t *off, const Segs sg,
+                                                           const TilePlan tp, const void *obs_rm,
+                                                           double *alpha_rm, int32_t *exps, int32_t *eP_seg,
+                                                           double *a_entry, double *a_exit, unsigned int *flags,
+                                                           unsigned long long *probe = nullptr)
 {
     using G = TileGeo<NT>;
-    constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX;
+    constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX, NP = G::NP;
     __shared__ __attribute__((aligned(16))) double sX[2 * 16 * PX];
+    __shared__ __attribute__((aligned(16))) double sP[2 * 4 * TPW * 2 * 64 * 2];
     __shared__ int sE[64];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool matrix = wid < 4;
+    const int w = wid & 3;
     const int s = lane & 15, q = lane >> 4;
-    const int n = FULL ? 16 * NT : m.n;
+    const int n = FULL ? NP : m.n;
 
-    // ---- my four rows ----------------------------------------------------------------------
-    int seg[4], nst[4], r0[4], nlast[4];
+    // ---- my four rows (both roles: lane (s, q), register r <-> row q + 4 r) --------------------
+    int nst[4], r0[4], nlast[4];
     int64_t ob[4]; // global step index of the row's first (warm-up) step
     bool fs[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + q + 4 * r];
-        seg[r] = sgi;
         nst[r] = 0;
         r0[r] = 0;
         ob[r] = 0;
@@ -234,187 +254,276 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
     }
     // (every wavefront holds all 16 rows: these are uniform over the workgroup)
     const int nmax = tile_all_max(max(max(nst[0], nst[1]), max(nst[2], nst[3])));
-    const int nstmin = tile_all_min(min(min(nst[0], nst[1]), min(nst[2], nst[3])));
-    const int r0min = tile_all_min(min(min(r0[0], r0[1]), min(r0[2], r0[3])));
-    const int r0max = tile_all_max(max(max(r0[0], r0[1]), max(r0[2], r0[3])));
-    const bool anyfs = __any(fs[0] || fs[1] || fs[2] || fs[3]);
-    // steps [0, g1): all rows warm up; [g2, g3): all rows in their main part; the rest: general
     const int g4 = (nmax + 3) & ~3;
-    const int g1 = min(max(r0min - 1, 0) & ~3, g4);
-    const int g2 = min(max((r0max + 3) & ~3, anyfs ? 4 : 0), g4);
-    const int g3 = min(max(g2, max(nstmin - 1, 0) & ~3), g4); // (a row's last step stores its exit vector: general)
 
-    // ---- the model: my blocks of A (B operand), emission constants, pi ------------------------
-    double Breg[TPW * KK];
-    double mu_j[TPW], ga_j[TPW], gb_j[TPW], pi_j[TPW];
-    bool real[TPW];
-    int64_t abase[TPW][4]; // element index of (row's first step, my state) in a [step][n] array
-#pragma unroll
-    for (int c = 0; c < TPW; ++c) {
-        const int j = 16 * (w + 4 * c) + s;
-        real[c] = (w + 4 * c < NT) && (FULL || j < n);
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const int i = 4 * kk + q;
-            Breg[c * KK + kk] = (real[c] && (FULL || i < n)) ? m.A[(int64_t)i * n + j] : 0.0;
-        }
-        mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[j] : 0.0;
-        ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[j] : 0.0;
-        gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[j] : 1.0;
-        pi_j[c] = real[c] ? m.pi[j] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            abase[c][r] = ob[r] * n + j;
-    }
-    for (int e = tid; e < 16 * PX; e += 256)
+    for (int e = tid; e < 16 * PX; e += TILE_THREADS)
         sX[e] = (e % PX) < n ? 1.0 / (double)n : 0.0; // warm-ups start from the uniform vector
-    int xw[4];
+    bool real[TPW];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        xw[r] = tile_prow(q + 4 * r) * PX;
-    const int xr = tile_prow(s) * PX + q;
-
-    // what step rs reads (rows that have ended keep reading their last step)
-    auto load = [&](TileIn<KIND, TPW> &in, int rs) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = min(rs, nlast[r]);
-            if constexpr (KIND == EMIT_GAUSS)
-                in.o[r] = static_cast<const double *>(obs_rm)[ob[r] + rr];
-            else if constexpr (KIND == EMIT_DISC)
-                in.sym[r] = static_cast<const int32_t *>(obs_rm)[ob[r] + rr];
-            else {
-#pragma unroll
-                for (int c = 0; c < TPW; ++c)
-                    in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[abase[c][r] + (int64_t)rr * n] : 0.0;
-            }
+    for (int c = 0; c < TPW; ++c)
+        real[c] = (w + 4 * c < NT) && (FULL || 16 * (w + 4 * c) + s < n);
+    // groups of four steps; the matrix wavefronts only distinguish the first step (rows that start
+    // their trajectory take pi o p_0 instead of the product)
+    auto run = [&](auto &&step) __attribute__((always_inline)) {
+        int rs = 0;
+        if (g4 >= 4) {
+            step(0, tile_ic<0>{}, tile_ic<TM_GEN>{});
+            step(1, tile_ic<1>{}, tile_ic<TM_MAIN>{});
+            step(2, tile_ic<2>{}, tile_ic<TM_MAIN>{});
+            step(3, tile_ic<3>{}, tile_ic<TM_MAIN>{});
+            rs = 4;
+        }
+        for (; rs + 4 <= g4; rs += 4) {
+            step(rs, tile_ic<0>{}, tile_ic<TM_MAIN>{});
+            step(rs + 1, tile_ic<1>{}, tile_ic<TM_MAIN>{});
+            step(rs + 2, tile_ic<2>{}, tile_ic<TM_MAIN>{});
+            step(rs + 3, tile_ic<3>{}, tile_ic<TM_MAIN>{});
         }
     };
-    TileIn<KIND, TPW> ring[TILE_PF];
-#pragma unroll
-    for (int u = 0; u < TILE_PF; ++u)
-        load(ring[u], u);
-    double pcur[TPW][4]; // emission row of the step whose matrix instructions are issued next
-    tile_emit4<NT, KIND, TPW>(m, ring[0], w, s, real, mu_j, ga_j, gb_j, pcur);
-    load(ring[0], TILE_PF);
-    __syncthreads();
 
-    int eP[4] = {0, 0, 0, 0};
-    unsigned int trouble = 0u; // (bit 0: a vector below 2^-900)
-    auto step = [&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
-        constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
-        const double *X = sX + (u & 1) * 16 * PX; // (groups of four steps: the buffer is the step's parity)
-        double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
-        wide_d4 acc[TPW];
-        {
-            // (all operand reads first: issued one pair of matrix instructions ahead of its use, every
-            // read's latency sat in the dependent chain -- 168 instead of 128 cycles per pair)
-            double av[KK];
+    if (matrix) {
+        // ================= matrix wavefronts ==================================================
+        // (the serial chain runs here: its instructions go first whenever both wavefronts of a SIMD
+        // have one ready -- without this the stream wavefront's vector instructions went first and
+        // the matrix instructions started when it was done)
+        __builtin_amdgcn_s_setprio(3);
+        double Breg[TPW * KK], pi_j[TPW]; // my blocks of A (B operand)
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-                av[kk] = X[xr + 4 * kk];
+        for (int c = 0; c < TPW; ++c) {
+            const int j = 16 * (w + 4 * c) + s;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int i = q * KK + kk;
+                Breg[c * KK + kk] = (real[c] && (FULL || i < n)) ? m.A[(int64_t)i * n + j] : 0.0;
+            }
+            pi_j[c] = real[c] ? m.pi[j] : 0.0;
+        }
+        int xw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            xw[r] = tile_prow(q + 4 * r) * PX;
+        const int xr = tile_prow(s) * PX + q * KK; // my operand: KK consecutive doubles of row s
+        __syncthreads();
+        auto step = [&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
+            const bool pr = probe && blockIdx.x == 0 && wid == 0;
+            const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
+            const double *X = sX + (u & 1) * 16 * PX; // (groups of four steps: the buffer is the step's parity)
+            double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
+            tile_d2 av[KK / 2];
+#pragma unroll
+            for (int k2 = 0; k2 < KK / 2; ++k2)
+                av[k2] = *reinterpret_cast<const tile_d2 *>(X + xr + 2 * k2);
+            tile_d2 pl[TPW][2];
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) {
+                pl[c][0] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(u & 1, w, c, 0, lane)]);
+                pl[c][1] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(u & 1, w, c, 1, lane)]);
+            }
+            wide_d4 acc[TPW];
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
                     if (NT % 4 == 0 || w + 4 * c < NT)
-                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], Breg[c * KK + kk],
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk >> 1][kk & 1], Breg[c * KK + kk],
                                                                       kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
-        }
-        // in the shadow of the matrix instructions: the emission row of the next step, the loads of
-        // step rs + 1 + 4 (the pattern below asks the scheduler to issue them between the matrix
-        // instructions, all operand reads first)
-        double pnext[TPW][4];
-        tile_emit4<NT, KIND, TPW>(m, ring[(u + 1) & 3], w, s, real, mu_j, ga_j, gb_j, pnext);
-        load(ring[(u + 1) & 3], rs + 1 + TILE_PF);
-        __builtin_amdgcn_sched_group_barrier(0x100, KK / 2, 0); // LDS reads (pairs)
-        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);      // the loads
-#pragma unroll
-        for (int kk = 0; kk < KK * TPW; ++kk) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one matrix instruction
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); // ... six vector instructions behind it
-        }
-        // the exponent this step removes: row maxima of the step before, over the four wavefronts
-        int E[4] = {0, 0, 0, 0};
-        if constexpr (u == 3) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rho = q + 4 * r;
-                E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
-                const bool act = MODE != TM_GEN || rs < nst[r];
-                trouble |= (act && E[r] < WIDE_TROUBLE_EXP) ? 1u : 0u;
-                if (MODE == TM_MAIN || (MODE == TM_GEN && act && rs >= r0[r])) {
-                    eP[r] += E[r];
-                    if (w == 0 && s == 0)
-                        exps[ob[r] + rs] = E[r];
-                }
+            unsigned long long c1 = 0;
+            if (pr) {
+                asm volatile("" ::"v"(acc[0][0]));
+                c1 = __builtin_readcyclecounter();
             }
-        }
-        int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
-        const int64_t rsn = (int64_t)rs * n;
-#pragma unroll
-        for (int c = 0; c < TPW; ++c) {
-            if (NT % 4 == 0 || w + 4 * c < NT) {
-                const int j = 16 * (w + 4 * c) + s;
+            // the exponent this step removes: row maxima of the step before, over the four wavefronts
+            int E[4] = {0, 0, 0, 0};
+            if constexpr (u == 3) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double v = acc[c][r] * pcur[c][r];
-                    if constexpr (MODE == TM_GEN)
-                        if (fs[r] && rs == 0)
-                            v = pi_j[c] * pcur[c][r];
-                    if constexpr (u == 3)
-                        v = ldexp(v, -E[r]);
-                    Xn[xw[r] + j] = v;
-                    if constexpr (u == 2)
-                        pm[r] = max(pm[r], v > 0.0 ? exponent_of(v) : -(1 << 28));
-                    if constexpr (MODE == TM_MAIN) {
-                        if (FULL || real[c])
-                            alpha_rm[abase[c][r] + rsn] = v;
-                    } else if constexpr (MODE == TM_GEN) {
-                        if (real[c] && rs < nst[r]) {
-                            if (rs >= r0[r])
-                                alpha_rm[abase[c][r] + rsn] = v;
-                            else if (rs == r0[r] - 1)
-                                a_entry[(int64_t)seg[r] * n + j] = v;
-                            if (rs == nst[r] - 1)
-                                a_exit[(int64_t)seg[r] * n + j] = v;
-                        }
-                    }
-                    pcur[c][r] = pnext[c][r];
+                    const int rho = q + 4 * r;
+                    E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
                 }
             }
-        }
-        if constexpr (u == 2) {
+            int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mx = row16_max_i32(pm[r]);
-                if (s == 0)
-                    sE[16 * w + q + 4 * r] = mx;
+            for (int c = 0; c < TPW; ++c) {
+                if (NT % 4 == 0 || w + 4 * c < NT) {
+                    const int j = 16 * (w + 4 * c) + s;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double p = pl[c][r >> 1][r & 1];
+                        double v = acc[c][r] * p;
+                        if constexpr (MODE == TM_GEN)
+                            if (fs[r] && rs == 0)
+                                v = pi_j[c] * p;
+                        if constexpr (u == 3)
+                            v = ldexp(v, -E[r]);
+                        Xn[xw[r] + j] = v;
+                        if constexpr (u == 2)
+                            pm[r] = max(pm[r], v > 0.0 ? exponent_of(v) : -(1 << 28));
+                    }
+                }
+            }
+            if constexpr (u == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mx = row16_max_i32(pm[r]);
+                    if (s == 0)
+                        sE[16 * w + q + 4 * r] = mx;
+                }
+            }
+            const unsigned long long c2 = pr ? __builtin_readcyclecounter() : 0;
+            __syncthreads();
+            if (pr && lane == 0) {
+                const unsigned long long c3 = __builtin_readcyclecounter();
+                probe[0] += c1 - c0;
+                probe[1] += c2 - c1;
+                probe[2] += c3 - c2;
+                probe[3] += 1;
+            }
+        };
+        run(step);
+    } else {
+        // ================= stream wavefronts ==================================================
+        double mu_j[TPW], ga_j[TPW], gb_j[TPW];
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) {
+            const int j = 16 * (w + 4 * c) + s;
+            mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[j] : 0.0;
+            ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[j] : 0.0;
+            gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[j] : 1.0;
+        }
+        // the row whose alpha I carry to HBM: 16 lanes per row, NP / 16 states each
+        constexpr int SPL = NP / 16;
+        const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * SPL;
+        int s_seg = -1, s_nst = 0, s_r0 = 0;
+        int64_t s_ob = 0;
+        {
+            const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + srow];
+            s_seg = sgi;
+            if (sgi >= 0 && sg.len[sgi] > 0) {
+                const int64_t o0 = off[sg.traj[sgi]], t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+                const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0;
+                s_nst = (int)(t1 - tw);
+                s_r0 = (int)(t0 - tw);
+                s_ob = o0 + tw;
             }
         }
-        __syncthreads();
-    };
-    // groups [lo, hi) in mode mc
-    auto run = [&](int lo, int hi, auto mc) __attribute__((always_inline)) {
-        for (int rs = lo; rs + 4 <= hi; rs += 4) {
-            step(rs, tile_ic<0>{}, mc);
-            step(rs + 1, tile_ic<1>{}, mc);
-            step(rs + 2, tile_ic<2>{}, mc);
-            step(rs + 3, tile_ic<3>{}, mc);
-        }
-    };
-    run(0, g1, tile_ic<TM_WARM>{});
-    run(g1, g2, tile_ic<TM_GEN>{});
-    run(g2, g3, tile_ic<TM_MAIN>{});
-    run(g3, g4, tile_ic<TM_GEN>{});
-    if (w == 0 && s == 0) {
+        const int sxr = tile_prow(srow) * PX + sch;
+        // what step rs reads (rows that have ended keep reading their last step)
+        auto load = [&](TileIn<KIND, TPW> &in, int rs) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (seg[r] >= 0)
-                eP_seg[seg[r]] = eP[r];
+            for (int r = 0; r < 4; ++r) {
+                const int rr = min(rs, nlast[r]);
+                if constexpr (KIND == EMIT_GAUSS)
+                    in.o[r] = static_cast<const double *>(obs_rm)[ob[r] + rr];
+                else if constexpr (KIND == EMIT_DISC)
+                    in.sym[r] = static_cast<const int32_t *>(obs_rm)[ob[r] + rr];
+                else {
+#pragma unroll
+                    for (int c = 0; c < TPW; ++c)
+                        in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[(ob[r] + rr) * n + 16 * (w + 4 * c) + s] : 0.0;
+                }
+            }
+        };
+        // emission row of a step into slot (step & 1)
+        auto emit_to_lds = [&](const TileIn<KIND, TPW> &in, int slot) __attribute__((always_inline)) {
+            double p[TPW][4];
+            tile_emit4<NT, KIND, TPW>(m, in, w, s, real, mu_j, ga_j, gb_j, p);
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) {
+                *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 0, lane)]) = tile_d2{p[c][0], p[c][1]};
+                *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 1, lane)]) = tile_d2{p[c][2], p[c][3]};
+            }
+        };
+        // alpha of step rs (in LDS buffer (rs + 1) & 1 after that step's barrier) to HBM
+        auto store_row = [&](int rs) __attribute__((always_inline)) {
+            if (rs < 0 || rs >= s_nst)
+                return;
+            const double *X = sX + ((rs + 1) & 1) * 16 * PX + sxr;
+            double *dst = nullptr;
+            if (rs >= s_r0)
+                dst = alpha_rm + (s_ob + rs) * n + sch;
+            else if (rs == s_r0 - 1)
+                dst = a_entry + (int64_t)s_seg * n + sch;
+            if (dst) {
+                if constexpr (FULL) {
+#pragma unroll
+                    for (int e = 0; e < SPL; e += 2)
+                        *reinterpret_cast<tile_d2 *>(dst + e) = *reinterpret_cast<const tile_d2 *>(X + e);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < SPL; ++e)
+                        if (sch + e < n)
+                            dst[e] = X[e];
+                }
+            }
+            if (rs == s_nst - 1) {
+                double *dx = a_exit + (int64_t)s_seg * n + sch;
+#pragma unroll
+                for (int e = 0; e < SPL; ++e)
+                    if (FULL || sch + e < n)
+                        dx[e] = X[e];
+            }
+        };
+        TileIn<KIND, TPW> ring[TILE_PF];
+#pragma unroll
+        for (int u = 0; u < TILE_PF; ++u)
+            load(ring[u], u);
+        emit_to_lds(ring[0], 0);
+        load(ring[0], TILE_PF);
+        __syncthreads();
+        int eP[4] = {0, 0, 0, 0};
+        unsigned int trouble = 0u; // (bit 0: a vector below 2^-900)
+        auto step = [&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const bool pr = probe && blockIdx.x == 0 && wid == 4;
+            const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
+            // alpha of the previous step: LDS -> HBM.  First: none of this needs the fp64 pipe, which
+            // the matrix instructions of the other wavefront occupy for the first 1024 cycles of the step
+            store_row(rs - 1);
+            const TileIn<KIND, TPW> ein = ring[(u + 1) & 3];
+            load(ring[(u + 1) & 3], rs + 1 + TILE_PF);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long c1 = pr ? __builtin_readcyclecounter() : 0;
+            // the emission row of the next step
+            emit_to_lds(ein, (u + 1) & 1);
+            // bookkeeping of the exponents (one lane per row)
+            if constexpr (u == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rho = q + 4 * r;
+                    const int E = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
+                    const bool act = rs < nst[r];
+                    trouble |= (act && E < WIDE_TROUBLE_EXP) ? 1u : 0u;
+                    if (act && rs >= r0[r]) {
+                        eP[r] += E;
+                        if (w == 0 && s == 0)
+                            exps[ob[r] + rs] = E;
+                    }
+                }
+            }
+            const unsigned long long c2 = pr ? __builtin_readcyclecounter() : 0;
+            __syncthreads();
+            if (pr && lane == 0) {
+                const unsigned long long c3 = __builtin_readcyclecounter();
+                probe[4] += c1 - c0;
+                probe[5] += c2 - c1;
+                probe[6] += c3 - c2;
+                probe[7] += 1;
+            }
+        };
+        run(step);
+        store_row(g4 - 1);
+        if (w == 0 && s == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + q + 4 * r];
+                if (sgi >= 0)
+                    eP_seg[sgi] = eP[r];
+            }
+        }
+        if (trouble)
+            atomicOr(&flags[2], trouble);
     }
-    if (trouble)
-        atomicOr(&flags[2], trouble);
 }
 
 // log-likelihood of every segment from what k_tile_fwd left: log sum(exit vector) - log sum(entry
@@ -452,58 +561,82 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const WideModel m, const 
 // XIG: no xi accumulators; the rows W_{t-1} = p_t o beta_t / S are stored instead (counts by the
 // time-parallel GEMM of gen_kernels.hpp) -- for state counts whose accumulators do not fit.
 //
-// One iteration (step us = time t of a row): the matrix instructions of beta_{t-1} = A (p_t o beta_t)
-// | rescale, x' = p_{t-1} o beta_{t-1} into the other LDS buffer -- the serial chain -- | then, while
-// that exchange is in flight: the xi matrix instructions of the transition t-1 -> t (operands: alpha_{t-1}
-// in registers, p_t o beta_t still in this step's LDS buffer), gamma_{t-1} and the emission statistics,
-// the emission row of time t - 2, the loads of four steps ahead | barrier.
+// One iteration of the matrix wavefronts (step us = time t of a row): the matrix instructions of
+// beta_{t-1} = A (p_t o beta_t) | rescale, x' = p_{t-1} o beta_{t-1} into the other LDS buffer -- the
+// serial chain -- | then, while that exchange is in flight: the xi matrix instructions of the
+// transition t-1 -> t (operands: alpha_{t-1} in registers, p_t o beta_t still in this step's LDS
+// buffer), gamma_{t-1} and the emission statistics | barrier.  The stream wavefronts supply the
+// emission rows and the observations two steps ahead.
 // =========================================================================================
-template <int NT, int KIND, int WPS, bool FULL, bool XIG>
-__global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const int64_t *off, const Segs sg,
-                                                       const TilePlan tp, const void *obs_rm,
-                                                       const double *alpha_rm, const int32_t *exps,
-                                                       double *gamma_rm, double *gamma0, double *part,
-                                                       double *dstat, double *b_exit, double *b_entry,
-                                                       unsigned int *flags, double *Wg)
+template <int NT, int KIND, bool FULL, bool XIG>
+__global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, const int64_t *off, const Segs sg,
+                                                           const TilePlan tp, const void *obs_rm,
+                                                           const double *alpha_rm, const int32_t *exps,
+                                                           double *gamma_rm, double *gamma0, double *part,
+                                                           double *dstat, double *b_exit, double *b_entry,
+                                                           unsigned int *flags, double *Wg)
 {
     using G = TileGeo<NT>;
-    constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX;
+    constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX, NP = G::NP;
     __shared__ __attribute__((aligned(16))) double sX[2 * 16 * PX];
+    __shared__ __attribute__((aligned(16))) double sP[2 * 4 * TPW * 2 * 64 * 2];
+    __shared__ __attribute__((aligned(16))) double sO[2 * 16]; // observation (or symbol) of every row, [slot][4 q + r]
+    __shared__ __attribute__((aligned(16))) double sA[2 * 4 * TPW * 2 * 64 * 2]; // alpha_{t-1} rows, laid out like sP
+    __shared__ __attribute__((aligned(16))) int sEx[2 * 16];  // exponent the forward pass removed at t, [slot][4 q + r]
     __shared__ int sE[64];
     __shared__ double sS[64];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool matrix = wid < 4;
+    const int w = wid & 3;
     const int s = lane & 15, q = lane >> 4;
-    const int n = FULL ? 16 * NT : m.n;
+    const int n = FULL ? NP : m.n;
 
-    // ---- my four rows: step us of the tile is time ttop - us of the row ------------------------
-    int seg[4], nwarm[4], nst[4], trj[4], nlast[4];
-    int64_t gtop[4]; // global step index of time ttop
-    int ttop[4];     // (time inside the trajectory; trajectories of up to 2^31 steps)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + q + 4 * r];
-        seg[r] = sgi;
-        nwarm[r] = 0;
-        nst[r] = 0;
-        gtop[r] = 0;
-        ttop[r] = 0;
-        trj[r] = 0;
+    // ---- the tile's rows: step us of the tile is time ttop - us of the row.  One lane per row works
+    // the numbers out and leaves them in LDS; the matrix wavefronts only read them in the general
+    // steps (their registers are needed elsewhere), the stream wavefronts keep their four rows'.
+    __shared__ int sMeta[16 * 8]; // per row: seg, nwarm, nst, trj, ttop, (pad), gtop lo, gtop hi
+    if (tid < 16) {
+        const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + tid];
+        int v_nwarm = 0, v_nst = 0, v_trj = 0, v_ttop = 0;
+        int64_t v_gtop = 0;
         if (sgi >= 0 && sg.len[sgi] > 0) {
             const int k = sg.traj[sgi];
             const int64_t o0 = off[k], T = off[k + 1] - o0, t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
             const int64_t te = (t1 - 1 + sg.W < T - 1) ? t1 - 1 + sg.W : T - 1;
-            nwarm[r] = t1 < T ? (int)(te - t1) + 1 : 0;
-            nst[r] = nwarm[r] + (int)(t1 - t0);
-            ttop[r] = (int)(t1 - 1 + nwarm[r]);
-            gtop[r] = o0 + ttop[r];
-            trj[r] = k;
+            v_nwarm = t1 < T ? (int)(te - t1) + 1 : 0;
+            v_nst = v_nwarm + (int)(t1 - t0);
+            v_ttop = (int)(t1 - 1 + v_nwarm);
+            v_gtop = o0 + v_ttop;
+            v_trj = k;
         }
-        nlast[r] = nst[r] > 0 ? nst[r] - 1 : 0;
+        int *mrow = sMeta + 8 * tid;
+        mrow[0] = sgi;
+        mrow[1] = v_nwarm;
+        mrow[2] = v_nst;
+        mrow[3] = v_trj;
+        mrow[4] = v_ttop;
+        mrow[5] = 0;
+        mrow[6] = (int)(v_gtop & 0xffffffffll);
+        mrow[7] = (int)(v_gtop >> 32);
     }
-    const int nmax = tile_all_max(max(max(nst[0], nst[1]), max(nst[2], nst[3])));
-    const int nstmin = tile_all_min(min(min(nst[0], nst[1]), min(nst[2], nst[3])));
-    const int emin = tile_all_min(min(min(nwarm[0], nwarm[1]), min(nwarm[2], nwarm[3])));
-    const int emax = tile_all_max(max(max(nwarm[0], nwarm[1]), max(nwarm[2], nwarm[3])));
+    __syncthreads();
+    // (volatile: these reads must stay where they are written -- hoisted out of the loops they would
+    // occupy the registers this exists to free)
+    auto meta = [&](int r, int k) __attribute__((always_inline)) {
+        return const_cast<const volatile int *>(sMeta)[8 * (q + 4 * r) + k];
+    };
+    auto meta_gtop = [&](int r) __attribute__((always_inline)) {
+        return (int64_t)(((uint64_t)(uint32_t)meta(r, 7) << 32) | (uint32_t)meta(r, 6));
+    };
+    int nmax = 0, nstmin = 1 << 30, emin = 1 << 30, emax = 0;
+    for (int rho = 0; rho < 16; ++rho) {
+        const int vw = sMeta[8 * rho + 1], vn = sMeta[8 * rho + 2];
+        nmax = max(nmax, vn);
+        nstmin = min(nstmin, vn);
+        emin = min(emin, vw);
+        emax = max(emax, vw);
+    }
     // Iteration us does the back half of step us and the front half of step us + 1.
     // [0, g1): both are warm-up steps of every row, and none reads alpha yet (also not four steps
     // ahead); [g2, g3): both are main-part steps of every row (entered, before the last step, t > 0
@@ -513,26 +646,195 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
     const int g2 = min((emax + 1 + 3) & ~3, g4);
     const int g3 = min(max(g2, max(nstmin - 2 - TILE_PF, 0) & ~3), g4);
 
-    // ---- the model: my blocks of A^T (B operand of the beta product) --------------------------
-    double Breg[TPW * KK];
-    double mu_j[TPW], ga_j[TPW], gb_j[TPW];
     bool real[TPW];
-    int64_t abase[TPW][4]; // element index of (time ttop, my state) in a [step][n] array
+#pragma unroll
+    for (int c = 0; c < TPW; ++c)
+        real[c] = (w + 4 * c < NT) && (FULL || 16 * (w + 4 * c) + s < n);
+    // which steps need the sums over all states (both roles take the barriers of those exchanges)
+    auto any_enter_at = [&](int us) __attribute__((always_inline)) {
+        bool a = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            a |= us == meta(r, 1) && meta(r, 2) > 0;
+        return (bool)__any(a); // (every wavefront holds all 16 rows: uniform over the workgroup)
+    };
+    auto any_last_at = [&](int us) __attribute__((always_inline)) {
+        bool a = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            a |= us == meta(r, 2) - 1 && meta(r, 4) - us > 0;
+        return (bool)__any(a);
+    };
+    // groups [lo, hi) in mode mc; the last group of a phase takes the general path (its last
+    // iteration does the front half of the next phase's first step) and fetches for it
+    auto run = [&](auto &&step, int lo, int hi, auto mc) __attribute__((always_inline)) {
+        int us = lo;
+        for (; us + 8 <= hi; us += 4) {
+            step(us, tile_ic<0>{}, mc, mc);
+            step(us + 1, tile_ic<1>{}, mc, mc);
+            step(us + 2, tile_ic<2>{}, mc, mc);
+            step(us + 3, tile_ic<3>{}, mc, mc);
+        }
+        for (; us + 4 <= hi; us += 4) {
+            step(us, tile_ic<0>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
+            step(us + 1, tile_ic<1>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
+            step(us + 2, tile_ic<2>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
+            step(us + 3, tile_ic<3>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
+        }
+    };
+
+    if (!matrix) {
+        // ================= stream wavefronts: emission rows and observations two steps ahead ======
+        int nwarm[4], nst[4], nlast[4], ttop[4];
+        int64_t gtop[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            nwarm[r] = meta(r, 1);
+            nst[r] = meta(r, 2);
+            ttop[r] = meta(r, 4);
+            gtop[r] = meta_gtop(r);
+            nlast[r] = nst[r] > 0 ? nst[r] - 1 : 0;
+        }
+        double mu_j[TPW], ga_j[TPW], gb_j[TPW];
+        int64_t abase[TPW][4]; // element index of (time ttop, my state) in a [step][n] array
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) {
+            const int i = 16 * (w + 4 * c) + s;
+            mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[i] : 0.0;
+            ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[i] : 0.0;
+            gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[i] : 1.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                abase[c][r] = gtop[r] * n + i;
+        }
+        auto loadE = [&](TileIn<KIND, TPW> &in, int us) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int uu = min(us, nlast[r]);
+                const int64_t g = gtop[r] - uu; // global index of time t
+                if constexpr (KIND == EMIT_GAUSS)
+                    in.o[r] = static_cast<const double *>(obs_rm)[g];
+                else if constexpr (KIND == EMIT_DISC)
+                    in.sym[r] = static_cast<const int32_t *>(obs_rm)[g];
+                else {
+#pragma unroll
+                    for (int c = 0; c < TPW; ++c)
+                        in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[abase[c][r] - (int64_t)uu * n] : 0.0;
+                }
+            }
+        };
+        auto emit_to_lds = [&](const TileIn<KIND, TPW> &in, int slot) __attribute__((always_inline)) {
+            double p[TPW][4];
+            tile_emit4<NT, KIND, TPW>(m, in, w, s, real, mu_j, ga_j, gb_j, p);
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) {
+                *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 0, lane)]) = tile_d2{p[c][0], p[c][1]};
+                *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 1, lane)]) = tile_d2{p[c][2], p[c][3]};
+            }
+            if (w == 0 && s == 0) { // the rows' observations for the statistics: position 4 q + r
+                if constexpr (KIND == EMIT_GAUSS) {
+                    *reinterpret_cast<tile_d2 *>(&sO[slot * 16 + 4 * q]) = tile_d2{in.o[0], in.o[1]};
+                    *reinterpret_cast<tile_d2 *>(&sO[slot * 16 + 4 * q + 2]) = tile_d2{in.o[2], in.o[3]};
+                } else if constexpr (KIND == EMIT_DISC) {
+                    int *so = reinterpret_cast<int *>(sO);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        so[slot * 16 + 4 * q + r] = in.sym[r];
+                }
+            }
+        };
+        // alpha of time t - 1 and the exponent removed at t (what the back half of step us consumes)
+        struct AIn {
+            double ap[TPW][4];
+            int ex[4];
+        };
+        auto loadA = [&](AIn &in, int us) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int uu = min(us, nlast[r]);
+                const int t = ttop[r] - uu;
+                const int64_t un = (int64_t)uu * n;
+                // alpha_{t-1} from the last warm-up step on (it becomes alpha_t of the first main step)
+                const bool wanta = us + 1 >= nwarm[r] && us < nst[r] && t > 0;
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    in.ap[c][r] = (wanta && real[c]) ? alpha_rm[abase[c][r] - un - n] : 0.0;
+                in.ex[r] = (us >= nwarm[r] && us < nst[r] && (t & 3) == 3) ? exps[gtop[r] - uu] : 0;
+            }
+        };
+        auto a_to_lds = [&](const AIn &in, int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) {
+                *reinterpret_cast<tile_d2 *>(&sA[tile_p_index<TPW>(slot, w, c, 0, lane)]) = tile_d2{in.ap[c][0], in.ap[c][1]};
+                *reinterpret_cast<tile_d2 *>(&sA[tile_p_index<TPW>(slot, w, c, 1, lane)]) = tile_d2{in.ap[c][2], in.ap[c][3]};
+            }
+            if (w == 0 && s == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sEx[slot * 16 + 4 * q + r] = in.ex[r];
+            }
+        };
+        TileIn<KIND, TPW> ringE[TILE_PF];
+        AIn ringA[TILE_PF];
+#pragma unroll
+        for (int u = 0; u < TILE_PF; ++u) {
+            loadE(ringE[u], u);
+            loadA(ringA[u], u);
+        }
+        emit_to_lds(ringE[0], 0);
+        loadE(ringE[0], TILE_PF);
+        emit_to_lds(ringE[1], 1);
+        loadE(ringE[1], 1 + TILE_PF);
+        a_to_lds(ringA[0], 0);
+        loadA(ringA[0], TILE_PF);
+        __syncthreads(); // (the emission rows of steps 0 and 1, alpha for step 0 are in LDS)
+        if (any_enter_at(0)) {
+            __syncthreads();
+            __syncthreads();
+        }
+        __syncthreads(); // (end of the prologue)
+        auto step = [&](int us, auto uc, auto mc, auto) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
+            if constexpr (MODE == TM_GEN) { // the barriers of the matrix wavefronts' exchanges
+                if (any_last_at(us)) {
+                    __syncthreads();
+                    __syncthreads();
+                }
+                if (any_enter_at(us + 1)) {
+                    __syncthreads();
+                    __syncthreads();
+                }
+            }
+            // the emission row and the observations of step us + 2, the loads of four steps further
+            emit_to_lds(ringE[(u + 2) & 3], u & 1);
+            loadE(ringE[(u + 2) & 3], us + 2 + TILE_PF);
+            // alpha / exponent for the back half of step us + 1
+            a_to_lds(ringA[(u + 1) & 3], (u + 1) & 1);
+            loadA(ringA[(u + 1) & 3], us + 1 + TILE_PF);
+            __syncthreads();
+        };
+        run(step, 0, g1, tile_ic<TM_WARM>{});
+        run(step, g1, g2, tile_ic<TM_GEN>{});
+        run(step, g2, g3, tile_ic<TM_MAIN>{});
+        run(step, g3, g4, tile_ic<TM_GEN>{});
+        __syncthreads(); // (the gamma mass check of the matrix wavefronts)
+        __syncthreads();
+        return;
+    }
+
+    // ================= matrix wavefronts ==========================================================
+    __builtin_amdgcn_s_setprio(3); // (the serial chain runs here, see k_tile_fwd)
+    double Breg[TPW * KK]; // my blocks of A^T (B operand of the beta product)
+    double mu_j[TPW];
 #pragma unroll
     for (int c = 0; c < TPW; ++c) {
         const int i = 16 * (w + 4 * c) + s; // my state: row i of A
-        real[c] = (w + 4 * c < NT) && (FULL || i < n);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            const int j = 4 * kk + q;
+            const int j = q * KK + kk;
             Breg[c * KK + kk] = (real[c] && (FULL || j < n)) ? m.A[(int64_t)i * n + j] : 0.0;
         }
         mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[i] : 0.0;
-        ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[i] : 0.0;
-        gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[i] : 1.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            abase[c][r] = gtop[r] * n + i;
     }
     int xw[4], xq[4];
 #pragma unroll
@@ -540,7 +842,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
         xw[r] = tile_prow(q + 4 * r) * PX;
         xq[r] = xw[r] + s; // xi operand: row q + 4 r, column 16 J + s
     }
-    const int xr = tile_prow(s) * PX + q;
+    const int xr = tile_prow(s) * PX + q * KK;
 
     // xi accumulators: C'[16 (w + 4 c) .., 16 J ..]
     wide_d4 Cacc[XIG ? 1 : TPW][XIG ? 1 : NT];
@@ -565,79 +867,41 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
                     mytab[(int64_t)(16 * (w + 4 * c) + s) * m.M + z] = 0.0;
     }
 
-    // what one step reads: the observation of time t (ringE; consumed two iterations before the
-    // rest: the emission row is computed ahead), alpha of time t - 1 and the exponent removed at t (ringA)
+    // alpha of time t - 1 and the exponent removed at t: from the LDS slot the stream wavefronts filled
     struct AIn {
         double ap[TPW][4];
         int ex[4];
     };
-    auto loadE = [&](TileIn<KIND, TPW> &in, int us) __attribute__((always_inline)) {
+    auto fetch_a = [&](int slot, AIn &in) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int uu = min(us, nlast[r]);
-            const int64_t g = gtop[r] - uu; // global index of time t
-            if constexpr (KIND == EMIT_GAUSS)
-                in.o[r] = static_cast<const double *>(obs_rm)[g];
-            else if constexpr (KIND == EMIT_DISC)
-                in.sym[r] = static_cast<const int32_t *>(obs_rm)[g];
-            else {
-#pragma unroll
-                for (int c = 0; c < TPW; ++c)
-                    in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[abase[c][r] - (int64_t)uu * n] : 0.0;
-            }
+        for (int c = 0; c < TPW; ++c) {
+            const tile_d2 lo = *reinterpret_cast<const tile_d2 *>(&sA[tile_p_index<TPW>(slot, w, c, 0, lane)]);
+            const tile_d2 hi = *reinterpret_cast<const tile_d2 *>(&sA[tile_p_index<TPW>(slot, w, c, 1, lane)]);
+            in.ap[c][0] = lo[0];
+            in.ap[c][1] = lo[1];
+            in.ap[c][2] = hi[0];
+            in.ap[c][3] = hi[1];
         }
+        typedef int tile_i4 __attribute__((ext_vector_type(4)));
+        const tile_i4 e = *reinterpret_cast<const tile_i4 *>(&sEx[slot * 16 + 4 * q]);
+        in.ex[0] = e[0];
+        in.ex[1] = e[1];
+        in.ex[2] = e[2];
+        in.ex[3] = e[3];
     };
-    auto loadA = [&](AIn &in, int us, auto lm) __attribute__((always_inline)) {
-        constexpr int LM = decltype(lm)::value;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if constexpr (LM == TM_WARM) {
-#pragma unroll
-                for (int c = 0; c < TPW; ++c)
-                    in.ap[c][r] = 0.0;
-                in.ex[r] = 0;
-            } else if constexpr (LM == TM_MAIN) {
-                const int64_t un = (int64_t)us * n;
-#pragma unroll
-                for (int c = 0; c < TPW; ++c)
-                    in.ap[c][r] = (FULL || real[c]) ? alpha_rm[abase[c][r] - un - n] : 0.0;
-                const int e = exps[gtop[r] - us];
-                in.ex[r] = ((ttop[r] - us) & 3) == 3 ? e : 0;
-            } else {
-                const int uu = min(us, nlast[r]);
-                const int t = ttop[r] - uu;
-                const int64_t un = (int64_t)uu * n;
-                // alpha_{t-1} from the last warm-up step on (it becomes alpha_t of the first main step)
-                const bool wanta = us + 1 >= nwarm[r] && us < nst[r] && t > 0;
-#pragma unroll
-                for (int c = 0; c < TPW; ++c)
-                    in.ap[c][r] = (wanta && real[c]) ? alpha_rm[abase[c][r] - un - n] : 0.0;
-                in.ex[r] = (us >= nwarm[r] && us < nst[r] && (t & 3) == 3) ? exps[gtop[r] - uu] : 0;
-            }
-        }
-    };
-    TileIn<KIND, TPW> ringE[TILE_PF];
-    AIn ringA[TILE_PF];
-#pragma unroll
-    for (int u = 0; u < TILE_PF; ++u) {
-        loadE(ringE[u], u);
-        loadA(ringA[u], u, tile_ic<TM_GEN>{});
-    }
 
-    // state of my rows
-    double beta[TPW][4], acur[TPW][4];
-    double rS0[4] = {0.0, 0.0, 0.0, 0.0}, mass[4] = {0.0, 0.0, 0.0, 0.0};
-    int cg[4] = {0, 0, 0, 0};
+    // state of my rows: beta; fcur = 1 / (S0 2^(exponents removed since the row entered its main part)),
+    // the factor that normalises alpha_t o beta_t to gamma_t (0 outside the main part)
+    double beta[TPW][4];
+    double fcur[4] = {0.0, 0.0, 0.0, 0.0}, mass = 0.0;
 #pragma unroll
     for (int c = 0; c < TPW; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r)
             beta[c][r] = real[c] ? 1.0 / (double)n : 0.0; // _hidden.c:79-88 (any scale)
-            // rows without a warm-up (end of the trajectory) start in the main part: alpha_{T-1}
-            acur[c][r] = (nst[r] > 0 && nwarm[r] == 0 && real[c]) ? alpha_rm[abase[c][r]] : 0.0;
-        }
     unsigned int trouble = 0u; // (bits: 4 S0, 8 entry normaliser, 16 a vector below 2^-900, 32 gamma mass)
-    // sum over all states of v (my states, my four rows), exchanged through sS: two barriers
+    // sum over all states of v (my states, my four rows), exchanged through sS: two barriers (which
+    // the stream wavefronts take as well)
     auto rows_sum = [&](const double (&v)[4], double (&out)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -654,27 +918,22 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
         __syncthreads();
     };
 
-    // emission row / observation of the step whose front half comes next
-    double pcur[TPW][4];
-    TileIn<KIND, TPW> ecur;
-
-    // front half of step us (time t): [a row enters its main part: normaliser S0] ; x = p_t o beta_t
-    // into LDS buffer us & 1.  Returns through `fg` the gamma factors of the step.
-    auto front_chain = [&](int us, auto uc, auto mc, double (&fg)[4], bool (&mainr)[4]) __attribute__((always_inline)) {
+    // front half of step us (time t), the chain part: [a row enters its main part: normaliser S0] ;
+    // x = p_t o beta_t into LDS buffer us & 1; the gamma factors of the step
+    auto front_chain = [&](int us, auto uc, auto mc, double (&fg)[4], bool (&mainr)[4],
+                           const tile_d2 (&pl)[TPW][2], const double (&acur)[TPW][4]) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             mainr[r] = MODE == TM_MAIN;
         if constexpr (MODE == TM_GEN) {
-            bool enter[4], any_enter = false;
+            bool enter[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                mainr[r] = us >= nwarm[r] && us < nst[r];
-                enter[r] = us == nwarm[r] && nst[r] > 0;
-                any_enter |= enter[r];
+                mainr[r] = us >= meta(r, 1) && us < meta(r, 2);
+                enter[r] = us == meta(r, 1) && meta(r, 2) > 0;
             }
-            any_enter = __any(any_enter); // (every wavefront holds all 16 rows: uniform over the workgroup)
-            if (any_enter) {
+            if (any_enter_at(us)) {
                 // the warm-up's beta for the boundary check, and the normaliser of the whole
                 // segment, S0 = sum_j alpha_t*[j] beta_t*[j]
                 double g[4] = {0.0, 0.0, 0.0, 0.0}, S0[4];
@@ -683,34 +942,35 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         g[r] += acur[c][r] * beta[c][r];
-                        if (enter[r] && nwarm[r] > 0 && real[c])
-                            b_exit[(int64_t)seg[r] * n + 16 * (w + 4 * c) + s] = beta[c][r];
+                        if (enter[r] && meta(r, 1) > 0 && real[c])
+                            b_exit[(int64_t)meta(r, 0) * n + 16 * (w + 4 * c) + s] = beta[c][r];
                     }
                 rows_sum(g, S0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (enter[r]) {
                         trouble |= (!(S0[r] >= 0x1p-959) || !(S0[r] < 0x1p1000)) ? 4u : 0u;
-                        rS0[r] = fast_rcp(S0[r]);
-                        cg[r] = 0;
+                        fcur[r] = fast_rcp(S0[r]);
                     }
             }
         }
         double *Xn = sX + (u & 1) * 16 * PX;
 #pragma unroll
         for (int c = 0; c < TPW; ++c)
-            if (w + 4 * c < NT)
+            if (NT % 4 == 0 || w + 4 * c < NT)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    Xn[xw[r] + 16 * (w + 4 * c) + s] = pcur[c][r] * beta[c][r];
+                    Xn[xw[r] + 16 * (w + 4 * c) + s] = pl[c][r >> 1][r & 1] * beta[c][r];
         if constexpr (MODE != TM_WARM) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                fg[r] = mainr[r] ? ldexp(rS0[r], -cg[r]) : 0.0;
+                fg[r] = mainr[r] ? fcur[r] : 0.0;
         }
     };
     // ... and off the chain: gamma_t and the emission statistics of the rows in their main part
-    auto front_stats = [&](int us, auto mc, const double (&fg)[4], const bool (&mainr)[4]) __attribute__((always_inline)) {
+    // (ol: the observations of the step, position r of my lane row)
+    auto front_stats = [&](int us, auto mc, const double (&fg)[4], const bool (&mainr)[4],
+                           const tile_d2 (&ol)[2], const double (&acur)[TPW][4]) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mc)::value;
         if constexpr (MODE != TM_WARM) {
             const int64_t usn = (int64_t)us * n;
@@ -720,66 +980,71 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double gam = acur[c][r] * beta[c][r] * fg[r];
-                    mass[r] += gam;
+                    mass += gam;
                     sgm[c] += gam;
                     if constexpr (KIND == EMIT_GAUSS) {
-                        const double d = ecur.o[r] - mu_j[c];
+                        const double d = ol[r >> 1][r & 1] - mu_j[c];
                         const double gd = gam * d;
                         sd[c] += gd;
                         sdd[c] = fma(gd, d, sdd[c]);
                     }
-                    if constexpr (KIND == EMIT_DISC)
-                        if (real[c] && mainr[r])
-                            mytab[(int64_t)j * m.M + ecur.sym[r]] += gam;
+                    if constexpr (KIND == EMIT_DISC) {
+                        if (real[c] && mainr[r]) {
+                            const int sym = reinterpret_cast<const int *>(&ol[0])[r];
+                            mytab[(int64_t)j * m.M + sym] += gam;
+                        }
+                    }
                     if (real[c] && mainr[r]) {
                         if (gamma_rm)
-                            gamma_rm[abase[c][r] - usn] = gam;
-                        if (MODE == TM_GEN && ttop[r] - us == 0)
-                            gamma0[(int64_t)trj[r] * n + j] = gam;
+                            gamma_rm[meta_gtop(r) * n + j - usn] = gam;
+                        if constexpr (MODE == TM_GEN)
+                            if (meta(r, 4) - us == 0)
+                                gamma0[(int64_t)meta(r, 3) * n + j] = gam;
                     }
                 }
             }
         }
     };
+    // emission row / observations of a step from the LDS slot the stream wavefronts filled
+    auto fetch_p = [&](int slot, tile_d2 (&pl)[TPW][2], tile_d2 (&ol)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) {
+            pl[c][0] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 0, lane)]);
+            pl[c][1] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 1, lane)]);
+        }
+        if constexpr (KIND == EMIT_GAUSS) {
+            ol[0] = *reinterpret_cast<const tile_d2 *>(&sO[slot * 16 + 4 * q]);
+            ol[1] = *reinterpret_cast<const tile_d2 *>(&sO[slot * 16 + 4 * q + 2]);
+        } else if constexpr (KIND == EMIT_DISC) {
+            ol[0] = *reinterpret_cast<const tile_d2 *>(reinterpret_cast<const int *>(sO) + slot * 16 + 4 * q);
+            ol[1] = tile_d2{0.0, 0.0};
+        } else {
+            ol[0] = ol[1] = tile_d2{0.0, 0.0};
+        }
+    };
 
+    __syncthreads(); // (the emission rows of steps 0 and 1 are in LDS)
     // prologue: the front half of step 0
     {
-        tile_emit4<NT, KIND, TPW>(m, ringE[0], w, s, real, mu_j, ga_j, gb_j, pcur);
-        ecur = ringE[0];
-        loadE(ringE[0], TILE_PF);
-        double fg[4];
+        tile_d2 pl[TPW][2], ol[2];
+        double fg[4] = {0.0, 0.0, 0.0, 0.0};
         bool mainr[4];
-        front_chain(0, tile_ic<0>{}, tile_ic<TM_GEN>{}, fg, mainr);
-        front_stats(0, tile_ic<TM_GEN>{}, fg, mainr);
-        // the emission row of step 1
-        tile_emit4<NT, KIND, TPW>(m, ringE[1], w, s, real, mu_j, ga_j, gb_j, pcur);
-        ecur = ringE[1];
-        loadE(ringE[1], 1 + TILE_PF);
+        // rows without a warm-up (end of the trajectory) start in the main part: alpha_{T-1}
+        double a0[TPW][4];
+#pragma unroll
+        for (int c = 0; c < TPW; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                a0[c][r] = (meta(r, 2) > 0 && meta(r, 1) == 0 && real[c])
+                               ? alpha_rm[meta_gtop(r) * n + 16 * (w + 4 * c) + s] : 0.0;
+        fetch_p(0, pl, ol);
+        front_chain(0, tile_ic<0>{}, tile_ic<TM_GEN>{}, fg, mainr, pl, a0);
+        front_stats(0, tile_ic<TM_GEN>{}, fg, mainr, ol, a0);
         __syncthreads();
     }
 
     auto step = [&](int us, auto uc, auto mc, auto lc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
-        const AIn in = ringA[u];
-        loadA(ringA[u], us + TILE_PF, lc);
-        // ---- back half of step us: beta_{t-1} (raw) = A (p_t o beta_t) ----------------------------
-        const double *X = sX + (u & 1) * 16 * PX;
-        wide_d4 acc[TPW];
-        {
-            // (all operand reads first: issued one pair of matrix instructions ahead of its use, every
-            // read's latency sat in the dependent chain -- 168 instead of 128 cycles per pair)
-            double av[KK];
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-                av[kk] = X[xr + 4 * kk];
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                for (int c = 0; c < TPW; ++c)
-                    if (NT % 4 == 0 || w + 4 * c < NT)
-                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], Breg[c * KK + kk],
-                                                                      kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
-        }
         bool mainr[4], lastr[4];
         int tt[4];
 #pragma unroll
@@ -788,33 +1053,47 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
             lastr[r] = false;
             tt[r] = 1;
         }
-        bool any_last = false;
         if constexpr (MODE == TM_GEN) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                mainr[r] = us >= nwarm[r] && us < nst[r];
-                tt[r] = ttop[r] - us;
-                lastr[r] = us == nst[r] - 1 && tt[r] > 0; // the transition into the segment
-                any_last |= lastr[r];
+                mainr[r] = us >= meta(r, 1) && us < meta(r, 2);
+                tt[r] = meta(r, 4) - us;
+                lastr[r] = us == meta(r, 2) - 1 && tt[r] > 0; // the transition into the segment
             }
-            any_last = __any(any_last);
         }
-        // factors of xi for the transition t-1 -> t
-        int cx[4] = {0, 0, 0, 0};
-        double fx[4] = {0.0, 0.0, 0.0, 0.0};
+        AIn in;
+        fetch_a(u & 1, in);
+        // ---- back half of step us: beta_{t-1} (raw) = A (p_t o beta_t) ----------------------------
+        const double *X = sX + (u & 1) * 16 * PX;
+        tile_d2 av[KK / 2];
+#pragma unroll
+        for (int k2 = 0; k2 < KK / 2; ++k2)
+            av[k2] = *reinterpret_cast<const tile_d2 *>(X + xr + 2 * k2);
+        tile_d2 pl[TPW][2], ol[2];
+        fetch_p((u + 1) & 1, pl, ol); // emission row / observations of step us + 1
+        wide_d4 acc[TPW];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int c = 0; c < TPW; ++c)
+                if (NT % 4 == 0 || w + 4 * c < NT)
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk >> 1][kk & 1], Breg[c * KK + kk],
+                                                                  kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+        // factors of xi for the transition t-1 -> t: the exponent the forward pass removed at t comes off
+        double fx[4] = {0.0, 0.0, 0.0, 0.0}, fnx[4] = {0.0, 0.0, 0.0, 0.0};
         if constexpr (MODE != TM_WARM) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                cx[r] = cg[r] + in.ex[r];
-                fx[r] = (mainr[r] && tt[r] > 0) ? ldexp(rS0[r], -cx[r]) : 0.0;
+                fnx[r] = ldexp(fcur[r], -in.ex[r]);
+                fx[r] = (mainr[r] && tt[r] > 0) ? fnx[r] : 0.0;
             }
             if constexpr (MODE == TM_GEN) {
-                if (any_last) {
+                if (any_last_at(us)) {
                     // alpha_{t0-1} belongs to the neighbouring segment's chain: its own normaliser
                     double g[4] = {0.0, 0.0, 0.0, 0.0}, SL[4];
 #pragma unroll
                     for (int c = 0; c < TPW; ++c)
-                        if (w + 4 * c < NT)
+                        if (NT % 4 == 0 || w + 4 * c < NT)
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 g[r] += in.ap[c][r] * acc[c][r];
@@ -835,7 +1114,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
             for (int r = 0; r < 4; ++r) {
                 const int rho = q + 4 * r;
                 E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
-                trouble |= ((MODE != TM_GEN || us < nst[r]) && E[r] < WIDE_TROUBLE_EXP) ? 16u : 0u;
+                trouble |= ((MODE != TM_GEN || us < meta(r, 2)) && E[r] < WIDE_TROUBLE_EXP) ? 16u : 0u;
             }
         }
         int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
@@ -843,27 +1122,21 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
         for (int c = 0; c < TPW; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double b = (w + 4 * c < NT) ? acc[c][r] : 0.0;
+                double b = (NT % 4 == 0 || w + 4 * c < NT) ? acc[c][r] : 0.0;
                 if constexpr (u == 3)
                     b = ldexp(b, -E[r]);
                 if constexpr (u == 2)
                     pm[r] = max(pm[r], b > 0.0 ? exponent_of(b) : -(1 << 28));
                 if constexpr (MODE == TM_GEN)
-                    if (us == nst[r] - 1 && real[c] && tt[r] > 0)
-                        b_entry[(int64_t)seg[r] * n + 16 * (w + 4 * c) + s] = b; // beta one step before the segment
+                    if (lastr[r] && real[c])
+                        b_entry[(int64_t)meta(r, 0) * n + 16 * (w + 4 * c) + s] = b; // beta one step before the segment
                 beta[c][r] = b;
-                if constexpr (MODE != TM_WARM)
-                    acur[c][r] = in.ap[c][r];
             }
-        if constexpr (MODE != TM_WARM) {
+        if constexpr (MODE != TM_WARM) { // ... and the exponent just removed from beta goes on
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                cg[r] = cx[r] - E[r];
+                fcur[r] = u == 3 ? ldexp(fnx[r], E[r]) : fnx[r];
         }
-        // ---- front half of step us + 1, the chain part: x' into the other buffer ------------------
-        double fg[4] = {0.0, 0.0, 0.0, 0.0};
-        bool mainn[4];
-        front_chain(us + 1, tile_ic<(u + 1) & 3>{}, mc, fg, mainn);
         if constexpr (u == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -872,6 +1145,10 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
                     sE[16 * w + q + 4 * r] = mx;
             }
         }
+        // ---- front half of step us + 1, the chain part: x' into the other buffer ------------------
+        double fg[4] = {0.0, 0.0, 0.0, 0.0};
+        bool mainn[4];
+        front_chain(us + 1, tile_ic<(u + 1) & 3>{}, mc, fg, mainn, pl, in.ap);
         __builtin_amdgcn_sched_barrier(0);
         // ---- off the chain: xi of the transition t-1 -> t -----------------------------------------
         if constexpr (MODE != TM_WARM) {
@@ -884,7 +1161,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
                         xb[J] = X[xq[r] + 16 * J];
 #pragma unroll
                     for (int c = 0; c < TPW; ++c)
-                        if (w + 4 * c < NT) {
+                        if (NT % 4 == 0 || w + 4 * c < NT) {
                             const double aw = in.ap[c][r] * fx[r];
 #pragma unroll
                             for (int J = 0; J < NT; ++J)
@@ -895,52 +1172,31 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
                 const int64_t usn = (int64_t)us * n;
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
-                    if (w + 4 * c < NT)
+                    if (NT % 4 == 0 || w + 4 * c < NT)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (real[c] && mainr[r] && tt[r] > 0)
-                                Wg[abase[c][r] - usn - n] = X[xw[r] + 16 * (w + 4 * c) + s] * fx[r];
+                                Wg[meta_gtop(r) * n + 16 * (w + 4 * c) + s - usn - n] = X[xw[r] + 16 * (w + 4 * c) + s] * fx[r];
             }
         }
-        front_stats(us + 1, mc, fg, mainn);
-        // the emission row of step us + 2, the observation loads of four steps further
-        tile_emit4<NT, KIND, TPW>(m, ringE[(u + 2) & 3], w, s, real, mu_j, ga_j, gb_j, pcur);
-        ecur = ringE[(u + 2) & 3];
-        loadE(ringE[(u + 2) & 3], us + 2 + TILE_PF);
-        __builtin_amdgcn_sched_barrier(0);
+        front_stats(us + 1, mc, fg, mainn, ol, in.ap);
         __syncthreads();
     };
-    // groups [lo, hi) in mode mc; the last group of a phase takes the general path (its last
-    // iteration does the front half of the next phase's first step) and fetches for it
-    auto run = [&](int lo, int hi, auto mc) __attribute__((always_inline)) {
-        int us = lo;
-        for (; us + 8 <= hi; us += 4) {
-            step(us, tile_ic<0>{}, mc, mc);
-            step(us + 1, tile_ic<1>{}, mc, mc);
-            step(us + 2, tile_ic<2>{}, mc, mc);
-            step(us + 3, tile_ic<3>{}, mc, mc);
-        }
-        for (; us + 4 <= hi; us += 4) {
-            step(us, tile_ic<0>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
-            step(us + 1, tile_ic<1>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
-            step(us + 2, tile_ic<2>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
-            step(us + 3, tile_ic<3>{}, tile_ic<TM_GEN>{}, tile_ic<TM_GEN>{});
-        }
-    };
-    run(0, g1, tile_ic<TM_WARM>{});
-    run(g1, g2, tile_ic<TM_GEN>{});
-    run(g2, g3, tile_ic<TM_MAIN>{});
-    run(g3, g4, tile_ic<TM_GEN>{});
+    run(step, 0, g1, tile_ic<TM_WARM>{});
+    run(step, g1, g2, tile_ic<TM_GEN>{});
+    run(step, g2, g3, tile_ic<TM_MAIN>{});
+    run(step, g3, g4, tile_ic<TM_GEN>{});
 
     // ---- self-check: unit gamma mass per step of every row -------------------------------------
     {
-        double tot[4];
-        rows_sum(mass, tot);
+        // (the mass of all rows of my lane row q; the wanted number likewise)
+        const double mq[4] = {mass, 0.0, 0.0, 0.0};
+        double tot[4], want = 0.0;
+        rows_sum(mq, tot);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double want = (double)(nst[r] - nwarm[r]);
-            trouble |= !(fabs(tot[r] - want) <= 1e-8 * want) ? 32u : 0u;
-        }
+        for (int r = 0; r < 4; ++r)
+            want += (double)(meta(r, 2) - meta(r, 1));
+        trouble |= !(fabs(tot[0] - want) <= 1e-8 * want) ? 32u : 0u;
         if (trouble)
             atomicOr(&flags[2], trouble);
     }
@@ -950,7 +1206,7 @@ __global__ __launch_bounds__(256, WPS) void k_tile_bwd(const WideModel m, const 
     if constexpr (!XIG) {
 #pragma unroll
         for (int c = 0; c < TPW; ++c)
-            if (w + 4 * c < NT)
+            if (NT % 4 == 0 || w + 4 * c < NT)
 #pragma unroll
                 for (int J = 0; J < NT; ++J)
 #pragma unroll

@@ -1,5 +1,6 @@
 // wide_api.hip -- host side of the 9..64-state kernel family (wide_kernels.hpp).
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -92,10 +93,29 @@ static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
 {
     const Segs sg = segs_of(c, which);
     const TilePlan tp{c->d_tile_seg[which].p, c->w_ntiles[which]};
-    hipLaunchKernelGGL((k_tile_fwd<4, KIND, 2, true>), dim3(tp.ntiles), dim3(256), 0, c->stream, m,
+    // BHMM_AMD_TILE_PROBE=1: cycles of the phases of a step (workgroup 0), printed after the pass
+    static const bool probe_on = getenv("BHMM_AMD_TILE_PROBE") != nullptr;
+    unsigned long long *probe = nullptr;
+    if (probe_on) {
+        int rc = c->d_probe.ensure(4096);
+        if (rc)
+            return rc;
+        probe = reinterpret_cast<unsigned long long *>(c->d_probe.p);
+        BHMM_HIP(hipMemsetAsync(probe, 0, 64, c->stream));
+    }
+    hipLaunchKernelGGL((k_tile_fwd<4, KIND, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p, c->d_alpha_rm.p,
-                       c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p);
+                       c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p, probe);
     BHMM_HIP(hipGetLastError());
+    if (probe_on) {
+        unsigned long long h[8];
+        BHMM_HIP(hipMemcpyAsync(h, probe, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "tile fwd probe: matrix [operands+matrix %.0f | emission row, write %.0f | barrier %.0f] "
+                        "stream [emission %.0f | store %.0f | barrier %.0f] cycles/step (%llu steps)\n",
+                (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[7],
+                (double)h[5] / h[7], (double)h[6] / h[7], h[3]);
+    }
     hipLaunchKernelGGL(k_tile_logl, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg, c->n,
                        (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
                        (const int32_t *)c->d_wePseg.p, c->d_wlogLseg.p, c->d_specres.p);
@@ -112,7 +132,7 @@ static int tile_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
     const Segs sg = segs_of(c, which);
     const TilePlan tp{c->d_tile_seg[which].p, c->w_ntiles[which]};
     double *gam = store_gamma ? c->d_gamma_ci.p : (double *)nullptr;
-    hipLaunchKernelGGL((k_tile_bwd<4, KIND, 1, true, false>), dim3(tp.ntiles), dim3(256), 0, c->stream, m,
+    hipLaunchKernelGGL((k_tile_bwd<4, KIND, true, false>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
                        (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
                        c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,

@@ -32,10 +32,10 @@ def run(tile, per_cu=1, W=None):
     r = eng.estep(*args)
     eng.sync()
     km = eng.kernel_ms_all().copy()
-    print("tile %d per_cu %d: %.2f ms  kernels(ms) %s  segs %d W %d ok/fail %d/%d dev %.2e tile_used %d careful %d"
+    print("tile %d per_cu %d: %.2f ms  kernels(ms) %s  segs %d W %d ok/fail %d/%d dev %.2e tile_used %d careful %d trouble %d"
           % (tile, per_cu, dt * 1e3, np.round(km, 3), eng.get_option("wide_segments"), eng.get_option("spec_W"),
              eng.get_option("spec_ok"), eng.get_option("spec_fail"), eng.get_option("spec_last_dev"),
-             eng.get_option("tile"), eng.get_option("careful")), flush=True)
+             eng.get_option("tile"), eng.get_option("careful"), eng.get_option("wide_trouble")), flush=True)
     eng.close()
     return r
 
