@@ -159,8 +159,9 @@ struct bhmm_ctx {
     // row-batched matrix-core recursions (tile_kernels.hpp): 16 segments per workgroup
     bool tile_enabled = true;        // option "tile" / BHMM_AMD_TILE=0
     int tile_per_cu = 1;             // tiles the segment plan aims at per compute unit (option "tile_per_cu")
-    int w_ntiles[3] = {0, 0, 0};
-    bhmm::DevBuf<int32_t> d_tile_seg[3]; // [16 * ntiles] segment of every tile row (-1: none)
+    int w_ntiles[3] = {0, 0, 0}, w_ntilesb[3] = {0, 0, 0};
+    bhmm::DevBuf<int32_t> d_tile_seg[3];  // [16 * ntiles] segment of every tile row (-1: none), forward pass
+    bhmm::DevBuf<int32_t> d_tile_segb[3]; // ... backward pass (tiles are formed per direction, plan.hpp)
     bhmm::DevBuf<int32_t> d_wexp;    // [total] exponent the forward pass removed at every step
     bhmm::DevBuf<int32_t> d_wePseg;  // [segments] ... summed over the main part of every segment
     unsigned int wide_trouble = 0;   // flag word of the last lazily scaled E-step (which self-check fired)

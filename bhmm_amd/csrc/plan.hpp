@@ -140,16 +140,29 @@ inline void plan_segments(const std::vector<int64_t> &offsets, int K, int64_t se
 }
 
 // Tiles of the row-batched kernels (tile_kernels.hpp): 16 segments per workgroup, which runs as long
-// as its longest row -- segments sorted by length (stable, longest first), empty slots -1.
-inline void plan_tiles(const SegPlan &s, std::vector<int32_t> &tile_seg)
+// as its longest row and takes its fast paths where all 16 rows are in the same phase -- so segments
+// without a warm-up in the direction of the pass (backward = false: those that start a trajectory;
+// backward = true: those that end one) get tiles of their own, and inside each class the segments are
+// sorted by length (stable, longest first).  Empty slots: -1.
+inline void plan_tiles(const SegPlan &s, const std::vector<int64_t> &offsets, bool backward,
+                       std::vector<int32_t> &tile_seg)
 {
-    std::vector<int32_t> order;
-    for (size_t i = 0; i < s.len.size(); ++i)
-        if (s.len[i] > 0)
-            order.push_back((int32_t)i);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return s.len[a] > s.len[b]; });
-    tile_seg.assign((order.size() + 15) / 16 * 16, -1);
-    std::copy(order.begin(), order.end(), tile_seg.begin());
+    tile_seg.clear();
+    for (int cls = 0; cls < 2; ++cls) {
+        std::vector<int32_t> order;
+        for (size_t i = 0; i < s.len.size(); ++i) {
+            if (s.len[i] <= 0)
+                continue;
+            const int64_t T = offsets[s.traj[i] + 1] - offsets[s.traj[i]];
+            const bool edge = backward ? s.t0[i] + s.len[i] >= T : s.t0[i] == 0;
+            if ((edge ? 0 : 1) == cls)
+                order.push_back((int32_t)i);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return s.len[a] > s.len[b]; });
+        const size_t base = tile_seg.size();
+        tile_seg.resize(base + (order.size() + 15) / 16 * 16, -1);
+        std::copy(order.begin(), order.end(), tile_seg.begin() + base);
+    }
 }
 
 // For every segment of the plan with `seglen`: the start of a segment of the twice-as-fine plan

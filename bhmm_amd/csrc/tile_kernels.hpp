@@ -224,6 +224,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
     __shared__ __attribute__((aligned(16))) double sX[2 * 16 * PX];
     __shared__ __attribute__((aligned(16))) double sP[2 * 4 * TPW * 2 * 64 * 2];
     __shared__ int sE[64];
+    __shared__ __attribute__((aligned(16))) double sObs[16 * 16]; // observations of 16 steps: [step & 15][4 q + r]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool matrix = wid < 4;
@@ -255,6 +256,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
     // (every wavefront holds all 16 rows: these are uniform over the workgroup)
     const int nmax = tile_all_max(max(max(nst[0], nst[1]), max(nst[2], nst[3])));
     const int g4 = (nmax + 3) & ~3;
+    // steps [g2, g3): every row of the tile is inside its main part
+    const int g2 = tile_all_max(max(max(r0[0], r0[1]), max(r0[2], r0[3])));
+    const int g3 = tile_all_min(min(min(nst[0], nst[1]), min(nst[2], nst[3]))) - 1;
 
     for (int e = tid; e < 16 * PX; e += TILE_THREADS)
         sX[e] = (e % PX) < n ? 1.0 / (double)n : 0.0; // warm-ups start from the uniform vector
@@ -303,7 +307,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
         for (int r = 0; r < 4; ++r)
             xw[r] = tile_prow(q + 4 * r) * PX;
         const int xr = tile_prow(s) * PX + q * KK; // my operand: KK consecutive doubles of row s
-        __syncthreads();
+        __syncthreads(); // (the stream wavefronts: first observations in LDS ...
+        __syncthreads(); //  ... first emission row in LDS)
         auto step = [&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
             const bool pr = probe && blockIdx.x == 0 && wid == 0;
@@ -408,16 +413,55 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
             }
         }
         const int sxr = tile_prow(srow) * PX + sch;
-        // what step rs reads (rows that have ended keep reading their last step)
-        auto load = [&](TileIn<KIND, TPW> &in, int rs) __attribute__((always_inline)) {
+        // ---- the observation stream.  Every vector instruction of this SIMD waits for the matrix
+        // instructions of the other wavefront (and they for it), so the stream is read ONCE per tile:
+        // wavefront 4 loads, per group of four steps, one value per (row, step) -- lane = 4 row + step --
+        // and passes them on through LDS; everybody reads the four rows of a step with two 16-byte reads.
+        const int lrow = lane >> 2, ldt = lane & 3;
+        int64_t l_ob = 0;
+        int l_last = 0;
+        if (w == 0) {
+            const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + lrow];
+            if (sgi >= 0 && sg.len[sgi] > 0) {
+                const int64_t o0 = off[sg.traj[sgi]], t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+                const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0;
+                l_ob = o0 + tw;
+                l_last = (int)(t1 - tw) - 1;
+            }
+        }
+        const int lpos = 4 * (lrow & 3) + (lrow >> 2); // row q + 4 r sits at position 4 q + r
+        auto obs_load = [&](int step) __attribute__((always_inline)) -> double {
+            const int64_t g = l_ob + min(step, l_last);
+            if constexpr (KIND == EMIT_DISC)
+                return __hiloint2double(0, static_cast<const int32_t *>(obs_rm)[g]);
+            else
+                return static_cast<const double *>(obs_rm)[g];
+        };
+        double pend = 0.0; // the group two ahead, on its way
+        if constexpr (KIND != EMIT_EXPL) {
+            if (w == 0) {
+                sObs[ldt * 16 + lpos] = obs_load(ldt);
+                sObs[(4 + ldt) * 16 + lpos] = obs_load(4 + ldt);
+                pend = obs_load(8 + ldt);
+            }
+        }
+        // what the emission row of step rs is computed from
+        auto fetch_in = [&](TileIn<KIND, TPW> &in, int rs) __attribute__((always_inline)) {
+            if constexpr (KIND == EMIT_GAUSS) {
+                const tile_d2 lo = *reinterpret_cast<const tile_d2 *>(&sObs[(rs & 15) * 16 + 4 * q]);
+                const tile_d2 hi = *reinterpret_cast<const tile_d2 *>(&sObs[(rs & 15) * 16 + 4 * q + 2]);
+                in.o[0] = lo[0];
+                in.o[1] = lo[1];
+                in.o[2] = hi[0];
+                in.o[3] = hi[1];
+            } else if constexpr (KIND == EMIT_DISC) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = min(rs, nlast[r]);
-                if constexpr (KIND == EMIT_GAUSS)
-                    in.o[r] = static_cast<const double *>(obs_rm)[ob[r] + rr];
-                else if constexpr (KIND == EMIT_DISC)
-                    in.sym[r] = static_cast<const int32_t *>(obs_rm)[ob[r] + rr];
-                else {
+                for (int r = 0; r < 4; ++r)
+                    in.sym[r] = __double2loint(sObs[(rs & 15) * 16 + 4 * q + r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = min(rs, nlast[r]);
 #pragma unroll
                     for (int c = 0; c < TPW; ++c)
                         in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[(ob[r] + rr) * n + 16 * (w + 4 * c) + s] : 0.0;
@@ -435,26 +479,28 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
             }
         };
         // alpha of step rs (in LDS buffer (rs + 1) & 1 after that step's barrier) to HBM
+        const int64_t s_abase = s_ob * n + sch;
         auto store_row = [&](int rs) __attribute__((always_inline)) {
+            const double *X = sX + ((rs + 1) & 1) * 16 * PX + sxr;
+            if (FULL && rs >= g2 && rs < g3) { // (uniform: every row of the tile in its main part)
+                double *dst = alpha_rm + s_abase + (int64_t)rs * n;
+#pragma unroll
+                for (int e = 0; e < SPL; e += 2)
+                    *reinterpret_cast<tile_d2 *>(dst + e) = *reinterpret_cast<const tile_d2 *>(X + e);
+                return;
+            }
             if (rs < 0 || rs >= s_nst)
                 return;
-            const double *X = sX + ((rs + 1) & 1) * 16 * PX + sxr;
             double *dst = nullptr;
             if (rs >= s_r0)
-                dst = alpha_rm + (s_ob + rs) * n + sch;
+                dst = alpha_rm + s_abase + (int64_t)rs * n;
             else if (rs == s_r0 - 1)
                 dst = a_entry + (int64_t)s_seg * n + sch;
             if (dst) {
-                if constexpr (FULL) {
 #pragma unroll
-                    for (int e = 0; e < SPL; e += 2)
-                        *reinterpret_cast<tile_d2 *>(dst + e) = *reinterpret_cast<const tile_d2 *>(X + e);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < SPL; ++e)
-                        if (sch + e < n)
-                            dst[e] = X[e];
-                }
+                for (int e = 0; e < SPL; ++e)
+                    if (FULL || sch + e < n)
+                        dst[e] = X[e];
             }
             if (rs == s_nst - 1) {
                 double *dx = a_exit + (int64_t)s_seg * n + sch;
@@ -464,12 +510,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
                         dx[e] = X[e];
             }
         };
-        TileIn<KIND, TPW> ring[TILE_PF];
-#pragma unroll
-        for (int u = 0; u < TILE_PF; ++u)
-            load(ring[u], u);
-        emit_to_lds(ring[0], 0);
-        load(ring[0], TILE_PF);
+        __syncthreads(); // (the first observations are in LDS)
+        {
+            TileIn<KIND, TPW> in0;
+            fetch_in(in0, 0);
+            emit_to_lds(in0, 0);
+        }
         __syncthreads();
         int eP[4] = {0, 0, 0, 0};
         unsigned int trouble = 0u; // (bit 0: a vector below 2^-900)
@@ -477,30 +523,36 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
             constexpr int u = decltype(uc)::value;
             const bool pr = probe && blockIdx.x == 0 && wid == 4;
             const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
-            // alpha of the previous step: LDS -> HBM.  First: none of this needs the fp64 pipe, which
-            // the matrix instructions of the other wavefront occupy for the first 1024 cycles of the step
+            // alpha of the previous step: LDS -> HBM
             store_row(rs - 1);
-            const TileIn<KIND, TPW> ein = ring[(u + 1) & 3];
-            load(ring[(u + 1) & 3], rs + 1 + TILE_PF);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long c1 = pr ? __builtin_readcyclecounter() : 0;
-            // the emission row of the next step
-            emit_to_lds(ein, (u + 1) & 1);
-            // bookkeeping of the exponents (one lane per row)
+            if constexpr (KIND != EMIT_EXPL && u == 0) {
+                if (w == 0) { // the observations of the group two ahead go to LDS, the next ones are fetched
+                    sObs[((rs + 8 + ldt) & 15) * 16 + lpos] = pend;
+                    pend = obs_load(rs + 12 + ldt);
+                }
+            }
+            // bookkeeping of the exponents (wavefront 5, one lane per row)
             if constexpr (u == 3) {
+                if (w == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rho = q + 4 * r;
-                    const int E = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
-                    const bool act = rs < nst[r];
-                    trouble |= (act && E < WIDE_TROUBLE_EXP) ? 1u : 0u;
-                    if (act && rs >= r0[r]) {
-                        eP[r] += E;
-                        if (w == 0 && s == 0)
-                            exps[ob[r] + rs] = E;
+                    for (int r = 0; r < 4; ++r) {
+                        const int rho = q + 4 * r;
+                        const int E = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
+                        const bool act = rs < nst[r];
+                        trouble |= (act && E < WIDE_TROUBLE_EXP) ? 1u : 0u;
+                        if (act && rs >= r0[r]) {
+                            eP[r] += E;
+                            if (s == 0)
+                                exps[ob[r] + rs] = E;
+                        }
                     }
                 }
             }
+            const unsigned long long c1 = pr ? __builtin_readcyclecounter() : 0;
+            // the emission row of the next step
+            TileIn<KIND, TPW> ein;
+            fetch_in(ein, rs + 1);
+            emit_to_lds(ein, (u + 1) & 1);
             const unsigned long long c2 = pr ? __builtin_readcyclecounter() : 0;
             __syncthreads();
             if (pr && lane == 0) {
@@ -513,7 +565,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
         };
         run(step);
         store_row(g4 - 1);
-        if (w == 0 && s == 0) {
+        if (w == 1 && s == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + q + 4 * r];
@@ -574,14 +626,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
                                                            const double *alpha_rm, const int32_t *exps,
                                                            double *gamma_rm, double *gamma0, double *part,
                                                            double *dstat, double *b_exit, double *b_entry,
-                                                           unsigned int *flags, double *Wg)
+                                                           unsigned int *flags, double *Wg, unsigned long long *probe = nullptr)
 {
     using G = TileGeo<NT>;
     constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX, NP = G::NP;
     __shared__ __attribute__((aligned(16))) double sX[2 * 16 * PX];
     __shared__ __attribute__((aligned(16))) double sP[2 * 4 * TPW * 2 * 64 * 2];
-    __shared__ __attribute__((aligned(16))) double sO[2 * 16]; // observation (or symbol) of every row, [slot][4 q + r]
-    __shared__ __attribute__((aligned(16))) double sA[2 * 4 * TPW * 2 * 64 * 2]; // alpha_{t-1} rows, laid out like sP
+    __shared__ __attribute__((aligned(16))) double sObs[16 * 16]; // observations of 16 steps: [step & 15][4 q + r]
+    __shared__ __attribute__((aligned(16))) double sAl[2 * 16 * PX]; // alpha_{t-1} tile of a step, laid out like sX
     __shared__ __attribute__((aligned(16))) int sEx[2 * 16];  // exponent the forward pass removed at t, [slot][4 q + r]
     __shared__ int sE[64];
     __shared__ double sS[64];
@@ -684,42 +736,104 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
     };
 
     if (!matrix) {
-        // ================= stream wavefronts: emission rows and observations two steps ahead ======
-        int nwarm[4], nst[4], nlast[4], ttop[4];
-        int64_t gtop[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            nwarm[r] = meta(r, 1);
-            nst[r] = meta(r, 2);
-            ttop[r] = meta(r, 4);
-            gtop[r] = meta_gtop(r);
-            nlast[r] = nst[r] > 0 ? nst[r] - 1 : 0;
-        }
+        // ================= stream wavefronts ========================================================
+        // (every vector instruction here competes with the matrix instructions for the SIMD: the
+        // observation stream is read once per tile and passed on through LDS, alpha comes in
+        // 16-byte pieces, one lane per (row, four states), and is laid out for the matrix wavefronts
+        // by the LDS -- see k_tile_fwd)
         double mu_j[TPW], ga_j[TPW], gb_j[TPW];
-        int64_t abase[TPW][4]; // element index of (time ttop, my state) in a [step][n] array
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
             const int i = 16 * (w + 4 * c) + s;
             mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[i] : 0.0;
             ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[i] : 0.0;
             gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[i] : 1.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                abase[c][r] = gtop[r] * n + i;
         }
-        auto loadE = [&](TileIn<KIND, TPW> &in, int us) __attribute__((always_inline)) {
+        auto rmeta = [&](int row, int k) __attribute__((always_inline)) { return sMeta[8 * row + k]; };
+        auto rmeta_gtop = [&](int row) __attribute__((always_inline)) {
+            return (int64_t)(((uint64_t)(uint32_t)rmeta(row, 7) << 32) | (uint32_t)rmeta(row, 6));
+        };
+        // ---- alpha_{t-1}: my row and my NP / 16 states of it
+        constexpr int SPL = NP / 16;
+        const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * SPL;
+        const int s_nwarm = rmeta(srow, 1), s_nst = rmeta(srow, 2), s_ttop = rmeta(srow, 4);
+        const int64_t s_abase = rmeta_gtop(srow) * n + sch;
+        const int sxr = tile_prow(srow) * PX + sch;
+        struct ARow {
+            double v[SPL];
+        };
+        auto loadA = [&](ARow &a, int us) __attribute__((always_inline)) {
+            // alpha_{t-1} from the last warm-up step on (it becomes alpha_t of the first main step)
+            const bool wanta = us + 1 >= s_nwarm && us < s_nst && s_ttop - us > 0;
+            const double *src = alpha_rm + s_abase - ((int64_t)us + 1) * n;
+            if constexpr (FULL) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int uu = min(us, nlast[r]);
-                const int64_t g = gtop[r] - uu; // global index of time t
-                if constexpr (KIND == EMIT_GAUSS)
-                    in.o[r] = static_cast<const double *>(obs_rm)[g];
-                else if constexpr (KIND == EMIT_DISC)
-                    in.sym[r] = static_cast<const int32_t *>(obs_rm)[g];
-                else {
+                for (int e = 0; e < SPL; e += 2) {
+                    const tile_d2 t2 = wanta ? *reinterpret_cast<const tile_d2 *>(src + e) : tile_d2{0.0, 0.0};
+                    a.v[e] = t2[0];
+                    a.v[e + 1] = t2[1];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < SPL; ++e)
+                    a.v[e] = (wanta && sch + e < n) ? src[e] : 0.0;
+            }
+        };
+        auto a_to_lds = [&](const ARow &a, int slot) __attribute__((always_inline)) {
+            double *dst = sAl + slot * 16 * PX + sxr;
+#pragma unroll
+            for (int e = 0; e < SPL; e += 2)
+                *reinterpret_cast<tile_d2 *>(dst + e) = tile_d2{a.v[e], a.v[e + 1]};
+        };
+        // ---- the exponent the forward pass removed at time t (wavefront 5, one lane per row)
+        const int xrow = lane & 15;
+        const int x_nwarm = rmeta(xrow, 1), x_nst = rmeta(xrow, 2), x_ttop = rmeta(xrow, 4);
+        const int64_t x_gtop = rmeta_gtop(xrow);
+        const int xpos = 4 * (xrow & 3) + (xrow >> 2);
+        auto loadX = [&](int us) __attribute__((always_inline)) -> int {
+            return (w == 1 && lane < 16 && us >= x_nwarm && us < x_nst && ((x_ttop - us) & 3) == 3) ? exps[x_gtop - us] : 0;
+        };
+        // ---- the observation stream (wavefront 4: lane = 4 row + step of a group of four)
+        const int lrow = lane >> 2, ldt = lane & 3;
+        const int64_t l_gtop = rmeta_gtop(lrow);
+        const int l_last = rmeta(lrow, 2) > 0 ? rmeta(lrow, 2) - 1 : 0;
+        const int lpos = 4 * (lrow & 3) + (lrow >> 2); // row q + 4 r sits at position 4 q + r
+        auto obs_load = [&](int step) __attribute__((always_inline)) -> double {
+            const int64_t g = l_gtop - min(step, l_last);
+            if constexpr (KIND == EMIT_DISC)
+                return __hiloint2double(0, static_cast<const int32_t *>(obs_rm)[g]);
+            else
+                return static_cast<const double *>(obs_rm)[g];
+        };
+        double pend = 0.0; // the group two ahead, on its way
+        if constexpr (KIND != EMIT_EXPL) {
+            if (w == 0) {
+                sObs[ldt * 16 + lpos] = obs_load(ldt);
+                sObs[(4 + ldt) * 16 + lpos] = obs_load(4 + ldt);
+                pend = obs_load(8 + ldt);
+            }
+        }
+        // what the emission row of step us is computed from
+        auto fetch_in = [&](TileIn<KIND, TPW> &in, int us) __attribute__((always_inline)) {
+            if constexpr (KIND == EMIT_GAUSS) {
+                const tile_d2 lo = *reinterpret_cast<const tile_d2 *>(&sObs[(us & 15) * 16 + 4 * q]);
+                const tile_d2 hi = *reinterpret_cast<const tile_d2 *>(&sObs[(us & 15) * 16 + 4 * q + 2]);
+                in.o[0] = lo[0];
+                in.o[1] = lo[1];
+                in.o[2] = hi[0];
+                in.o[3] = hi[1];
+            } else if constexpr (KIND == EMIT_DISC) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    in.sym[r] = __double2loint(sObs[(us & 15) * 16 + 4 * q + r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nl = meta(r, 2) > 0 ? meta(r, 2) - 1 : 0;
+                    const int64_t g = meta_gtop(r) - min(us, nl);
 #pragma unroll
                     for (int c = 0; c < TPW; ++c)
-                        in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[abase[c][r] - (int64_t)uu * n] : 0.0;
+                        in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[g * n + 16 * (w + 4 * c) + s] : 0.0;
                 }
             }
         };
@@ -731,62 +845,27 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
                 *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 0, lane)]) = tile_d2{p[c][0], p[c][1]};
                 *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 1, lane)]) = tile_d2{p[c][2], p[c][3]};
             }
-            if (w == 0 && s == 0) { // the rows' observations for the statistics: position 4 q + r
-                if constexpr (KIND == EMIT_GAUSS) {
-                    *reinterpret_cast<tile_d2 *>(&sO[slot * 16 + 4 * q]) = tile_d2{in.o[0], in.o[1]};
-                    *reinterpret_cast<tile_d2 *>(&sO[slot * 16 + 4 * q + 2]) = tile_d2{in.o[2], in.o[3]};
-                } else if constexpr (KIND == EMIT_DISC) {
-                    int *so = reinterpret_cast<int *>(sO);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        so[slot * 16 + 4 * q + r] = in.sym[r];
-                }
-            }
         };
-        // alpha of time t - 1 and the exponent removed at t (what the back half of step us consumes)
-        struct AIn {
-            double ap[TPW][4];
-            int ex[4];
-        };
-        auto loadA = [&](AIn &in, int us) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int uu = min(us, nlast[r]);
-                const int t = ttop[r] - uu;
-                const int64_t un = (int64_t)uu * n;
-                // alpha_{t-1} from the last warm-up step on (it becomes alpha_t of the first main step)
-                const bool wanta = us + 1 >= nwarm[r] && us < nst[r] && t > 0;
-#pragma unroll
-                for (int c = 0; c < TPW; ++c)
-                    in.ap[c][r] = (wanta && real[c]) ? alpha_rm[abase[c][r] - un - n] : 0.0;
-                in.ex[r] = (us >= nwarm[r] && us < nst[r] && (t & 3) == 3) ? exps[gtop[r] - uu] : 0;
-            }
-        };
-        auto a_to_lds = [&](const AIn &in, int slot) __attribute__((always_inline)) {
-#pragma unroll
-            for (int c = 0; c < TPW; ++c) {
-                *reinterpret_cast<tile_d2 *>(&sA[tile_p_index<TPW>(slot, w, c, 0, lane)]) = tile_d2{in.ap[c][0], in.ap[c][1]};
-                *reinterpret_cast<tile_d2 *>(&sA[tile_p_index<TPW>(slot, w, c, 1, lane)]) = tile_d2{in.ap[c][2], in.ap[c][3]};
-            }
-            if (w == 0 && s == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sEx[slot * 16 + 4 * q + r] = in.ex[r];
-            }
-        };
-        TileIn<KIND, TPW> ringE[TILE_PF];
-        AIn ringA[TILE_PF];
+        ARow ringA[TILE_PF];
+        int ringX[TILE_PF];
 #pragma unroll
         for (int u = 0; u < TILE_PF; ++u) {
-            loadE(ringE[u], u);
             loadA(ringA[u], u);
+            ringX[u] = loadX(u);
         }
-        emit_to_lds(ringE[0], 0);
-        loadE(ringE[0], TILE_PF);
-        emit_to_lds(ringE[1], 1);
-        loadE(ringE[1], 1 + TILE_PF);
         a_to_lds(ringA[0], 0);
         loadA(ringA[0], TILE_PF);
+        if (w == 1 && lane < 16)
+            sEx[xpos] = ringX[0];
+        ringX[0] = loadX(TILE_PF);
+        __syncthreads(); // (the first observations are in LDS)
+        {
+            TileIn<KIND, TPW> in0;
+            fetch_in(in0, 0);
+            emit_to_lds(in0, 0);
+            fetch_in(in0, 1);
+            emit_to_lds(in0, 1);
+        }
         __syncthreads(); // (the emission rows of steps 0 and 1, alpha for step 0 are in LDS)
         if (any_enter_at(0)) {
             __syncthreads();
@@ -805,12 +884,22 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
                     __syncthreads();
                 }
             }
-            // the emission row and the observations of step us + 2, the loads of four steps further
-            emit_to_lds(ringE[(u + 2) & 3], u & 1);
-            loadE(ringE[(u + 2) & 3], us + 2 + TILE_PF);
-            // alpha / exponent for the back half of step us + 1
+            // alpha / exponent for the back half of step us + 1; the loads of four steps further
             a_to_lds(ringA[(u + 1) & 3], (u + 1) & 1);
             loadA(ringA[(u + 1) & 3], us + 1 + TILE_PF);
+            if (w == 1 && lane < 16)
+                sEx[((u + 1) & 1) * 16 + xpos] = ringX[(u + 1) & 3];
+            ringX[(u + 1) & 3] = loadX(us + 1 + TILE_PF);
+            if constexpr (KIND != EMIT_EXPL && u == 0) {
+                if (w == 0) { // the observations of the group two ahead go to LDS, the next ones are fetched
+                    sObs[((us + 8 + ldt) & 15) * 16 + lpos] = pend;
+                    pend = obs_load(us + 12 + ldt);
+                }
+            }
+            // the emission row of step us + 2
+            TileIn<KIND, TPW> ein;
+            fetch_in(ein, us + 2);
+            emit_to_lds(ein, u & 1);
             __syncthreads();
         };
         run(step, 0, g1, tile_ic<TM_WARM>{});
@@ -874,14 +963,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
     };
     auto fetch_a = [&](int slot, AIn &in) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < TPW; ++c) {
-            const tile_d2 lo = *reinterpret_cast<const tile_d2 *>(&sA[tile_p_index<TPW>(slot, w, c, 0, lane)]);
-            const tile_d2 hi = *reinterpret_cast<const tile_d2 *>(&sA[tile_p_index<TPW>(slot, w, c, 1, lane)]);
-            in.ap[c][0] = lo[0];
-            in.ap[c][1] = lo[1];
-            in.ap[c][2] = hi[0];
-            in.ap[c][3] = hi[1];
-        }
+        for (int c = 0; c < TPW; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                in.ap[c][r] = sAl[slot * 16 * PX + xw[r] + 16 * (w + 4 * c) + s];
         typedef int tile_i4 __attribute__((ext_vector_type(4)));
         const tile_i4 e = *reinterpret_cast<const tile_i4 *>(&sEx[slot * 16 + 4 * q]);
         in.ex[0] = e[0];
@@ -990,7 +1075,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
                     }
                     if constexpr (KIND == EMIT_DISC) {
                         if (real[c] && mainr[r]) {
-                            const int sym = reinterpret_cast<const int *>(&ol[0])[r];
+                            const int sym = __double2loint(ol[r >> 1][r & 1]);
                             mytab[(int64_t)j * m.M + sym] += gam;
                         }
                     }
@@ -1006,24 +1091,23 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
         }
     };
     // emission row / observations of a step from the LDS slot the stream wavefronts filled
-    auto fetch_p = [&](int slot, tile_d2 (&pl)[TPW][2], tile_d2 (&ol)[2]) __attribute__((always_inline)) {
+    auto fetch_p = [&](int us, tile_d2 (&pl)[TPW][2], tile_d2 (&ol)[2]) __attribute__((always_inline)) {
+        const int slot = us & 1;
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
             pl[c][0] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 0, lane)]);
             pl[c][1] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 1, lane)]);
         }
-        if constexpr (KIND == EMIT_GAUSS) {
-            ol[0] = *reinterpret_cast<const tile_d2 *>(&sO[slot * 16 + 4 * q]);
-            ol[1] = *reinterpret_cast<const tile_d2 *>(&sO[slot * 16 + 4 * q + 2]);
-        } else if constexpr (KIND == EMIT_DISC) {
-            ol[0] = *reinterpret_cast<const tile_d2 *>(reinterpret_cast<const int *>(sO) + slot * 16 + 4 * q);
-            ol[1] = tile_d2{0.0, 0.0};
+        if constexpr (KIND != EMIT_EXPL) { // (discrete: the symbol is the low word)
+            ol[0] = *reinterpret_cast<const tile_d2 *>(&sObs[(us & 15) * 16 + 4 * q]);
+            ol[1] = *reinterpret_cast<const tile_d2 *>(&sObs[(us & 15) * 16 + 4 * q + 2]);
         } else {
             ol[0] = ol[1] = tile_d2{0.0, 0.0};
         }
     };
 
-    __syncthreads(); // (the emission rows of steps 0 and 1 are in LDS)
+    __syncthreads(); // (the stream wavefronts: first observations in LDS ...
+    __syncthreads(); //  ... the emission rows of steps 0 and 1, alpha for step 0 in LDS)
     // prologue: the front half of step 0
     {
         tile_d2 pl[TPW][2], ol[2];
@@ -1061,6 +1145,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
                 lastr[r] = us == meta(r, 2) - 1 && tt[r] > 0; // the transition into the segment
             }
         }
+        const bool pr = probe && blockIdx.x == 0 && wid == 0;
+        const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
         AIn in;
         fetch_a(u & 1, in);
         // ---- back half of step us: beta_{t-1} (raw) = A (p_t o beta_t) ----------------------------
@@ -1070,7 +1156,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
         for (int k2 = 0; k2 < KK / 2; ++k2)
             av[k2] = *reinterpret_cast<const tile_d2 *>(X + xr + 2 * k2);
         tile_d2 pl[TPW][2], ol[2];
-        fetch_p((u + 1) & 1, pl, ol); // emission row / observations of step us + 1
+        fetch_p(us + 1, pl, ol); // emission row / observations of step us + 1
         wide_d4 acc[TPW];
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
@@ -1079,6 +1165,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
                 if (NT % 4 == 0 || w + 4 * c < NT)
                     acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk >> 1][kk & 1], Breg[c * KK + kk],
                                                                   kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+        unsigned long long c1 = 0;
+        if (pr) {
+            asm volatile("" ::"v"(acc[0][0]));
+            c1 = __builtin_readcyclecounter();
+        }
         // factors of xi for the transition t-1 -> t: the exponent the forward pass removed at t comes off
         double fx[4] = {0.0, 0.0, 0.0, 0.0}, fnx[4] = {0.0, 0.0, 0.0, 0.0};
         if constexpr (MODE != TM_WARM) {
@@ -1150,6 +1241,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
         bool mainn[4];
         front_chain(us + 1, tile_ic<(u + 1) & 3>{}, mc, fg, mainn, pl, in.ap);
         __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long c2 = pr ? __builtin_readcyclecounter() : 0;
         // ---- off the chain: xi of the transition t-1 -> t -----------------------------------------
         if constexpr (MODE != TM_WARM) {
             if constexpr (!XIG) {
@@ -1180,7 +1272,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
             }
         }
         front_stats(us + 1, mc, fg, mainn, ol, in.ap);
+        const unsigned long long c3 = pr ? __builtin_readcyclecounter() : 0;
         __syncthreads();
+        if (pr && lane == 0) {
+            const unsigned long long c4 = __builtin_readcyclecounter();
+            const int o = MODE == TM_WARM ? 0 : 8;
+            probe[o + 0] += c1 - c0;
+            probe[o + 1] += c2 - c1;
+            probe[o + 2] += c3 - c2;
+            probe[o + 3] += c4 - c3;
+            probe[o + 4] += 1;
+        }
     };
     run(step, 0, g1, tile_ic<TM_WARM>{});
     run(step, g1, g2, tile_ic<TM_GEN>{});

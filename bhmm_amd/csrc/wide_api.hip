@@ -112,7 +112,7 @@ static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
         BHMM_HIP(hipMemcpyAsync(h, probe, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         BHMM_HIP(hipStreamSynchronize(c->stream));
         fprintf(stderr, "tile fwd probe: matrix [operands+matrix %.0f | emission row, write %.0f | barrier %.0f] "
-                        "stream [emission %.0f | store %.0f | barrier %.0f] cycles/step (%llu steps)\n",
+                        "stream [store, loads %.0f | emission %.0f | barrier %.0f] cycles/step (%llu steps)\n",
                 (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[7],
                 (double)h[5] / h[7], (double)h[6] / h[7], h[3]);
     }
@@ -130,14 +130,33 @@ template <int KIND>
 static int tile_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool store_gamma, double *stats_dev)
 {
     const Segs sg = segs_of(c, which);
-    const TilePlan tp{c->d_tile_seg[which].p, c->w_ntiles[which]};
+    const TilePlan tp{c->d_tile_segb[which].p, c->w_ntilesb[which]};
     double *gam = store_gamma ? c->d_gamma_ci.p : (double *)nullptr;
+    static const bool probe_on = getenv("BHMM_AMD_TILE_PROBE") != nullptr;
+    unsigned long long *probe = nullptr;
+    if (probe_on) {
+        int rc = c->d_probe.ensure(4096);
+        if (rc)
+            return rc;
+        probe = reinterpret_cast<unsigned long long *>(c->d_probe.p) + 16;
+        BHMM_HIP(hipMemsetAsync(probe, 0, 128, c->stream));
+    }
     hipLaunchKernelGGL((k_tile_bwd<4, KIND, true, false>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
                        (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
                        c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
-                       (double *)nullptr);
+                       (double *)nullptr, probe);
     BHMM_HIP(hipGetLastError());
+    if (probe_on) {
+        unsigned long long h[16];
+        BHMM_HIP(hipMemcpyAsync(h, probe, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        for (int o = 0; o < 16; o += 8)
+            if (h[o + 4])
+                fprintf(stderr, "tile bwd probe (%s steps): operands+matrix %.0f | rescale, x' write %.0f | xi, statistics %.0f | "
+                                "barrier %.0f cycles/step (%llu steps)\n", o ? "main" : "warm-up", (double)h[o] / h[o + 4],
+                        (double)h[o + 1] / h[o + 4], (double)h[o + 2] / h[o + 4], (double)h[o + 3] / h[o + 4], h[o + 4]);
+    }
     const int n = c->n;
     const int nfin = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0) + (KIND == EMIT_DISC ? n * c->M : 0) +
                      n + 1;
@@ -283,11 +302,16 @@ static int wide_plan(bhmm_ctx *c, int which, int64_t seglen, int mult = 1)
     if (wide_tile(c)) {
         // tiles of 16 segments of about the same number of steps (a tile runs as long as its longest row)
         std::vector<int32_t> ts;
-        plan::plan_tiles(sp, ts);
+        plan::plan_tiles(sp, c->offsets, false, ts);
         c->w_ntiles[which] = (int)(ts.size() / 16);
         if ((rc = c->d_tile_seg[which].ensure(std::max<size_t>(ts.size(), 16))))
             return rc;
         BHMM_HIP(hipMemcpy(c->d_tile_seg[which].p, ts.data(), ts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        plan::plan_tiles(sp, c->offsets, true, ts);
+        c->w_ntilesb[which] = (int)(ts.size() / 16);
+        if ((rc = c->d_tile_segb[which].ensure(std::max<size_t>(ts.size(), 16))))
+            return rc;
+        BHMM_HIP(hipMemcpy(c->d_tile_segb[which].p, ts.data(), ts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     return BHMM_OK;
 }
@@ -355,7 +379,7 @@ int wide_alloc(bhmm_ctx *c)
         (rc = c->d_specres.ensure(4)) ||
         (rc = c->d_stats.ensure(1 + n + n * n + n + std::max(2 * n, n * c->M))))
         return rc;
-    if (c->kind == EMIT_DISC && (rc = c->d_dpartials.ensure((size_t)std::max(nsmax, 4 * (nsmax / 16 + 1)) * n * c->M)))
+    if (c->kind == EMIT_DISC && (rc = c->d_dpartials.ensure((size_t)std::max(nsmax, 4 * (nsmax / 16 + 2)) * n * c->M)))
         return rc;
     if (wide_tile(c) && ((rc = c->d_wexp.ensure((size_t)std::max<int64_t>(c->total, 1))) ||
                          (rc = c->d_wePseg.ensure(nsmax))))
