@@ -186,18 +186,24 @@ __device__ __forceinline__ int tile_all_max(int v)
     return max(v, __shfl_xor(v, 32, 64));
 }
 
-// Workgroup = EIGHT wavefronts on one tile.  Measured on gfx950 (tools/proto/step_lat.hip,
-// tile_proto.hip): the matrix instructions of a step are a dependent chain (1024 cycles) that
-// vector instructions of the same wavefront cannot hide behind, 16-byte LDS reads feed it at 1390
-// cycles per step where 8-byte reads need 1830, and four global stores per lane cost it another 220.
-// So the roles are split:
+// Workgroup = EIGHT wavefronts on one tile (SPLIT).  Measured on gfx950 (tools/proto/step_lat.hip,
+// tile_proto.hip, the in-kernel probe): the matrix instructions of a step are a dependent chain
+// (1024 cycles at 64 states) that OCCUPIES THE SIMD'S VECTOR UNIT -- no other vector instruction of
+// either wavefront of the SIMD issues meanwhile --, 16-byte LDS reads feed it at 1390 cycles per step
+// where 8-byte reads need 1830, and four global stores per lane cost it another 220.  So the roles
+// are split:
 //   wavefronts 0-3 ("matrix"): operand reads, matrix instructions, times the emission row, LDS write;
 //   wavefronts 4-7 ("stream"): the emission rows one step ahead (into LDS), the observation
-//       stream, alpha rows from the LDS tile to HBM in 16-byte pieces, exponent bookkeeping --
-//       wavefront 4 + w shares the SIMD of matrix wavefront w and fills the cycles its chain leaves.
+//       stream (read once per tile, passed on through LDS), alpha rows between the LDS tile and HBM
+//       in 16-byte pieces, exponent bookkeeping -- wavefront 4 + w shares the SIMD of matrix
+//       wavefront w and works while that one waits for the exchange of the step.
 // One barrier per step for all eight.  The K index of the products is (q, kk) <-> state q * KK + kk,
 // so that the operand of lane (m, q) is 8 * KK consecutive bytes of row m of the tile.
+// !SPLIT (more than 64 states: two column tiles per wavefront, whose blocks of A need half of a
+// 512-register budget): four wavefronts that take both roles in turn.
 constexpr int TILE_THREADS = 512;
+template <bool SPLIT>
+constexpr int tile_threads() { return SPLIT ? TILE_THREADS : TILE_THREADS / 2; }
 
 // emission rows handed from the stream wavefronts to the matrix wavefronts: [slot][w][c][half][lane][2]
 template <int TPW>
@@ -212,12 +218,12 @@ __device__ __forceinline__ int tile_p_index(int slot, int w, int c, int h, int l
 // entry (after the warm-up) and exit for the boundary check and the log-likelihood.
 // FULL: n == 16 NT (no padded states).
 // =========================================================================================
-template <int NT, int KIND, bool FULL>
-__global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, const int64_t *off, const Segs sg,
-                                                           const TilePlan tp, const void *obs_rm,
-                                                           double *alpha_rm, int32_t *exps, int32_t *eP_seg,
-                                                           double *a_entry, double *a_exit, unsigned int *flags,
-                                                           unsigned long long *probe = nullptr)
+template <int NT, int KIND, bool FULL, bool SPLIT>
+__global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideModel m, const int64_t *off, const Segs sg,
+                                                                    const TilePlan tp, const void *obs_rm,
+                                                                    double *alpha_rm, int32_t *exps, int32_t *eP_seg,
+                                                                    double *a_entry, double *a_exit, unsigned int *flags,
+                                                                    unsigned long long *probe = nullptr)
 {
     using G = TileGeo<NT>;
     constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX, NP = G::NP;
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
     __shared__ __attribute__((aligned(16))) double sObs[16 * 16]; // observations of 16 steps: [step & 15][4 q + r]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool matrix = wid < 4;
+    const bool matrix = !SPLIT || wid < 4, stream = !SPLIT || wid >= 4;
     const int w = wid & 3;
     const int s = lane & 15, q = lane >> 4;
     const int n = FULL ? NP : m.n;
@@ -260,14 +266,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
     const int g2 = tile_all_max(max(max(r0[0], r0[1]), max(r0[2], r0[3])));
     const int g3 = tile_all_min(min(min(nst[0], nst[1]), min(nst[2], nst[3]))) - 1;
 
-    for (int e = tid; e < 16 * PX; e += TILE_THREADS)
+    for (int e = tid; e < 16 * PX; e += tile_threads<SPLIT>())
         sX[e] = (e % PX) < n ? 1.0 / (double)n : 0.0; // warm-ups start from the uniform vector
     bool real[TPW];
 #pragma unroll
     for (int c = 0; c < TPW; ++c)
         real[c] = (w + 4 * c < NT) && (FULL || 16 * (w + 4 * c) + s < n);
-    // groups of four steps; the matrix wavefronts only distinguish the first step (rows that start
-    // their trajectory take pi o p_0 instead of the product)
+    // groups of four steps; the matrix part only distinguishes the first step (rows that start their
+    // trajectory take pi o p_0 instead of the product)
     auto run = [&](auto &&step) __attribute__((always_inline)) {
         int rs = 0;
         if (g4 >= 4) {
@@ -285,159 +291,264 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
         }
     };
 
-    if (matrix) {
-        // ================= matrix wavefronts ==================================================
-        // (the serial chain runs here: its instructions go first whenever both wavefronts of a SIMD
-        // have one ready -- without this the stream wavefront's vector instructions went first and
-        // the matrix instructions started when it was done)
-        __builtin_amdgcn_s_setprio(3);
-        double Breg[TPW * KK], pi_j[TPW]; // my blocks of A (B operand)
+    // ================= the matrix part ==========================================================
+    double Breg[TPW * KK], pi_j[TPW]; // my blocks of A (B operand)
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const int j = 16 * (w + 4 * c) + s;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int i = q * KK + kk;
+            Breg[c * KK + kk] = (matrix && real[c] && (FULL || i < n)) ? m.A[(int64_t)i * n + j] : 0.0;
+        }
+        pi_j[c] = real[c] ? m.pi[j] : 0.0;
+    }
+    int xw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        xw[r] = tile_prow(q + 4 * r) * PX;
+    const int xr = tile_prow(s) * PX + q * KK; // my operand: KK consecutive doubles of row s
+    unsigned long long pc = 0; // (probe: end of the previous step's work)
+    auto m_step = [&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
+        const bool pr = probe && blockIdx.x == 0 && wid == 0;
+        const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
+        const double *X = sX + (u & 1) * 16 * PX; // (groups of four steps: the buffer is the step's parity)
+        double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
+        tile_d2 pl[TPW][2];
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
-            const int j = 16 * (w + 4 * c) + s;
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                const int i = q * KK + kk;
-                Breg[c * KK + kk] = (real[c] && (FULL || i < n)) ? m.A[(int64_t)i * n + j] : 0.0;
-            }
-            pi_j[c] = real[c] ? m.pi[j] : 0.0;
+            pl[c][0] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(u & 1, w, c, 0, lane)]);
+            pl[c][1] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(u & 1, w, c, 1, lane)]);
         }
-        int xw[4];
+        wide_d4 acc[TPW];
+        // (operands in pieces of eight: all of them first is no faster and costs the registers)
+        constexpr int CH = KK < 8 ? KK : 8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            xw[r] = tile_prow(q + 4 * r) * PX;
-        const int xr = tile_prow(s) * PX + q * KK; // my operand: KK consecutive doubles of row s
-        __syncthreads(); // (the stream wavefronts: first observations in LDS ...
-        __syncthreads(); //  ... first emission row in LDS)
-        auto step = [&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
-            constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
-            const bool pr = probe && blockIdx.x == 0 && wid == 0;
-            const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
-            const double *X = sX + (u & 1) * 16 * PX; // (groups of four steps: the buffer is the step's parity)
-            double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
-            tile_d2 av[KK / 2];
+        for (int k0 = 0; k0 < KK; k0 += CH) {
+            tile_d2 av[CH / 2];
 #pragma unroll
-            for (int k2 = 0; k2 < KK / 2; ++k2)
-                av[k2] = *reinterpret_cast<const tile_d2 *>(X + xr + 2 * k2);
-            tile_d2 pl[TPW][2];
+            for (int k2 = 0; k2 < CH / 2; ++k2)
+                av[k2] = *reinterpret_cast<const tile_d2 *>(X + xr + k0 + 2 * k2);
 #pragma unroll
-            for (int c = 0; c < TPW; ++c) {
-                pl[c][0] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(u & 1, w, c, 0, lane)]);
-                pl[c][1] = *reinterpret_cast<const tile_d2 *>(&sP[tile_p_index<TPW>(u & 1, w, c, 1, lane)]);
-            }
-            wide_d4 acc[TPW];
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
+            for (int kk = k0; kk < k0 + CH; ++kk)
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
                     if (NT % 4 == 0 || w + 4 * c < NT)
-                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk >> 1][kk & 1], Breg[c * KK + kk],
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[(kk - k0) >> 1][(kk - k0) & 1], Breg[c * KK + kk],
                                                                       kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
-            unsigned long long c1 = 0;
-            if (pr) {
-                asm volatile("" ::"v"(acc[0][0]));
-                c1 = __builtin_readcyclecounter();
-            }
-            // the exponent this step removes: row maxima of the step before, over the four wavefronts
-            int E[4] = {0, 0, 0, 0};
-            if constexpr (u == 3) {
+        }
+        unsigned long long c1 = 0;
+        if (pr) {
+            asm volatile("" ::"v"(acc[0][0]));
+            c1 = __builtin_readcyclecounter();
+        }
+        // the exponent this step removes: row maxima of the step before, over the four wavefronts
+        int E[4] = {0, 0, 0, 0};
+        if constexpr (u == 3) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rho = q + 4 * r;
-                    E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int rho = q + 4 * r;
+                E[r] = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
             }
-            int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
-#pragma unroll
-            for (int c = 0; c < TPW; ++c) {
-                if (NT % 4 == 0 || w + 4 * c < NT) {
-                    const int j = 16 * (w + 4 * c) + s;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double p = pl[c][r >> 1][r & 1];
-                        double v = acc[c][r] * p;
-                        if constexpr (MODE == TM_GEN)
-                            if (fs[r] && rs == 0)
-                                v = pi_j[c] * p;
-                        if constexpr (u == 3)
-                            v = ldexp(v, -E[r]);
-                        Xn[xw[r] + j] = v;
-                        if constexpr (u == 2)
-                            pm[r] = max(pm[r], v > 0.0 ? exponent_of(v) : -(1 << 28));
-                    }
-                }
-            }
-            if constexpr (u == 2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int mx = row16_max_i32(pm[r]);
-                    if (s == 0)
-                        sE[16 * w + q + 4 * r] = mx;
-                }
-            }
-            const unsigned long long c2 = pr ? __builtin_readcyclecounter() : 0;
-            __syncthreads();
-            if (pr && lane == 0) {
-                const unsigned long long c3 = __builtin_readcyclecounter();
-                probe[0] += c1 - c0;
-                probe[1] += c2 - c1;
-                probe[2] += c3 - c2;
-                probe[3] += 1;
-            }
-        };
-        run(step);
-    } else {
-        // ================= stream wavefronts ==================================================
-        double mu_j[TPW], ga_j[TPW], gb_j[TPW];
+        }
+        int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
-            const int j = 16 * (w + 4 * c) + s;
-            mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[j] : 0.0;
-            ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[j] : 0.0;
-            gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[j] : 1.0;
-        }
-        // the row whose alpha I carry to HBM: 16 lanes per row, NP / 16 states each
-        constexpr int SPL = NP / 16;
-        const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * SPL;
-        int s_seg = -1, s_nst = 0, s_r0 = 0;
-        int64_t s_ob = 0;
-        {
-            const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + srow];
-            s_seg = sgi;
-            if (sgi >= 0 && sg.len[sgi] > 0) {
-                const int64_t o0 = off[sg.traj[sgi]], t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
-                const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0;
-                s_nst = (int)(t1 - tw);
-                s_r0 = (int)(t0 - tw);
-                s_ob = o0 + tw;
+            if (NT % 4 == 0 || w + 4 * c < NT) {
+                const int j = 16 * (w + 4 * c) + s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double p = pl[c][r >> 1][r & 1];
+                    double v = acc[c][r] * p;
+                    if constexpr (MODE == TM_GEN)
+                        if (fs[r] && rs == 0)
+                            v = pi_j[c] * p;
+                    if constexpr (u == 3)
+                        v = ldexp(v, -E[r]);
+                    Xn[xw[r] + j] = v;
+                    if constexpr (u == 2)
+                        pm[r] = max(pm[r], v > 0.0 ? exponent_of(v) : -(1 << 28));
+                }
             }
         }
-        const int sxr = tile_prow(srow) * PX + sch;
-        // ---- the observation stream.  Every vector instruction of this SIMD waits for the matrix
-        // instructions of the other wavefront (and they for it), so the stream is read ONCE per tile:
-        // wavefront 4 loads, per group of four steps, one value per (row, step) -- lane = 4 row + step --
-        // and passes them on through LDS; everybody reads the four rows of a step with two 16-byte reads.
-        const int lrow = lane >> 2, ldt = lane & 3;
-        int64_t l_ob = 0;
-        int l_last = 0;
+        if constexpr (u == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mx = row16_max_i32(pm[r]);
+                if (s == 0)
+                    sE[16 * w + q + 4 * r] = mx;
+            }
+        }
+        if (pr && lane == 0) {
+            const unsigned long long c2 = __builtin_readcyclecounter();
+            probe[0] += c1 - c0;
+            probe[1] += c2 - c1;
+            probe[2] += pc ? c0 - pc : 0;
+            probe[3] += 1;
+            pc = c2;
+        }
+    };
+
+    // ================= the stream part ==========================================================
+    double mu_j[TPW], ga_j[TPW], gb_j[TPW];
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const int j = 16 * (w + 4 * c) + s;
+        mu_j[c] = (KIND == EMIT_GAUSS && stream && real[c]) ? m.mu[j] : 0.0;
+        ga_j[c] = (KIND == EMIT_GAUSS && stream && real[c]) ? m.ga[j] : 0.0;
+        gb_j[c] = (KIND == EMIT_GAUSS && stream && real[c]) ? m.gb[j] : 1.0;
+    }
+    // the row whose alpha I carry to HBM: 16 lanes per row, NP / 16 states each
+    constexpr int SPL = NP / 16;
+    const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * SPL;
+    int s_seg = -1, s_nst = 0, s_r0 = 0;
+    int64_t s_ob = 0;
+    // the observation stream: read ONCE per tile -- wavefront 4 loads, per group of four steps, one
+    // value per (row, step), lane = 4 row + step, and passes them on through LDS; everybody reads
+    // the four rows of a step with two 16-byte reads
+    const int lrow = lane >> 2, ldt = lane & 3;
+    int64_t l_ob = 0;
+    int l_last = 0;
+    if (stream) {
+        const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + srow];
+        s_seg = sgi;
+        if (sgi >= 0 && sg.len[sgi] > 0) {
+            const int64_t o0 = off[sg.traj[sgi]], t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+            const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0;
+            s_nst = (int)(t1 - tw);
+            s_r0 = (int)(t0 - tw);
+            s_ob = o0 + tw;
+        }
         if (w == 0) {
-            const int sgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + lrow];
-            if (sgi >= 0 && sg.len[sgi] > 0) {
-                const int64_t o0 = off[sg.traj[sgi]], t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+            const int lgi = tp.tile_seg[(int64_t)blockIdx.x * 16 + lrow];
+            if (lgi >= 0 && sg.len[lgi] > 0) {
+                const int64_t o0 = off[sg.traj[lgi]], t0 = sg.t0[lgi], t1 = t0 + sg.len[lgi];
                 const int64_t tw = (t0 - sg.W > 0) ? t0 - sg.W : 0;
                 l_ob = o0 + tw;
                 l_last = (int)(t1 - tw) - 1;
             }
         }
-        const int lpos = 4 * (lrow & 3) + (lrow >> 2); // row q + 4 r sits at position 4 q + r
-        auto obs_load = [&](int step) __attribute__((always_inline)) -> double {
-            const int64_t g = l_ob + min(step, l_last);
-            if constexpr (KIND == EMIT_DISC)
-                return __hiloint2double(0, static_cast<const int32_t *>(obs_rm)[g]);
-            else
-                return static_cast<const double *>(obs_rm)[g];
-        };
-        double pend = 0.0; // the group two ahead, on its way
+    }
+    const int sxr = tile_prow(srow) * PX + sch;
+    const int lpos = 4 * (lrow & 3) + (lrow >> 2); // row q + 4 r sits at position 4 q + r
+    auto obs_load = [&](int step) __attribute__((always_inline)) -> double {
+        const int64_t g = l_ob + min(step, l_last);
+        if constexpr (KIND == EMIT_DISC)
+            return __hiloint2double(0, static_cast<const int32_t *>(obs_rm)[g]);
+        else
+            return static_cast<const double *>(obs_rm)[g];
+    };
+    double pend = 0.0; // the group two ahead, on its way
+    // what the emission row of step rs is computed from
+    auto fetch_in = [&](TileIn<KIND, TPW> &in, int rs) __attribute__((always_inline)) {
+        if constexpr (KIND == EMIT_GAUSS) {
+            const tile_d2 lo = *reinterpret_cast<const tile_d2 *>(&sObs[(rs & 15) * 16 + 4 * q]);
+            const tile_d2 hi = *reinterpret_cast<const tile_d2 *>(&sObs[(rs & 15) * 16 + 4 * q + 2]);
+            in.o[0] = lo[0];
+            in.o[1] = lo[1];
+            in.o[2] = hi[0];
+            in.o[3] = hi[1];
+        } else if constexpr (KIND == EMIT_DISC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                in.sym[r] = __double2loint(sObs[(rs & 15) * 16 + 4 * q + r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = min(rs, nlast[r]);
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[(ob[r] + rr) * n + 16 * (w + 4 * c) + s] : 0.0;
+            }
+        }
+    };
+    // emission row of a step into slot (step & 1)
+    auto emit_to_lds = [&](const TileIn<KIND, TPW> &in, int slot) __attribute__((always_inline)) {
+        double p[TPW][4];
+        tile_emit4<NT, KIND, TPW>(m, in, w, s, real, mu_j, ga_j, gb_j, p);
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) {
+            *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 0, lane)]) = tile_d2{p[c][0], p[c][1]};
+            *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 1, lane)]) = tile_d2{p[c][2], p[c][3]};
+        }
+    };
+    // alpha of step rs (in LDS buffer (rs + 1) & 1 after that step's barrier) to HBM
+    const int64_t s_abase = s_ob * n + sch;
+    auto store_row = [&](int rs) __attribute__((always_inline)) {
+        const double *X = sX + ((rs + 1) & 1) * 16 * PX + sxr;
+        if (FULL && rs >= g2 && rs < g3) { // (uniform: every row of the tile in its main part)
+            double *dst = alpha_rm + s_abase + (int64_t)rs * n;
+#pragma unroll
+            for (int e = 0; e < SPL; e += 2)
+                *reinterpret_cast<tile_d2 *>(dst + e) = *reinterpret_cast<const tile_d2 *>(X + e);
+            return;
+        }
+        if (rs < 0 || rs >= s_nst)
+            return;
+        double *dst = nullptr;
+        if (rs >= s_r0)
+            dst = alpha_rm + s_abase + (int64_t)rs * n;
+        else if (rs == s_r0 - 1)
+            dst = a_entry + (int64_t)s_seg * n + sch;
+        if (dst) {
+#pragma unroll
+            for (int e = 0; e < SPL; ++e)
+                if (FULL || sch + e < n)
+                    dst[e] = X[e];
+        }
+        if (rs == s_nst - 1) {
+            double *dx = a_exit + (int64_t)s_seg * n + sch;
+#pragma unroll
+            for (int e = 0; e < SPL; ++e)
+                if (FULL || sch + e < n)
+                    dx[e] = X[e];
+        }
+    };
+    int eP[4] = {0, 0, 0, 0};
+    unsigned int trouble = 0u; // (bit 0: a vector below 2^-900)
+    auto s_step = [&](int rs, auto uc, auto) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        const bool pr = probe && blockIdx.x == 0 && wid == (SPLIT ? 4 : 0);
+        const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
+        // alpha of the previous step: LDS -> HBM
+        store_row(rs - 1);
+        if constexpr (KIND != EMIT_EXPL && u == 0) {
+            if (w == 0) { // the observations of the group two ahead go to LDS, the next ones are fetched
+                sObs[((rs + 8 + ldt) & 15) * 16 + lpos] = pend;
+                pend = obs_load(rs + 12 + ldt);
+            }
+        }
+        // bookkeeping of the exponents (wavefront 5, one lane per row)
+        if constexpr (u == 3) {
+            if (w == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rho = q + 4 * r;
+                    const int E = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
+                    const bool act = rs < nst[r];
+                    trouble |= (act && E < WIDE_TROUBLE_EXP) ? 1u : 0u;
+                    if (act && rs >= r0[r]) {
+                        eP[r] += E;
+                        if (s == 0)
+                            exps[ob[r] + rs] = E;
+                    }
+                }
+            }
+        }
+        const unsigned long long c1 = pr ? __builtin_readcyclecounter() : 0;
+        // the emission row of the next step
+        TileIn<KIND, TPW> ein;
+        fetch_in(ein, rs + 1);
+        emit_to_lds(ein, (u + 1) & 1);
+        if (pr && lane == 0) {
+            const unsigned long long c2 = __builtin_readcyclecounter();
+            probe[4] += c1 - c0;
+            probe[5] += c2 - c1;
+            probe[7] += 1;
+        }
+    };
+    auto s_prologue1 = [&]() __attribute__((always_inline)) {
         if constexpr (KIND != EMIT_EXPL) {
             if (w == 0) {
                 sObs[ldt * 16 + lpos] = obs_load(ldt);
@@ -445,125 +556,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
                 pend = obs_load(8 + ldt);
             }
         }
-        // what the emission row of step rs is computed from
-        auto fetch_in = [&](TileIn<KIND, TPW> &in, int rs) __attribute__((always_inline)) {
-            if constexpr (KIND == EMIT_GAUSS) {
-                const tile_d2 lo = *reinterpret_cast<const tile_d2 *>(&sObs[(rs & 15) * 16 + 4 * q]);
-                const tile_d2 hi = *reinterpret_cast<const tile_d2 *>(&sObs[(rs & 15) * 16 + 4 * q + 2]);
-                in.o[0] = lo[0];
-                in.o[1] = lo[1];
-                in.o[2] = hi[0];
-                in.o[3] = hi[1];
-            } else if constexpr (KIND == EMIT_DISC) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    in.sym[r] = __double2loint(sObs[(rs & 15) * 16 + 4 * q + r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rr = min(rs, nlast[r]);
-#pragma unroll
-                    for (int c = 0; c < TPW; ++c)
-                        in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[(ob[r] + rr) * n + 16 * (w + 4 * c) + s] : 0.0;
-                }
-            }
-        };
-        // emission row of a step into slot (step & 1)
-        auto emit_to_lds = [&](const TileIn<KIND, TPW> &in, int slot) __attribute__((always_inline)) {
-            double p[TPW][4];
-            tile_emit4<NT, KIND, TPW>(m, in, w, s, real, mu_j, ga_j, gb_j, p);
-#pragma unroll
-            for (int c = 0; c < TPW; ++c) {
-                *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 0, lane)]) = tile_d2{p[c][0], p[c][1]};
-                *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 1, lane)]) = tile_d2{p[c][2], p[c][3]};
-            }
-        };
-        // alpha of step rs (in LDS buffer (rs + 1) & 1 after that step's barrier) to HBM
-        const int64_t s_abase = s_ob * n + sch;
-        auto store_row = [&](int rs) __attribute__((always_inline)) {
-            const double *X = sX + ((rs + 1) & 1) * 16 * PX + sxr;
-            if (FULL && rs >= g2 && rs < g3) { // (uniform: every row of the tile in its main part)
-                double *dst = alpha_rm + s_abase + (int64_t)rs * n;
-#pragma unroll
-                for (int e = 0; e < SPL; e += 2)
-                    *reinterpret_cast<tile_d2 *>(dst + e) = *reinterpret_cast<const tile_d2 *>(X + e);
-                return;
-            }
-            if (rs < 0 || rs >= s_nst)
-                return;
-            double *dst = nullptr;
-            if (rs >= s_r0)
-                dst = alpha_rm + s_abase + (int64_t)rs * n;
-            else if (rs == s_r0 - 1)
-                dst = a_entry + (int64_t)s_seg * n + sch;
-            if (dst) {
-#pragma unroll
-                for (int e = 0; e < SPL; ++e)
-                    if (FULL || sch + e < n)
-                        dst[e] = X[e];
-            }
-            if (rs == s_nst - 1) {
-                double *dx = a_exit + (int64_t)s_seg * n + sch;
-#pragma unroll
-                for (int e = 0; e < SPL; ++e)
-                    if (FULL || sch + e < n)
-                        dx[e] = X[e];
-            }
-        };
-        __syncthreads(); // (the first observations are in LDS)
-        {
-            TileIn<KIND, TPW> in0;
-            fetch_in(in0, 0);
-            emit_to_lds(in0, 0);
-        }
-        __syncthreads();
-        int eP[4] = {0, 0, 0, 0};
-        unsigned int trouble = 0u; // (bit 0: a vector below 2^-900)
-        auto step = [&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
-            constexpr int u = decltype(uc)::value;
-            const bool pr = probe && blockIdx.x == 0 && wid == 4;
-            const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
-            // alpha of the previous step: LDS -> HBM
-            store_row(rs - 1);
-            if constexpr (KIND != EMIT_EXPL && u == 0) {
-                if (w == 0) { // the observations of the group two ahead go to LDS, the next ones are fetched
-                    sObs[((rs + 8 + ldt) & 15) * 16 + lpos] = pend;
-                    pend = obs_load(rs + 12 + ldt);
-                }
-            }
-            // bookkeeping of the exponents (wavefront 5, one lane per row)
-            if constexpr (u == 3) {
-                if (w == 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rho = q + 4 * r;
-                        const int E = max(max(sE[rho], sE[16 + rho]), max(sE[32 + rho], sE[48 + rho]));
-                        const bool act = rs < nst[r];
-                        trouble |= (act && E < WIDE_TROUBLE_EXP) ? 1u : 0u;
-                        if (act && rs >= r0[r]) {
-                            eP[r] += E;
-                            if (s == 0)
-                                exps[ob[r] + rs] = E;
-                        }
-                    }
-                }
-            }
-            const unsigned long long c1 = pr ? __builtin_readcyclecounter() : 0;
-            // the emission row of the next step
-            TileIn<KIND, TPW> ein;
-            fetch_in(ein, rs + 1);
-            emit_to_lds(ein, (u + 1) & 1);
-            const unsigned long long c2 = pr ? __builtin_readcyclecounter() : 0;
-            __syncthreads();
-            if (pr && lane == 0) {
-                const unsigned long long c3 = __builtin_readcyclecounter();
-                probe[4] += c1 - c0;
-                probe[5] += c2 - c1;
-                probe[6] += c3 - c2;
-                probe[7] += 1;
-            }
-        };
-        run(step);
+    };
+    auto s_prologue2 = [&]() __attribute__((always_inline)) {
+        TileIn<KIND, TPW> in0;
+        fetch_in(in0, 0);
+        emit_to_lds(in0, 0);
+    };
+    auto s_epilogue = [&]() __attribute__((always_inline)) {
         store_row(g4 - 1);
         if (w == 1 && s == 0) {
 #pragma unroll
@@ -575,6 +574,42 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
         }
         if (trouble)
             atomicOr(&flags[2], trouble);
+    };
+
+    // ================= the loop ===================================================================
+    if constexpr (SPLIT) {
+        if (matrix) {
+            // (the serial chain runs here: its instructions go first whenever both wavefronts of a
+            // SIMD have one ready)
+            __builtin_amdgcn_s_setprio(3);
+            __syncthreads(); // (the stream wavefronts: first observations in LDS ...
+            __syncthreads(); //  ... first emission row in LDS)
+            run([&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
+                m_step(rs, uc, mc);
+                __syncthreads();
+            });
+        } else {
+            s_prologue1();
+            __syncthreads();
+            s_prologue2();
+            __syncthreads();
+            run([&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
+                s_step(rs, uc, mc);
+                __syncthreads();
+            });
+            s_epilogue();
+        }
+    } else {
+        s_prologue1();
+        __syncthreads();
+        s_prologue2();
+        __syncthreads();
+        run([&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
+            m_step(rs, uc, mc);
+            s_step(rs, uc, mc);
+            __syncthreads();
+        });
+        s_epilogue();
     }
 }
 
@@ -620,8 +655,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_fwd(const WideModel m, co
 // buffer), gamma_{t-1} and the emission statistics | barrier.  The stream wavefronts supply the
 // emission rows and the observations two steps ahead.
 // =========================================================================================
-template <int NT, int KIND, bool FULL, bool XIG>
-__global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, const int64_t *off, const Segs sg,
+template <int NT, int KIND, bool FULL, bool XIG, bool SPLIT>
+__global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideModel m, const int64_t *off, const Segs sg,
                                                            const TilePlan tp, const void *obs_rm,
                                                            const double *alpha_rm, const int32_t *exps,
                                                            double *gamma_rm, double *gamma0, double *part,
@@ -639,7 +674,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
     __shared__ double sS[64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool matrix = wid < 4;
+    const bool matrix = !SPLIT || wid < 4, stream = !SPLIT || wid >= 4;
     const int w = wid & 3;
     const int s = lane & 15, q = lane >> 4;
     const int n = FULL ? NP : m.n;
@@ -735,77 +770,112 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
         }
     };
 
-    if (!matrix) {
-        // ================= stream wavefronts ========================================================
-        // (every vector instruction here competes with the matrix instructions for the SIMD: the
-        // observation stream is read once per tile and passed on through LDS, alpha comes in
-        // 16-byte pieces, one lane per (row, four states), and is laid out for the matrix wavefronts
-        // by the LDS -- see k_tile_fwd)
-        double mu_j[TPW], ga_j[TPW], gb_j[TPW];
+    // ================= the stream part ============================================================
+    // (every vector instruction here competes with the matrix instructions for the SIMD: the
+    // observation stream is read once per tile and passed on through LDS, alpha comes in
+    // 16-byte pieces, one lane per (row, four states), and is laid out for the matrix wavefronts
+    // by the LDS -- see k_tile_fwd)
+    double mu_j[TPW], ga_j[TPW], gb_j[TPW];
+#pragma unroll
+    for (int c = 0; c < TPW; ++c) {
+        const int i = 16 * (w + 4 * c) + s;
+        mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[i] : 0.0; // (both parts use it)
+        ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[i] : 0.0;
+        gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[i] : 1.0;
+    }
+    auto rmeta = [&](int row, int k) __attribute__((always_inline)) { return sMeta[8 * row + k]; };
+    auto rmeta_gtop = [&](int row) __attribute__((always_inline)) {
+        return (int64_t)(((uint64_t)(uint32_t)rmeta(row, 7) << 32) | (uint32_t)rmeta(row, 6));
+    };
+    // ---- alpha_{t-1}: my row and my NP / 16 states of it
+    constexpr int SPL = NP / 16;
+    const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * SPL;
+    const int s_nwarm = rmeta(srow, 1), s_nst = rmeta(srow, 2), s_ttop = rmeta(srow, 4);
+    const int64_t s_abase = rmeta_gtop(srow) * n + sch;
+    const int sxr = tile_prow(srow) * PX + sch;
+    struct ARow {
+        double v[SPL];
+    };
+    auto loadA = [&](ARow &a, int us) __attribute__((always_inline)) {
+        // alpha_{t-1} from the last warm-up step on (it becomes alpha_t of the first main step)
+        const bool wanta = us + 1 >= s_nwarm && us < s_nst && s_ttop - us > 0;
+        const double *src = alpha_rm + s_abase - ((int64_t)us + 1) * n;
+        if constexpr (FULL) {
+#pragma unroll
+            for (int e = 0; e < SPL; e += 2) {
+                const tile_d2 t2 = wanta ? *reinterpret_cast<const tile_d2 *>(src + e) : tile_d2{0.0, 0.0};
+                a.v[e] = t2[0];
+                a.v[e + 1] = t2[1];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < SPL; ++e)
+                a.v[e] = (wanta && sch + e < n) ? src[e] : 0.0;
+        }
+    };
+    auto a_to_lds = [&](const ARow &a, int slot) __attribute__((always_inline)) {
+        double *dst = sAl + slot * 16 * PX + sxr;
+#pragma unroll
+        for (int e = 0; e < SPL; e += 2)
+            *reinterpret_cast<tile_d2 *>(dst + e) = tile_d2{a.v[e], a.v[e + 1]};
+    };
+    // ---- the exponent the forward pass removed at time t (wavefront 5, one lane per row)
+    const int xrow = lane & 15;
+    const int x_nwarm = rmeta(xrow, 1), x_nst = rmeta(xrow, 2), x_ttop = rmeta(xrow, 4);
+    const int64_t x_gtop = rmeta_gtop(xrow);
+    const int xpos = 4 * (xrow & 3) + (xrow >> 2);
+    auto loadX = [&](int us) __attribute__((always_inline)) -> int {
+        return (w == 1 && lane < 16 && us >= x_nwarm && us < x_nst && ((x_ttop - us) & 3) == 3) ? exps[x_gtop - us] : 0;
+    };
+    // ---- the observation stream (wavefront 4: lane = 4 row + step of a group of four)
+    const int lrow = lane >> 2, ldt = lane & 3;
+    const int64_t l_gtop = rmeta_gtop(lrow);
+    const int l_last = rmeta(lrow, 2) > 0 ? rmeta(lrow, 2) - 1 : 0;
+    const int lpos = 4 * (lrow & 3) + (lrow >> 2); // row q + 4 r sits at position 4 q + r
+    auto obs_load = [&](int step) __attribute__((always_inline)) -> double {
+        const int64_t g = l_gtop - min(step, l_last);
+        if constexpr (KIND == EMIT_DISC)
+            return __hiloint2double(0, static_cast<const int32_t *>(obs_rm)[g]);
+        else
+            return static_cast<const double *>(obs_rm)[g];
+    };
+    double pend = 0.0; // the group two ahead, on its way
+    // what the emission row of step us is computed from
+    auto fetch_in = [&](TileIn<KIND, TPW> &in, int us) __attribute__((always_inline)) {
+        if constexpr (KIND == EMIT_GAUSS) {
+            const tile_d2 lo = *reinterpret_cast<const tile_d2 *>(&sObs[(us & 15) * 16 + 4 * q]);
+            const tile_d2 hi = *reinterpret_cast<const tile_d2 *>(&sObs[(us & 15) * 16 + 4 * q + 2]);
+            in.o[0] = lo[0];
+            in.o[1] = lo[1];
+            in.o[2] = hi[0];
+            in.o[3] = hi[1];
+        } else if constexpr (KIND == EMIT_DISC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                in.sym[r] = __double2loint(sObs[(us & 15) * 16 + 4 * q + r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nl = meta(r, 2) > 0 ? meta(r, 2) - 1 : 0;
+                const int64_t g = meta_gtop(r) - min(us, nl);
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[g * n + 16 * (w + 4 * c) + s] : 0.0;
+            }
+        }
+    };
+    auto emit_to_lds = [&](const TileIn<KIND, TPW> &in, int slot) __attribute__((always_inline)) {
+        double p[TPW][4];
+        tile_emit4<NT, KIND, TPW>(m, in, w, s, real, mu_j, ga_j, gb_j, p);
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
-            const int i = 16 * (w + 4 * c) + s;
-            mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[i] : 0.0;
-            ga_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.ga[i] : 0.0;
-            gb_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.gb[i] : 1.0;
+            *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 0, lane)]) = tile_d2{p[c][0], p[c][1]};
+            *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 1, lane)]) = tile_d2{p[c][2], p[c][3]};
         }
-        auto rmeta = [&](int row, int k) __attribute__((always_inline)) { return sMeta[8 * row + k]; };
-        auto rmeta_gtop = [&](int row) __attribute__((always_inline)) {
-            return (int64_t)(((uint64_t)(uint32_t)rmeta(row, 7) << 32) | (uint32_t)rmeta(row, 6));
-        };
-        // ---- alpha_{t-1}: my row and my NP / 16 states of it
-        constexpr int SPL = NP / 16;
-        const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * SPL;
-        const int s_nwarm = rmeta(srow, 1), s_nst = rmeta(srow, 2), s_ttop = rmeta(srow, 4);
-        const int64_t s_abase = rmeta_gtop(srow) * n + sch;
-        const int sxr = tile_prow(srow) * PX + sch;
-        struct ARow {
-            double v[SPL];
-        };
-        auto loadA = [&](ARow &a, int us) __attribute__((always_inline)) {
-            // alpha_{t-1} from the last warm-up step on (it becomes alpha_t of the first main step)
-            const bool wanta = us + 1 >= s_nwarm && us < s_nst && s_ttop - us > 0;
-            const double *src = alpha_rm + s_abase - ((int64_t)us + 1) * n;
-            if constexpr (FULL) {
-#pragma unroll
-                for (int e = 0; e < SPL; e += 2) {
-                    const tile_d2 t2 = wanta ? *reinterpret_cast<const tile_d2 *>(src + e) : tile_d2{0.0, 0.0};
-                    a.v[e] = t2[0];
-                    a.v[e + 1] = t2[1];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < SPL; ++e)
-                    a.v[e] = (wanta && sch + e < n) ? src[e] : 0.0;
-            }
-        };
-        auto a_to_lds = [&](const ARow &a, int slot) __attribute__((always_inline)) {
-            double *dst = sAl + slot * 16 * PX + sxr;
-#pragma unroll
-            for (int e = 0; e < SPL; e += 2)
-                *reinterpret_cast<tile_d2 *>(dst + e) = tile_d2{a.v[e], a.v[e + 1]};
-        };
-        // ---- the exponent the forward pass removed at time t (wavefront 5, one lane per row)
-        const int xrow = lane & 15;
-        const int x_nwarm = rmeta(xrow, 1), x_nst = rmeta(xrow, 2), x_ttop = rmeta(xrow, 4);
-        const int64_t x_gtop = rmeta_gtop(xrow);
-        const int xpos = 4 * (xrow & 3) + (xrow >> 2);
-        auto loadX = [&](int us) __attribute__((always_inline)) -> int {
-            return (w == 1 && lane < 16 && us >= x_nwarm && us < x_nst && ((x_ttop - us) & 3) == 3) ? exps[x_gtop - us] : 0;
-        };
-        // ---- the observation stream (wavefront 4: lane = 4 row + step of a group of four)
-        const int lrow = lane >> 2, ldt = lane & 3;
-        const int64_t l_gtop = rmeta_gtop(lrow);
-        const int l_last = rmeta(lrow, 2) > 0 ? rmeta(lrow, 2) - 1 : 0;
-        const int lpos = 4 * (lrow & 3) + (lrow >> 2); // row q + 4 r sits at position 4 q + r
-        auto obs_load = [&](int step) __attribute__((always_inline)) -> double {
-            const int64_t g = l_gtop - min(step, l_last);
-            if constexpr (KIND == EMIT_DISC)
-                return __hiloint2double(0, static_cast<const int32_t *>(obs_rm)[g]);
-            else
-                return static_cast<const double *>(obs_rm)[g];
-        };
-        double pend = 0.0; // the group two ahead, on its way
+    };
+    ARow ringA[TILE_PF];
+    int ringX[TILE_PF];
+    auto s_prologue1 = [&]() __attribute__((always_inline)) {
         if constexpr (KIND != EMIT_EXPL) {
             if (w == 0) {
                 sObs[ldt * 16 + lpos] = obs_load(ldt);
@@ -813,41 +883,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
                 pend = obs_load(8 + ldt);
             }
         }
-        // what the emission row of step us is computed from
-        auto fetch_in = [&](TileIn<KIND, TPW> &in, int us) __attribute__((always_inline)) {
-            if constexpr (KIND == EMIT_GAUSS) {
-                const tile_d2 lo = *reinterpret_cast<const tile_d2 *>(&sObs[(us & 15) * 16 + 4 * q]);
-                const tile_d2 hi = *reinterpret_cast<const tile_d2 *>(&sObs[(us & 15) * 16 + 4 * q + 2]);
-                in.o[0] = lo[0];
-                in.o[1] = lo[1];
-                in.o[2] = hi[0];
-                in.o[3] = hi[1];
-            } else if constexpr (KIND == EMIT_DISC) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    in.sym[r] = __double2loint(sObs[(us & 15) * 16 + 4 * q + r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int nl = meta(r, 2) > 0 ? meta(r, 2) - 1 : 0;
-                    const int64_t g = meta_gtop(r) - min(us, nl);
-#pragma unroll
-                    for (int c = 0; c < TPW; ++c)
-                        in.p[c][r] = real[c] ? static_cast<const double *>(obs_rm)[g * n + 16 * (w + 4 * c) + s] : 0.0;
-                }
-            }
-        };
-        auto emit_to_lds = [&](const TileIn<KIND, TPW> &in, int slot) __attribute__((always_inline)) {
-            double p[TPW][4];
-            tile_emit4<NT, KIND, TPW>(m, in, w, s, real, mu_j, ga_j, gb_j, p);
-#pragma unroll
-            for (int c = 0; c < TPW; ++c) {
-                *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 0, lane)]) = tile_d2{p[c][0], p[c][1]};
-                *reinterpret_cast<tile_d2 *>(&sP[tile_p_index<TPW>(slot, w, c, 1, lane)]) = tile_d2{p[c][2], p[c][3]};
-            }
-        };
-        ARow ringA[TILE_PF];
-        int ringX[TILE_PF];
 #pragma unroll
         for (int u = 0; u < TILE_PF; ++u) {
             loadA(ringA[u], u);
@@ -858,72 +893,44 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
         if (w == 1 && lane < 16)
             sEx[xpos] = ringX[0];
         ringX[0] = loadX(TILE_PF);
-        __syncthreads(); // (the first observations are in LDS)
-        {
-            TileIn<KIND, TPW> in0;
-            fetch_in(in0, 0);
-            emit_to_lds(in0, 0);
-            fetch_in(in0, 1);
-            emit_to_lds(in0, 1);
-        }
-        __syncthreads(); // (the emission rows of steps 0 and 1, alpha for step 0 are in LDS)
-        if (any_enter_at(0)) {
-            __syncthreads();
-            __syncthreads();
-        }
-        __syncthreads(); // (end of the prologue)
-        auto step = [&](int us, auto uc, auto mc, auto) __attribute__((always_inline)) {
-            constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
-            if constexpr (MODE == TM_GEN) { // the barriers of the matrix wavefronts' exchanges
-                if (any_last_at(us)) {
-                    __syncthreads();
-                    __syncthreads();
-                }
-                if (any_enter_at(us + 1)) {
-                    __syncthreads();
-                    __syncthreads();
-                }
+    };
+    auto s_prologue2 = [&]() __attribute__((always_inline)) {
+        TileIn<KIND, TPW> in0;
+        fetch_in(in0, 0);
+        emit_to_lds(in0, 0);
+        fetch_in(in0, 1);
+        emit_to_lds(in0, 1);
+    };
+    auto s_step = [&](int us, auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        // alpha / exponent for the back half of step us + 1; the loads of four steps further
+        a_to_lds(ringA[(u + 1) & 3], (u + 1) & 1);
+        loadA(ringA[(u + 1) & 3], us + 1 + TILE_PF);
+        if (w == 1 && lane < 16)
+            sEx[((u + 1) & 1) * 16 + xpos] = ringX[(u + 1) & 3];
+        ringX[(u + 1) & 3] = loadX(us + 1 + TILE_PF);
+        if constexpr (KIND != EMIT_EXPL && u == 0) {
+            if (w == 0) { // the observations of the group two ahead go to LDS, the next ones are fetched
+                sObs[((us + 8 + ldt) & 15) * 16 + lpos] = pend;
+                pend = obs_load(us + 12 + ldt);
             }
-            // alpha / exponent for the back half of step us + 1; the loads of four steps further
-            a_to_lds(ringA[(u + 1) & 3], (u + 1) & 1);
-            loadA(ringA[(u + 1) & 3], us + 1 + TILE_PF);
-            if (w == 1 && lane < 16)
-                sEx[((u + 1) & 1) * 16 + xpos] = ringX[(u + 1) & 3];
-            ringX[(u + 1) & 3] = loadX(us + 1 + TILE_PF);
-            if constexpr (KIND != EMIT_EXPL && u == 0) {
-                if (w == 0) { // the observations of the group two ahead go to LDS, the next ones are fetched
-                    sObs[((us + 8 + ldt) & 15) * 16 + lpos] = pend;
-                    pend = obs_load(us + 12 + ldt);
-                }
-            }
-            // the emission row of step us + 2
-            TileIn<KIND, TPW> ein;
-            fetch_in(ein, us + 2);
-            emit_to_lds(ein, u & 1);
-            __syncthreads();
-        };
-        run(step, 0, g1, tile_ic<TM_WARM>{});
-        run(step, g1, g2, tile_ic<TM_GEN>{});
-        run(step, g2, g3, tile_ic<TM_MAIN>{});
-        run(step, g3, g4, tile_ic<TM_GEN>{});
-        __syncthreads(); // (the gamma mass check of the matrix wavefronts)
-        __syncthreads();
-        return;
-    }
+        }
+        // the emission row of step us + 2
+        TileIn<KIND, TPW> ein;
+        fetch_in(ein, us + 2);
+        emit_to_lds(ein, u & 1);
+    };
 
-    // ================= matrix wavefronts ==========================================================
-    __builtin_amdgcn_s_setprio(3); // (the serial chain runs here, see k_tile_fwd)
+    // ================= the matrix part ============================================================
     double Breg[TPW * KK]; // my blocks of A^T (B operand of the beta product)
-    double mu_j[TPW];
 #pragma unroll
     for (int c = 0; c < TPW; ++c) {
         const int i = 16 * (w + 4 * c) + s; // my state: row i of A
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const int j = q * KK + kk;
-            Breg[c * KK + kk] = (real[c] && (FULL || j < n)) ? m.A[(int64_t)i * n + j] : 0.0;
+            Breg[c * KK + kk] = (matrix && real[c] && (FULL || j < n)) ? m.A[(int64_t)i * n + j] : 0.0;
         }
-        mu_j[c] = (KIND == EMIT_GAUSS && real[c]) ? m.mu[i] : 0.0;
     }
     int xw[4], xq[4];
 #pragma unroll
@@ -949,11 +956,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
     double *mytab = nullptr;
     if constexpr (KIND == EMIT_DISC) {
         mytab = dstat + ((int64_t)blockIdx.x * 4 + q) * n * m.M;
+        if (matrix) {
 #pragma unroll
-        for (int c = 0; c < TPW; ++c)
-            if (real[c])
-                for (int z = 0; z < m.M; ++z)
-                    mytab[(int64_t)(16 * (w + 4 * c) + s) * m.M + z] = 0.0;
+            for (int c = 0; c < TPW; ++c)
+                if (real[c])
+                    for (int z = 0; z < m.M; ++z)
+                        mytab[(int64_t)(16 * (w + 4 * c) + s) * m.M + z] = 0.0;
+        }
     }
 
     // alpha of time t - 1 and the exponent removed at t: from the LDS slot the stream wavefronts filled
@@ -1106,10 +1115,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
         }
     };
 
-    __syncthreads(); // (the stream wavefronts: first observations in LDS ...
-    __syncthreads(); //  ... the emission rows of steps 0 and 1, alpha for step 0 in LDS)
     // prologue: the front half of step 0
-    {
+    auto m_prologue = [&]() __attribute__((always_inline)) {
         tile_d2 pl[TPW][2], ol[2];
         double fg[4] = {0.0, 0.0, 0.0, 0.0};
         bool mainr[4];
@@ -1124,10 +1131,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
         fetch_p(0, pl, ol);
         front_chain(0, tile_ic<0>{}, tile_ic<TM_GEN>{}, fg, mainr, pl, a0);
         front_stats(0, tile_ic<TM_GEN>{}, fg, mainr, ol, a0);
-        __syncthreads();
-    }
+    };
 
-    auto step = [&](int us, auto uc, auto mc, auto lc) __attribute__((always_inline)) {
+    unsigned long long pc = 0; // (probe: end of the previous step's work)
+    auto m_step = [&](int us, auto uc, auto mc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
         bool mainr[4], lastr[4];
         int tt[4];
@@ -1151,20 +1158,24 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
         fetch_a(u & 1, in);
         // ---- back half of step us: beta_{t-1} (raw) = A (p_t o beta_t) ----------------------------
         const double *X = sX + (u & 1) * 16 * PX;
-        tile_d2 av[KK / 2];
-#pragma unroll
-        for (int k2 = 0; k2 < KK / 2; ++k2)
-            av[k2] = *reinterpret_cast<const tile_d2 *>(X + xr + 2 * k2);
         tile_d2 pl[TPW][2], ol[2];
         fetch_p(us + 1, pl, ol); // emission row / observations of step us + 1
         wide_d4 acc[TPW];
+        constexpr int CH = KK < 8 ? KK : 8; // (operands in pieces of eight, see k_tile_fwd)
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
+        for (int k0 = 0; k0 < KK; k0 += CH) {
+            tile_d2 av[CH / 2];
 #pragma unroll
-            for (int c = 0; c < TPW; ++c)
-                if (NT % 4 == 0 || w + 4 * c < NT)
-                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk >> 1][kk & 1], Breg[c * KK + kk],
-                                                                  kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+            for (int k2 = 0; k2 < CH / 2; ++k2)
+                av[k2] = *reinterpret_cast<const tile_d2 *>(X + xr + k0 + 2 * k2);
+#pragma unroll
+            for (int kk = k0; kk < k0 + CH; ++kk)
+#pragma unroll
+                for (int c = 0; c < TPW; ++c)
+                    if (NT % 4 == 0 || w + 4 * c < NT)
+                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[(kk - k0) >> 1][(kk - k0) & 1], Breg[c * KK + kk],
+                                                                      kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+        }
         unsigned long long c1 = 0;
         if (pr) {
             asm volatile("" ::"v"(acc[0][0]));
@@ -1272,22 +1283,77 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_bwd(const WideModel m, co
             }
         }
         front_stats(us + 1, mc, fg, mainn, ol, in.ap);
-        const unsigned long long c3 = pr ? __builtin_readcyclecounter() : 0;
-        __syncthreads();
         if (pr && lane == 0) {
-            const unsigned long long c4 = __builtin_readcyclecounter();
+            const unsigned long long c3 = __builtin_readcyclecounter();
             const int o = MODE == TM_WARM ? 0 : 8;
             probe[o + 0] += c1 - c0;
             probe[o + 1] += c2 - c1;
             probe[o + 2] += c3 - c2;
-            probe[o + 3] += c4 - c3;
+            probe[o + 3] += pc ? c0 - pc : 0;
             probe[o + 4] += 1;
+            pc = c3;
         }
     };
-    run(step, 0, g1, tile_ic<TM_WARM>{});
-    run(step, g1, g2, tile_ic<TM_GEN>{});
-    run(step, g2, g3, tile_ic<TM_MAIN>{});
-    run(step, g3, g4, tile_ic<TM_GEN>{});
+
+    // ================= the loop ===================================================================
+    auto run_all = [&](auto &&step) __attribute__((always_inline)) {
+        run(step, 0, g1, tile_ic<TM_WARM>{});
+        run(step, g1, g2, tile_ic<TM_GEN>{});
+        run(step, g2, g3, tile_ic<TM_MAIN>{});
+        run(step, g3, g4, tile_ic<TM_GEN>{});
+    };
+    if constexpr (SPLIT) {
+        if (!matrix) {
+            s_prologue1();
+            __syncthreads(); // (the first observations are in LDS)
+            s_prologue2();
+            __syncthreads(); // (the emission rows of steps 0 and 1, alpha for step 0 are in LDS)
+            if (any_enter_at(0)) { // (the barriers of the matrix wavefronts' exchanges, here and below)
+                __syncthreads();
+                __syncthreads();
+            }
+            __syncthreads(); // (end of the prologue)
+            run_all([&](int us, auto uc, auto mc, auto) __attribute__((always_inline)) {
+                constexpr int MODE = decltype(mc)::value;
+                if constexpr (MODE == TM_GEN) {
+                    if (any_last_at(us)) {
+                        __syncthreads();
+                        __syncthreads();
+                    }
+                    if (any_enter_at(us + 1)) {
+                        __syncthreads();
+                        __syncthreads();
+                    }
+                }
+                s_step(us, uc);
+                __syncthreads();
+            });
+            __syncthreads(); // (the gamma mass check)
+            __syncthreads();
+            return;
+        }
+        __builtin_amdgcn_s_setprio(3); // (the serial chain runs here, see k_tile_fwd)
+        __syncthreads();
+        __syncthreads();
+        m_prologue();
+        __syncthreads();
+        run_all([&](int us, auto uc, auto mc, auto) __attribute__((always_inline)) {
+            m_step(us, uc, mc);
+            __syncthreads();
+        });
+    } else {
+        s_prologue1();
+        __syncthreads();
+        s_prologue2();
+        __syncthreads();
+        m_prologue();
+        __syncthreads();
+        run_all([&](int us, auto uc, auto mc, auto) __attribute__((always_inline)) {
+            m_step(us, uc, mc);
+            s_step(us, uc);
+            __syncthreads();
+        });
+    }
 
     // ---- self-check: unit gamma mass per step of every row -------------------------------------
     {

@@ -103,7 +103,7 @@ static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
         probe = reinterpret_cast<unsigned long long *>(c->d_probe.p);
         BHMM_HIP(hipMemsetAsync(probe, 0, 64, c->stream));
     }
-    hipLaunchKernelGGL((k_tile_fwd<4, KIND, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
+    hipLaunchKernelGGL((k_tile_fwd<4, KIND, true, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p, c->d_alpha_rm.p,
                        c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p, probe);
     BHMM_HIP(hipGetLastError());
@@ -141,7 +141,7 @@ static int tile_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
         probe = reinterpret_cast<unsigned long long *>(c->d_probe.p) + 16;
         BHMM_HIP(hipMemsetAsync(probe, 0, 128, c->stream));
     }
-    hipLaunchKernelGGL((k_tile_bwd<4, KIND, true, false>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
+    hipLaunchKernelGGL((k_tile_bwd<4, KIND, true, false, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
                        (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
                        c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,

@@ -376,6 +376,7 @@ def test_forward_pass_on_its_own_finer_segments():
     res = {}
     for tag, opts in (("serial", {"wide_segments": 0}), ("common", {"wide_split": 0}), ("split", {"wide_split": 1})):
         eng = Engine(0)
+        eng.set_option("tile", 0)      # (the one-segment-per-wavefront kernels: the tile kernels have one plan)
         eng.set_option("spec_W", 32)
         eng.set_option("wide_segment_len", 1000)
         for k, v in opts.items():
