@@ -16,6 +16,10 @@ namespace bhmm {
 int invalid_arg(const std::string &msg);
 int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, const double *par0,
                    const double *par1, WideModel &m);
+// tile_gen.hip: up to 128 states on the row-batched matrix-core kernels
+bool tile_gen_capable(const bhmm_ctx *c);
+int tile_gen_alloc(bhmm_ctx *c);
+int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags, bool *done);
 
 namespace {
 
@@ -108,6 +112,8 @@ int gen_alloc(bhmm_ctx *c)
     if ((rc = c->d_alpha_rm.ensure(rows)) || (rc = c->d_logLk.ensure(K)) ||
         (rc = c->d_gamma0.ensure((size_t)K * n)) || (rc = c->d_stats.ensure(S)))
         return rc;
+    if (tile_gen_capable(c) && (rc = tile_gen_alloc(c)))
+        return rc;
     return BHMM_OK;
 }
 
@@ -162,6 +168,13 @@ int gen_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0
     int rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m);
     if (rc)
         return rc;
+    {
+        // up to 128 states: the row-batched matrix-core kernels (tolerance-compared statistics); the
+        // order-faithful kernels below where those do not apply or left their range
+        bool done = false;
+        if ((rc = tile_gen_estep(c, m, stats_dev, flags, &done)) || done)
+            return rc;
+    }
     const int n = c->n, K = c->K;
     const bool sg = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
     const int nsplit = gen_nsplit(c);

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_backward(
 // v_mfma_f64_16x16x4: lane = 16 k + i holds A-operand element (i, k) and B-operand element (k, i);
 // result register r of lane l is element (row (l >> 4) + 4 r, column l & 15).
 typedef double gen_v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_gen_xi_gemm(const double *alpha, const double *W,
+[[maybe_unused]] static __global__ __launch_bounds__(256) void k_gen_xi_gemm(const double *alpha, const double *W,
                                                      int64_t total, int n, int nsplit, double *part)
 {
     const int tiles = (n + 31) / 32;
@@ -525,7 +525,7 @@ __global__ void k_gen_finalize(const WideModel m, int K, int nsplit, const doubl
 
 // W rows from GIVEN alpha / beta / pobs (single-trajectory bhmm_transition_counts, _hidden.c:148-183):
 // one workgroup per step t < T - 1.
-__global__ __launch_bounds__(GEN_TPB) void k_gen_w_rows(const double *At, int n, int64_t T,
+[[maybe_unused]] static __global__ __launch_bounds__(GEN_TPB) void k_gen_w_rows(const double *At, int n, int64_t T,
                                                         const double *pobs, const double *alpha,
                                                         const double *beta, double *W)
 {
@@ -799,7 +799,7 @@ __global__ void k_gen_pack_path_stats(const WideModel m, int K, const unsigned l
     }
 }
 
-__global__ void k_gen_transpose(const double *A, int n, double *At)
+[[maybe_unused]] static __global__ void k_gen_transpose(const double *A, int n, double *At)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (int64_t)n * n)

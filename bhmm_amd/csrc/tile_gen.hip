@@ -1,0 +1,298 @@
+// tile_gen.hip -- more than 64 (up to 128) hidden states on the row-batched matrix-core kernels
+// (tile_kernels.hpp): the E-step of the any-N family (gen_api.hip) without its order-faithful,
+// one-workgroup-per-trajectory recursions -- those stay for Viterbi / path sampling (bit-exact) and as
+// the fallback of this path.  Reference: bhmm/hidden/impl_c/_hidden.c:42-63,91-109,148-183.
+//
+// Time segments with verified warm-up boundaries as for 64 states (wide_api.hip); the warm-up length
+// is calibrated with forward passes alone (each leaves, at every segment boundary, the distance between
+// the warmed-up vector and the one the neighbouring segment computed -- the curve k_wide_probe measures
+// for up to 64 states); the xi counts are the time-parallel GEMM of gen_kernels.hpp over the rows
+// W_{t-1} = p_t o beta_t / S the backward pass stores.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "host_common.hpp"
+#include "plan.hpp"
+#include "gen_kernels.hpp"
+#include "tile_kernels.hpp"
+
+namespace bhmm {
+int wide_plan_pub(bhmm_ctx *c, int which, int64_t seglen);
+Segs wide_segs_pub(bhmm_ctx *c, int which);
+
+bool tile_gen_capable(const bhmm_ctx *c) { return c->tile_enabled && c->gen && c->n <= 128; }
+
+namespace {
+
+int64_t max_len(const bhmm_ctx *c)
+{
+    int64_t maxT = 0;
+    for (int k = 0; k < c->K; ++k)
+        maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+    return maxT;
+}
+
+// segments that fill the chip (16 per workgroup, one workgroup per compute unit), but at least two
+// warm-ups long
+int64_t fill_len(const bhmm_ctx *c)
+{
+    const int64_t want = 16 * (int64_t)(c->num_simd / 4) * c->tile_per_cu;
+    return std::max<int64_t>(((c->total + want - 1) / want + 3) & ~(int64_t)3, 16);
+}
+
+int plan_for(bhmm_ctx *c, int W)
+{
+    int64_t seglen = c->wseg_len > 0 ? (int64_t)c->wseg_len : std::max<int64_t>(fill_len(c), 2 * (int64_t)W);
+    seglen = std::max(seglen, c->wseg_cur_len); // never more segments than allocated for
+    if (seglen >= max_len(c))
+        seglen = 0; // one segment per trajectory: no boundaries to verify
+    if (c->w_nseg[1] > 0 && seglen == c->wseg_cur_len)
+        return BHMM_OK;
+    c->wseg_cur_len = seglen;
+    return wide_plan_pub(c, 1, seglen);
+}
+
+template <int NT, int KIND>
+int launch_fwd(bhmm_ctx *c, const WideModel &m)
+{
+    const Segs sg = wide_segs_pub(c, 1);
+    const TilePlan tp{c->d_tile_seg[1].p, c->w_ntiles[1]};
+    hipLaunchKernelGGL((k_tile_fwd<NT, KIND, false, false>), dim3(tp.ntiles), dim3(tile_threads<false>()), 0,
+                       c->stream, m, (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
+                       c->d_alpha_rm.p, c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p,
+                       c->d_specres.p, (unsigned long long *)nullptr);
+    BHMM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_tile_logl, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg, c->n,
+                       (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
+                       (const int32_t *)c->d_wePseg.p, c->d_wlogLseg.p, c->d_specres.p);
+    hipLaunchKernelGGL(k_logl, dim3(c->K), dim3(64), 0, c->stream, (const int32_t *)c->d_wseg_traj0[1].p,
+                       c->K, (const double *)c->d_wlogLseg.p, c->d_logLk.p);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+template <int NT, int KIND>
+int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
+{
+    const Segs sg = wide_segs_pub(c, 1);
+    const TilePlan tp{c->d_tile_segb[1].p, c->w_ntilesb[1]};
+    const int n = c->n;
+    const int tiles = (n + 31) / 32;
+    const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>({4096 / ((int64_t)tiles * tiles) + 1,
+                                                                    (c->total + 63) / 64, (int64_t)256}));
+    int rc;
+    if ((rc = c->d_gW.ensure((size_t)c->total * n)) || (rc = c->d_gxipart.ensure((size_t)nsplit * n * n)))
+        return rc;
+    hipLaunchKernelGGL(k_wide_zero_last_rows, dim3(c->K), dim3(64), 0, c->stream, (const int64_t *)c->d_offsets.p,
+                       c->K, n, c->d_gW.p);
+    hipLaunchKernelGGL((k_tile_bwd<NT, KIND, false, true, false>), dim3(tp.ntiles), dim3(tile_threads<false>()), 0,
+                       c->stream, m, (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
+                       (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
+                       c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
+                       c->d_gW.p, (unsigned long long *)nullptr);
+    BHMM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_gen_xi_gemm, dim3(tiles * tiles, nsplit), dim3(256), 0, c->stream,
+                       (const double *)c->d_alpha_rm.p, (const double *)c->d_gW.p, c->total, n, nsplit,
+                       c->d_gxipart.p);
+    const int64_t nfin = (int64_t)n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0) +
+                         (KIND == EMIT_DISC ? (int64_t)n * c->M : 0) + n + 1;
+    hipLaunchKernelGGL((k_tile_finalize_xig<KIND>), dim3((unsigned)nfin), dim3(64), 0, c->stream, m, c->K, tp.ntiles,
+                       nsplit, (const double *)c->d_gxipart.p, (const double *)c->d_partials.p,
+                       (const double *)c->d_dpartials.p, (const double *)c->d_logLk.p,
+                       (const double *)c->d_gamma0.p, stats_dev);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+#define TILE_GEN_DISPATCH(fn, ...)                                                                       \
+    (c->kind == EMIT_GAUSS  ? (c->n <= 96 ? fn<6, EMIT_GAUSS>(__VA_ARGS__) : fn<8, EMIT_GAUSS>(__VA_ARGS__)) \
+     : c->kind == EMIT_DISC ? (c->n <= 96 ? fn<6, EMIT_DISC>(__VA_ARGS__) : fn<8, EMIT_DISC>(__VA_ARGS__))   \
+                            : (c->n <= 96 ? fn<6, EMIT_EXPL>(__VA_ARGS__) : fn<8, EMIT_EXPL>(__VA_ARGS__)))
+
+// boundary check of one direction (0 forward, 1 backward): flags -> host
+int run_check(bhmm_ctx *c, int dir)
+{
+    const Segs sg = wide_segs_pub(c, 1);
+    if (dir == 0)
+        hipLaunchKernelGGL(k_wide_check, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg, c->n,
+                           (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
+                           (const double *)nullptr, (const double *)nullptr, 1e-11, c->d_specres.p);
+    else
+        hipLaunchKernelGGL(k_wide_check, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg, c->n,
+                           (const double *)nullptr, (const double *)nullptr, (const double *)c->d_wbexit.p,
+                           (const double *)c->d_wbentry.p, 1e-11, c->d_specres.p);
+    BHMM_HIP(hipGetLastError());
+    return BHMM_OK;
+}
+
+int read_flags(bhmm_ctx *c)
+{
+    BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost,
+                            c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    return BHMM_OK;
+}
+
+// The warm-up length from forward passes: deviation at the segment boundaries after W steps, twice,
+// and the geometric decay between the two (the filter forgets its start vector) extrapolated to 1e-13.
+int calibrate(bhmm_ctx *c, const WideModel &m, bool *usable)
+{
+    *usable = false;
+    const int64_t maxT = max_len(c);
+    int W = std::max(16, (c->spec_W_fixed ? c->spec_W : 32) / 8 * 8);
+    double prevW = 0.0, prevdev = 1.0;
+    for (int it = 0; it < 8; ++it) {
+        c->spec_W = W;
+        int rc = plan_for(c, W);
+        if (rc)
+            return rc;
+        if (c->w_nseg[1] <= c->w_nseg[0]) { // no time segmentation (short trajectories): nothing to verify
+            *usable = true;
+            return BHMM_OK;
+        }
+        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 3 * sizeof(unsigned int), c->stream));
+        if ((rc = TILE_GEN_DISPATCH(launch_fwd, c, m)) || (rc = run_check(c, 0)) || (rc = read_flags(c)))
+            return rc;
+        if (c->h_specres[2]) { // left the range of the lazily scaled kernels: the order-faithful family
+            c->wide_trouble = c->h_specres[2];
+            return BHMM_OK;
+        }
+        float devf;
+        memcpy(&devf, &c->h_specres[1], sizeof(float));
+        const double dev = std::max((double)devf, 1e-300);
+        c->spec_last_dev = devf;
+        if (c->h_specres[0] == 0 && dev <= 3e-13) {
+            *usable = true;
+            return BHMM_OK;
+        }
+        if (c->spec_W_fixed)
+            return BHMM_OK; // the caller's warm-up does not verify: not ours to change
+        double Wn;
+        if (prevW > 0.0 && dev < 0.5 * prevdev) {
+            const double rate = log(prevdev / dev) / ((double)W - prevW); // per step
+            Wn = W + 1.25 * log(dev / 1e-13) / rate;
+        } else {
+            Wn = 2.0 * W;
+        }
+        prevW = W;
+        prevdev = dev;
+        W = (int)std::min<double>(std::max(Wn, W + 8.0), 4.0 * W + 64.0);
+        W = (W + 7) / 8 * 8;
+        if (W >= maxT / 2)
+            return BHMM_OK; // chains that do not forget within the trajectories: serial family
+    }
+    return BHMM_OK;
+}
+
+} // namespace
+
+int tile_gen_alloc(bhmm_ctx *c)
+{
+    const int n = c->n;
+    c->N = 64; // (not used by this family; wide_fill_len never sees these contexts)
+    int rc;
+    if ((rc = wide_plan_pub(c, 0, 0)))
+        return rc;
+    c->w_nseg[1] = 0;
+    c->wseg_cur_len = 0;
+    c->spec_calibrated = c->spec_W_fixed && false;
+    c->wseg_given_up = false;
+    c->wide_careful = false;
+    // buffers for the finest plan there can be
+    const int64_t minlen = c->wseg_len > 0 ? (int64_t)c->wseg_len : fill_len(c);
+    int64_t nsmax = c->K;
+    for (int k = 0; k < c->K; ++k)
+        nsmax += (c->offsets[k + 1] - c->offsets[k]) / std::max<int64_t>(minlen & ~(int64_t)3, 4) + 1;
+    const size_t S = (size_t)n * n + 3 * n;
+    const size_t ntmax = (size_t)nsmax / 16 + 3;
+    if ((rc = c->d_wlogLseg.ensure(nsmax)) || (rc = c->d_wePseg.ensure(nsmax)) ||
+        (rc = c->d_waentry.ensure((size_t)nsmax * n)) || (rc = c->d_waexit.ensure((size_t)nsmax * n)) ||
+        (rc = c->d_wbexit.ensure((size_t)nsmax * n)) || (rc = c->d_wbentry.ensure((size_t)nsmax * n)) ||
+        (rc = c->d_wexp.ensure((size_t)std::max<int64_t>(c->total, 1))) || (rc = c->d_specres.ensure(4)) ||
+        (rc = c->d_partials.ensure(ntmax * S)))
+        return rc;
+    if (c->kind == EMIT_DISC && (rc = c->d_dpartials.ensure(4 * ntmax * (size_t)n * c->M)))
+        return rc;
+    if (!c->h_specres)
+        BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
+                               hipHostMallocDefault));
+    BHMM_HIP(hipMemsetAsync(c->d_gamma0.p, 0, (size_t)std::max(c->K, 1) * n * sizeof(double), c->stream));
+    return BHMM_OK;
+}
+
+// *done: statistics are in stats_dev, verified; else the caller runs the order-faithful kernels
+int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags, bool *done)
+{
+    *done = false;
+    c->tile_used = false;
+    if (!tile_gen_capable(c) || c->wseg_given_up || c->wide_careful || !c->wseg_enabled)
+        return BHMM_OK;
+    int rc;
+    if (!c->spec_calibrated) {
+        c->spec_calibrated = true;
+        bool usable = false;
+        if ((rc = calibrate(c, m, &usable)))
+            return rc;
+        if (!usable) {
+            c->wseg_given_up = true;
+            return BHMM_OK;
+        }
+    }
+    const bool sg = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
+    if (sg && (rc = c->d_gamma_ci.ensure((size_t)c->total * c->n)))
+        return rc;
+    double *gam = sg ? c->d_gamma_ci.p : nullptr;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 3 * sizeof(unsigned int), c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[0], c->stream));
+        if ((rc = TILE_GEN_DISPATCH(launch_fwd, c, m)))
+            return rc;
+        BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[2], c->stream));
+        if ((rc = TILE_GEN_DISPATCH(launch_bwd, c, m, gam, stats_dev)))
+            return rc;
+        BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
+        const bool segmented = c->w_nseg[1] > c->w_nseg[0];
+        if (segmented && ((rc = run_check(c, 0)) || (rc = run_check(c, 1))))
+            return rc;
+        if ((rc = read_flags(c)))
+            return rc;
+        c->wide_trouble = c->h_specres[2];
+        if (c->h_specres[2]) { // out of the lazily scaled kernels' range on these data: stay away
+            c->wide_careful = true;
+            return BHMM_OK;
+        }
+        float devf;
+        memcpy(&devf, &c->h_specres[1], sizeof(float));
+        c->spec_last_dev = devf;
+        if (!segmented || c->h_specres[0] == 0) {
+            c->spec_ok++;
+            c->ev_pending = true;
+            c->tile_used = true;
+            *done = true;
+            return BHMM_OK;
+        }
+        c->spec_fail++;
+        // the model has moved to slower forgetting: extrapolate (geometric decay) and try again
+        if (c->spec_W_fixed)
+            break;
+        const double d = std::min(std::max((double)devf, 1e-300), 0.5);
+        const double f = std::min(std::max(log(1e-13) / log(d), 1.25), 4.0);
+        const int Wn = ((int)ceil(c->spec_W * f) + 7) / 8 * 8;
+        if (Wn >= max_len(c) / 2)
+            break;
+        c->spec_W = Wn;
+        if ((rc = plan_for(c, Wn)))
+            return rc;
+    }
+    c->wseg_given_up = true;
+    return BHMM_OK;
+}
+
+} // namespace bhmm

@@ -674,7 +674,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
     __shared__ double sS[64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool matrix = !SPLIT || wid < 4, stream = !SPLIT || wid >= 4;
+    const bool matrix = !SPLIT || wid < 4;
     const int w = wid & 3;
     const int s = lane & 15, q = lane >> 4;
     const int n = FULL ? NP : m.n;
@@ -1405,6 +1405,66 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
             }
         }
     }
+}
+
+// packed statistics (bhmm_amd.h layout) of a pass whose xi counts come from the time-parallel GEMM
+// (XIG): C = A o sum of the GEMM's split partials; everything else from the tiles' partial blocks.
+// One wavefront per output entry, fixed summation order.
+template <int KIND>
+__global__ __launch_bounds__(64) void k_tile_finalize_xig(const WideModel m, int K, int ntiles, int nsplit,
+                                                          const double *xipart, const double *part,
+                                                          const double *dstat, const double *logL_k,
+                                                          const double *gamma0, double *stats)
+{
+    const int n = m.n;
+    const int64_t nn = (int64_t)n * n;
+    const int S = n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0); // (the tiles' block layout, C' part unused)
+    const int nE = KIND == EMIT_GAUSS ? 2 * n : 0;
+    const int64_t MN = KIND == EMIT_DISC ? (int64_t)n * m.M : 0;
+    const int64_t oG0 = 1, oC = 1 + n, oSG = oC + nn, oE = oSG + n;
+    const int lane = threadIdx.x;
+    int64_t e = blockIdx.x;
+    double s = 0.0;
+    if (e < nn) {
+        for (int k = lane; k < nsplit; k += 64)
+            s += xipart[(int64_t)k * nn + e];
+        s = wave_sum(s);
+        if (lane == 0)
+            stats[oC + e] = s * m.A[e];
+        return;
+    }
+    e -= nn;
+    if (e < n + nE) {
+        for (int k = lane; k < ntiles; k += 64)
+            s += part[(int64_t)k * S + nn + e];
+        s = wave_sum(s);
+        if (lane == 0)
+            stats[(e < n ? oSG : oE - n) + e] = s;
+        return;
+    }
+    e -= n + nE;
+    if (e < MN) {
+        for (int k = lane; k < 4 * ntiles; k += 64)
+            s += dstat[(int64_t)k * MN + e];
+        s = wave_sum(s);
+        if (lane == 0)
+            stats[oE + e] = s;
+        return;
+    }
+    e -= MN;
+    if (e < n) {
+        for (int k = lane; k < K; k += 64)
+            s += gamma0[(int64_t)k * n + e];
+        s = wave_sum(s);
+        if (lane == 0)
+            stats[oG0 + e] = s;
+        return;
+    }
+    for (int k = lane; k < K; k += 64)
+        s += logL_k[k];
+    s = wave_sum(s);
+    if (lane == 0)
+        stats[0] = s;
 }
 
 } // namespace bhmm

@@ -86,7 +86,7 @@ static int wide_fwd_plan(const bhmm_ctx *c, int which)
 }
 
 // 64 states: the lazily scaled E-step runs on the row-batched matrix-core kernels (tile_kernels.hpp)
-static bool wide_tile(const bhmm_ctx *c) { return c->tile_enabled && c->n == 64; }
+static bool wide_tile(const bhmm_ctx *c) { return c->tile_enabled && (c->n == 64 || (c->gen && c->n <= 128)); }
 
 template <int KIND>
 static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
@@ -340,6 +340,9 @@ static int wide_plan_segments(bhmm_ctx *c, int64_t seglen)
     }
     return rc;
 }
+
+int wide_plan_pub(bhmm_ctx *c, int which, int64_t seglen) { return wide_plan(c, which, seglen); }
+Segs wide_segs_pub(bhmm_ctx *c, int which) { return segs_of(c, which); }
 
 int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, const double *par0,
                    const double *par1, WideModel &m)
