@@ -1301,6 +1301,8 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
         c->spec_W = 288;
     c->vit_W = 0;
     c->wide_replans = 0;
+    c->tile_settle = 0;
+    c->tile_W_good = 0;
     c->wseg_given_up = false;
     c->wide_careful = false;
     // discrete alphabets whose emission / count tables do not fit the LDS of the sweep kernels

@@ -165,6 +165,8 @@ struct bhmm_ctx {
     bhmm::DevBuf<int32_t> d_wexp;    // [total] exponent the forward pass removed at every step
     bhmm::DevBuf<int32_t> d_wePseg;  // [segments] ... summed over the main part of every segment
     unsigned int wide_trouble = 0;   // flag word of the last lazily scaled E-step (which self-check fired)
+    int tile_settle = 0;             // warm-up refinements done for these observations (at most 4, first E-step)
+    int tile_W_good = 0;             // ... the last warm-up that verified
     bool tile_used = false;          // the last E-step ran on the tile kernels
     bool wseg_enabled = true;
     bool wseg_split = true;     // 64 states: own, finer plan for the forward pass (wide_plan_segments)

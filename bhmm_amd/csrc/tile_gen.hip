@@ -276,7 +276,29 @@ int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags
             c->ev_pending = true;
             c->tile_used = true;
             *done = true;
+            // (first E-step on these observations: more than two decades inside the tolerance -> 10 %
+            // shorter and once more, at most four times; wide_api.hip)
+            if (segmented && !c->spec_W_fixed && c->tile_settle < 4 && devf > 0.f && devf < 1e-13f) {
+                const double f = std::max(log(3e-13) / log((double)devf), 0.9);
+                const int Wn = std::max(16, ((int)ceil(c->spec_W * f) + 7) / 8 * 8);
+                if (Wn < c->spec_W) {
+                    ++c->tile_settle;
+                    c->tile_W_good = c->spec_W;
+                    c->spec_W = Wn;
+                    *done = false;
+                    attempt = -1; // (not an attempt after a failure)
+                    continue;
+                }
+            }
+            c->tile_settle = 4;
             return BHMM_OK;
+        }
+        if (c->tile_W_good > c->spec_W && c->tile_settle > 0 && c->tile_settle <= 4) {
+            c->spec_W = c->tile_W_good; // a refinement too far: back to the warm-up that verified, for good
+            c->tile_W_good = 0;
+            c->tile_settle = 5;
+            attempt = -1;
+            continue;
         }
         c->spec_fail++;
         // the model has moved to slower forgetting: extrapolate (geometric decay) and try again

@@ -275,8 +275,9 @@ def test_configs3_full_size_properties():
     eng = Engine(0)
     eng.set_observations_device("gaussian", obs.data_ptr(), off, n)
     assert eng.get_option("wide_segments") >= 1024
-    res = eng.estep(*args)                  # the probe sets a warm-up that verifies at once
-    assert eng.get_option("spec_ok") == 1 and eng.get_option("spec_fail") == 0
+    res = eng.estep(*args)                  # the probe sets a warm-up that verifies at once (the tile
+    #                                         kernels then refine it with up to four more verified runs)
+    assert 1 <= eng.get_option("spec_ok") <= 5 and eng.get_option("spec_fail") == 0
     assert eng.get_option("spec_last_dev") < 1e-11 and eng.get_option("spec_W") > 288  # measured
     assert eng.get_option("careful") == 0.0
     assert np.all(np.isfinite(res.logL_k))

@@ -26,7 +26,7 @@ def run(tile, per_cu=1, W=None):
     if W:
         eng.set_option("spec_W", W)
     eng.set_observations_device("gaussian", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, n)
-    for _ in range(3):
+    for _ in range(12):
         r = eng.estep(*args)
     dt = timeit(lambda: eng.estep(*args), 3)
     r = eng.estep(*args)
