@@ -145,6 +145,14 @@ __device__ __forceinline__ void tile_emit4(const WideModel &m, const TileIn<KIND
                                            const double (&ga_j)[TPW], const double (&gb_j)[TPW],
                                            double (&p)[TPW][4])
 {
+#ifdef TILE_X_NOEMIT
+#pragma unroll
+    for (int c = 0; c < TPW; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            p[c][r] = real[c] ? 0.05 : 0.0;
+    return;
+#endif
 #pragma unroll
     for (int c = 0; c < TPW; ++c) {
         if constexpr (KIND == EMIT_GAUSS) {
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
     unsigned long long pc = 0; // (probe: end of the previous step's work)
     auto m_step = [&](int rs, auto uc, auto mc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
-        const bool pr = probe && blockIdx.x == 0 && wid == 0;
+        const bool pr = probe && blockIdx.x == gridDim.x - 1 && wid == 0;
         const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
         const double *X = sX + (u & 1) * 16 * PX; // (groups of four steps: the buffer is the step's parity)
         double *Xn = sX + ((u & 1) ^ 1) * 16 * PX;
@@ -476,6 +484,9 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
     // alpha of step rs (in LDS buffer (rs + 1) & 1 after that step's barrier) to HBM
     const int64_t s_abase = s_ob * n + sch;
     auto store_row = [&](int rs) __attribute__((always_inline)) {
+#ifdef TILE_X_NOSTORE
+        return;
+#endif
         const double *X = sX + ((rs + 1) & 1) * 16 * PX + sxr;
         if (FULL && rs >= g2 && rs < g3) { // (uniform: every row of the tile in its main part)
             double *dst = alpha_rm + s_abase + (int64_t)rs * n;
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
     unsigned int trouble = 0u; // (bit 0: a vector below 2^-900)
     auto s_step = [&](int rs, auto uc, auto) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
-        const bool pr = probe && blockIdx.x == 0 && wid == (SPLIT ? 4 : 0);
+        const bool pr = probe && blockIdx.x == gridDim.x - 1 && wid == (SPLIT ? 4 : 0);
         const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
         // alpha of the previous step: LDS -> HBM
         store_row(rs - 1);
@@ -1066,6 +1077,9 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
     auto front_stats = [&](int us, auto mc, const double (&fg)[4], const bool (&mainr)[4],
                            const tile_d2 (&ol)[2], const double (&acur)[TPW][4]) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mc)::value;
+#ifdef TILE_X_NOSTATS
+        return;
+#endif
         if constexpr (MODE != TM_WARM) {
             const int64_t usn = (int64_t)us * n;
 #pragma unroll
@@ -1152,7 +1166,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
                 lastr[r] = us == meta(r, 2) - 1 && tt[r] > 0; // the transition into the segment
             }
         }
-        const bool pr = probe && blockIdx.x == 0 && wid == 0;
+        const bool pr = probe && blockIdx.x == gridDim.x - 1 && wid == 0;
         const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
         AIn in;
         fetch_a(u & 1, in);
@@ -1254,6 +1268,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long c2 = pr ? __builtin_readcyclecounter() : 0;
         // ---- off the chain: xi of the transition t-1 -> t -----------------------------------------
+#ifndef TILE_X_NOXI
         if constexpr (MODE != TM_WARM) {
             if constexpr (!XIG) {
 #pragma unroll
@@ -1282,6 +1297,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
                                 Wg[meta_gtop(r) * n + 16 * (w + 4 * c) + s - usn - n] = X[xw[r] + 16 * (w + 4 * c) + s] * fx[r];
             }
         }
+#endif
         front_stats(us + 1, mc, fg, mainn, ol, in.ap);
         if (pr && lane == 0) {
             const unsigned long long c3 = __builtin_readcyclecounter();

@@ -102,16 +102,24 @@ static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
             return rc;
         probe = reinterpret_cast<unsigned long long *>(c->d_probe.p);
         BHMM_HIP(hipMemsetAsync(probe, 0, 64, c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[5], c->stream));
     }
+    static const bool probe_in = probe_on && atoi(getenv("BHMM_AMD_TILE_PROBE")) == 1; // (2: kernel times only)
     hipLaunchKernelGGL((k_tile_fwd<4, KIND, true, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p, c->d_alpha_rm.p,
-                       c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p, probe);
+                       c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p,
+                       probe_in ? probe : (unsigned long long *)nullptr);
     BHMM_HIP(hipGetLastError());
     if (probe_on) {
         unsigned long long h[8];
+        BHMM_HIP(hipEventRecord(c->ev[1], c->stream));
         BHMM_HIP(hipMemcpyAsync(h, probe, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         BHMM_HIP(hipStreamSynchronize(c->stream));
-        fprintf(stderr, "tile fwd probe: matrix [operands+matrix %.0f | emission row, write %.0f | barrier %.0f] "
+        float kms = 0.f;
+        (void)hipEventElapsedTime(&kms, c->ev[5], c->ev[1]);
+        fprintf(stderr, "tile fwd kernel %.3f ms; ", kms);
+        if (h[3])
+            fprintf(stderr, "tile fwd probe: matrix [operands+matrix %.0f | emission row, write %.0f | barrier %.0f] "
                         "stream [store, loads %.0f | emission %.0f | barrier %.0f] cycles/step (%llu steps)\n",
                 (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[7],
                 (double)h[5] / h[7], (double)h[6] / h[7], h[3]);
@@ -140,17 +148,23 @@ static int tile_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
             return rc;
         probe = reinterpret_cast<unsigned long long *>(c->d_probe.p) + 16;
         BHMM_HIP(hipMemsetAsync(probe, 0, 128, c->stream));
+        BHMM_HIP(hipEventRecord(c->ev[5], c->stream));
     }
     hipLaunchKernelGGL((k_tile_bwd<4, KIND, true, false, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
                        (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
                        c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
-                       (double *)nullptr, probe);
+                       (double *)nullptr,
+                       atoi(getenv("BHMM_AMD_TILE_PROBE") ? getenv("BHMM_AMD_TILE_PROBE") : "0") == 1 ? probe : (unsigned long long *)nullptr);
     BHMM_HIP(hipGetLastError());
     if (probe_on) {
         unsigned long long h[16];
+        BHMM_HIP(hipEventRecord(c->ev[3], c->stream));
         BHMM_HIP(hipMemcpyAsync(h, probe, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         BHMM_HIP(hipStreamSynchronize(c->stream));
+        float kms = 0.f;
+        (void)hipEventElapsedTime(&kms, c->ev[5], c->ev[3]);
+        fprintf(stderr, "tile bwd kernel %.3f ms\n", kms);
         for (int o = 0; o < 16; o += 8)
             if (h[o + 4])
                 fprintf(stderr, "tile bwd probe (%s steps): operands+matrix %.0f | rescale, x' write %.0f | xi, statistics %.0f | "
