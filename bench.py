@@ -157,18 +157,22 @@ def cpu_baseline(kind, A, pi, par0, par1, obs_sample, threads=1):
     t0 = time.perf_counter()
     if threads <= 1:
         res = work(range(K))
+        dt = time.perf_counter() - t0
+        ll = [l for _, l in sorted(res)]
+        how = "%.1f s on 1 core" % dt
     else:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(threads) as ex:
-            res = sum(ex.map(work, [range(w, K, threads) for w in range(threads)]), [])
-    dt = time.perf_counter() - t0
-    ll = [l for _, l in sorted(res)]
+        # all host cores: OpenMP over trajectories in C (oracle/omp_driver.c) around the same kernels
+        ll, used, which = orc.estep_batch_omp(kind, obs_sample, A, pi, par0, par1, threads=threads)
+        dt = time.perf_counter() - t0
+        ll = list(ll)
+        use_ref = which == "reference"
+        how = "%.1f s on %d OpenMP threads (oracle/omp_driver.c)" % (dt, used)
+        threads = used
     return dict(value=K * T / dt, unit="timesteps/s", cores=threads,
                 kind="reference" if use_ref else "port",
                 sample="%d of the workload's trajectories x %d steps, %d-state %s, "
                        "p_obs+forward+backward+gamma+xi per trajectory as in "
-                       "maximum_likelihood.py:249-265, %.1f s on %d core(s)"
-                       % (K, T, n, kind, dt, threads)), ll
+                       "maximum_likelihood.py:249-265, %s" % (K, T, n, kind, how)), ll
 
 
 def host_cores():
@@ -232,6 +236,8 @@ def timeit(fn, reps, sync, batches=1):
 # measured at N = 1 (profiles/r03): every N must reproduce it, the trajectories being drawn by
 # GLOBAL index.  None = not recorded for this shape.
 C3_LOGLIK_N1 = {(1024, 1000000): -4043229364.929859}
+# ... and its one-GPU E-step time (ms), the reference point of `strong_scaling` at N > 1 (BENCH_r03: 18.36)
+C3_MS_N1 = {(1024, 1000000): 18.36}
 
 
 class Ranks(object):
@@ -504,8 +510,46 @@ def secondary_c4(torch, dev, local, args):
                         "achieved": flops * K * T / dt / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                         "frac": flops * K * T / dt / 1e12 / 78.6},
            "segments": eng.get_option("wide_segments"),
+           "kernels": "k_tile_fwd / k_tile_bwd (row-batched v_mfma_f64_16x16x4, 16 segments per workgroup)"
+                      if eng.get_option("tile") else "k_wide_fwd / k_wide_bwd (one segment per wavefront)",
+           "kernel_ms": {"forward": eng.kernel_ms(0), "backward_and_statistics": eng.kernel_ms(2)},
            "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")}}
     eng.close()
+    return out
+
+
+def secondary_gen(torch, dev, local, args):
+    """More than 64 states (the any-N family, 128 x 1e4): E-step on the row-batched matrix-core
+    kernels up to 128 states (csrc/tile_gen.hip)."""
+    from bhmm_amd.engine import Engine
+    out = []
+    for n in (65, 128):
+        K, T = 128, 10000
+        rng = np.random.default_rng(n)
+        A = metastable_matrix(n, rng)
+        pi = stationary(A)
+        mu, sig = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
+        g = torch.Generator(device=dev)
+        g.manual_seed(n)
+        obs = torch.randn(K * T, dtype=torch.float64, device=dev, generator=g) * 3.0
+        eng = Engine(local)
+        eng.set_observations_device("gaussian", obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, n)
+        margs = (0.9 * A + 0.1 / n, pi, mu + 0.05, sig)
+        for _ in range(3):
+            eng.estep(*margs)
+        dt = timeit(lambda: eng.estep(*margs), 3, eng.sync)
+        r = eng.estep(*margs)
+        np.testing.assert_allclose(r.state_counts.sum(), K * T, rtol=1e-9)
+        flops = 2.0 * 3 * n * n
+        out.append({"config": "%d-state Gaussian HMM, %d x %d, one full E-step" % (n, K, T),
+                    "ms": 1e3 * dt, "timesteps_per_s": K * T / dt,
+                    "roofline": {"bound": "fp64", "achieved": flops * K * T / dt / 1e12, "peak": 78.6,
+                                 "unit": "TFLOP/s", "frac": flops * K * T / dt / 1e12 / 78.6},
+                    "tile_kernels": bool(eng.get_option("tile")), "segments": eng.get_option("wide_segments"),
+                    "self_checks_fired": int(eng.get_option("wide_trouble")),
+                    "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")}})
+        eng.close()
+        del obs
     return out
 
 
@@ -669,7 +713,7 @@ def main():
         # kernel k_estep carries them (obs twice, alpha written once and read once).
         alg_bytes_launch = B_ALG_GAUSS * K * T
         achieved = alg_bytes_launch / (kern_ms[2] * 1e-3) / 1e9
-        traffic, traffic_file = None, None
+        traffic, traffic_file, valu_insts, issue_rate = None, None, None, None
         tj = args.traffic_json if os.path.isabs(args.traffic_json) else os.path.join(ROOT, args.traffic_json)
         if os.path.exists(tj) and (K, T) == (256, 100000):
             # HBM bytes of the sweep launches of one E-step from the PMC counters: collected
@@ -680,6 +724,8 @@ def main():
             if eng.get_option("spec_ok") > 0 and eng.get_option("spec_fail") == 0:
                 tdoc = json.load(open(tj))
                 traffic = tdoc["traffic_bytes_per_launch"]
+                valu_insts = tdoc.get("valu_wave_insts_per_launch")
+                issue_rate = tdoc.get("issue_ceiling_insts_per_us_per_simd")
                 traffic_file = "%s (%s)" % (args.traffic_json, tdoc.get("source", "source not recorded"))
         out = {
             "metric": "timesteps/sec forward-backward (whole node), N=8 states",
@@ -710,6 +756,15 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_is_live": False,
+                         # the binding ceilings, named: HBM bytes the counters saw / time / peak, and
+                         # vector instructions issued / what this part issues on 1024 SIMDs in that time
+                         "hbm_counter_frac": None if traffic is None else
+                         traffic / (kern_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "issue_frac": None if not (valu_insts and issue_rate) else
+                         valu_insts / (issue_rate * 1024 * kern_ms[2] * 1e3),
+                         "issue_note": None if not (valu_insts and issue_rate) else
+                         "SQ_INSTS_VALU of the two sweep launches (offline PMC pass) over the measured issue "
+                         "ceiling of a chip-wide fp64 stream (tools/ubench/issue_rate.hip)",
                          "traffic_source": ("offline rocprofv3 PMC passes on the same workload, "
                                             "%s" % traffic_file) if traffic_file else None,
                          "alg_bytes_per_launch": alg_bytes_launch,
@@ -741,12 +796,37 @@ def main():
         eng.close()
         del obs_dev, stats
         torch.cuda.empty_cache()
-        sec.insert(0, secondary_c3(rk, args))
+        c3 = secondary_c3(rk, args)
+        sec.insert(0, c3)
+        c4 = gen = None
         if world == 1:
-            sec.append(secondary_c4(torch, dev, local, args))
+            c4 = secondary_c4(torch, dev, local, args)
+            sec.append(c4)
+            gen = secondary_gen(torch, dev, local, args)
+            sec.extend(gen)
         sec.extend(secondary_whole_iterations(rk, model, args))
         if out is not None:
             out["secondary"] = sec
+            # what a reader of the line must not have to dig out of `secondary`:
+            # the north-star target shape (configs[2], 1024 x 1e6 x 8 states) ...
+            ts = {k: c3.get(k) for k in ("config", "n_gpus", "scaling", "ms", "timesteps_per_s", "loglik_matches_n1",
+                                         "allreduce_plus_copy_ms", "roofline", "cpu_baseline", "speedup_vs_1core",
+                                         "target_50x_met") if k in c3}
+            out["target_shape"] = ts
+            if world > 1:
+                # ... strong-scaled: the same 1024 x 1e6 steps on N GPUs against the committed one-GPU time
+                n1 = C3_MS_N1.get((args.c3_ntraj, args.c3_length))
+                out["strong_scaling"] = {"config": c3["config"], "value": c3["timesteps_per_s"],
+                                         "unit": "timesteps/s", "ms": c3["ms"], "n_gpus": world,
+                                         "n1_ms_committed": n1,
+                                         "speedup_vs_n1": None if n1 is None else n1 / c3["ms"],
+                                         "efficiency_vs_n1": None if n1 is None else n1 / c3["ms"] / world}
+            if c4 is not None:
+                out["configs3_64_states"] = {k: c4[k] for k in ("config", "ms", "timesteps_per_s", "roofline",
+                                                                "kernels", "kernel_ms", "segments", "spec")}
+            if gen:
+                out["more_than_64_states"] = [{k: g[k] for k in ("config", "ms", "roofline", "tile_kernels")}
+                                              for g in gen]
     if out is not None:
         print(json.dumps(out))
     eng.close()

@@ -264,6 +264,38 @@ def ref():
     return _ref
 
 
+_omp = {}
+
+
+def estep_batch_omp(kind, obs, A, pi, par0, par1=None, threads=0):
+    """The per-trajectory E-step sequence of maximum_likelihood.py:249-265 over a (K, T) batch, one
+    OpenMP task per trajectory (oracle/omp_driver.c): with the reference's own C kernels when
+    oracle/_ref/libbhmm_ref_omp.so exists, else with this repo's restatement.  Returns
+    (per-trajectory log-likelihoods, threads used, 'reference' | 'port')."""
+    which = "reference" if os.path.exists(os.path.join(_HERE, "_ref", "libbhmm_ref_omp.so")) else "port"
+    if which not in _omp:
+        path = os.path.join(_HERE, "_ref", "libbhmm_ref_omp.so") if which == "reference" else \
+            os.path.join(_HERE, "liboracle_omp.so")
+        if which == "port" and not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "liboracle_omp.so"])
+        L = ctypes.CDLL(path)
+        L.orc_estep_batch_omp.restype = ctypes.c_int
+        _omp[which] = L
+    A, pi, par0 = _f64(A), _f64(pi), _f64(par0)
+    par1 = _f64(par1) if par1 is not None else par0
+    obs = np.ascontiguousarray(obs, dtype=np.float64 if kind == 'gaussian' else np.int32)
+    K, T = obs.shape
+    N = A.shape[0]
+    M = par0.shape[1] if kind == 'discrete' else 0
+    logL = np.zeros(K)
+    used = _omp[which].orc_estep_batch_omp(0 if kind == 'gaussian' else 1, obs.ctypes.data_as(ctypes.c_void_p),
+                                           ctypes.c_int(K), ctypes.c_long(T), ctypes.c_int(N), ctypes.c_int(M),
+                                           _dp(A), _dp(pi), _dp(par0), _dp(par1), ctypes.c_int(threads), _dp(logL))
+    if used < 0:
+        raise MemoryError()
+    return logL, used, which
+
+
 def ref_pobs_gaussian(obs, mu, sigma, out=None):
     obs, mu, sigma = _f64(obs), _f64(mu), _f64(sigma)
     T, N = obs.shape[0], mu.shape[0]
