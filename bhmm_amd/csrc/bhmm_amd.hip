@@ -1517,9 +1517,10 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
     if (!c || !name)
         return invalid("NULL argument");
     const std::string n(name);
-    if (n == "spec_enabled")
+    if (n == "spec_enabled") {
         c->spec_enabled = value != 0.0;
-    else if (n == "carry") { // warm-ups from the previous E-step's boundary vectors (EM sequences)
+        c->carry_valid = false; // (an E-step outside the verified split path leaves no vectors to carry)
+    } else if (n == "carry") { // warm-ups from the previous E-step's boundary vectors (EM sequences)
         c->carry_enabled = value != 0.0;
         c->carry_valid = false;
     } else if (n == "carry_kappa") { // (tests: the sensitivity bound that sizes the carried warm-ups)
@@ -1689,26 +1690,38 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         // block): finite log-likelihoods but non-finite counts.  The observations are re-planned with
         // one chunk per trajectory -- the plain sequential recursions -- and the E-step is repeated,
         // once per set of observations.
+        // Only where the statistics are on the host already (the library's own landing zone): an
+        // E-step launched into a caller's device buffer stays asynchronous, and bhmm_estep_fetch
+        // reports non-finite counts loudly there (BHMM_ERR_NONFINITE).
         const int S = stats_size(c);
-        if (!c->prefetched) {
-            BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->last_stats, S * sizeof(double), hipMemcpyDeviceToHost,
-                                    c->stream));
-            BHMM_HIP(hipStreamSynchronize(c->stream));
-        }
         const int ncheck = std::min(S, 1 + c->n + c->n * c->n + c->n);
         bool finite = true;
-        for (int e = 0; e < ncheck; ++e)
-            finite = finite && std::isfinite(c->h_pinned[e]);
+        if (c->prefetched)
+            for (int e = 0; e < ncheck; ++e)
+                finite = finite && std::isfinite(c->h_pinned[e]);
         int64_t maxT = 0;
         for (int k = 0; k < c->K; ++k)
             maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
         if (!finite && std::isfinite(c->h_pinned[0]) && maxT < ((int64_t)1 << 30)) {
             c->serial_retry_done = true;
-            c->chunk_auto = false;
-            if ((rc = replan_coarse(c, false, (int)maxT)))
-                return rc;
-            c->prefetched = false;
-            rc = BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
+            // does the one-chunk-per-trajectory plan fit?  Its workspace is (K padded to 64) x maxT
+            // records (few long trajectories: hundreds of GB): if not, leave the plan alone -- the
+            // fetch then reports the non-finite statistic instead of an allocation failure on a
+            // half-replaced plan
+            const double recs = (double)((c->K + 63) / 64) * (double)maxT * 64.0;
+            const double need = recs * ((double)c->N * 8.0 * 1.5 + 16.0);
+            size_t free_b = 0, total_b = 0;
+            BHMM_HIP(hipMemGetInfo(&free_b, &total_b));
+            const double held = (double)c->d_ws.n * 8.0 + (double)c->d_obs_ci.n + (double)c->d_gamma_ci.n * 8.0;
+            if (need <= 0.9 * ((double)free_b + held)) {
+                c->chunk_auto = false;
+                if ((rc = replan_coarse(c, false, (int)maxT))) {
+                    c->kind = -1; // (a failed re-plan leaves no usable plan: the context needs new observations)
+                    return rc;
+                }
+                c->prefetched = false;
+                rc = BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
+            }
         }
     }
     c->gamma_valid = rc == BHMM_OK && c->gamma_wanted;

@@ -348,9 +348,14 @@ def sample_reversible(C, nsteps=1000, P0=None, rng=np.random):
     143, 174101 (2015) on the symmetric flux matrix X (x_ij = pi_i p_ij), prior x_ij^-1, started at
     the reversible MLE.  Diagonal: x_ii / x_i ~ Beta(c_ii, c_i - c_ii) given the rest of the row;
     off-diagonal: independence Metropolis step with a Gamma proposal matched to the conditional
-    v^(c0-1) (v + v1)^-c1 (v + v2)^-c2.  This is the numpy statement of host_model.cpp's
-    sample_reversible_sweeps (which the estimators call; same algorithm, own generator).
-    PARITY UNPINNED with respect to msmtools itself (statistical agreement only)."""
+    v^(c0-1) (v + v1)^-c1 (v + v2)^-c2.  This is a plain numpy statement of the same published
+    sampler that host_model.cpp's sample_reversible_sweeps implements (which the estimators call);
+    it is NOT a line-by-line twin: pairs are visited in lexicographic instead of round-robin order,
+    a pair for which no Gamma proposal exists (a == 0 or h >= 0) is skipped where the native code
+    takes a log-uniform random-walk step, and there is no accept-at-once branch for v0 == 0 -- same
+    stationary distribution, other chain.  `nsteps` full sweeps cost about nsteps * n^2 Python-level
+    updates: the native sampler (native_parameters=True, the default) is the one to use beyond a
+    few states.  PARITY UNPINNED with respect to msmtools itself (statistical agreement only)."""
     C = np.asarray(C, dtype=np.float64)
     n = C.shape[0]
     if P0 is None:

@@ -344,6 +344,7 @@ class MaximumLikelihoodEstimator(object):
         best, best_ll = None, -np.inf
         for cand in candidates:
             self._hmm = cand
+            self._reset_mstep_state()      # (the warm start of the fixed point belongs to one model sequence)
             cand.output_model.set_implementation(config.kernel)
             ll = -np.inf
             try:
@@ -358,9 +359,17 @@ class MaximumLikelihoodEstimator(object):
         if best is not None:
             self._hmm = best
 
+    def _reset_mstep_state(self):
+        """The native M-step warm-starts its reversible fixed point from the previous call's solution
+        (within maxerr of the cold result); a new model sequence starts cold, so that a fit
+        does not depend on what the estimator object did before."""
+        if self._mstep is not None:
+            self._mstep.warm[:] = 0.0
+
     def fit(self):
         """maximum_likelihood.py:354-446."""
         self._select_start()
+        self._reset_mstep_state()
         it = 0
         self._likelihoods = np.zeros(self.maxit)
         loglik = 0.0
