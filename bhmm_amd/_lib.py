@@ -91,6 +91,12 @@ SIGNATURES = {
     "bhmm_ctx_last_kernel_ms_all": (ctypes.c_int, [c_void_p, c_double_p]),
     "bhmm_ctx_stream": (c_void_p, [c_void_p]),
     "bhmm_ctx_sync": (ctypes.c_int, [c_void_p]),
+    "bhmm_comm_unique_id": (ctypes.c_int, [c_void_p]),
+    "bhmm_comm_init_rank": (ctypes.c_int, [ctypes.POINTER(c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           c_void_p]),
+    "bhmm_comm_destroy": (ctypes.c_int, [c_void_p]),
+    "bhmm_comm_size": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "bhmm_ctx_allreduce_stats": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int64]),
     "bhmm_synth_observations": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p,
                                                ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                                c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -360,6 +360,49 @@ class Engine(object):
         return plist, C, n0, emis
 
 
+class NativeComm(object):
+    """The library's own communicator (include/bhmm_amd.h, section 2b): RCCL behind the C ABI, for
+    callers that do not bring torch.distributed -- one all-reduce of the packed statistics per EM
+    iteration / Gibbs sweep (maximum_likelihood.py:271-282 in distributed form).  Rank 0 calls
+    NativeComm.unique_id() and hands the 128 bytes to the other ranks; every rank then constructs
+    NativeComm(device, nranks, rank, uid) (a collective)."""
+
+    def __init__(self, device, nranks=1, rank=0, uid=None):
+        self._L = _lib.load()
+        if uid is None:
+            if nranks != 1:
+                raise ValueError("more than one rank: pass the unique id of rank 0")
+            uid = NativeComm.unique_id()
+        self._uid = ctypes.create_string_buffer(bytes(uid), 128)
+        self._h = ctypes.c_void_p()
+        _lib.check(self._L.bhmm_comm_init_rank(ctypes.byref(self._h), int(device), int(nranks), int(rank),
+                                               ctypes.cast(self._uid, ctypes.c_void_p)))
+        self.nranks, self.rank, self.device = int(nranks), int(rank), int(device)
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().bhmm_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return buf.raw
+
+    def allreduce_stats(self, engine, dev_ptr, count):
+        """In-place sum over the ranks of `count` doubles at device address dev_ptr, enqueued on the
+        engine's stream (no host synchronisation)."""
+        _lib.check(self._L.bhmm_ctx_allreduce_stats(engine._h, self._h, ctypes.c_void_p(int(dev_ptr)),
+                                                    ctypes.c_int64(int(count))))
+
+    def close(self):
+        if self._h:
+            self._L.bhmm_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def synth_observations(kind, obs_dev, A, pi, par0, par1, K, T, seed, device=0, stream=None,
                        states_dev=None, first_traj=0):
     """Draw K synthetic trajectories of T steps on the GPU into the device buffer at address

@@ -237,6 +237,31 @@ double bhmm_ctx_last_kernel_ms(bhmm_ctx *ctx, int which);
 int bhmm_ctx_last_kernel_ms_all(bhmm_ctx *ctx, double *out);
 void *bhmm_ctx_stream(bhmm_ctx *ctx);
 int bhmm_ctx_sync(bhmm_ctx *ctx);
+/* ------------------------------------------------------------------------------------
+ * (2b) more than one GPU: one process (or thread) per device, trajectories sharded over the
+ *      ranks (they are independent given the model: maximum_likelihood.py:383-385,
+ *      bayesian_sampling.py:288-290), ONE all-reduce of the packed sufficient statistics per EM
+ *      iteration / Gibbs sweep -- the distributed form of the host sums at
+ *      bhmm/estimators/maximum_likelihood.py:271-282.  RCCL over xGMI, loaded on first use
+ *      (librccl.so; BHMM_ERR_INVALID with a message if it is not there -- the rest of the
+ *      library does not need it).  The Python estimators use torch.distributed for the same sum
+ *      (bhmm_amd/sharding.py); these entry points give a non-Python binder the same thing.
+ *
+ *   bhmm_comm_unique_id : rank 0 fills 128 bytes and hands them to the other ranks out of band
+ *   bhmm_comm_init_rank : collective over the nranks callers; `device` is this rank's GPU
+ *   bhmm_ctx_allreduce_stats : in-place sum over the ranks of count doubles in a DEVICE buffer --
+ *                          what bhmm_estep(..., stats_dev) / bhmm_sample_paths_dev left there --
+ *                          enqueued on the context's stream (no host synchronisation: follow it
+ *                          with the copy to the host on the same stream, or bhmm_ctx_sync)
+ * ---------------------------------------------------------------------------------- */
+typedef struct bhmm_comm bhmm_comm;
+#define BHMM_COMM_ID_BYTES 128
+int bhmm_comm_unique_id(void *id);
+int bhmm_comm_init_rank(bhmm_comm **out, int device, int nranks, int rank, const void *id);
+int bhmm_comm_destroy(bhmm_comm *comm);
+int bhmm_comm_size(const bhmm_comm *comm, int *nranks, int *rank);
+int bhmm_ctx_allreduce_stats(bhmm_ctx *ctx, bhmm_comm *comm, double *stats_dev, int64_t count);
+
 /* Measurement / test support: K synthetic trajectories of T steps each, drawn ON
  * THE DEVICE from the HMM (A, pi, emission) -- hidden path by inverse CDF of pi / the rows of A,
  * one emission per step (recipe of bhmm/hmm/generic_hmm.py:435-507) -- with the counter-based

@@ -115,3 +115,37 @@ def test_bench_starts_its_own_ranks(launcher):
     em = [[e for e in o["secondary"] if "WHOLE EM" in e["config"]] for o in outs]
     for a, b in zip(*em):
         np.testing.assert_allclose(a["loglik_first_last"], b["loglik_first_last"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_allreduce_of_the_statistics_through_the_c_abi_on_rccl():
+    """include/bhmm_amd.h section 2b: bhmm_comm_init_rank + bhmm_ctx_allreduce_stats (RCCL loaded by the
+    library itself, no torch.distributed).  One rank is what a one-GPU box can run: the statistics an
+    E-step left in a device buffer go through ncclAllReduce on the engine's stream and come back
+    unchanged; the communicator reports its geometry; a buffer on another device is refused."""
+    import torch
+    from bhmm_amd.engine import Engine, NativeComm
+    from oracle import oracle as orc
+    rng = np.random.default_rng(11)
+    n = 8
+    A = rng.random((n, n)) + 0.1
+    A /= A.sum(axis=1)[:, None]
+    pi = np.full(n, 1.0 / n)
+    mu, sig = np.linspace(-4, 4, n), np.linspace(0.6, 1.5, n)
+    obs = [rng.normal(0, 3, T) for T in (5000, 1234, 77)]
+    eng = Engine(0)
+    eng.set_observations("gaussian", obs, n)
+    stats = torch.zeros(eng.stats_size, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    comm = NativeComm(0)                                   # nranks = 1
+    assert (comm.nranks, comm.rank) == (1, 0)
+    eng.estep_launch(A, pi, mu, sig, stats_dev=stats.data_ptr())
+    comm.allreduce_stats(eng, stats.data_ptr(), eng.stats_size)
+    eng.sync()
+    res = eng.unpack(stats.cpu().numpy())
+    ref = orc.estep("gaussian", obs, A, pi, mu, sig)
+    np.testing.assert_allclose(res.loglik, ref["logL"].sum(), rtol=1e-11)
+    np.testing.assert_allclose(res.C, ref["C"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-9)
+    comm.close()
+    eng.close()
