@@ -1300,6 +1300,8 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     if (!c->spec_W_fixed)
         c->spec_W = 288;
     c->vit_W = 0;
+    c->vit_bad = 0;
+    c->vit_explore = true;
     c->wide_replans = 0;
     c->tile_settle = 0;
     c->tile_W_good = 0;
@@ -1567,6 +1569,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->viterbi_chunked ? 1.0 : 0.0;
     else if (n == "viterbi_close")
         *value = c->viterbi_close;
+    else if (n == "viterbi_W") // warm-up the chunk-parallel Viterbi last verified with
+        *value = c->vit_W;
     else if (n == "carry")
         *value = c->carry_enabled ? 1.0 : 0.0;
     else if (n == "carry_W") // warm-up steps of the last E-step's carried starts (0: full warm-ups)
@@ -1581,6 +1585,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
     else if (n == "wide_trouble") // which self-check of the lazily scaled kernels fired last (bit mask)
         *value = c->wide_trouble;
+    else if (n == "tile_reason") // more than 64 states: why the tile kernels were left (ctx.hpp), 0: they were not
+        *value = c->tile_reason;
     else if (n == "tile") // 1: the last E-step ran on the row-batched matrix-core kernels
         *value = c->tile_used ? 1.0 : 0.0;
     else if (n == "wide_fwd_segments") // the forward pass's own, finer plan (64 states), 0 if none
@@ -1690,13 +1696,19 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         // block): finite log-likelihoods but non-finite counts.  The observations are re-planned with
         // one chunk per trajectory -- the plain sequential recursions -- and the E-step is repeated,
         // once per set of observations.
-        // Only where the statistics are on the host already (the library's own landing zone): an
-        // E-step launched into a caller's device buffer stays asynchronous, and bhmm_estep_fetch
-        // reports non-finite counts loudly there (BHMM_ERR_NONFINITE).
+        // Only where the statistics are on the host already or are the library's own (the caller
+        // fetches them next anyway): an E-step launched into a CALLER's device buffer stays
+        // asynchronous, and bhmm_estep_fetch reports non-finite counts loudly there (BHMM_ERR_NONFINITE).
         const int S = stats_size(c);
         const int ncheck = std::min(S, 1 + c->n + c->n * c->n + c->n);
         bool finite = true;
-        if (c->prefetched)
+        const bool look = c->prefetched || c->last_stats_internal;
+        if (look && !c->prefetched) {
+            BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->last_stats, S * sizeof(double), hipMemcpyDeviceToHost,
+                                    c->stream));
+            BHMM_HIP(hipStreamSynchronize(c->stream));
+        }
+        if (look)
             for (int e = 0; e < ncheck; ++e)
                 finite = finite && std::isfinite(c->h_pinned[e]);
         int64_t maxT = 0;

@@ -129,6 +129,8 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_tbpart;    // k_tail: per trajectory block [sum logL | sum gamma_0 (N)]
     int tail_slot = 0;                // verdict word set of the next E-step
     int vit_W = 0;                    // warm-up the chunked Viterbi last verified with (0: spec_W)
+    int vit_bad = 0;                  // ... a shorter one that did not verify
+    bool vit_explore = true;          // ... still trying shorter ones (path_api.hip)
     bool chunk_auto = true;           // the caller left the chunk length to the library
     bool replanned_half = false;      // ... and it has been re-planned with half the chunks (once)
     bool serial_retry_done = false;   // non-finite counts: re-planned with one chunk per trajectory (once)
@@ -167,6 +169,9 @@ struct bhmm_ctx {
     unsigned int wide_trouble = 0;   // flag word of the last lazily scaled E-step (which self-check fired)
     int tile_settle = 0;             // warm-up refinements done for these observations (at most 4, first E-step)
     int tile_W_good = 0;             // ... the last warm-up that verified
+    int tile_reason = 0;             // why the tile path was left (0: it was not): 1 calibration saw a self-check fire,
+                                     // 2 calibration did not converge, 3 warm-up >= half a trajectory, 4 self-check in an
+                                     // E-step, 5 boundaries did not verify after three attempts, 6 fixed warm-up does not verify
     bool tile_used = false;          // the last E-step ran on the tile kernels
     bool wseg_enabled = true;
     bool wseg_split = true;     // 64 states: own, finer plan for the forward pass (wide_plan_segments)

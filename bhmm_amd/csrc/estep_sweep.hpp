@@ -320,6 +320,7 @@ __device__ __forceinline__ int scaled_emit(const ObsIn &in, int q, int nreal,
     constexpr int H = N / 2;
     double n0, n1;
     int hm;
+    int extra = 0; // CAREFUL: 900 if the products were re-formed from the row times 2^900
     if constexpr (CAREFUL && KIND == EMIT_GAUSS) {
         for (;;) { // runs once; a second time only after the outlier rule replaced p
             n0 = s[0] * p[0];
@@ -327,6 +328,25 @@ __device__ __forceinline__ int scaled_emit(const ObsIn &in, int q, int nreal,
             hm = grp_max_i32<H>(max(__double2hiint(n0), __double2hiint(n1)));
             if (__builtin_expect(__ballot(tiny_hi(hm)) == 0ull, 1))
                 break;
+            // A step whose likelihood is in the denormal range although the emission row is not (the
+            // mass sits on a state the observation excludes, the others contribute 1e-66 x 1e-257;
+            // soak seed 16001 case 2087): the products of normal factors underflow to a few bits --
+            // the reference's _hidden.c:57-66 loses them the same way, at another scale.  Re-formed
+            // from the row times 2^900 (exact) they keep all bits; the 900 comes off the exponent count.
+            {
+                const double q0 = s[0] * ldexp(p[0], 900), q1 = s[1] * ldexp(p[1], 900);
+                const int hq = grp_max_i32<H>(max(__double2hiint(q0), __double2hiint(q1)));
+                if (__ballot(tiny_hi(hm) && !tiny_hi(hq) && hq < (2046 << 20)) != 0ull) {
+                    if (tiny_hi(hm) && !tiny_hi(hq) && hq < (2046 << 20)) {
+                        n0 = q0;
+                        n1 = q1;
+                        hm = hq;
+                        extra = 900;
+                    }
+                    if (__ballot(tiny_hi(hm)) == 0ull)
+                        break;
+                }
+            }
             if (__ballot(fix_outlier<N, KIND>(in, q, nreal, gmask, p)) == 0ull)
                 break;
         }
@@ -346,7 +366,7 @@ __device__ __forceinline__ int scaled_emit(const ObsIn &in, int q, int nreal,
     const int ne = 1022 - (hm >> 20);
     a[0] = ldexp(n0, ne);
     a[1] = ldexp(n1, ne);
-    return -ne;
+    return -ne - extra;
 }
 
 // All-gather of a state-pair over the H lanes of a chunk.  ESTEP_LDS_GATHER: through a

@@ -400,8 +400,34 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         // A warm-up too short for some boundary (the survivors of that stretch had not met yet) shows
         // as a boundary out of tolerance: the run is repeated with twice, then four times the warm-up
         // (one more pass of ~1 ms each) before the serial kernel (tens of ms) has to decide.
-        int W_try = std::max(c->spec_W, c->vit_W);
-        for (int attempt = 0; attempt < 3; ++attempt, W_try *= 2) {
+        // The warm-up of THIS recursion (round 4): the max-product chains coalesce faster than the
+        // E-step's filter forgets to 1e-13 (configs[1]: bit-identical boundaries from W ~ 128 on, the
+        // E-step's probe says 280).  The first call on new observations starts from the E-step's
+        // length; every later call that verified tries three quarters of the last good length, until
+        // one does not verify -- that one is repeated with the last good length in the same call, and
+        // the search ends (at most one lost pass per set of observations).
+        int W_try = c->vit_W > 0 ? c->vit_W : c->spec_W;
+        bool exploring = false;
+        if (c->vit_W > 0 && c->vit_explore && !c->spec_W_fixed) {
+            const int Wn = std::max(32, (c->vit_W * 3 / 4 + 7) / 8 * 8);
+            if (Wn < c->vit_W && Wn > c->vit_bad) {
+                W_try = Wn;
+                exploring = true;
+            } else {
+                c->vit_explore = false;
+            }
+        }
+        for (int attempt = 0; attempt < 3; ++attempt) {
+        if (attempt > 0) {
+            if (exploring) { // the shorter warm-up did not verify: back to the one that did
+                c->vit_bad = W_try;
+                c->vit_explore = false;
+                exploring = false;
+                W_try = c->vit_W;
+            } else {
+                W_try *= 2;
+            }
+        }
         // first without the close-decision count; bit-identical boundaries make it irrelevant
         for (int pass = 0; pass < 2; ++pass) {
             BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
@@ -459,6 +485,9 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
             if (c->h_specres[3] == 0 || c->h_specres[0] != 0)
                 break; // the serial run outright / out of tolerance: the count cannot help
         }
+        const bool accepted = c->h_specres[3] == 0 || (c->h_specres[0] == 0 && c->h_specres[2] == 0);
+        if (exploring && !accepted)
+            continue; // (a shorter warm-up must be as good as the longer one was, not merely tolerable)
         if (c->h_specres[0] == 0) {
             c->vit_W = W_try; // (what worked is where the next call on these observations starts)
             break; // every boundary within tolerance: a longer warm-up changes nothing

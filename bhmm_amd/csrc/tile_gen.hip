@@ -160,6 +160,7 @@ int calibrate(bhmm_ctx *c, const WideModel &m, bool *usable)
             return rc;
         if (c->h_specres[2]) { // left the range of the lazily scaled kernels: the order-faithful family
             c->wide_trouble = c->h_specres[2];
+            c->tile_reason = 1;
             return BHMM_OK;
         }
         float devf;
@@ -170,8 +171,10 @@ int calibrate(bhmm_ctx *c, const WideModel &m, bool *usable)
             *usable = true;
             return BHMM_OK;
         }
-        if (c->spec_W_fixed)
+        if (c->spec_W_fixed) {
+            c->tile_reason = 6;
             return BHMM_OK; // the caller's warm-up does not verify: not ours to change
+        }
         double Wn;
         if (prevW > 0.0 && dev < 0.5 * prevdev) {
             const double rate = log(prevdev / dev) / ((double)W - prevW); // per step
@@ -183,9 +186,12 @@ int calibrate(bhmm_ctx *c, const WideModel &m, bool *usable)
         prevdev = dev;
         W = (int)std::min<double>(std::max(Wn, W + 8.0), 4.0 * W + 64.0);
         W = (W + 7) / 8 * 8;
-        if (W >= maxT / 2)
+        if (W >= maxT / 2) {
+            c->tile_reason = 3;
             return BHMM_OK; // chains that do not forget within the trajectories: serial family
+        }
     }
+    c->tile_reason = 2;
     return BHMM_OK;
 }
 
@@ -203,6 +209,7 @@ int tile_gen_alloc(bhmm_ctx *c)
     c->spec_calibrated = c->spec_W_fixed && false;
     c->wseg_given_up = false;
     c->wide_careful = false;
+    c->tile_reason = 0;
     // buffers for the finest plan there can be
     const int64_t minlen = c->wseg_len > 0 ? (int64_t)c->wseg_len : fill_len(c);
     int64_t nsmax = c->K;
@@ -266,6 +273,7 @@ int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags
         c->wide_trouble = c->h_specres[2];
         if (c->h_specres[2]) { // out of the lazily scaled kernels' range on these data: stay away
             c->wide_careful = true;
+            c->tile_reason = 4;
             return BHMM_OK;
         }
         float devf;
@@ -314,6 +322,7 @@ int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags
             return rc;
     }
     c->wseg_given_up = true;
+    c->tile_reason = 5;
     return BHMM_OK;
 }
 

@@ -110,11 +110,11 @@ for case in range(ncase):
                     # where the reference itself is far off the 80-bit recursion (seed 8001 case 278: 3.5e-3
                     # in the log-likelihood, rows of a few bits), being as close to it as the reference is
                     # -- here the kernels follow the reference to 3.6e-6 -- is all that can be asked
-                    # (3 x for the log-likelihood: seed 16001 case 2087 -- a step in which every state that
-                    # carries alpha has p = 0 and the step's likelihood is a denormal of three bits, 3.4585e-323:
-                    # the reference is 3.5 % off in that factor, the kernels, whose vectors carry another power
-                    # of two, 7.2 %; tests/golden/cases/gauss7_denormal_entries_16001_2087.npz)
-                    ok = (np.abs(res.logL_k - ld_logL).max() <= max(3.0 * np.abs(ref["logL"] - ld_logL).max(), 1e-9) and
+                    # (seed 16001 case 2087 -- a step in which every state that carries alpha has p = 0 and the
+                    # step's likelihood is a denormal of three bits, 3.4585e-323: the reference is 3.5 % off in
+                    # that factor; the kernels re-form such products from the row times 2^900 since round 4;
+                    # tests/golden/cases/gauss7_denormal_entries_16001_2087.npz)
+                    ok = (np.abs(res.logL_k - ld_logL).max() <= max(2.0 * np.abs(ref["logL"] - ld_logL).max(), 1e-9) and
                           np.abs(res.C - ld_C).max() <= max(10.0 * np.abs(ref["C"] - ld_C).max(), 1e-9))
                 if not ok:
                     print("  (denormal regime; vs 80-bit recursion) logL", np.abs(res.logL_k - ld_logL).max(), "C", np.abs(res.C - ld_C).max(),

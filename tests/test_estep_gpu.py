@@ -815,7 +815,8 @@ def test_reducible_model_with_wide_emissions_is_repeated_on_one_chunk_per_trajec
 
 
 @pytest.mark.parametrize("case,kind", [("gauss8_denormal_entries_8101_681", "gaussian"),
-                                       ("disc4_M1150_9501_20", "discrete")])
+                                       ("disc4_M1150_9501_20", "discrete"),
+                                       ("gauss7_denormal_entries_16001_2087", "gaussian")])
 @pytest.mark.parametrize("spec,store_gamma", [(1, False), (1, True), (0, False)])
 def test_weight_on_entries_in_the_denormal_range(case, kind, spec, store_gamma):
     """Two saved cases of tests/sweeps/stress_small.py in which a sparse transition matrix puts the whole

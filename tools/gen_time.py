@@ -20,5 +20,7 @@ for n, K, T in ((64, 128, 10000), (65, 128, 10000), (100, 128, 10000), (128, 128
     ts = timeit(lambda: eng.sample_paths(*margs, seed=1, want_paths=False), 1, eng.sync)
     print("n=%d K=%d T=%d: E-step %.1f ms (%.3g steps/s, %.2f TFLOP/s on 6 n^2), Viterbi %.1f ms, Gibbs path step %.1f ms, kernel ms %s"
           % (n, K, T, 1e3 * dt, K * T / dt, 6.0 * n * n * K * T / dt / 1e12, 1e3 * tv, 1e3 * ts,
-             [round(eng.kernel_ms(i), 2) for i in range(5)]))
+             [round(eng.kernel_ms(i), 2) for i in range(5)]),
+          "| tile", eng.get_option("tile"), "reason", eng.get_option("tile_reason"), "self-checks", eng.get_option("wide_trouble"),
+          "W", eng.get_option("spec_W"), "dev", eng.get_option("spec_last_dev"), "fail", eng.get_option("spec_fail"))
     eng.close()

@@ -11,11 +11,11 @@ for n, K, T in ((65, 128, 10000), (128, 128, 10000), (64, 128, 20000)):
     rng = np.random.default_rng(n)
     A = metastable_matrix(n, rng); pi = stationary(A)
     mu, sig = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
-    g = torch.Generator(device=dev); g.manual_seed(n)
-    obs = torch.randn(K * T, dtype=torch.float64, device=dev, generator=g) * 3.0
     margs = (0.9 * A + 0.1 / n, pi, mu + 0.05, sig)
     ref = None
     for rep in range(reps):
+        obs = torch.randn(K * T, dtype=torch.float64, device=dev) * 3.0      # new data every time
+        ref = None
         junk = torch.full((int(1e8) + 1000 * rep,), float("nan"), dtype=torch.float64, device=dev)
         del junk
         eng = Engine(0)
