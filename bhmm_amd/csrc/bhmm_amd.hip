@@ -1300,6 +1300,9 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     if (!c->spec_W_fixed)
         c->spec_W = 288;
     c->vit_W = 0;
+    c->pplan[0].nseg = c->pplan[1].nseg = 0;
+    c->smp_W = 0;
+    c->vit_seg_given_up = false;
     c->vit_bad = 0;
     c->vit_explore = true;
     c->wide_replans = 0;
@@ -1527,6 +1530,12 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
         c->carry_valid = false;
     } else if (n == "carry_kappa") { // (tests: the sensitivity bound that sizes the carried warm-ups)
         c->carry_kappa = value;
+    } else if (n == "viterbi_seg_per_simd") { // 9..64 states: segments per SIMD of the Viterbi pass
+        if (value < 1 || value > 64)
+            return BHMM_ERR_INVALID;
+        c->vit_seg_per_simd = (int)value;
+        c->pplan[0].nseg = c->pplan[1].nseg = 0;
+        c->vit_seg_given_up = false;
     } else if (n == "spec_W") {
         c->carry_valid = false;
         c->spec_W = std::max(1, (int)value);
@@ -1571,6 +1580,22 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->viterbi_close;
     else if (n == "viterbi_W") // warm-up the chunk-parallel Viterbi last verified with
         *value = c->vit_W;
+    else if (n == "viterbi_segments") // 9..64 states: time segments of the last Viterbi pass's plan
+        *value = c->pplan[0].nseg;
+    else if (n == "sample_segmented") // 9..64 states: the last path sampling ran over time segments
+        *value = c->smp_segmented ? 1.0 : 0.0;
+    else if (n == "sample_segments")
+        *value = c->pplan[1].nseg;
+    else if (n == "sample_W")
+        *value = c->smp_W;
+    else if (n == "sample_mismatch") // ... segments its first pass left to the fix-up rounds
+        *value = c->smp_seg_mismatch;
+    else if (n == "sample_rounds")
+        *value = c->smp_seg_rounds;
+    else if (n == "viterbi_rounds") // ... fix-up rounds its last pass needed
+        *value = c->vit_seg_rounds;
+    else if (n == "viterbi_mismatch") // ... boundaries of its last attempt that were not bit-identical
+        *value = c->vit_seg_mismatch;
     else if (n == "carry")
         *value = c->carry_enabled ? 1.0 : 0.0;
     else if (n == "carry_W") // warm-up steps of the last E-step's carried starts (0: full warm-ups)

@@ -128,6 +128,22 @@ struct bhmm_ctx {
     bhmm::DevBuf<double> d_fold;      // partial statistics folded 128 rows at a time (k_fold_rows)
     bhmm::DevBuf<double> d_tbpart;    // k_tail: per trajectory block [sum logL | sum gamma_0 (N)]
     int tail_slot = 0;                // verdict word set of the next E-step
+    // 9..64 states: time segments of the Viterbi pass [0] and of the backward sampler [1] (path_api.hip)
+    struct PathPlan {
+        int nseg = 0;
+        int64_t seglen = 0;
+        bhmm::DevBuf<int32_t> traj, len;
+        bhmm::DevBuf<int64_t> t0;
+    } pplan[2];
+    int smp_W = 0;                    // sampler: warm-up (steps above a segment) of the next call
+    int smp_seg_mismatch = 0, smp_seg_rounds = 0;
+    bool smp_segmented = false;       // the last sample_paths call ran over time segments
+    bhmm::DevBuf<int32_t> d_sentry, d_sexit;
+    int vit_seg_per_simd = 2;
+    int vit_seg_mismatch = 0, vit_seg_rounds = 0;
+    bhmm::DevBuf<double> d_vckpt;  // the first pass's vector at every 64th step
+    bhmm::DevBuf<uint8_t> d_vflag; // segments the next fix-up round repeats
+    bool vit_seg_given_up = false;    // ... boundaries did not coalesce on these observations: serial kernel
     int vit_W = 0;                    // warm-up the chunked Viterbi last verified with (0: spec_W)
     int vit_bad = 0;                  // ... a shorter one that did not verify
     bool vit_explore = true;          // ... still trying shorter ones (path_api.hip)

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "host_common.hpp"
+#include "plan.hpp"
 #include "path_kernels.hpp"
 
 namespace bhmm {
@@ -247,6 +248,33 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
                 for (int o = 0; o < c->M; ++o)
                     emis[(size_t)i * c->M + o] = he[(size_t)o * N + i];
     }
+    return BHMM_OK;
+}
+
+// time segments of at most seglen steps for the segment-parallel Viterbi pass (which = 0) / backward
+// sampler (which = 1); rebuilt only when the length changes
+static int wide_path_plan(bhmm_ctx *c, int which, int64_t seglen, Segs &sg)
+{
+    bhmm_ctx::PathPlan &pp = c->pplan[which];
+    if (pp.nseg == 0 || pp.seglen != seglen) {
+        plan::SegPlan sp;
+        plan::plan_segments(c->offsets, c->K, seglen, 1, sp);
+        const int ns = (int)sp.traj.size();
+        int rc;
+        if ((rc = pp.traj.ensure(std::max(ns, 1))) || (rc = pp.len.ensure(std::max(ns, 1))) ||
+            (rc = pp.t0.ensure(std::max(ns, 1))))
+            return rc;
+        BHMM_HIP(hipMemcpyAsync(pp.traj.p, sp.traj.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        BHMM_HIP(hipMemcpyAsync(pp.len.p, sp.len.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        BHMM_HIP(hipMemcpyAsync(pp.t0.p, sp.t0.data(), ns * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream)); // (the vectors go out of scope)
+        pp.nseg = ns;
+        pp.seglen = seglen;
+    }
+    sg.traj = pp.traj.p;
+    sg.len = pp.len.p;
+    sg.t0 = pp.t0.p;
+    sg.nseg = pp.nseg;
     return BHMM_OK;
 }
 
@@ -502,6 +530,128 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         c->spec_last_dev = dev;
         c->viterbi_close = c->h_specres[2];
     }
+    // 9..64 states: one lane group per time segment (k_wide_viterbi_seg); accepted only if EVERY
+    // segment arrives at its first step with the bit pattern its predecessor left there -- then the
+    // back-pointers are the serial run's, by induction from the exact first segment of each trajectory
+    if (c->wide && c->spec_enabled && !c->vit_seg_given_up) {
+        int W_try = c->vit_W > 0 ? c->vit_W : std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
+        bool exploring = false;
+        if (c->vit_W > 0 && c->vit_explore && !c->spec_W_fixed) {
+            const int Wn = std::max(32, (c->vit_W * 3 / 4 + 7) / 8 * 8);
+            if (Wn < c->vit_W && Wn > c->vit_bad) {
+                W_try = Wn;
+                exploring = true;
+            } else {
+                c->vit_explore = false;
+            }
+        }
+        if ((rc = c->d_specres.ensure(4)))
+            return rc;
+        if (!c->h_specres)
+            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
+                                   hipHostMallocDefault));
+        for (int attempt = 0; attempt < 2 && !done; ++attempt) {
+            if (attempt > 0) {
+                if (exploring) {
+                    c->vit_bad = W_try;
+                    c->vit_explore = false;
+                    exploring = false;
+                    W_try = c->vit_W;
+                } else {
+                    W_try *= 2;
+                }
+            }
+            // two lane groups' worth of segments per SIMD, none shorter than four warm-ups
+            const int64_t want = (int64_t)c->vit_seg_per_simd * c->num_simd * GP;
+            const int64_t seglen = std::max<int64_t>((c->total + want - 1) / want, 4 * (int64_t)W_try);
+            Segs sg;
+            if ((rc = wide_path_plan(c, 0, seglen, sg)))
+                return rc;
+            if (sg.nseg <= K)
+                break; // nothing to gain: one segment per trajectory is the serial kernel
+            sg.W = W_try;
+            if ((rc = c->d_aentry.ensure((size_t)sg.nseg * NP)) || (rc = c->d_aexit.ensure((size_t)sg.nseg * NP)))
+                return rc;
+            const dim3 sgrid((sg.nseg + GP * WVS_WPB - 1) / (GP * WVS_WPB)), sblk(64 * WVS_WPB);
+            if ((rc = c->d_vckpt.ensure(((size_t)(c->total >> 6) + 1) * NP)) ||
+                (rc = c->d_vflag.ensure((size_t)sg.nseg)))
+                return rc;
+#define BHMM_WVS(NPV, KINDV, FIXV)                                                                    \
+    hipLaunchKernelGGL((k_wide_viterbi_seg<NPV, KINDV, FIXV>), sgrid, sblk, 0, c->stream, m, off, sg,  \
+                       obs, ptr, last, c->d_aentry.p, c->d_aexit.p, c->d_vckpt.p,                     \
+                       (const uint8_t *)c->d_vflag.p)
+#define BHMM_WVS_KIND(NPV, FIXV)                                                                      \
+    do {                                                                                              \
+        if (vkind == EMIT_GAUSS)                                                                      \
+            BHMM_WVS(NPV, EMIT_GAUSS, FIXV);                                                          \
+        else if (vkind == EMIT_DISC)                                                                  \
+            BHMM_WVS(NPV, EMIT_DISC, FIXV);                                                           \
+        else                                                                                          \
+            BHMM_WVS(NPV, EMIT_EXPL, FIXV);                                                           \
+        hipLaunchKernelGGL((k_wide_vit_check<NPV>), dim3((sg.nseg + 255) / 256), dim3(256), 0,      \
+                           c->stream, sg, c->d_aentry.p, (const double *)c->d_aexit.p, c->d_vflag.p,  \
+                           c->d_specres.p);                                                           \
+    } while (0)
+#define BHMM_WVS_NP(FIXV)              \
+    do {                               \
+        if (NP == 16)                  \
+            BHMM_WVS_KIND(16, FIXV);   \
+        else if (NP == 32)             \
+            BHMM_WVS_KIND(32, FIXV);   \
+        else                           \
+            BHMM_WVS_KIND(64, FIXV);   \
+    } while (0)
+            // pass 0 with warm-ups, then fix-up rounds while any boundary is not bit-identical
+            const int max_rounds = 12;
+            int round = 0;
+            for (; round <= max_rounds; ++round) {
+                BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                if (round == 0)
+                    BHMM_WVS_NP(false);
+                else
+                    BHMM_WVS_NP(true);
+                BHMM_HIP(hipGetLastError());
+                BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
+                                        hipMemcpyDeviceToHost, c->stream));
+                BHMM_HIP(hipStreamSynchronize(c->stream));
+                if (round == 0)
+                    c->vit_seg_mismatch = (int)c->h_specres[3];
+                if (c->h_specres[3] == 0)
+                    break;
+            }
+#undef BHMM_WVS_NP
+#undef BHMM_WVS_KIND
+#undef BHMM_WVS
+            c->vit_seg_rounds = round;
+            const bool accepted = c->h_specres[3] == 0;
+            // a warm-up that leaves more than a fifth of the boundaries to the fix-up is too short
+            const bool short_W = !c->spec_W_fixed && (int64_t)c->vit_seg_mismatch * 5 > sg.nseg;
+            if (exploring && (!accepted || short_W)) {
+                if (accepted) { // (the paths are right; only the search ends here)
+                    c->vit_bad = W_try;
+                    c->vit_explore = false;
+                    done = true;
+                }
+                continue;
+            }
+            if (accepted) {
+                done = true;
+                c->vit_W = short_W ? 2 * W_try : W_try;
+            }
+        }
+        if (!done && c->pplan[0].nseg > K)
+            c->vit_seg_given_up = true; // these observations go to the serial kernel from now on
+        c->viterbi_chunked = done;
+        if (done) { // (the back-trace below is the serial family's)
+            if (out_fmt == 0)
+                hipLaunchKernelGGL(k_wide_viterbi_trace<int32_t>, dim3(K), dim3(64), 0, c->stream, off, K, n,
+                                   (const uint8_t *)ptr, (const int32_t *)last, path);
+            else
+                hipLaunchKernelGGL(k_wide_viterbi_trace<uint8_t>, dim3(K), dim3(64), 0, c->stream, off, K, n,
+                                   (const uint8_t *)ptr, (const int32_t *)last, path8);
+            walks_in_flight = true;
+        }
+    }
     if (done)
         ;
     else if (NP == 8)
@@ -587,18 +737,92 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
         BHMM_HIP(hipMemsetAsync(ered, 0, esz * sizeof(double), c->stream));
     const dim3 grid((K + GP - 1) / GP), blk(64);
     const int64_t *off = c->d_offsets.p;
-    if (NP == 16)
-        hipLaunchKernelGGL((k_wide_sample_path<16>), grid, blk, 0, c->stream, m, off, K,
-                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,
-                           (const int64_t *)c->d_soff.p);
-    else if (NP == 32)
-        hipLaunchKernelGGL((k_wide_sample_path<32>), grid, blk, 0, c->stream, m, off, K,
-                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,
-                           (const int64_t *)c->d_soff.p);
-    else
-        hipLaunchKernelGGL((k_wide_sample_path<64>), grid, blk, 0, c->stream, m, off, K,
-                           (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,
-                           (const int64_t *)c->d_soff.p);
+    auto launch_serial = [&]() {
+        if (NP == 16)
+            hipLaunchKernelGGL((k_wide_sample_path<16>), grid, blk, 0, c->stream, m, off, K,
+                               (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,
+                               (const int64_t *)c->d_soff.p);
+        else if (NP == 32)
+            hipLaunchKernelGGL((k_wide_sample_path<32>), grid, blk, 0, c->stream, m, off, K,
+                               (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,
+                               (const int64_t *)c->d_soff.p);
+        else
+            hipLaunchKernelGGL((k_wide_sample_path<64>), grid, blk, 0, c->stream, m, off, K,
+                               (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,
+                               (const int64_t *)c->d_soff.p);
+    };
+    // parallel over time segments where that fills more of the device than the trajectories do
+    // (k_wide_sample_seg): the draws are coupled through the per-step uniforms, segments that did not
+    // continue their successor's state are drawn again until none is left
+    c->smp_segmented = false;
+    bool seg_done = false;
+    if (c->spec_enabled) {
+        const int64_t want = (int64_t)c->vit_seg_per_simd * c->num_simd * GP;
+        const int64_t seglen = std::max<int64_t>((c->total + want - 1) / want, 64);
+        Segs sg;
+        if ((rc = wide_path_plan(c, 1, seglen, sg)))
+            return rc;
+        if (sg.nseg > K) {
+            if (c->smp_W <= 0)
+                c->smp_W = 64;
+            sg.W = c->smp_W;
+            if ((rc = c->d_sentry.ensure((size_t)sg.nseg)) || (rc = c->d_sexit.ensure((size_t)sg.nseg)) ||
+                (rc = c->d_vflag.ensure((size_t)sg.nseg)) || (rc = c->d_specres.ensure(4)))
+                return rc;
+            if (!c->h_specres)
+                BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
+                                       hipHostMallocDefault));
+            const dim3 sgrid((sg.nseg + GP * WVS_WPB - 1) / (GP * WVS_WPB)), sblk(64 * WVS_WPB);
+#define BHMM_WSS(NPV, FIXV)                                                                              \
+    hipLaunchKernelGGL((k_wide_sample_seg<NPV, FIXV>), sgrid, sblk, 0, c->stream, m, off, sg,           \
+                       (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,       \
+                       (const int64_t *)c->d_soff.p, c->d_sentry.p, c->d_sexit.p,                       \
+                       (const uint8_t *)c->d_vflag.p)
+#define BHMM_WSS_NP(FIXV)          \
+    do {                           \
+        if (NP == 16)              \
+            BHMM_WSS(16, FIXV);    \
+        else if (NP == 32)         \
+            BHMM_WSS(32, FIXV);    \
+        else                       \
+            BHMM_WSS(64, FIXV);    \
+    } while (0)
+            const int max_rounds = 16;
+            int round = 0;
+            for (; round <= max_rounds; ++round) {
+                BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                if (round == 0)
+                    BHMM_WSS_NP(false);
+                else
+                    BHMM_WSS_NP(true);
+                hipLaunchKernelGGL(k_wide_smp_check, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg,
+                                   c->d_sentry.p, (const int32_t *)c->d_sexit.p, c->d_vflag.p, c->d_specres.p);
+                BHMM_HIP(hipGetLastError());
+                BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
+                                        hipMemcpyDeviceToHost, c->stream));
+                BHMM_HIP(hipMemcpyAsync(&c->h_specres[0], status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                BHMM_HIP(hipStreamSynchronize(c->stream));
+                if (round == 0)
+                    c->smp_seg_mismatch = (int)c->h_specres[3];
+                if (c->h_specres[3] == 0)
+                    break;
+            }
+#undef BHMM_WSS_NP
+#undef BHMM_WSS
+            c->smp_seg_rounds = round;
+            // (a draw that found no state may belong to a segment that was drawn again afterwards:
+            // the serial kernel decides such a call)
+            seg_done = c->h_specres[3] == 0 && c->h_specres[0] == 0;
+            if (!seg_done)
+                BHMM_HIP(hipMemsetAsync(status, 0, sizeof(int), c->stream));
+            // more than a tenth of the segments left to the fix-up: a longer warm-up next time
+            if ((int64_t)c->smp_seg_mismatch * 10 > sg.nseg && c->smp_W < 4096)
+                c->smp_W *= 2;
+            c->smp_segmented = seg_done;
+        }
+    }
+    if (!seg_done)
+        launch_serial();
     BHMM_HIP(hipGetLastError());
     if (counts || n0 || emis || stats_dev) {
         // the per-trajectory emission table in LDS, or -- alphabets too large for it -- in epart itself

@@ -1085,6 +1085,210 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
     }
 }
 
+// =========================================================================================
+// 9..64 states, parallel over time segments (round 4): the same order-faithful step as
+// k_wide_viterbi_fwd, one lane group per SEGMENT instead of per trajectory, and bit-identical to the
+// serial run by construction:
+//   pass 0   every segment that does not start its trajectory begins W steps early from the uniform
+//            vector (the max-product recursion forgets its start: the survivors coalesce);
+//   check    k_wide_vit_check compares the vector a segment arrived with at its first step (v_entry)
+//            BITWISE with the one its predecessor computed there (v_exit).  In the typical run nine
+//            boundaries in ten are identical to the bit (the two runs, a few ulp apart after the
+//            survivors met, fall onto the same sequence of doubles); the others are flagged, and
+//            their v_entry is replaced by the predecessor's vector;
+//   fix-up   (FIX = true) a flagged segment is run again from that exact vector, without warm-up.  The
+//            first pass left its vector every 64th step (`ckpt`); as soon as the repeated run
+//            reproduces one of them bitwise, everything behind it -- back-pointers, v_exit -- is what
+//            the first pass wrote, and the segment stops.  One that reaches its end writes a new
+//            v_exit, which the next check compares with its successor's entry.
+// When a check finds no difference, every segment started from the serial run's vector (induction
+// from the first segment of each trajectory, which starts from pi exactly), so every back-pointer is
+// the serial run's.  The host bounds the number of rounds and runs the serial kernel beyond it.
+// Argmax: the select tree carries (product, index) only; v[i^] and A[i^][j] are looked up afterwards
+// in LDS (three selects per node instead of seven).  A is shared by the WPB wavefronts of a workgroup.
+//   v_entry / v_exit [nseg][NP];  ckpt [(total >> 6) + 1][NP];  flag [nseg]
+// =========================================================================================
+constexpr int WVS_WPB = 4;
+template <int NP, int KIND, bool FIX>
+__global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
+    const WideModel m, const int64_t *off, const Segs sg, const void *obs_rm, uint8_t *ptr,
+    int32_t *last_state, double *v_entry, double *v_exit, double *ckpt, const uint8_t *flag)
+{
+    constexpr int GP = 64 / NP;
+    constexpr int TL = NP < 16 ? NP : 16; // argmax tile
+    __shared__ __attribute__((aligned(16))) double xv[WVS_WPB][GP][NP];
+    __shared__ __attribute__((aligned(16))) double xn[WVS_WPB][GP][NP];
+    __shared__ double sA[NP * NP];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gi = lane / NP, j = lane % NP;
+    const int n = m.n;
+    for (int e = threadIdx.x; e < NP * NP; e += 64 * WVS_WPB)
+        sA[e] = (e / NP < n && e % NP < n) ? m.A[(int64_t)(e / NP) * n + e % NP] : 0.0;
+    __syncthreads(); // (the only one: from here on the wavefronts are on their own)
+    const int sgi = (blockIdx.x * WVS_WPB + w) * GP + gi;
+    if (sgi >= sg.nseg || sg.len[sgi] <= 0)
+        return;
+    if constexpr (FIX) {
+        if (!flag[sgi])
+            return;
+    }
+    const bool real = j < n;
+    const unsigned long long gmask = wgroup_mask<NP>(lane);
+    double Acol[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        Acol[i] = sA[i * NP + j];
+    const double mu_j = (KIND == EMIT_GAUSS && real) ? m.mu[j] : 0.0;
+    const double sg_j = (KIND == EMIT_GAUSS && real) ? m.sigma[j] : 1.0;
+    const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
+    const double pi_j = real ? m.pi[j] : 0.0;
+    const int k = sg.traj[sgi];
+    const int64_t o0 = off[k], T = off[k + 1] - o0;
+    const int64_t t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+    const int64_t tw = FIX ? t0 : ((t0 - sg.W > 0) ? t0 - sg.W : 0);
+    auto emis = [&](int64_t gt) __attribute__((always_inline)) {
+        double p;
+        if constexpr (KIND == EMIT_GAUSS) {
+            const double o = static_cast<const double *>(obs_rm)[gt];
+            const double d = (o - mu_j) / sg_j;
+            p = real ? cn_j * exp_nonpos(-0.5 * d * d) : 0.0; // _gaussian.c:18-20
+            if ((__ballot(p != 0.0) & gmask) == 0ull)
+                p = real ? 1.0 : 0.0;
+        } else if constexpr (KIND == EMIT_DISC) {
+            const int sym = static_cast<const int32_t *>(obs_rm)[gt];
+            p = real ? m.B[(int64_t)j * m.M + sym] : 0.0;
+        } else {
+            p = real ? static_cast<const double *>(obs_rm)[gt * n + j] : 0.0;
+        }
+        return p;
+    };
+    // (warm-up start; replaced at t = 0.  FIX: the predecessor's vector, t0 > 0 for a flagged segment)
+    double v = FIX ? v_entry[(int64_t)sgi * NP + j] : (real ? 1.0 / (double)n : 0.0);
+    double p_next = emis(o0 + tw);
+    bool met = false; // FIX: the run reproduced a vector of the first pass
+    for (int64_t t = tw; t < t1; ++t) {
+        const double p = p_next;
+        if (t + 1 < t1)
+            p_next = emis(o0 + t + 1); // independent of the recursion
+        double vn;
+        if (t == 0) {
+            vn = p * pi_j; // _hidden.c:232
+        } else {
+            xv[w][gi][j] = v;
+            // first-maximum argmax (_hidden.c:186-200) as a select tree per tile of <= 16 states: the
+            // later candidate wins only if strictly greater, which is exactly the linear scan's
+            // result; tiles are folded in index order with the same rule
+            double bh = 0.0;
+            int bi = 0;
+#pragma unroll
+            for (int tl = 0; tl < NP; tl += TL) {
+                double hh[TL];
+                int ii[TL];
+#pragma unroll
+                for (int i = 0; i < TL; i += 2) {
+                    const double2 x = *reinterpret_cast<const double2 *>(&xv[w][gi][tl + i]);
+                    hh[i] = x.x * Acol[tl + i]; // _hidden.c:249
+                    hh[i + 1] = x.y * Acol[tl + i + 1];
+                    ii[i] = tl + i;
+                    ii[i + 1] = tl + i + 1;
+                }
+#define BHMM_ARGMAX_LEVEL(W)                                           \
+    if constexpr (TL > W) {                                            \
+        _Pragma("unroll") for (int i = 0; i + W < TL; i += 2 * W)      \
+        {                                                              \
+            const bool take = hh[i + W] > hh[i];                       \
+            hh[i] = take ? hh[i + W] : hh[i];                          \
+            ii[i] = take ? ii[i + W] : ii[i];                          \
+        }                                                              \
+    }
+                BHMM_ARGMAX_LEVEL(1)
+                BHMM_ARGMAX_LEVEL(2)
+                BHMM_ARGMAX_LEVEL(4)
+                BHMM_ARGMAX_LEVEL(8)
+#undef BHMM_ARGMAX_LEVEL
+                const bool take = (tl == 0) || (hh[0] > bh);
+                bh = take ? hh[0] : bh;
+                bi = take ? ii[0] : bi;
+            }
+            if (real && t >= t0)
+                ptr[(o0 + t) * n + j] = (uint8_t)bi;
+            const double bv = xv[w][gi][bi], bA = sA[bi * NP + j];
+            vn = p * bv * bA; // _hidden.c:253: (p v[i^]) A[i^][j]
+        }
+        xn[w][gi][j] = vn;
+        double S = 0.0;
+#pragma unroll
+        for (int tl = 0; tl < NP; tl += TL) {
+            double xs[TL];
+#pragma unroll
+            for (int i = 0; i < TL; i += 2) {
+                const double2 x = *reinterpret_cast<const double2 *>(&xn[w][gi][tl + i]);
+                xs[i] = x.x;
+                xs[i + 1] = x.y;
+            }
+#pragma unroll
+            for (int i = 0; i < TL; ++i)
+                S += xs[i]; // ascending order; padded states add exact zeros
+        }
+        v = vn / S;
+        if constexpr (!FIX) {
+            if (t == t0 - 1)
+                v_entry[(int64_t)sgi * NP + j] = v;
+        }
+        if (((o0 + t) & 63) == 63 && t >= t0) {
+            double *cp = ckpt + ((o0 + t) >> 6) * NP + j;
+            if constexpr (FIX) {
+                const bool same = __double_as_longlong(*cp) == __double_as_longlong(v);
+                if ((__ballot(!same) & gmask) == 0ull) {
+                    met = true;
+                    break;
+                }
+            }
+            *cp = v;
+        }
+    }
+    if (met)
+        return;
+    v_exit[(int64_t)sgi * NP + j] = v;
+    if (t1 == T) { // the trajectory's final state (_hidden.c:262-267: first maximum)
+        xv[w][gi][j] = v;
+        if (j == 0) {
+            double bm = xv[w][gi][0];
+            int bi = 0;
+            for (int i = 1; i < n; ++i)
+                if (xv[w][gi][i] > bm) {
+                    bm = xv[w][gi][i];
+                    bi = i;
+                }
+            last_state[k] = bi;
+        }
+    }
+}
+
+// result[3] = segments whose entry vector is not bit-identical to the predecessor's exit vector; those
+// are flagged, and their entry vector becomes the predecessor's (what the fix-up pass starts from)
+template <int NP>
+__global__ void k_wide_vit_check(const Segs sg, double *v_entry, const double *v_exit, uint8_t *flag,
+                                 unsigned int *result)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool differs = false;
+    if (s < sg.nseg && sg.len[s] > 0 && sg.t0[s] != 0) {
+        double *x = v_entry + (int64_t)s * NP;
+        const double *y = v_exit + (int64_t)(s - 1) * NP;
+        for (int j = 0; j < NP; ++j)
+            differs |= __double_as_longlong(x[j]) != __double_as_longlong(y[j]);
+        if (differs)
+            for (int j = 0; j < NP; ++j)
+                x[j] = y[j];
+    }
+    if (s < sg.nseg)
+        flag[s] = differs ? 1 : 0;
+    const unsigned long long d = __ballot(differs);
+    if ((threadIdx.x & 63) == 0 && d)
+        atomicAdd(&result[3], (unsigned int)__popcll(d));
+}
+
 // ---- instruction-count diet of the chunked Viterbi step (round 3) ------------------------------
 // The chunked Viterbi kernel is bound by the length of its instruction stream (four wavefronts per
 // SIMD at ~0.9 of the issue ceiling), so what follows removes instructions without touching a
@@ -1831,6 +2035,141 @@ __global__ __launch_bounds__(64) void k_wide_sample_path(const WideModel m, cons
         if (i == 0)
             path[o0 + t] = pick;
     }
+}
+
+// =========================================================================================
+// 9..64 states, backward sampling parallel over time segments (round 4).  The draw at step t is a
+// function of (alpha_t, the state drawn at t + 1, the uniform of step t) -- the uniforms belong to the
+// steps, not to the run -- so two runs that differ in where they started are COUPLED: once they draw
+// the same state at some step they agree at every earlier one.
+//   pass 0   a segment that does not end its trajectory starts W steps above its last step from state
+//            0 (or from the exact rule at T - 1 where the warm-up reaches it) and notes the state it
+//            drew for the step above its own (s_entry);
+//   check    k_wide_smp_check: s_entry against the state the successor drew there (s_exit of s + 1);
+//            where they differ the segment is flagged and s_entry becomes the successor's state;
+//   fix-up   (FIX) a flagged segment is drawn again from that state and stops as soon as it draws the
+//            state the path already holds at that step -- from there down nothing changes.  One
+//            that reaches its first step writes a new s_exit for the next check.
+// When a check finds nothing, every segment continued the state its successor drew: the path is the
+// serial run's (_hidden.c:331-380), by induction from the last segment of each trajectory.
+// A in LDS, transposed ([next state][i]: the lanes of a group read consecutive words).
+// =========================================================================================
+template <int NP, bool FIX>
+__global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
+    const WideModel m, const int64_t *off, const Segs sg, const double *alpha_rm, const double *u,
+    uint64_t seed, int32_t *path, int *status, const int64_t *soff, int32_t *s_entry, int32_t *s_exit,
+    const uint8_t *flag)
+{
+    constexpr int GP = 64 / NP;
+    constexpr int TL = NP < 16 ? NP : 16;
+    __shared__ __attribute__((aligned(16))) double xs[WVS_WPB][GP][NP];
+    __shared__ __attribute__((aligned(16))) double xp[WVS_WPB][GP][NP];
+    __shared__ double sAT[NP * NP];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gi = lane / NP, i = lane % NP;
+    const int n = m.n;
+    for (int e = threadIdx.x; e < NP * NP; e += 64 * WVS_WPB) // sAT[nxt][i] = A[i][nxt]
+        sAT[e] = (e / NP < n && e % NP < n) ? m.A[(int64_t)(e % NP) * n + e / NP] : 0.0;
+    __syncthreads(); // (the only one)
+    const int sgi = (blockIdx.x * WVS_WPB + w) * GP + gi;
+    if (sgi >= sg.nseg || sg.len[sgi] <= 0)
+        return;
+    if constexpr (FIX) {
+        if (!flag[sgi])
+            return;
+    }
+    const bool real = i < n;
+    const int k = sg.traj[sgi];
+    const int64_t o0 = off[k], T = off[k + 1] - o0;
+    const int64_t s0 = soff ? soff[k] : o0; // position of this trajectory in the random stream
+    const int64_t t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+    const int64_t ts = FIX ? t1 - 1 : ((t1 + sg.W < T ? t1 + sg.W : T) - 1);
+    int nxt = FIX ? s_entry[sgi] : 0;
+    double a_next = real ? alpha_rm[(o0 + ts) * n + i] : 0.0;
+    bool met = false;
+    for (int64_t t = ts; t >= t0; --t) {
+        const double a = a_next;
+        if (t > t0)
+            a_next = real ? alpha_rm[(o0 + t - 1) * n + i] : 0.0; // independent of the draw
+        double ps = a;
+        if (t != T - 1)
+            ps = a * sAT[nxt * NP + i]; // _hidden.c:365 (padded states: 0 * 0)
+        xs[w][gi][i] = ps;
+        const double r = u ? u[o0 + t] : uniform01(seed, (uint64_t)(s0 + t));
+        double S = 0.0;
+#pragma unroll
+        for (int tl = 0; tl < NP; tl += TL) {
+            double x[TL];
+#pragma unroll
+            for (int q = 0; q < TL; q += 2) {
+                const double2 y = *reinterpret_cast<const double2 *>(&xs[w][gi][tl + q]);
+                x[q] = y.x;
+                x[q + 1] = y.y;
+            }
+#pragma unroll
+            for (int q = 0; q < TL; ++q)
+                S += x[q]; // _normalize, ascending
+        }
+        xp[w][gi][i] = ps / S;
+        double acc = 0.0;
+        int pick = NP;
+#pragma unroll
+        for (int tl = 0; tl < NP; tl += TL) {
+            double x[TL];
+#pragma unroll
+            for (int q = 0; q < TL; q += 2) {
+                const double2 y = *reinterpret_cast<const double2 *>(&xp[w][gi][tl + q]);
+                x[q] = y.x;
+                x[q + 1] = y.y;
+            }
+#pragma unroll
+            for (int q = 0; q < TL; ++q) {
+                acc += x[q]; // _hidden.c:299-303: the first state whose cumulative sum reaches r
+                const int cand = (acc >= r) ? tl + q : NP;
+                pick = cand < pick ? cand : pick;
+            }
+        }
+        if (pick >= n) { // (a padded state's sum is the last real one's: it would have been drawn there)
+            if (i == 0 && t < t1)
+                status[0] = BHMM_ERR_CHOICE;
+            pick = n - 1;
+        }
+        nxt = pick;
+        if constexpr (!FIX) {
+            if (t == t1 && i == 0)
+                s_entry[sgi] = pick;
+        }
+        if (t < t1) {
+            if constexpr (FIX) {
+                if (path[o0 + t] == pick) {
+                    met = true;
+                    break;
+                }
+            }
+            if (i == 0)
+                path[o0 + t] = pick;
+        }
+    }
+    if (!met && i == 0)
+        s_exit[sgi] = nxt;
+}
+
+// result[3] = segments that did not continue the state their successor drew; flagged, s_entry replaced
+[[maybe_unused]] static __global__ void k_wide_smp_check(const Segs sg, int32_t *s_entry, const int32_t *s_exit, uint8_t *flag,
+                                 unsigned int *result)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool differs = false;
+    if (s + 1 < sg.nseg && sg.len[s] > 0 && sg.traj[s + 1] == sg.traj[s]) {
+        differs = s_entry[s] != s_exit[s + 1];
+        if (differs)
+            s_entry[s] = s_exit[s + 1];
+    }
+    if (s < sg.nseg)
+        flag[s] = differs ? 1 : 0;
+    const unsigned long long d = __ballot(differs);
+    if ((threadIdx.x & 63) == 0 && d)
+        atomicAdd(&result[3], (unsigned int)__popcll(d));
 }
 
 // hidden-path statistics for 9..64 states: one workgroup per trajectory; integer counts in

@@ -129,6 +129,57 @@ def test_wide_viterbi_bit_exact(golden):
     eng.close()
 
 
+@pytest.mark.parametrize("n,kind", [(64, "gaussian"), (33, "gaussian"), (16, "discrete"), (9, "gaussian"),
+                                    (40, "discrete")])
+def test_wide_viterbi_over_time_segments_is_the_serial_run(n, kind):
+    """9..64 states, trajectories cut into time segments (k_wide_viterbi_seg): segments whose start vector
+    is not the predecessor's to the bit are repeated from it until none is left, and then the paths are
+    the oracle's (_hidden.c:186-276) byte for byte; ragged lengths, a trajectory shorter than a warm-up
+    and one of a single step included."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(900 + n)
+    M = 30
+    A, pi, p0, p1 = _random_model(n, rng, kind, M)
+    lengths = (30011, 1, 9000, 257, 12345)
+    if kind == "gaussian":
+        obs = [rng.normal(0, 3, T) for T in lengths]
+        pobs = [orc.pobs_gaussian(o, p0, p1) for o in obs]
+    else:
+        obs = [rng.integers(0, M, T).astype(np.int32) for T in lengths]
+        pobs = [orc.pobs_discrete(o, p0) for o in obs]
+    eng = Engine(0)
+    eng.set_option("viterbi_seg_per_simd", 1)
+    eng.set_observations(kind, obs, n, nsymbols=M if kind == "discrete" else 0)
+    for rep in range(3):                              # (later calls search a shorter warm-up)
+        paths = eng.viterbi(A, pi, p0, p1)
+        assert eng.get_option("viterbi_chunked") == 1 and eng.get_option("viterbi_segments") > 40
+        for p, po in zip(paths, pobs):
+            assert np.array_equal(p, orc.viterbi(A, po, pi)), rep
+    eng.close()
+
+
+def test_wide_viterbi_segments_that_do_not_coalesce_go_to_the_serial_kernel():
+    """A model that never forgets (the identity plus a whisper) and flat emissions: warm-ups from the
+    uniform vector do not reproduce the serial run's vectors, and the repeated segments do not fall
+    back onto the first pass's either; after a bounded number of rounds the serial kernel decides, and
+    keeps these observations -- the paths are still the oracle's."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(12)
+    n = 16
+    A = np.eye(n) * (1 - 1e-9) + 1e-9 / n
+    A /= A.sum(axis=1)[:, None]
+    pi = rng.dirichlet(np.ones(n))
+    mu, sig = np.zeros(n) + 1e-3 * np.arange(n), np.ones(n)
+    obs = [rng.normal(0, 1, 200000)]
+    eng = Engine(0)
+    eng.set_observations("gaussian", obs, n)
+    for _ in range(2):
+        p = eng.viterbi(A, pi, mu, sig)[0]
+        assert eng.get_option("viterbi_chunked") == 0
+        assert np.array_equal(p, orc.viterbi(A, orc.pobs_gaussian(obs[0], mu, sig), pi))
+    eng.close()
+
+
 def test_wide_path_sampling():
     import bhmm_amd.hidden as hidden
     from bhmm_amd.engine import Engine
