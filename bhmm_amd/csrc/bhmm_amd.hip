@@ -1584,6 +1584,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->pplan[0].nseg;
     else if (n == "sample_segmented") // 9..64 states: the last path sampling ran over time segments
         *value = c->smp_segmented ? 1.0 : 0.0;
+    else if (n == "sample_forward_segmented")
+        *value = c->draw_fwd_segmented ? 1.0 : 0.0;
     else if (n == "sample_segments")
         *value = c->pplan[1].nseg;
     else if (n == "sample_W")

@@ -137,6 +137,7 @@ struct bhmm_ctx {
     } pplan[2];
     int smp_W = 0;                    // sampler: warm-up (steps above a segment) of the next call
     int smp_seg_mismatch = 0, smp_seg_rounds = 0;
+    bool draw_fwd_segmented = false;  // ... its alpha rows came from the time-segmented forward pass
     bool smp_segmented = false;       // the last sample_paths call ran over time segments
     bhmm::DevBuf<int32_t> d_sentry, d_sexit;
     int vit_seg_per_simd = 2;

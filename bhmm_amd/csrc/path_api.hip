@@ -18,6 +18,8 @@ namespace bhmm {
 int invalid_arg(const std::string &msg);
 int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, const double *par0,
                    const double *par1, WideModel &m);
+int wide_forward_draw(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                      const double *par1);
 int wide_forward(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                  const double *par1);
 int wide_transition_counts(double *C, const double *A, const double *pobs, const double *alpha,
@@ -705,7 +707,7 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
                     const double *par1, const double *u, uint64_t seed, int32_t *paths,
                     int64_t *counts, int64_t *n0, double *emis, double *stats_dev)
 {
-    int rc = wide_forward(c, A, pi, par0, par1); // alpha (row-major) in d_alpha_rm
+    int rc = wide_forward_draw(c, A, pi, par0, par1); // alpha (row-major, any scale per row) in d_alpha_rm
     if (rc)
         return rc;
     WideModel m;

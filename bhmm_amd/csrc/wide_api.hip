@@ -466,6 +466,50 @@ static int wide_probe_run(bhmm_ctx *c, const WideModel &m, int *W_out)
     return BHMM_OK;
 }
 
+// First pass over these observations with this family: measure how fast the model forgets
+// (wide_probe_run) and plan the segments for that warm-up length (at least four warm-ups long, or
+// what fills the chip).
+static int wide_calibrate(bhmm_ctx *c, const WideModel &m)
+{
+    int rc = BHMM_OK;
+    c->spec_calibrated = true;
+    int W = 0;
+    switch (c->kind) {
+    case EMIT_GAUSS:
+        rc = WIDE_DISPATCH(c, EMIT_GAUSS, wide_probe_run, c, m, &W);
+        break;
+    case EMIT_DISC:
+        rc = WIDE_DISPATCH(c, EMIT_DISC, wide_probe_run, c, m, &W);
+        break;
+    default:
+        rc = WIDE_DISPATCH(c, EMIT_EXPL, wide_probe_run, c, m, &W);
+    }
+    if (rc)
+        return rc;
+    const int W_planned = c->spec_W;
+    if (W > 0)
+        c->spec_W = W;
+    if (W > W_planned) { // longer warm-ups than the plan assumed: longer segments
+        int64_t maxT = 0;
+        for (int k = 0; k < c->K; ++k)
+            maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+        int64_t seglen = c->wseg_len;
+        if (seglen <= 0)
+            seglen = std::max<int64_t>(wide_fill_len(c), (wide_tile(c) ? 2 : 4) * (int64_t)W);
+        seglen = std::max(seglen, c->wseg_cur_len); // never more segments than allocated for
+        if (seglen >= maxT) {
+            c->wseg_given_up = true;
+        } else if (seglen > c->wseg_cur_len) {
+            c->wseg_cur_len = seglen;
+            if ((rc = wide_plan_segments(c, seglen)))
+                return rc;
+            if (c->w_nseg[1] <= c->w_nseg[0])
+                c->wseg_given_up = true;
+        }
+    }
+    return BHMM_OK;
+}
+
 int wide_forward(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                  const double *par1)
 {
@@ -481,6 +525,52 @@ int wide_forward(bhmm_ctx *c, const double *A, const double *pi, const double *p
     default:
         return WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m, 0);
     }
+}
+
+// alpha rows for the backward draw (path_api.hip): the time-segmented forward pass of the E-step
+// (lazily scaled / matrix-core kernels where the context uses them -- the draw normalises
+// alpha_t[i] A[i][s_{t+1}] itself, any positive factor per row cancels), boundaries verified to 1e-11
+// like the E-step's; anything else -- the exact serial recursion of wide_forward.
+int wide_forward_draw(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
+                      const double *par1)
+{
+    WideModel m;
+    int rc = wide_model(c, c->kind, A, pi, par0, par1, m);
+    if (rc)
+        return rc;
+    if (c->spec_enabled && c->wseg_enabled) {
+        if (!c->spec_calibrated && c->w_nseg[1] > c->w_nseg[0] && (rc = wide_calibrate(c, m)))
+            return rc;
+        if (!c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) {
+            const bool lazy = !c->careful && !c->wide_careful;
+            BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 3 * sizeof(unsigned int), c->stream));
+            switch (c->kind) {
+            case EMIT_GAUSS:
+                rc = WIDE_DISPATCH(c, EMIT_GAUSS, wide_launch_fwd, c, m, 1, lazy);
+                break;
+            case EMIT_DISC:
+                rc = WIDE_DISPATCH(c, EMIT_DISC, wide_launch_fwd, c, m, 1, lazy);
+                break;
+            default:
+                rc = WIDE_DISPATCH(c, EMIT_EXPL, wide_launch_fwd, c, m, 1, lazy);
+            }
+            if (rc)
+                return rc;
+            const Segs sgf = segs_of(c, wide_fwd_plan(c, 1));
+            hipLaunchKernelGGL(k_wide_check, dim3((sgf.nseg + 255) / 256), dim3(256), 0, c->stream, sgf,
+                               c->n, (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
+                               (const double *)nullptr, (const double *)nullptr, 1e-11, c->d_specres.p);
+            BHMM_HIP(hipGetLastError());
+            BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 3 * sizeof(unsigned int),
+                                    hipMemcpyDeviceToHost, c->stream));
+            BHMM_HIP(hipStreamSynchronize(c->stream));
+            c->draw_fwd_segmented = c->h_specres[0] == 0 && (!lazy || c->h_specres[2] == 0);
+            if (c->draw_fwd_segmented)
+                return BHMM_OK;
+        }
+    }
+    c->draw_fwd_segmented = false;
+    return wide_forward(c, A, pi, par0, par1);
 }
 
 int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
@@ -523,45 +613,8 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipEventRecord(c->ev[4], c->stream));
         return BHMM_OK;
     };
-    if (c->wseg_enabled && !c->spec_calibrated && c->w_nseg[1] > c->w_nseg[0]) {
-        // first E-step on these observations: measure how fast this model forgets and plan the
-        // segments for that warm-up length (at least four warm-ups long, or what fills the chip)
-        c->spec_calibrated = true;
-        int W = 0;
-        switch (c->kind) {
-        case EMIT_GAUSS:
-            rc = WIDE_DISPATCH(c, EMIT_GAUSS, wide_probe_run, c, m, &W);
-            break;
-        case EMIT_DISC:
-            rc = WIDE_DISPATCH(c, EMIT_DISC, wide_probe_run, c, m, &W);
-            break;
-        default:
-            rc = WIDE_DISPATCH(c, EMIT_EXPL, wide_probe_run, c, m, &W);
-        }
-        if (rc)
-            return rc;
-        const int W_planned = c->spec_W;
-        if (W > 0)
-            c->spec_W = W;
-        if (W > W_planned) { // longer warm-ups than the plan assumed: longer segments
-            int64_t maxT = 0;
-            for (int k = 0; k < c->K; ++k)
-                maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
-            int64_t seglen = c->wseg_len;
-            if (seglen <= 0)
-                seglen = std::max<int64_t>(wide_fill_len(c), (wide_tile(c) ? 2 : 4) * (int64_t)W);
-            seglen = std::max(seglen, c->wseg_cur_len); // never more segments than allocated for
-            if (seglen >= maxT) {
-                c->wseg_given_up = true;
-            } else if (seglen > c->wseg_cur_len) {
-                c->wseg_cur_len = seglen;
-                if ((rc = wide_plan_segments(c, seglen)))
-                    return rc;
-                if (c->w_nseg[1] <= c->w_nseg[0])
-                    c->wseg_given_up = true;
-            }
-        }
-    }
+    if (c->wseg_enabled && !c->spec_calibrated && c->w_nseg[1] > c->w_nseg[0] && (rc = wide_calibrate(c, m)))
+        return rc;
     if (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) {
         // time-segmented run with warm-up boundaries, verified afterwards
         // lazily scaled kernels unless an earlier E-step on these data left their range

@@ -224,6 +224,41 @@ def test_wide_path_sampling():
     eng.close()
 
 
+@pytest.mark.parametrize("n,kind", [(64, "gaussian"), (20, "discrete"), (33, "gaussian")])
+def test_wide_path_sampling_over_time_segments_is_the_serial_draw(n, kind):
+    """9..64 states: the backward draw (_hidden.c:331-380) over time segments coupled through the
+    per-step uniforms -- with the caller's uniforms the paths are the oracle's, state for state; with the
+    device's counter-based stream they are the serial kernel's (spec_enabled = 0)."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(300 + n)
+    M = 18
+    A, pi, p0, p1 = _random_model(n, rng, kind, M)
+    lengths = (40011, 1, 9000, 2, 257, 20000)
+    if kind == "gaussian":
+        obs = [rng.normal(0, 3, T) for T in lengths]
+        pobs = [orc.pobs_gaussian(o, p0, p1) for o in obs]
+    else:
+        obs = [rng.integers(0, M, T).astype(np.int32) for T in lengths]
+        pobs = [orc.pobs_discrete(o, p0) for o in obs]
+    u = [rng.random(T) for T in lengths]
+    eng = Engine(0)
+    eng.set_option("viterbi_seg_per_simd", 1)
+    eng.set_observations(kind, obs, n, nsymbols=M if kind == "discrete" else 0)
+    for rep in range(2):
+        paths, C, n0, emis = eng.sample_paths(A, pi, p0, p1, u=u)
+        assert eng.get_option("sample_segmented") == 1 and eng.get_option("sample_segments") > 40
+        ref = [orc.sample_path(orc.forward(A, po, pi)[1], A, u=uu) for po, uu in zip(pobs, u)]
+        assert sum(int((p != r).sum()) for p, r in zip(paths, ref)) == 0
+        Cr, n0r = orc.path_counts(ref, n)
+        assert np.array_equal(C, Cr) and np.array_equal(n0, n0r)
+    seeded = eng.sample_paths(A, pi, p0, p1, seed=11)[0]
+    eng.set_option("spec_enabled", 0)
+    serial = eng.sample_paths(A, pi, p0, p1, seed=11)[0]
+    assert eng.get_option("sample_segmented") == 0
+    assert all(np.array_equal(a, b) for a, b in zip(seeded, serial))
+    eng.close()
+
+
 def test_wide_time_segments_verified_or_fallback():
     """9..64 states: trajectories cut into time segments with warm-up boundaries; the result
     must equal the serial recursion, and a too-short warm-up must be caught."""
