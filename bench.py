@@ -514,7 +514,51 @@ def secondary_c4(torch, dev, local, args):
                       if eng.get_option("tile") else "k_wide_fwd / k_wide_bwd (one segment per wavefront)",
            "kernel_ms": {"forward": eng.kernel_ms(0), "backward_and_statistics": eng.kernel_ms(2)},
            "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")}}
+    # the other two passes of the path on this shape: both run over time segments (round 4) and are
+    # accepted only as the serial run's result (bitwise boundary vectors / coupled draws)
+    pdev = torch.empty(K * T, dtype=torch.uint8, device=dev)
+    for _ in range(5):                 # (the Viterbi pass searches its own warm-up over the first calls)
+        eng.viterbi_u8(*margs, out=pdev)
+    dv = timeit(lambda: eng.viterbi_u8(*margs, out=pdev), 3, eng.sync)
+    out["viterbi"] = {"ms": 1e3 * dv, "timesteps_per_s": K * T / dv,
+                      "over_time_segments": bool(eng.get_option("viterbi_chunked")),
+                      "segments": eng.get_option("viterbi_segments"), "warmup": eng.get_option("viterbi_W"),
+                      "boundaries_not_bit_identical_after_first_pass": eng.get_option("viterbi_mismatch"),
+                      "fixup_rounds": eng.get_option("viterbi_rounds"),
+                      "note": "paths as one byte per step into a device buffer"}
+    for _ in range(3):
+        eng.sample_paths(*margs, seed=1, want_paths=False)
+    dg = timeit(lambda: eng.sample_paths(*margs, seed=1, want_paths=False), 3, eng.sync)
+    out["gibbs_path_step"] = {"ms": 1e3 * dg, "timesteps_per_s": K * T / dg,
+                              "over_time_segments": bool(eng.get_option("sample_segmented")),
+                              "forward_pass_segmented": bool(eng.get_option("sample_forward_segmented")),
+                              "segments": eng.get_option("sample_segments"), "warmup": eng.get_option("sample_W"),
+                              "segments_drawn_again": eng.get_option("sample_mismatch"),
+                              "fixup_rounds": eng.get_option("sample_rounds"),
+                              "note": "forward filter + backward draw + path statistics, counts on the device"}
     eng.close()
+    # whole EM iterations on this shape (E-step + native M-step, the model changes every iteration)
+    import bhmm_amd
+    host = obs.cpu().numpy().reshape(K, T)
+    init = bhmm_amd.gaussian_hmm(pi, margs[0], margs[2], sig)
+    est = bhmm_amd.MaximumLikelihoodEstimator([host[k] for k in range(K)], n, initial_model=init,
+                                              reversible=False, device=local)
+    for _ in range(4):
+        est.em_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 8
+    lls = [est.em_step() for _ in range(iters)]
+    torch.cuda.synchronize()
+    de = (time.perf_counter() - t0) / iters
+    e2 = est._engine
+    out["whole_em_iteration"] = {"ms": 1e3 * de, "timesteps_per_s": K * T / de, "iterations": iters,
+                                 "loglik_first_last": [lls[0], lls[-1]],
+                                 "tile_kernels": bool(e2.get_option("tile")),
+                                 "spec": {k: e2.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail")},
+                                 "note": "MaximumLikelihoodEstimator.em_step, non-reversible, host side included"}
+    e2.close()
+    del est
     return out
 
 

@@ -76,7 +76,8 @@ int replan_for_warmup(bhmm_ctx *c);
 #endif
 
 // componentwise relative tolerance of the boundary check (k_spec_check / k_tail)
-constexpr double SPEC_TOL = 1e-11;
+// boundary tolerance of the time-split E-step, N <= 8: the context's spec_tol (option, default 1e-11)
+#define SPEC_TOL (c->spec_tol)
 
 // One E-step launch sequence for a fixed padded N.
 template <int N>
@@ -416,7 +417,7 @@ struct Runner {
         BHMM_HIP(hipStreamSynchronize(c->stream)); // starts / curve are temporaries
         int last = -1;
         for (int w = 0; w < Wmax; ++w)
-            if (std::max(curve[w], curve[Wmax + w]) >= 1e-13f)
+            if (std::max(curve[w], curve[Wmax + w]) >= (float)(0.01 * c->spec_tol)) // (default: 1e-13)
                 last = w;
         int W = last + 2; // steps needed to get below the target and stay there
         W = (int)std::ceil(1.15 * W);
@@ -448,7 +449,7 @@ struct Runner {
             // decades of forgetting per step, from the calibrated warm-up (1e-13 after W / 1.15 steps)
             // (the calibration is conservative -- 1e-13 on 256 sampled stretches plus 15 % --; what the
             // boundary check of a full warm-up actually measured is the better estimate, when known)
-            double rdec = 13.0 * 1.15 / std::max(c->spec_W, 16);
+            double rdec = -log10(0.01 * c->spec_tol) * 1.15 / std::max(c->spec_W, 16);
             if (c->carry_rdec > 0.0)
                 rdec = std::min(rdec, c->carry_rdec);
             bool eligible = c->carry_enabled && ESTEP_SPLIT && KIND != EMIT_EXPL && !c->careful &&
@@ -1530,11 +1531,25 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
         c->carry_valid = false;
     } else if (n == "carry_kappa") { // (tests: the sensitivity bound that sizes the carried warm-ups)
         c->carry_kappa = value;
+    } else if (n == "spec_tol") {
+        // N <= 8: componentwise relative tolerance of the boundary check of the time-split E-step (and
+        // what the warm-up is calibrated for, a hundred times inside it).  Default 1e-11; the parity
+        // contract is 1e-6, so 1e-9 still leaves three decades -- and shortens the warm-ups by a sixth.
+        if (!(value >= 1e-13 && value <= 1e-7))
+            return invalid("spec_tol outside [1e-13, 1e-7]");
+        c->spec_tol = value;
+        c->spec_calibrated = c->spec_W_fixed; // (the next E-step measures the warm-up for it)
+        c->carry_valid = false;
+    } else if (n == "sample_seg_per_simd") { // 9..64 states: segments per SIMD of the backward draw
+        if (value < 1 || value > 64)
+            return BHMM_ERR_INVALID;
+        c->smp_seg_per_simd = (int)value;
+        c->pplan[1].nseg = 0;
     } else if (n == "viterbi_seg_per_simd") { // 9..64 states: segments per SIMD of the Viterbi pass
         if (value < 1 || value > 64)
             return BHMM_ERR_INVALID;
         c->vit_seg_per_simd = (int)value;
-        c->pplan[0].nseg = c->pplan[1].nseg = 0;
+        c->pplan[0].nseg = 0;
         c->vit_seg_given_up = false;
     } else if (n == "spec_W") {
         c->carry_valid = false;
@@ -1566,6 +1581,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->spec_enabled ? 1.0 : 0.0;
     else if (n == "spec_W")
         *value = c->spec_W;
+    else if (n == "spec_tol")
+        *value = c->spec_tol;
     else if (n == "spec_ok")
         *value = c->spec_ok;
     else if (n == "spec_fail")

@@ -140,7 +140,9 @@ struct bhmm_ctx {
     bool draw_fwd_segmented = false;  // ... its alpha rows came from the time-segmented forward pass
     bool smp_segmented = false;       // the last sample_paths call ran over time segments
     bhmm::DevBuf<int32_t> d_sentry, d_sexit;
+    double spec_tol = 1e-11;          // N <= 8: tolerance of the boundary check (option spec_tol)
     int vit_seg_per_simd = 2;
+    int smp_seg_per_simd = 4;         // (the draw is a short dependent chain: more wavefronts per SIMD hide it)
     int vit_seg_mismatch = 0, vit_seg_rounds = 0;
     bhmm::DevBuf<double> d_vckpt;  // the first pass's vector at every 64th step
     bhmm::DevBuf<uint8_t> d_vflag; // segments the next fix-up round repeats

@@ -759,7 +759,7 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
     c->smp_segmented = false;
     bool seg_done = false;
     if (c->spec_enabled) {
-        const int64_t want = (int64_t)c->vit_seg_per_simd * c->num_simd * GP;
+        const int64_t want = (int64_t)c->smp_seg_per_simd * c->num_simd * GP;
         const int64_t seglen = std::max<int64_t>((c->total + want - 1) / want, 64);
         Segs sg;
         if ((rc = wide_path_plan(c, 1, seglen, sg)))

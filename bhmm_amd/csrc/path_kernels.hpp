@@ -2037,6 +2037,29 @@ __global__ __launch_bounds__(64) void k_wide_sample_path(const WideModel m, cons
     }
 }
 
+// Inclusive prefix sum over the NP lanes of a group (NP = 16: one row of 16 lanes, 32: two, 64: the
+// wavefront) with DPP moves: row_shr 1, 2, 4, 8 inside the rows, row_bcast15 / row_bcast31 across them.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take_f64(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo); // (lanes without a source, or masked out: 0)
+}
+template <int NP>
+__device__ __forceinline__ double group_prefix_sum(double x)
+{
+    x += dpp_take_f64<0x111, 0xF>(x); // row_shr:1
+    x += dpp_take_f64<0x112, 0xF>(x); // row_shr:2
+    x += dpp_take_f64<0x114, 0xF>(x); // row_shr:4
+    x += dpp_take_f64<0x118, 0xF>(x); // row_shr:8
+    if constexpr (NP >= 32)
+        x += dpp_take_f64<0x142, 0xA>(x); // row_bcast15 into rows 1 and 3
+    if constexpr (NP >= 64)
+        x += dpp_take_f64<0x143, 0xC>(x); // row_bcast31 into rows 2 and 3
+    return x;
+}
+
 // =========================================================================================
 // 9..64 states, backward sampling parallel over time segments (round 4).  The draw at step t is a
 // function of (alpha_t, the state drawn at t + 1, the uniform of step t) -- the uniforms belong to the
@@ -2053,6 +2076,12 @@ __global__ __launch_bounds__(64) void k_wide_sample_path(const WideModel m, cons
 // When a check finds nothing, every segment continued the state its successor drew: the path is the
 // serial run's (_hidden.c:331-380), by induction from the last segment of each trajectory.
 // A in LDS, transposed ([next state][i]: the lanes of a group read consecutive words).
+// The draw itself (_hidden.c:283-305: normalise, then the first state whose cumulative sum reaches r)
+// is decided WITHOUT its two ordered chains of n additions wherever that cannot change it: with the
+// unnormalised prefix sums P_q of alpha_t[i] A[i][s_{t+1}] (a DPP scan, any order: within 64 eps S of
+// the exact ones) the state is the first q with P_q >= r S, and the reference's normalised sums
+// (within ~130 eps of P_q / S) order the same way unless some P_q lies within 1e-12 S of r S.  Only
+// then -- or when S is not a normal number -- the step takes the reference's own arithmetic.
 // =========================================================================================
 template <int NP, bool FIX>
 __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
@@ -2079,6 +2108,7 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
             return;
     }
     const bool real = i < n;
+    const unsigned long long gmask = wgroup_mask<NP>(lane);
     const int k = sg.traj[sgi];
     const int64_t o0 = off[k], T = off[k + 1] - o0;
     const int64_t s0 = soff ? soff[k] : o0; // position of this trajectory in the random stream
@@ -2094,39 +2124,53 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
         double ps = a;
         if (t != T - 1)
             ps = a * sAT[nxt * NP + i]; // _hidden.c:365 (padded states: 0 * 0)
-        xs[w][gi][i] = ps;
         const double r = u ? u[o0 + t] : uniform01(seed, (uint64_t)(s0 + t));
-        double S = 0.0;
-#pragma unroll
-        for (int tl = 0; tl < NP; tl += TL) {
-            double x[TL];
-#pragma unroll
-            for (int q = 0; q < TL; q += 2) {
-                const double2 y = *reinterpret_cast<const double2 *>(&xs[w][gi][tl + q]);
-                x[q] = y.x;
-                x[q + 1] = y.y;
-            }
-#pragma unroll
-            for (int q = 0; q < TL; ++q)
-                S += x[q]; // _normalize, ascending
-        }
-        xp[w][gi][i] = ps / S;
-        double acc = 0.0;
         int pick = NP;
+        {
+            const double P = group_prefix_sum<NP>(ps);
+            const double Sf = __shfl(P, NP - 1, NP); // the group's total
+            const double thr = r * Sf;
+            const bool ok = Sf > 1e-290 && Sf < 1e290; // (also false for NaN)
+            const bool near = !ok || !(fabs(P - thr) > 1e-12 * Sf);
+            const unsigned long long nearm = __ballot(near && real) & gmask;
+            if (nearm == 0ull) {
+                const unsigned long long ge = __ballot(P >= thr) & gmask;
+                pick = ge ? (int)__builtin_ctzll(ge) - gi * NP : NP;
+            } else {
+                // the reference's arithmetic, chain for chain
+                xs[w][gi][i] = ps;
+                double S = 0.0;
 #pragma unroll
-        for (int tl = 0; tl < NP; tl += TL) {
-            double x[TL];
+                for (int tl = 0; tl < NP; tl += TL) {
+                    double x[TL];
 #pragma unroll
-            for (int q = 0; q < TL; q += 2) {
-                const double2 y = *reinterpret_cast<const double2 *>(&xp[w][gi][tl + q]);
-                x[q] = y.x;
-                x[q + 1] = y.y;
-            }
+                    for (int q = 0; q < TL; q += 2) {
+                        const double2 y = *reinterpret_cast<const double2 *>(&xs[w][gi][tl + q]);
+                        x[q] = y.x;
+                        x[q + 1] = y.y;
+                    }
 #pragma unroll
-            for (int q = 0; q < TL; ++q) {
-                acc += x[q]; // _hidden.c:299-303: the first state whose cumulative sum reaches r
-                const int cand = (acc >= r) ? tl + q : NP;
-                pick = cand < pick ? cand : pick;
+                    for (int q = 0; q < TL; ++q)
+                        S += x[q]; // _normalize, ascending
+                }
+                xp[w][gi][i] = ps / S;
+                double acc = 0.0;
+#pragma unroll
+                for (int tl = 0; tl < NP; tl += TL) {
+                    double x[TL];
+#pragma unroll
+                    for (int q = 0; q < TL; q += 2) {
+                        const double2 y = *reinterpret_cast<const double2 *>(&xp[w][gi][tl + q]);
+                        x[q] = y.x;
+                        x[q + 1] = y.y;
+                    }
+#pragma unroll
+                    for (int q = 0; q < TL; ++q) {
+                        acc += x[q]; // _hidden.c:299-303: the first state whose cumulative sum reaches r
+                        const int cand = (acc >= r) ? tl + q : NP;
+                        pick = cand < pick ? cand : pick;
+                    }
+                }
             }
         }
         if (pick >= n) { // (a padded state's sum is the last real one's: it would have been drawn there)

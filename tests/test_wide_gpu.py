@@ -242,7 +242,7 @@ def test_wide_path_sampling_over_time_segments_is_the_serial_draw(n, kind):
         pobs = [orc.pobs_discrete(o, p0) for o in obs]
     u = [rng.random(T) for T in lengths]
     eng = Engine(0)
-    eng.set_option("viterbi_seg_per_simd", 1)
+    eng.set_option("sample_seg_per_simd", 1)
     eng.set_observations(kind, obs, n, nsymbols=M if kind == "discrete" else 0)
     for rep in range(2):
         paths, C, n0, emis = eng.sample_paths(A, pi, p0, p1, u=u)

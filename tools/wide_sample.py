@@ -31,7 +31,7 @@ for ci, (kind, n, K, T) in enumerate((("gaussian", 64, 128, 10000), ("gaussian",
         if ps == 0:
             eng.set_option("spec_enabled", 0)
         else:
-            eng.set_option("viterbi_seg_per_simd", ps)
+            eng.set_option("sample_seg_per_simd", ps)
         eng.set_observations_device(kind, obs.data_ptr(), np.arange(K + 1, dtype=np.int64) * T, n,
                                     **({"nsymbols": M} if kind == "discrete" else {}))
         for _ in range(4):
