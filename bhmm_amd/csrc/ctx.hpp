@@ -132,9 +132,10 @@ struct bhmm_ctx {
     struct PathPlan {
         int nseg = 0;
         int64_t seglen = 0;
-        bhmm::DevBuf<int32_t> traj, len;
+        bhmm::DevBuf<int32_t> traj, len, traj0; // traj0[k]: first segment of trajectory k, [K + 1]
         bhmm::DevBuf<int64_t> t0;
     } pplan[2];
+    bhmm::DevBuf<uint8_t> d_vmaps, d_vend; // back-trace over segments: maps [nseg][64], last state of each segment
     int smp_W = 0;                    // sampler: warm-up (steps above a segment) of the next call
     int smp_seg_mismatch = 0, smp_seg_rounds = 0;
     bool draw_fwd_segmented = false;  // ... its alpha rows came from the time-segmented forward pass

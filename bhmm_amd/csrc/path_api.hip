@@ -264,8 +264,9 @@ static int wide_path_plan(bhmm_ctx *c, int which, int64_t seglen, Segs &sg)
         const int ns = (int)sp.traj.size();
         int rc;
         if ((rc = pp.traj.ensure(std::max(ns, 1))) || (rc = pp.len.ensure(std::max(ns, 1))) ||
-            (rc = pp.t0.ensure(std::max(ns, 1))))
+            (rc = pp.t0.ensure(std::max(ns, 1))) || (rc = pp.traj0.ensure(c->K + 1)))
             return rc;
+        BHMM_HIP(hipMemcpyAsync(pp.traj0.p, sp.traj0.data(), (c->K + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         BHMM_HIP(hipMemcpyAsync(pp.traj.p, sp.traj.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         BHMM_HIP(hipMemcpyAsync(pp.len.p, sp.len.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         BHMM_HIP(hipMemcpyAsync(pp.t0.p, sp.t0.data(), ns * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
@@ -644,13 +645,21 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         if (!done && c->pplan[0].nseg > K)
             c->vit_seg_given_up = true; // these observations go to the serial kernel from now on
         c->viterbi_chunked = done;
-        if (done) { // (the back-trace below is the serial family's)
+        if (done) { // back-trace over the segments: maps, stitch, apply
+            const Segs sg{c->pplan[0].traj.p, c->pplan[0].t0.p, c->pplan[0].len.p, c->pplan[0].nseg, 0};
+            if ((rc = c->d_vmaps.ensure((size_t)sg.nseg * 64)) || (rc = c->d_vend.ensure((size_t)sg.nseg)))
+                return rc;
+            hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                               (const uint8_t *)ptr, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
+                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p,
+                               (const int32_t *)last, c->d_vend.p);
             if (out_fmt == 0)
-                hipLaunchKernelGGL(k_wide_viterbi_trace<int32_t>, dim3(K), dim3(64), 0, c->stream, off, K, n,
-                                   (const uint8_t *)ptr, (const int32_t *)last, path);
+                hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                   (const uint8_t *)ptr, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path);
             else
-                hipLaunchKernelGGL(k_wide_viterbi_trace<uint8_t>, dim3(K), dim3(64), 0, c->stream, off, K, n,
-                                   (const uint8_t *)ptr, (const int32_t *)last, path8);
+                hipLaunchKernelGGL((k_wide_vit_walk<true, uint8_t>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                   (const uint8_t *)ptr, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path8);
             walks_in_flight = true;
         }
     }

@@ -1104,10 +1104,69 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_fwd(const WideModel m, cons
 // When a check finds no difference, every segment started from the serial run's vector (induction
 // from the first segment of each trajectory, which starts from pi exactly), so every back-pointer is
 // the serial run's.  The host bounds the number of rounds and runs the serial kernel beyond it.
-// Argmax: the select tree carries (product, index) only; v[i^] and A[i^][j] are looked up afterwards
-// in LDS (three selects per node instead of seven).  A is shared by the WPB wavefronts of a workgroup.
+// Argmax: the select tree carries (product, index) only; v[i^] (a lane read) and A[i^][j] (LDS, shared
+// by the WPB wavefronts of a workgroup) are looked up afterwards: three selects per node instead of seven.
 //   v_entry / v_exit [nseg][NP];  ckpt [(total >> 6) + 1][NP];  flag [nseg]
 // =========================================================================================
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// h[i] = fma(v[16 ROW + B + i], w(B + i), 0), i = 0..7, with v given as its row copy `src`: ONE assembly
+// block per eight products (as single statements the compiler pads every one with an s_nop: its hazard
+// model cannot see which operand of an inline statement is the DPP one).
+template <int B, typename WF>
+__device__ __forceinline__ void prod8_bcast(double (&h)[16], const double &src, WF &&w)
+{
+#define BHMM_W(I) "v"(w(std::integral_constant<int, B + I>{}))
+    asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\t"
+                 "v_mov_b64 %4, 0\n\tv_mov_b64 %5, 0\n\tv_mov_b64 %6, 0\n\tv_mov_b64 %7, 0\n\t"
+                 "v_fmac_f64_dpp %0, %8, %9 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %8, %10 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %8, %11 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %8, %12 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %4, %8, %13 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %5, %8, %14 row_newbcast:%22 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %6, %8, %15 row_newbcast:%23 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %7, %8, %16 row_newbcast:%24 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(h[B + 0]), "=&v"(h[B + 1]), "=&v"(h[B + 2]), "=&v"(h[B + 3]), "=&v"(h[B + 4]),
+                   "=&v"(h[B + 5]), "=&v"(h[B + 6]), "=&v"(h[B + 7])
+                 : "v"(src), BHMM_W(0), BHMM_W(1), BHMM_W(2), BHMM_W(3), BHMM_W(4), BHMM_W(5), BHMM_W(6),
+                   BHMM_W(7), "n"(B + 0), "n"(B + 1), "n"(B + 2), "n"(B + 3), "n"(B + 4), "n"(B + 5),
+                   "n"(B + 6), "n"(B + 7));
+#undef BHMM_W
+}
+
+// S = (...((S + v[16 ROW]) + v[16 ROW + 1]) + ...) + v[16 ROW + 15], every sum rounded once
+// (fma(x, 1, S)), with v given as its row copy `src`
+__device__ __forceinline__ void sum16_bcast(double &S, const double &src, const double &one)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                 : "+v"(S)
+                 : "v"(src), "v"(one));
+}
+
 constexpr int WVS_WPB = 4;
 template <int NP, int KIND, bool FIX>
 __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
@@ -1115,9 +1174,7 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     int32_t *last_state, double *v_entry, double *v_exit, double *ckpt, const uint8_t *flag)
 {
     constexpr int GP = 64 / NP;
-    constexpr int TL = NP < 16 ? NP : 16; // argmax tile
     __shared__ __attribute__((aligned(16))) double xv[WVS_WPB][GP][NP];
-    __shared__ __attribute__((aligned(16))) double xn[WVS_WPB][GP][NP];
     __shared__ double sA[NP * NP];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gi = lane / NP, j = lane % NP;
@@ -1174,61 +1231,57 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
         if (t == 0) {
             vn = p * pi_j; // _hidden.c:232
         } else {
-            xv[w][gi][j] = v;
-            // first-maximum argmax (_hidden.c:186-200) as a select tree per tile of <= 16 states: the
+            // Every lane needs every element of v: row copies (permlane swaps) and the DPP form
+            // fma(v[16 k + i] broadcast within the row, A[16 k + i][j], 0) -- the product
+            // v[i] * A[i][j] of _hidden.c:249, rounded once like the multiplication -- instead of
+            // 32 broadcast reads from LDS, which was what bound this kernel with all CUs busy.
+            // First-maximum argmax (_hidden.c:186-200) as a select tree per row of 16 states: the
             // later candidate wins only if strictly greater, which is exactly the linear scan's
-            // result; tiles are folded in index order with the same rule
+            // result; rows are folded in index order with the same rule.
+            const Rows4 R = rows_of_group<NP>(v);
             double bh = 0.0;
             int bi = 0;
 #pragma unroll
-            for (int tl = 0; tl < NP; tl += TL) {
-                double hh[TL];
-                int ii[TL];
+            for (int k = 0; k < NP / 16; ++k) {
+                double hh[16];
+                int ii[16];
+                auto wk = [&](auto ic) __attribute__((always_inline)) { return Acol[16 * k + decltype(ic)::value]; };
+                asm volatile("s_nop 1"); // (a DPP read needs two wait states after the write of its register)
+                prod8_bcast<0>(hh, R.r[k], wk);
+                prod8_bcast<8>(hh, R.r[k], wk);
 #pragma unroll
-                for (int i = 0; i < TL; i += 2) {
-                    const double2 x = *reinterpret_cast<const double2 *>(&xv[w][gi][tl + i]);
-                    hh[i] = x.x * Acol[tl + i]; // _hidden.c:249
-                    hh[i + 1] = x.y * Acol[tl + i + 1];
-                    ii[i] = tl + i;
-                    ii[i + 1] = tl + i + 1;
-                }
+                for (int i = 0; i < 16; ++i)
+                    ii[i] = 16 * k + i;
 #define BHMM_ARGMAX_LEVEL(W)                                           \
-    if constexpr (TL > W) {                                            \
-        _Pragma("unroll") for (int i = 0; i + W < TL; i += 2 * W)      \
-        {                                                              \
-            const bool take = hh[i + W] > hh[i];                       \
-            hh[i] = take ? hh[i + W] : hh[i];                          \
-            ii[i] = take ? ii[i + W] : ii[i];                          \
-        }                                                              \
+    _Pragma("unroll") for (int i = 0; i + W < 16; i += 2 * W)          \
+    {                                                                  \
+        const bool take = hh[i + W] > hh[i];                           \
+        hh[i] = take ? hh[i + W] : hh[i];                              \
+        ii[i] = take ? ii[i + W] : ii[i];                              \
     }
                 BHMM_ARGMAX_LEVEL(1)
                 BHMM_ARGMAX_LEVEL(2)
                 BHMM_ARGMAX_LEVEL(4)
                 BHMM_ARGMAX_LEVEL(8)
 #undef BHMM_ARGMAX_LEVEL
-                const bool take = (tl == 0) || (hh[0] > bh);
+                const bool take = (k == 0) || (hh[0] > bh);
                 bh = take ? hh[0] : bh;
                 bi = take ? ii[0] : bi;
             }
             if (real && t >= t0)
                 ptr[(o0 + t) * n + j] = (uint8_t)bi;
-            const double bv = xv[w][gi][bi], bA = sA[bi * NP + j];
+            const double bv = __shfl(v, bi, NP), bA = sA[bi * NP + j];
             vn = p * bv * bA; // _hidden.c:253: (p v[i^]) A[i^][j]
         }
-        xn[w][gi][j] = vn;
+        // the normalising sum in ascending order (_hidden.c:256-259), S = fma(vn[i], 1, S) = S + vn[i]
+        // rounded once, on the row copies of vn (padded states add exact zeros)
         double S = 0.0;
+        {
+            const Rows4 Rn = rows_of_group<NP>(vn);
+            const double one = 1.0;
 #pragma unroll
-        for (int tl = 0; tl < NP; tl += TL) {
-            double xs[TL];
-#pragma unroll
-            for (int i = 0; i < TL; i += 2) {
-                const double2 x = *reinterpret_cast<const double2 *>(&xn[w][gi][tl + i]);
-                xs[i] = x.x;
-                xs[i + 1] = x.y;
-            }
-#pragma unroll
-            for (int i = 0; i < TL; ++i)
-                S += xs[i]; // ascending order; padded states add exact zeros
+            for (int k = 0; k < NP / 16; ++k)
+                sum16_bcast(S, Rn.r[k], one);
         }
         v = vn / S;
         if constexpr (!FIX) {
@@ -1980,6 +2033,78 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_trace(const int64_t *off, i
             path[o0 + lo + lane - 1] = (PT)outp[lane];
         cur = outp[0];
         __syncthreads();
+    }
+}
+
+// back-trace of a segment-parallel run, parallel over the segments (the scheme of k_vit_walk, one lane
+// per candidate state): APPLY = false -- lane c walks the back-pointers of segment s down from "state c
+// at the segment's last step" and leaves the state that implies for the last step of segment s - 1
+// (maps[s][c]); k_wide_vit_stitch chains the maps of a trajectory from its final state; APPLY = true --
+// the segment is walked once more from its now known last state and the path is written
+// (_hidden.c:269-272).  Back-pointer rows are staged through LDS 64 steps at a time.
+template <bool APPLY, typename PT>
+__global__ __launch_bounds__(64) void k_wide_vit_walk(const int64_t *off, const Segs sg, int n,
+                                                      const uint8_t *ptr, uint8_t *maps,
+                                                      const uint8_t *end_state, PT *path)
+{
+    __shared__ uint8_t tile[64 * 64];
+    __shared__ int32_t outp[64];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= sg.nseg || sg.len[s] <= 0)
+        return;
+    const int k = sg.traj[s];
+    const int64_t o0 = off[k];
+    const int64_t t0 = sg.t0[s], t1 = t0 + sg.len[s];
+    int cur = APPLY ? (int)end_state[s] : (lane < n ? lane : 0);
+    if (APPLY && lane == 0)
+        path[o0 + t1 - 1] = (PT)cur;
+    // steps t = hi .. lo (descending) use ptr[t] to produce the state at t - 1; APPLY stops above the
+    // segment's first step (the state below it is the previous segment's last), the map pass goes on
+    // to it -- except at the start of a trajectory, where there is nothing below
+    const int64_t low = APPLY ? t0 + 1 : (t0 > 1 ? t0 : 1);
+    for (int64_t hi = t1 - 1; hi >= low; hi -= 64) {
+        const int64_t lo = (hi - 63 > low) ? hi - 63 : low;
+        const int cnt = (int)(hi - lo + 1);
+        const int64_t base = (o0 + lo) * n;
+        for (int e = lane; e < cnt * n; e += 64)
+            tile[e] = ptr[base + e];
+        __syncthreads();
+        if constexpr (APPLY) {
+            if (lane == 0) {
+                for (int q = cnt - 1; q >= 0; --q) {
+                    cur = tile[q * n + cur];
+                    outp[q] = cur; // path[lo + q - 1]
+                }
+            }
+            __syncthreads();
+            if (lane < cnt)
+                path[o0 + lo + lane - 1] = (PT)outp[lane];
+            cur = outp[0];
+        } else {
+            for (int q = cnt - 1; q >= 0; --q)
+                cur = tile[q * n + cur];
+        }
+        __syncthreads();
+    }
+    if constexpr (!APPLY)
+        maps[(int64_t)s * 64 + lane] = (uint8_t)cur;
+}
+
+// end_state[s] for every segment: the trajectory's final state for its last segment, then map by map
+[[maybe_unused]] static __global__ void k_wide_vit_stitch(const int32_t *traj0, int K, const uint8_t *maps,
+                                                           const int32_t *last_state, uint8_t *end_state)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K)
+        return;
+    const int s0 = traj0[k], s1 = traj0[k + 1];
+    if (s1 <= s0)
+        return;
+    int cur = last_state[k];
+    end_state[s1 - 1] = (uint8_t)cur;
+    for (int s = s1 - 1; s > s0; --s) {
+        cur = maps[(int64_t)s * 64 + cur];
+        end_state[s - 1] = (uint8_t)cur;
     }
 }
 

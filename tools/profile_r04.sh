@@ -6,13 +6,16 @@
 #                                                    one-segment-per-wavefront kernels, kernel averages
 #   TAG_c4_clock.txt                                 shader clock, SQ busy, VALU / MFMA instruction counts
 #   TAG_c4_traffic.txt                               FETCH_SIZE / WRITE_SIZE of the tile kernels (separate passes)
-#   TAG_gen_time.txt                                 more than 64 states
+#   TAG_gen_time.txt                                 64 and more states: E-step, Viterbi, Gibbs path step
+#   TAG_wide_viterbi.txt, TAG_wide_sample.txt        9..64 states over time segments vs the serial kernels,
+#   TAG_wide_paths_kernel_stats.csv                  per-kernel averages of both tools
+#   TAG_spec_tol.txt                                 headline shape against the boundary tolerance
 tag=$1
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 bash $R/tools/profile_driver_flags.sh $tag > $O/${tag}_driver_flags.txt 2>&1
-python3 $R/tools/c4_tile.py 1 > $O/${tag}_c4_time.txt 2>&1
+python3 $R/tools/c4_tile.py 1 2 > $O/${tag}_c4_time.txt 2>&1
 rm -rf /tmp/prof_c4
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c4 -- python3 $R/tools/c4_tile.py 1 > /tmp/prof_c4.log 2>&1
 cp $(find /tmp/prof_c4 -name "*kernel_stats.csv" | head -1) $O/${tag}_c4_kernel_stats.csv
@@ -46,4 +49,10 @@ for k in sorted(set(f) | set(w)):
     print(k, "|", f.get(k), "|", w.get(k), "| %.4g" % (1024.0 * (2 * f.get(k, 0) + w.get(k, 0))))
 PY
 python3 $R/tools/gen_time.py > $O/${tag}_gen_time.txt 2>&1
+python3 $R/tools/wide_viterbi.py 2 > $O/${tag}_wide_viterbi.txt 2>&1
+python3 $R/tools/wide_sample.py 4 > $O/${tag}_wide_sample.txt 2>&1
+python3 $R/tools/spec_tol.py > $O/${tag}_spec_tol.txt 2>&1
+rm -rf /tmp/prof_wp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_wp -- python3 $R/tools/wide_paths_once.py > /tmp/prof_wp.log 2>&1
+cp $(find /tmp/prof_wp -name "*kernel_stats.csv" | head -1) $O/${tag}_wide_paths_kernel_stats.csv
 cat $O/${tag}_driver_flags.txt | tail -6; cat $O/${tag}_c4_time.txt | tail -4; head -8 $O/${tag}_c4_clock.txt; cat $O/${tag}_c4_mfma.txt; cat $O/${tag}_c4_traffic.txt; tail -7 $O/${tag}_gen_time.txt
