@@ -319,7 +319,11 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     // n <= 8 with a chunk plan: the chunk-parallel kernel evaluates the emission itself (gathers
     // from B / evaluates the gaussian density): no (total, n) emission matrix is written and re-read
     const bool disc_direct = !c->wide && c->kind != EMIT_EXPL && c->spec_enabled && c->G > K;
-    if (c->kind != EMIT_EXPL && !disc_direct) {
+    // 9..64 states over time segments, discrete: the kernel gathers from B itself (no (total, n) matrix).
+    // Measured for the Gaussian kind too: the division by sigma and the exponential in every step,
+    // warm-ups included, cost more than the matrix pass saves (64 states: 9.0 -> 9.7 ms, 16: 0.67 -> 0.81).
+    const bool wide_direct = c->wide && c->kind == EMIT_DISC && c->spec_enabled && !c->vit_seg_given_up;
+    if (c->kind != EMIT_EXPL && !disc_direct && !wide_direct) {
         size_t freeb = 0, totb = 0;
         const size_t need = (size_t)c->total * n * sizeof(double);
         if (hipMemGetInfo(&freeb, &totb) == hipSuccess && need + ((size_t)1 << 30) < freeb + c->d_alpha_rm.n * sizeof(double) &&
