@@ -67,7 +67,7 @@ int launch_fwd(bhmm_ctx *c, const WideModel &m)
                        c->d_alpha_rm.p, c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p,
                        c->d_specres.p, (unsigned long long *)nullptr);
     BHMM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_tile_logl, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg, c->n,
+    hipLaunchKernelGGL(k_tile_logl, dim3((sg.nseg + 15) / 16), dim3(256), 0, c->stream, sg, c->n,
                        (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
                        (const int32_t *)c->d_wePseg.p, c->d_wlogLseg.p, c->d_specres.p);
     hipLaunchKernelGGL(k_logl, dim3(c->K), dim3(64), 0, c->stream, (const int32_t *)c->d_wseg_traj0[1].p,
@@ -119,11 +119,11 @@ int run_check(bhmm_ctx *c, int dir)
 {
     const Segs sg = wide_segs_pub(c, 1);
     if (dir == 0)
-        hipLaunchKernelGGL(k_wide_check, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg, c->n,
+        hipLaunchKernelGGL(k_wide_check, dim3((sg.nseg + 15) / 16), dim3(256), 0, c->stream, sg, c->n,
                            (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
                            (const double *)nullptr, (const double *)nullptr, 1e-11, c->d_specres.p);
     else
-        hipLaunchKernelGGL(k_wide_check, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg, c->n,
+        hipLaunchKernelGGL(k_wide_check, dim3((sg.nseg + 15) / 16), dim3(256), 0, c->stream, sg, c->n,
                            (const double *)nullptr, (const double *)nullptr, (const double *)c->d_wbexit.p,
                            (const double *)c->d_wbentry.p, 1e-11, c->d_specres.p);
     BHMM_HIP(hipGetLastError());

@@ -627,25 +627,32 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
 // log-likelihood of every segment from what k_tile_fwd left: log sum(exit vector) - log sum(entry
 // vector) + ln 2 * removed exponents (the entry vector of a segment that starts its trajectory is
 // exact: pi o p_0 carries the whole likelihood, nothing is subtracted)
+// (sixteen lanes per segment: launched with (nseg + 15) / 16 workgroups of 256)
 [[maybe_unused]] static __global__ void k_tile_logl(const Segs sg, int n, const double *a_entry,
                                                     const double *a_exit, const int32_t *eP_seg,
                                                     double *logL_seg, unsigned int *flags)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= sg.nseg)
+    const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const bool live = s < sg.nseg && sg.len[s] > 0;
+    const bool warm = live && sg.t0[s] > 0;
+    double se = 0.0, sx = 0.0;
+    if (live)
+        for (int j = l; j < n; j += 16)
+            sx += a_exit[(int64_t)s * n + j];
+    if (warm)
+        for (int j = l; j < n; j += 16)
+            se += a_entry[(int64_t)s * n + j];
+    for (int h = 8; h >= 1; h >>= 1) {
+        sx += __shfl_xor(sx, h, 16);
+        se += __shfl_xor(se, h, 16);
+    }
+    if (s >= sg.nseg || l != 0)
         return;
-    if (sg.len[s] <= 0) {
+    if (!live) {
         logL_seg[s] = 0.0;
         return;
     }
-    double se = 0.0, sx = 0.0;
-    for (int j = 0; j < n; ++j)
-        sx += a_exit[(int64_t)s * n + j];
-    const bool warm = sg.t0[s] > 0;
-    if (warm)
-        for (int j = 0; j < n; ++j)
-            se += a_entry[(int64_t)s * n + j];
-    else
+    if (!warm)
         se = 1.0;
     if (!(sx > 0.0) || !(se > 0.0))
         atomicOr(&flags[2], 2u);

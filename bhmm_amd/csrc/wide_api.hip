@@ -124,7 +124,7 @@ static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
                 (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[7],
                 (double)h[5] / h[7], (double)h[6] / h[7], h[3]);
     }
-    hipLaunchKernelGGL(k_tile_logl, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg, c->n,
+    hipLaunchKernelGGL(k_tile_logl, dim3((sg.nseg + 15) / 16), dim3(256), 0, c->stream, sg, c->n,
                        (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
                        (const int32_t *)c->d_wePseg.p, c->d_wlogLseg.p, c->d_specres.p);
     hipLaunchKernelGGL(k_logl, dim3(c->K), dim3(64), 0, c->stream,
@@ -557,7 +557,7 @@ int wide_forward_draw(bhmm_ctx *c, const double *A, const double *pi, const doub
             if (rc)
                 return rc;
             const Segs sgf = segs_of(c, wide_fwd_plan(c, 1));
-            hipLaunchKernelGGL(k_wide_check, dim3((sgf.nseg + 255) / 256), dim3(256), 0, c->stream, sgf,
+            hipLaunchKernelGGL(k_wide_check, dim3((sgf.nseg + 15) / 16), dim3(256), 0, c->stream, sgf,
                                c->n, (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
                                (const double *)nullptr, (const double *)nullptr, 1e-11, c->d_specres.p);
             BHMM_HIP(hipGetLastError());
@@ -623,10 +623,10 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         if ((rc = run(1, lazy)))
             return rc;
         const Segs sgs = segs_of(c, 1), sgf = segs_of(c, wide_fwd_plan(c, 1));
-        hipLaunchKernelGGL(k_wide_check, dim3((sgf.nseg + 255) / 256), dim3(256), 0, c->stream, sgf,
+        hipLaunchKernelGGL(k_wide_check, dim3((sgf.nseg + 15) / 16), dim3(256), 0, c->stream, sgf,
                            c->n, (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
                            (const double *)nullptr, (const double *)nullptr, 1e-11, c->d_specres.p);
-        hipLaunchKernelGGL(k_wide_check, dim3((sgs.nseg + 255) / 256), dim3(256), 0, c->stream, sgs,
+        hipLaunchKernelGGL(k_wide_check, dim3((sgs.nseg + 15) / 16), dim3(256), 0, c->stream, sgs,
                            c->n, (const double *)nullptr, (const double *)nullptr,
                            (const double *)c->d_wbexit.p, (const double *)c->d_wbentry.p, 1e-11,
                            c->d_specres.p);

@@ -961,35 +961,52 @@ __global__ __launch_bounds__(64) void k_wide_probe(const WideModel m, const void
 }
 
 // boundary consistency of a segmented run (see k_spec_check): one thread per segment
+// (sixteen lanes per boundary, 16 boundaries per workgroup of 256: launched with (nseg + 15) / 16 workgroups)
 [[maybe_unused]] static __global__ void k_wide_check(const Segs sg, int n, const double *a_entry,
                                     const double *a_exit, const double *b_exit,
                                     const double *b_entry, double tol, unsigned int *result)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= sg.nseg || sg.len[s] == 0 || sg.t0[s] == 0)
-        return;
+    const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const bool live = s < sg.nseg && sg.len[s] != 0 && sg.t0[s] != 0;
+    auto sum16 = [](double v) {
+        v += __shfl_xor(v, 8, 16);
+        v += __shfl_xor(v, 4, 16);
+        v += __shfl_xor(v, 2, 16);
+        return v + __shfl_xor(v, 1, 16);
+    };
     double dev = 0.0;
     auto cmp = [&](const double *x, const double *y) {
         double sx = 0.0, sy = 0.0;
-        for (int j = 0; j < n; ++j) {
-            sx += x[j];
-            sy += y[j];
-        }
+        if (live)
+            for (int j = l; j < n; j += 16) {
+                sx += x[j];
+                sy += y[j];
+            }
+        sx = sum16(sx);
+        sy = sum16(sy);
+        if (!live)
+            return;
         if (!(sx > 0.0) || !(sy > 0.0)) {
             dev = 1.0;
             return;
         }
-        for (int j = 0; j < n; ++j) {
+        for (int j = l; j < n; j += 16) {
             const double xs = x[j] / sx, ys = y[j] / sy;
             const double d = fabs(xs - ys);
             const double r = (ys > 1e-280) ? d / ys : (d > 1e-280 ? 1.0 : 0.0);
-            dev = fmax(dev, r);
+            dev = fmax(dev, r == r ? r : 1.0);
         }
     };
     if (a_entry) // (the two passes may run on different segment plans: one launch per plan)
         cmp(a_entry + (int64_t)s * n, a_exit + (int64_t)(s - 1) * n);
     if (b_exit)
         cmp(b_exit + (int64_t)(s - 1) * n, b_entry + (int64_t)s * n);
+    dev = fmax(dev, __shfl_xor(dev, 8, 16));
+    dev = fmax(dev, __shfl_xor(dev, 4, 16));
+    dev = fmax(dev, __shfl_xor(dev, 2, 16));
+    dev = fmax(dev, __shfl_xor(dev, 1, 16));
+    if (!live || l != 0)
+        return;
     if (!(dev <= tol))
         atomicAdd(&result[0], 1u);
     atomicMax(&result[1], __float_as_uint((float)fmin(dev, 1.0)));
