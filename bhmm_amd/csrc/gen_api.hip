@@ -20,6 +20,8 @@ int wide_model_pub(bhmm_ctx *c, int kind, const double *A, const double *pi, con
 bool tile_gen_capable(const bhmm_ctx *c);
 int tile_gen_alloc(bhmm_ctx *c);
 int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags, bool *done);
+int tile_gen_forward_draw(bhmm_ctx *c, const WideModel &m, bool *done);
+int wide_path_plan_pub(bhmm_ctx *c, int which, int64_t seglen, Segs &sg);
 
 namespace {
 
@@ -309,11 +311,18 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
                    const double *par1, const double *u, uint64_t seed, int32_t *paths,
                    int64_t *counts, int64_t *n0, double *emis, double *stats_dev)
 {
-    int rc = gen_forward(c, A, pi, par0, par1); // alpha rows in d_alpha_rm
+    WideModel m;
+    int rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m);
     if (rc)
         return rc;
-    WideModel m;
-    if ((rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m)))
+    // alpha rows in d_alpha_rm: from the tile forward pass over time segments where it verifies
+    // (65..128 states; the draw normalises alpha_t[i] A[i][s_{t+1}] itself, any factor per row cancels),
+    // else from the serial recursion
+    bool fwd_seg = false;
+    if ((rc = tile_gen_forward_draw(c, m, &fwd_seg)))
+        return rc;
+    c->draw_fwd_segmented = fwd_seg;
+    if (!fwd_seg && (rc = gen_forward(c, A, pi, par0, par1)))
         return rc;
     const int n = c->n, K = c->K;
     const size_t nstat = (size_t)n * n + n;
@@ -337,8 +346,80 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
     }
     BHMM_HIP(hipMemsetAsync(cnt, 0, (nstat + nsym) * sizeof(unsigned long long), c->stream));
     BHMM_HIP(hipMemsetAsync(status, 0, sizeof(int), c->stream));
+    // up to 512 states: the draw over time segments (k_gen_sample_seg), coupled through the per-step
+    // uniforms; segments that did not continue their successor's state are drawn again until none is left
+    c->smp_segmented = false;
+    bool seg_done = false;
+    if (c->spec_enabled && n <= 512) {
+        const int64_t want = (int64_t)c->smp_seg_per_simd * c->num_simd;
+        const int64_t seglen = std::max<int64_t>((c->total + want - 1) / want, 64);
+        Segs sg;
+        if ((rc = wide_path_plan_pub(c, 1, seglen, sg)))
+            return rc;
+        if (sg.nseg > K) {
+            if (c->smp_W <= 0)
+                c->smp_W = 64;
+            sg.W = c->smp_W;
+            if ((rc = gen_transposed(c, m)) || (rc = c->d_sentry.ensure((size_t)sg.nseg)) ||
+                (rc = c->d_sexit.ensure((size_t)sg.nseg)) || (rc = c->d_vflag.ensure((size_t)sg.nseg)) ||
+                (rc = c->d_specres.ensure(4)))
+                return rc;
+            if (!c->h_specres)
+                BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
+                                       hipHostMallocDefault));
+            const dim3 sgrid((sg.nseg + 3) / 4), sblk(256);
+#define BHMM_GSS(SPLV, FIXV)                                                                            \
+    hipLaunchKernelGGL((k_gen_sample_seg<SPLV, FIXV>), sgrid, sblk, 0, c->stream, m,                    \
+                       (const double *)c->d_gAt.p, (const int64_t *)c->d_offsets.p, sg,                 \
+                       (const double *)c->d_alpha_rm.p, (const double *)udev, seed,                     \
+                       (const int64_t *)c->d_soff.p, path, status, c->d_sentry.p, c->d_sexit.p,         \
+                       (const uint8_t *)c->d_vflag.p)
+#define BHMM_GSS_SPL(FIXV)       \
+    do {                         \
+        if (n <= 128)            \
+            BHMM_GSS(2, FIXV);   \
+        else if (n <= 256)       \
+            BHMM_GSS(4, FIXV);   \
+        else                     \
+            BHMM_GSS(8, FIXV);   \
+    } while (0)
+            const int max_rounds = 16;
+            int round = 0;
+            for (; round <= max_rounds; ++round) {
+                BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                if (round == 0)
+                    BHMM_GSS_SPL(false);
+                else
+                    BHMM_GSS_SPL(true);
+                hipLaunchKernelGGL(k_wide_smp_check, dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg,
+                                   c->d_sentry.p, (const int32_t *)c->d_sexit.p, c->d_vflag.p, c->d_specres.p);
+                BHMM_HIP(hipGetLastError());
+                BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
+                                        hipMemcpyDeviceToHost, c->stream));
+                BHMM_HIP(hipMemcpyAsync(&c->h_specres[0], status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                BHMM_HIP(hipStreamSynchronize(c->stream));
+                if (round == 0)
+                    c->smp_seg_mismatch = (int)c->h_specres[3];
+                if (c->h_specres[3] == 0)
+                    break;
+            }
+#undef BHMM_GSS_SPL
+#undef BHMM_GSS
+            c->smp_seg_rounds = round;
+            // (a draw that found no state may belong to a segment that was drawn again afterwards:
+            // the serial kernel decides such a call)
+            seg_done = c->h_specres[3] == 0 && c->h_specres[0] == 0;
+            if (!seg_done)
+                BHMM_HIP(hipMemsetAsync(status, 0, sizeof(int), c->stream));
+            if ((int64_t)c->smp_seg_mismatch * 10 > sg.nseg && c->smp_W < 4096)
+                c->smp_W *= 2;
+            c->smp_segmented = seg_done;
+        }
+    }
     size_t sm = gen_smem(n, 2, 4);
-    if (gen_a_in_lds(n, sm)) {
+    if (seg_done) {
+        ;
+    } else if (gen_a_in_lds(n, sm)) {
         sm += gen_a_bytes(n);
         if ((rc = gen_set_smem(k_gen_sample<true>, sm)))
             return rc;

@@ -730,6 +730,122 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_sample(const WideModel m, const
     }
 }
 
+// Backward draw over time segments for 65..512 states (round 4): the scheme of k_wide_sample_seg
+// (path_kernels.hpp) with SPL states per lane -- state e * 64 + lane in slot e --, one wavefront per
+// segment, column s_{t+1} of A read from the transposed copy `At` (coalesced).  The draws of different
+// runs are coupled through the per-step uniforms; pass 0 starts W steps above a segment from state 0,
+// k_wide_smp_check flags the segments that did not continue their successor's state, and the fix-up
+// rounds (FIX) draw those again until the path they meet is the one already there.  The decision uses
+// prefix sums from a DPP scan wherever a margin of 1e-12 S makes the reference's ordered chains
+// (_hidden.c:283-319) redundant, and those chains themselves otherwise.
+template <int SPL, bool FIX>
+__global__ __launch_bounds__(256) void k_gen_sample_seg(const WideModel m, const double *At, const int64_t *off,
+                                                        const Segs sg, const double *alpha, const double *u,
+                                                        uint64_t seed, const int64_t *soff, int32_t *path,
+                                                        int *status, int32_t *s_entry, int32_t *s_exit,
+                                                        const uint8_t *flag)
+{
+    __shared__ double xs[4][64 * SPL];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sgi = blockIdx.x * 4 + w;
+    if (sgi >= sg.nseg || sg.len[sgi] <= 0)
+        return;
+    if constexpr (FIX) {
+        if (!flag[sgi])
+            return;
+    }
+    const int n = m.n;
+    bool real[SPL];
+#pragma unroll
+    for (int e = 0; e < SPL; ++e)
+        real[e] = e * 64 + lane < n;
+    const int k = sg.traj[sgi];
+    const int64_t o0 = off[k], T = off[k + 1] - o0;
+    const int64_t s0 = soff ? soff[k] : o0;
+    const int64_t t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+    const int64_t ts = FIX ? t1 - 1 : ((t1 + sg.W < T ? t1 + sg.W : T) - 1);
+    int nxt = FIX ? s_entry[sgi] : 0;
+    double a_next[SPL];
+#pragma unroll
+    for (int e = 0; e < SPL; ++e)
+        a_next[e] = real[e] ? alpha[(o0 + ts) * n + e * 64 + lane] : 0.0;
+    bool met = false;
+    for (int64_t t = ts; t >= t0; --t) {
+        double ps[SPL], P[SPL];
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) {
+            const double a = a_next[e];
+            ps[e] = a;
+            if (t != T - 1)
+                ps[e] = real[e] ? a * At[(int64_t)nxt * n + e * 64 + lane] : 0.0; // _hidden.c:365
+            if (t > t0)
+                a_next[e] = real[e] ? alpha[(o0 + t - 1) * n + e * 64 + lane] : 0.0; // independent of the draw
+        }
+        const double r = u ? u[o0 + t] : uniform01(seed, (uint64_t)(s0 + t));
+        double base = 0.0;
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) {
+            P[e] = group_prefix_sum<64>(ps[e]) + base;
+            base = __shfl(P[e], 63, 64);
+        }
+        const double Sf = base, thr = r * Sf;
+        const bool ok = Sf > 1e-290 && Sf < 1e290; // (also false for NaN)
+        bool near = !ok;
+#pragma unroll
+        for (int e = 0; e < SPL; ++e)
+            near |= real[e] && !(fabs(P[e] - thr) > 1e-12 * Sf);
+        int pick = -1;
+        if (__ballot(near) == 0ull) {
+#pragma unroll
+            for (int e = 0; e < SPL; ++e) {
+                const unsigned long long ge = __ballot(real[e] && P[e] >= thr);
+                if (pick < 0 && ge)
+                    pick = e * 64 + (int)__builtin_ctzll(ge);
+            }
+        } else {
+            // the reference's arithmetic: _normalize (ascending sum, quotients), then the first state
+            // whose cumulative sum reaches r -- every lane runs the same chains on the LDS copy
+#pragma unroll
+            for (int e = 0; e < SPL; ++e)
+                xs[w][e * 64 + lane] = ps[e];
+            double S = 0.0;
+            for (int i = 0; i < n; ++i)
+                S += xs[w][i];
+#pragma unroll
+            for (int e = 0; e < SPL; ++e)
+                xs[w][e * 64 + lane] = ps[e] / S;
+            double acc = 0.0;
+            for (int i = 0; i < n; ++i) {
+                acc += xs[w][i];
+                if (pick < 0 && acc >= r)
+                    pick = i;
+            }
+        }
+        if (pick < 0) {
+            if (lane == 0 && t < t1)
+                status[0] = BHMM_ERR_CHOICE;
+            pick = n - 1;
+        }
+        nxt = pick;
+        if constexpr (!FIX) {
+            if (t == t1 && lane == 0)
+                s_entry[sgi] = pick;
+        }
+        if (t < t1) {
+            if constexpr (FIX) {
+                if (path[o0 + t] == pick) {
+                    met = true;
+                    break;
+                }
+            }
+            if (lane == 0)
+                path[o0 + t] = pick;
+        }
+    }
+    if (!met && lane == 0)
+        s_exit[sgi] = nxt;
+}
+
 // hidden-path statistics (generic_hmm.py:297-334,398-431): transition / start counts by integer
 // atomics (exact, order-free); per-state emission statistics without atomics -- thread q walks the
 // trajectory once per state it owns (O(n T) per trajectory, small against the O(n^2 T) forward pass)

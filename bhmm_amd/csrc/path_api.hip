@@ -255,7 +255,7 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
 
 // time segments of at most seglen steps for the segment-parallel Viterbi pass (which = 0) / backward
 // sampler (which = 1); rebuilt only when the length changes
-static int wide_path_plan(bhmm_ctx *c, int which, int64_t seglen, Segs &sg)
+int wide_path_plan(bhmm_ctx *c, int which, int64_t seglen, Segs &sg)
 {
     bhmm_ctx::PathPlan &pp = c->pplan[which];
     if (pp.nseg == 0 || pp.seglen != seglen) {
@@ -919,6 +919,9 @@ int cur_device()
 }
 
 } // namespace
+
+int wide_path_plan_pub(bhmm_ctx *c, int which, int64_t seglen, Segs &sg) { return wide_path_plan(c, which, seglen, sg); }
+
 } // namespace bhmm
 
 using namespace bhmm;

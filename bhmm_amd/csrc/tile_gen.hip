@@ -326,4 +326,34 @@ int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags
     return BHMM_OK;
 }
 
+// alpha rows (row-major, any positive factor per row) for the backward draw of 65..128 states from the
+// tile forward pass, boundaries verified to 1e-11; *done = false: the caller runs the serial forward pass
+int tile_gen_forward_draw(bhmm_ctx *c, const WideModel &m, bool *done)
+{
+    *done = false;
+    if (!tile_gen_capable(c) || c->wseg_given_up || c->wide_careful || !c->wseg_enabled || !c->spec_enabled)
+        return BHMM_OK;
+    int rc;
+    if (!c->spec_calibrated) {
+        c->spec_calibrated = true;
+        bool usable = false;
+        if ((rc = calibrate(c, m, &usable)))
+            return rc;
+        if (!usable) {
+            c->wseg_given_up = true;
+            return BHMM_OK;
+        }
+    }
+    BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 3 * sizeof(unsigned int), c->stream));
+    if ((rc = TILE_GEN_DISPATCH(launch_fwd, c, m)))
+        return rc;
+    const bool segmented = c->w_nseg[1] > c->w_nseg[0];
+    if (segmented && (rc = run_check(c, 0)))
+        return rc;
+    if ((rc = read_flags(c)))
+        return rc;
+    *done = c->h_specres[2] == 0 && (!segmented || c->h_specres[0] == 0);
+    return BHMM_OK;
+}
+
 } // namespace bhmm

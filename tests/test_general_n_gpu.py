@@ -177,3 +177,41 @@ def test_transition_matrix_in_lds_up_to_the_size_that_fits(n):
     for p, po, uu in zip(paths, pobs, u):
         assert np.array_equal(p, orc.sample_path(orc.forward(A, po, pi)[1], A, uu))
     eng.close()
+
+
+@pytest.mark.parametrize("n,kind", [(65, "gaussian"), (100, "discrete"), (128, "gaussian"), (200, "gaussian"), (300, "discrete")])
+def test_backward_draw_over_time_segments_is_the_serial_draw(n, kind):
+    """More than 64 states (k_gen_sample_seg, SPL = 2 / 4 / 8 states per lane): the draw over time segments,
+    coupled through the per-step uniforms -- the oracle's paths (_hidden.c:330-378) state for state with the
+    caller's uniforms, the serial kernel's with the device stream; up to 128 states the alpha rows come
+    from the tile forward pass."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(4000 + n)
+    M = 25
+    A, pi, p0, p1 = _model(n, rng, kind, M)
+    lengths = (20011, 1, 7000, 2, 300) if n <= 128 else (6000, 1, 2500)
+    if kind == "gaussian":
+        obs = [rng.normal(0, 0.12 * n, T) for T in lengths]
+        pobs = [orc.pobs_gaussian(o, p0, p1) for o in obs]
+    else:
+        obs = [rng.integers(0, M, T).astype(np.int32) for T in lengths]
+        pobs = [orc.pobs_discrete(o, p0) for o in obs]
+    u = [rng.random(T) for T in lengths]
+    eng = Engine(0)
+    eng.set_option("sample_seg_per_simd", 1)
+    eng.set_observations(kind, obs, n, nsymbols=M if kind == "discrete" else 0)
+    for rep in range(2):
+        paths, C, n0, emis = eng.sample_paths(A, pi, p0, p1, u=u)
+        assert eng.get_option("sample_segmented") == 1 and eng.get_option("sample_segments") > 10
+        if n in (65, 100):                # (the tile forward pass verified on these models; it need not)
+            assert eng.get_option("sample_forward_segmented") == 1
+        ref = [orc.sample_path(orc.forward(A, po, pi)[1], A, u=uu) for po, uu in zip(pobs, u)]
+        assert sum(int((p != r).sum()) for p, r in zip(paths, ref)) == 0
+        Cr, n0r = orc.path_counts(ref, n)
+        assert np.array_equal(C, Cr) and np.array_equal(n0, n0r)
+    seeded = eng.sample_paths(A, pi, p0, p1, seed=11)[0]
+    eng.set_option("spec_enabled", 0)
+    serial = eng.sample_paths(A, pi, p0, p1, seed=11)[0]
+    assert eng.get_option("sample_segmented") == 0
+    assert all(np.array_equal(a, b) for a, b in zip(seeded, serial))
+    eng.close()
