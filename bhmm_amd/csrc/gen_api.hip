@@ -329,7 +329,7 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
     const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)n : (c->kind == EMIT_DISC ? (size_t)n * c->M : 0);
     const size_t nsym = c->kind == EMIT_DISC ? (size_t)n * c->M : 0;
     if ((rc = c->d_scratch2.ensure(((size_t)c->total + 4) * sizeof(int32_t))) ||
-        (rc = c->d_scratch.ensure((nstat + nsym + (size_t)std::max(K, 1) * 3 * n + nstat + esz +
+        (rc = c->d_scratch.ensure((nstat + nsym + (size_t)std::max(K, 1) * GEN_PS_SLABS * 3 * n + nstat + esz +
                                    (u ? (size_t)c->total : 0) + 8) * sizeof(double))))
         return rc;
     int32_t *path = reinterpret_cast<int32_t *>(c->d_scratch2.p);
@@ -337,7 +337,7 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(c->d_scratch.p);
     unsigned long long *symcnt = cnt + nstat;
     double *epart = reinterpret_cast<double *>(symcnt + nsym);
-    double *packed = epart + (size_t)std::max(K, 1) * 3 * n;
+    double *packed = epart + (size_t)std::max(K, 1) * GEN_PS_SLABS * 3 * n;
     double *udev = nullptr;
     if (u) {
         udev = packed + nstat + esz;
@@ -445,7 +445,7 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
     const dim3 pg(256), pb(256);
 #define BHMM_GEN_PS(KINDV)                                                                          \
     do {                                                                                            \
-        hipLaunchKernelGGL((k_gen_path_stats<KINDV>), dim3(K), dim3(GEN_TPB), 0, c->stream, m,      \
+        hipLaunchKernelGGL((k_gen_path_stats<KINDV>), dim3(K, GEN_PS_SLABS), dim3(GEN_TPB), 0, c->stream, m,      \
                            (const int64_t *)c->d_offsets.p, K, obs, (const int32_t *)path, cnt,     \
                            epart, symcnt);                                                          \
         hipLaunchKernelGGL((k_gen_pack_path_stats<KINDV>), pg, pb, 0, c->stream, m, K,              \

@@ -16,6 +16,7 @@
 namespace bhmm {
 
 constexpr int GEN_TPB = 256;   // threads per workgroup; thread q owns states q, q + 256, ...
+constexpr int GEN_PS_SLABS = 16; // time slabs per trajectory of k_gen_path_stats
 constexpr int GEN_MAXPT = 16;  // states per thread: up to 4096 states
 constexpr int GEN_MAXN = GEN_TPB * GEN_MAXPT;
 
@@ -855,19 +856,22 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_path_stats(const WideModel m, c
                                                             int K, const void *obs_rm,
                                                             const int32_t *path,
                                                             unsigned long long *cnt /* n*n + n */,
-                                                            double *epart /* gauss [K][3][n] */,
+                                                            double *epart /* gauss [K][GEN_PS_SLABS][3][n] */,
                                                             unsigned long long *symcnt /* [n][M] */)
 {
+    // grid (K, GEN_PS_SLABS): a block takes one slab of the trajectory's steps; the emission partials of
+    // the slabs are added in (trajectory, slab) order by k_gen_pack_path_stats (run-to-run identical)
     const int n = m.n, tid = threadIdx.x;
-    const int k = blockIdx.x;
+    const int k = blockIdx.x, slab = blockIdx.y;
     const int64_t t0 = off[k], T = off[k + 1] - t0;
-    if (T > 0 && tid == 0)
+    const int64_t ta = T * slab / GEN_PS_SLABS, tb = T * (slab + 1) / GEN_PS_SLABS;
+    if (T > 0 && tid == 0 && slab == 0)
         atomicAdd(&cnt[(int64_t)n * n + path[t0]], 1ull);
-    for (int64_t t = tid; t + 1 < T; t += GEN_TPB)
+    for (int64_t t = ta + tid; t < tb && t + 1 < T; t += GEN_TPB)
         atomicAdd(&cnt[(int64_t)path[t0 + t] * n + path[t0 + t + 1]], 1ull);
     if constexpr (KIND == EMIT_DISC) {
         const int32_t *sym = static_cast<const int32_t *>(obs_rm);
-        for (int64_t t = tid; t < T; t += GEN_TPB)
+        for (int64_t t = ta + tid; t < tb; t += GEN_TPB)
             atomicAdd(&symcnt[(int64_t)path[t0 + t] * m.M + sym[t0 + t]], 1ull);
     }
     if constexpr (KIND == EMIT_GAUSS) {
@@ -875,21 +879,21 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_path_stats(const WideModel m, c
         for (int i = tid; i < n; i += GEN_TPB) {
             double c = 0.0, s = 0.0, ss = 0.0;
             const double mu = m.mu[i];
-            for (int64_t t = 0; t < T; ++t)
+            for (int64_t t = ta; t < tb; ++t)
                 if (path[t0 + t] == i) {
                     const double d = o[t0 + t] - mu;
                     c += 1.0;
                     s += d;
                     ss += d * d;
                 }
-            epart[((int64_t)k * 3 + 0) * n + i] = c;
-            epart[((int64_t)k * 3 + 1) * n + i] = s;
-            epart[((int64_t)k * 3 + 2) * n + i] = ss;
+            const int64_t row = (int64_t)k * GEN_PS_SLABS + slab;
+            epart[(row * 3 + 0) * n + i] = c;
+            epart[(row * 3 + 1) * n + i] = s;
+            epart[(row * 3 + 2) * n + i] = ss;
         }
     }
 }
 
-// [counts n*n | n0 n | emission block] as fp64 (bhmm_sample_paths_dev) or raw tables for the host
 template <int KIND>
 __global__ void k_gen_pack_path_stats(const WideModel m, int K, const unsigned long long *cnt,
                                       const double *epart, const unsigned long long *symcnt,
@@ -906,8 +910,8 @@ __global__ void k_gen_pack_path_stats(const WideModel m, int K, const unsigned l
         } else if (KIND == EMIT_GAUSS) {
             const int64_t r = e - nn;
             v = 0.0;
-            for (int k = 0; k < K; ++k)
-                v += epart[((int64_t)k * 3 + r / n) * n + r % n];
+            for (int64_t k = 0; k < (int64_t)K * GEN_PS_SLABS; ++k)
+                v += epart[(k * 3 + r / n) * n + r % n];
         } else {
             v = (double)symcnt[e - nn];
         }
