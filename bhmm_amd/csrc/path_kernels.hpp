@@ -1241,33 +1241,44 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
             const Rows4 R = rows_of_group<NP>(v);
             double bh = 0.0;
             int bi = 0;
+            // USEMAX: without NaNs the winner's value is the maximum -- one v_max_f64 instead of two selects
+            auto argmax_rows = [&](auto usemax) __attribute__((always_inline)) {
+                constexpr bool USEMAX = decltype(usemax)::value;
 #pragma unroll
-            for (int k = 0; k < NP / 16; ++k) {
-                double hh[16];
-                int ii[16];
-                auto wk = [&](auto ic) __attribute__((always_inline)) { return Acol[16 * k + decltype(ic)::value]; };
-                asm volatile("s_nop 1"); // (a DPP read needs two wait states after the write of its register)
-                prod8_bcast<0>(hh, R.r[k], wk);
-                prod8_bcast<8>(hh, R.r[k], wk);
+                for (int k = 0; k < NP / 16; ++k) {
+                    double hh[16];
+                    int ii[16];
+                    auto wk = [&](auto ic) __attribute__((always_inline)) { return Acol[16 * k + decltype(ic)::value]; };
+                    asm volatile("s_nop 1"); // (a DPP read needs two wait states after the write of its register)
+                    prod8_bcast<0>(hh, R.r[k], wk);
+                    prod8_bcast<8>(hh, R.r[k], wk);
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    ii[i] = 16 * k + i;
-#define BHMM_ARGMAX_LEVEL(W)                                           \
-    _Pragma("unroll") for (int i = 0; i + W < 16; i += 2 * W)          \
-    {                                                                  \
-        const bool take = hh[i + W] > hh[i];                           \
-        hh[i] = take ? hh[i + W] : hh[i];                              \
-        ii[i] = take ? ii[i + W] : ii[i];                              \
+                    for (int i = 0; i < 16; ++i)
+                        ii[i] = 16 * k + i;
+#define BHMM_ARGMAX_LEVEL(W)                                                                 \
+    _Pragma("unroll") for (int i = 0; i + W < 16; i += 2 * W)                                \
+    {                                                                                        \
+        const bool take = hh[i + W] > hh[i];                                                 \
+        ii[i] = take ? ii[i + W] : ii[i];                                                    \
+        if constexpr (USEMAX)                                                                \
+            asm("v_max_f64 %0, %1, %2" : "=v"(hh[i]) : "v"(hh[i]), "v"(hh[i + W]));           \
+        else                                                                                 \
+            hh[i] = take ? hh[i + W] : hh[i];                                                \
     }
-                BHMM_ARGMAX_LEVEL(1)
-                BHMM_ARGMAX_LEVEL(2)
-                BHMM_ARGMAX_LEVEL(4)
-                BHMM_ARGMAX_LEVEL(8)
+                    BHMM_ARGMAX_LEVEL(1)
+                    BHMM_ARGMAX_LEVEL(2)
+                    BHMM_ARGMAX_LEVEL(4)
+                    BHMM_ARGMAX_LEVEL(8)
 #undef BHMM_ARGMAX_LEVEL
-                const bool take = (k == 0) || (hh[0] > bh);
-                bh = take ? hh[0] : bh;
-                bi = take ? ii[0] : bi;
-            }
+                    const bool take = (k == 0) || (hh[0] > bh);
+                    bh = take ? hh[0] : bh;
+                    bi = take ? ii[0] : bi;
+                }
+            };
+            if (__ballot(v != v) == 0ull) // (wave-uniform; v is NaN-free, A is, so are the products)
+                argmax_rows(std::true_type{});
+            else
+                argmax_rows(std::false_type{});
             if (real && t >= t0)
                 ptr[(o0 + t) * n + j] = (uint8_t)bi;
             const double bv = __shfl(v, bi, NP), bA = sA[bi * NP + j];
