@@ -1545,6 +1545,11 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
             return BHMM_ERR_INVALID;
         c->smp_seg_per_simd = (int)value;
         c->pplan[1].nseg = 0;
+    } else if (n == "viterbi_seg_warmups") { // 9..64 states: a Viterbi segment is at least this many warm-ups long
+        if (value < 1 || value > 64)
+            return BHMM_ERR_INVALID;
+        c->vit_seg_warmups = (int)value;
+        c->pplan[0].nseg = 0;
     } else if (n == "viterbi_seg_per_simd") { // 9..64 states: segments per SIMD of the Viterbi pass
         if (value < 1 || value > 64)
             return BHMM_ERR_INVALID;

@@ -143,6 +143,7 @@ struct bhmm_ctx {
     bhmm::DevBuf<int32_t> d_sentry, d_sexit;
     double spec_tol = 1e-11;          // N <= 8: tolerance of the boundary check (option spec_tol)
     int vit_seg_per_simd = 2;
+    int vit_seg_warmups = 2;          // a Viterbi segment is at least this many warm-ups long (measured: 1, 2, 4)
     int smp_seg_per_simd = 4;         // (the draw is a short dependent chain: more wavefronts per SIMD hide it)
     int vit_seg_mismatch = 0, vit_seg_rounds = 0;
     bhmm::DevBuf<double> d_vckpt;  // the first pass's vector at every 64th step

@@ -568,9 +568,9 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                     W_try *= 2;
                 }
             }
-            // two lane groups' worth of segments per SIMD, none shorter than four warm-ups
+            // two lane groups' worth of segments per SIMD, none shorter than two warm-ups
             const int64_t want = (int64_t)c->vit_seg_per_simd * c->num_simd * GP;
-            const int64_t seglen = std::max<int64_t>((c->total + want - 1) / want, 4 * (int64_t)W_try);
+            const int64_t seglen = std::max<int64_t>((c->total + want - 1) / want, c->vit_seg_warmups * (int64_t)W_try);
             Segs sg;
             if ((rc = wide_path_plan(c, 0, seglen, sg)))
                 return rc;
