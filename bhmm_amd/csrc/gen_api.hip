@@ -271,6 +271,92 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
     uint16_t *ptr = reinterpret_cast<uint16_t *>(c->d_scratch.p);
     int32_t *last = reinterpret_cast<int32_t *>(c->d_scratch2.p);
     int32_t *path = last + K;
+    // up to 128 states: over time segments (k_gen_viterbi_seg), accepted only when every segment started
+    // from the bit pattern its predecessor computed -- then the back-pointers are the serial run's
+    if (n <= 128 && c->spec_enabled && !c->vit_seg_given_up) {
+        bool done = false;
+        uint8_t *ptr8 = reinterpret_cast<uint8_t *>(c->d_scratch.p);
+        const size_t smv = (size_t)(128 * GVS_PITCH + 8 * 128) * sizeof(double);
+        if ((rc = gen_set_smem(k_gen_viterbi_seg<false>, smv)) || (rc = gen_set_smem(k_gen_viterbi_seg<true>, smv)) ||
+            (rc = c->d_specres.ensure(4)))
+            return rc;
+        if (!c->h_specres)
+            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
+                                   hipHostMallocDefault));
+        int W_try = c->vit_W > 0 ? c->vit_W : std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
+        Segs sg;
+        for (int attempt = 0; attempt < 2 && !done; ++attempt) {
+            if (attempt > 0)
+                W_try *= 2;
+            const int64_t want = (int64_t)c->vit_seg_per_simd * c->num_simd;
+            const int64_t seglen = std::max<int64_t>((c->total + want - 1) / want, c->vit_seg_warmups * (int64_t)W_try);
+            if ((rc = wide_path_plan_pub(c, 0, seglen, sg)))
+                return rc;
+            if (sg.nseg <= K)
+                break;
+            sg.W = W_try;
+            if ((rc = c->d_aentry.ensure((size_t)sg.nseg * 128)) || (rc = c->d_aexit.ensure((size_t)sg.nseg * 128)) ||
+                (rc = c->d_vckpt.ensure(((size_t)(c->total >> 6) + 1) * 128)) || (rc = c->d_vflag.ensure((size_t)sg.nseg)))
+                return rc;
+            const dim3 sgrid((sg.nseg + 7) / 8), sblk(512);
+            int round = 0;
+            for (; round <= 12; ++round) {
+                BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                if (round == 0)
+                    hipLaunchKernelGGL(k_gen_viterbi_seg<false>, sgrid, sblk, smv, c->stream, m, (const int64_t *)c->d_offsets.p,
+                                       sg, pobs, ptr8, last, c->d_aentry.p, c->d_aexit.p, c->d_vckpt.p,
+                                       (const uint8_t *)c->d_vflag.p);
+                else
+                    hipLaunchKernelGGL(k_gen_viterbi_seg<true>, sgrid, sblk, smv, c->stream, m, (const int64_t *)c->d_offsets.p,
+                                       sg, pobs, ptr8, last, c->d_aentry.p, c->d_aexit.p, c->d_vckpt.p,
+                                       (const uint8_t *)c->d_vflag.p);
+                hipLaunchKernelGGL((k_wide_vit_check<128>), dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg,
+                                   c->d_aentry.p, (const double *)c->d_aexit.p, c->d_vflag.p, c->d_specres.p);
+                BHMM_HIP(hipGetLastError());
+                BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
+                                        hipMemcpyDeviceToHost, c->stream));
+                BHMM_HIP(hipStreamSynchronize(c->stream));
+                if (round == 0)
+                    c->vit_seg_mismatch = (int)c->h_specres[3];
+                if (c->h_specres[3] == 0)
+                    break;
+            }
+            c->vit_seg_rounds = round;
+            if (c->h_specres[3] == 0) {
+                done = true;
+                c->vit_W = W_try; // (what converged is where the next call on these observations starts)
+            }
+        }
+        if (!done && c->pplan[0].nseg > K)
+            c->vit_seg_given_up = true; // these observations go to the serial kernel from now on
+        c->viterbi_chunked = done;
+        if (done) { // back-trace over the segments: maps, stitch, apply
+            if ((rc = c->d_vmaps.ensure((size_t)sg.nseg * 128)) || (rc = c->d_vend.ensure((size_t)sg.nseg)))
+                return rc;
+            const int64_t *off = c->d_offsets.p;
+            hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t, 2>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                               (const uint8_t *)ptr8, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
+                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 128,
+                               (const int32_t *)last, c->d_vend.p);
+            if (out_fmt == 0) {
+                hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t, 2>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path);
+                BHMM_HIP(hipGetLastError());
+                BHMM_HIP(hipMemcpyAsync(paths_out, path, (size_t)c->total * sizeof(int32_t),
+                                        hipMemcpyDeviceToHost, c->stream));
+            } else {
+                uint8_t *p8 = out_fmt == 2 ? static_cast<uint8_t *>(paths_out) : reinterpret_cast<uint8_t *>(path);
+                hipLaunchKernelGGL((k_wide_vit_walk<true, uint8_t, 2>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, p8);
+                BHMM_HIP(hipGetLastError());
+                if (out_fmt == 1)
+                    BHMM_HIP(hipMemcpyAsync(paths_out, p8, (size_t)c->total, hipMemcpyDeviceToHost, c->stream));
+            }
+            BHMM_HIP(hipStreamSynchronize(c->stream));
+            return BHMM_OK;
+        }
+    }
     size_t sm = gen_smem(n, 2, 2);
     if (gen_a_in_lds(n, sm)) {
         sm += gen_a_bytes(n);

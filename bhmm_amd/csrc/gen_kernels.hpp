@@ -731,6 +731,179 @@ __global__ __launch_bounds__(GEN_TPB) void k_gen_sample(const WideModel m, const
     }
 }
 
+// Viterbi over time segments for 65..128 states (round 4): the scheme of k_wide_viterbi_seg
+// (path_kernels.hpp: warm-up, bitwise boundary check, fix-up rounds from the predecessor's exact vector,
+// checkpoints every 64th step) with TWO target states per lane -- j = lane and lane + 64 -- and the
+// columns of A in LDS (sAT[j][i], pitch 130: sixteen lanes read their 16-byte pieces conflict-free).
+// One wavefront per segment, eight per workgroup.  `pobs`: the (total, n) emission matrix (gen_pobs).
+//   v_entry / v_exit [nseg][128];  ckpt [(total >> 6) + 1][128];  flag [nseg]
+constexpr int GVS_PITCH = 130;
+template <bool FIX>
+__global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, const int64_t *off, const Segs sg,
+                                                         const double *pobs, uint8_t *ptr, int32_t *last_state,
+                                                         double *v_entry, double *v_exit, double *ckpt,
+                                                         const uint8_t *flag)
+{
+    extern __shared__ __attribute__((aligned(16))) double gvs_sm[];
+    double *sAT = gvs_sm;                         // [128][GVS_PITCH]
+    double *xv = gvs_sm + 128 * GVS_PITCH;        // [8][128]: the final-state search
+    const int n = m.n;
+    for (int e = threadIdx.x; e < 128 * 128; e += 512) {
+        const int j = e >> 7, i = e & 127;
+        sAT[j * GVS_PITCH + i] = (i < n && j < n) ? m.A[(int64_t)i * n + j] : 0.0;
+    }
+    __syncthreads(); // (the only one: from here on the wavefronts are on their own)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sgi = blockIdx.x * 8 + w;
+    if (sgi >= sg.nseg || sg.len[sgi] <= 0)
+        return;
+    if constexpr (FIX) {
+        if (!flag[sgi])
+            return;
+    }
+    const int j[2] = {lane, lane + 64};
+    const bool real[2] = {j[0] < n, j[1] < n};
+    const int k = sg.traj[sgi];
+    const int64_t o0 = off[k], T = off[k + 1] - o0;
+    const int64_t t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+    const int64_t tw = FIX ? t0 : ((t0 - sg.W > 0) ? t0 - sg.W : 0);
+    auto emis = [&](int64_t gt, int e) __attribute__((always_inline)) {
+        return real[e] ? pobs[gt * n + j[e]] : 0.0;
+    };
+    double v[2], p_next[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        // (warm-up start; replaced at t = 0.  FIX: the predecessor's vector, t0 > 0 for a flagged segment)
+        v[e] = FIX ? v_entry[(int64_t)sgi * 128 + j[e]] : (real[e] ? 1.0 / (double)n : 0.0);
+        p_next[e] = emis(o0 + tw, e);
+    }
+    bool met = false;
+    for (int64_t t = tw; t < t1; ++t) {
+        double p[2], vn[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            p[e] = p_next[e];
+            if (t + 1 < t1)
+                p_next[e] = emis(o0 + t + 1, e); // independent of the recursion
+        }
+        if (t == 0) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                vn[e] = real[e] ? p[e] * m.pi[j[e]] : 0.0; // _hidden.c:232
+        } else {
+            const Rows4 R0 = rows_of(v[0]), R1 = rows_of(v[1]);
+            const bool nanfree = __ballot(v[0] != v[0] || v[1] != v[1]) == 0ull;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double *col = sAT + j[e] * GVS_PITCH;
+                double bh = 0.0;
+                int bi = 0;
+                auto argmax_rows = [&](auto usemax) __attribute__((always_inline)) {
+                    constexpr bool USEMAX = decltype(usemax)::value;
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        double hh[16], wv[16];
+                        int ii[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q += 2) {
+                            const double2 y = *reinterpret_cast<const double2 *>(col + 16 * kk + q);
+                            wv[q] = y.x;
+                            wv[q + 1] = y.y;
+                        }
+                        auto wk = [&](auto ic) __attribute__((always_inline)) { return wv[decltype(ic)::value]; };
+                        const double src = kk < 4 ? R0.r[kk & 3] : R1.r[kk & 3];
+                        asm volatile("s_nop 1"); // (a DPP read needs two wait states after the write of its register)
+                        prod8_bcast<0>(hh, src, wk);
+                        prod8_bcast<8>(hh, src, wk);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            ii[i] = 16 * kk + i;
+#define BHMM_ARGMAX_LEVEL(W)                                                                 \
+    _Pragma("unroll") for (int i = 0; i + W < 16; i += 2 * W)                                \
+    {                                                                                        \
+        const bool take = hh[i + W] > hh[i];                                                 \
+        ii[i] = take ? ii[i + W] : ii[i];                                                    \
+        if constexpr (USEMAX)                                                                \
+            asm("v_max_f64 %0, %1, %2" : "=v"(hh[i]) : "v"(hh[i]), "v"(hh[i + W]));           \
+        else                                                                                 \
+            hh[i] = take ? hh[i + W] : hh[i];                                                \
+    }
+                        BHMM_ARGMAX_LEVEL(1)
+                        BHMM_ARGMAX_LEVEL(2)
+                        BHMM_ARGMAX_LEVEL(4)
+                        BHMM_ARGMAX_LEVEL(8)
+#undef BHMM_ARGMAX_LEVEL
+                        const bool take = (kk == 0) || (hh[0] > bh); // first maximum: _hidden.c:186-200
+                        bh = take ? hh[0] : bh;
+                        bi = take ? ii[0] : bi;
+                    }
+                };
+                if (nanfree)
+                    argmax_rows(std::true_type{});
+                else
+                    argmax_rows(std::false_type{});
+                if (real[e] && t >= t0)
+                    ptr[(o0 + t) * n + j[e]] = (uint8_t)bi;
+                const double b0 = __shfl(v[0], bi & 63, 64), b1 = __shfl(v[1], bi & 63, 64);
+                const double bv = bi < 64 ? b0 : b1, bA = col[bi];
+                vn[e] = p[e] * bv * bA; // _hidden.c:253: (p v[i^]) A[i^][j]
+            }
+        }
+        // the normalising sum in ascending order (_hidden.c:256-259): S = fma(vn[i], 1, S), rounded once
+        double S = 0.0;
+        {
+            const Rows4 Rn0 = rows_of(vn[0]), Rn1 = rows_of(vn[1]);
+            const double one = 1.0;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                sum16_bcast(S, Rn0.r[kk], one);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                sum16_bcast(S, Rn1.r[kk], one);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            v[e] = vn[e] / S;
+        if constexpr (!FIX) {
+            if (t == t0 - 1) {
+                v_entry[(int64_t)sgi * 128 + j[0]] = v[0];
+                v_entry[(int64_t)sgi * 128 + j[1]] = v[1];
+            }
+        }
+        if (((o0 + t) & 63) == 63 && t >= t0) {
+            double *cp = ckpt + ((o0 + t) >> 6) * 128;
+            if constexpr (FIX) {
+                const bool same = __double_as_longlong(cp[j[0]]) == __double_as_longlong(v[0]) &&
+                                  __double_as_longlong(cp[j[1]]) == __double_as_longlong(v[1]);
+                if (__ballot(!same) == 0ull) {
+                    met = true;
+                    break;
+                }
+            }
+            cp[j[0]] = v[0];
+            cp[j[1]] = v[1];
+        }
+    }
+    if (met)
+        return;
+    v_exit[(int64_t)sgi * 128 + j[0]] = v[0];
+    v_exit[(int64_t)sgi * 128 + j[1]] = v[1];
+    if (t1 == T) { // the trajectory's final state (_hidden.c:262-267: first maximum)
+        xv[w * 128 + j[0]] = v[0];
+        xv[w * 128 + j[1]] = v[1];
+        if (lane == 0) {
+            double bm = xv[w * 128];
+            int bi = 0;
+            for (int i = 1; i < n; ++i)
+                if (xv[w * 128 + i] > bm) {
+                    bm = xv[w * 128 + i];
+                    bi = i;
+                }
+            last_state[k] = bi;
+        }
+    }
+}
+
 // Backward draw over time segments for 65..512 states (round 4): the scheme of k_wide_sample_seg
 // (path_kernels.hpp) with SPL states per lane -- state e * 64 + lane in slot e --, one wavefront per
 // segment, column s_{t+1} of A read from the transposed copy `At` (coalesced).  The draws of different

@@ -541,17 +541,10 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     // segment arrives at its first step with the bit pattern its predecessor left there -- then the
     // back-pointers are the serial run's, by induction from the exact first segment of each trajectory
     if (c->wide && c->spec_enabled && !c->vit_seg_given_up) {
+        // warm-up: the E-step's (the filter's forgetting length) where it has been measured; no search of
+        // its own -- every length is exact, and the time is flat over a factor of four (tools/wide_viterbi.py)
         int W_try = c->vit_W > 0 ? c->vit_W : std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
-        bool exploring = false;
-        if (c->vit_W > 0 && c->vit_explore && !c->spec_W_fixed) {
-            const int Wn = std::max(32, (c->vit_W * 3 / 4 + 7) / 8 * 8);
-            if (Wn < c->vit_W && Wn > c->vit_bad) {
-                W_try = Wn;
-                exploring = true;
-            } else {
-                c->vit_explore = false;
-            }
-        }
+        const bool exploring = false;
         if ((rc = c->d_specres.ensure(4)))
             return rc;
         if (!c->h_specres)
@@ -559,14 +552,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                                    hipHostMallocDefault));
         for (int attempt = 0; attempt < 2 && !done; ++attempt) {
             if (attempt > 0) {
-                if (exploring) {
-                    c->vit_bad = W_try;
-                    c->vit_explore = false;
-                    exploring = false;
-                    W_try = c->vit_W;
-                } else {
-                    W_try *= 2;
-                }
+                W_try *= 2;
             }
             // two lane groups' worth of segments per SIMD, none shorter than two warm-ups
             const int64_t want = (int64_t)c->vit_seg_per_simd * c->num_simd * GP;
@@ -631,19 +617,14 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
 #undef BHMM_WVS
             c->vit_seg_rounds = round;
             const bool accepted = c->h_specres[3] == 0;
-            // a warm-up that leaves more than a fifth of the boundaries to the fix-up is too short
-            const bool short_W = !c->spec_W_fixed && (int64_t)c->vit_seg_mismatch * 5 > sg.nseg;
-            if (exploring && (!accepted || short_W)) {
-                if (accepted) { // (the paths are right; only the search ends here)
-                    c->vit_bad = W_try;
-                    c->vit_explore = false;
-                    done = true;
-                }
+            // (How many boundaries the first pass left to the fix-up does not say whether the warm-up was
+            // too short -- most of them are rounding noise, and a round costs the same for one segment as
+            // for a thousand: doubling the warm-up on that count was measured slower everywhere.)
+            if (exploring && !accepted)
                 continue;
-            }
             if (accepted) {
                 done = true;
-                c->vit_W = short_W ? 2 * W_try : W_try;
+                c->vit_W = W_try;
             }
         }
         if (!done && c->pplan[0].nseg > K)
@@ -656,7 +637,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
             hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
                                (const uint8_t *)ptr, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
             hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
-                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p,
+                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 64,
                                (const int32_t *)last, c->d_vend.p);
             if (out_fmt == 0)
                 hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,

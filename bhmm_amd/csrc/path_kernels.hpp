@@ -2053,12 +2053,13 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_trace(const int64_t *off, i
 // (maps[s][c]); k_wide_vit_stitch chains the maps of a trajectory from its final state; APPLY = true --
 // the segment is walked once more from its now known last state and the path is written
 // (_hidden.c:269-272).  Back-pointer rows are staged through LDS 64 steps at a time.
-template <bool APPLY, typename PT>
+// NC: candidate states per lane (1: up to 64 states, 2: up to 128; maps[s][64 NC])
+template <bool APPLY, typename PT, int NC = 1>
 __global__ __launch_bounds__(64) void k_wide_vit_walk(const int64_t *off, const Segs sg, int n,
                                                       const uint8_t *ptr, uint8_t *maps,
                                                       const uint8_t *end_state, PT *path)
 {
-    __shared__ uint8_t tile[64 * 64];
+    __shared__ uint8_t tile[64 * 64 * NC];
     __shared__ int32_t outp[64];
     const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= sg.nseg || sg.len[s] <= 0)
@@ -2066,9 +2067,12 @@ __global__ __launch_bounds__(64) void k_wide_vit_walk(const int64_t *off, const 
     const int k = sg.traj[s];
     const int64_t o0 = off[k];
     const int64_t t0 = sg.t0[s], t1 = t0 + sg.len[s];
-    int cur = APPLY ? (int)end_state[s] : (lane < n ? lane : 0);
+    int cur[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        cur[c] = APPLY ? (int)end_state[s] : (lane + 64 * c < n ? lane + 64 * c : 0);
     if (APPLY && lane == 0)
-        path[o0 + t1 - 1] = (PT)cur;
+        path[o0 + t1 - 1] = (PT)cur[0];
     // steps t = hi .. lo (descending) use ptr[t] to produce the state at t - 1; APPLY stops above the
     // segment's first step (the state below it is the previous segment's last), the map pass goes on
     // to it -- except at the start of a trajectory, where there is nothing below
@@ -2083,27 +2087,33 @@ __global__ __launch_bounds__(64) void k_wide_vit_walk(const int64_t *off, const 
         if constexpr (APPLY) {
             if (lane == 0) {
                 for (int q = cnt - 1; q >= 0; --q) {
-                    cur = tile[q * n + cur];
-                    outp[q] = cur; // path[lo + q - 1]
+                    cur[0] = tile[q * n + cur[0]];
+                    outp[q] = cur[0]; // path[lo + q - 1]
                 }
             }
             __syncthreads();
             if (lane < cnt)
                 path[o0 + lo + lane - 1] = (PT)outp[lane];
-            cur = outp[0];
+            cur[0] = outp[0];
         } else {
             for (int q = cnt - 1; q >= 0; --q)
-                cur = tile[q * n + cur];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    cur[c] = tile[q * n + cur[c]];
         }
         __syncthreads();
     }
-    if constexpr (!APPLY)
-        maps[(int64_t)s * 64 + lane] = (uint8_t)cur;
+    if constexpr (!APPLY) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            maps[(int64_t)s * 64 * NC + lane + 64 * c] = (uint8_t)cur[c];
+    }
 }
 
 // end_state[s] for every segment: the trajectory's final state for its last segment, then map by map
 [[maybe_unused]] static __global__ void k_wide_vit_stitch(const int32_t *traj0, int K, const uint8_t *maps,
-                                                           const int32_t *last_state, uint8_t *end_state)
+                                                           int stride, const int32_t *last_state,
+                                                           uint8_t *end_state)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K)
@@ -2114,7 +2124,7 @@ __global__ __launch_bounds__(64) void k_wide_vit_walk(const int64_t *off, const 
     int cur = last_state[k];
     end_state[s1 - 1] = (uint8_t)cur;
     for (int s = s1 - 1; s > s0; --s) {
-        cur = maps[(int64_t)s * 64 + cur];
+        cur = maps[(int64_t)s * stride + cur];
         end_state[s - 1] = (uint8_t)cur;
     }
 }

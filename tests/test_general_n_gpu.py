@@ -215,3 +215,32 @@ def test_backward_draw_over_time_segments_is_the_serial_draw(n, kind):
     assert eng.get_option("sample_segmented") == 0
     assert all(np.array_equal(a, b) for a, b in zip(seeded, serial))
     eng.close()
+
+
+@pytest.mark.parametrize("n,kind", [(65, "gaussian"), (100, "discrete"), (128, "gaussian"), (97, "gaussian")])
+def test_viterbi_over_time_segments_65_to_128_states(n, kind):
+    """65..128 states, two target states per lane (k_gen_viterbi_seg): segments whose start vector is not
+    the predecessor's to the bit are repeated from it until none is left; the paths are the oracle's
+    (_hidden.c:186-276) byte for byte, ragged lengths and single steps included."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(5000 + n)
+    M = 25
+    A, pi, p0, p1 = _model(n, rng, kind, M)
+    lengths = (20011, 1, 7000, 2, 300)
+    if kind == "gaussian":
+        obs = [rng.normal(0, 0.12 * n, T) for T in lengths]
+        pobs = [orc.pobs_gaussian(o, p0, p1) for o in obs]
+    else:
+        obs = [rng.integers(0, M, T).astype(np.int32) for T in lengths]
+        pobs = [orc.pobs_discrete(o, p0) for o in obs]
+    eng = Engine(0)
+    eng.set_option("viterbi_seg_per_simd", 1)
+    eng.set_observations(kind, obs, n, nsymbols=M if kind == "discrete" else 0)
+    for rep in range(2):
+        paths = eng.viterbi(A, pi, p0, p1)
+        assert eng.get_option("viterbi_chunked") == 1 and eng.get_option("viterbi_segments") > 10
+        for p, po in zip(paths, pobs):
+            assert np.array_equal(p, orc.viterbi(A, po, pi)), rep
+    p8 = eng.viterbi_u8(A, pi, p0, p1)
+    assert np.array_equal(p8, np.concatenate(paths).astype(np.uint8))
+    eng.close()
