@@ -590,7 +590,7 @@ def secondary_gen(torch, dev, local, args):
                     "roofline": {"bound": "fp64", "achieved": flops * K * T / dt / 1e12, "peak": 78.6,
                                  "unit": "TFLOP/s", "frac": flops * K * T / dt / 1e12 / 78.6},
                     "tile_kernels": bool(eng.get_option("tile")), "segments": eng.get_option("wide_segments"),
-                    "self_checks_fired": int(eng.get_option("wide_trouble")),
+                    "self_checks_fired": int(eng.get_option("wide_trouble")), "tile_retries": int(eng.get_option("tile_retries")),
                     "tile_reason": int(eng.get_option("tile_reason")),
                     "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")}})
         eng.close()

@@ -1303,6 +1303,7 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     c->vit_W = 0;
     c->pplan[0].nseg = c->pplan[1].nseg = 0;
     c->smp_W = 0;
+    c->tile_retries = 0;
     c->vit_seg_given_up = false;
     c->vit_bad = 0;
     c->vit_explore = true;
@@ -1616,6 +1617,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->smp_seg_mismatch;
     else if (n == "sample_rounds")
         *value = c->smp_seg_rounds;
+    else if (n == "tile_retries") // E-steps on the tile kernels that were repeated because a self-check fired
+        *value = c->tile_retries;
     else if (n == "viterbi_rounds") // ... fix-up rounds its last pass needed
         *value = c->vit_seg_rounds;
     else if (n == "viterbi_mismatch") // ... boundaries of its last attempt that were not bit-identical

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -40,6 +41,14 @@ struct DevBuf {
             return BHMM_ERR_NO_MEM;
         }
         n = count;
+        // debugging aid: BHMM_AMD_POISON=1 fills every fresh allocation with 0xFF bytes (NaN doubles,
+        // -1 integers), so that a kernel that reads what nothing wrote shows up at once instead of
+        // depending on what the allocator handed out
+        static const bool poison = getenv("BHMM_AMD_POISON") != nullptr;
+        if (poison) { // (the fill runs on the null stream; the context's streams do not wait for it by themselves)
+            (void)hipMemset(p, 0xFF, count * sizeof(T));
+            (void)hipDeviceSynchronize();
+        }
         return BHMM_OK;
     }
     void release()
@@ -142,6 +151,7 @@ struct bhmm_ctx {
     bool smp_segmented = false;       // the last sample_paths call ran over time segments
     bhmm::DevBuf<int32_t> d_sentry, d_sexit;
     double spec_tol = 1e-11;          // N <= 8: tolerance of the boundary check (option spec_tol)
+    int tile_retries = 0;             // E-steps on the tile kernels repeated once after a self-check fired (see tile_gen.hip)
     int vit_seg_per_simd = 2;
     int vit_seg_warmups = 2;          // a Viterbi segment is at least this many warm-ups long (measured: 1, 2, 4)
     int smp_seg_per_simd = 4;         // (the draw is a short dependent chain: more wavefronts per SIMD hide it)

@@ -636,6 +636,10 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipStreamSynchronize(c->stream));
         if (lazy)
             c->wide_trouble = c->h_specres[2];
+        if (lazy && c->h_specres[2] != 0 && c->tile_used && c->tile_retries < 1) {
+            ++c->tile_retries; // (the tile kernels once more before the context leaves them: tile_gen.hip)
+            return wide_estep(c, A, pi, par0, par1, stats_dev, flags);
+        }
         if (lazy && c->h_specres[2] != 0) {
             // a vector left the range the lazy scaling covers: per-step normalisation from now on
             c->wide_careful = true;
