@@ -593,8 +593,18 @@ def secondary_gen(torch, dev, local, args):
                     "self_checks_fired": int(eng.get_option("wide_trouble")), "tile_retries": int(eng.get_option("tile_retries")),
                     "tile_reason": int(eng.get_option("tile_reason")),
                     "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")}})
+        pdev = torch.empty(K * T, dtype=torch.uint8, device=dev)
+        eng.viterbi_u8(*margs, out=pdev)
+        dv = timeit(lambda: eng.viterbi_u8(*margs, out=pdev), 2, eng.sync)
+        eng.sample_paths(*margs, seed=1, want_paths=False)
+        dg = timeit(lambda: eng.sample_paths(*margs, seed=1, want_paths=False), 2, eng.sync)
+        out[-1]["viterbi"] = {"ms": 1e3 * dv, "over_time_segments": bool(eng.get_option("viterbi_chunked")),
+                              "segments": eng.get_option("viterbi_segments"), "fixup_rounds": eng.get_option("viterbi_rounds")}
+        out[-1]["gibbs_path_step"] = {"ms": 1e3 * dg, "over_time_segments": bool(eng.get_option("sample_segmented")),
+                                      "forward_pass_segmented": bool(eng.get_option("sample_forward_segmented")),
+                                      "fixup_rounds": eng.get_option("sample_rounds")}
         eng.close()
-        del obs
+        del obs, pdev
     return out
 
 

@@ -858,3 +858,35 @@ def test_weight_on_entries_in_the_denormal_range(case, kind, spec, store_gamma):
     if store_gamma:
         np.testing.assert_allclose(eng.gamma(0), ref["gammas"][0], rtol=1e-8, atol=1e-12)
     eng.close()
+
+
+def test_boundary_tolerance_option_shortens_the_warm_up():
+    """spec_tol (N <= 8): the boundary check's tolerance, the warm-up calibrated a hundred times inside it.
+    1e-9 gives a shorter warm-up than the default 1e-11, boundaries that verify, and statistics equal to
+    the default's far inside the 1e-6 contract; values outside [1e-13, 1e-7] are refused."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(77)
+    n = 8
+    A = rng.random((n, n)) + np.eye(n) * 6.0
+    A /= A.sum(axis=1)[:, None]
+    pi = np.full(n, 1.0 / n)
+    mu, sig = np.linspace(-4, 4, n), np.full(n, 1.3)
+    obs = [rng.normal(0, 3, T) for T in (300000, 200000)]
+    out = {}
+    for tol in (1e-11, 1e-9):
+        eng = Engine(0)
+        eng.set_option("spec_tol", tol)
+        assert eng.get_option("spec_tol") == tol
+        eng.set_observations("gaussian", obs, n)
+        r = eng.estep(A, pi, mu, sig)
+        r = eng.estep(A, pi, mu, sig)
+        assert eng.get_option("spec_fail") == 0 and eng.get_option("spec_last_dev") <= tol
+        out[tol] = (r, eng.get_option("spec_W"))
+        eng.close()
+    assert out[1e-9][1] < out[1e-11][1]
+    np.testing.assert_allclose(out[1e-9][0].logL_k, out[1e-11][0].logL_k, rtol=1e-9)
+    np.testing.assert_allclose(out[1e-9][0].C, out[1e-11][0].C, rtol=1e-7, atol=1e-7)
+    eng = Engine(0)
+    with pytest.raises(Exception):
+        eng.set_option("spec_tol", 1e-3)
+    eng.close()
