@@ -302,6 +302,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
             int round = 0;
             for (; round <= 12; ++round) {
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                lds_poison(c->stream);
                 if (round == 0)
                     hipLaunchKernelGGL(k_gen_viterbi_seg<false>, sgrid, sblk, smv, c->stream, m, (const int64_t *)c->d_offsets.p,
                                        sg, pobs, ptr8, last, c->d_aentry.p, c->d_aexit.p, c->d_vckpt.p,
@@ -473,6 +474,7 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
             int round = 0;
             for (; round <= max_rounds; ++round) {
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                lds_poison(c->stream);
                 if (round == 0)
                     BHMM_GSS_SPL(false);
                 else

@@ -599,6 +599,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
             int round = 0;
             for (; round <= max_rounds; ++round) {
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                lds_poison(c->stream);
                 if (round == 0)
                     BHMM_WVS_NP(false);
                 else
@@ -787,6 +788,7 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
             int round = 0;
             for (; round <= max_rounds; ++round) {
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                lds_poison(c->stream);
                 if (round == 0)
                     BHMM_WSS_NP(false);
                 else

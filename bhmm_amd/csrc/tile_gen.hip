@@ -60,6 +60,7 @@ int plan_for(bhmm_ctx *c, int W)
 template <int NT, int KIND>
 int launch_fwd(bhmm_ctx *c, const WideModel &m)
 {
+    lds_poison(c->stream);
     const Segs sg = wide_segs_pub(c, 1);
     const TilePlan tp{c->d_tile_seg[1].p, c->w_ntiles[1]};
     hipLaunchKernelGGL((k_tile_fwd<NT, KIND, false, false>), dim3(tp.ntiles), dim3(tile_threads<false>()), 0,
@@ -79,6 +80,7 @@ int launch_fwd(bhmm_ctx *c, const WideModel &m)
 template <int NT, int KIND>
 int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
 {
+    lds_poison(c->stream);
     const Segs sg = wide_segs_pub(c, 1);
     const TilePlan tp{c->d_tile_segb[1].p, c->w_ntilesb[1]};
     const int n = c->n;

@@ -993,7 +993,10 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
         for (int c = 0; c < TPW; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                in.ap[c][r] = sAl[slot * 16 * PX + xw[r] + 16 * (w + 4 * c) + s];
+                // (a column tile beyond NT does not exist in the LDS tile: what lies there -- another row,
+                // another array, whatever the previous kernel left -- may be a NaN pattern, and 0 x NaN would
+                // reach the row sums: the transient of 65 states)
+                in.ap[c][r] = (NT % 4 == 0 || w + 4 * c < NT) ? sAl[slot * 16 * PX + xw[r] + 16 * (w + 4 * c) + s] : 0.0;
         typedef int tile_i4 __attribute__((ext_vector_type(4)));
         const tile_i4 e = *reinterpret_cast<const tile_i4 *>(&sEx[slot * 16 + 4 * q]);
         in.ex[0] = e[0];

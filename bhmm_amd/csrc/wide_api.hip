@@ -105,6 +105,7 @@ static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
         BHMM_HIP(hipEventRecord(c->ev[5], c->stream));
     }
     static const bool probe_in = probe_on && atoi(getenv("BHMM_AMD_TILE_PROBE")) == 1; // (2: kernel times only)
+    lds_poison(c->stream);
     hipLaunchKernelGGL((k_tile_fwd<4, KIND, true, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p, c->d_alpha_rm.p,
                        c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p,
@@ -150,6 +151,7 @@ static int tile_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
         BHMM_HIP(hipMemsetAsync(probe, 0, 128, c->stream));
         BHMM_HIP(hipEventRecord(c->ev[5], c->stream));
     }
+    lds_poison(c->stream);
     hipLaunchKernelGGL((k_tile_bwd<4, KIND, true, false, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
                        (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
                        (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
