@@ -1684,6 +1684,8 @@ int bhmm_ctx_last_kernel_ms_all(bhmm_ctx *c, double *out)
 int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1, double *stats_dev, int flags)
 {
+    if (c)
+        lds_poison(c->stream); // (debugging aid, BHMM_AMD_POISON=1 only)
     if (!c || c->kind < 0)
         return invalid("no observations loaded");
     if (!A || !pi)

@@ -914,6 +914,8 @@ extern "C" {
 int bhmm_viterbi_batch(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                        const double *par1, int32_t *paths)
 {
+    if (c)
+        lds_poison(c->stream); // (debugging aid, BHMM_AMD_POISON=1 only)
     if (!c || c->kind < 0)
         return invalid_arg("no observations loaded");
     if (!A || !pi || !paths)
@@ -932,6 +934,8 @@ int bhmm_viterbi_batch(bhmm_ctx *c, const double *A, const double *pi, const dou
 int bhmm_viterbi_batch_u8(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                           const double *par1, uint8_t *paths, int paths_on_device)
 {
+    if (c)
+        lds_poison(c->stream); // (debugging aid, BHMM_AMD_POISON=1 only)
     if (!c || c->kind < 0)
         return invalid_arg("no observations loaded");
     if (!A || !pi || !paths)
@@ -950,6 +954,8 @@ int bhmm_sample_paths(bhmm_ctx *c, const double *A, const double *pi, const doub
                       const double *par1, const double *u, uint64_t seed, int32_t *paths,
                       int64_t *counts, int64_t *n0, double *emis)
 {
+    if (c)
+        lds_poison(c->stream); // (debugging aid, BHMM_AMD_POISON=1 only)
     if (!c || c->kind < 0)
         return invalid_arg("no observations loaded");
     if (!A || !pi)
@@ -997,6 +1003,8 @@ int bhmm_sample_paths_dev(bhmm_ctx *c, const double *A, const double *pi, const 
                           const double *par1, const double *u, uint64_t seed, int32_t *paths,
                           double *stats_dev)
 {
+    if (c)
+        lds_poison(c->stream); // (debugging aid, BHMM_AMD_POISON=1 only)
     if (!c || c->kind < 0)
         return invalid_arg("no observations loaded");
     if (!A || !pi || !stats_dev)

@@ -1185,28 +1185,4 @@ __global__ __launch_bounds__(64) void k_wide_xi(const double *A, const double *p
         C[e] = s * A[e];
 }
 
-// debugging aid (BHMM_AMD_POISON=1): every byte of every compute unit's LDS set to 0xFF before a
-// kernel that exchanges vectors through LDS starts, so that a kernel that reads LDS it has not written meets NaNs instead of whatever the
-// previous kernel on that compute unit left there
-[[maybe_unused]] static __global__ void k_lds_poison(int words)
-{
-    extern __shared__ unsigned int lds_all[];
-    for (int e = threadIdx.x; e < words; e += blockDim.x)
-        lds_all[e] = 0xFFFFFFFFu;
-    __syncthreads();
-    if (lds_all[(threadIdx.x * 7) % words] != 0xFFFFFFFFu) // (keeps the stores)
-        __builtin_trap();
-}
-[[maybe_unused]] static void lds_poison(hipStream_t stream)
-{
-    static const bool poison = getenv("BHMM_AMD_POISON") != nullptr;
-    if (!poison)
-        return;
-    const int bytes = 160 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lds_poison),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL(k_lds_poison, dim3(2048), dim3(1024), bytes, stream, bytes / 4);
-    (void)hipGetLastError();
-}
-
 } // namespace bhmm
