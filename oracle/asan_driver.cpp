@@ -101,6 +101,32 @@ static void check_seg_plan(const std::vector<int64_t> &off, int K, int64_t segle
     }
     CHECK(covered == off[K] - off[0]);
     CHECK((int)s.traj0.size() == K + 1 && s.traj0[K] == (int32_t)s.traj.size());
+    // tiles of the row-batched kernels, per direction: every segment exactly once, 16 slots per tile, empty
+    // slots only at the end of a class, and (inside a class) longest rows first
+    for (int dir = 0; dir < 2; ++dir) {
+        std::vector<int32_t> ts;
+        bhmm::plan::plan_tiles(s, off, dir == 1, ts);
+        CHECK(ts.size() % 16 == 0);
+        std::vector<int> seen(s.traj.size(), 0);
+        for (size_t q = 0; q < ts.size(); ++q)
+            if (ts[q] >= 0) {
+                CHECK((size_t)ts[q] < s.traj.size());
+                seen[ts[q]]++;
+            }
+        for (size_t q = 0; q < s.traj.size(); ++q)
+            CHECK(seen[q] == (s.len[q] > 0 ? 1 : 0));
+        for (size_t q = 0; q + 1 < ts.size(); ++q) {
+            if (ts[q] < 0 || ts[q + 1] < 0)
+                continue;
+            const int a = ts[q], b = ts[q + 1];
+            const int64_t Ta = off[s.traj[a] + 1] - off[s.traj[a]], Tb = off[s.traj[b] + 1] - off[s.traj[b]];
+            const bool ea = dir ? s.t0[a] + s.len[a] >= Ta : s.t0[a] == 0;
+            const bool eb = dir ? s.t0[b] + s.len[b] >= Tb : s.t0[b] == 0;
+            CHECK(ea || !eb);                      // rows without a warm-up come first
+            if (ea == eb)
+                CHECK(s.len[a] >= s.len[b]);       // longest first inside a class
+        }
+    }
     if (seglen > 0 && mult == 1) {
         std::vector<int64_t> mid;
         bhmm::plan::plan_forward_mids(off, K, seglen, mid);
