@@ -878,9 +878,11 @@ def main():
                                          "efficiency_vs_n1": None if n1 is None else n1 / c3["ms"] / world}
             if c4 is not None:
                 out["configs3_64_states"] = {k: c4[k] for k in ("config", "ms", "timesteps_per_s", "roofline",
-                                                                "kernels", "kernel_ms", "segments", "spec")}
+                                                                "kernels", "kernel_ms", "segments", "spec", "viterbi",
+                                                                "gibbs_path_step", "whole_em_iteration") if k in c4}
             if gen:
-                out["more_than_64_states"] = [{k: g[k] for k in ("config", "ms", "roofline", "tile_kernels")}
+                out["more_than_64_states"] = [{k: g[k] for k in ("config", "ms", "roofline", "tile_kernels", "tile_retries",
+                                                                 "viterbi", "gibbs_path_step") if k in g}
                                               for g in gen]
     if out is not None:
         print(json.dumps(out))
