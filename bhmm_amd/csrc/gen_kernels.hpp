@@ -802,6 +802,8 @@ __global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, cons
                     constexpr bool USEMAX = decltype(usemax)::value;
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
+                        if (16 * kk >= n) // (row blocks of padded states only: exact zeros, never a winner)
+                            continue;
                         double hh[16], wv[16];
                         int ii[16];
 #pragma unroll
@@ -859,7 +861,8 @@ __global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, cons
                 sum16_bcast(S, Rn0.r[kk], one);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                sum16_bcast(S, Rn1.r[kk], one);
+                if (64 + 16 * kk < n) // (the rest adds exact zeros)
+                    sum16_bcast(S, Rn1.r[kk], one);
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e)
