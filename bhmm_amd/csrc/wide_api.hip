@@ -86,7 +86,12 @@ static int wide_fwd_plan(const bhmm_ctx *c, int which)
 }
 
 // 64 states: the lazily scaled E-step runs on the row-batched matrix-core kernels (tile_kernels.hpp)
-static bool wide_tile(const bhmm_ctx *c) { return c->tile_enabled && (c->n == 64 || (c->gen && c->n <= 128)); }
+// 33..64 states (64 lanes anyway: four column tiles, the last ones partly padded) and, through tile_gen.hip,
+// 65..128
+static bool wide_tile(const bhmm_ctx *c)
+{
+    return c->tile_enabled && ((c->n > 32 && c->n <= 64 && !c->gen) || (c->gen && c->n <= 128));
+}
 
 template <int KIND>
 static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
@@ -106,10 +111,16 @@ static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
     }
     static const bool probe_in = probe_on && atoi(getenv("BHMM_AMD_TILE_PROBE")) == 1; // (2: kernel times only)
     lds_poison(c->stream);
-    hipLaunchKernelGGL((k_tile_fwd<4, KIND, true, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p, c->d_alpha_rm.p,
-                       c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p,
-                       probe_in ? probe : (unsigned long long *)nullptr);
+    if (c->n == 64)
+        hipLaunchKernelGGL((k_tile_fwd<4, KIND, true, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p, c->d_alpha_rm.p,
+                           c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p,
+                           probe_in ? probe : (unsigned long long *)nullptr);
+    else
+        hipLaunchKernelGGL((k_tile_fwd<4, KIND, false, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p, c->d_alpha_rm.p,
+                           c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p, c->d_specres.p,
+                           probe_in ? probe : (unsigned long long *)nullptr);
     BHMM_HIP(hipGetLastError());
     if (probe_on) {
         unsigned long long h[8];
@@ -152,12 +163,20 @@ static int tile_launch_bwd(bhmm_ctx *c, const WideModel &m, int which, bool stor
         BHMM_HIP(hipEventRecord(c->ev[5], c->stream));
     }
     lds_poison(c->stream);
-    hipLaunchKernelGGL((k_tile_bwd<4, KIND, true, false, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
-                       (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
-                       (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
-                       c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
-                       (double *)nullptr,
-                       atoi(getenv("BHMM_AMD_TILE_PROBE") ? getenv("BHMM_AMD_TILE_PROBE") : "0") == 1 ? probe : (unsigned long long *)nullptr);
+    if (c->n == 64)
+        hipLaunchKernelGGL((k_tile_bwd<4, KIND, true, false, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
+                           (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
+                           c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
+                           (double *)nullptr,
+                           atoi(getenv("BHMM_AMD_TILE_PROBE") ? getenv("BHMM_AMD_TILE_PROBE") : "0") == 1 ? probe : (unsigned long long *)nullptr);
+    else
+        hipLaunchKernelGGL((k_tile_bwd<4, KIND, false, false, true>), dim3(tp.ntiles), dim3(TILE_THREADS), 0, c->stream, m,
+                           (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
+                           (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
+                           c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
+                           (double *)nullptr,
+                           atoi(getenv("BHMM_AMD_TILE_PROBE") ? getenv("BHMM_AMD_TILE_PROBE") : "0") == 1 ? probe : (unsigned long long *)nullptr);
     BHMM_HIP(hipGetLastError());
     if (probe_on) {
         unsigned long long h[16];

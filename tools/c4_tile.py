@@ -11,7 +11,7 @@ from bhmm_amd.engine import Engine, synth_observations
 
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(64)
-n, K, T = 64, 128, 100000
+n, K, T = int(os.environ.get("C4_N", 64)), 128, 100000      # (C4_N=48: the same comparison for 33..63 states)
 A = metastable_matrix(n, rng); pi = stationary(A)
 mu, sig = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
 obs = torch.empty(K * T, dtype=torch.float64, device=dev)
