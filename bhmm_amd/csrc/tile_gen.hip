@@ -63,7 +63,10 @@ int launch_fwd(bhmm_ctx *c, const WideModel &m)
     lds_poison(c->stream);
     const Segs sg = wide_segs_pub(c, 1);
     const TilePlan tp{c->d_tile_seg[1].p, c->w_ntiles[1]};
-    hipLaunchKernelGGL((k_tile_fwd<NT, KIND, false, false>), dim3(tp.ntiles), dim3(tile_threads<false>()), 0,
+    // up to 96 states the forward kernel fits the eight-wavefront form (matrix + stream wavefronts, 225
+    // registers); the backward kernel does not (it would spill 440 registers), nor does either at 128
+    constexpr bool FWD_SPLIT = true;
+    hipLaunchKernelGGL((k_tile_fwd<NT, KIND, false, FWD_SPLIT>), dim3(tp.ntiles), dim3(tile_threads<FWD_SPLIT>()), 0,
                        c->stream, m, (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
                        c->d_alpha_rm.p, c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p,
                        c->d_specres.p, (unsigned long long *)nullptr);
