@@ -101,9 +101,24 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
                        c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
                        c->d_gW.p, (unsigned long long *)nullptr);
     BHMM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_gen_xi_gemm, dim3(tiles * tiles, nsplit), dim3(256), 0, c->stream,
-                       (const double *)c->d_alpha_rm.p, (const double *)c->d_gW.p, c->total, n, nsplit,
-                       c->d_gxipart.p);
+    // (NT row tiles: 5 .. 8 for 65 .. 128 states)
+    switch ((n + 15) / 16) {
+    case 5:
+        hipLaunchKernelGGL((k_gen_xi_gemm_rows<5>), dim3(nsplit), dim3(320), 0, c->stream, (const double *)c->d_alpha_rm.p,
+                           (const double *)c->d_gW.p, c->total, n, nsplit, c->d_gxipart.p);
+        break;
+    case 6:
+        hipLaunchKernelGGL((k_gen_xi_gemm_rows<6>), dim3(nsplit), dim3(384), 0, c->stream, (const double *)c->d_alpha_rm.p,
+                           (const double *)c->d_gW.p, c->total, n, nsplit, c->d_gxipart.p);
+        break;
+    case 7:
+        hipLaunchKernelGGL((k_gen_xi_gemm_rows<7>), dim3(nsplit), dim3(448), 0, c->stream, (const double *)c->d_alpha_rm.p,
+                           (const double *)c->d_gW.p, c->total, n, nsplit, c->d_gxipart.p);
+        break;
+    default:
+        hipLaunchKernelGGL((k_gen_xi_gemm_rows<8>), dim3(nsplit), dim3(512), 0, c->stream, (const double *)c->d_alpha_rm.p,
+                           (const double *)c->d_gW.p, c->total, n, nsplit, c->d_gxipart.p);
+    }
     const int64_t nfin = (int64_t)n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0) +
                          (KIND == EMIT_DISC ? (int64_t)n * c->M : 0) + n + 1;
     hipLaunchKernelGGL((k_tile_finalize_xig<KIND>), dim3((unsigned)nfin), dim3(64), 0, c->stream, m, c->K, tp.ntiles,
