@@ -87,9 +87,8 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
     const Segs sg = wide_segs_pub(c, 1);
     const TilePlan tp{c->d_tile_segb[1].p, c->w_ntilesb[1]};
     const int n = c->n;
-    const int tiles = (n + 31) / 32;
-    const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>({4096 / ((int64_t)tiles * tiles) + 1,
-                                                                    (c->total + 63) / 64, (int64_t)256}));
+    // time slabs of the xi GEMM: one workgroup of NT wavefronts each; four per compute unit hide the loads
+    const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((c->total + 63) / 64, (int64_t)c->num_simd));
     int rc;
     if ((rc = c->d_gW.ensure((size_t)c->total * n)) || (rc = c->d_gxipart.ensure((size_t)nsplit * n * n)))
         return rc;
