@@ -495,6 +495,18 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
                 *reinterpret_cast<tile_d2 *>(dst + e) = *reinterpret_cast<const tile_d2 *>(X + e);
             return;
         }
+        if (!FULL && rs >= g2 && rs < g3) { // (the same with padded columns: pairs where both states exist)
+            typedef double tile_d2u __attribute__((ext_vector_type(2), aligned(8)));
+            double *dst = alpha_rm + s_abase + (int64_t)rs * n;
+#pragma unroll
+            for (int e = 0; e < SPL; e += 2) {
+                if (sch + e + 1 < n)
+                    *reinterpret_cast<tile_d2u *>(dst + e) = *reinterpret_cast<const tile_d2 *>(X + e);
+                else if (sch + e < n)
+                    dst[e] = X[e];
+            }
+            return;
+        }
         if (rs < 0 || rs >= s_nst)
             return;
         double *dst = nullptr;
