@@ -243,6 +243,103 @@ __global__ __launch_bounds__(256, WPS) void k_tile_fwd(const double *__restrict_
     }
 }
 
+// Two tiles per workgroup, advanced alternately by the same four wavefronts (explicit "ping-pong"): while the
+// matrix instructions of one tile run, the operands of the other tile's next product -- written one half-step
+// earlier -- are already on their way from LDS, so the exchange of a tile hides behind the other tile's chain.
+// A's block in registers is shared by both tiles.  No emission (p = 1): what the recursion alone costs, to be
+// compared with v4.
+template <int N>
+__global__ __launch_bounds__(256, 1) void k_tile_fwd_pp(const double *__restrict__ A, int T, int nsteps,
+                                                        double *__restrict__ alpha)
+{
+    constexpr int KK = N / 4;
+    constexpr int PX = N + 2;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sX = smem;                                            // [tile][buffer][16 * PX]
+    int *sE = reinterpret_cast<int *>(sX + 4 * 16 * PX);          // [tile][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    double Breg[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+        Breg[kk] = A[(4 * kk + q) * N + 16 * w + s];
+    for (int e = tid; e < 4 * 16 * PX; e += 256)
+        sX[e] = 1.0 / N;
+    for (int e = tid; e < 128; e += 256)
+        sE[e] = 0;
+    const int j = 16 * w + s;
+    int xw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        xw[r] = prow(q + 4 * r) * PX;
+    const int xr = prow(s) * PX + q;
+    __syncthreads();
+    double av[2][KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+        av[0][kk] = sX[xr + 4 * kk]; // tile 0, buffer 0
+    int eP[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int tb = 0; tb < nsteps; tb += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+                // operands of the OTHER tile's next product (tile 1: this step; tile 0: the next step)
+                {
+                    const int ob = tile == 0 ? (u & 1) : ((u + 1) & 1);
+                    const double *Xo = sX + ((tile ^ 1) * 2 + ob) * 16 * PX;
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk)
+                        av[tile ^ 1][kk] = Xo[xr + 4 * kk];
+                }
+                d4 acc;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tile][kk], Breg[kk], kk == 0 ? d4{0.0, 0.0, 0.0, 0.0} : acc, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, KK, 0); // the LDS reads first
+                __builtin_amdgcn_sched_group_barrier(0x008, KK, 0); // then the matrix instructions
+                double *Xn = sX + (tile * 2 + ((u & 1) ^ 1)) * 16 * PX;
+                int *sEt = sE + 64 * tile;
+                int E[4] = {0, 0, 0, 0};
+                if (u == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rho = q + 4 * r;
+                        E[r] = max(max(sEt[rho], sEt[16 + rho]), max(sEt[32 + rho], sEt[48 + rho]));
+                        eP[tile][r] += E[r];
+                    }
+                }
+                int pm[4] = {-(1 << 28), -(1 << 28), -(1 << 28), -(1 << 28)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = acc[r];
+                    if (u == 3)
+                        v = ldexp(v, -E[r]);
+                    Xn[xw[r] + j] = v;
+                    if (u == 2)
+                        pm[r] = max(pm[r], v > 0.0 ? exponent_of(v) : -(1 << 28));
+                }
+                if (u == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = row16_max(pm[r]);
+                        if (s == 0)
+                            sEt[16 * w + q + 4 * r] = m;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = ((int64_t)blockIdx.x * 2 + tile) * 16 + q + 4 * r;
+            alpha[row * (int64_t)T * N + j] = sX[(tile * 2 + (nsteps & 1)) * 16 * PX + xw[r] + j] + eP[tile][r];
+        }
+}
+
 // naive reference: one workgroup of N threads per row, normalised every step
 template <int N>
 __global__ void k_ref_fwd(const double *A, const double *mu, const double *sig, const double *obs, int T,
@@ -400,6 +497,43 @@ int main(int argc, char **argv)
         run<N, 2, 2>("v2 emission before barrier", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
         run<N, 3, 2>("v3 emission between mfma", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, ref, refrows);
         run<N, 4, 2>("v4 no emission", tiles, T, nsteps, dA, dmu, dga, dgb, gmg, dobs, dalpha, 0 ? ref : ref, 0);
+        {   // two tiles per workgroup, alternated explicitly: tiles / 2 workgroups
+            constexpr int PX = N + 2;
+            const size_t sm = ((size_t)4 * 16 * PX) * sizeof(double) + 128 * sizeof(int);
+            auto kern = k_tile_fwd_pp<N>;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0));
+            CK(hipEventCreate(&e1));
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL(kern, dim3(tiles / 2), dim3(256), sm, 0, dA, T, nsteps, dalpha);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best = fminf(best, ms);
+            }
+            CK(hipGetLastError());
+            // the same rows through v4 (one tile per workgroup) for the comparison of the results
+            std::vector<double> a((size_t)64 * N), b((size_t)64 * N);
+            for (int r = 0; r < 64; ++r)
+                CK(hipMemcpy(a.data() + (size_t)r * N, dalpha + (size_t)r * T * N, N * sizeof(double), hipMemcpyDeviceToHost));
+            auto k4 = k_tile_fwd<N, 4, 2>;
+            const size_t sm4 = ((size_t)2 * 16 * PX) * sizeof(double) + 64 * sizeof(int);
+            hipLaunchKernelGGL(k4, dim3(4), dim3(256), sm4, 0, dA, dmu, dga, dgb, gmg, dobs, T, nsteps, dalpha, 0, (unsigned long long *)nullptr);
+            CK(hipDeviceSynchronize());
+            for (int r = 0; r < 64; ++r)
+                CK(hipMemcpy(b.data() + (size_t)r * N, dalpha + (size_t)r * T * N, N * sizeof(double), hipMemcpyDeviceToHost));
+            double md = 0.0;
+            for (size_t e = 0; e < a.size(); ++e)
+                md = fmax(md, fabs(a[e] - b[e]) / fmax(fabs(b[e]), 1e-300));
+            const double rowsteps = (double)tiles * 16 * nsteps;
+            printf("%-28s N=%d tiles=%d steps=%d: %.3f ms (no store)  %.1f ns per step of the %d workgroups  %.2f TFLOP/s  "
+                   "final vectors vs v4: %.2e\n", "v5 two tiles per workgroup", N, tiles, nsteps, best, 1e6 * best / nsteps, tiles / 2,
+                   2.0 * N * N * rowsteps / (best * 1e-3) / 1e12, md);
+        }
     }
     return 0;
 }
