@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Static check of the hand-written DPP instructions (wide_kernels.hpp) in the compiled code.
+"""Static check of the hand-written DPP instructions (wide_kernels.hpp, path_kernels.hpp, gen_kernels.hpp) in the
+compiled code.
 
 A DPP read of a VGPR needs two wait states after a VALU write of that VGPR (LLVM
 GCNHazardRecognizer::checkDPPHazards, DppVgprWaitStates = 2).  The compiler inserts them for its
@@ -9,7 +10,7 @@ every row group.  This script re-derives that property from the assembly: for ev
 v_fmac_f64_dpp it walks back until two wait states have passed and fails if a VALU instruction
 in that window writes the DPP source register (or if control flow joins inside the window).
 
-    python tools/check_dpp_hazard.py            # compiles bhmm_amd/csrc/wide_api.hip to assembly
+    python tools/check_dpp_hazard.py            # compiles wide_api.hip, path_api.hip, gen_api.hip to assembly
     python tools/check_dpp_hazard.py file.s ... # checks given assembly files
 """
 import os
@@ -71,12 +72,15 @@ def main():
     tmp = None
     if not files:
         tmp = tempfile.mkdtemp(prefix='dpphaz')
-        out = os.path.join(tmp, 'wide_api.s')
-        cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics',
-               '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'bhmm_amd', 'csrc'),
-               '--cuda-device-only', '-S', os.path.join(ROOT, 'bhmm_amd', 'csrc', 'wide_api.hip'), '-o', out]
-        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
-        files = [out]
+        # every translation unit with inline-assembly DPP FMAs: the 64-lane E-step kernels (wide_api), the
+        # segment-parallel Viterbi passes for 9..64 states (path_api) and for 65..128 states (gen_api)
+        for tu, flags in (('wide_api', []), ('path_api', ['-ffp-contract=off']), ('gen_api', ['-ffp-contract=off'])):
+            out = os.path.join(tmp, tu + '.s')
+            cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics'] + flags + [
+                   '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'bhmm_amd', 'csrc'),
+                   '--cuda-device-only', '-S', os.path.join(ROOT, 'bhmm_amd', 'csrc', tu + '.hip'), '-o', out]
+            subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+            files.append(out)
     total, allbad = 0, []
     for f in files:
         n, bad = check(f)
