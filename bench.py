@@ -4,29 +4,31 @@
 Metric (BASELINE.json): timesteps/s of one full E-step (fused emission probabilities +
 scaled forward + backward + gamma / xi / emission sufficient statistics), whole job.
 One "step" of this benchmark = one E-step over the whole resident batch, from "model handed
-to the engine" to "reduced statistics on the host".
+to the engine" to "reduced statistics on the host" -- the call sequence of
+bhmm/estimators/maximum_likelihood.py:249-265 plus the sums of :271-282.
 
-Workload at N GPUs: BASELINE.json configs[1] per GPU -- 8-state Gaussian HMM,
-256 trajectories x 1e5 time steps of synthetic observations (weak scaling: every rank holds
-its own 256 trajectories; the packed sufficient statistics are all-reduced over RCCL).
+Workload (`value`, at every N): BASELINE.json configs[2], the shape the metric and the north-star
+target are quoted on -- 8-state discrete-output HMM (M = 64 symbols), 1024 trajectories x 1e6 time
+steps IN TOTAL.  One MI355X holds it (4.1 GB of observations, 16 GB of workspace); at N GPUs it is
+STRONG-scaled: rank r holds trajectories r*1024/N .. of the same global set (drawn on the device by
+global index, so every N sees the same data and the summed log-likelihood must reproduce the
+committed N = 1 value), and the packed sufficient statistics are all-reduced over RCCL, once per step.
 
-    python bench.py --gpus 1 --steps 200 --warmup 50    # the defaults (steady state)
+    python bench.py --gpus 1 --steps 200 --warmup 50    # the defaults
     python bench.py --gpus N ...        # WORLD_SIZE unset: starts N ranks itself (torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-At N = 1 the same JSON line also carries `cpu_baseline` (the reference's own C kernels on one
-core, plus `all_cores`), and `secondary`: the other BASELINE configs on the same GPU -- first of
-all configs[2] on ONE GPU (8-state discrete, 1024 x 1e6: the north-star target shape, with its
-own CPU figure and the >= 50x check), then Viterbi and the Gibbs sweep at the configs[1] shape,
-configs[3] (64 states), and the WHOLE iterations the estimator classes run: one EM iteration
-(E-step + native M-step) and one Gibbs sweep (path step + parameter draws + model update).
+The JSON line carries, for THAT workload, `roofline` (algorithmic bytes of SURVEY.md 8(d), 136 B per
+time step, over the sweep kernels' duration by HIP events; PMC traffic and issue rate from the offline
+passes named in `traffic_source`) and `cpu_baseline` (the reference's own C kernels on one core on a
+bounded sample of the same trajectories, plus `all_cores`; rank 0, also at N > 1).
 
-At N > 1 `secondary` holds the two configs BASELINE quotes on 8 GPUs, run on all ranks:
-configs[2] STRONG-scaled (1024 / N trajectories x 1e6 per rank; the trajectories are drawn on the
-device by global index, so every N sees the same data and the summed log-likelihood is checked
-against the committed N = 1 value) and the configs[4] chain (whole Gibbs sweeps of
-BayesianHMMSampler: sharded path step, one all-reduce, parameter draws on every rank).
+At N = 1 the line additionally carries `configs1_gaussian` -- BASELINE configs[1] (8-state Gaussian,
+256 x 1e5), the headline of rounds 1-4, with its own roofline and CPU figure so that series
+continues -- `configs3_64_states`, `more_than_64_states`, and `secondary` (Viterbi and the Gibbs
+path step at the configs[1] shape, whole EM iterations and whole Gibbs sweeps, host side included).
+At N > 1 `secondary` holds the whole EM iterations / Gibbs sweeps of the estimator classes, sharded.
 """
 import argparse
 import json
@@ -230,23 +232,15 @@ def timeit(fn, reps, sync, batches=1):
 
 
 # ---------------------------------------------------------------------------------------
-# secondary measurements (N = 1): the other BASELINE configs on the same GPU
+# what the measurements need to know about the job
 # ---------------------------------------------------------------------------------------
-# log-likelihood of the configs[2] evaluation model on the default workload (1024 x 1e6, seed 3000),
-# measured at N = 1 (profiles/r03): every N must reproduce it, the trajectories being drawn by
-# GLOBAL index.  None = not recorded for this shape.
-C3_LOGLIK_N1 = {(1024, 1000000): -4043229364.929859}
-# ... and its one-GPU E-step time (ms), the reference point of `strong_scaling` at N > 1 (BENCH_r03: 18.36)
-C3_MS_N1 = {(1024, 1000000): 18.36}
-
-
 class Ranks(object):
     """What the secondary measurements need to know about the job."""
 
-    def __init__(self, torch, dist, world, rank, local, dev, backend, distributed):
+    def __init__(self, torch, dist, world, rank, local, dev, backend, distributed, stream=None):
         self.torch, self.dist = torch, dist
         self.world, self.rank, self.local, self.dev = world, rank, local, dev
-        self.backend, self.distributed = backend, distributed
+        self.backend, self.distributed, self.stream = backend, distributed, stream
 
     def fence(self):
         self.torch.cuda.synchronize(self.dev)
@@ -274,95 +268,235 @@ class Ranks(object):
         return h.numpy()
 
 
-def secondary_c3(rk, args):
-    """configs[2]: 8-state discrete (M = 64), 1024 x 1e6 -- the north-star target shape -- on ONE
-    GPU, or STRONG-scaled over the ranks (1024 / N trajectories per rank, statistics all-reduced).
-    Observations are drawn on the device by global trajectory index."""
-    from bhmm_amd.engine import Engine, synth_observations
-    torch, dev, local = rk.torch, rk.dev, rk.local
+
+# ---------------------------------------------------------------------------------------
+# the two E-step workloads of the line
+# ---------------------------------------------------------------------------------------
+# log-likelihood of the configs[2] evaluation model on the default workload (1024 x 1e6, seed 3000),
+# measured at N = 1 (profiles/r03): every N must reproduce it, the trajectories being drawn by
+# GLOBAL index.  Other shapes: not recorded.
+C2_LOGLIK_N1 = {(1024, 1000000): -4043229364.929859}
+
+
+class Workload(object):
+    """One E-step workload: the generating model (data), the model the E-step is evaluated with,
+    the shape, and the algorithmic bytes per time step of SURVEY.md 8(d)."""
+
+    def __init__(self, key, name, kind, n, M, K, T, seed, gen, margs, b_alg, kernel):
+        self.key, self.name, self.kind, self.n, self.M = key, name, kind, n, M
+        self.K, self.T, self.seed, self.gen, self.margs = K, T, seed, gen, margs
+        self.b_alg, self.kernel = b_alg, kernel
+
+
+def workload_configs2(K, T, n=NSTATES, M=64):
+    """BASELINE configs[2]: 8-state discrete-output HMM, M = 64 symbols (M is this
+    build's choice, BASELINE leaves it open), 1024 trajectories x 1e6 steps."""
     rng = np.random.default_rng(3000)
-    n, M, K, T = 8, 64, args.c3_ntraj, args.c3_length
-    assert K % rk.world == 0, "configs[2]: %d trajectories do not split over %d ranks" % (K, rk.world)
-    Kloc = K // rk.world
     A = metastable_matrix(n, rng)
     pi = stationary(A)
     B = rng.dirichlet(np.ones(M), size=n)
-    A_eval, B_eval = 0.9 * A + 0.1 / n, 0.8 * B + 0.2 / M
-    obs = torch.empty(Kloc * T, dtype=torch.int32, device=dev)
-    t0 = time.perf_counter()
-    synth_observations("discrete", obs.data_ptr(), A, pi, B, None, Kloc, T, seed=3000, device=local,
-                       first_traj=rk.rank * Kloc)
-    t_gen = time.perf_counter() - t0
-    eng = Engine(local)
-    eng.set_observations_device("discrete", obs.data_ptr(), np.arange(Kloc + 1, dtype=np.int64) * T,
-                                n, nsymbols=M)
-    stats = torch.empty(eng.stats_size, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize(dev)
+    return Workload("configs2", "configs[2]: 8-state discrete HMM (M=%d), %d traj x %d steps" % (M, K, T),
+                    "discrete", n, M, K, T, 3000, (A, pi, B, None),
+                    (0.9 * A + 0.1 / n, pi, 0.8 * B + 0.2 / M, None), 2 * 4 + 16 * n,
+                    "k_estep_light<8,discrete,spec,P1> + k_estep<8,discrete,spec,P2> (the sweep of one E-step)")
 
-    def one():
+
+def workload_configs1(K, T):
+    """BASELINE configs[1]: 8-state Gaussian HMM, 256 trajectories x 1e5 steps."""
+    m = make_c2_model()
+    return Workload("configs1", "configs[1]: 8-state Gaussian HMM, %d traj x %d steps" % (K, T),
+                    "gaussian", NSTATES, 0, K, T, 2000, (m["A"], m["pi"], m["mu"], m["sigma"]),
+                    (m["A_eval"], m["pi"], m["mu_eval"], m["sigma"]), B_ALG_GAUSS,
+                    "k_estep_light<8,gauss,spec,P1> + k_estep<8,gauss,spec,P2> (the sweep of one E-step)")
+
+
+KERNEL_NAMES = ["prescan", "stitch", "fwdbwd", "finalize", "estep_total"]
+
+
+class Series(object):
+    """This rank's share of a workload on its GPU and the timing protocol of the contract on it."""
+
+    def __init__(self, rk, wl, Kloc, first_traj, chunk=0):
+        from bhmm_amd.engine import Engine, synth_observations
+        torch = rk.torch
+        self.rk, self.wl, self.Kloc = rk, wl, Kloc
+        self.obs = torch.empty(Kloc * wl.T, dtype=torch.int32 if wl.kind == "discrete" else torch.float64,
+                               device=rk.dev)
+        t0 = time.perf_counter()
+        # drawn ON THE DEVICE by global trajectory index (bhmm_synth_observations_at): rank r's slice is
+        # exactly what one call for the whole set would have drawn for these trajectories
+        synth_observations(wl.kind, self.obs.data_ptr(), wl.gen[0], wl.gen[1], wl.gen[2], wl.gen[3], Kloc, wl.T,
+                           seed=wl.seed, device=rk.local, first_traj=first_traj)
+        torch.cuda.synchronize(rk.dev)
+        self.synth_seconds = time.perf_counter() - t0
+        # a dedicated (non-default) stream shared by the engine and the collective: the legacy default
+        # stream would serialise against every other stream of the process
+        self.eng = eng = Engine(rk.local, stream=rk.stream.cuda_stream)
+        self.off = np.arange(Kloc + 1, dtype=np.int64) * wl.T
+        eng.set_observations_device(wl.kind, self.obs.data_ptr(), self.off, wl.n, nsymbols=wl.M, chunk=chunk)
+        self.S = eng.stats_size
+        self.stats = torch.zeros(self.S, dtype=torch.float64, device=rk.dev)
+        self.host_stats = torch.zeros(self.S, dtype=torch.float64).pin_memory()
+        self.host_np = self.host_stats.numpy()          # (same memory)
+        self.allreduces = 0
+
+    def one_step(self):
+        """Model in -> reduced statistics of ALL ranks on the host."""
+        rk, eng, m = self.rk, self.eng, self.wl.margs
         if not rk.distributed:
-            return eng.estep(A_eval, pi, B_eval).packed
-        eng.estep_launch(A_eval, pi, B_eval, stats_dev=stats.data_ptr())
-        eng.sync()
-        return rk.sum_stats(stats)
+            # single GPU: the library lands the statistics in pinned host memory itself
+            eng.estep_launch(m[0], m[1], m[2], m[3])
+            eng.estep_fetch_packed(self.host_np)
+            return self.host_stats
+        eng.estep_launch(m[0], m[1], m[2], m[3], stats_dev=self.stats.data_ptr())
+        self.allreduces += 1
+        if rk.backend == "nccl":
+            rk.dist.all_reduce(self.stats)                  # RCCL sum of the packed statistics
+            self.host_stats.copy_(self.stats, non_blocking=True)
+            rk.stream.synchronize()                         # statistics are on the host
+        else:
+            self.host_stats.copy_(self.stats)
+            rk.dist.all_reduce(self.host_stats)
+        return self.host_stats
 
-    one()                                              # measures the warm-up length, verifies
-    rk.fence()
-    t0 = time.perf_counter()
-    for _ in range(args.c3_steps):
-        one()
-    rk.fence()
-    dt = rk.max_over_ranks(time.perf_counter() - t0) / args.c3_steps
-    packed = one()
-    kms = eng.kernel_ms(2)
-    logL_k = eng.estep_fetch_logL() if rk.distributed else eng.estep_fetch().logL_k
-    coll_ms = None
-    if rk.distributed:
+    def run(self, warmup, steps, steady_n):
+        rk, eng = self.rk, self.eng
+        for _ in range(warmup):
+            self.one_step()
+        kern_ms = np.zeros(5)
+        n0 = self.allreduces
         rk.fence()
         t0 = time.perf_counter()
-        for _ in range(20):
-            rk.sum_stats(stats)
-        coll_ms = 1e3 * (time.perf_counter() - t0) / 20
-    r = eng.unpack(packed)
-    np.testing.assert_allclose(r.state_counts.sum(), K * T, rtol=1e-9)
-    np.testing.assert_allclose(r.C.sum(), K * (T - 1), rtol=1e-9)
-    want = C3_LOGLIK_N1.get((K, T))
-    if want is not None:
-        assert abs(r.loglik - want) <= 1e-12 * abs(want), \
-            "configs[2]: log-likelihood %r differs from the N = 1 value %r" % (r.loglik, want)
-    b_alg = 2 * 4 + 16 * n                               # 136 B / step, SURVEY.md 8(d)
-    out = {"config": "configs[2]%s: 8-state discrete HMM (M=64), %d trajectories x %d timesteps, one "
-                     "full E-step%s" % (" on ONE GPU" if rk.world == 1 else " STRONG-scaled over %d GPUs"
-                                        % rk.world, K, T,
-                                        "" if rk.world == 1 else " (%d trajectories per rank, all-reduce of "
-                                        "%d statistics)" % (Kloc, eng.stats_size)),
-           "n_gpus": rk.world, "scaling": "strong",
-           "ms": 1e3 * dt, "timesteps_per_s": K * T / dt, "loglik": r.loglik,
-           "loglik_matches_n1": None if want is None else True,
-           "allreduce_plus_copy_ms": coll_ms,
-           "roofline": {"bound": "hbm", "alg_bytes_per_timestep": b_alg,
-                        "achieved": b_alg * Kloc * T / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": b_alg * Kloc * T / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "kernel_ms": kms, "per": "GPU (rank 0's sweep launches)",
-                        "whole_estep_frac": b_alg * K * T / dt / 1e9 / HBM_PEAK_GBS / rk.world},
-           "chunk_len": eng.chunk_len, "chunks": eng.num_chunks,
-           "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")},
-           "synth_seconds": t_gen}
-    if rk.world == 1 and not args.no_cpu:
-        kc = min(args.c3_cpu_traj, K)
-        sample = obs[: kc * T].cpu().numpy().reshape(kc, T)
-        cb, ll = cpu_baseline("discrete", A_eval, pi, B_eval, None, sample, threads=1)
-        rel = float(np.max(np.abs((logL_k[:kc] - np.array(ll)) / np.array(ll))))
-        assert rel < 1e-9, "configs[2]: GPU/CPU log-likelihood mismatch %g" % rel
-        cb["loglik_rel_diff_vs_gpu"] = rel
-        out["cpu_baseline"] = cb
-        out["speedup_vs_1core"] = out["timesteps_per_s"] / cb["value"]
-        out["target_50x_met"] = bool(out["speedup_vs_1core"] >= 50.0)
-        assert out["target_50x_met"], "north-star target (>= 50x the reference CPU path) missed"
-    eng.close()
-    del obs, stats
-    torch.cuda.empty_cache()
-    return out
+        for _ in range(steps):
+            self.one_step()                         # returns with the results on the host: events complete
+            if rk.distributed:
+                eng.sync()                          # (no fetch on this path: read the events here)
+            kern_ms += eng.kernel_ms_all()
+        rk.fence()
+        self.elapsed = rk.max_over_ranks(time.perf_counter() - t0)
+        self.allreduces_per_step = (self.allreduces - n0) / float(max(steps, 1))
+        self.kern_ms = kern_ms / max(steps, 1)
+        # a second window right behind the requested steps, untimed by the contract: what an EM loop of
+        # hundreds of iterations sees once the GPU's power management has settled (DESIGN.md section 7)
+        steady = []
+        for _ in range(steady_n):
+            t1 = time.perf_counter()
+            self.one_step()
+            steady.append(time.perf_counter() - t1)
+        self.steady_ms = 1e3 * float(np.median(steady[len(steady) // 2:])) if steady else None
+        self.res = eng.unpack(self.host_np.copy())
+        assert np.isfinite(self.res.loglik)
+        # sanity of the reduced statistics: every step of every rank carries unit gamma mass
+        total = rk.world * self.Kloc * self.wl.T
+        np.testing.assert_allclose(self.res.state_counts.sum(), total, rtol=1e-9)
+        np.testing.assert_allclose(self.res.C.sum(), total - rk.world * self.Kloc, rtol=1e-9)
+        return self
+
+    def logL_k(self):
+        """Per-trajectory log-likelihoods of this rank's shard (one more E-step)."""
+        m = self.wl.margs
+        if not self.rk.distributed:
+            return self.eng.estep(m[0], m[1], m[2], m[3]).logL_k
+        self.eng.estep_launch(m[0], m[1], m[2], m[3], stats_dev=self.stats.data_ptr())
+        return self.eng.estep_fetch_logL()
+
+    def collective_ms(self, reps=20):
+        """The all-reduce + copy of the packed statistics alone."""
+        rk = self.rk
+        if not rk.distributed:
+            return None
+        rk.fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rk.sum_stats(self.stats)
+        return 1e3 * (time.perf_counter() - t0) / reps
+
+    def close(self):
+        self.eng.close()
+        self.obs = self.stats = None
+        self.rk.torch.cuda.empty_cache()
+
+
+def load_traffic(args, key):
+    """Offline PMC figures of one workload's sweep launches (profiles/traffic_current.json, written
+    by tools/profile_r05.sh): HBM bytes per launch pair (separate FETCH_SIZE / WRITE_SIZE passes, the
+    gfx950 correction of MI355X_MICROARCH.md applied) and SQ_INSTS_VALU.  Not re-measured by this run."""
+    tj = args.traffic_json if os.path.isabs(args.traffic_json) else os.path.join(ROOT, args.traffic_json)
+    if not os.path.exists(tj):
+        return None
+    tdoc = json.load(open(tj))
+    ent = tdoc.get("workloads", {}).get(key)
+    if ent is None and key == "configs1" and "traffic_bytes_per_launch" in tdoc:
+        ent = tdoc                                    # (the rounds 1-4 layout: configs[1] at top level)
+    if ent is None:
+        return None
+    ent = dict(ent)
+    ent["file"] = "%s (%s)" % (args.traffic_json, ent.get("source", tdoc.get("source", "source not recorded")))
+    return ent
+
+
+def roofline_block(wl, ser, args, steps_per_s_per_gpu):
+    """algorithmic bytes of this rank's launch pair over its duration by HIP events
+    (recorded on the launch stream inside the library), against the 8 TB/s HBM peak."""
+    Kloc, T, eng = ser.Kloc, wl.T, ser.eng
+    sweep_ms = float(ser.kern_ms[2])
+    alg = wl.b_alg * Kloc * T
+    achieved = alg / (sweep_ms * 1e-3) / 1e9
+    ent = load_traffic(args, wl.key)
+    traffic = valu = rate = src = None
+    if ent is not None and eng.get_option("spec_ok") > 0 and eng.get_option("spec_fail") == 0:
+        shape = ent.get("shape")
+        if shape is None or (int(shape[1]) == T and int(shape[0]) % Kloc == 0 and int(shape[0]) >= Kloc):
+            # measured at N = 1 on the whole set; a shard of it moves that fraction of the bytes
+            share = 1.0 if shape is None else Kloc / float(shape[0])
+            traffic = ent["traffic_bytes_per_launch"] * share
+            if ent.get("valu_wave_insts_per_launch"):
+                valu = ent["valu_wave_insts_per_launch"] * share
+            rate = ent.get("issue_ceiling_insts_per_us_per_simd")
+            src = ent["file"] + ("" if share == 1.0 else " x %g (this rank's share of the trajectories)" % share)
+    return {"bound": "hbm", "kernel": wl.kernel,
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_is_live": False,
+            # the other ceilings, named: HBM bytes the counters saw / time / peak, and vector
+            # instructions issued / what this part issues on 1024 SIMDs in that time
+            "hbm_counter_frac": None if traffic is None else traffic / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "issue_frac": None if not (valu and rate) else valu / (rate * 1024 * sweep_ms * 1e3),
+            "traffic_source": src,
+            "alg_bytes_per_launch": alg, "alg_bytes_per_timestep": wl.b_alg,
+            "sweep_kernel_ms": sweep_ms, "per": "GPU (rank 0's two sweep launches of one E-step)",
+            "whole_estep_frac": wl.b_alg * steps_per_s_per_gpu / 1e9 / HBM_PEAK_GBS}
+
+
+def cpu_legs(wl, ser, ncpu, all_cores=True):
+    """Rank 0: the reference's C kernels on `ncpu` of this rank's trajectories on one core, and (when
+    the host has the memory: every thread materialises pobs, alpha, beta, gamma like the reference)
+    on one OpenMP thread per core.  Asserts GPU/CPU parity of the log-likelihoods in the same run."""
+    T, n = wl.T, wl.n
+    ncpu = max(1, min(ncpu, ser.Kloc))
+    m = wl.margs
+    sample = ser.obs[: ncpu * T].cpu().numpy().reshape(ncpu, T)
+    cb, ll = cpu_baseline(wl.kind, m[0], m[1], m[2], m[3], sample, threads=1)
+    gpu_ll = ser.logL_k()[:ncpu]
+    rel = float(np.max(np.abs((gpu_ll - np.array(ll)) / np.array(ll))))
+    assert rel < 1e-9, "%s: GPU/CPU log-likelihood mismatch %g" % (wl.key, rel)
+    cb["loglik_rel_diff_vs_gpu"] = rel
+    nc = host_cores()
+    if all_cores and nc > 1:
+        per_thread = 4 * T * n * 8 + 64                  # bytes: pobs, alpha, beta, gamma (omp_driver.c)
+        try:
+            import psutil
+            avail = psutil.virtual_memory().available
+        except Exception:
+            avail = 16 << 30
+        threads = int(max(1, min(nc, ser.Kloc, (avail // 3) // per_thread)))
+        if threads > 1:
+            ktot = int(min(ser.Kloc, max(threads, min(ser.Kloc, int(2.5e8 // T)))))   # ~10-15 s of work
+            big = ser.obs[: ktot * T].cpu().numpy().reshape(ktot, T)
+            cba, lla = cpu_baseline(wl.kind, m[0], m[1], m[2], m[3], big, threads=threads)
+            k = min(ncpu, ktot)
+            assert np.allclose(lla[:k], ll[:k], rtol=1e-13)
+            cb["all_cores"] = {k_: cba[k_] for k_ in ("value", "unit", "cores", "sample")}
+    return cb
 
 
 def secondary_whole_iterations(rk, model, args):
@@ -376,7 +510,7 @@ def secondary_whole_iterations(rk, model, args):
     from bhmm_amd.engine import synth_observations
     from bhmm_amd.estimators import _tmatrix
     torch, dev, local = rk.torch, rk.dev, rk.local
-    n, K, T = NSTATES, args.ntraj, args.length
+    n, K, T = NSTATES, args.c1_ntraj, args.c1_length
     buf = torch.empty(K * T, dtype=torch.float64, device=dev)
     synth_observations("gaussian", buf.data_ptr(), model["A"], model["pi"], model["mu"],
                        model["sigma"], K, T, seed=2000, device=local, first_traj=0)
@@ -513,6 +647,7 @@ def secondary_c4(torch, dev, local, args):
            "kernels": "k_tile_fwd / k_tile_bwd (row-batched v_mfma_f64_16x16x4, 16 segments per workgroup)"
                       if eng.get_option("tile") else "k_wide_fwd / k_wide_bwd (one segment per wavefront)",
            "kernel_ms": {"forward": eng.kernel_ms(0), "backward_and_statistics": eng.kernel_ms(2)},
+           "self_checks_fired": int(eng.get_option("wide_trouble")),
            "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")}}
     # the other two passes of the path on this shape: both run over time segments (round 4) and are
     # accepted only as the serial run's result (bitwise boundary vectors / coupled draws)
@@ -590,7 +725,7 @@ def secondary_gen(torch, dev, local, args):
                     "roofline": {"bound": "fp64", "achieved": flops * K * T / dt / 1e12, "peak": 78.6,
                                  "unit": "TFLOP/s", "frac": flops * K * T / dt / 1e12 / 78.6},
                     "tile_kernels": bool(eng.get_option("tile")), "segments": eng.get_option("wide_segments"),
-                    "self_checks_fired": int(eng.get_option("wide_trouble")), "tile_retries": int(eng.get_option("tile_retries")),
+                    "self_checks_fired": int(eng.get_option("wide_trouble")),
                     "tile_reason": int(eng.get_option("tile_reason")),
                     "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")}})
         pdev = torch.empty(K * T, dtype=torch.uint8, device=dev)
@@ -614,21 +749,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--ntraj", type=int, default=256)
-    ap.add_argument("--length", type=int, default=100000)
+    ap.add_argument("--ntraj", type=int, default=1024, help="trajectories of the headline workload, IN TOTAL")
+    ap.add_argument("--length", type=int, default=1000000)
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--cpu-traj", type=int, default=200, help="trajectories in the 1-core CPU baseline")
+    ap.add_argument("--cpu-traj", type=int, default=48,
+                    help="trajectories in the 1-core CPU baseline of the headline (~10 s at 1e6 steps each)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-steady", action="store_true",
                     help="skip the extra steady-state window (profiling runs: the kernel statistics then "
                          "cover exactly the warm-up and timed launches)")
-    ap.add_argument("--c3-ntraj", type=int, default=1024)
-    ap.add_argument("--c3-length", type=int, default=1000000)
-    ap.add_argument("--c3-steps", type=int, default=5)
-    ap.add_argument("--c3-cpu-traj", type=int, default=6)
+    ap.add_argument("--c1-ntraj", type=int, default=256, help="configs[1] (N = 1 secondary): trajectories")
+    ap.add_argument("--c1-length", type=int, default=100000)
+    ap.add_argument("--c1-steps", type=int, default=200)
+    ap.add_argument("--c1-warmup", type=int, default=50)
+    ap.add_argument("--c1-cpu-traj", type=int, default=100)
     ap.add_argument("--traffic-json", default="profiles/traffic_current.json",
-                    help="offline PMC measurement quoted as roofline.traffic (tools/profile_round*.sh)")
+                    help="offline PMC measurements quoted as roofline.traffic (tools/profile_r05.sh)")
     ap.add_argument("--chain-sweeps", type=int, default=20, help="Gibbs sweeps timed per chain variant")
     ap.add_argument("--em-iterations", type=int, default=30, help="whole EM iterations timed")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -648,12 +785,11 @@ def main():
     distributed = launched
 
     K, T = args.ntraj, args.length
-    model = make_c2_model()
-    off = np.arange(K + 1, dtype=np.int64) * T
+    assert K % world == 0, "%d trajectories do not split evenly over %d ranks" % (K, world)
+    Kloc = K // world
 
     import torch
     import torch.distributed as dist
-    from bhmm_amd.engine import Engine, synth_observations
 
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -671,190 +807,111 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    # this rank's trajectories, drawn ON THE DEVICE (bhmm_synth_observations_at): rank r holds
-    # trajectories r*K .. (r+1)*K - 1 of one global set -- no per-rank numpy loop over 1e5 steps
-    obs_dev = torch.empty(K * T, dtype=torch.float64, device=dev)
-    synth_observations("gaussian", obs_dev.data_ptr(), model["A"], model["pi"], model["mu"],
-                       model["sigma"], K, T, seed=2000, device=local, first_traj=rank * K)
-    torch.cuda.synchronize(dev)
-
-    # (the CPU legs run AFTER the GPU timing: tens of seconds of host work between drawing the data
-    # and the timed loop would let the GPU fall back to its idle clocks right before the warm-up steps)
-
-    # a dedicated (non-default) stream shared by the engine and the collective: the legacy default
-    # stream would serialise against every other stream of the process
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    eng = Engine(local, stream=stream.cuda_stream)
-    eng.set_observations_device("gaussian", obs_dev.data_ptr(), off, NSTATES, chunk=args.chunk)
-    S = eng.stats_size
-    stats = torch.zeros(S, dtype=torch.float64, device=dev)
-    host_stats = torch.zeros(S, dtype=torch.float64).pin_memory()
-    host_np = host_stats.numpy()                    # (same memory)
+    rk = Ranks(torch, dist, world, rank, local, dev, backend, distributed, stream)
 
-    def one_step():
-        if not distributed:
-            # single GPU: the library lands the statistics in pinned host memory itself
-            eng.estep_launch(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
-            eng.estep_fetch_packed(host_np)         # reduced statistics, on the host
-            return host_stats
-        eng.estep_launch(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"],
-                         stats_dev=stats.data_ptr())
-        if backend == "nccl":
-            dist.all_reduce(stats)                      # RCCL sum of the packed statistics
-            host_stats.copy_(stats, non_blocking=True)
-            stream.synchronize()                        # statistics are on the host
-        else:
-            host_stats.copy_(stats)
-            dist.all_reduce(host_stats)
-        return host_stats
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        one_step()
-    kern_ms = np.zeros(5)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()                              # returns with the results on the host: events complete
-        if distributed:
-            eng.sync()                          # (no fetch on this path: read the events here)
-        kern_ms += eng.kernel_ms_all()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # ---- the headline: configs[2], strong-scaled --------------------------------------------------
+    # (the CPU legs run AFTER the GPU timing: tens of seconds of host work between drawing the data
+    # and the timed loop would let the GPU fall back to its idle clocks right before the warm-up steps)
+    wl = workload_configs2(K, T)
+    ser = Series(rk, wl, Kloc, rank * Kloc, chunk=args.chunk)
+    ser.run(args.warmup, args.steps, 0 if args.no_steady else 40)
+    elapsed = ser.elapsed
+    res = ser.res
+    want = C2_LOGLIK_N1.get((K, T))
+    if want is not None:
+        assert abs(res.loglik - want) <= 1e-12 * abs(want), \
+            "configs[2]: log-likelihood %r differs from the committed N = 1 value %r" % (res.loglik, want)
+    # every rank must hold the same reduced statistics (one all-reduce, nothing rank-dependent after it)
+    same = True
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    # a second, untimed-by-the-contract window right behind the requested steps: what an EM loop of
-    # hundreds of iterations sees once the GPU's power management has settled
-    steady = []
-    for _ in range(0 if args.no_steady else 100):
-        t1 = time.perf_counter()
-        one_step()
-        steady.append(time.perf_counter() - t1)
-    steady_ms = 1e3 * float(np.median(steady[50:])) if steady else None
-    res = eng.unpack(host_stats.numpy().copy())
-    assert np.isfinite(res.loglik)
-
-    # CPU legs (rank 0, N = 1 only) on host copies of the same trajectories
-    cb = cb_all = ll_cpu = None
-    if world == 1 and not args.no_cpu:
-        obs_host = obs_dev.cpu().numpy().reshape(K, T)
-        mcpu = (model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
-        cb, ll_cpu = cpu_baseline("gaussian", *mcpu, obs_host[: args.cpu_traj], threads=1)
-        nc = host_cores()
-        if nc > 1:
-            cb_all, ll_all = cpu_baseline("gaussian", *mcpu, obs_host, threads=nc)
-            assert np.allclose(ll_all[: args.cpu_traj], ll_cpu, rtol=1e-13)
-        del obs_host
-    # sanity of the reduced statistics: every step of every rank carries unit gamma mass
-    np.testing.assert_allclose(res.state_counts.sum(), world * K * T, rtol=1e-9)
+        mine = torch.from_numpy(ser.host_np.copy())
+        if backend == "nccl":
+            mine = mine.to(dev)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(lo, hi))
+        assert same, "the ranks hold different reduced statistics"
+    coll_ms = ser.collective_ms()
+    cb = None
+    if not args.no_cpu:
+        if rank == 0:
+            # at N > 1 a smaller sample: the other ranks wait at the next barrier meanwhile
+            cb = cpu_legs(wl, ser, args.cpu_traj if world == 1 else min(args.cpu_traj, 8), all_cores=(world == 1))
+        rk.fence()
 
     out = None
     if rank == 0:
-        steps_total = world * K * T
-        value = steps_total * args.steps / elapsed
-        kern_ms /= args.steps
-        names = ["prescan", "stitch", "fwdbwd", "finalize", "estep_total"]
-        dom = int(np.argmax(kern_ms[:4]))
-        # algorithmic bytes of the canonical two-pass algorithm: the streaming
-        # kernel k_estep carries them (obs twice, alpha written once and read once).
-        alg_bytes_launch = B_ALG_GAUSS * K * T
-        achieved = alg_bytes_launch / (kern_ms[2] * 1e-3) / 1e9
-        traffic, traffic_file, valu_insts, issue_rate = None, None, None, None
-        tj = args.traffic_json if os.path.isabs(args.traffic_json) else os.path.join(ROOT, args.traffic_json)
-        if os.path.exists(tj) and (K, T) == (256, 100000):
-            # HBM bytes of the sweep launches of one E-step from the PMC counters: collected
-            # OFFLINE with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction
-            # applied), same workload and kernels -- not re-measured by this run.  The file is
-            # named by --traffic-json (default: profiles/traffic_current.json, a copy of the
-            # latest round's measurement; its "source" field says which)
-            if eng.get_option("spec_ok") > 0 and eng.get_option("spec_fail") == 0:
-                tdoc = json.load(open(tj))
-                traffic = tdoc["traffic_bytes_per_launch"]
-                valu_insts = tdoc.get("valu_wave_insts_per_launch")
-                issue_rate = tdoc.get("issue_ceiling_insts_per_us_per_simd")
-                traffic_file = "%s (%s)" % (args.traffic_json, tdoc.get("source", "source not recorded"))
+        value = K * T * args.steps / elapsed
+        eng = ser.eng
         out = {
             "metric": "timesteps/sec forward-backward (whole node), N=8 states",
             "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "steady_state_ms": steady_ms,
-            "timing_note": "ms_per_step covers exactly the requested steps; with few warm-up steps "
-                           "they can fall into the GPU's power ramp after idling (first ~30 E-steps "
-                           "~10 % slower, DESIGN.md section 7; the only GPU work before them is drawing "
-                           "the data and the one-off calibration of the engine, the CPU legs run "
-                           "afterwards); steady_state_ms is the median of steps 51-100 of an extra "
-                           "window right behind them",
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "steady_state_ms": ser.steady_ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 8-state Gaussian HMM, %d trajectories x %d "
-                                   "timesteps per GPU, one full E-step" % (K, T),
-                       "trajectories_per_gpu": K, "timesteps_per_trajectory": T,
-                       "chunk_len": eng.chunk_len, "chunks": eng.num_chunks,
+            "config": {"workload": "%s in total, %d per GPU, one full E-step" % (wl.name, Kloc),
+                       "trajectories_total": K, "trajectories_per_gpu": Kloc, "timesteps_per_trajectory": T,
+                       "first_trajectory_of_rank": "rank r holds trajectories r*%d .. (r+1)*%d-1 of ONE global set" % (Kloc, Kloc),
+                       "symbols": wl.M, "chunk_len": eng.chunk_len, "chunks": eng.num_chunks,
                        "speculative_boundaries": {k: eng.get_option(k) for k in
                                                   ("spec_enabled", "spec_W", "spec_ok", "spec_fail",
                                                    "spec_last_dev", "careful")},
                        "collective": ("RCCL all-reduce" if backend == "nccl" else
                                       "gloo all-reduce (--oversubscribe test aid: ranks share GPUs)")
                                      if distributed else "none (one process)",
+                       "allreduces_per_step": ser.allreduces_per_step,
                        "parallelism": "trajectories sharded over %d GPU(s), all-reduce of "
-                                      "%d statistics" % (world, S)},
-            "roofline": {"bound": "hbm", "kernel": "k_estep_light<8,gauss,spec,P1> + k_estep<8,gauss,spec,P2> (the sweep of one E-step)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_is_live": False,
-                         # the binding ceilings, named: HBM bytes the counters saw / time / peak, and
-                         # vector instructions issued / what this part issues on 1024 SIMDs in that time
-                         "hbm_counter_frac": None if traffic is None else
-                         traffic / (kern_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "issue_frac": None if not (valu_insts and issue_rate) else
-                         valu_insts / (issue_rate * 1024 * kern_ms[2] * 1e3),
-                         "issue_note": None if not (valu_insts and issue_rate) else
-                         "SQ_INSTS_VALU of the two sweep launches (offline PMC pass) over the measured issue "
-                         "ceiling of a chip-wide fp64 stream (tools/ubench/issue_rate.hip)",
-                         "traffic_source": ("offline rocprofv3 PMC passes on the same workload, "
-                                            "%s" % traffic_file) if traffic_file else None,
-                         "alg_bytes_per_launch": alg_bytes_launch,
-                         "alg_bytes_per_timestep": B_ALG_GAUSS,
-                         "whole_estep_frac": B_ALG_GAUSS * value / world / 1e9 / HBM_PEAK_GBS},
-            "kernel_ms": {names[i]: float(kern_ms[i]) for i in range(5)},
-            "dominant_kernel": names[dom],
+                                      "%d statistics" % (world, ser.S)},
+            "roofline": roofline_block(wl, ser, args, value / world),
+            "kernel_ms": {KERNEL_NAMES[i]: float(ser.kern_ms[i]) for i in range(5)},
+            "dominant_kernel": KERNEL_NAMES[int(np.argmax(ser.kern_ms[:4]))],
+            "loglik": res.loglik, "loglik_matches_n1": None if want is None else True,
+            "statistics_identical_on_all_ranks": same if distributed else None,
+            "allreduce_plus_copy_ms": coll_ms,
+            "synth_seconds": ser.synth_seconds,
+            "timing_note": "ms_per_step covers exactly the requested steps, max over ranks, between barriers; "
+                           "steady_state_ms is the median of the last 20 steps of an extra 40-step window "
+                           "right behind them (DESIGN.md section 7)",
         }
         if cb is not None:
-            # parity on the very same trajectories, asserted in the same run
-            eng2 = Engine(local, stream=stream.cuda_stream)
-            sub = obs_dev[: args.cpu_traj * T]
-            eng2.set_observations_device("gaussian", sub.data_ptr(),
-                                         off[: args.cpu_traj + 1], NSTATES)
-            r2 = eng2.estep(model["A_eval"], model["pi"], model["mu_eval"], model["sigma"])
-            rel = abs(r2.loglik - sum(ll_cpu)) / abs(sum(ll_cpu))
-            assert rel < 1e-9, "GPU/CPU log-likelihood mismatch %g" % rel
-            cb["loglik_rel_diff_vs_gpu"] = rel
-            eng2.close()
-            if cb_all is not None:
-                cb["all_cores"] = {k: cb_all[k] for k in ("value", "unit", "cores", "sample")}
             out["cpu_baseline"] = cb
+            out["speedup_vs_1core"] = value / cb["value"]
+            out["target_50x_met"] = bool(world > 1 or out["speedup_vs_1core"] >= 50.0)
+            if world == 1:
+                assert out["target_50x_met"], "north-star target (>= 50x the reference CPU path) missed"
+    ser.close()
+    del ser
+
     if not args.no_secondary:
         # the secondary measurements run on ALL ranks (their collectives need everyone)
-        rk = Ranks(torch, dist, world, rank, local, dev, backend, distributed)
         sec = []
+        c1 = c4 = gen = None
+        model = make_c2_model()
         if world == 1:
-            sec = secondary_c2_paths(torch, dev, local, eng, model, K, T, args)
-        eng.close()
-        del obs_dev, stats
-        torch.cuda.empty_cache()
-        c3 = secondary_c3(rk, args)
-        sec.insert(0, c3)
-        c4 = gen = None
-        if world == 1:
+            # configs[1]: the headline of rounds 1-4, same protocol, its own roofline and CPU figure
+            w1 = workload_configs1(args.c1_ntraj, args.c1_length)
+            s1 = Series(rk, w1, w1.K, 0)
+            s1.run(args.c1_warmup, args.c1_steps, 0 if args.no_steady else 100)
+            v1 = w1.K * w1.T * args.c1_steps / s1.elapsed
+            c1 = {"config": w1.name + ", one full E-step, one GPU", "value": v1, "unit": "timesteps/s",
+                  "steps": args.c1_steps, "warmup": args.c1_warmup, "ms_per_step": 1e3 * s1.elapsed / args.c1_steps,
+                  "steady_state_ms": s1.steady_ms, "roofline": roofline_block(w1, s1, args, v1),
+                  "kernel_ms": {KERNEL_NAMES[i]: float(s1.kern_ms[i]) for i in range(5)},
+                  "chunk_len": s1.eng.chunk_len, "chunks": s1.eng.num_chunks,
+                  "speculative_boundaries": {k: s1.eng.get_option(k) for k in
+                                             ("spec_W", "spec_ok", "spec_fail", "spec_last_dev", "careful")},
+                  "note": "the `value` of BENCH_r01..r04 (there with the driver's --warmup 5 --steps 20 "
+                          "right after start-up: 0.96-1.02 ms)"}
+            if not args.no_cpu:
+                c1["cpu_baseline"] = cpu_legs(w1, s1, args.c1_cpu_traj)
+                c1["speedup_vs_1core"] = v1 / c1["cpu_baseline"]["value"]
+            sec = secondary_c2_paths(torch, dev, local, s1.eng, model, w1.K, w1.T, args)
+            s1.close()
+            del s1
             c4 = secondary_c4(torch, dev, local, args)
             sec.append(c4)
             gen = secondary_gen(torch, dev, local, args)
@@ -862,31 +919,19 @@ def main():
         sec.extend(secondary_whole_iterations(rk, model, args))
         if out is not None:
             out["secondary"] = sec
-            # what a reader of the line must not have to dig out of `secondary`:
-            # the north-star target shape (configs[2], 1024 x 1e6 x 8 states) ...
-            ts = {k: c3.get(k) for k in ("config", "n_gpus", "scaling", "ms", "timesteps_per_s", "loglik_matches_n1",
-                                         "allreduce_plus_copy_ms", "roofline", "cpu_baseline", "speedup_vs_1core",
-                                         "target_50x_met") if k in c3}
-            out["target_shape"] = ts
-            if world > 1:
-                # ... strong-scaled: the same 1024 x 1e6 steps on N GPUs against the committed one-GPU time
-                n1 = C3_MS_N1.get((args.c3_ntraj, args.c3_length))
-                out["strong_scaling"] = {"config": c3["config"], "value": c3["timesteps_per_s"],
-                                         "unit": "timesteps/s", "ms": c3["ms"], "n_gpus": world,
-                                         "n1_ms_committed": n1,
-                                         "speedup_vs_n1": None if n1 is None else n1 / c3["ms"],
-                                         "efficiency_vs_n1": None if n1 is None else n1 / c3["ms"] / world}
+            if c1 is not None:
+                out["configs1_gaussian"] = c1
             if c4 is not None:
                 out["configs3_64_states"] = {k: c4[k] for k in ("config", "ms", "timesteps_per_s", "roofline",
                                                                 "kernels", "kernel_ms", "segments", "spec", "viterbi",
-                                                                "gibbs_path_step", "whole_em_iteration") if k in c4}
+                                                                "gibbs_path_step", "whole_em_iteration",
+                                                                "self_checks_fired") if k in c4}
             if gen:
-                out["more_than_64_states"] = [{k: g[k] for k in ("config", "ms", "roofline", "tile_kernels", "tile_retries",
+                out["more_than_64_states"] = [{k: g[k] for k in ("config", "ms", "roofline", "tile_kernels", "self_checks_fired",
                                                                  "viterbi", "gibbs_path_step") if k in g}
                                               for g in gen]
     if out is not None:
         print(json.dumps(out))
-    eng.close()
     if distributed:
         dist.destroy_process_group()
 

@@ -1303,7 +1303,7 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     c->vit_W = 0;
     c->pplan[0].nseg = c->pplan[1].nseg = 0;
     c->smp_W = 0;
-    c->tile_retries = 0;
+    c->tile_latched = c->tile_enabled; // (ctx.hpp: one decision per set of observations)
     c->vit_seg_given_up = false;
     c->vit_bad = 0;
     c->vit_explore = true;
@@ -1617,8 +1617,6 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->smp_seg_mismatch;
     else if (n == "sample_rounds")
         *value = c->smp_seg_rounds;
-    else if (n == "tile_retries") // E-steps on the tile kernels that were repeated because a self-check fired
-        *value = c->tile_retries;
     else if (n == "viterbi_rounds") // ... fix-up rounds its last pass needed
         *value = c->vit_seg_rounds;
     else if (n == "viterbi_mismatch") // ... boundaries of its last attempt that were not bit-identical
@@ -1635,6 +1633,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->carry_kappa;
     else if (n == "wide_segments")
         *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) ? c->w_nseg[1] : 0;
+    else if (n == "wide_segment_len") // segment length of the current time-segmented plan (0: none)
+        *value = (c->wseg_enabled && !c->wseg_given_up && c->w_nseg[1] > c->w_nseg[0]) ? (double)c->wseg_cur_len : 0.0;
     else if (n == "wide_trouble") // which self-check of the lazily scaled kernels fired last (bit mask)
         *value = c->wide_trouble;
     else if (n == "tile_reason") // more than 64 states: why the tile kernels were left (ctx.hpp), 0: they were not
@@ -1679,6 +1679,65 @@ int bhmm_ctx_last_kernel_ms_all(bhmm_ctx *c, double *out)
     for (int i = 0; i < 5; ++i)
         out[i] = c->last_ms[i];
     return BHMM_OK;
+}
+
+// Safety net for the one situation in which a chunked evaluation cannot follow the reference
+// (reducible transition matrices whose blocks' relative weight leaves the double
+// range -- the reference's result depends on the order in which ITS recursions lose a block): finite
+// log-likelihoods but non-finite counts.  The observations are re-planned with one chunk per
+// trajectory -- the plain sequential recursions -- and the E-step is repeated with the model of the
+// last bhmm_estep call (kept in the context) into the same statistics buffer, once per set of
+// observations.  *retried (optional) reports whether that happened.
+static int nonfinite_retry(bhmm_ctx *c, bool *retried)
+{
+    if (retried)
+        *retried = false;
+    if (c->wide || c->gen || c->G <= c->K || c->serial_retry_done || !c->last_stats)
+        return BHMM_OK;
+    const int S = stats_size(c);
+    const int n = c->n;
+    const int ncheck = std::min(S, 1 + n + n * n + n);
+    if (!c->prefetched) {
+        BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->last_stats, S * sizeof(double), hipMemcpyDeviceToHost,
+                                c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+    }
+    bool finite = true;
+    for (int e = 0; e < ncheck; ++e)
+        finite = finite && std::isfinite(c->h_pinned[e]);
+    int64_t maxT = 0;
+    for (int k = 0; k < c->K; ++k)
+        maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+    if (finite || !std::isfinite(c->h_pinned[0]) || maxT >= ((int64_t)1 << 30))
+        return BHMM_OK;
+    c->serial_retry_done = true;
+    // does the one-chunk-per-trajectory plan fit?  Its workspace is (K padded to 64) x maxT records (few
+    // long trajectories: hundreds of GB): if not, leave the plan alone -- the fetch then reports the
+    // non-finite statistic instead of an allocation failure on a half-replaced plan
+    const double recs = (double)((c->K + 63) / 64) * (double)maxT * 64.0;
+    const double need = recs * ((double)c->N * 8.0 * 1.5 + 16.0);
+    size_t free_b = 0, total_b = 0;
+    BHMM_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double held = (double)c->d_ws.n * 8.0 + (double)c->d_obs_ci.n + (double)c->d_gamma_ci.n * 8.0;
+    const size_t ne = c->kind == BHMM_EMIT_GAUSSIAN ? 2 * (size_t)n
+                      : (c->kind == BHMM_EMIT_DISCRETE ? (size_t)n * c->M : 0);
+    if (need > 0.9 * ((double)free_b + held) || c->prev_model.size() != (size_t)n * n + ne ||
+        c->last_pi.size() != (size_t)n)
+        return BHMM_OK;
+    c->chunk_auto = false;
+    c->gamma_wanted = (c->last_flags & BHMM_FLAG_STORE_GAMMA) != 0; // (the re-plan re-sizes the gamma rows)
+    int rc;
+    if ((rc = replan_coarse(c, false, (int)maxT))) {
+        c->kind = -1; // (a failed re-plan leaves no usable plan: the context needs new observations)
+        return rc;
+    }
+    c->prefetched = false;
+    const double *A = c->prev_model.data();
+    const double *p0 = ne ? A + (size_t)n * n : nullptr;
+    const double *p1 = c->kind == BHMM_EMIT_GAUSSIAN ? p0 + n : nullptr;
+    if (retried)
+        *retried = true;
+    return BHMM_DISPATCH_N(c, estep(c, A, c->last_pi.data(), p0, p1, c->last_stats, c->last_flags));
 }
 
 int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
@@ -1731,6 +1790,8 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         }
         c->carry_delta = delta;
         c->prev_model.swap(cur);
+        c->last_pi.assign(pi, pi + n); // (with prev_model: the model of this call, for nonfinite_retry)
+        c->last_flags = flags;
     }
     double *sd = stats_dev ? stats_dev : c->d_stats.p;
     c->last_stats_internal = (stats_dev == nullptr);
@@ -1743,53 +1804,12 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         rc = wide_estep(c, A, pi, par0, par1, sd, flags);
     else
         rc = BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
-    if (rc == BHMM_OK && !c->wide && !c->gen && c->G > c->K && !c->serial_retry_done) {
-        // Safety net for the one situation in which a chunked evaluation cannot follow the reference
-        // (reducible transition matrices whose blocks' relative weight leaves the
-        // double range -- the reference's result depends on the order in which ITS recursions lose a
-        // block): finite log-likelihoods but non-finite counts.  The observations are re-planned with
-        // one chunk per trajectory -- the plain sequential recursions -- and the E-step is repeated,
-        // once per set of observations.
-        // Only where the statistics are on the host already or are the library's own (the caller
-        // fetches them next anyway): an E-step launched into a CALLER's device buffer stays
-        // asynchronous, and bhmm_estep_fetch reports non-finite counts loudly there (BHMM_ERR_NONFINITE).
-        const int S = stats_size(c);
-        const int ncheck = std::min(S, 1 + c->n + c->n * c->n + c->n);
-        bool finite = true;
-        const bool look = c->prefetched || c->last_stats_internal;
-        if (look && !c->prefetched) {
-            BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->last_stats, S * sizeof(double), hipMemcpyDeviceToHost,
-                                    c->stream));
-            BHMM_HIP(hipStreamSynchronize(c->stream));
-        }
-        if (look)
-            for (int e = 0; e < ncheck; ++e)
-                finite = finite && std::isfinite(c->h_pinned[e]);
-        int64_t maxT = 0;
-        for (int k = 0; k < c->K; ++k)
-            maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
-        if (!finite && std::isfinite(c->h_pinned[0]) && maxT < ((int64_t)1 << 30)) {
-            c->serial_retry_done = true;
-            // does the one-chunk-per-trajectory plan fit?  Its workspace is (K padded to 64) x maxT
-            // records (few long trajectories: hundreds of GB): if not, leave the plan alone -- the
-            // fetch then reports the non-finite statistic instead of an allocation failure on a
-            // half-replaced plan
-            const double recs = (double)((c->K + 63) / 64) * (double)maxT * 64.0;
-            const double need = recs * ((double)c->N * 8.0 * 1.5 + 16.0);
-            size_t free_b = 0, total_b = 0;
-            BHMM_HIP(hipMemGetInfo(&free_b, &total_b));
-            const double held = (double)c->d_ws.n * 8.0 + (double)c->d_obs_ci.n + (double)c->d_gamma_ci.n * 8.0;
-            if (need <= 0.9 * ((double)free_b + held)) {
-                c->chunk_auto = false;
-                if ((rc = replan_coarse(c, false, (int)maxT))) {
-                    c->kind = -1; // (a failed re-plan leaves no usable plan: the context needs new observations)
-                    return rc;
-                }
-                c->prefetched = false;
-                rc = BHMM_DISPATCH_N(c, estep(c, A, pi, par0, par1, sd, flags));
-            }
-        }
-    }
+    if (rc == BHMM_OK && (c->prefetched || c->last_stats_internal))
+        // (the statistics are on the host already, or are the library's own and fetched next anyway: look
+        // now.  An E-step launched into a CALLER's device buffer stays asynchronous; bhmm_estep_fetch, which
+        // such a caller uses to wait for it, takes the same look -- so a sharded caller is repaired too,
+        // BEFORE its all-reduce)
+        rc = nonfinite_retry(c, nullptr);
     c->gamma_valid = rc == BHMM_OK && c->gamma_wanted;
     c->gamma_wanted = false;
     return rc;
@@ -1804,9 +1824,20 @@ int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
     // statistics come from the buffer the E-step wrote (the caller's, if it gave one: a caller that
     // all-reduces that buffer in place fetches before reducing, or asks for logL_k only)
     bool have_logLk = true;
+    if (!c->prefetched && !c->last_stats)
+        return invalid("no E-step has run on these observations");
+    if (!c->last_stats_internal) {
+        // an E-step launched into the caller's buffer: this is where its result is first looked at
+        bool retried = false;
+        int rc = nonfinite_retry(c, &retried);
+        if (retried) { // (what bhmm_estep does at its end)
+            c->gamma_valid = rc == BHMM_OK && c->gamma_wanted;
+            c->gamma_wanted = false;
+        }
+        if (rc)
+            return rc;
+    }
     if (!c->prefetched) {
-        if (!c->last_stats)
-            return invalid("no E-step has run on these observations");
         BHMM_HIP(hipMemcpyAsync(c->h_pinned, c->last_stats, S * sizeof(double), hipMemcpyDeviceToHost,
                                 c->stream));
         BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, c->K * sizeof(double),

@@ -129,6 +129,8 @@ struct bhmm_ctx {
                                   // check found after a FULL warm-up from the uniform vector (0: unknown)
     int carry_ok = 0, carry_fail = 0, carry_last_W = 0;
     std::vector<double> prev_model; // [A | par0 | par1] of the previous E-step
+    std::vector<double> last_pi;    // ... and its initial distribution, flags (nonfinite_retry repeats that call)
+    int last_flags = 0;
     bhmm::DevBuf<double> d_carry_a, d_carry_b;
     bhmm::DevBuf<int32_t> d_carry_da, d_carry_db;
     bhmm::DevBuf<unsigned int> d_specres;
@@ -151,7 +153,6 @@ struct bhmm_ctx {
     bool smp_segmented = false;       // the last sample_paths call ran over time segments
     bhmm::DevBuf<int32_t> d_sentry, d_sexit;
     double spec_tol = 1e-11;          // N <= 8: tolerance of the boundary check (option spec_tol)
-    int tile_retries = 0;             // E-steps on the tile kernels repeated once after a self-check fired (see tile_gen.hip)
     int vit_seg_per_simd = 2;
     int vit_seg_warmups = 2;          // a Viterbi segment is at least this many warm-ups long (measured: 1, 2, 4)
     int smp_seg_per_simd = 4;         // (the draw is a short dependent chain: more wavefronts per SIMD hide it)
@@ -190,7 +191,8 @@ struct bhmm_ctx {
     bhmm::DevBuf<int64_t> d_wseg_fmid;  // plan 1: start of the forward pass's second segment inside each
     bhmm::DevBuf<double> d_wlogLseg, d_waentry, d_waexit, d_wbexit, d_wbentry;
     // row-batched matrix-core recursions (tile_kernels.hpp): 16 segments per workgroup
-    bool tile_enabled = true;        // option "tile" / BHMM_AMD_TILE=0
+    bool tile_enabled = true;        // option "tile" / BHMM_AMD_TILE=0: takes effect at the next set_observations ...
+    bool tile_latched = true;        // ... where it is latched: plans, buffers and launches of one data set all use THIS
     int tile_per_cu = 1;             // tiles the segment plan aims at per compute unit (option "tile_per_cu")
     int w_ntiles[3] = {0, 0, 0}, w_ntilesb[3] = {0, 0, 0};
     bhmm::DevBuf<int32_t> d_tile_seg[3];  // [16 * ntiles] segment of every tile row (-1: none), forward pass

@@ -25,7 +25,7 @@ namespace bhmm {
 int wide_plan_pub(bhmm_ctx *c, int which, int64_t seglen);
 Segs wide_segs_pub(bhmm_ctx *c, int which);
 
-bool tile_gen_capable(const bhmm_ctx *c) { return c->tile_enabled && c->gen && c->n <= 128; }
+bool tile_gen_capable(const bhmm_ctx *c) { return c->tile_latched && c->gen && c->n <= 128; }
 
 namespace {
 
@@ -179,11 +179,6 @@ int calibrate(bhmm_ctx *c, const WideModel &m, bool *usable)
             return rc;
         if (c->h_specres[2]) { // left the range of the lazily scaled kernels: the order-faithful family
             c->wide_trouble = c->h_specres[2];
-            if (c->tile_retries < 1) { // (once per set of observations: see tile_gen_estep)
-                ++c->tile_retries;
-                --it;
-                continue;
-            }
             c->tile_reason = 1;
             return BHMM_OK;
         }
@@ -296,16 +291,10 @@ int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags
             return rc;
         c->wide_trouble = c->h_specres[2];
         if (c->h_specres[2]) {
-            // A self-check fired.  Data that leave the lazily scaled kernels' range do so every time; but a
-            // context of 65 states has been seen (three times in some hundred runs, never reproduced on
-            // purpose) to report bits 4 + 32 once and then never again on the same data -- so the run is
-            // repeated once per set of observations before the context is moved to the order-faithful
-            // family for good.  Nothing of a flagged run is used either way.
-            if (c->tile_retries < 1) {
-                ++c->tile_retries;
-                attempt = -1;
-                continue;
-            }
+            // A self-check fired: the kernels are deterministic, so these data leave the lazily scaled
+            // kernels' range every time (a run that was merely repeated would hide an uninitialised read --
+            // round 4's LDS over-read was found because such a flag did NOT repeat).  Nothing of a flagged
+            // run is used; the context moves to the order-faithful family for these observations.
             c->wide_careful = true; // out of the lazily scaled kernels' range on these data: stay away
             c->tile_reason = 4;
             return BHMM_OK;

@@ -90,7 +90,7 @@ static int wide_fwd_plan(const bhmm_ctx *c, int which)
 // 65..128
 static bool wide_tile(const bhmm_ctx *c)
 {
-    return c->tile_enabled && ((c->n > 32 && c->n <= 64 && !c->gen) || (c->gen && c->n <= 128));
+    return c->tile_latched && ((c->n > 32 && c->n <= 64 && !c->gen) || (c->gen && c->n <= 128));
 }
 
 template <int KIND>
@@ -657,10 +657,6 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipStreamSynchronize(c->stream));
         if (lazy)
             c->wide_trouble = c->h_specres[2];
-        if (lazy && c->h_specres[2] != 0 && c->tile_used && c->tile_retries < 1) {
-            ++c->tile_retries; // (the tile kernels once more before the context leaves them: tile_gen.hip)
-            return wide_estep(c, A, pi, par0, par1, stats_dev, flags);
-        }
         if (lazy && c->h_specres[2] != 0) {
             // a vector left the range the lazy scaling covers: per-step normalisation from now on
             c->wide_careful = true;

@@ -239,13 +239,25 @@ class MaximumLikelihoodEstimator(object):
             S = packed_stats_size(self._output, self._nstates, self._nsymbols)
             buf = comm.stats_buffer(S)
             logL_k = np.zeros(0)
+            failed = None
             if self._mine:
                 eng.estep_launch(A, pi, par0, par1, stats_dev=buf.data_ptr(),
                                  store_gamma=self._store_gamma)
-                logL_k = eng.estep_fetch_logL()          # waits for the E-step of this shard
+                try:
+                    # waits for the E-step of this shard (and repairs what the library can repair,
+                    # bhmm_estep_fetch: non-finite counts -> one chunk per trajectory, repeated)
+                    logL_k = eng.estep_fetch_logL()
+                except (AssertionError, RuntimeError) as e:
+                    # A shard that cannot be evaluated must not leave the other ranks alone in the
+                    # collective: its buffer holds the non-finite statistics the error is about, the
+                    # sum is non-finite on EVERY rank, and every rank fails the checks below together.
+                    failed = e
+                    buf[0] = float('nan')
             else:
                 buf.zero_()
             packed = comm.allreduce_stats(buf)
+            if failed is not None:
+                raise failed
             res = EStepResult(self._output, self._nstates, self._nsymbols, packed, logL_k)
         else:
             # host-side engine (the CPU test double of tests/): host all-reduce

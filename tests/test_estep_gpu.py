@@ -812,6 +812,23 @@ def test_reducible_model_with_wide_emissions_is_repeated_on_one_chunk_per_trajec
         np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-8, atol=1e-10)
     assert eng.num_chunks == len(obs)
     eng.close()
+    # the sharded estimator's call sequence (maximum_likelihood.py:271-282 in distributed form): the
+    # statistics go to the CALLER's device buffer, bhmm_estep_fetch(logL_k only) waits for them -- and must
+    # repair them there, before the all-reduce that follows (a rank that raised instead would leave the
+    # others alone in the collective)
+    import torch
+    eng = Engine(0)
+    eng.set_observations("discrete", obs, 2, nsymbols=B.shape[1], chunk=int(d["chunk"]))
+    buf = torch.full((eng.stats_size,), -1.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    eng.estep_launch(A, pi, B, stats_dev=buf.data_ptr())
+    logL_k = eng.estep_fetch_logL()
+    assert eng.num_chunks == len(obs)
+    res = eng.unpack(buf.cpu().numpy(), logL_k)
+    np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-10)
+    np.testing.assert_allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(res.state_counts, ref["state_counts"], rtol=1e-8, atol=1e-10)
+    eng.close()
 
 
 @pytest.mark.parametrize("case,kind", [("gauss8_denormal_entries_8101_681", "gaussian"),

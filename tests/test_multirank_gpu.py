@@ -76,45 +76,77 @@ def test_rccl_collectives_one_rank(launcher):
     assert np.array_equal(got["chain_paths"], ref["chain_paths"])
 
 
-@pytest.mark.gpu
-def test_bench_starts_its_own_ranks(launcher):
-    """`python bench.py --gpus 2` without a launcher environment starts two ranks itself and
-    reports n_gpus = 2 (here both ranks share the box's one GPU: --oversubscribe, gloo).  Its
-    `secondary` carries the two configs BASELINE quotes on 8 GPUs -- configs[2] strong-scaled and
-    the configs[4] chain as whole sweeps -- and, the trajectories being drawn by global index, the
-    2-rank run sees the data of the 1-rank run: same configs[2] log-likelihood."""
+def _bench_line(launcher, gpus, small, timeout=900):
     import json
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    small = ["--steps", "3", "--warmup", "1", "--ntraj", "16", "--length", "20000", "--no-cpu",
-             "--c3-ntraj", "8", "--c3-length", "50000", "--c3-steps", "2", "--chain-sweeps", "3",
-             "--em-iterations", "3"]
-    outs = []
-    for gpus in (1, 2):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + small
-        if gpus > 1:
-            cmd.append("--oversubscribe")
-        r = launcher.run([cmd], timeout=900, env=env)[0]
-        assert r["rc"] == 0, r["out"]
-        line = [ln for ln in r["out"].splitlines() if ln.startswith('{"metric"')]
-        assert len(line) == 1, r["out"]
-        outs.append(json.loads(line[0]))
-    one, two = outs
-    assert two["n_gpus"] == 2 and two["steps"] == 3 and two["scaling"] == "weak"
-    assert abs(two["value"] - 2 * 16 * 20000 * 3 / (two["ms_per_step"] * 3e-3)) < 1e-6 * two["value"]
-    c3 = [[e for e in o["secondary"] if e["config"].startswith("configs[2]")][0] for o in outs]
-    assert c3[0]["n_gpus"] == 1 and c3[1]["n_gpus"] == 2 and c3[1]["scaling"] == "strong"
-    assert abs(c3[1]["loglik"] - c3[0]["loglik"]) <= 1e-12 * abs(c3[0]["loglik"])
-    assert c3[1]["allreduce_plus_copy_ms"] > 0
-    for o in outs:
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + small
+    if gpus > 1:
+        cmd.append("--oversubscribe")
+    r = launcher.run([cmd], timeout=timeout, env=env)[0]
+    assert r["rc"] == 0, r["out"]
+    line = [ln for ln in r["out"].splitlines() if ln.startswith('{"metric"')]
+    assert len(line) == 1, r["out"]
+    return json.loads(line[0])
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks(launcher):
+    """`python bench.py --gpus 2` without a launcher environment starts two ranks itself and
+    reports n_gpus = 2 (here both ranks share the box's one GPU: --oversubscribe, gloo).  `value` is
+    configs[2] STRONG-scaled: the trajectories are drawn by global index, so the 2-rank run sees the
+    data of the 1-rank run -- same log-likelihood --, the line carries the same roofline /
+    cpu_baseline keys at both N, and `secondary` the whole iterations of the estimator classes."""
+    small = ["--steps", "3", "--warmup", "1", "--ntraj", "8", "--length", "50000", "--cpu-traj", "2",
+             "--c1-ntraj", "16", "--c1-length", "20000", "--c1-steps", "3", "--c1-warmup", "1",
+             "--c1-cpu-traj", "2", "--chain-sweeps", "3", "--em-iterations", "3"]
+    one, two = [_bench_line(launcher, g, small) for g in (1, 2)]
+    assert two["n_gpus"] == 2 and two["steps"] == 3 and two["scaling"] == "strong" == one["scaling"]
+    for o in (one, two):
+        assert abs(o["value"] - 8 * 50000 * 3 / (o["ms_per_step"] * 3e-3)) < 1e-6 * o["value"]
+        assert o["config"]["workload"].startswith("configs[2]")
+        assert o["roofline"]["alg_bytes_per_timestep"] == 136
+        assert o["roofline"]["alg_bytes_per_launch"] == 136 * (8 // o["n_gpus"]) * 50000
+        assert 0 < o["roofline"]["frac"] < 1 and o["roofline"]["sweep_kernel_ms"] > 0
+        assert o["cpu_baseline"]["kind"] == "reference" and o["cpu_baseline"]["cores"] == 1
+        assert o["cpu_baseline"]["loglik_rel_diff_vs_gpu"] < 1e-9
+    assert abs(two["loglik"] - one["loglik"]) <= 1e-12 * abs(one["loglik"])
+    assert two["allreduce_plus_copy_ms"] > 0 and two["config"]["allreduces_per_step"] == 1.0
+    assert two["statistics_identical_on_all_ranks"] is True
+    assert one["configs1_gaussian"]["roofline"]["alg_bytes_per_timestep"] == 144
+    assert one["configs1_gaussian"]["cpu_baseline"]["loglik_rel_diff_vs_gpu"] < 1e-9
+    assert one["configs3_64_states"]["self_checks_fired"] == 0
+    assert all(g["self_checks_fired"] == 0 and g["tile_kernels"] for g in one["more_than_64_states"])
+    for o in (one, two):
         whole = [e for e in o["secondary"] if "WHOLE" in e["config"]]
         assert len(whole) == 5 and all(e["n_gpus"] == o["n_gpus"] for e in whole)
         assert all(e.get("ms_per_iteration", e.get("ms_per_sweep")) > 0 for e in whole)
     # the EM sequence of the sharded run is the single-process sequence
-    em = [[e for e in o["secondary"] if "WHOLE EM" in e["config"]] for o in outs]
+    em = [[e for e in o["secondary"] if "WHOLE EM" in e["config"]] for o in (one, two)]
     for a, b in zip(*em):
         np.testing.assert_allclose(a["loglik_first_last"], b["loglik_first_last"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_bench_eight_rank_dry_run(launcher):
+    """The 8-GPU job of BASELINE configs[2] before an 8-GPU node exists: `bench.py --gpus 8
+    --oversubscribe` (eight ranks sharing this box's GPU, the sum over gloo -- everything else is the
+    production path): 1024 trajectories in 128-trajectory shards, rank r drawing trajectories
+    r*128 .. by global index, ONE all-reduce per step, identical reduced statistics on every rank,
+    and the log-likelihood of the one-rank run on the same (short) trajectories.  No scaling number
+    is expected from it."""
+    small = ["--steps", "2", "--warmup", "1", "--ntraj", "1024", "--length", "3000", "--no-cpu",
+             "--no-secondary", "--no-steady"]
+    one = _bench_line(launcher, 1, small)
+    eight = _bench_line(launcher, 8, small, timeout=1500)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong"
+    assert eight["config"]["trajectories_per_gpu"] == 128 and eight["config"]["trajectories_total"] == 1024
+    assert eight["config"]["allreduces_per_step"] == 1.0
+    assert eight["statistics_identical_on_all_ranks"] is True
+    assert abs(eight["loglik"] - one["loglik"]) <= 1e-12 * abs(one["loglik"])
+    assert eight["roofline"]["alg_bytes_per_launch"] == 136 * 128 * 3000
+    assert abs(eight["value"] - 1024 * 3000 * 2 / (eight["ms_per_step"] * 2e-3)) < 1e-6 * eight["value"]
 
 
 @pytest.mark.gpu

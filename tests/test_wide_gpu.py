@@ -337,11 +337,15 @@ def test_wide64_segments_lazy_scaling_and_mfma_counts():
 
 
 def test_configs3_full_size_properties():
-    """BASELINE configs[3] shape (64 states, 128 x 1e5 Gaussian), size-independent checks:
-    (1) sum gamma = K T, sum C = K (T - 1), sum gamma_0 = K;  (2) the time-segmented run (lazy
-    scaling, DPP products, counts on the matrix cores, verified warm-up boundaries) equals the
-    serial plan (one segment per trajectory, per-step normalisation);  (3) one trajectory
-    against the oracle."""
+    """BASELINE configs[3] shape (64 states, 128 x 1e5 Gaussian) on the row-batched matrix-core
+    kernels (k_tile_fwd / k_tile_bwd, asserted):  (1) size-independent: sum gamma = K T,
+    sum C = K (T - 1), sum gamma_0 = K;  (2) the time-segmented run equals the serial plan (one
+    segment per trajectory, per-step normalisation, the 64-lane kernels);  (3) AGAINST THE ORACLE
+    at the benchmark's own segment geometry: a two-trajectory sub-batch of the same data, T = 1e5,
+    cut with the segment length and the warm-up the full batch settled on (3 125-step segments,
+    W ~ 900): log-likelihoods, C, sum gamma, sum gamma_0, emission sums and stored gamma rows
+    against orc.estep (_hidden.c:16-183);  (4) the full batch's own log-likelihoods of those two
+    trajectories against the same oracle run."""
     import torch
     from bench import metastable_matrix, stationary
     from bhmm_amd.engine import Engine
@@ -380,9 +384,33 @@ def test_configs3_full_size_properties():
     np.testing.assert_allclose(res.state_counts, rs.state_counts, rtol=1e-9)
     np.testing.assert_allclose(res.sum_gd, rs.sum_gd, rtol=1e-7, atol=1e-6)
     np.testing.assert_allclose(res.sum_gdd, rs.sum_gdd, rtol=1e-8)
-    o0 = obs[:T].cpu().numpy()
-    ref = orc.estep("gaussian", [o0], *args)
-    np.testing.assert_allclose(res.logL_k[0], ref["logL"][0], rtol=1e-11)
+    assert eng.get_option("tile") == 1, eng.get_option("tile_reason")
+    assert eng.get_option("wide_trouble") == 0
+    seg_len, W = int(eng.get_option("wide_segment_len")), int(eng.get_option("spec_W"))
+    assert 2000 <= seg_len <= 4000 and W < seg_len, (seg_len, W)      # 4096 segments of ~3 125 steps
+    sub = [obs[k * T:(k + 1) * T].cpu().numpy() for k in (0, 77)]
+    ref = orc.estep("gaussian", sub, *args, want_gamma=True)
+    np.testing.assert_allclose(res.logL_k[[0, 77]], ref["logL"], rtol=1e-11)
+    e2 = Engine(0)
+    e2.set_option("wide_segment_len", seg_len)
+    e2.set_option("spec_W", W)
+    e2.set_observations("gaussian", sub, n)
+    r2 = e2.estep(*args, store_gamma=True)
+    assert e2.get_option("tile") == 1 and e2.get_option("careful") == 0
+    assert e2.get_option("spec_fail") == 0 and e2.get_option("wide_trouble") == 0
+    assert e2.get_option("wide_segments") >= 2 * (T // seg_len) and e2.get_option("spec_W") == W
+    np.testing.assert_allclose(r2.logL_k, ref["logL"], rtol=1e-11)
+    np.testing.assert_allclose(r2.C, ref["C"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(r2.state_counts, ref["state_counts"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(r2.gamma0_sum, ref["gamma0_sum"], rtol=1e-9, atol=1e-13)
+    mu_e = args[2]
+    sd = sum((g * (o[:, None] - mu_e[None, :])).sum(axis=0) for o, g in zip(sub, ref["gammas"]))
+    sdd = sum((g * (o[:, None] - mu_e[None, :]) ** 2).sum(axis=0) for o, g in zip(sub, ref["gammas"]))
+    np.testing.assert_allclose(r2.sum_gd, sd, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(r2.sum_gdd, sdd, rtol=1e-8, atol=1e-8)
+    for k in (0, 1):
+        np.testing.assert_allclose(e2.gamma(k), ref["gammas"][k], rtol=1e-8, atol=1e-13)
+    e2.close()
     eng.close()
     ser.close()
     del obs, s
