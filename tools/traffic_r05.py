@@ -24,7 +24,9 @@ valu = {}
 for ln in open(sys.argv[3]):
     p = [x.strip() for x in ln.split('|')]
     if len(p) >= 9 and p[0] != 'kernel':
-        valu[p[0]] = (float(p[7]), float(p[2]), float(p[3]))     # SQ_INSTS_VALU, avg us, clock GHz
+        clk = float(p[3])
+        valu[p[0]] = (float(p[7]), float(p[2]), clk / 8.0 if clk > 4.0 else clk)   # SQ_INSTS_VALU, avg us, clock GHz
+        # (GRBM_GUI_ACTIVE comes summed over the 8 XCDs from this rocprofv3)
 out = {"unit": "FETCH_SIZE / WRITE_SIZE in KB per launch (mean of the last 3 launches); bytes = 1024 * (2 * FETCH_SIZE + "
                "WRITE_SIZE): on gfx950 FETCH_SIZE reports half of the bytes of a wide streaming read (MI355X_MICROARCH.md, "
                "HBM) -- checked on the 1 GiB clone below (expected FETCH 524288 KB = half, WRITE 1048576 KB)",
