@@ -1763,7 +1763,8 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     }
     c->gamma_valid = false;
     c->gamma_wanted = (flags & BHMM_FLAG_STORE_GAMMA) != 0;
-    if (!c->wide && !c->gen) {
+    c->wide_retry = 0;
+    {
         // how far the model moved since the previous E-step on these observations (max norm;
         // emission parameters in units of sigma): sizes the warm-ups from carried boundary vectors
         const int n = c->n;

@@ -200,6 +200,7 @@ struct bhmm_ctx {
     bhmm::DevBuf<int32_t> d_wexp;    // [total] exponent the forward pass removed at every step
     bhmm::DevBuf<int32_t> d_wePseg;  // [segments] ... summed over the main part of every segment
     unsigned int wide_trouble = 0;   // flag word of the last lazily scaled E-step (which self-check fired)
+    int wide_retry = 0;              // time-segmented attempts of the E-step call in flight that did not verify
     int tile_settle = 0;             // warm-up refinements done for these observations (at most 4, first E-step)
     int tile_W_good = 0;             // ... the last warm-up that verified
     int tile_reason = 0;             // why the tile path was left (0: it was not): 1 calibration saw a self-check fire,

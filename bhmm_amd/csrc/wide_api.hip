@@ -685,6 +685,22 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
                 }
             }
             c->tile_settle = 4;
+            // An EM sequence moves the model, and with it the length the filter needs to forget its start
+            // (configs[3]: the worst boundary went 5e-14 -> 1.3e-11 over 14 iterations at a fixed warm-up,
+            // profiles/r05).  A check that fails costs this call a second pass, so the warm-up FOLLOWS the
+            // measured deviation whenever the model has changed since the previous call: it aims at 3e-13
+            // (1.5 decades inside the tolerance), one decade being spec_W / 12.5 steps.  Calls that repeat a
+            // model never change it (bit-identical results, as before).
+            if (wide_tile(c) && lazy && !c->spec_W_fixed && c->carry_delta > 0.0 && dev > 0.f) {
+                const double dec = log10((double)dev / 3e-13);
+                int Wn = c->spec_W;
+                if (dev > 2e-12f)
+                    Wn = ((int)ceil(c->spec_W * (1.0 + dec / 12.5)) + 7) / 8 * 8;
+                else if (dev < 2e-14f)
+                    Wn = std::max(16, ((int)ceil(c->spec_W * (1.0 + 0.5 * dec / 12.5)) + 7) / 8 * 8);
+                if ((int64_t)Wn <= c->wseg_cur_len) // (a warm-up may be as long as a segment; beyond: re-plan below)
+                    c->spec_W = Wn;
+            }
             return BHMM_OK;
         }
         if (c->tile_W_good > c->spec_W && c->tile_settle > 0 && c->tile_settle <= 4) {
@@ -695,6 +711,19 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
             return wide_estep(c, A, pi, par0, par1, stats_dev, flags);
         }
         c->spec_fail++;
+        if (wide_tile(c) && lazy && !c->spec_W_fixed && c->wide_retry < 2) {
+            // the tile kernels once more with the warm-up the measured deviation asks for (it decays
+            // geometrically with the warm-up length), as long as it is no longer than a segment: 10 ms
+            // instead of the 300 ms of the serial plan below
+            const double d = std::min(std::max((double)dev, 1e-300), 0.5);
+            const double f = std::min(std::max(log(3e-13) / log(d), 1.08), 2.0);
+            const int Wn = ((int)ceil(c->spec_W * f) + 7) / 8 * 8;
+            if ((int64_t)Wn <= c->wseg_cur_len) {
+                ++c->wide_retry;
+                c->spec_W = Wn;
+                return wide_estep(c, A, pi, par0, par1, stats_dev, flags);
+            }
+        }
         // The deviation decays geometrically with the warm-up length (the filter forgets its start
         // vector): extrapolate to where it reaches a tenth of the tolerance, lengthen the
         // segments to at least four warm-ups and try again at the next call; give up (serial
