@@ -181,6 +181,7 @@ struct bhmm_ctx {
     bool gen = false;                // nstates > 64: gen_kernels.hpp family (any N, trajectory-major,
                                      // one workgroup per trajectory; `wide` is false then)
     bhmm::DevBuf<double> d_gpobs, d_gW, d_gAt, d_gxipart, d_gpart, d_gsym;
+    bhmm::DevBuf<double> d_bigBf, d_bigBb; // more than 128 states: A / A^T in matrix-operand order (big_kernels.hpp)
     // wide family: segment tables.  [0] = one segment per trajectory (exact serial recursion),
     // [1] = time-segmented plan with verified warm-up boundaries (optional)
     // plans: 0 = one segment per trajectory, 1 = time segments (both passes), 2 = the forward pass's

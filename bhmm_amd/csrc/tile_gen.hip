@@ -24,8 +24,11 @@
 namespace bhmm {
 int wide_plan_pub(bhmm_ctx *c, int which, int64_t seglen);
 Segs wide_segs_pub(bhmm_ctx *c, int which);
+int big_launch_fwd(bhmm_ctx *c, const WideModel &m);
+int big_launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev);
 
-bool tile_gen_capable(const bhmm_ctx *c) { return c->tile_latched && c->gen && c->n <= 128; }
+// 65 .. 128 states: tile_kernels.hpp (A's blocks in registers); 129 .. 512: big_kernels.hpp (streamed from L2)
+bool tile_gen_capable(const bhmm_ctx *c) { return c->tile_latched && c->gen && c->n <= 512; }
 
 namespace {
 
@@ -47,7 +50,11 @@ int64_t fill_len(const bhmm_ctx *c)
 
 int plan_for(bhmm_ctx *c, int W)
 {
-    int64_t seglen = c->wseg_len > 0 ? (int64_t)c->wseg_len : std::max<int64_t>(fill_len(c), 2 * (int64_t)W);
+    // (more than 128 states: a step is tens of microseconds of matrix instructions and there are seldom enough
+    // segments for every compute unit -- filling the chip is worth more than short warm-ups relative to the
+    // segments: half a warm-up is long enough there)
+    const int64_t wmin = c->n > 128 ? std::max<int64_t>(W / 2, 32) : 2 * (int64_t)W;
+    int64_t seglen = c->wseg_len > 0 ? (int64_t)c->wseg_len : std::max<int64_t>(fill_len(c), wmin);
     seglen = std::max(seglen, c->wseg_cur_len); // never more segments than allocated for
     if (seglen >= max_len(c))
         seglen = 0; // one segment per trajectory: no boundaries to verify
@@ -128,10 +135,12 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
     return BHMM_OK;
 }
 
-#define TILE_GEN_DISPATCH(fn, ...)                                                                       \
+#define TILE_GEN_DISPATCH_128(fn, ...)                                                                   \
     (c->kind == EMIT_GAUSS  ? (c->n <= 96 ? fn<6, EMIT_GAUSS>(__VA_ARGS__) : fn<8, EMIT_GAUSS>(__VA_ARGS__)) \
      : c->kind == EMIT_DISC ? (c->n <= 96 ? fn<6, EMIT_DISC>(__VA_ARGS__) : fn<8, EMIT_DISC>(__VA_ARGS__))   \
                             : (c->n <= 96 ? fn<6, EMIT_EXPL>(__VA_ARGS__) : fn<8, EMIT_EXPL>(__VA_ARGS__)))
+// (more than 128 states: big_api.hip)
+#define TILE_GEN_DISPATCH(fn, ...) (c->n > 128 ? big_##fn(__VA_ARGS__) : TILE_GEN_DISPATCH_128(fn, __VA_ARGS__))
 
 // boundary check of one direction (0 forward, 1 backward): flags -> host
 int run_check(bhmm_ctx *c, int dir)
@@ -234,7 +243,7 @@ int tile_gen_alloc(bhmm_ctx *c)
     int64_t nsmax = c->K;
     for (int k = 0; k < c->K; ++k)
         nsmax += (c->offsets[k + 1] - c->offsets[k]) / std::max<int64_t>(minlen & ~(int64_t)3, 4) + 1;
-    const size_t S = (size_t)n * n + 3 * n;
+    const size_t S = (n > 128 ? 0 : (size_t)n * n) + 3 * n; // (big_kernels.hpp: the counts come from the xi GEMM)
     const size_t ntmax = (size_t)nsmax / 16 + 3;
     if ((rc = c->d_wlogLseg.ensure(nsmax)) || (rc = c->d_wePseg.ensure(nsmax)) ||
         (rc = c->d_waentry.ensure((size_t)nsmax * n)) || (rc = c->d_waexit.ensure((size_t)nsmax * n)) ||

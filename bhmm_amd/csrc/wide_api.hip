@@ -90,7 +90,7 @@ static int wide_fwd_plan(const bhmm_ctx *c, int which)
 // 65..128
 static bool wide_tile(const bhmm_ctx *c)
 {
-    return c->tile_latched && ((c->n > 32 && c->n <= 64 && !c->gen) || (c->gen && c->n <= 128));
+    return c->tile_latched && ((c->n > 32 && c->n <= 64 && !c->gen) || (c->gen && c->n <= 512));
 }
 
 template <int KIND>
