@@ -698,12 +698,12 @@ def secondary_c4(torch, dev, local, args):
 
 
 def secondary_gen(torch, dev, local, args):
-    """More than 64 states (the any-N family, 128 x 1e4): E-step on the row-batched matrix-core
-    kernels up to 128 states (csrc/tile_gen.hip)."""
+    """More than 64 states (the any-N family): E-step on the row-batched matrix-core kernels -- up to 128
+    states with A's blocks in registers (csrc/tile_gen.hip), 129 .. 512 with A streamed from L2
+    (csrc/big_kernels.hpp, round 5)."""
     from bhmm_amd.engine import Engine
     out = []
-    for n in (65, 128):
-        K, T = 128, 10000
+    for n, K, T in ((65, 128, 10000), (128, 128, 10000), (256, 128, 4000)):
         rng = np.random.default_rng(n)
         A = metastable_matrix(n, rng)
         pi = stationary(A)

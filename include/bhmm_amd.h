@@ -102,7 +102,8 @@ int bhmm_ctx_destroy(bhmm_ctx *ctx);
 /* Upload K trajectories.  obs is the concatenation of all trajectories (element type per
  * `kind`), offsets[K+1] the element offsets of each trajectory in time steps.
  * nstates = N (1 .. 4096: N <= 8 chunk-parallel kernels, 9 .. 64 the lane-per-state family, above
- * that the any-N family of gen_kernels.hpp -- the reference's _hidden.c has no limit either),
+ * that the any-N family -- E-step on the matrix cores up to 512 states, order-faithful kernels of
+ * gen_kernels.hpp beyond and for the bit-exact passes; the reference's _hidden.c has no limit either),
  * nsymbols = M (discrete only).  chunk = time-chunk length used for the
  * parallel-in-time decomposition (0 = choose automatically).  obs_on_device != 0 means
  * `obs` is already a device pointer on the context's device (offsets stay on the host). */

@@ -17,14 +17,16 @@ import numpy as np
 from bhmm_amd.engine import Engine
 from oracle import oracle as orc
 rng = np.random.default_rng(1)
-for n, kind in ((8, "gaussian"), (20, "gaussian"), (48, "gaussian"), (64, "gaussian"), (65, "gaussian"), (96, "discrete"), (128, "gaussian")):
+for n, kind in ((8, "gaussian"), (20, "gaussian"), (48, "gaussian"), (64, "gaussian"), (65, "gaussian"), (96, "discrete"), (128, "gaussian"), (200, "gaussian"), (260, "discrete")):
     M = 12
     A = rng.random((n, n)) + np.eye(n) * 3.0
     A /= A.sum(axis=1)[:, None]
     pi = rng.dirichlet(np.ones(n))
     if kind == "gaussian":
         p0, p1 = np.linspace(-0.1 * n, 0.1 * n, n), rng.uniform(0.5, 1.5, n)
-        obs = [rng.normal(0, 0.12 * n, T) for T in (6000, 1, 2500)]
+        # (beyond 128 states a narrower spread: at 0.12 n observations 25 sigma from every state make stretches of
+        # p o beta exactly zero, and the REFERENCE's own counts come out 0 / 0 there)
+        obs = [rng.normal(0, (0.12 if n <= 128 else 0.04) * n, T) for T in (6000, 1, 2500)]
         pobs = [orc.pobs_gaussian(o, p0, p1) for o in obs]
     else:
         p0, p1 = rng.dirichlet(np.ones(M), n), None
@@ -40,7 +42,7 @@ for n, kind in ((8, "gaussian"), (20, "gaussian"), (48, "gaussian"), (64, "gauss
         if n != 128:                  # (at 128 states these data leave the lazily scaled kernels' range: the
             # self-checks fire with and without the poison, and the order-faithful family takes over)
             assert eng.get_option("wide_trouble") == 0, (n, eng.get_option("wide_trouble"))
-        if n in (48, 64, 65, 96):
+        if n in (48, 64, 65, 96, 200, 260):
             assert eng.get_option("tile") == 1, (n, eng.get_option("tile_reason"))
         np.testing.assert_allclose(res.logL_k, ref["logL"], rtol=1e-10)
         np.testing.assert_allclose(res.C, ref["C"], rtol=1e-8, atol=1e-10)

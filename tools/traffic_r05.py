@@ -32,8 +32,9 @@ out = {"unit": "FETCH_SIZE / WRITE_SIZE in KB per launch (mean of the last 3 lau
                "HBM) -- checked on the 1 GiB clone below (expected FETCH 524288 KB = half, WRITE 1048576 KB)",
        "source": "profiles/r05/%s_traffic.json (tools/profile_r05.sh %s: tools/pmc_r05.py under rocprofv3 --pmc, one "
                  "counter per pass; SQ_INSTS_VALU from profiles/r05/%s_clock.txt)" % (tag, tag, tag),
-       "issue_source": "profiles/r02/r02_ubench_issue_rate.txt (454 / 419 instructions per us per SIMD with 4 / 2 "
-                       "wavefronts per SIMD: P1 runs four, P2 two; the figure below weights them by instruction count)",
+       "issue_source": "one vector instruction per SIMD and four cycles (fp64 FMA, DPP move and integer instructions alike: "
+                       "tools/ubench/issue_rate.hip, profiles/r02/r02_ubench_issue_rate.txt) at the shader clock of the same "
+                       "counter pass, GRBM_GUI_ACTIVE / duration / 8 XCDs",
        "workloads": {}, "kernels": {}}
 for k in sorted(set(f) | set(w)):
     out["kernels"][k] = {"FETCH_SIZE_KB": f.get(k), "WRITE_SIZE_KB": w.get(k), "launches_seen": nf.get(k, nw.get(k)),
@@ -53,7 +54,9 @@ for key, kind, shape, balg in (("configs2", 1, (1024, 1000000), 136), ("configs1
         i1, i2 = v1[0][0], v2[0][0]
         ent["valu_wave_insts_per_launch"] = i1 + i2
         ent["valu_wave_insts"] = {"P1": i1, "P2": i2}
-        ent["issue_ceiling_insts_per_us_per_simd"] = (i1 + i2) / (i1 / 454.0 + i2 / 419.0)
+        # issue ceiling of a SIMD: one vector instruction per four cycles at the clock the counters saw
+        # (GRBM_GUI_ACTIVE / duration), weighted by the two kernels' instruction counts
+        ent["issue_ceiling_insts_per_us_per_simd"] = (i1 + i2) / (i1 / (250.0 * v1[0][2]) + i2 / (250.0 * v2[0][2]))
         ent["under_counters"] = {"P1_us": v1[0][1], "P2_us": v2[0][1], "P1_clock_GHz": v1[0][2], "P2_clock_GHz": v2[0][2]}
     out["workloads"][key] = ent
 print(json.dumps(out, indent=1))
