@@ -31,7 +31,6 @@
 namespace bhmm {
 
 constexpr int BIG_KC = 16;   // matrix instructions per streamed block of A
-constexpr int BIG_RING = 4;  // blocks in flight
 
 template <int TPW>
 struct BigGeo {
@@ -61,25 +60,60 @@ struct BigGeo {
     Bb[o] = in ? A[(int64_t)j * n + i] : 0.0;
 }
 
-// tile[16 x NP] (LDS buffer X) times the streamed matrix Bp: acc[c] = column tile w + 4 c of the product
-// (C/D layout: lane (s, q), register r <-> row q + 4 r, state 16 (w + 4 c) + s)
+// blocks of A in flight: the ring of register buffers lives ACROSS the steps (the matrix is the same at
+// every step), so that the first blocks of step t + 1 are requested during the last blocks of step t --
+// i.e. BEFORE step t's alpha / W / gamma stores.  Memory operations of a wavefront retire in order
+// (vmcnt): with the ring refilled at the top of a step, its first matrix instruction waited for the
+// previous step's stores to reach HBM (~7 of 11 us per step at 256 states, profiles/r05).
 template <int TPW>
-__device__ __forceinline__ void big_product(const double *X, int xr, const double *__restrict__ Bp, int w, int lane,
-                                            wide_d4 (&acc)[TPW])
+constexpr int big_ring() { return BigGeo<TPW>::NBLK % 4 == 0 ? 4 : 3; } // (divides the block count: slots wrap)
+
+template <int TPW>
+struct BigRing {
+    tile_d2 v[big_ring<TPW>()][BIG_KC / 2];
+};
+
+template <int TPW, int B>
+__device__ __forceinline__ void big_issue(BigRing<TPW> &ring, const double *__restrict__ Bp, int w, int lane)
 {
     using G = BigGeo<TPW>;
-    constexpr int KK = G::KK, NBLK = G::NBLK, KC = BIG_KC;
-    tile_d2 ring[BIG_RING][KC / 2];
-    // block b: K chunk b / TPW, column tile w + 4 (b % TPW)
-    auto issue = [&](auto bc) __attribute__((always_inline)) {
-        constexpr int b = decltype(bc)::value;
-        constexpr int k0 = (b / TPW) * KC, c = b % TPW;
-        const tile_d2 *src = reinterpret_cast<const tile_d2 *>(Bp) +
-                             ((int64_t)(w + 4 * c) * (KK / 2) + k0 / 2) * 64 + lane;
+    constexpr int k0 = (B / TPW) * BIG_KC, c = B % TPW;
+    const tile_d2 *src = reinterpret_cast<const tile_d2 *>(Bp) + ((int64_t)(w + 4 * c) * (G::KK / 2) + k0 / 2) * 64 + lane;
+#ifdef BIG_X_NOSTREAM // (experiment builds, tools/proto/big_variants.sh: what does a piece of the step cost?)
+    (void)src;
 #pragma unroll
-        for (int k2 = 0; k2 < KC / 2; ++k2)
-            ring[b % BIG_RING][k2] = src[(int64_t)k2 * 64];
-    };
+    for (int k2 = 0; k2 < BIG_KC / 2; ++k2)
+        ring.v[B % big_ring<TPW>()][k2] = tile_d2{1.0 / 256, 1.0 / 256};
+#else
+#pragma unroll
+    for (int k2 = 0; k2 < BIG_KC / 2; ++k2)
+        ring.v[B % big_ring<TPW>()][k2] = src[(int64_t)k2 * 64];
+#endif
+}
+
+// before the first step: blocks 0 .. RING - 2
+template <int TPW>
+__device__ __forceinline__ void big_prime(BigRing<TPW> &ring, const double *__restrict__ Bp, int w, int lane)
+{
+    big_issue<TPW, 0>(ring, Bp, w, lane);
+    if constexpr (big_ring<TPW>() > 2)
+        big_issue<TPW, 1>(ring, Bp, w, lane);
+    if constexpr (big_ring<TPW>() > 3)
+        big_issue<TPW, 2>(ring, Bp, w, lane);
+}
+
+// tile[16 x NP] (LDS buffer X) times the streamed matrix Bp: acc[c] = column tile w + 4 c of the product
+// (C/D layout: lane (s, q), register r <-> row q + 4 r, state 16 (w + 4 c) + s).  On entry the ring holds
+// (or has in flight) blocks 0 .. RING - 2; on exit those of the next step.
+template <int TPW>
+__device__ __forceinline__ void big_product(const double *X, int xr, const double *__restrict__ Bp, int w, int lane,
+                                            BigRing<TPW> &ring, wide_d4 (&acc)[TPW])
+{
+    using G = BigGeo<TPW>;
+    constexpr int KK = G::KK, NBLK = G::NBLK, KC = BIG_KC, RING = big_ring<TPW>();
+    static_assert(NBLK % RING == 0 && NBLK >= RING, "ring slots must wrap with the blocks");
+    tile_d2 av[2][KC / 2];
+    // block b: K chunk b / TPW, column tile w + 4 (b % TPW)
     auto for_blocks = [&](auto &&self, auto bc) __attribute__((always_inline)) -> void {
         constexpr int b = decltype(bc)::value;
         if constexpr (b < NBLK) {
@@ -87,15 +121,17 @@ __device__ __forceinline__ void big_product(const double *X, int xr, const doubl
             // (the scheduler would hoist every block's loads to the top of the step -- independent loads --
             // and spill a thousand registers: nothing moves across a block boundary)
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (b + BIG_RING - 1 < NBLK)
-                issue(tile_ic<b + BIG_RING - 1>{});
-            tile_d2 av[KC / 2];
+            big_issue<TPW, (b + RING - 1) % NBLK>(ring, Bp, w, lane);
+            // the tile's operands of a K chunk serve all TPW column tiles; those of the NEXT chunk are read
+            // while this chunk's matrix instructions run (the read latency was exposed once per block)
+            if constexpr (c == 0 && k0 + KC < KK) {
 #pragma unroll
-            for (int k2 = 0; k2 < KC / 2; ++k2)
-                av[k2] = *reinterpret_cast<const tile_d2 *>(X + xr + k0 + 2 * k2);
+                for (int k2 = 0; k2 < KC / 2; ++k2)
+                    av[((b / TPW) + 1) & 1][k2] = *reinterpret_cast<const tile_d2 *>(X + xr + k0 + KC + 2 * k2);
+            }
 #pragma unroll
             for (int kk = 0; kk < KC; ++kk)
-                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk >> 1][kk & 1], ring[b % BIG_RING][kk >> 1][kk & 1],
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[(b / TPW) & 1][kk >> 1][kk & 1], ring.v[b % RING][kk >> 1][kk & 1],
                                                               (b / TPW == 0 && kk == 0) ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c],
                                                               0, 0, 0);
             self(self, tile_ic<b + 1>{});
@@ -104,11 +140,9 @@ __device__ __forceinline__ void big_product(const double *X, int xr, const doubl
 #pragma unroll
     for (int c = 0; c < TPW; ++c)
         acc[c] = wide_d4{0.0, 0.0, 0.0, 0.0};
-    issue(tile_ic<0>{});
-    if constexpr (NBLK > 1 && BIG_RING > 2)
-        issue(tile_ic<1>{});
-    if constexpr (NBLK > 2 && BIG_RING > 3)
-        issue(tile_ic<2>{});
+#pragma unroll
+    for (int k2 = 0; k2 < KC / 2; ++k2)
+        av[0][k2] = *reinterpret_cast<const tile_d2 *>(X + xr + 2 * k2);
     for_blocks(for_blocks, tile_ic<0>{});
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -201,6 +235,14 @@ __global__ __launch_bounds__(256) void k_big_fwd(const WideModel m, const double
         }
     };
     auto emit = [&](const BigObs<KIND> &in, int rs, double (&p)[TPW][4]) __attribute__((always_inline)) {
+#ifdef BIG_X_NOEMIT
+#pragma unroll
+        for (int c = 0; c < TPW; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                p[c][r] = real[c] ? 0.05 : 0.0;
+        return;
+#endif
 #pragma unroll
         for (int c = 0; c < TPW; ++c) {
             const int j = 16 * (w + 4 * c) + s;
@@ -227,13 +269,15 @@ __global__ __launch_bounds__(256) void k_big_fwd(const WideModel m, const double
     unsigned int trouble = 0u;
     BigObs<KIND> cur, nxt;
     obs_at(cur, 0);
+    BigRing<TPW> ring;
+    big_prime<TPW>(ring, Bf, w, lane);
     __syncthreads();
     for (int rs = 0; rs < nmax; ++rs) {
         const double *X = sX + (rs & 1) * 16 * PX;
         double *Xn = sX + ((rs & 1) ^ 1) * 16 * PX;
         obs_at(nxt, rs + 1); // (the next step's observations are on their way during the product)
         wide_d4 acc[TPW];
-        big_product<TPW>(X, xr, big_stream_ptr<TPW>(Bf), w, lane, acc);
+        big_product<TPW>(X, xr, big_stream_ptr<TPW>(Bf), w, lane, ring, acc);
         double p[TPW][4];
         emit(cur, rs, p);
         double v[TPW][4], ps[4] = {0.0, 0.0, 0.0, 0.0};
@@ -258,16 +302,21 @@ __global__ __launch_bounds__(256) void k_big_fwd(const WideModel m, const double
             const bool act = rs < nst[r], mainp = act && rs >= r0[r];
             trouble |= (act && !(cs > 0x1p-1000 && cs < 0x1p1000)) ? 1u : 0u;
             const double inv = act ? 1.0 / cs : 0.0;
-            if (mainp && w == 0 && s == 0)
+#ifndef BIG_X_NOLOG
+            if (mainp && w == r && s == 0) // (wavefront w keeps the sums of the rows q + 4 w: one log per lane and step)
                 ll[r] += log(cs); // _hidden.c:57-66
+#endif
 #pragma unroll
             for (int c = 0; c < TPW; ++c) {
                 const int j = 16 * (w + 4 * c) + s;
                 const double a = v[c][r] * inv;
                 Xn[xw[r] + j] = a;
                 if (real[c] && act) {
-                    if (mainp)
+                    if (mainp) {
+#ifndef BIG_X_NOSTORE
                         alpha_rm[(ob[r] + rs) * n + j] = a;
+#endif
+                    }
                     else if (rs == r0[r] - 1)
                         a_entry[(int64_t)seg[r] * n + j] = a;
                     if (rs == nst[r] - 1)
@@ -278,10 +327,10 @@ __global__ __launch_bounds__(256) void k_big_fwd(const WideModel m, const double
         cur = nxt;
         __syncthreads();
     }
-    if (w == 0 && s == 0) {
+    if (s == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (seg[r] >= 0)
+            if (w == r && seg[r] >= 0)
                 logL_seg[seg[r]] = ll[r];
     }
     if (trouble)
@@ -416,6 +465,8 @@ __global__ __launch_bounds__(256) void k_big_bwd(const WideModel m, const double
     BigObs<KIND> cur, nxt;
     obs_at(cur, 0);
     alpha_at(0, acur);
+    BigRing<TPW> ring;
+    big_prime<TPW>(ring, Bb, w, lane);
     for (int us = 0; us < nmax; ++us) {
         double *X = sX + (us & 1) * 16 * PX;
         obs_at(nxt, us + 1);
@@ -441,7 +492,7 @@ __global__ __launch_bounds__(256) void k_big_bwd(const WideModel m, const double
             }
         __syncthreads();
         wide_d4 acc[TPW];
-        big_product<TPW>(X, xr, big_stream_ptr<TPW>(Bb), w, lane, acc);
+        big_product<TPW>(X, xr, big_stream_ptr<TPW>(Bb), w, lane, ring, acc);
         double aprev[TPW][4]; // alpha_{t-1}
         alpha_at(us + 1, aprev);
         double pb[4] = {0.0, 0.0, 0.0, 0.0}, pS[4] = {0.0, 0.0, 0.0, 0.0};

@@ -1,6 +1,7 @@
 """Test infrastructure (uses the oracle).  Random parity sweep for the two kernel families that the small-
 shape sweep does not reach: 9..64 states (lane-per-state kernels, wide_kernels.hpp) and 65..200 states
-(any-N family, gen_kernels.hpp) -- gaussian / discrete, ragged trajectories (lengths 1, 2, ... included),
+(any-N family: tile_kernels.hpp / gen_kernels.hpp; MANY_MAXN=420 MANY_PBIG=0.8: mostly 65..420 states, i.e.
+also the matrix-core kernels of big_kernels.hpp) -- gaussian / discrete, ragged trajectories (lengths 1, 2, ... included),
 sparse transition matrices, zero entries in pi, far-away observations.  E-step statistics against the
 oracle (logL 1e-10, counts 1e-8), Viterbi and sampled paths (given the uniforms) bit for bit.
 Prints one line per failure and a summary; exit code 1 on failure."""
@@ -15,10 +16,12 @@ from ld_reference import estep_longdouble
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 11)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 ONLY = int(os.environ["ONLY"]) if os.environ.get("ONLY") else -1   # replay one case (same random stream)
+MAXN = int(os.environ.get("MANY_MAXN", 200))   # (MANY_MAXN=420: also the 129 .. 512-state kernels of big_kernels.hpp)
+PBIG = float(os.environ.get("MANY_PBIG", 0.35))
 bad = skipped = nbig = 0
 for case in range(ncase):
-    big = rng.random() < 0.35
-    n = int(rng.integers(65, 201)) if big else int(rng.integers(9, 65))
+    big = rng.random() < PBIG
+    n = int(rng.integers(65, MAXN + 1)) if big else int(rng.integers(9, 65))
     kind = "gaussian" if rng.random() < 0.5 else "discrete"
     K = int(rng.integers(1, 6))
     tmax = int(rng.choice([30, 300, 700])) if big else int(rng.choice([40, 500, 4000]))
