@@ -20,6 +20,7 @@
 #include "plan.hpp"
 #include "gen_kernels.hpp"
 #include "tile_kernels.hpp"
+#include "big_kernels.hpp"
 
 namespace bhmm {
 int wide_plan_pub(bhmm_ctx *c, int which, int64_t seglen);
@@ -107,7 +108,19 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
                        c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
                        c->d_gW.p, (unsigned long long *)nullptr);
     BHMM_HIP(hipGetLastError());
-    // (NT row tiles: 5 .. 8 for 65 .. 128 states)
+    // xi counts: C' = alpha^T W over all time steps.  BHMM_AMD_XI_ROWS=1: round 4's kernel (one workgroup per
+    // time slab computes the whole n x n block, NT wavefronts); default: k_big_xi_gemm (128 x 128 blocks of
+    // 4 x 4 matrix tiles per wavefront, operands three K steps ahead)
+    // (up to 80 states the 128 x 128 blocks are mostly padding: 4.80 against 4.69 ms at 65 states, 4.23 against 4.63
+    // at 128 -- profiles/r05)
+    static const bool xi_rows_env = getenv("BHMM_AMD_XI_ROWS") != nullptr;
+    const bool xi_rows = xi_rows_env || n <= 80;
+    const int nsl = xi_rows ? nsplit : std::min(nsplit, 2 * c->num_simd / 4); // (two workgroups per compute unit)
+    if (!xi_rows) {
+        const int nb = (n + 127) / 128;
+        hipLaunchKernelGGL(k_big_xi_gemm, dim3(nb * nb * nsl), dim3(256), 0, c->stream, (const double *)c->d_alpha_rm.p,
+                           (const double *)c->d_gW.p, c->total, n, nb, nsl, c->d_gxipart.p);
+    } else
     switch ((n + 15) / 16) {
     case 5:
         hipLaunchKernelGGL((k_gen_xi_gemm_rows<5>), dim3(nsplit), dim3(320), 0, c->stream, (const double *)c->d_alpha_rm.p,
@@ -128,7 +141,7 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
     const int64_t nfin = (int64_t)n * n + n + (KIND == EMIT_GAUSS ? 2 * n : 0) +
                          (KIND == EMIT_DISC ? (int64_t)n * c->M : 0) + n + 1;
     hipLaunchKernelGGL((k_tile_finalize_xig<KIND>), dim3((unsigned)nfin), dim3(64), 0, c->stream, m, c->K, tp.ntiles,
-                       nsplit, (const double *)c->d_gxipart.p, (const double *)c->d_partials.p,
+                       nsl, (const double *)c->d_gxipart.p, (const double *)c->d_partials.p,
                        (const double *)c->d_dpartials.p, (const double *)c->d_logLk.p,
                        (const double *)c->d_gamma0.p, stats_dev);
     BHMM_HIP(hipGetLastError());

@@ -129,6 +129,32 @@ def test_bench_starts_its_own_ranks(launcher):
 
 
 @pytest.mark.gpu
+def test_bench_collective_path_on_rccl_with_one_rank(launcher):
+    """The driver launches `bench.py --gpus N` under torch.distributed.run with backend nccl (= RCCL).  A
+    one-GPU box can run that code path with ONE rank: RANK / WORLD_SIZE in the environment make the bench take
+    its distributed branch -- statistics into a device buffer, `all_reduce` on the engine's stream, one
+    non-blocking copy, the MIN / MAX comparison of the ranks' statistics, the max-over-ranks timing -- on RCCL,
+    and the line must equal the plain one-process run's."""
+    small = ["--steps", "2", "--warmup", "1", "--ntraj", "16", "--length", "30000", "--cpu-traj", "2",
+             "--no-secondary", "--no-steady"]
+    plain = _bench_line(launcher, 1, small)
+    import json
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small
+    r = launcher.run([cmd], timeout=900, env=env)[0]
+    assert r["rc"] == 0, r["out"]
+    line = [ln for ln in r["out"].splitlines() if ln.startswith('{"metric"')]
+    assert len(line) == 1, r["out"]
+    rccl = json.loads(line[0])
+    assert rccl["config"]["collective"] == "RCCL all-reduce" and rccl["config"]["allreduces_per_step"] == 1.0
+    assert rccl["statistics_identical_on_all_ranks"] is True and rccl["allreduce_plus_copy_ms"] > 0
+    assert abs(rccl["loglik"] - plain["loglik"]) <= 1e-13 * abs(plain["loglik"])
+    assert rccl["cpu_baseline"]["loglik_rel_diff_vs_gpu"] < 1e-9
+    assert rccl["roofline"]["alg_bytes_per_launch"] == plain["roofline"]["alg_bytes_per_launch"]
+
+
+@pytest.mark.gpu
 def test_bench_eight_rank_dry_run(launcher):
     """The 8-GPU job of BASELINE configs[2] before an 8-GPU node exists: `bench.py --gpus 8
     --oversubscribe` (eight ranks sharing this box's GPU, the sum over gloo -- everything else is the
