@@ -650,7 +650,8 @@ def secondary_c4(torch, dev, local, args):
            "self_checks_fired": int(eng.get_option("wide_trouble")),
            "spec": {k: eng.get_option(k) for k in ("spec_W", "spec_ok", "spec_fail", "spec_last_dev")}}
     # the other two passes of the path on this shape: both run over time segments (round 4) and are
-    # accepted only as the serial run's result (bitwise boundary vectors / coupled draws)
+    # exact by construction: Viterbi is accepted only with bitwise-identical boundary vectors; the draw is the
+    # serial draw GIVEN its alpha rows, which come from the segmented forward pass verified to 1e-11
     pdev = torch.empty(K * T, dtype=torch.uint8, device=dev)
     for _ in range(5):                 # (the Viterbi pass searches its own warm-up over the first calls)
         eng.viterbi_u8(*margs, out=pdev)
