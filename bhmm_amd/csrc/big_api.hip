@@ -84,10 +84,13 @@ int big_bwd_t(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
     return BHMM_OK;
 }
 
-// (column tiles per wavefront: 3, 4, 6, 8 for up to 192, 256, 384, 512 states)
+// (column tiles per wavefront: 3, 4, 5, 6, 8 for up to 192, 256, 320, 384, 512 states; seven -- 448 states --
+// was measured: its backward kernel needs a ring of seven blocks and spills, 22.9 ms against 20.1 on the
+// 512-state kernel at 400 states, 128 x 4000)
 #define BIG_TPW(fn, KINDV, ...)                                              \
     (c->n <= 192   ? fn<3, KINDV>(__VA_ARGS__)                               \
      : c->n <= 256 ? fn<4, KINDV>(__VA_ARGS__)                               \
+     : c->n <= 320 ? fn<5, KINDV>(__VA_ARGS__)                               \
      : c->n <= 384 ? fn<6, KINDV>(__VA_ARGS__)                               \
                    : fn<8, KINDV>(__VA_ARGS__))
 #define BIG_DISPATCH(fn, ...)                                                \

@@ -66,7 +66,10 @@ struct BigGeo {
 // (vmcnt): with the ring refilled at the top of a step, its first matrix instruction waited for the
 // previous step's stores to reach HBM (~7 of 11 us per step at 256 states, profiles/r05).
 template <int TPW>
-constexpr int big_ring() { return BigGeo<TPW>::NBLK % 4 == 0 ? 4 : 3; } // (divides the block count: slots wrap)
+constexpr int big_ring() // (divides the block count, so that the slots wrap with the blocks)
+{
+    return BigGeo<TPW>::NBLK % 4 == 0 ? 4 : (BigGeo<TPW>::NBLK % 3 == 0 ? 3 : (BigGeo<TPW>::NBLK % 5 == 0 ? 5 : 7));
+}
 
 template <int TPW>
 struct BigRing {
@@ -100,6 +103,12 @@ __device__ __forceinline__ void big_prime(BigRing<TPW> &ring, const double *__re
         big_issue<TPW, 1>(ring, Bp, w, lane);
     if constexpr (big_ring<TPW>() > 3)
         big_issue<TPW, 2>(ring, Bp, w, lane);
+    if constexpr (big_ring<TPW>() > 4)
+        big_issue<TPW, 3>(ring, Bp, w, lane);
+    if constexpr (big_ring<TPW>() > 5)
+        big_issue<TPW, 4>(ring, Bp, w, lane);
+    if constexpr (big_ring<TPW>() > 6)
+        big_issue<TPW, 5>(ring, Bp, w, lane);
 }
 
 // tile[16 x NP] (LDS buffer X) times the streamed matrix Bp: acc[c] = column tile w + 4 c of the product
