@@ -88,7 +88,8 @@ int big_bwd_t(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
 // was measured: its backward kernel needs a ring of seven blocks and spills, 22.9 ms against 20.1 on the
 // 512-state kernel at 400 states, 128 x 4000)
 #define BIG_TPW(fn, KINDV, ...)                                              \
-    (c->n <= 192   ? fn<3, KINDV>(__VA_ARGS__)                               \
+    (c->n <= 128   ? fn<2, KINDV>(__VA_ARGS__)                               \
+     : c->n <= 192 ? fn<3, KINDV>(__VA_ARGS__)                               \
      : c->n <= 256 ? fn<4, KINDV>(__VA_ARGS__)                               \
      : c->n <= 320 ? fn<5, KINDV>(__VA_ARGS__)                               \
      : c->n <= 384 ? fn<6, KINDV>(__VA_ARGS__)                               \

@@ -274,7 +274,12 @@ __global__ __launch_bounds__(256) void k_big_fwd(const WideModel m, const double
             }
         }
     };
-    double ll[4] = {0.0, 0.0, 0.0, 0.0};
+    double *arow[4]; // alpha row of my rows at the current step (running pointers: no 64-bit multiply per store)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        arow[r] = alpha_rm + ob[r] * n;
+    double lm[4] = {1.0, 1.0, 1.0, 1.0}; // log-likelihood of my rows: product of the c_t, mantissa ...
+    int le[4] = {0, 0, 0, 0};            // ... and exponent
     unsigned int trouble = 0u;
     BigObs<KIND> cur, nxt;
     obs_at(cur, 0);
@@ -310,10 +315,16 @@ __global__ __launch_bounds__(256) void k_big_fwd(const WideModel m, const double
             const double cs = (sS[rho] + sS[16 + rho]) + (sS[32 + rho] + sS[48 + rho]); // c_t, _hidden.c:53-56
             const bool act = rs < nst[r], mainp = act && rs >= r0[r];
             trouble |= (act && !(cs > 0x1p-1000 && cs < 0x1p1000)) ? 1u : 0u;
-            const double inv = act ? 1.0 / cs : 0.0;
+            const double inv = act ? fast_rcp(cs) : 0.0; // (1 ulp; the IEEE division sequence is 30 instructions)
 #ifndef BIG_X_NOLOG
-            if (mainp && w == r && s == 0) // (wavefront w keeps the sums of the rows q + 4 w: one log per lane and step)
-                ll[r] += log(cs); // _hidden.c:57-66
+            // _hidden.c:57-66 sums log c_t; here the c_t of a row are multiplied up (mantissa in [0.5, 1) and
+            // exponent apart: no range to leave) and the logarithm is taken once at the end -- the whole
+            // wavefront would execute log() at every step for four lanes' sake
+            if (mainp) {
+                int e;
+                lm[r] = frexp(lm[r] * cs, &e);
+                le[r] += e;
+            }
 #endif
 #pragma unroll
             for (int c = 0; c < TPW; ++c) {
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256) void k_big_fwd(const WideModel m, const double
                 if (real[c] && act) {
                     if (mainp) {
 #ifndef BIG_X_NOSTORE
-                        alpha_rm[(ob[r] + rs) * n + j] = a;
+                        arow[r][16 * (w + 4 * c) + s] = a; // (= alpha_rm[(ob[r] + rs) * n + j])
 #endif
                     }
                     else if (rs == r0[r] - 1)
@@ -334,13 +345,16 @@ __global__ __launch_bounds__(256) void k_big_fwd(const WideModel m, const double
             }
         }
         cur = nxt;
-        __syncthreads();
-    }
-    if (s == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (w == r && seg[r] >= 0)
-                logL_seg[seg[r]] = ll[r];
+            arow[r] += n;
+        __syncthreads();
+    }
+    if (s == 0 && w == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (seg[r] >= 0)
+                logL_seg[seg[r]] = log(lm[r]) + (double)le[r] * 0.693147180559945309417232121458;
     }
     if (trouble)
         atomicOr(&flags[2], trouble);
@@ -534,7 +548,7 @@ __global__ __launch_bounds__(256) void k_big_bwd(const WideModel m, const double
             trouble |= (act && !(Sb > 0x1p-1000 && Sb < 0x1p1000)) ? 2u : 0u;
             trouble |= (mainp[r] && !(Sg > 0x1p-1000 && Sg < 0x1p1000)) ? 4u : 0u;
             trouble |= (trans && !(SS > 0x1p-1000 && SS < 0x1p1000)) ? 8u : 0u;
-            const double ig = mainp[r] ? 1.0 / Sg : 0.0, ib = act ? 1.0 / Sb : 0.0, iS = trans ? 1.0 / SS : 0.0;
+            const double ig = mainp[r] ? fast_rcp(Sg) : 0.0, ib = act ? fast_rcp(Sb) : 0.0, iS = trans ? fast_rcp(SS) : 0.0;
             const int64_t grow = (gtop[r] - us) * n;
 #pragma unroll
             for (int c = 0; c < TPW; ++c) {

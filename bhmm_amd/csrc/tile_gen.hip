@@ -33,6 +33,13 @@ bool tile_gen_capable(const bhmm_ctx *c) { return c->tile_latched && c->gen && c
 
 namespace {
 
+// above this many states the kernels of big_kernels.hpp run the E-step (BHMM_AMD_BIG_FROM: experiments)
+static int big_from()
+{
+    static const int v = getenv("BHMM_AMD_BIG_FROM") ? atoi(getenv("BHMM_AMD_BIG_FROM")) : 128;
+    return v;
+}
+
 int64_t max_len(const bhmm_ctx *c)
 {
     int64_t maxT = 0;
@@ -54,7 +61,7 @@ int plan_for(bhmm_ctx *c, int W)
     // (more than 128 states: a step is tens of microseconds of matrix instructions and there are seldom enough
     // segments for every compute unit -- filling the chip is worth more than short warm-ups relative to the
     // segments: half a warm-up is long enough there)
-    const int64_t wmin = c->n > 128 ? std::max<int64_t>(W / 2, 32) : 2 * (int64_t)W;
+    const int64_t wmin = c->n > big_from() ? std::max<int64_t>(W / 2, 32) : 2 * (int64_t)W;
     int64_t seglen = c->wseg_len > 0 ? (int64_t)c->wseg_len : std::max<int64_t>(fill_len(c), wmin);
     seglen = std::max(seglen, c->wseg_cur_len); // never more segments than allocated for
     if (seglen >= max_len(c))
@@ -153,7 +160,7 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
      : c->kind == EMIT_DISC ? (c->n <= 96 ? fn<6, EMIT_DISC>(__VA_ARGS__) : fn<8, EMIT_DISC>(__VA_ARGS__))   \
                             : (c->n <= 96 ? fn<6, EMIT_EXPL>(__VA_ARGS__) : fn<8, EMIT_EXPL>(__VA_ARGS__)))
 // (more than 128 states: big_api.hip)
-#define TILE_GEN_DISPATCH(fn, ...) (c->n > 128 ? big_##fn(__VA_ARGS__) : TILE_GEN_DISPATCH_128(fn, __VA_ARGS__))
+#define TILE_GEN_DISPATCH(fn, ...) (c->n > big_from() ? big_##fn(__VA_ARGS__) : TILE_GEN_DISPATCH_128(fn, __VA_ARGS__))
 
 // boundary check of one direction (0 forward, 1 backward): flags -> host
 int run_check(bhmm_ctx *c, int dir)
@@ -256,7 +263,7 @@ int tile_gen_alloc(bhmm_ctx *c)
     int64_t nsmax = c->K;
     for (int k = 0; k < c->K; ++k)
         nsmax += (c->offsets[k + 1] - c->offsets[k]) / std::max<int64_t>(minlen & ~(int64_t)3, 4) + 1;
-    const size_t S = (n > 128 ? 0 : (size_t)n * n) + 3 * n; // (big_kernels.hpp: the counts come from the xi GEMM)
+    const size_t S = (size_t)n * n + 3 * n;
     const size_t ntmax = (size_t)nsmax / 16 + 3;
     if ((rc = c->d_wlogLseg.ensure(nsmax)) || (rc = c->d_wePseg.ensure(nsmax)) ||
         (rc = c->d_waentry.ensure((size_t)nsmax * n)) || (rc = c->d_waexit.ensure((size_t)nsmax * n)) ||
