@@ -654,6 +654,16 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
         BHMM_HIP(hipGetLastError());
         BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 3 * sizeof(unsigned int),
                                 hipMemcpyDeviceToHost, c->stream));
+        // the statistics (and, for moderately many trajectories, the log-likelihoods) travel with the verdict
+        // words: ONE host round trip per verified E-step -- bhmm_estep_fetch finds them in the pinned buffer
+        const int S = bhmm_ctx_stats_size(c);
+        const bool pre = stats_dev && c->h_pinned && c->h_pinned_n >= (size_t)S + (size_t)c->K;
+        if (pre) {
+            BHMM_HIP(hipMemcpyAsync(c->h_pinned, stats_dev, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            if (c->K <= 4096)
+                BHMM_HIP(hipMemcpyAsync(c->h_pinned + S, c->d_logLk.p, (size_t)c->K * sizeof(double),
+                                        hipMemcpyDeviceToHost, c->stream));
+        }
         BHMM_HIP(hipStreamSynchronize(c->stream));
         if (lazy)
             c->wide_trouble = c->h_specres[2];
@@ -700,6 +710,10 @@ int wide_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
                     Wn = std::max(16, ((int)ceil(c->spec_W * (1.0 + 0.5 * dec / 12.5)) + 7) / 8 * 8);
                 if ((int64_t)Wn <= c->wseg_cur_len) // (a warm-up may be as long as a segment; beyond: re-plan below)
                     c->spec_W = Wn;
+            }
+            if (pre) {
+                c->prefetched = true;
+                c->logLk_prefetched = c->K <= 4096;
             }
             return BHMM_OK;
         }
