@@ -159,3 +159,35 @@ def test_big_forward_pass_feeds_the_backward_draw():
         po = orc.pobs_gaussian(o, mu, sig)
         assert np.array_equal(p, orc.sample_path(orc.forward(A, po, pi)[1], A, u=uu))
     eng.close()
+
+
+def test_em_and_gibbs_run_on_the_big_kernels():
+    """MaximumLikelihoodEstimator / BayesianHMMSampler with 160 Gaussian states: every E-step of the EM run
+    stays on the matrix-core kernels of big_kernels.hpp (time-segmented), the likelihood rises, and the
+    log-likelihood of every iteration equals the oracle's for the model that iteration was evaluated with."""
+    import bhmm_amd
+    from bhmm_amd.engine import Engine
+    n = 160
+    rng = np.random.default_rng(21)
+    A, pi, mu, sig = _model(n, rng, "gaussian")
+    obs = [rng.normal(0, 4.5, T) for T in (1500, 700, 300)]
+    init = bhmm_amd.gaussian_hmm(pi, A, mu, sig)
+    est = bhmm_amd.MaximumLikelihoodEstimator(obs, n, initial_model=init, reversible=False, maxit=5, accuracy=-1.0)
+    est._engine.set_option("wide_segment_len", 150)
+    est._engine.set_observations("gaussian", obs, n)      # (re-plan with the shorter segments)
+    models, lls = [], []
+    for _ in range(4):
+        h = est.hmm
+        models.append((h.transition_matrix.copy(), h.initial_distribution.copy(),
+                       h.output_model.means.copy(), h.output_model.sigmas.copy()))
+        lls.append(est.em_step())
+        assert est._engine.get_option("tile") == 1 and est._engine.get_option("wide_trouble") == 0
+        assert est._engine.get_option("wide_segments") > len(obs)
+    assert np.all(np.diff(lls) > 0)
+    for (Am, pim, mum, sgm), ll in zip(models, lls):
+        ref = orc.estep("gaussian", obs, Am, pim, mum, sgm)
+        np.testing.assert_allclose(ll, ref["logL"].sum(), rtol=1e-11)
+    smp = bhmm_amd.BayesianHMMSampler(obs, n, initial_model=est.hmm, reversible=False)
+    ms = smp.sample(2, seed=5)
+    assert len(ms) == 2
+    np.testing.assert_allclose(ms[-1].transition_matrix.sum(axis=1), 1.0, rtol=1e-12)
