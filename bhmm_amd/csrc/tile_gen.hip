@@ -109,12 +109,32 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
         return rc;
     hipLaunchKernelGGL(k_wide_zero_last_rows, dim3(c->K), dim3(64), 0, c->stream, (const int64_t *)c->d_offsets.p,
                        c->K, n, c->d_gW.p);
+    // BHMM_AMD_TILE_PROBE=1: cycles of the phases of a step (last workgroup, wavefront 0), printed after the pass
+    static const bool probe_on = getenv("BHMM_AMD_TILE_PROBE") != nullptr && atoi(getenv("BHMM_AMD_TILE_PROBE")) == 1;
+    unsigned long long *probe = nullptr;
+    if (probe_on) {
+        if ((rc = c->d_probe.ensure(4096)))
+            return rc;
+        probe = reinterpret_cast<unsigned long long *>(c->d_probe.p) + 16;
+        BHMM_HIP(hipMemsetAsync(probe, 0, 128, c->stream));
+    }
     hipLaunchKernelGGL((k_tile_bwd<NT, KIND, false, true, false>), dim3(tp.ntiles), dim3(tile_threads<false>()), 0,
                        c->stream, m, (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
                        (const double *)c->d_alpha_rm.p, (const int32_t *)c->d_wexp.p, gam, c->d_gamma0.p,
                        c->d_partials.p, c->d_dpartials.p, c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p,
-                       c->d_gW.p, (unsigned long long *)nullptr);
+                       c->d_gW.p, probe);
     BHMM_HIP(hipGetLastError());
+    if (probe_on) {
+        unsigned long long h[16];
+        BHMM_HIP(hipMemcpyAsync(h, probe, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        for (int o = 0; o < 16; o += 8)
+            if (h[o + 4])
+                fprintf(stderr, "tile bwd<%d> probe (%s steps): operands+matrix %.0f | rescale, x' write %.0f | W rows, statistics %.0f | "
+                                "stream part + barrier %.0f cycles/step (%llu steps)\n", NT, o ? "main" : "warm-up",
+                        (double)h[o] / h[o + 4], (double)h[o + 1] / h[o + 4], (double)h[o + 2] / h[o + 4],
+                        (double)h[o + 3] / h[o + 4], h[o + 4]);
+    }
     // xi counts: C' = alpha^T W over all time steps.  BHMM_AMD_XI_ROWS=1: round 4's kernel (one workgroup per
     // time slab computes the whole n x n block, NT wavefronts); default: k_big_xi_gemm (128 x 128 blocks of
     // 4 x 4 matrix tiles per wavefront, operands three K steps ahead)

@@ -740,8 +740,12 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
     __syncthreads();
     // (volatile: these reads must stay where they are written -- hoisted out of the loops they would
     // occupy the registers this exists to free)
+    // (... and the LDS address space spelled out: through a generic volatile pointer every one of them is a flat
+    // load with s_waitcnt vmcnt(0) behind it, i.e. a drain of all global stores in flight -- 3 150 cycles per
+    // step of the W-row stores of 128 states, profiles/r05)
+    typedef const volatile __attribute__((address_space(3))) int tile_lds_cvint;
     auto meta = [&](int r, int k) __attribute__((always_inline)) {
-        return const_cast<const volatile int *>(sMeta)[8 * (q + 4 * r) + k];
+        return ((tile_lds_cvint *)sMeta)[8 * (q + 4 * r) + k];
     };
     auto meta_gtop = [&](int r) __attribute__((always_inline)) {
         return (int64_t)(((uint64_t)(uint32_t)meta(r, 7) << 32) | (uint32_t)meta(r, 6));

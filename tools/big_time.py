@@ -9,7 +9,7 @@ from bhmm_amd.engine import Engine
 dev = torch.device("cuda", 0)
 shapes = {129: (128, 4000), 192: (128, 4000), 256: (128, 4000), 300: (128, 4000), 384: (64, 4000), 512: (64, 2000)}
 for n in [int(a) for a in sys.argv[1:]] or [192, 256, 384, 512]:
-    K, T = shapes.get(n, (128, 4000))
+    K, T = shapes.get(n, (128, 10000 if n <= 128 else 4000))
     rng = np.random.default_rng(n)
     A = metastable_matrix(n, rng); pi = stationary(A)
     mu, sig = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
