@@ -342,9 +342,11 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
             for (int kk = k0; kk < k0 + CH; ++kk)
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
-                    if (NT % 4 == 0 || w + 4 * c < NT)
-                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[(kk - k0) >> 1][(kk - k0) & 1], Breg[c * KK + kk],
-                                                                      kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+                    // (a column tile beyond NT: its block of A is zero, the product is computed all the same -- the
+                    // wavefronts with two real tiles set the pace of the step, and a chain without branches keeps the
+                    // accumulators where they are: with the branch, 770 register moves per step at NT = 6)
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[(kk - k0) >> 1][(kk - k0) & 1], Breg[c * KK + kk],
+                                                                  kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
         }
         unsigned long long c1 = 0;
         if (pr) {
@@ -695,6 +697,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
 {
     using G = TileGeo<NT>;
     constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX, NP = G::NP;
+    static_assert(!(XIG && SPLIT), "the W rows are stored by the both-role wavefronts (w_store)");
     __shared__ __attribute__((aligned(16))) double sX[2 * 16 * PX];
     __shared__ __attribute__((aligned(16))) double sP[2 * 4 * TPW * 2 * 64 * 2];
     __shared__ __attribute__((aligned(16))) double sObs[16 * 16]; // observations of 16 steps: [step & 15][4 q + r]
@@ -832,7 +835,11 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
     };
     auto loadA = [&](ARow &a, int us) __attribute__((always_inline)) {
         // alpha_{t-1} from the last warm-up step on (it becomes alpha_t of the first main step)
+#ifdef TILE_X_NOLOADA
+        const bool wanta = false;
+#else
         const bool wanta = us + 1 >= s_nwarm && us < s_nst && s_ttop - us > 0;
+#endif
         const double *src = alpha_rm + s_abase - ((int64_t)us + 1) * n;
         if constexpr (FULL) {
 #pragma unroll
@@ -1173,6 +1180,35 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
         front_stats(0, tile_ic<TM_GEN>{}, fg, mainr, ol, a0);
     };
 
+    // XIG: W_{t-1} = (p_t o beta_t) fx of my row, my NP / 16 states of it -- the piece of the LDS tile and the
+    // address the alpha loads of the stream part use (one address per lane and step, 16-byte pieces), instead of
+    // eight scattered 8-byte stores per lane from the matrix layout
+    double fxs = 0.0;
+    auto w_store = [&](int us, auto uc, auto mc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
+#ifdef TILE_X_NOW
+        return;
+#endif
+        if constexpr (XIG && MODE != TM_WARM) {
+            const bool want = MODE == TM_MAIN || (us >= s_nwarm && us < s_nst && s_ttop - us > 0);
+            if (want) {
+                const double *Xs = sX + (u & 1) * 16 * PX + sxr;
+                double *dst = Wg + s_abase - ((int64_t)us + 1) * n;
+#pragma unroll
+                for (int e = 0; e < SPL; e += 2) {
+                    const tile_d2 x2 = *reinterpret_cast<const tile_d2 *>(Xs + e);
+                    if constexpr (FULL) {
+                        *reinterpret_cast<tile_d2 *>(dst + e) = tile_d2{x2[0] * fxs, x2[1] * fxs};
+                    } else {
+                        if (sch + e < n)
+                            dst[e] = x2[0] * fxs;
+                        if (sch + e + 1 < n)
+                            dst[e + 1] = x2[1] * fxs;
+                    }
+                }
+            }
+        }
+    };
     unsigned long long pc = 0; // (probe: end of the previous step's work)
     auto m_step = [&](int us, auto uc, auto mc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, MODE = decltype(mc)::value;
@@ -1212,9 +1248,11 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
             for (int kk = k0; kk < k0 + CH; ++kk)
 #pragma unroll
                 for (int c = 0; c < TPW; ++c)
-                    if (NT % 4 == 0 || w + 4 * c < NT)
-                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[(kk - k0) >> 1][(kk - k0) & 1], Breg[c * KK + kk],
-                                                                      kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
+                    // (a column tile beyond NT: its block of A is zero, the product is computed all the same -- the
+                    // wavefronts with two real tiles set the pace of the step, and a chain without branches keeps the
+                    // accumulators where they are: with the branch, 770 register moves per step at NT = 6)
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[(kk - k0) >> 1][(kk - k0) & 1], Breg[c * KK + kk],
+                                                                  kk == 0 ? wide_d4{0.0, 0.0, 0.0, 0.0} : acc[c], 0, 0, 0);
         }
         unsigned long long c1 = 0;
         if (pr) {
@@ -1313,14 +1351,9 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
                         }
                 }
             } else {
-                const int64_t usn = (int64_t)us * n;
-#pragma unroll
-                for (int c = 0; c < TPW; ++c)
-                    if (NT % 4 == 0 || w + 4 * c < NT)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (real[c] && mainr[r] && tt[r] > 0)
-                                Wg[meta_gtop(r) * n + 16 * (w + 4 * c) + s - usn - n] = X[xw[r] + 16 * (w + 4 * c) + s] * fx[r];
+                // (the rows W_{t-1} leave in the stream layout -- w_store below; row 4 w + q of that layout
+                // is register w of this lane)
+                fxs = w == 0 ? fx[0] : (w == 1 ? fx[1] : (w == 2 ? fx[2] : fx[3]));
             }
         }
 #endif
@@ -1392,6 +1425,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
         __syncthreads();
         run_all([&](int us, auto uc, auto mc, auto) __attribute__((always_inline)) {
             m_step(us, uc, mc);
+            w_store(us, uc, mc);
             s_step(us, uc);
             __syncthreads();
         });
