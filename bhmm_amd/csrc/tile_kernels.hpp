@@ -824,9 +824,14 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
     auto rmeta_gtop = [&](int row) __attribute__((always_inline)) {
         return (int64_t)(((uint64_t)(uint32_t)rmeta(row, 7) << 32) | (uint32_t)rmeta(row, 6));
     };
-    // ---- alpha_{t-1}: my row and my NP / 16 states of it
+    // ---- alpha_{t-1}: my row and my NP / 16 states of it.  FULL: SPL consecutive states.  Otherwise pairs of
+    // states, pair e / 2 at 2 (lane & 15) + 16 e: sixteen lanes on 256 consecutive bytes of a row, one 16-byte
+    // access per pair when n is even (a pair is then inside the row or outside it, and every row starts on a
+    // 16-byte boundary), two 8-byte ones when it is odd
     constexpr int SPL = NP / 16;
-    const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * SPL;
+    const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * (FULL ? SPL : 2);
+    auto spos = [&](int e) __attribute__((always_inline)) { return FULL ? e : 16 * e; }; // (e even)
+    const bool n_even = FULL || (n & 1) == 0;
     const int s_nwarm = rmeta(srow, 1), s_nst = rmeta(srow, 2), s_ttop = rmeta(srow, 4);
     const int64_t s_abase = rmeta_gtop(srow) * n + sch;
     const int sxr = tile_prow(srow) * PX + sch;
@@ -841,24 +846,27 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
         const bool wanta = us + 1 >= s_nwarm && us < s_nst && s_ttop - us > 0;
 #endif
         const double *src = alpha_rm + s_abase - ((int64_t)us + 1) * n;
-        if constexpr (FULL) {
+        if (n_even) {
 #pragma unroll
             for (int e = 0; e < SPL; e += 2) {
-                const tile_d2 t2 = wanta ? *reinterpret_cast<const tile_d2 *>(src + e) : tile_d2{0.0, 0.0};
+                const bool in = wanta && (FULL || sch + spos(e) < n);
+                const tile_d2 t2 = in ? *reinterpret_cast<const tile_d2 *>(src + spos(e)) : tile_d2{0.0, 0.0};
                 a.v[e] = t2[0];
                 a.v[e + 1] = t2[1];
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < SPL; ++e)
-                a.v[e] = (wanta && sch + e < n) ? src[e] : 0.0;
+            for (int e = 0; e < SPL; e += 2) {
+                a.v[e] = (wanta && sch + spos(e) < n) ? src[spos(e)] : 0.0;
+                a.v[e + 1] = (wanta && sch + spos(e) + 1 < n) ? src[spos(e) + 1] : 0.0;
+            }
         }
     };
     auto a_to_lds = [&](const ARow &a, int slot) __attribute__((always_inline)) {
         double *dst = sAl + slot * 16 * PX + sxr;
 #pragma unroll
         for (int e = 0; e < SPL; e += 2)
-            *reinterpret_cast<tile_d2 *>(dst + e) = tile_d2{a.v[e], a.v[e + 1]};
+            *reinterpret_cast<tile_d2 *>(dst + spos(e)) = tile_d2{a.v[e], a.v[e + 1]};
     };
     // ---- the exponent the forward pass removed at time t (wavefront 5, one lane per row)
     const int xrow = lane & 15;
@@ -1194,16 +1202,21 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
             if (want) {
                 const double *Xs = sX + (u & 1) * 16 * PX + sxr;
                 double *dst = Wg + s_abase - ((int64_t)us + 1) * n;
+                if (n_even) {
 #pragma unroll
-                for (int e = 0; e < SPL; e += 2) {
-                    const tile_d2 x2 = *reinterpret_cast<const tile_d2 *>(Xs + e);
-                    if constexpr (FULL) {
-                        *reinterpret_cast<tile_d2 *>(dst + e) = tile_d2{x2[0] * fxs, x2[1] * fxs};
-                    } else {
-                        if (sch + e < n)
-                            dst[e] = x2[0] * fxs;
-                        if (sch + e + 1 < n)
-                            dst[e + 1] = x2[1] * fxs;
+                    for (int e = 0; e < SPL; e += 2) {
+                        const tile_d2 x2 = *reinterpret_cast<const tile_d2 *>(Xs + spos(e));
+                        if (FULL || sch + spos(e) < n)
+                            *reinterpret_cast<tile_d2 *>(dst + spos(e)) = tile_d2{x2[0] * fxs, x2[1] * fxs};
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < SPL; e += 2) {
+                        const tile_d2 x2 = *reinterpret_cast<const tile_d2 *>(Xs + spos(e));
+                        if (sch + spos(e) < n)
+                            dst[spos(e)] = x2[0] * fxs;
+                        if (sch + spos(e) + 1 < n)
+                            dst[spos(e) + 1] = x2[1] * fxs;
                     }
                 }
             }
