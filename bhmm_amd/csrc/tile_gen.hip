@@ -116,7 +116,7 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
         if ((rc = c->d_probe.ensure(4096)))
             return rc;
         probe = reinterpret_cast<unsigned long long *>(c->d_probe.p) + 16;
-        BHMM_HIP(hipMemsetAsync(probe, 0, 128, c->stream));
+        BHMM_HIP(hipMemsetAsync(probe, 0, 48 * 8, c->stream));
     }
     hipLaunchKernelGGL((k_tile_bwd<NT, KIND, false, true, false>), dim3(tp.ntiles), dim3(tile_threads<false>()), 0,
                        c->stream, m, (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
@@ -125,9 +125,18 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
                        c->d_gW.p, probe);
     BHMM_HIP(hipGetLastError());
     if (probe_on) {
-        unsigned long long h[16];
+        unsigned long long h[48];
         BHMM_HIP(hipMemcpyAsync(h, probe, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         BHMM_HIP(hipStreamSynchronize(c->stream));
+#ifdef TILE_X_PROBE_REGS
+        for (int o = 0; o < 2; ++o)
+            if (h[32 + 8 * o + 4])
+                fprintf(stderr, "tile bwd<%d> phases (%s steps): matrix part %.0f | W rows %.0f | stream part %.0f | barrier %.0f "
+                                "cycles/step (%llu steps)\n", NT, o ? "main / general" : "warm-up",
+                        (double)h[32 + 8 * o] / h[32 + 8 * o + 4], (double)h[32 + 8 * o + 1] / h[32 + 8 * o + 4],
+                        (double)h[32 + 8 * o + 2] / h[32 + 8 * o + 4], (double)h[32 + 8 * o + 3] / h[32 + 8 * o + 4],
+                        h[32 + 8 * o + 4]);
+#endif
         for (int o = 0; o < 16; o += 8)
             if (h[o + 4])
                 fprintf(stderr, "tile bwd<%d> probe (%s steps): operands+matrix %.0f | rescale, x' write %.0f | W rows, statistics %.0f | "

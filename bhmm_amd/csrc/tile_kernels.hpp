@@ -1241,7 +1241,11 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
                 lastr[r] = us == meta(r, 2) - 1 && tt[r] > 0; // the transition into the segment
             }
         }
+#ifdef TILE_X_PROBE_REGS
+        const bool pr = false;
+#else
         const bool pr = probe && blockIdx.x == gridDim.x - 1 && wid == 0;
+#endif
         const unsigned long long c0 = pr ? __builtin_readcyclecounter() : 0;
         AIn in;
         fetch_a(u & 1, in);
@@ -1436,12 +1440,44 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
         __syncthreads();
         m_prologue();
         __syncthreads();
+#ifdef TILE_X_PROBE_REGS
+        // (variant builds only: phase times of the both-role wavefront 0 of the last workgroup, summed in
+        // registers -- the run-time probe above adds to global memory in every step, and the wait that needs
+        // drains the step's stores)
+        unsigned long long pa[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+        const bool prr = probe && blockIdx.x == gridDim.x - 1 && wid == 0;
+        run_all([&](int us, auto uc, auto mc, auto) __attribute__((always_inline)) {
+            constexpr int o = decltype(mc)::value == TM_WARM ? 0 : 1;
+            const unsigned long long t0 = prr ? __builtin_readcyclecounter() : 0;
+            m_step(us, uc, mc);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t1 = prr ? __builtin_readcyclecounter() : 0;
+            w_store(us, uc, mc);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t2 = prr ? __builtin_readcyclecounter() : 0;
+            s_step(us, uc);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t3 = prr ? __builtin_readcyclecounter() : 0;
+            __syncthreads();
+            const unsigned long long t4 = prr ? __builtin_readcyclecounter() : 0;
+            pa[o][0] += t1 - t0;
+            pa[o][1] += t2 - t1;
+            pa[o][2] += t3 - t2;
+            pa[o][3] += t4 - t3;
+            pa[o][4] += 1;
+        });
+        if (prr && lane == 0)
+            for (int o = 0; o < 2; ++o)
+                for (int i = 0; i < 5; ++i)
+                    probe[32 + 8 * o + i] = pa[o][i];
+#else
         run_all([&](int us, auto uc, auto mc, auto) __attribute__((always_inline)) {
             m_step(us, uc, mc);
             w_store(us, uc, mc);
             s_step(us, uc);
             __syncthreads();
         });
+#endif
     }
 
     // ---- self-check: unit gamma mass per step of every row -------------------------------------
