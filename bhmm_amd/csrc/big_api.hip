@@ -74,7 +74,7 @@ int big_bwd_t(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
                        (const double *)c->d_alpha_rm.p, gam, c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p,
                        c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p, c->d_gW.p);
     BHMM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_big_xi_gemm, dim3(nb * nb * nsplit), dim3(256), 0, c->stream, (const double *)c->d_alpha_rm.p,
+    hipLaunchKernelGGL(k_big_xi_gemm<4>, dim3(nb * nb * nsplit), dim3(256), 0, c->stream, (const double *)c->d_alpha_rm.p,
                        (const double *)c->d_gW.p, c->total, n, nb, nsplit, c->d_gxipart.p);
     hipLaunchKernelGGL((k_big_finalize<KIND>), dim3(4096), dim3(64), 0, c->stream, m, c->K, tp.ntiles, nsplit,
                        (const double *)c->d_gxipart.p, (const double *)c->d_partials.p,

@@ -606,12 +606,14 @@ __global__ __launch_bounds__(256) void k_big_bwd(const WideModel m, const double
 // =========================================================================================
 // k_big_xi_gemm: C' = alpha^T W over all time steps (the xi counts of _hidden.c:148-183 up to the factor
 // A[i][j], W_t = p_{t+1} o beta_{t+1} / S_t as k_big_bwd left them; W of a trajectory's last step is zero).
-// Workgroup (bi, bj, slab): the 128 x 128 block (bi, bj) of C' over time slab `slab`; wavefront (wi, wj) its
-// 64 x 64 quarter as 4 x 4 tiles of v_mfma_f64_16x16x4 -- K = four consecutive time steps, the operands
+// Workgroup (bi, bj, slab): the 32 TI x 32 TI block (bi, bj) of C' over time slab `slab` (TI = 4: 128 x 128;
+// TI = 3: 96 x 96, for 65 .. 96 states, where the larger block is mostly padding); wavefront (wi, wj) its
+// quarter as TI x TI tiles of v_mfma_f64_16x16x4 -- K = four consecutive time steps, the operands
 // straight from HBM in operand order (lane (s, q): row t + q, state 16 I + s: 128 contiguous bytes per
 // sixteen lanes), three K steps ahead.  Every row of alpha and W is read ceil(n / 128) times in all.
 //   xipart [slab][n][n]   (summed in slab order by k_big_finalize)
 // =========================================================================================
+template <int TI>
 [[maybe_unused]] static __global__ __launch_bounds__(256) void k_big_xi_gemm(const double *__restrict__ alpha,
                                                                            const double *__restrict__ W, int64_t total,
                                                                            int n, int nb, int nsplit, double *xipart)
@@ -619,29 +621,29 @@ __global__ __launch_bounds__(256) void k_big_bwd(const WideModel m, const double
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
     const int blk = blockIdx.x % (nb * nb), slab = blockIdx.x / (nb * nb);
-    const int i0 = 128 * (blk / nb) + 64 * (wv >> 1), j0 = 128 * (blk % nb) + 64 * (wv & 1);
+    const int i0 = 32 * TI * (blk / nb) + 16 * TI * (wv >> 1), j0 = 32 * TI * (blk % nb) + 16 * TI * (wv & 1);
     // time slab, a multiple of four steps
     const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~(int64_t)3;
     const int64_t tb = (int64_t)slab * per, te = tb + per < total ? tb + per : total;
-    wide_d4 acc[4][4];
+    wide_d4 acc[TI][TI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TI; ++j)
             acc[i][j] = wide_d4{0.0, 0.0, 0.0, 0.0};
-    bool ci[4], cj[4];
+    bool ci[TI], cj[TI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TI; ++i) {
         ci[i] = i0 + 16 * i + s < n;
         cj[i] = j0 + 16 * i + s < n;
     }
     constexpr int PF = 3;
-    double ra[PF + 1][4], rb[PF + 1][4];
+    double ra[PF + 1][TI], rb[PF + 1][TI];
     auto load = [&](int slot, int64_t t) __attribute__((always_inline)) {
         const bool in = t + q < te;
         const double *pa = alpha + (t + q) * n + i0 + s, *pb = W + (t + q) * n + j0 + s;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TI; ++i) {
             ra[slot][i] = (in && ci[i]) ? pa[16 * i] : 0.0;
             rb[slot][i] = (in && cj[i]) ? pb[16 * i] : 0.0;
         }
@@ -653,9 +655,9 @@ __global__ __launch_bounds__(256) void k_big_bwd(const WideModel m, const double
         constexpr int u = decltype(uc)::value;
         load((u + PF) & 3, t + 4 * PF);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TI; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[u][i], rb[u][j], acc[i][j], 0, 0, 0);
     };
     for (int64_t t = tb; t < te; t += 16) { // (four K steps per round: the ring slots are compile-time)
@@ -666,9 +668,9 @@ __global__ __launch_bounds__(256) void k_big_bwd(const WideModel m, const double
     }
     double *out = xipart + (int64_t)slab * n * n;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + 16 * i + q + 4 * r, col = j0 + 16 * j + s; // (C/D layout)

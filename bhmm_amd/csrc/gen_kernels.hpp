@@ -482,17 +482,21 @@ __global__ __launch_bounds__(64 * NT) void k_gen_xi_gemm_rows(const double *alph
         for (int J = 0; J < NT; ++J)
             b[J] = (live && 16 * J + li < n) ? W[tt * n + 16 * J + li] : 0.0;
     };
-    double a, b[NT], an, bn[NT];
-    fetch(tb, a, b);
-    for (int64_t t = tb; t < te; t += 4) {
-        fetch(t + 4, an, bn); // (the next four steps' operands are on their way while these multiply)
+    // operands of the next three groups of four steps on their way while one group multiplies (round 5: with one
+    // group ahead the kernel waited for memory two thirds of the time -- 620 us at 65 states, 128 x 10 000)
+    constexpr int XPF = 4;
+    double a[XPF], b[XPF][NT];
 #pragma unroll
-        for (int J = 0; J < NT; ++J)
-            acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[J], acc[J], 0, 0, 0);
-        a = an;
+    for (int u = 0; u < XPF - 1; ++u)
+        fetch(tb + 4 * u, a[u], b[u]);
+    for (int64_t t = tb; t < te; t += 4 * XPF) {
 #pragma unroll
-        for (int J = 0; J < NT; ++J)
-            b[J] = bn[J];
+        for (int u = 0; u < XPF; ++u) {
+            fetch(t + 4 * (u + XPF - 1), a[(u + XPF - 1) % XPF], b[(u + XPF - 1) % XPF]); // (beyond te: zeros, no loads)
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+                acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][J], acc[J], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int J = 0; J < NT; ++J)

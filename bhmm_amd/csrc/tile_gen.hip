@@ -150,12 +150,15 @@ int launch_bwd(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
     // (up to 80 states the 128 x 128 blocks are mostly padding: 4.80 against 4.69 ms at 65 states, 4.23 against 4.63
     // at 128 -- profiles/r05)
     static const bool xi_rows_env = getenv("BHMM_AMD_XI_ROWS") != nullptr;
-    const bool xi_rows = xi_rows_env || n <= 80;
+    const bool xi_rows = xi_rows_env;
     const int nsl = xi_rows ? nsplit : std::min(nsplit, 2 * c->num_simd / 4); // (two workgroups per compute unit)
     if (!xi_rows) {
-        const int nb = (n + 127) / 128;
-        hipLaunchKernelGGL(k_big_xi_gemm, dim3(nb * nb * nsl), dim3(256), 0, c->stream, (const double *)c->d_alpha_rm.p,
-                           (const double *)c->d_gW.p, c->total, n, nb, nsl, c->d_gxipart.p);
+        if (n <= 96) // (one 96 x 96 block, 3 x 3 tiles per wavefront)
+            hipLaunchKernelGGL(k_big_xi_gemm<3>, dim3(nsl), dim3(256), 0, c->stream, (const double *)c->d_alpha_rm.p,
+                               (const double *)c->d_gW.p, c->total, n, 1, nsl, c->d_gxipart.p);
+        else
+            hipLaunchKernelGGL(k_big_xi_gemm<4>, dim3(nsl), dim3(256), 0, c->stream, (const double *)c->d_alpha_rm.p,
+                               (const double *)c->d_gW.p, c->total, n, 1, nsl, c->d_gxipart.p);
     } else
     switch ((n + 15) / 16) {
     case 5:
