@@ -81,11 +81,30 @@ int launch_fwd(bhmm_ctx *c, const WideModel &m)
     // up to 96 states the forward kernel fits the eight-wavefront form (matrix + stream wavefronts, 225
     // registers); the backward kernel does not (it would spill 440 registers), nor does either at 128
     constexpr bool FWD_SPLIT = true;
+    static const bool probe_on = getenv("BHMM_AMD_TILE_PROBE") != nullptr && atoi(getenv("BHMM_AMD_TILE_PROBE")) == 1;
+    unsigned long long *probe = nullptr;
+    if (probe_on) {
+        int rc = c->d_probe.ensure(4096);
+        if (rc)
+            return rc;
+        probe = reinterpret_cast<unsigned long long *>(c->d_probe.p);
+        BHMM_HIP(hipMemsetAsync(probe, 0, 64, c->stream));
+    }
     hipLaunchKernelGGL((k_tile_fwd<NT, KIND, false, FWD_SPLIT>), dim3(tp.ntiles), dim3(tile_threads<FWD_SPLIT>()), 0,
                        c->stream, m, (const int64_t *)c->d_offsets.p, sg, tp, (const void *)c->d_obs_rm.p,
                        c->d_alpha_rm.p, c->d_wexp.p, c->d_wePseg.p, c->d_waentry.p, c->d_waexit.p,
-                       c->d_specres.p, (unsigned long long *)nullptr);
+                       c->d_specres.p, probe);
     BHMM_HIP(hipGetLastError());
+    if (probe_on) {
+        unsigned long long h[8];
+        BHMM_HIP(hipMemcpyAsync(h, probe, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        if (h[3] && h[7])
+            fprintf(stderr, "tile fwd<%d> probe: matrix [operands+matrix %.0f | emission row, write %.0f | barrier %.0f] "
+                            "stream [store, loads %.0f | emission %.0f | barrier %.0f] cycles/step (%llu steps)\n", NT,
+                    (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[7],
+                    (double)h[5] / h[7], (double)h[6] / h[7], h[3]);
+    }
     hipLaunchKernelGGL(k_tile_logl, dim3((sg.nseg + 15) / 16), dim3(256), 0, c->stream, sg, c->n,
                        (const double *)c->d_waentry.p, (const double *)c->d_waexit.p,
                        (const int32_t *)c->d_wePseg.p, c->d_wlogLseg.p, c->d_specres.p);
