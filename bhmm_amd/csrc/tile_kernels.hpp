@@ -331,7 +331,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
         }
         wide_d4 acc[TPW];
         // (operands in pieces of eight: all of them first is no faster and costs the registers)
-        constexpr int CH = KK < 8 ? KK : 8;
+        constexpr int CH = KK % 8 == 0 ? 8 : (KK % 4 == 0 ? 4 : 2);
 #pragma unroll
         for (int k0 = 0; k0 < KK; k0 += CH) {
             tile_d2 av[CH / 2];
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
     // the row whose alpha I carry to HBM: 16 lanes per row, NP / 16 states each -- FULL: consecutive ones;
     // otherwise pairs, pair e / 2 at 2 (lane & 15) + 16 e (sixteen lanes on 256 consecutive bytes, one 16-byte
     // piece per pair when n is even, see k_tile_bwd)
-    constexpr int SPL = NP / 16;
+    constexpr int SPL = FULL ? NP / 16 : 2 * ((NP + 31) / 32); // (pairs: up to the row's pitch, never beyond it)
     const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * (FULL ? SPL : 2);
     auto spos = [&](int e) __attribute__((always_inline)) { return FULL ? e : 16 * e; }; // (e even)
     const bool n_even = FULL || (n & 1) == 0;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
     // states, pair e / 2 at 2 (lane & 15) + 16 e: sixteen lanes on 256 consecutive bytes of a row, one 16-byte
     // access per pair when n is even (a pair is then inside the row or outside it, and every row starts on a
     // 16-byte boundary), two 8-byte ones when it is odd
-    constexpr int SPL = NP / 16;
+    constexpr int SPL = FULL ? NP / 16 : 2 * ((NP + 31) / 32); // (pairs: up to the row's pitch, never beyond it)
     const int srow = (w * 64 + lane) >> 4, sch = ((w * 64 + lane) & 15) * (FULL ? SPL : 2);
     auto spos = [&](int e) __attribute__((always_inline)) { return FULL ? e : 16 * e; }; // (e even)
     const bool n_even = FULL || (n & 1) == 0;
@@ -1268,7 +1268,7 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
         tile_d2 pl[TPW][2], ol[2];
         fetch_p(us + 1, pl, ol); // emission row / observations of step us + 1
         wide_d4 acc[TPW];
-        constexpr int CH = KK < 8 ? KK : 8; // (operands in pieces of eight, see k_tile_fwd)
+        constexpr int CH = KK % 8 == 0 ? 8 : (KK % 4 == 0 ? 4 : 2); // (operands in pieces of eight, see k_tile_fwd)
 #pragma unroll
         for (int k0 = 0; k0 < KK; k0 += CH) {
             tile_d2 av[CH / 2];
