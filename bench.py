@@ -661,6 +661,7 @@ def secondary_c4(torch, dev, local, args):
                       "segments": eng.get_option("viterbi_segments"), "warmup": eng.get_option("viterbi_W"),
                       "boundaries_not_bit_identical_after_first_pass": eng.get_option("viterbi_mismatch"),
                       "fixup_rounds": eng.get_option("viterbi_rounds"),
+                      "accepted_by_path_margins": bool(eng.get_option("viterbi_margin_used")),
                       "note": "paths as one byte per step into a device buffer"}
     for _ in range(3):
         eng.sample_paths(*margs, seed=1, want_paths=False)
@@ -735,7 +736,9 @@ def secondary_gen(torch, dev, local, args):
         eng.sample_paths(*margs, seed=1, want_paths=False)
         dg = timeit(lambda: eng.sample_paths(*margs, seed=1, want_paths=False), 2, eng.sync)
         out[-1]["viterbi"] = {"ms": 1e3 * dv, "over_time_segments": bool(eng.get_option("viterbi_chunked")),
-                              "segments": eng.get_option("viterbi_segments"), "fixup_rounds": eng.get_option("viterbi_rounds")}
+                              "segments": eng.get_option("viterbi_segments"), "warmup": eng.get_option("viterbi_W"),
+                              "fixup_rounds": eng.get_option("viterbi_rounds"),
+                              "accepted_by_path_margins": bool(eng.get_option("viterbi_margin_used"))}
         out[-1]["gibbs_path_step"] = {"ms": 1e3 * dg, "over_time_segments": bool(eng.get_option("sample_segmented")),
                                       "forward_pass_segmented": bool(eng.get_option("sample_forward_segmented")),
                                       "fixup_rounds": eng.get_option("sample_rounds")}

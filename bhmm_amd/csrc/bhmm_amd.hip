@@ -1305,6 +1305,7 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     c->smp_W = 0;
     c->tile_latched = c->tile_enabled; // (ctx.hpp: one decision per set of observations)
     c->vit_seg_given_up = false;
+    c->vit_margin_want = getenv("BHMM_AMD_VIT_MARGIN_FORCE") != nullptr; // (sweeps: the margin rule at every state count)
     c->vit_bad = 0;
     c->vit_explore = true;
     c->wide_replans = 0;
@@ -1551,6 +1552,14 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
             return BHMM_ERR_INVALID;
         c->vit_seg_warmups = (int)value;
         c->pplan[0].nseg = 0;
+    } else if (n == "viterbi_W") { // warm-up of the next segment-parallel Viterbi pass (0: from the E-step's)
+        if (value < 0 || value > (1 << 20))
+            return BHMM_ERR_INVALID;
+        c->vit_W = (int)value;
+    } else if (n == "viterbi_margin") { // 9..128 states: the path-margin acceptance of the segment-parallel first pass
+        c->vit_margin = value != 0.0;
+        if (value == 2.0) // (up to 64 states: from the next call on, not only after a call with two or more rounds)
+            c->vit_margin_want = true;
     } else if (n == "viterbi_seg_per_simd") { // 9..64 states: segments per SIMD of the Viterbi pass
         if (value < 1 || value > 64)
             return BHMM_ERR_INVALID;
@@ -1621,6 +1630,14 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->vit_seg_rounds;
     else if (n == "viterbi_mismatch") // ... boundaries of its last attempt that were not bit-identical
         *value = c->vit_seg_mismatch;
+    else if (n == "viterbi_margin")
+        *value = c->vit_margin ? 1.0 : 0.0;
+    else if (n == "viterbi_far") // ... boundaries of its first pass that were not equal to 1e-12
+        *value = c->vit_far;
+    else if (n == "viterbi_margin_used") // ... accepted by the margins of the decisions on its path (no fix-up rounds)
+        *value = c->vit_margin_used;
+    else if (n == "viterbi_margin_close") // ... segments with a close decision on the path (the rounds ran instead)
+        *value = c->vit_margin_close;
     else if (n == "carry")
         *value = c->carry_enabled ? 1.0 : 0.0;
     else if (n == "carry_W") // warm-up steps of the last E-step's carried starts (0: full warm-ups)

@@ -157,6 +157,13 @@ struct bhmm_ctx {
     int vit_seg_warmups = 2;          // a Viterbi segment is at least this many warm-ups long (measured: 1, 2, 4)
     int smp_seg_per_simd = 4;         // (the draw is a short dependent chain: more wavefronts per SIMD hide it)
     int vit_seg_mismatch = 0, vit_seg_rounds = 0;
+    bool vit_margin = true;           // accept a first pass whose boundaries are equal to 1e-12 when every decision ON its
+                                      // path has a margin (k_vit_margin) instead of running fix-up rounds
+    bool vit_margin_want = false;     // 9..64 states: a call on these observations needed two or more fix-up rounds (the
+                                      // margin acceptance costs about one short round: it is tried from then on)
+    int vit_far = 0;                  // ... boundaries of the last first pass that were not equal to 1e-12
+    int vit_margin_used = 0;          // ... the last call was accepted that way
+    int vit_margin_close = 0;         // ... segments with a close decision on the path in the last call (then: rounds)
     bhmm::DevBuf<double> d_vckpt;  // the first pass's vector at every 64th step
     bhmm::DevBuf<uint8_t> d_vflag; // segments the next fix-up round repeats
     bool vit_seg_given_up = false;    // ... boundaries did not coalesce on these observations: serial kernel

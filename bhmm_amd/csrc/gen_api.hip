@@ -283,13 +283,54 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
         if (!c->h_specres)
             BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
                                    hipHostMallocDefault));
-        int W_try = c->vit_W > 0 ? c->vit_W : std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
+        // warm-up: the max-product survivors of these larger models meet later than the filter forgets (128
+        // states, 128 x 10 000: 236 of 2048 boundaries further than 1e-12 apart after the E-step's 120 steps, 4
+        // after 240, none after 480), and a fix-up round costs half a first pass here: four times the E-step's
+        // length, and segments as short as one warm-up (round 5; with the path-margin acceptance 25.7 -> 11 ms)
+        const int wmul = c->vit_margin ? 4 : 1, seg_warmups = c->vit_margin ? 1 : c->vit_seg_warmups;
+        int W_try = c->vit_W > 0 ? c->vit_W : std::max(64, c->spec_W > 0 ? (wmul * c->spec_W + 7) / 8 * 8 : 128 * wmul);
         Segs sg;
+        // the path-margin acceptance of the first pass (k_vit_margin, path_kernels.hpp; see wide_viterbi_run)
+        const double vm_tol = 1e-12;
+        double *vall = nullptr;
+        int64_t maxT = 0;
+        const size_t smm = (size_t)n * n * sizeof(double);
+        if (c->vit_margin && c->d_gW.ensure((size_t)c->total * n) == BHMM_OK &&
+            gen_set_smem(k_vit_margin<int32_t, 2>, smm) == BHMM_OK && gen_set_smem(k_vit_margin<uint8_t, 2>, smm) == BHMM_OK) {
+            vall = c->d_gW.p;
+            for (int k = 0; k < K; ++k)
+                maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+        } else {
+            (void)hipGetLastError();
+        }
+        c->vit_margin_used = 0;
+        c->vit_margin_close = 0;
+        const int64_t *off = c->d_offsets.p;
+        uint8_t *p8 = out_fmt == 2 ? static_cast<uint8_t *>(paths_out) : reinterpret_cast<uint8_t *>(path);
+        // back-trace over the segments: maps, stitch, apply
+        auto seg_walks = [&]() -> int {
+            int rcw;
+            if ((rcw = c->d_vmaps.ensure((size_t)sg.nseg * 128)) || (rcw = c->d_vend.ensure((size_t)sg.nseg)))
+                return rcw;
+            hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t, 2>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                               (const uint8_t *)ptr8, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
+                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 128,
+                               (const int32_t *)last, c->d_vend.p);
+            if (out_fmt == 0)
+                hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t, 2>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path);
+            else
+                hipLaunchKernelGGL((k_wide_vit_walk<true, uint8_t, 2>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, p8);
+            BHMM_HIP(hipGetLastError());
+            return BHMM_OK;
+        };
         for (int attempt = 0; attempt < 2 && !done; ++attempt) {
             if (attempt > 0)
                 W_try *= 2;
             const int64_t want = (int64_t)c->vit_seg_per_simd * c->num_simd;
-            const int64_t seglen = std::max<int64_t>((c->total + want - 1) / want, c->vit_seg_warmups * (int64_t)W_try);
+            const int64_t seglen = std::max<int64_t>((c->total + want - 1) / want, seg_warmups * (int64_t)W_try);
             if ((rc = wide_path_plan_pub(c, 0, seglen, sg)))
                 return rc;
             if (sg.nseg <= K)
@@ -300,30 +341,60 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                 return rc;
             const dim3 sgrid((sg.nseg + 7) / 8), sblk(512);
             int round = 0;
+            bool margin_accepted = false;
             for (; round <= 12; ++round) {
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
                 lds_poison(c->stream);
                 if (round == 0)
                     hipLaunchKernelGGL(k_gen_viterbi_seg<false>, sgrid, sblk, smv, c->stream, m, (const int64_t *)c->d_offsets.p,
                                        sg, pobs, ptr8, last, c->d_aentry.p, c->d_aexit.p, c->d_vckpt.p,
-                                       (const uint8_t *)c->d_vflag.p);
+                                       (const uint8_t *)c->d_vflag.p, vall);
                 else
                     hipLaunchKernelGGL(k_gen_viterbi_seg<true>, sgrid, sblk, smv, c->stream, m, (const int64_t *)c->d_offsets.p,
                                        sg, pobs, ptr8, last, c->d_aentry.p, c->d_aexit.p, c->d_vckpt.p,
                                        (const uint8_t *)c->d_vflag.p);
                 hipLaunchKernelGGL((k_wide_vit_check<128>), dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg,
-                                   c->d_aentry.p, (const double *)c->d_aexit.p, c->d_vflag.p, c->d_specres.p);
+                                   c->d_aentry.p, (const double *)c->d_aexit.p, c->d_vflag.p, c->d_specres.p,
+                                   (round == 0 && vall) ? vm_tol : 0.0);
                 BHMM_HIP(hipGetLastError());
                 BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
                                         hipMemcpyDeviceToHost, c->stream));
                 BHMM_HIP(hipStreamSynchronize(c->stream));
-                if (round == 0)
+                if (round == 0) {
                     c->vit_seg_mismatch = (int)c->h_specres[3];
+                    c->vit_far = (int)c->h_specres[0];
+                }
                 if (c->h_specres[3] == 0)
                     break;
+                if (round == 0 && vall && c->h_specres[0] == 0) {
+                    // every boundary within vm_tol: the path of this pass, and the margins of the decisions on it
+                    const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1;
+                    const double margin = std::max(1e-10, 16.0 * (2e-15 * (double)maxT + vm_tol * maxseg));
+                    if ((rc = seg_walks()))
+                        return rc;
+                    BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                    const dim3 mgrid(sg.nseg, (unsigned)((seglen + 255) / 256));
+                    if (out_fmt == 0)
+                        hipLaunchKernelGGL((k_vit_margin<int32_t, 2>), mgrid, dim3(256), smm, c->stream, m.A, n, off, sg,
+                                           (const double *)vall, (const int32_t *)path, margin, c->d_specres.p);
+                    else
+                        hipLaunchKernelGGL((k_vit_margin<uint8_t, 2>), mgrid, dim3(256), smm, c->stream, m.A, n, off, sg,
+                                           (const double *)vall, (const uint8_t *)p8, margin, c->d_specres.p);
+                    BHMM_HIP(hipGetLastError());
+                    BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
+                                            hipMemcpyDeviceToHost, c->stream));
+                    BHMM_HIP(hipStreamSynchronize(c->stream));
+                    c->vit_margin_close = (int)c->h_specres[2];
+                    if (c->h_specres[2] == 0) {
+                        c->vit_margin_used = 1;
+                        margin_accepted = true;
+                        break;
+                    }
+                    // (a close decision on the path: the rounds decide)
+                }
             }
             c->vit_seg_rounds = round;
-            if (c->h_specres[3] == 0) {
+            if (c->h_specres[3] == 0 || margin_accepted) {
                 done = true;
                 c->vit_W = W_try; // (what converged is where the next call on these observations starts)
             }
@@ -331,29 +402,14 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
         if (!done && c->pplan[0].nseg > K)
             c->vit_seg_given_up = true; // these observations go to the serial kernel from now on
         c->viterbi_chunked = done;
-        if (done) { // back-trace over the segments: maps, stitch, apply
-            if ((rc = c->d_vmaps.ensure((size_t)sg.nseg * 128)) || (rc = c->d_vend.ensure((size_t)sg.nseg)))
+        if (done) {
+            if (!c->vit_margin_used && (rc = seg_walks())) // (a margin-accepted pass has its path already)
                 return rc;
-            const int64_t *off = c->d_offsets.p;
-            hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t, 2>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
-                               (const uint8_t *)ptr8, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
-            hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
-                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 128,
-                               (const int32_t *)last, c->d_vend.p);
-            if (out_fmt == 0) {
-                hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t, 2>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
-                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path);
-                BHMM_HIP(hipGetLastError());
+            if (out_fmt == 0)
                 BHMM_HIP(hipMemcpyAsync(paths_out, path, (size_t)c->total * sizeof(int32_t),
                                         hipMemcpyDeviceToHost, c->stream));
-            } else {
-                uint8_t *p8 = out_fmt == 2 ? static_cast<uint8_t *>(paths_out) : reinterpret_cast<uint8_t *>(path);
-                hipLaunchKernelGGL((k_wide_vit_walk<true, uint8_t, 2>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
-                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, p8);
-                BHMM_HIP(hipGetLastError());
-                if (out_fmt == 1)
-                    BHMM_HIP(hipMemcpyAsync(paths_out, p8, (size_t)c->total, hipMemcpyDeviceToHost, c->stream));
-            }
+            else if (out_fmt == 1)
+                BHMM_HIP(hipMemcpyAsync(paths_out, p8, (size_t)c->total, hipMemcpyDeviceToHost, c->stream));
             BHMM_HIP(hipStreamSynchronize(c->stream));
             return BHMM_OK;
         }

@@ -793,7 +793,7 @@ template <bool FIX>
 __global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, const int64_t *off, const Segs sg,
                                                          const double *pobs, uint8_t *ptr, int32_t *last_state,
                                                          double *v_entry, double *v_exit, double *ckpt,
-                                                         const uint8_t *flag)
+                                                         const uint8_t *flag, double *vall = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double gvs_sm[];
     double *sAT = gvs_sm;                         // [128][GVS_PITCH]
@@ -922,6 +922,12 @@ __global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, cons
             if (t == t0 - 1) {
                 v_entry[(int64_t)sgi * 128 + j[0]] = v[0];
                 v_entry[(int64_t)sgi * 128 + j[1]] = v[1];
+            }
+            if (vall && t >= t0) { // (every vector of the first pass, [total][n]: k_vit_margin)
+                if (real[0])
+                    vall[(o0 + t) * n + j[0]] = v[0];
+                if (real[1])
+                    vall[(o0 + t) * n + j[1]] = v[1];
             }
         }
         if (((o0 + t) & 63) == 63 && t >= t0) {

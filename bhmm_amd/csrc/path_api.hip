@@ -550,6 +550,42 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         if (!c->h_specres)
             BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
                                    hipHostMallocDefault));
+        // the path-margin acceptance (k_vit_margin): every vector of the first pass is kept ([total][n], in the
+        // buffer of the 65..128-state E-step's W rows), boundaries equal to vm_tol count as usable
+        const double vm_tol = 1e-12;
+        double *vall = nullptr;
+        int64_t maxT = 0;
+        // (up to 64 states one fix-up round is short -- 1.1 ms at configs[3] -- and cheaper than keeping the
+        // vectors and checking the margins: only observations that needed two or more rounds before take this way)
+        if (c->vit_margin && c->vit_margin_want && c->d_gW.ensure((size_t)c->total * n) == BHMM_OK) {
+            vall = c->d_gW.p;
+            for (int k = 0; k < K; ++k)
+                maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+        } else {
+            (void)hipGetLastError();
+        }
+        c->vit_margin_used = 0;
+        c->vit_margin_close = 0;
+        // back-trace over the segments: maps, stitch, apply
+        auto seg_walks = [&]() -> int {
+            const Segs sgw{c->pplan[0].traj.p, c->pplan[0].t0.p, c->pplan[0].len.p, c->pplan[0].nseg, 0};
+            int rcw;
+            if ((rcw = c->d_vmaps.ensure((size_t)sgw.nseg * 64)) || (rcw = c->d_vend.ensure((size_t)sgw.nseg)))
+                return rcw;
+            hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t>), dim3(sgw.nseg), dim3(64), 0, c->stream, off, sgw, n,
+                               (const uint8_t *)ptr, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
+                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 64,
+                               (const int32_t *)last, c->d_vend.p);
+            if (out_fmt == 0)
+                hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t>), dim3(sgw.nseg), dim3(64), 0, c->stream, off, sgw, n,
+                                   (const uint8_t *)ptr, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path);
+            else
+                hipLaunchKernelGGL((k_wide_vit_walk<true, uint8_t>), dim3(sgw.nseg), dim3(64), 0, c->stream, off, sgw, n,
+                                   (const uint8_t *)ptr, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path8);
+            BHMM_HIP(hipGetLastError());
+            return BHMM_OK;
+        };
         for (int attempt = 0; attempt < 2 && !done; ++attempt) {
             if (attempt > 0) {
                 W_try *= 2;
@@ -572,7 +608,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
 #define BHMM_WVS(NPV, KINDV, FIXV)                                                                    \
     hipLaunchKernelGGL((k_wide_viterbi_seg<NPV, KINDV, FIXV>), sgrid, sblk, 0, c->stream, m, off, sg,  \
                        obs, ptr, last, c->d_aentry.p, c->d_aexit.p, c->d_vckpt.p,                     \
-                       (const uint8_t *)c->d_vflag.p)
+                       (const uint8_t *)c->d_vflag.p, FIXV ? (double *)nullptr : vall)
 #define BHMM_WVS_KIND(NPV, FIXV)                                                                      \
     do {                                                                                              \
         if (vkind == EMIT_GAUSS)                                                                      \
@@ -583,7 +619,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
             BHMM_WVS(NPV, EMIT_EXPL, FIXV);                                                           \
         hipLaunchKernelGGL((k_wide_vit_check<NPV>), dim3((sg.nseg + 255) / 256), dim3(256), 0,      \
                            c->stream, sg, c->d_aentry.p, (const double *)c->d_aexit.p, c->d_vflag.p,  \
-                           c->d_specres.p);                                                           \
+                           c->d_specres.p, (!FIXV && vall) ? vm_tol : 0.0);                           \
     } while (0)
 #define BHMM_WVS_NP(FIXV)              \
     do {                               \
@@ -597,6 +633,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
             // pass 0 with warm-ups, then fix-up rounds while any boundary is not bit-identical
             const int max_rounds = 12;
             int round = 0;
+            bool margin_accepted = false;
             for (; round <= max_rounds; ++round) {
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
                 lds_poison(c->stream);
@@ -608,16 +645,47 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                 BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
                                         hipMemcpyDeviceToHost, c->stream));
                 BHMM_HIP(hipStreamSynchronize(c->stream));
-                if (round == 0)
+                if (round == 0) {
                     c->vit_seg_mismatch = (int)c->h_specres[3];
+                    c->vit_far = (int)c->h_specres[0];
+                }
                 if (c->h_specres[3] == 0)
                     break;
+                if (round == 0 && vall && c->h_specres[0] == 0) {
+                    // every boundary within vm_tol: the path of this pass, and the margins of the decisions on it
+                    const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1;
+                    const double margin = std::max(1e-10, 16.0 * (2e-15 * (double)maxT + vm_tol * maxseg));
+                    if ((rc = seg_walks()))
+                        return rc;
+                    BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                    const size_t smm = (size_t)n * n * sizeof(double);
+                    const dim3 mgrid(sg.nseg, (unsigned)((seglen + 255) / 256));
+                    if (out_fmt == 0)
+                        hipLaunchKernelGGL((k_vit_margin<int32_t, 1>), mgrid, dim3(256), smm, c->stream, m.A, n, off,
+                                           sg, (const double *)vall, (const int32_t *)path, margin, c->d_specres.p);
+                    else
+                        hipLaunchKernelGGL((k_vit_margin<uint8_t, 1>), mgrid, dim3(256), smm, c->stream, m.A, n, off,
+                                           sg, (const double *)vall, (const uint8_t *)path8, margin, c->d_specres.p);
+                    BHMM_HIP(hipGetLastError());
+                    BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int),
+                                            hipMemcpyDeviceToHost, c->stream));
+                    BHMM_HIP(hipStreamSynchronize(c->stream));
+                    c->vit_margin_close = (int)c->h_specres[2];
+                    if (c->h_specres[2] == 0) {
+                        c->vit_margin_used = 1;
+                        margin_accepted = true;
+                        break;
+                    }
+                    // (a close decision on the path: the rounds decide)
+                }
             }
 #undef BHMM_WVS_NP
 #undef BHMM_WVS_KIND
 #undef BHMM_WVS
             c->vit_seg_rounds = round;
-            const bool accepted = c->h_specres[3] == 0;
+            if (round >= 2)
+                c->vit_margin_want = true;
+            const bool accepted = c->h_specres[3] == 0 || margin_accepted;
             // (How many boundaries the first pass left to the fix-up does not say whether the warm-up was
             // too short -- most of them are rounding noise, and a round costs the same for one segment as
             // for a thousand: doubling the warm-up on that count was measured slower everywhere.)
@@ -631,21 +699,9 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         if (!done && c->pplan[0].nseg > K)
             c->vit_seg_given_up = true; // these observations go to the serial kernel from now on
         c->viterbi_chunked = done;
-        if (done) { // back-trace over the segments: maps, stitch, apply
-            const Segs sg{c->pplan[0].traj.p, c->pplan[0].t0.p, c->pplan[0].len.p, c->pplan[0].nseg, 0};
-            if ((rc = c->d_vmaps.ensure((size_t)sg.nseg * 64)) || (rc = c->d_vend.ensure((size_t)sg.nseg)))
+        if (done) {
+            if (!c->vit_margin_used && (rc = seg_walks())) // (a margin-accepted pass has its path already)
                 return rc;
-            hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
-                               (const uint8_t *)ptr, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
-            hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
-                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 64,
-                               (const int32_t *)last, c->d_vend.p);
-            if (out_fmt == 0)
-                hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
-                                   (const uint8_t *)ptr, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path);
-            else
-                hipLaunchKernelGGL((k_wide_vit_walk<true, uint8_t>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
-                                   (const uint8_t *)ptr, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path8);
             walks_in_flight = true;
         }
     }

@@ -1171,7 +1171,8 @@ constexpr int WVS_WPB = 4;
 template <int NP, int KIND, bool FIX>
 __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     const WideModel m, const int64_t *off, const Segs sg, const void *obs_rm, uint8_t *ptr,
-    int32_t *last_state, double *v_entry, double *v_exit, double *ckpt, const uint8_t *flag)
+    int32_t *last_state, double *v_entry, double *v_exit, double *ckpt, const uint8_t *flag,
+    double *vall = nullptr)
 {
     constexpr int GP = 64 / NP;
     __shared__ __attribute__((aligned(16))) double xv[WVS_WPB][GP][NP];
@@ -1298,6 +1299,8 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
         if constexpr (!FIX) {
             if (t == t0 - 1)
                 v_entry[(int64_t)sgi * NP + j] = v;
+            if (vall && real && t >= t0) // (every vector of the first pass, [total][n]: k_vit_margin)
+                vall[(o0 + t) * n + j] = v;
         }
         if (((o0 + t) & 63) == 63 && t >= t0) {
             double *cp = ckpt + ((o0 + t) >> 6) * NP + j;
@@ -1330,27 +1333,118 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
 }
 
 // result[3] = segments whose entry vector is not bit-identical to the predecessor's exit vector; those
-// are flagged, and their entry vector becomes the predecessor's (what the fix-up pass starts from)
+// are flagged, and their entry vector becomes the predecessor's (what the fix-up pass starts from).
+// result[0] = those of them that are not even equal to `tol` relative in every component, with the same
+// zero pattern (k_vit_margin's condition; tol = 0: not counted)
 template <int NP>
 __global__ void k_wide_vit_check(const Segs sg, double *v_entry, const double *v_exit, uint8_t *flag,
-                                 unsigned int *result)
+                                 unsigned int *result, double tol = 0.0)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    bool differs = false;
+    bool differs = false, far = false;
     if (s < sg.nseg && sg.len[s] > 0 && sg.t0[s] != 0) {
         double *x = v_entry + (int64_t)s * NP;
         const double *y = v_exit + (int64_t)(s - 1) * NP;
-        for (int j = 0; j < NP; ++j)
+        for (int j = 0; j < NP; ++j) {
             differs |= __double_as_longlong(x[j]) != __double_as_longlong(y[j]);
+            far |= !(fabs(x[j] - y[j]) <= tol * y[j]) || ((x[j] == 0.0) != (y[j] == 0.0));
+        }
         if (differs)
             for (int j = 0; j < NP; ++j)
                 x[j] = y[j];
     }
     if (s < sg.nseg)
         flag[s] = differs ? 1 : 0;
-    const unsigned long long d = __ballot(differs);
+    const unsigned long long d = __ballot(differs), f = __ballot(differs && far);
     if ((threadIdx.x & 63) == 0 && d)
         atomicAdd(&result[3], (unsigned int)__popcll(d));
+    if ((threadIdx.x & 63) == 0 && f && tol > 0.0)
+        atomicAdd(&result[0], (unsigned int)__popcll(f));
+}
+
+// =========================================================================================
+// k_vit_margin (round 5): the segment-parallel first pass without fix-up rounds.  When every boundary of the
+// first pass is equal to `tol` (most are equal to the bit; the rest are the two runs' rounding noise after the
+// survivors met, which the max-product recursion never sheds exactly), the vectors of the first pass are the
+// serial run's up to delta = (number of boundaries) tol + the roundings of both runs: the step
+// v -> normalise(p o max_i v_i A_ij) is non-expansive in Hilbert's projective metric, four roundings per
+// component and step are not common to all components.  The back-pointers may still differ from the serial
+// run's where a decision was closer than that -- but the PATH only uses one decision per step: if the final
+// state and every decision ON the path of the first pass was taken with a relative margin above `margin`
+// (>= 16 delta, host), the serial run takes the same decisions there, and by induction from the last step its
+// path is this one.  Step t of the path: j = path[t], i^ = path[t - 1], all
+// candidates v_{t-1}[i] A[i][j] (_hidden.c:249) against the winner's.  Violations (a close or tied decision,
+// a winner that is zero, denormal or not finite) are counted in result[2]; the host then runs the fix-up
+// rounds, which need none of this.   vall [total][n]: every vector of the first pass.
+// =========================================================================================
+template <typename PT, int NC>
+__global__ __launch_bounds__(256) void k_vit_margin(const double *A, int n, const int64_t *off, const Segs sg,
+                                                    const double *vall, const PT *path, double margin,
+                                                    unsigned int *result)
+{
+    // workgroup (s, c): steps [256 c, 256 c + 256) of segment s, 64 per wavefront; lane l holds the path at
+    // "its" step and the one before (one coalesced read each), the rows of v eight steps at a time
+    extern __shared__ double vm_sAT[]; // [j][i] = A[i][j]
+    const int s = blockIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (s >= sg.nseg || sg.len[s] <= 0 || (int64_t)blockIdx.y * 256 >= sg.len[s])
+        return;
+    for (int e = threadIdx.x; e < n * n; e += 256)
+        vm_sAT[(e % n) * n + e / n] = A[e];
+    __syncthreads();
+    const int k = sg.traj[s];
+    const int64_t o0 = off[k], T = off[k + 1] - o0;
+    const int64_t t1 = sg.t0[s] + sg.len[s];
+    const int64_t tb = sg.t0[s] + (int64_t)blockIdx.y * 256 + 64 * wid;
+    if (tb >= t1)
+        return;
+    const int cnt = (int)(t1 - tb < 64 ? t1 - tb : 64);
+    const int pj = lane < cnt ? (int)path[o0 + tb + lane] : 0;
+    const int pi = (lane < cnt && tb + lane >= 1) ? (int)path[o0 + tb + lane - 1] : 0;
+    bool bad = false;
+    constexpr int U = 8;
+    for (int q0 = 0; q0 < cnt; q0 += U) {
+        double vr[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t t = tb + q0 + u;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                vr[u][c] = (q0 + u < cnt && t >= 1 && lane + 64 * c < n) ? vall[(o0 + t - 1) * n + lane + 64 * c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t t = tb + q0 + u;
+            if (q0 + u < cnt && t >= 1) { // (uniform)
+                const int j = __shfl(pj, q0 + u, 64), ih = __shfl(pi, q0 + u, 64);
+                const double *col = vm_sAT + (int64_t)j * n;
+                double h[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    h[c] = lane + 64 * c < n ? vr[u][c] * col[lane + 64 * c] : 0.0; // _hidden.c:249
+                double hb = __shfl(h[0], ih & 63, 64);
+                if constexpr (NC > 1) {
+                    const double hb1 = __shfl(h[1], ih & 63, 64);
+                    hb = ih < 64 ? hb : hb1;
+                }
+                const double lim = hb - margin * hb;
+                bad |= !(hb >= 0x1p-960) || !(hb < 0x1p1000);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    bad |= lane + 64 * c < n && lane + 64 * c != ih && !(h[c] < lim);
+            }
+        }
+    }
+    if (t1 == T && tb + cnt == t1) { // the final state (_hidden.c:262-267), by the wavefront that holds the last step
+        const int j = __shfl(pj, cnt - 1, 64);
+        const double *vp = vall + (o0 + T - 1) * n;
+        const double vb = vp[j], lim = vb - margin * vb;
+        bad |= !(vb >= 0x1p-960) || !(vb < 0x1p1000);
+        for (int i = lane; i < n; i += 64)
+            bad |= i != j && !(vp[i] < lim);
+    }
+    const unsigned long long b = __ballot(bad);
+    if (lane == 0 && b)
+        atomicAdd(&result[2], 1u);
 }
 
 // ---- instruction-count diet of the chunked Viterbi step (round 3) ------------------------------

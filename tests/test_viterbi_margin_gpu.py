@@ -1,0 +1,135 @@
+"""Viterbi over time segments accepted by the margins of the decisions ON the path (k_vit_margin, round 5):
+when every boundary of the first pass equals its predecessor's vector to 1e-12 and no decision on the path of
+that pass was close, the path is the serial run's without any fix-up round -- checked here byte for byte
+against the oracle of bhmm/hidden/impl_c/_hidden.c:186-276, together with the cases in which the rule must
+NOT be used (tied decisions on the path, the switch off)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(n, rng, kind, M=0):
+    A = rng.random((n, n)) + 0.05
+    A += np.eye(n) * 8.0
+    A /= A.sum(axis=1)[:, None]
+    pi = rng.dirichlet(np.ones(n))
+    if kind == "gaussian":
+        return A, pi, np.linspace(-6, 6, n), rng.uniform(0.5, 1.5, n)
+    return A, pi, rng.dirichlet(np.ones(M), n), None
+
+
+def _data(kind, rng, lengths, n, M, p0, p1):
+    if kind == "gaussian":
+        obs = [rng.normal(0, 4, T) for T in lengths]
+        return obs, [orc.pobs_gaussian(o, p0, p1) for o in obs]
+    obs = [rng.integers(0, M, T).astype(np.int32) for T in lengths]
+    return obs, [orc.pobs_discrete(o, p0) for o in obs]
+
+
+@pytest.mark.parametrize("n,kind", [(72, "gaussian"), (96, "discrete"), (128, "gaussian")])
+def test_margin_acceptance_65_to_128_states(n, kind):
+    """Default policy above 64 states: four E-step warm-ups, margins instead of rounds.  Whatever way a call was
+    accepted, the paths are the oracle's; with boundaries that are not bit-identical, none further than 1e-12 and
+    no close decision, it was accepted by the margins."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(7100 + n)
+    M = 21
+    A, pi, p0, p1 = _model(n, rng, kind, M)
+    lengths = (24001, 1, 9000, 2, 700)
+    obs, pobs = _data(kind, rng, lengths, n, M, p0, p1)
+    ref = [orc.viterbi(A, po, pi) for po in pobs]
+    eng = Engine(0)
+    eng.set_option("viterbi_seg_per_simd", 1)
+    eng.set_observations(kind, obs, n, nsymbols=M if kind == "discrete" else 0)
+    used = 0
+    for W in (0, 48, 200):      # the policy's warm-up, one that is too short for some boundaries, one in between
+        if W:
+            eng.set_option("viterbi_W", W)
+        paths = eng.viterbi(A, pi, p0, p1)
+        assert eng.get_option("viterbi_chunked") == 1 and eng.get_option("viterbi_segments") > 10
+        mism, far = eng.get_option("viterbi_mismatch"), eng.get_option("viterbi_far")
+        mu, close, rounds = (eng.get_option("viterbi_margin_used"), eng.get_option("viterbi_margin_close"),
+                             eng.get_option("viterbi_rounds"))
+        if mism > 0 and far == 0 and close == 0:
+            assert mu == 1 and rounds == 0
+        if mu == 0 and mism > 0:
+            assert rounds >= 1
+        used += mu
+        for p, r in zip(paths, ref):
+            assert np.array_equal(p, r), W
+    assert used >= 1        # (these seeds: the 48- or the 200-step warm-up leaves rounding-noise boundaries only)
+    p8 = eng.viterbi_u8(A, pi, p0, p1)
+    assert np.array_equal(p8, np.concatenate(ref).astype(np.uint8))
+    eng.set_option("viterbi_margin", 0)          # the switch: fix-up rounds only, the same paths
+    paths = eng.viterbi(A, pi, p0, p1)
+    assert eng.get_option("viterbi_margin_used") == 0
+    for p, r in zip(paths, ref):
+        assert np.array_equal(p, r)
+    eng.close()
+
+
+@pytest.mark.parametrize("n,kind", [(64, "gaussian"), (40, "discrete"), (20, "gaussian")])
+def test_margin_acceptance_up_to_64_states_when_asked_for(n, kind):
+    """Up to 64 states the rule is only tried after a call that needed two rounds (a round is cheap there);
+    viterbi_margin = 2 asks for it at once."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(7300 + n)
+    M = 17
+    A, pi, p0, p1 = _model(n, rng, kind, M)
+    lengths = (30011, 1, 9000, 257)
+    obs, pobs = _data(kind, rng, lengths, n, M, p0, p1)
+    ref = [orc.viterbi(A, po, pi) for po in pobs]
+    eng = Engine(0)
+    eng.set_option("viterbi_seg_per_simd", 1)
+    eng.set_observations(kind, obs, n, nsymbols=M if kind == "discrete" else 0)
+    paths = eng.viterbi(A, pi, p0, p1)
+    assert eng.get_option("viterbi_margin_used") == 0
+    eng.set_option("viterbi_margin", 2)
+    used = 0
+    for W in (0, 48, 96):
+        if W:
+            eng.set_option("viterbi_W", W)
+        paths = eng.viterbi(A, pi, p0, p1)
+        assert eng.get_option("viterbi_chunked") == 1
+        mism, far, close = (eng.get_option("viterbi_mismatch"), eng.get_option("viterbi_far"),
+                            eng.get_option("viterbi_margin_close"))
+        if mism > 0 and far == 0 and close == 0:
+            assert eng.get_option("viterbi_margin_used") == 1 and eng.get_option("viterbi_rounds") == 0
+        used += eng.get_option("viterbi_margin_used")
+        for p, r in zip(paths, ref):
+            assert np.array_equal(p, r), W
+    if n == 64:
+        assert used >= 1
+    eng.close()
+
+
+def test_tied_decisions_on_the_path_are_left_to_the_rounds():
+    """Pairs of identical states: v[2k] == v[2k + 1] to the bit at every step, so every decision on the path has a
+    runner-up with the same product -- the first-maximum rule (_hidden.c:186-200) decides, and a perturbation
+    could decide otherwise.  The margin rule must refuse such a pass (or never be asked), the paths stay the
+    oracle's."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(99)
+    h = 40
+    Ah = rng.random((h, h)) + 0.05 + np.eye(h) * 6.0
+    A = np.kron(Ah, np.ones((2, 2)))
+    A /= A.sum(axis=1)[:, None]
+    n = 2 * h
+    pi = np.repeat(rng.dirichlet(np.ones(h)), 2) / 2.0
+    mu, sig = np.repeat(np.linspace(-5, 5, h), 2), np.repeat(rng.uniform(0.5, 1.5, h), 2)
+    obs = [rng.normal(0, 3.5, T) for T in (20000, 5000)]
+    ref = [orc.viterbi(A, orc.pobs_gaussian(o, mu, sig), pi) for o in obs]
+    eng = Engine(0)
+    eng.set_option("viterbi_seg_per_simd", 1)
+    eng.set_observations("gaussian", obs, n)
+    for W in (0, 40):
+        if W:
+            eng.set_option("viterbi_W", W)
+        paths = eng.viterbi(A, pi, mu, sig)
+        assert eng.get_option("viterbi_margin_used") == 0
+        for p, r in zip(paths, ref):
+            assert np.array_equal(p, r)
+    eng.close()
