@@ -60,7 +60,21 @@ int big_bwd_t(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
     const int n = c->n;
     // the xi counts: C' = alpha^T W over the rows W this pass stores (k_big_xi_gemm: 128 x 128 blocks of C',
     // time slabs that give every compute unit a workgroup or two)
-    const int nb = (n + 127) / 128;
+    // block edge 32 TI (TI x TI tiles per wavefront, TI = 3 .. 5) and nb x nb blocks: the combination with the
+    // fewest padded tiles (129 .. 160 states: one 160 x 160 block instead of four 128 x 128 ones)
+    int ti = 4, nb = (n + 127) / 128;
+    for (int t = 3; t <= 5; ++t) { // (6 x 6 tiles per wavefront: measured slower than 4 x 4 on more blocks)
+        const int b = (n + 32 * t - 1) / (32 * t);
+        if ((b * t) * (b * t) < (nb * ti) * (nb * ti) || ((b * t) * (b * t) == (nb * ti) * (nb * ti) && b < nb)) {
+            ti = t;
+            nb = b;
+        }
+    }
+    static const int ti_env = getenv("BHMM_AMD_XI_TI") ? atoi(getenv("BHMM_AMD_XI_TI")) : 0; // (experiments)
+    if (ti_env >= 3 && ti_env <= 6) {
+        ti = ti_env;
+        nb = (n + 32 * ti - 1) / (32 * ti);
+    }
     const int nsplit = (int)std::max<int64_t>(
         1, std::min<int64_t>({(int64_t)(2 * c->num_simd / 4) / (nb * nb), (c->total + 255) / 256, (int64_t)256}));
     int rc;
@@ -74,8 +88,19 @@ int big_bwd_t(bhmm_ctx *c, const WideModel &m, double *gam, double *stats_dev)
                        (const double *)c->d_alpha_rm.p, gam, c->d_gamma0.p, c->d_partials.p, c->d_dpartials.p,
                        c->d_wbexit.p, c->d_wbentry.p, c->d_specres.p, c->d_gW.p);
     BHMM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_big_xi_gemm<4>, dim3(nb * nb * nsplit), dim3(256), 0, c->stream, (const double *)c->d_alpha_rm.p,
-                       (const double *)c->d_gW.p, c->total, n, nb, nsplit, c->d_gxipart.p);
+#define BIG_XI(TIV)                                                                                              \
+    hipLaunchKernelGGL(k_big_xi_gemm<TIV>, dim3(nb * nb * nsplit), dim3(256), 0, c->stream,                        \
+                       (const double *)c->d_alpha_rm.p, (const double *)c->d_gW.p, c->total, n, nb, nsplit,        \
+                       c->d_gxipart.p)
+    if (ti == 3)
+        BIG_XI(3);
+    else if (ti == 5)
+        BIG_XI(5);
+    else if (ti == 6)
+        BIG_XI(6);
+    else
+        BIG_XI(4);
+#undef BIG_XI
     hipLaunchKernelGGL((k_big_finalize<KIND>), dim3(4096), dim3(64), 0, c->stream, m, c->K, tp.ntiles, nsplit,
                        (const double *)c->d_gxipart.p, (const double *)c->d_partials.p,
                        (const double *)c->d_dpartials.p, (const double *)c->d_logLk.p, (const double *)c->d_gamma0.p,

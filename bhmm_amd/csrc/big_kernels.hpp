@@ -81,7 +81,11 @@ __device__ __forceinline__ void big_issue(BigRing<TPW> &ring, const double *__re
 {
     using G = BigGeo<TPW>;
     constexpr int k0 = (B / TPW) * BIG_KC, c = B % TPW;
-    const tile_d2 *src = reinterpret_cast<const tile_d2 *>(Bp) + ((int64_t)(w + 4 * c) * (G::KK / 2) + k0 / 2) * 64 + lane;
+    // (the global address space spelled out: behind the opaque copy of big_stream_ptr the compiler no longer knows
+    // it, and flat loads count against the LDS counter as well -- every wait for the tile's operands would drain
+    // the ring)
+    typedef const tile_d2 __attribute__((address_space(1))) big_gd2;
+    big_gd2 *src = (big_gd2 *)(reinterpret_cast<const tile_d2 *>(Bp) + ((int64_t)(w + 4 * c) * (G::KK / 2) + k0 / 2) * 64 + lane);
 #ifdef BIG_X_NOSTREAM // (experiment builds, tools/proto/big_variants.sh: what does a piece of the step cost?)
     (void)src;
 #pragma unroll
