@@ -9,7 +9,7 @@ for v in "$@"; do
 done
 wait
 for v in "$@"; do
-  objs="../lib/obj/bhmm_amd.o ../lib/obj/path_api.o ../lib/obj/wide_api.o ../lib/obj/synth_api.o ../lib/obj/gen_api.o ../lib/obj/tile_gen.o ../lib/obj/host_model.o ../lib/obj/host_api.o ../lib/obj/comm_api.o"
+  objs="../lib/obj/bhmm_amd.o ../lib/obj/path_api.o ../lib/obj/wide_api.o ../lib/obj/synth_api.o ../lib/obj/gen_api.o ../lib/obj/tile_gen.o ../lib/obj/tile_gen_5.o ../lib/obj/tile_gen_6.o ../lib/obj/tile_gen_7.o ../lib/obj/tile_gen_8.o ../lib/obj/host_model.o ../lib/obj/host_api.o ../lib/obj/comm_api.o"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/build_variants/libbig_$v.so $objs /root/repo/build_variants/big_api_$v.o -ldl
 done
 ls -la /root/repo/build_variants/libbig_*.so

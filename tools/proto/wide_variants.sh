@@ -12,7 +12,7 @@ while [ $# -ge 2 ]; do
 done
 wait
 for n in "${names[@]}"; do
-  objs="../lib/obj/bhmm_amd.o ../lib/obj/path_api.o ../lib/obj/synth_api.o ../lib/obj/gen_api.o ../lib/obj/tile_gen.o ../lib/obj/big_api.o ../lib/obj/host_model.o ../lib/obj/host_api.o ../lib/obj/comm_api.o"
+  objs="../lib/obj/bhmm_amd.o ../lib/obj/path_api.o ../lib/obj/synth_api.o ../lib/obj/gen_api.o ../lib/obj/tile_gen.o ../lib/obj/tile_gen_5.o ../lib/obj/tile_gen_6.o ../lib/obj/tile_gen_7.o ../lib/obj/tile_gen_8.o ../lib/obj/big_api.o ../lib/obj/host_model.o ../lib/obj/host_api.o ../lib/obj/comm_api.o"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/build_variants/libwide_$n.so $objs /root/repo/build_variants/wide_api_$n.o -ldl
 done
 ls -la /root/repo/build_variants/libwide_*.so
