@@ -278,10 +278,14 @@ __global__ __launch_bounds__(256) void k_big_fwd(const WideModel m, const double
             }
         }
     };
-    double *arow[4]; // alpha row of my rows at the current step (running pointers: no 64-bit multiply per store)
+    // alpha row of my rows at the current step (running pointers: no 64-bit multiply per store; the global address
+    // space spelled out -- as plain pointers in an array they became flat stores, which count against the LDS
+    // counter too: every wait for the next product's operands waited for the alpha rows to reach memory)
+    typedef double __attribute__((address_space(1))) big_gdouble;
+    big_gdouble *arow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        arow[r] = alpha_rm + ob[r] * n;
+        arow[r] = (big_gdouble *)(alpha_rm + ob[r] * n);
     double lm[4] = {1.0, 1.0, 1.0, 1.0}; // log-likelihood of my rows: product of the c_t, mantissa ...
     int le[4] = {0, 0, 0, 0};            // ... and exponent
     unsigned int trouble = 0u;
