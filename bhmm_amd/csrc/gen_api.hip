@@ -287,8 +287,14 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
         // states, 128 x 10 000: 236 of 2048 boundaries further than 1e-12 apart after the E-step's 120 steps, 4
         // after 240, none after 480), and a fix-up round costs half a first pass here: four times the E-step's
         // length, and segments as short as one warm-up (round 5; with the path-margin acceptance 25.7 -> 11 ms)
-        const int wmul = c->vit_margin ? 4 : 1, seg_warmups = c->vit_margin ? 1 : c->vit_seg_warmups;
-        int W_try = c->vit_W > 0 ? c->vit_W : std::max(64, c->spec_W > 0 ? (wmul * c->spec_W + 7) / 8 * 8 : 128 * wmul);
+        // -- but never longer than the segments that fill the chip (a slowly forgetting model keeps the E-step's
+        // length and its segment count; the rounds then do what the margins cannot)
+        const int seg_warmups = c->vit_margin ? 1 : c->vit_seg_warmups;
+        const int W0 = std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
+        const int64_t fill0 = ((c->total + (int64_t)c->vit_seg_per_simd * c->num_simd - 1) /
+                               ((int64_t)c->vit_seg_per_simd * c->num_simd) + 7) / 8 * 8;
+        int W_try = c->vit_W > 0 ? c->vit_W
+                    : (c->vit_margin ? (int)std::max<int64_t>(W0, std::min<int64_t>(4 * (int64_t)W0, fill0)) : W0);
         Segs sg;
         // the path-margin acceptance of the first pass (k_vit_margin, path_kernels.hpp; see wide_viterbi_run)
         const double vm_tol = 1e-12;
