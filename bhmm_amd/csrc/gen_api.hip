@@ -420,6 +420,116 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
             return BHMM_OK;
         }
     }
+    // 129 .. 256 states (round 5): four segments per workgroup share every pass over A (k_gen_viterbi_rows); first
+    // pass only -- accepted when every boundary is bit-identical or by the margins of the decisions on its path
+    // (k_vit_margin), else the serial kernel below decides
+    if (n > 128 && n <= 256 && c->spec_enabled && c->vit_margin && !c->vit_seg_given_up) {
+        uint8_t *ptr8 = reinterpret_cast<uint8_t *>(c->d_scratch.p);
+        uint8_t *p8 = out_fmt == 2 ? static_cast<uint8_t *>(paths_out) : reinterpret_cast<uint8_t *>(path);
+        const int64_t *off = c->d_offsets.p;
+        const int64_t want = (int64_t)GVR_ROWS * (c->num_simd / 4); // one workgroup of four segments per compute unit
+        const int64_t fill0 = ((c->total + want - 1) / want + 7) / 8 * 8;
+        const int W0 = std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
+        // (six E-step forgetting lengths, at most one and a half fill lengths: at 256 states one boundary of 749 was
+        // still 1e-12 off after 504 steps, none after 750 -- and a pass that is not accepted is lost time)
+        const int W_try = c->vit_W > 0 ? c->vit_W
+                                       : (int)std::max<int64_t>(W0, std::min<int64_t>(6 * (int64_t)W0, (3 * fill0 / 2 + 7) / 8 * 8));
+        const int64_t seglen = std::max<int64_t>(fill0, W_try);
+        Segs sg;
+        if ((rc = wide_path_plan_pub(c, 0, seglen, sg)))
+            return rc;
+        int64_t maxT = 0;
+        for (int k = 0; k < K; ++k)
+            maxT = std::max(maxT, c->offsets[k + 1] - c->offsets[k]);
+        c->vit_margin_used = 0;
+        c->vit_margin_close = 0;
+        c->vit_seg_rounds = 0;
+        // threads per target state (candidate ranges): 2 (BHMM_AMD_GVR_S = 1 / 4: experiments; measured 15.8 / 13.3 /
+        // 14.1 ms at 129 states with 1 / 2 / 4)
+        static const int gvr_s = getenv("BHMM_AMD_GVR_S") ? atoi(getenv("BHMM_AMD_GVR_S")) : 2;
+        const int GVR_S = gvr_s == 1 ? 1 : (gvr_s == 2 ? 2 : 4);
+        const size_t smr = (size_t)(2 * GVR_ROWS * n + GVR_ROWS) * sizeof(double) +
+                           (size_t)(GVR_S - 1) * GVR_ROWS * 256 * (sizeof(double) + sizeof(int));
+        if (sg.nseg > K && (rc = gen_transposed(c, m)) == BHMM_OK && c->d_gW.ensure((size_t)c->total * n) == BHMM_OK &&
+            c->d_aentry.ensure((size_t)sg.nseg * 256) == BHMM_OK && c->d_aexit.ensure((size_t)sg.nseg * 256) == BHMM_OK &&
+            c->d_vflag.ensure((size_t)sg.nseg) == BHMM_OK && c->d_specres.ensure(4) == BHMM_OK &&
+            c->d_vmaps.ensure((size_t)sg.nseg * 256) == BHMM_OK && c->d_vend.ensure((size_t)sg.nseg) == BHMM_OK) {
+            if (!c->h_specres)
+                BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
+                                       hipHostMallocDefault));
+            sg.W = W_try;
+            const double vm_tol = 1e-12;
+            double *vall = c->d_gW.p;
+            BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+            lds_poison(c->stream);
+#define BHMM_GVR(SV)                                                                                                  \
+    hipLaunchKernelGGL((k_gen_viterbi_rows<GVR_ROWS, SV>), dim3((sg.nseg + GVR_ROWS - 1) / GVR_ROWS), dim3(256 * SV), smr, \
+                       c->stream, m, off, sg, pobs, ptr8, last, c->d_aentry.p, c->d_aexit.p, vall)
+            if (GVR_S == 1)
+                BHMM_GVR(1);
+            else if (GVR_S == 2)
+                BHMM_GVR(2);
+            else
+                BHMM_GVR(4);
+#undef BHMM_GVR
+            hipLaunchKernelGGL((k_wide_vit_check<256>), dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg,
+                               c->d_aentry.p, (const double *)c->d_aexit.p, c->d_vflag.p, c->d_specres.p, vm_tol);
+            // the back-trace of this pass (needed either way)
+            hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t, 4>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                               (const uint8_t *)ptr8, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
+                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 256,
+                               (const int32_t *)last, c->d_vend.p);
+            if (out_fmt == 0)
+                hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t, 4>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path);
+            else
+                hipLaunchKernelGGL((k_wide_vit_walk<true, uint8_t, 4>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, p8);
+            BHMM_HIP(hipGetLastError());
+            BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost,
+                                    c->stream));
+            BHMM_HIP(hipStreamSynchronize(c->stream));
+            c->vit_seg_mismatch = (int)c->h_specres[3];
+            c->vit_far = (int)c->h_specres[0];
+            bool accepted = c->h_specres[3] == 0;
+            if (!accepted && c->h_specres[0] == 0) {
+                const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1;
+                const double margin = std::max(1e-10, 16.0 * (2e-15 * (double)maxT + vm_tol * maxseg));
+                BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                const dim3 mgrid(sg.nseg, (unsigned)((seglen + 255) / 256));
+                if (out_fmt == 0)
+                    hipLaunchKernelGGL((k_vit_margin<int32_t, 4, false>), mgrid, dim3(256), 0, c->stream,
+                                       (const double *)c->d_gAt.p, n, off, sg, (const double *)vall, (const int32_t *)path,
+                                       margin, c->d_specres.p);
+                else
+                    hipLaunchKernelGGL((k_vit_margin<uint8_t, 4, false>), mgrid, dim3(256), 0, c->stream,
+                                       (const double *)c->d_gAt.p, n, off, sg, (const double *)vall, (const uint8_t *)p8,
+                                       margin, c->d_specres.p);
+                BHMM_HIP(hipGetLastError());
+                BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost,
+                                        c->stream));
+                BHMM_HIP(hipStreamSynchronize(c->stream));
+                c->vit_margin_close = (int)c->h_specres[2];
+                accepted = c->h_specres[2] == 0;
+                c->vit_margin_used = accepted ? 1 : 0;
+            }
+            if (accepted) {
+                c->viterbi_chunked = true;
+                c->vit_W = W_try;
+                if (out_fmt == 0)
+                    BHMM_HIP(hipMemcpyAsync(paths_out, path, (size_t)c->total * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                            c->stream));
+                else if (out_fmt == 1)
+                    BHMM_HIP(hipMemcpyAsync(paths_out, p8, (size_t)c->total, hipMemcpyDeviceToHost, c->stream));
+                BHMM_HIP(hipStreamSynchronize(c->stream));
+                return BHMM_OK;
+            }
+            c->vit_seg_given_up = true; // these observations: the serial kernel from now on
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     size_t sm = gen_smem(n, 2, 2);
     if (gen_a_in_lds(n, sm)) {
         sm += gen_a_bytes(n);

@@ -964,6 +964,248 @@ __global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, cons
     }
 }
 
+// Viterbi over time segments for 129 .. 256 states (round 5): FOUR segments ("rows") per workgroup of 256 threads,
+// thread j = target state j of every row.  A no longer fits LDS (512 KB at 256 states) and the serial kernel above is
+// bound by streaming it from L2 once per step and trajectory; here one pass over A serves four rows: candidate i's
+// entry A[i][j] is loaded once (coalesced over j) and multiplied with v_r[i] of the four rows (LDS, [i][4]: two
+// 16-byte broadcast reads).  The arithmetic is the reference's, operation for operation (_hidden.c:203-281:
+// products v[i] A[i][j] in ascending i with a strict comparison -- the first maximum --, (p v[i^]) A[i^][j], the
+// normalising sum in ascending order by one thread per row, IEEE division), so a segment that starts from the serial
+// run's vector reproduces its vectors and back-pointers bit for bit.  First pass only (warm-up from the uniform
+// vector, every vector kept for k_vit_margin): the host accepts it when every boundary is bit-identical or by
+// the margins of the decisions on the path, and runs the serial kernel otherwise -- no fix-up rounds here.
+//   v_entry / v_exit [nseg][256];  vall [total][n];  ptr one byte per (t, j)
+typedef double gen_d2 __attribute__((ext_vector_type(2)));
+constexpr int GVR_ROWS = 4;
+template <int R, int S>
+__global__ __launch_bounds__(256 * S) void k_gen_viterbi_rows(const WideModel m, const int64_t *off, const Segs sg,
+                                                              const double *pobs, uint8_t *ptr, int32_t *last_state,
+                                                              double *v_entry, double *v_exit, double *vall)
+{
+    // S threads per target state (sp = threadIdx.x / 256, uniform per wavefront): candidate range sp of S, ascending.
+    // A range's winner is its FIRST maximum; ranges are merged in ascending order with a strict comparison, which is
+    // the first maximum over all candidates (_hidden.c:186-200).  The point of S: one wavefront per SIMD waits ten
+    // cycles per dependent fp64 instruction; S wavefronts per SIMD fill the pipe without more segments (= warm-ups).
+    static_assert(R == 4, "the candidate loop reads the four rows of v as two 16-byte pieces");
+    extern __shared__ __attribute__((aligned(16))) double gvr_sm[];
+    const int n = m.n, j = threadIdx.x & 255, sp = threadIdx.x >> 8, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *vT = gvr_sm;             // [n][R]: v of the previous step
+    double *vn = gvr_sm + R * n;     // [R][n]: this step's unnormalised vector
+    double *sS = gvr_sm + 2 * R * n; // [R]
+    double *mh = gvr_sm + 2 * R * n + R;                              // [S - 1][R][256]: winners of the ranges 1 .. S - 1
+    int *mb = reinterpret_cast<int *>(mh + (S > 1 ? (S - 1) * R * 256 : 0)); // ... and their indices
+    const bool real = j < n;
+    int sgi[R], k[R], nst[R];
+    int64_t o0[R], T[R], t0[R], t1[R], tw[R];
+    int nmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        sgi[r] = blockIdx.x * R + r;
+        const bool has = sgi[r] < sg.nseg && sg.len[sgi[r]] > 0;
+        k[r] = has ? sg.traj[sgi[r]] : 0;
+        o0[r] = has ? off[k[r]] : 0;
+        T[r] = has ? off[k[r] + 1] - o0[r] : 0;
+        t0[r] = has ? sg.t0[sgi[r]] : 0;
+        t1[r] = has ? t0[r] + sg.len[sgi[r]] : 0;
+        tw[r] = has ? ((t0[r] - sg.W > 0) ? t0[r] - sg.W : 0) : 0;
+        nst[r] = has ? (int)(t1[r] - tw[r]) : 0;
+        nmax = max(nmax, nst[r]);
+    }
+    if (real && sp == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            vT[j * R + r] = 1.0 / (double)n; // (warm-up start; replaced at t = 0)
+    }
+    __syncthreads();
+    const double pi_j = real ? m.pi[j] : 0.0;
+    const double *Ac = m.A + (real ? j : 0);
+    // my candidates: [lo, hi)
+    const int chunk = ((n + S - 1) / S + 7) / 8 * 8;
+    const int lo = min(sp * chunk, n), hi = min(lo + chunk, n);
+    for (int u = 0; u < nmax; ++u) {
+        bool act[R];
+        int64_t t[R];
+        double p[R], hm[R];
+        int best[R];
+        bool anyrec = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            act[r] = u < nst[r];
+            t[r] = tw[r] + u;
+            p[r] = (act[r] && real && sp == 0) ? pobs[(o0[r] + t[r]) * n + j] : 0.0;
+            best[r] = 0;
+            hm[r] = -1.0; // (an empty range never wins: the products are >= 0)
+            anyrec |= act[r] && t[r] > 0;
+        }
+        if (anyrec && real && lo < hi) { // (uniform per wavefront but for the idle threads)
+            {
+                const double a0 = Ac[(int64_t)lo * n];
+                const gen_d2 x0 = *reinterpret_cast<const gen_d2 *>(vT + lo * R);
+                const gen_d2 x1 = *reinterpret_cast<const gen_d2 *>(vT + lo * R + 2);
+                hm[0] = x0[0] * a0;
+                hm[1] = x0[1] * a0;
+                hm[2] = x1[0] * a0;
+                hm[3] = x1[1] * a0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    best[r] = lo;
+            }
+            // batches of eight candidates, the column entries of the next three batches on their way
+            const int i0 = lo + 1;
+            // (S wavefronts per SIMD have 512 / S registers each and hide latencies among themselves: shallower rings)
+            constexpr int NB = S > 1 ? 4 : 8, RD = S > 1 ? 2 : 4;
+            const int nb = (hi - i0) / NB;
+            double av[RD][NB];
+            // (every load is issued unconditionally, beyond the column with a clamped row index: with the loads under
+            // a branch the compiler's wait counts assumed the newest batch and the ring was one batch deep in effect)
+            auto issue = [&](int b, double (&dst)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int e = 0; e < NB; ++e)
+                    dst[e] = Ac[(int64_t)min(i0 + NB * b + e, n - 1) * n];
+            };
+#pragma unroll
+            for (int d = 0; d < RD - 1; ++d)
+                issue(d, av[d]);
+            // ... and the four rows of v for the next batch of candidates (a read issued where it is used costs its
+            // whole LDS latency: 325 cycles per candidate instead of the 90 of its arithmetic)
+            gen_d2 xv[2][NB][2];
+            auto vread = [&](int b, gen_d2 (&dst)[NB][2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int e = 0; e < NB; ++e) {
+                    const int ii = min(i0 + NB * b + e, n - 1);
+                    dst[e][0] = *reinterpret_cast<const gen_d2 *>(vT + ii * R);
+                    dst[e][1] = *reinterpret_cast<const gen_d2 *>(vT + ii * R + 2);
+                }
+            };
+            vread(0, xv[0]);
+#ifdef GVR_X_NOLOOP
+            for (int b0 = 0; b0 < 0; b0 += RD) {
+#else
+            for (int b0 = 0; b0 < nb; b0 += RD) {
+#endif
+#pragma unroll
+                for (int d = 0; d < RD; ++d) {
+                    const int b = b0 + d;
+                    issue(b + RD - 1, av[(d + RD - 1) % RD]);
+                    vread(b + 1, xv[(d + 1) & 1]);
+                    if (b < nb) { // (uniform)
+#pragma unroll
+                        for (int e = 0; e < NB; ++e) {
+                            const int ii = i0 + NB * b + e;
+                            const gen_d2 x0 = xv[d & 1][e][0], x1 = xv[d & 1][e][1];
+                            const double a = av[d][e];
+                            const double h0 = x0[0] * a, h1 = x0[1] * a, h2 = x1[0] * a, h3 = x1[1] * a; // _hidden.c:249
+                            if (h0 > hm[0]) { hm[0] = h0; best[0] = ii; }
+                            if (h1 > hm[1]) { hm[1] = h1; best[1] = ii; }
+                            if (h2 > hm[2]) { hm[2] = h2; best[2] = ii; }
+                            if (h3 > hm[3]) { hm[3] = h3; best[3] = ii; }
+                        }
+                    }
+                }
+            }
+            for (int i = i0 + NB * nb; i < hi; ++i) {
+                const double a = Ac[(int64_t)i * n];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double h = vT[i * R + r] * a;
+                    if (h > hm[r]) {
+                        hm[r] = h;
+                        best[r] = i;
+                    }
+                }
+            }
+        }
+        if constexpr (S > 1) { // the ranges' winners to range 0, merged in ascending order
+            if (sp > 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    mh[((sp - 1) * R + r) * 256 + j] = hm[r];
+                    mb[((sp - 1) * R + r) * 256 + j] = best[r];
+                }
+            }
+            __syncthreads();
+            if (sp == 0) {
+#pragma unroll
+                for (int q = 1; q < S; ++q)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double h = mh[((q - 1) * R + r) * 256 + j];
+                        const int bq = mb[((q - 1) * R + r) * 256 + j];
+                        if (h > hm[r]) {
+                            hm[r] = h;
+                            best[r] = bq;
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double x = 0.0;
+            if (act[r] && real && sp == 0) {
+                if (t[r] == 0) {
+                    x = p[r] * pi_j; // _hidden.c:232
+                } else {
+                    if (t[r] >= t0[r])
+                        ptr[(o0[r] + t[r]) * n + j] = (uint8_t)best[r];
+                    x = p[r] * vT[best[r] * R + r] * Ac[(int64_t)best[r] * n]; // _hidden.c:253: (p v[i^]) A[i^][j]
+                }
+            }
+            if (real && sp == 0)
+                vn[r * n + j] = x;
+        }
+        __syncthreads();
+        if (lane == 0 && wid < R) { // the normalising sum in ascending order (_hidden.c:256-259), one thread per row
+            const double *x = vn + wid * n;
+            double s = 0.0;
+            int i = 0;
+#ifdef GVR_X_NOSUM
+            i = n - 1;
+#endif
+            for (; i + 8 <= n; i += 8) {
+                double w8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    w8[e] = x[i + e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    s += w8[e];
+            }
+            for (; i < n; ++i)
+                s += x[i];
+            sS[wid] = s;
+        }
+        __syncthreads();
+        if (sp == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (act[r]) { // (the boundary vectors are compared over all 256 entries: zeros beyond n)
+                    const double v = real ? vn[r * n + j] / sS[r] : 0.0;
+                    if (real)
+                        vT[j * R + r] = v;
+                    if (t[r] == t0[r] - 1)
+                        v_entry[(int64_t)sgi[r] * 256 + j] = v;
+                    if (real && t[r] >= t0[r])
+                        vall[(o0[r] + t[r]) * n + j] = v;
+                    if (t[r] == t1[r] - 1)
+                        v_exit[(int64_t)sgi[r] * 256 + j] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the trajectory's final state (_hidden.c:262-267: first maximum) by the row that holds its last step
+    if (lane == 0 && wid < R && nst[wid] > 0 && t1[wid] == T[wid]) {
+        double bm = vT[wid];
+        int bi = 0;
+        for (int i = 1; i < n; ++i)
+            if (vT[i * R + wid] > bm) {
+                bm = vT[i * R + wid];
+                bi = i;
+            }
+        last_state[k[wid]] = bi;
+    }
+}
+
 // Backward draw over time segments for 65..512 states (round 4): the scheme of k_wide_sample_seg
 // (path_kernels.hpp) with SPL states per lane -- state e * 64 + lane in slot e --, one wavefront per
 // segment, column s_{t+1} of A read from the transposed copy `At` (coalesced).  The draws of different

@@ -1377,7 +1377,8 @@ __global__ void k_wide_vit_check(const Segs sg, double *v_entry, const double *v
 // a winner that is zero, denormal or not finite) are counted in result[2]; the host then runs the fix-up
 // rounds, which need none of this.   vall [total][n]: every vector of the first pass.
 // =========================================================================================
-template <typename PT, int NC>
+// ALDS = false (more than 128 states: A^T does not fit LDS): `A` is A TRANSPOSED in global memory, read per step.
+template <typename PT, int NC, bool ALDS = true>
 __global__ __launch_bounds__(256) void k_vit_margin(const double *A, int n, const int64_t *off, const Segs sg,
                                                     const double *vall, const PT *path, double margin,
                                                     unsigned int *result)
@@ -1388,9 +1389,11 @@ __global__ __launch_bounds__(256) void k_vit_margin(const double *A, int n, cons
     const int s = blockIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (s >= sg.nseg || sg.len[s] <= 0 || (int64_t)blockIdx.y * 256 >= sg.len[s])
         return;
-    for (int e = threadIdx.x; e < n * n; e += 256)
-        vm_sAT[(e % n) * n + e / n] = A[e];
-    __syncthreads();
+    if constexpr (ALDS) {
+        for (int e = threadIdx.x; e < n * n; e += 256)
+            vm_sAT[(e % n) * n + e / n] = A[e];
+        __syncthreads();
+    }
     const int k = sg.traj[s];
     const int64_t o0 = off[k], T = off[k + 1] - o0;
     const int64_t t1 = sg.t0[s] + sg.len[s];
@@ -1416,15 +1419,16 @@ __global__ __launch_bounds__(256) void k_vit_margin(const double *A, int n, cons
             const int64_t t = tb + q0 + u;
             if (q0 + u < cnt && t >= 1) { // (uniform)
                 const int j = __shfl(pj, q0 + u, 64), ih = __shfl(pi, q0 + u, 64);
-                const double *col = vm_sAT + (int64_t)j * n;
+                const double *col = (ALDS ? vm_sAT : A) + (int64_t)j * n;
                 double h[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
                     h[c] = lane + 64 * c < n ? vr[u][c] * col[lane + 64 * c] : 0.0; // _hidden.c:249
                 double hb = __shfl(h[0], ih & 63, 64);
-                if constexpr (NC > 1) {
-                    const double hb1 = __shfl(h[1], ih & 63, 64);
-                    hb = ih < 64 ? hb : hb1;
+#pragma unroll
+                for (int c = 1; c < NC; ++c) {
+                    const double hbc = __shfl(h[c], ih & 63, 64);
+                    hb = (ih >> 6) == c ? hbc : hb;
                 }
                 const double lim = hb - margin * hb;
                 bad |= !(hb >= 0x1p-960) || !(hb < 0x1p1000);

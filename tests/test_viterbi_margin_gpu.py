@@ -133,3 +133,39 @@ def test_tied_decisions_on_the_path_are_left_to_the_rounds():
         for p, r in zip(paths, ref):
             assert np.array_equal(p, r)
     eng.close()
+
+
+@pytest.mark.parametrize("n,kind", [(160, "gaussian"), (256, "discrete"), (129, "gaussian"), (200, "discrete")])
+def test_row_batched_first_pass_129_to_256_states(n, kind):
+    """129 .. 256 states: four segments per workgroup share every pass over A (k_gen_viterbi_rows), accepted when all
+    boundaries are bit-identical or by the margins on the path, else the serial kernel decides -- the oracle's paths
+    byte for byte either way (int32 and one-byte results), ragged lengths and single steps included."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(7700 + n)
+    M = 19
+    A, pi, p0, p1 = _model(n, rng, kind, M)
+    lengths = (9001, 1, 3000, 2, 650)
+    obs, pobs = _data(kind, rng, lengths, n, M, p0, p1)
+    ref = [orc.viterbi(A, po, pi) for po in pobs]
+    eng = Engine(0)
+    eng.set_observations(kind, obs, n, nsymbols=M if kind == "discrete" else 0)
+    accepted = 0
+    for W in (0, 160):
+        if W:
+            eng.set_option("viterbi_W", W)
+        paths = eng.viterbi(A, pi, p0, p1)
+        if eng.get_option("viterbi_chunked") == 1:
+            accepted += 1
+            assert eng.get_option("viterbi_segments") > len(lengths)
+            assert eng.get_option("viterbi_mismatch") == 0 or eng.get_option("viterbi_margin_used") == 1
+        for p, r in zip(paths, ref):
+            assert np.array_equal(p, r), W
+        p8 = eng.viterbi_u8(A, pi, p0, p1)
+        assert np.array_equal(p8, np.concatenate(ref).astype(np.uint8))
+    assert accepted >= 1
+    eng.set_option("viterbi_margin", 0)          # the serial kernel
+    paths = eng.viterbi(A, pi, p0, p1)
+    assert eng.get_option("viterbi_chunked") == 0
+    for p, r in zip(paths, ref):
+        assert np.array_equal(p, r)
+    eng.close()

@@ -7,7 +7,7 @@ from bench import metastable_matrix, stationary, timeit
 from bhmm_amd.engine import Engine
 dev = torch.device("cuda", 0)
 for n in [int(a) for a in sys.argv[1:]] or [64, 128]:
-    K, T = (128, 100000) if n == 64 else (128, 10000)
+    K, T = (128, 100000) if n == 64 else ((128, 4000) if n > 128 else (128, 10000))
     rng = np.random.default_rng(n)
     A = metastable_matrix(n, rng); pi = stationary(A)
     mu, sig = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
