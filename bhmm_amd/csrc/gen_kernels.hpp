@@ -1095,10 +1095,17 @@ __global__ __launch_bounds__(256 * S) void k_gen_viterbi_rows(const WideModel m,
                             const gen_d2 x0 = xv[d & 1][e][0], x1 = xv[d & 1][e][1];
                             const double a = av[d][e];
                             const double h0 = x0[0] * a, h1 = x0[1] * a, h2 = x1[0] * a, h3 = x1[1] * a; // _hidden.c:249
-                            if (h0 > hm[0]) { hm[0] = h0; best[0] = ii; }
-                            if (h1 > hm[1]) { hm[1] = h1; best[1] = ii; }
-                            if (h2 > hm[2]) { hm[2] = h2; best[2] = ii; }
-                            if (h3 > hm[3]) { hm[3] = h3; best[3] = ii; }
+                            // (the running maximum by v_max_f64 instead of two selects: the same value unless the
+                            // maximum so far is NaN -- and v is NaN in all components or in none, the normalising
+                            // sum sees to that; then every product is NaN and no comparison holds either way)
+                            best[0] = h0 > hm[0] ? ii : best[0];
+                            best[1] = h1 > hm[1] ? ii : best[1];
+                            best[2] = h2 > hm[2] ? ii : best[2];
+                            best[3] = h3 > hm[3] ? ii : best[3];
+                            hm[0] = __builtin_fmax(hm[0], h0);
+                            hm[1] = __builtin_fmax(hm[1], h1);
+                            hm[2] = __builtin_fmax(hm[2], h2);
+                            hm[3] = __builtin_fmax(hm[3], h3);
                         }
                     }
                 }

@@ -67,6 +67,22 @@ __global__ __launch_bounds__(256) void k(double *out, double seed)
         } else if constexpr (KIND == 12) { // one dependent chain of fma
             REP4(asm volatile("v_fma_f64 %0, %0, %1, %2\nv_fma_f64 %0, %0, %1, %2\nv_fma_f64 %0, %0, %1, %2\nv_fma_f64 %0, %0, %1, %2"
                               : "+v"(x0) : "v"(b), "v"(c));)
+        } else if constexpr (KIND == 14) { // fp64 compare into VCC (the select tree of the Viterbi kernels)
+            REP4(asm volatile("v_cmp_gt_f64 vcc, %0, %4\nv_cmp_gt_f64 vcc, %1, %4\nv_cmp_gt_f64 vcc, %2, %4\nv_cmp_gt_f64 vcc, %3, %4"
+                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(b) : "vcc");)
+        } else if constexpr (KIND == 15) { // 64-bit unsigned compare (the same order for non-negative doubles)
+            REP4(asm volatile("v_cmp_gt_u64 vcc, %0, %4\nv_cmp_gt_u64 vcc, %1, %4\nv_cmp_gt_u64 vcc, %2, %4\nv_cmp_gt_u64 vcc, %3, %4"
+                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(b) : "vcc");)
+        } else if constexpr (KIND == 16) { // select
+            REP4(asm volatile("v_cndmask_b32 %0, %0, %4, vcc\nv_cndmask_b32 %1, %1, %4, vcc\nv_cndmask_b32 %2, %2, %4, vcc\nv_cndmask_b32 %3, %3, %4, vcc"
+                              : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(e) : "vcc");)
+        } else if constexpr (KIND == 17) { // 32-bit compare
+            REP4(asm volatile("v_cmp_gt_u32 vcc, %0, %4\nv_cmp_gt_u32 vcc, %1, %4\nv_cmp_gt_u32 vcc, %2, %4\nv_cmp_gt_u32 vcc, %3, %4"
+                              : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(e) : "vcc");)
+        } else if constexpr (KIND == 18) { // the node of the select tree: compare, select index, max
+            REP4(asm volatile("v_cmp_gt_f64 vcc, %0, %4\nv_cndmask_b32 %2, %2, %5, vcc\nv_max_f64 %0, %0, %4\n"
+                              "v_cmp_gt_f64 vcc, %1, %4\nv_cndmask_b32 %3, %3, %5, vcc\nv_max_f64 %1, %1, %4"
+                              : "+v"(x0), "+v"(x1), "+v"(i0), "+v"(i1) : "v"(b), "v"(e) : "vcc");)
         } else if constexpr (KIND == 13) { // s_nop 1 between (hazard filler cost)
             REP4(asm volatile("v_fma_f64 %0, %0, %4, %5\ns_nop 1\nv_fma_f64 %1, %1, %4, %5\ns_nop 1\nv_fma_f64 %2, %2, %4, %5\ns_nop 1\nv_fma_f64 %3, %3, %4, %5\ns_nop 1"
                               : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(b), "v"(c));)
@@ -118,5 +134,10 @@ int main()
     run<9>("v_max_i32", out, ncu);
     run<11>("16 dpp + 16 fma_f64", out, ncu, 32);
     run<13>("v_fma_f64 + s_nop 1 (VALU only)", out, ncu);
+    run<14>("v_cmp_gt_f64", out, ncu);
+    run<15>("v_cmp_gt_u64", out, ncu);
+    run<17>("v_cmp_gt_u32", out, ncu);
+    run<16>("v_cndmask_b32", out, ncu);
+    run<18>("cmp_f64 + cndmask + max_f64 (x2)", out, ncu, 24);
     return 0;
 }
