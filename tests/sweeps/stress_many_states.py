@@ -25,6 +25,8 @@ for case in range(ncase):
     kind = "gaussian" if rng.random() < 0.5 else "discrete"
     K = int(rng.integers(1, 6))
     tmax = int(rng.choice([30, 300, 700])) if big else int(rng.choice([40, 500, 4000]))
+    if big and os.environ.get("MANY_TBIG"):   # (long trajectories: the segment-parallel Viterbi passes above 64 states)
+        tmax = int(os.environ["MANY_TBIG"])
     lens = [int(x) for x in rng.integers(1, tmax, K)]
     chunk = int(rng.choice([0, 0, 0, 17, 64, 250]))
     A = rng.random((n, n)) ** 2 + rng.choice([0.0, 3.0, 20.0]) * np.eye(n)
@@ -137,6 +139,8 @@ for case in range(ncase):
                 bad += 1
                 print("EXPLICIT ESTEP MISMATCH", tag, np.abs(r2.logL_k - ref["logL"]).max(), np.abs(r2.C - ref["C"]).max())
             e2.close()
+        if os.environ.get("MANY_VITW"):
+            eng.set_option("viterbi_W", int(os.environ["MANY_VITW"]))
         vp = eng.viterbi(A, pi, *par)
         for k, (p, po) in enumerate(zip(vp, pobs)):
             vr = orc.viterbi(A, po, pi)
