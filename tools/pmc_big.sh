@@ -21,9 +21,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dd = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     k = r['Kernel_Name']
-    if 'k_big_' in k and 'pack' not in k and 'finalize' not in k:
-        agg[k[:40]][r['Counter_Name']].append(float(r['Counter_Value']))
-        dd[k[:40]].append(dur.get(r['Dispatch_Id'], 0))
+    if ('k_big_' in k or 'k_tile_' in k) and 'pack' not in k and 'finalize' not in k and 'logl' not in k:
+        agg[k[:48]][r["Counter_Name"]].append(float(r['Counter_Value']))
+        dd[k[:48]].append(dur.get(r['Dispatch_Id'], 0))
 for k, cs in agg.items():
     print(k, "| avg us %.1f |" % (sum(dd[k][-12:]) / max(len(dd[k][-12:]), 1) / 1e3), {c: "%.4g" % (sum(v[-3:]) / len(v[-3:])) for c, v in cs.items()})
 PY
