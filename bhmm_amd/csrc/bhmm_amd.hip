@@ -1572,6 +1572,14 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
         c->vit_W = 0;
         c->spec_W_fixed = c->spec_calibrated = true; // the caller's choice: no probe
     }
+    else if (n == "draw_watch") // draws inside the reach of the alpha rows' verified deviation are decided again (draw_verify.hpp)
+        c->draw_watch = value != 0.0;
+    else if (n == "draw_watch_tol") { // (tests) watch tolerance instead of 64 x the measured deviation; 0: automatic
+        if (!(value >= 0.0 && value <= 0.5))
+            return invalid("draw_watch_tol outside [0, 0.5]");
+        c->draw_watch_tol = value;
+    } else if (n == "draw_test_redo") // (tests) every watched draw counts as a decision that did not stand
+        c->draw_test_redo = value != 0.0;
     else if (n == "wide_segments")
         c->wseg_enabled = value != 0.0;
     else if (n == "wide_segment_len")
@@ -1638,6 +1646,16 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->vit_margin_used;
     else if (n == "viterbi_margin_close") // ... segments with a close decision on the path (the rounds ran instead)
         *value = c->vit_margin_close;
+    else if (n == "draw_watch")
+        *value = c->draw_watch ? 1.0 : 0.0;
+    else if (n == "draw_events") // last path sampling: draws inside the watch tolerance
+        *value = c->draw_events;
+    else if (n == "draw_checked") // ... of them decided again on the windowed serial recursion
+        *value = c->draw_checked;
+    else if (n == "draw_redone") // ... the call was repeated on the exact alpha rows
+        *value = c->draw_redone;
+    else if (n == "draw_alpha_dev") // ... largest boundary deviation of the forward pass the draws read
+        *value = c->draw_alpha_dev;
     else if (n == "carry")
         *value = c->carry_enabled ? 1.0 : 0.0;
     else if (n == "carry_W") // warm-up steps of the last E-step's carried starts (0: full warm-ups)

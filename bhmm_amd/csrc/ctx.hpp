@@ -143,6 +143,7 @@ struct bhmm_ctx {
     struct PathPlan {
         int nseg = 0;
         int64_t seglen = 0;
+        int64_t maxlen = 0; // longest segment of the plan (boundaries are rounded to multiples of four: up to seglen + 3)
         bhmm::DevBuf<int32_t> traj, len, traj0; // traj0[k]: first segment of trajectory k, [K + 1]
         bhmm::DevBuf<int64_t> t0;
     } pplan[2];
@@ -152,6 +153,16 @@ struct bhmm_ctx {
     bool draw_fwd_segmented = false;  // ... its alpha rows came from the time-segmented forward pass
     bool smp_segmented = false;       // the last sample_paths call ran over time segments
     bhmm::DevBuf<int32_t> d_sentry, d_sexit;
+    // draws decided within reach of the alpha rows' verified deviation (draw_verify.hpp)
+    bhmm::DevBuf<char> d_dv;          // [count | disagree | unconverged | pad] (16 B) | DrawEvent[DRAW_EVENT_CAP] | model
+    bool draw_watch = true;           // option "draw_watch": record and verify such draws
+    double draw_watch_tol = 0.0;      // option "draw_watch_tol" (tests): watch tolerance instead of 64 x deviation
+    bool draw_test_redo = false;      // option "draw_test_redo" (tests): treat every event as a decision that did not stand
+    double draw_alpha_dev = 0.0;      // largest boundary deviation of the forward pass the draws read (0: exact rows)
+    bool draw_force_exact = false;    // the call in flight is the repeat on exact alpha rows
+    unsigned int draw_events = 0;     // last call: draws inside the watch tolerance
+    unsigned int draw_checked = 0;    // ... of them decided again on the windowed serial recursion
+    unsigned int draw_redone = 0;     // ... calls repeated on the exact alpha rows (0 / 1)
     double spec_tol = 1e-11;          // N <= 8: tolerance of the boundary check (option spec_tol)
     int vit_seg_per_simd = 2;
     int vit_seg_warmups = 2;          // a Viterbi segment is at least this many warm-ups long (measured: 1, 2, 4)

@@ -22,6 +22,9 @@ int tile_gen_alloc(bhmm_ctx *c);
 int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags, bool *done);
 int tile_gen_forward_draw(bhmm_ctx *c, const WideModel &m, bool *done);
 int wide_path_plan_pub(bhmm_ctx *c, int which, int64_t seglen, Segs &sg);
+int draw_watch_prepare(bhmm_ctx *c, double tol, DrawWatch &w);
+int draw_verify_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0, const double *par1,
+                    unsigned int count, double thr, int64_t Wlong, bool *ok);
 
 namespace {
 
@@ -379,7 +382,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                     if ((rc = seg_walks()))
                         return rc;
                     BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
-                    const dim3 mgrid(sg.nseg, (unsigned)((seglen + 255) / 256));
+                    const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + 255) / 256)); // (the longest REAL segment)
                     if (out_fmt == 0)
                         hipLaunchKernelGGL((k_vit_margin<int32_t, 2>), mgrid, dim3(256), smm, c->stream, m.A, n, off, sg,
                                            (const double *)vall, (const int32_t *)path, margin, c->d_specres.p);
@@ -497,7 +500,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                 const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1;
                 const double margin = std::max(1e-10, 16.0 * (2e-15 * (double)maxT + vm_tol * maxseg));
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
-                const dim3 mgrid(sg.nseg, (unsigned)((seglen + 255) / 256));
+                const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + 255) / 256)); // (the longest REAL segment)
                 if (out_fmt == 0)
                     hipLaunchKernelGGL((k_vit_margin<int32_t, 4, false>), mgrid, dim3(256), 0, c->stream,
                                        (const double *)c->d_gAt.p, n, off, sg, (const double *)vall, (const int32_t *)path,
@@ -577,11 +580,19 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
     // alpha rows in d_alpha_rm: from the tile forward pass over time segments where it verifies
     // (65..128 states; the draw normalises alpha_t[i] A[i][s_{t+1}] itself, any factor per row cancels),
     // else from the serial recursion
+    // (the repeat of a call in which a watched draw did not stand, draw_verify.hpp: the serial recursion)
     bool fwd_seg = false;
-    if ((rc = tile_gen_forward_draw(c, m, &fwd_seg)))
+    if (!c->draw_force_exact && (rc = tile_gen_forward_draw(c, m, &fwd_seg)))
         return rc;
     c->draw_fwd_segmented = fwd_seg;
-    if (!fwd_seg && (rc = gen_forward(c, A, pi, par0, par1)))
+    if (!fwd_seg) {
+        c->draw_alpha_dev = 0.0;
+        if ((rc = gen_forward(c, A, pi, par0, par1)))
+            return rc;
+    }
+    // rows of a segmented pass: draws within 64 x the deviation its boundary check measured are recorded
+    DrawWatch watch;
+    if ((rc = draw_watch_prepare(c, fwd_seg ? 64.0 * std::max(c->draw_alpha_dev, 1e-16) : 0.0, watch)))
         return rc;
     const int n = c->n, K = c->K;
     const size_t nstat = (size_t)n * n + n;
@@ -632,7 +643,7 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
                        (const double *)c->d_gAt.p, (const int64_t *)c->d_offsets.p, sg,                 \
                        (const double *)c->d_alpha_rm.p, (const double *)udev, seed,                     \
                        (const int64_t *)c->d_soff.p, path, status, c->d_sentry.p, c->d_sexit.p,         \
-                       (const uint8_t *)c->d_vflag.p)
+                       (const uint8_t *)c->d_vflag.p, watch)
 #define BHMM_GSS_SPL(FIXV)       \
     do {                         \
         if (n <= 128)            \
@@ -677,6 +688,34 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
         }
     }
     size_t sm = gen_smem(n, 2, 4);
+    if (!seg_done && fwd_seg) { // (the serial draw has no watch: it reads rows of the serial recursion)
+        if ((rc = gen_forward(c, A, pi, par0, par1)))
+            return rc;
+        c->draw_fwd_segmented = false;
+        c->draw_alpha_dev = 0.0;
+    }
+    if (seg_done && watch.count) {
+        // watched draws are decided again on the serial recursion over a long window; if one does not stand, the
+        // whole call again on the rows of the serial recursion
+        unsigned int nwatched = 0;
+        BHMM_HIP(hipMemcpyAsync(&nwatched, watch.count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        if (nwatched) {
+            bool ok = false;
+            if ((rc = draw_verify_run(c, A, pi, par0, par1, nwatched, watch.tol, 8 * (int64_t)std::max(c->spec_W, 64), &ok)))
+                return rc;
+            if (!ok) {
+                const unsigned int ev = c->draw_events, ck = c->draw_checked;
+                c->draw_force_exact = true;
+                rc = gen_sample_run(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, stats_dev);
+                c->draw_force_exact = false;
+                c->draw_events = ev;
+                c->draw_checked = ck;
+                c->draw_redone = 1;
+                return rc;
+            }
+        }
+    }
     if (seg_done) {
         ;
     } else if (gen_a_in_lds(n, sm)) {

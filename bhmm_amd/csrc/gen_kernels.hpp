@@ -13,6 +13,8 @@
 
 #include "path_kernels.hpp"
 
+#include "draw_verify.hpp"
+
 namespace bhmm {
 
 constexpr int GEN_TPB = 256;   // threads per workgroup; thread q owns states q, q + 256, ...
@@ -1226,7 +1228,7 @@ __global__ __launch_bounds__(256) void k_gen_sample_seg(const WideModel m, const
                                                         const Segs sg, const double *alpha, const double *u,
                                                         uint64_t seed, const int64_t *soff, int32_t *path,
                                                         int *status, int32_t *s_entry, int32_t *s_exit,
-                                                        const uint8_t *flag)
+                                                        const uint8_t *flag, const DrawWatch watch)
 {
     __shared__ double xs[4][64 * SPL];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1273,10 +1275,15 @@ __global__ __launch_bounds__(256) void k_gen_sample_seg(const WideModel m, const
         }
         const double Sf = base, thr = r * Sf;
         const bool ok = Sf > 1e-290 && Sf < 1e290; // (also false for NaN)
-        bool near = !ok;
+        bool near = !ok, wnear = false;
 #pragma unroll
-        for (int e = 0; e < SPL; ++e)
+        for (int e = 0; e < SPL; ++e) {
             near |= real[e] && !(fabs(P[e] - thr) > 1e-12 * Sf);
+            wnear |= real[e] && !(fabs(P[e] - thr) > watch.tol * Sf);
+        }
+        // within reach of the deviation the alpha rows were verified to (watch.tol = 64 x that deviation; 0 for
+        // rows of the serial recursion): recorded below, decided again afterwards (draw_verify.hpp)
+        const bool watched = watch.tol > 0.0 && __ballot(wnear) != 0ull;
         int pick = -1;
         if (__ballot(near) == 0ull) {
 #pragma unroll
@@ -1308,6 +1315,8 @@ __global__ __launch_bounds__(256) void k_gen_sample_seg(const WideModel m, const
             if (lane == 0 && t < t1)
                 status[0] = BHMM_ERR_CHOICE;
             pick = n - 1;
+        } else if (__builtin_expect(watched && lane == 0 && t < t1, 0)) {
+            draw_record(watch, k, t, nxt, r, pick, -1.0);
         }
         nxt = pick;
         if constexpr (!FIX) {

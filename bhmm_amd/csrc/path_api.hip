@@ -13,6 +13,7 @@
 #include "host_common.hpp"
 #include "plan.hpp"
 #include "path_kernels.hpp"
+#include "draw_verify.hpp"
 
 namespace bhmm {
 int invalid_arg(const std::string &msg);
@@ -39,6 +40,66 @@ int gen_sample_path(int32_t *path, const double *alpha, const double *A, const d
                     int64_t T);
 int unpack_ws_rows(bhmm_ctx *c, double *dst_dev);
 Chunks chunks_pub(const bhmm_ctx *c);
+
+// ---- draws inside the reach of the alpha rows' verified deviation (draw_verify.hpp) ---------------
+// d_dv: [count | disagree | unconverged | checked] | DrawEvent[DRAW_EVENT_CAP] | model
+static inline size_t dv_model_offset() { return 16 + (size_t)DRAW_EVENT_CAP * sizeof(DrawEvent); }
+
+// watch for one sampling call: tol <= 0 (or the option off) leaves it switched off.  The four counters are
+// cleared on the stream.
+int draw_watch_prepare(bhmm_ctx *c, double tol, DrawWatch &w)
+{
+    w.ev = nullptr;
+    w.count = nullptr;
+    w.tol = 0.0;
+    c->draw_events = c->draw_checked = c->draw_redone = 0;
+    if (!c->draw_watch || !(tol > 0.0))
+        return BHMM_OK;
+    const size_t msz = ((size_t)c->n * c->n + 3 * (size_t)c->n +
+                        (c->kind == EMIT_DISC ? (size_t)c->n * c->M : 0)) * sizeof(double);
+    int rc = c->d_dv.ensure(dv_model_offset() + msz);
+    if (rc)
+        return rc;
+    BHMM_HIP(hipMemsetAsync(c->d_dv.p, 0, 16, c->stream));
+    w.count = reinterpret_cast<unsigned int *>(c->d_dv.p);
+    w.ev = reinterpret_cast<DrawEvent *>(c->d_dv.p + 16);
+    w.tol = c->draw_watch_tol > 0.0 ? c->draw_watch_tol : tol;
+    return BHMM_OK;
+}
+
+// `count` draws were recorded: those with gap <= thr are decided again on the windowed serial recursion.
+// *ok = every such decision stands (else the caller repeats the call on exact alpha rows).
+int draw_verify_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0, const double *par1,
+                    unsigned int count, double thr, int64_t Wlong, bool *ok)
+{
+    *ok = false;
+    c->draw_events = count;
+    if (count > DRAW_EVENT_CAP)
+        return BHMM_OK; // (more than the list holds: the exact rows decide)
+    const int n = c->n;
+    double *md = reinterpret_cast<double *>(c->d_dv.p + dv_model_offset());
+    BHMM_HIP(hipMemcpyAsync(md, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    BHMM_HIP(hipMemcpyAsync(md + (size_t)n * n, pi, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    double *mp0 = md + (size_t)n * n + n;
+    if (c->kind == EMIT_GAUSS) {
+        BHMM_HIP(hipMemcpyAsync(mp0, par0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        BHMM_HIP(hipMemcpyAsync(mp0 + n, par1, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    } else if (c->kind == EMIT_DISC) {
+        BHMM_HIP(hipMemcpyAsync(mp0, par0, (size_t)n * c->M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    unsigned int *res = reinterpret_cast<unsigned int *>(c->d_dv.p);
+    const size_t sm = (4 * (size_t)n + 8) * sizeof(double);
+    hipLaunchKernelGGL(k_draw_verify, dim3(count), dim3(256), sm, c->stream,
+                       reinterpret_cast<const DrawEvent *>(c->d_dv.p + 16), (int)count, (const double *)md, n, c->M,
+                       c->kind, (const void *)c->d_obs_rm.p, (const int64_t *)c->d_offsets.p, Wlong, thr, res + 1);
+    BHMM_HIP(hipGetLastError());
+    unsigned int h[4] = {0, 0, 0, 0};
+    BHMM_HIP(hipMemcpyAsync(h, res, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    BHMM_HIP(hipStreamSynchronize(c->stream));
+    c->draw_checked = h[3];
+    *ok = h[1] == 0 && h[2] == 0 && !(c->draw_test_redo && h[3] > 0);
+    return BHMM_OK;
+}
 
 namespace {
 
@@ -68,14 +129,20 @@ struct Tmp { // scoped raw device allocations for the context-free entry points
 template <int N>
 int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0,
                const double *par1, const double *u, uint64_t seed, int32_t *paths, int64_t *counts,
-               int64_t *n0, double *emis, double *stats_dev, bool defer_check = true)
+               int64_t *n0, double *emis, double *stats_dev, bool defer_check = true, bool exact = false)
 {
     // alpha -> CI workspace.  The boundary check of a speculative forward pass is only enqueued:
     // its verdict comes back with the results below, and a failed check repeats the call with the
     // waiting form (which then lengthens the warm-up / falls back to the exact pass).
     static const bool no_defer = getenv("BHMM_AMD_NO_DEFER") != nullptr; // (kernel experiments)
-    c->fwd_defer = defer_check && !no_defer;
+    c->fwd_defer = defer_check && !no_defer && !exact;
+    // exact: the transfer-matrix pass (every boundary vector computed, none assumed) -- the repeat of a call
+    // in which a watched draw did not stand (draw_verify.hpp)
+    const bool spec_saved = c->spec_enabled;
+    if (exact)
+        c->spec_enabled = false;
     int rc = forward_ci(c, A, pi, par0, par1);
+    c->spec_enabled = spec_saved;
     c->fwd_defer = false;
     if (rc)
         return rc;
@@ -144,6 +211,11 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     Model<N> m;
     fill_model_pub<N>(m, n, c->kind, c->M, A, pi, par0, par1);
     m.bt_global = bigM ? 1 : 0;
+    // rows of a speculative pass: draws within 64 x the tolerance of its boundary check are recorded (the
+    // measured deviation, usually far smaller, is applied when they are looked at)
+    DrawWatch watch;
+    if ((rc = draw_watch_prepare(c, c->rows32_valid && !exact ? 64.0 * c->spec_tol : 0.0, watch)))
+        return rc;
     {
         // exact chunk-parallel sampling: maps per part, stitch, apply + statistics
         const Chunks chs = chunks_pub(c);
@@ -156,15 +228,15 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         if (c->kind == EMIT_GAUSS)
             hipLaunchKernelGGL((k_smp_maps<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
                                chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
-                               fmap, status, dmark, nib, W8, Gp64, gw, Lp);
+                               fmap, status, dmark, nib, W8, Gp64, gw, Lp, watch);
         else if (c->kind == EMIT_DISC)
             hipLaunchKernelGGL((k_smp_maps<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
                                chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
-                               fmap, status, dmark, nib, W8, Gp64, gw, Lp);
+                               fmap, status, dmark, nib, W8, Gp64, gw, Lp, watch);
         else
             hipLaunchKernelGGL((k_smp_maps<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
                                chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
-                               fmap, status, dmark, nib, W8, Gp64, gw, Lp);
+                               fmap, status, dmark, nib, W8, Gp64, gw, Lp, watch);
         BHMM_HIP(hipGetLastError());
         if ((int64_t)c->G * P >= (int64_t)32 * K) // long chains: one wavefront per trajectory
             hipLaunchKernelGGL(k_smp_stitch, dim3(K), dim3(64), 0, c->stream,
@@ -214,6 +286,9 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
                                     c->stream));
     }
     BHMM_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    unsigned int nwatched = 0;
+    if (watch.count)
+        BHMM_HIP(hipMemcpyAsync(&nwatched, watch.count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     if (paths)
         BHMM_HIP(hipMemcpyAsync(paths, path, (size_t)c->total * sizeof(int32_t),
                                 hipMemcpyDeviceToHost, c->stream));
@@ -226,6 +301,24 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         if (!ok) // boundaries did not verify: everything above ran on wrong alpha rows
             return sample_run<N>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, stats_dev,
                                  false);
+    }
+    c->draw_alpha_dev = watch.count ? (double)c->spec_last_dev : 0.0;
+    if (nwatched) {
+        // draws inside 64 x the deviation the boundary check measured: decided again on the serial recursion
+        // over a long window; if one does not stand, the whole call again on the transfer-matrix rows
+        bool ok = false;
+        const double thr = c->draw_watch_tol > 0.0 ? c->draw_watch_tol
+                                                   : 64.0 * std::max((double)c->spec_last_dev, 1e-16);
+        if ((rc = draw_verify_run(c, A, pi, par0, par1, nwatched, thr, 8 * (int64_t)std::max(c->spec_W, 64), &ok)))
+            return rc;
+        if (!ok) {
+            const unsigned int ev = c->draw_events, ck = c->draw_checked;
+            rc = sample_run<N>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, stats_dev, false, true);
+            c->draw_events = ev;
+            c->draw_checked = ck;
+            c->draw_redone = 1;
+            return rc;
+        }
     }
     if (hstatus) {
         set_error("random choice found no state: alpha/A not normalisable (_hidden.c:299-304)");
@@ -273,6 +366,9 @@ int wide_path_plan(bhmm_ctx *c, int which, int64_t seglen, Segs &sg)
         BHMM_HIP(hipStreamSynchronize(c->stream)); // (the vectors go out of scope)
         pp.nseg = ns;
         pp.seglen = seglen;
+        pp.maxlen = 0;
+        for (int32_t l : sp.len)
+            pp.maxlen = std::max<int64_t>(pp.maxlen, l);
     }
     sg.traj = pp.traj.p;
     sg.len = pp.len.p;
@@ -659,7 +755,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                         return rc;
                     BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
                     const size_t smm = (size_t)n * n * sizeof(double);
-                    const dim3 mgrid(sg.nseg, (unsigned)((seglen + 255) / 256));
+                    const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + 255) / 256)); // (the longest REAL segment)
                     if (out_fmt == 0)
                         hipLaunchKernelGGL((k_vit_margin<int32_t, 1>), mgrid, dim3(256), smm, c->stream, m.A, n, off,
                                            sg, (const double *)vall, (const int32_t *)path, margin, c->d_specres.p);
@@ -758,13 +854,23 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
                     const double *par1, const double *u, uint64_t seed, int32_t *paths,
                     int64_t *counts, int64_t *n0, double *emis, double *stats_dev)
 {
-    int rc = wide_forward_draw(c, A, pi, par0, par1); // alpha (row-major, any scale per row) in d_alpha_rm
+    // alpha (row-major, any scale per row) in d_alpha_rm; the repeat of a call in which a watched draw did not
+    // stand (draw_verify.hpp) takes the serial recursion
+    int rc = c->draw_force_exact ? wide_forward(c, A, pi, par0, par1) : wide_forward_draw(c, A, pi, par0, par1);
     if (rc)
         return rc;
+    if (c->draw_force_exact) {
+        c->draw_fwd_segmented = false;
+        c->draw_alpha_dev = 0.0;
+    }
     WideModel m;
     if ((rc = wide_model_pub(c, c->kind, A, pi, par0, par1, m)))
         return rc;
     const int K = c->K, n = c->n, NP = c->N, GP = 64 / NP;
+    // rows of a segmented pass: draws within 64 x the deviation its boundary check measured are recorded
+    DrawWatch watch;
+    if ((rc = draw_watch_prepare(c, c->draw_fwd_segmented ? 64.0 * std::max(c->draw_alpha_dev, 1e-16) : 0.0, watch)))
+        return rc;
     const size_t nstat = (size_t)n * n + n;
     const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)n
                                              : (c->kind == EMIT_DISC ? (size_t)n * c->M : 0);
@@ -830,7 +936,7 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
     hipLaunchKernelGGL((k_wide_sample_seg<NPV, FIXV>), sgrid, sblk, 0, c->stream, m, off, sg,           \
                        (const double *)c->d_alpha_rm.p, (const double *)udev, seed, path, status,       \
                        (const int64_t *)c->d_soff.p, c->d_sentry.p, c->d_sexit.p,                       \
-                       (const uint8_t *)c->d_vflag.p)
+                       (const uint8_t *)c->d_vflag.p, watch)
 #define BHMM_WSS_NP(FIXV)          \
     do {                           \
         if (NP == 16)              \
@@ -875,8 +981,36 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
             c->smp_segmented = seg_done;
         }
     }
-    if (!seg_done)
+    if (!seg_done) {
+        if (c->draw_fwd_segmented) { // (the serial draw has no watch: it reads rows of the serial recursion)
+            if ((rc = wide_forward(c, A, pi, par0, par1)))
+                return rc;
+            c->draw_fwd_segmented = false;
+            c->draw_alpha_dev = 0.0;
+        }
         launch_serial();
+    } else if (watch.count) {
+        // watched draws are decided again on the serial recursion over a long window; if one does not stand, the
+        // whole call again on the rows of the serial recursion
+        unsigned int nwatched = 0;
+        BHMM_HIP(hipMemcpyAsync(&nwatched, watch.count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        BHMM_HIP(hipStreamSynchronize(c->stream));
+        if (nwatched) {
+            bool ok = false;
+            if ((rc = draw_verify_run(c, A, pi, par0, par1, nwatched, watch.tol, 8 * (int64_t)std::max(c->spec_W, 64), &ok)))
+                return rc;
+            if (!ok) {
+                const unsigned int ev = c->draw_events, ck = c->draw_checked;
+                c->draw_force_exact = true;
+                rc = wide_sample_run(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, stats_dev);
+                c->draw_force_exact = false;
+                c->draw_events = ev;
+                c->draw_checked = ck;
+                c->draw_redone = 1;
+                return rc;
+            }
+        }
+    }
     BHMM_HIP(hipGetLastError());
     if (counts || n0 || emis || stats_dev) {
         // the per-trajectory emission table in LDS, or -- alphabets too large for it -- in epart itself

@@ -18,6 +18,8 @@
 #include "estep_sweep.hpp"
 #include "wide_kernels.hpp"
 
+#include "draw_verify.hpp"
+
 namespace bhmm {
 
 // splitmix64-based uniform in [0,1) for global step index x (device-generated stream)
@@ -112,9 +114,10 @@ __global__ __launch_bounds__(64) void k_sample_path(const Model<N> m, const int6
 // SPEC (the map kernels, which also draw for next states the path may never take): a draw whose
 // weights are all zero -- an impossible next state under a sparse transition matrix -- returns -1
 // instead of raising; the caller marks that map entry, and only a walk that really uses it fails.
+// gap_out (optional): min_i |c_i - r S| / S, the distance of the uniform from the nearest cumulative sum
 template <int N, bool SPEC = false>
 __device__ __forceinline__ int pick_state(const double (&a)[N], const double *col, double r, int n,
-                                          int *status)
+                                          int *status, double *gap_out = nullptr)
 {
     double ps[N], c[N], S = 0.0;
 #pragma unroll
@@ -126,14 +129,18 @@ __device__ __forceinline__ int pick_state(const double (&a)[N], const double *co
     const double t = r * S, tol = 1e-13 * S;
     int pick = -1;
     bool amb = !(S > 0.0);
+    double gmin = 1e300;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double d = c[i] - t;
         const bool in = i < n;
         amb |= in && (fabs(d) <= tol);
+        gmin = in ? fmin(gmin, fabs(d)) : gmin;
         if (pick < 0 && in && d >= 0.0)
             pick = i;
     }
+    if (gap_out)
+        *gap_out = S > 0.0 ? gmin / S : 0.0;
     if (amb) { // the reference's own arithmetic (_normalize + _random_choice)
         double acc = 0.0;
         pick = -1;
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
                                                      const double *u, uint64_t seed, int P,
                                                      uint32_t *Fmap, int *status, int32_t *dmark,
                                                      uint32_t *nib, int W8, int64_t Gp, uint32_t *gw,
-                                                     int Lp)
+                                                     int Lp, const DrawWatch watch)
 {
     __shared__ __attribute__((aligned(16))) double sAt[N * N];
     __shared__ __attribute__((aligned(16))) double sEm[3 * N];
@@ -438,7 +445,12 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
             while (todo) {
                 const int x = __ffs(todo) - 1;
                 todo &= todo - 1;
-                const int y = pick_state<N, true>(a, last ? nullptr : sAt + x * N, r, n, status);
+                double gap;
+                const int y = pick_state<N, true>(a, last ? nullptr : sAt + x * N, r, n, status, &gap);
+                // a draw within reach of the deviation these alpha rows were verified to: recorded, decided
+                // again on the serial recursion afterwards (draw_verify.hpp; only rows of a speculative pass)
+                if (__builtin_expect(watch.tol > 0.0 && rows32 && y >= 0 && gap <= watch.tol, 0))
+                    draw_record(watch, ch.traj[g], t0 + s, x, r, y, gap); // (k re-read: not kept live for this)
                 // (bit 3 of a nibble: no state can precede next state x here)
                 G |= (y < 0 ? (8u | (uint32_t)(n - 1)) : (uint32_t)y) << (4 * x);
             }
@@ -2331,7 +2343,7 @@ template <int NP, bool FIX>
 __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
     const WideModel m, const int64_t *off, const Segs sg, const double *alpha_rm, const double *u,
     uint64_t seed, int32_t *path, int *status, const int64_t *soff, int32_t *s_entry, int32_t *s_exit,
-    const uint8_t *flag)
+    const uint8_t *flag, const DrawWatch watch)
 {
     constexpr int GP = 64 / NP;
     constexpr int TL = NP < 16 ? NP : 16;
@@ -2370,6 +2382,7 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
             ps = a * sAT[nxt * NP + i]; // _hidden.c:365 (padded states: 0 * 0)
         const double r = u ? u[o0 + t] : uniform01(seed, (uint64_t)(s0 + t));
         int pick = NP;
+        bool watched = false;
         {
             const double P = group_prefix_sum<NP>(ps);
             const double Sf = __shfl(P, NP - 1, NP); // the group's total
@@ -2377,6 +2390,9 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
             const bool ok = Sf > 1e-290 && Sf < 1e290; // (also false for NaN)
             const bool near = !ok || !(fabs(P - thr) > 1e-12 * Sf);
             const unsigned long long nearm = __ballot(near && real) & gmask;
+            // within reach of the deviation the alpha rows were verified to (watch.tol = 64 x that deviation;
+            // 0 for rows of the serial recursion): recorded below, decided again afterwards (draw_verify.hpp)
+            watched = watch.tol > 0.0 && (__ballot(real && !(fabs(P - thr) > watch.tol * Sf)) & gmask) != 0ull;
             if (nearm == 0ull) {
                 const unsigned long long ge = __ballot(P >= thr) & gmask;
                 pick = ge ? (int)__builtin_ctzll(ge) - gi * NP : NP;
@@ -2421,6 +2437,8 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
             if (i == 0 && t < t1)
                 status[0] = BHMM_ERR_CHOICE;
             pick = n - 1;
+        } else if (__builtin_expect(watched && i == 0 && t < t1, 0)) {
+            draw_record(watch, k, t, nxt, r, pick, -1.0);
         }
         nxt = pick;
         if constexpr (!FIX) {

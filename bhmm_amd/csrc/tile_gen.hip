@@ -335,6 +335,10 @@ int tile_gen_forward_draw(bhmm_ctx *c, const WideModel &m, bool *done)
     if ((rc = read_flags(c)))
         return rc;
     *done = c->h_specres[2] == 0 && (!segmented || c->h_specres[0] == 0);
+    float dev = 0.f; // (largest boundary deviation the check saw: what the draws' watch is sized by)
+    if (segmented)
+        memcpy(&dev, &c->h_specres[1], sizeof(float));
+    c->draw_alpha_dev = *done ? dev : 0.0;
     return BHMM_OK;
 }
 

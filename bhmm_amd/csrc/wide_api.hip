@@ -586,11 +586,16 @@ int wide_forward_draw(bhmm_ctx *c, const double *A, const double *pi, const doub
                                     hipMemcpyDeviceToHost, c->stream));
             BHMM_HIP(hipStreamSynchronize(c->stream));
             c->draw_fwd_segmented = c->h_specres[0] == 0 && (!lazy || c->h_specres[2] == 0);
-            if (c->draw_fwd_segmented)
+            if (c->draw_fwd_segmented) {
+                float dev; // (largest boundary deviation the check saw: what the draws' watch is sized by)
+                memcpy(&dev, &c->h_specres[1], sizeof(float));
+                c->draw_alpha_dev = dev;
                 return BHMM_OK;
+            }
         }
     }
     c->draw_fwd_segmented = false;
+    c->draw_alpha_dev = 0.0;
     return wide_forward(c, A, pi, par0, par1);
 }
 

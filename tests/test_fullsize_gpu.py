@@ -326,7 +326,33 @@ def test_configs2_full_batch_properties():
                                torch.bincount(obs, minlength=M).cpu().numpy(), rtol=1e-11)
     assert np.all(np.isfinite(res.logL_k)) and res.logL_k.shape == (K,)
     np.testing.assert_allclose(res.loglik, res.logL_k.sum(), rtol=1e-12)
+    full_chunk, full_W = eng.chunk_len, int(eng.get_option("spec_W"))   # the plan the bench's `value` runs on
+    full_per_traj = eng.num_chunks // K
+    assert eng.num_chunks == K * full_per_traj and full_per_traj > 32
     eng.close()                       # frees the 65 GB workspace
+    # The same time decomposition -- chunk length and warm-up of the full batch, forced -- on a 2-trajectory
+    # sub-batch, every statistic against the oracle (maximum_likelihood.py:249-282 on _hidden.c:16-183)
+    kk = [0, 1023]
+    sub2 = torch.cat([obs[k * T:(k + 1) * T] for k in kk])
+    eng3 = _engine()
+    eng3.set_option("spec_W", full_W)
+    eng3.set_observations_device("discrete", sub2.data_ptr(), off[:3], n, nsymbols=M, chunk=full_chunk)
+    assert eng3.chunk_len == full_chunk and eng3.num_chunks == 2 * full_per_traj
+    res3 = eng3.estep(A_eval, pi, B_eval)
+    assert eng3.get_option("spec_ok") == 1 and int(eng3.get_option("spec_W")) == full_W
+    np.testing.assert_allclose(res3.logL_k, res.logL_k[kk], rtol=1e-12)
+    host2 = [sub2[:T].cpu().numpy(), sub2[T:].cpu().numpy()]
+    ref2 = orc.estep("discrete", host2, A_eval, pi, B_eval, want_gamma=True)
+    np.testing.assert_allclose(res3.logL_k, ref2["logL"], rtol=1e-11)
+    np.testing.assert_allclose(res3.C, ref2["C"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(res3.state_counts, ref2["state_counts"], rtol=1e-9)
+    np.testing.assert_allclose(res3.gamma0_sum, ref2["gamma0_sum"], rtol=1e-9, atol=1e-14)
+    cnt2 = np.zeros((n, M))
+    for o2, g2 in zip(host2, ref2["gammas"]):
+        orc.update_pout(o2, g2, cnt2)
+    np.testing.assert_allclose(res3.symbol_counts, cnt2, rtol=1e-9, atol=1e-9)
+    eng3.close()
+    del sub2, ref2
     ks = [0, 511, 1023]               # sub-batch: first, middle, last trajectory
     sub = torch.cat([obs[k * T:(k + 1) * T] for k in ks])
     eng2 = _engine()

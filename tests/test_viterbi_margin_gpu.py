@@ -169,3 +169,97 @@ def test_row_batched_first_pass_129_to_256_states(n, kind):
     for p, r in zip(paths, ref):
         assert np.array_equal(p, r)
     eng.close()
+
+
+def _viterbi_vectors(A, pobs, pi):
+    """The max-product vectors of _hidden.c:203-281 (same association; used to place margins, not as a
+    reference: 1e-15 is enough for that) and the back-pointers."""
+    T, n = pobs.shape
+    V = np.empty((T, n))
+    ptr = np.zeros((T, n), dtype=np.int64)
+    v = pi * pobs[0]
+    v = v / v.sum()
+    V[0] = v
+    cols = np.arange(n)
+    for t in range(1, T):
+        h = v[:, None] * A
+        ih = h.argmax(axis=0)                    # first maximum, like the strict > of :186-200
+        vn = (pobs[t] * v[ih]) * A[ih, cols]
+        v = vn / vn.sum()
+        V[t] = v
+        ptr[t] = ih
+    return V, ptr
+
+
+def _path_margins(A, V, path):
+    """Relative margin of every decision ON the path: runner-up against winner (k_vit_margin's quantity)."""
+    T = len(path)
+    out = np.full(T, np.inf)
+    for t in range(1, T):
+        h = V[t - 1] * A[:, path[t]]
+        w = h[path[t - 1]]
+        h[path[t - 1]] = -1.0
+        out[t] = (w - h.max()) / w
+    return out
+
+
+@pytest.mark.parametrize("where", ["final", "middle"])
+def test_decision_with_a_margin_between_delta_and_16_delta_goes_to_the_rounds(where):
+    """A decision on the path whose margin (3e-10) lies between the bound delta on the first pass's deviation
+    (6e-11 here) and the 16 delta the rule asks for: the margin rule must refuse the pass (the fix-up rounds decide),
+    and the paths are the oracle's.  T = 40 * 256 - 1 with a 256-step warm-up makes the last segment 259 steps long
+    (plan_segments rounds the boundaries down to multiples of four): the final-state check and the steps above 256
+    of a segment are covered by the launch (round 5 sized its grid by the nominal segment length and skipped them)."""
+    from bhmm_amd.engine import Engine
+    n, T = 72, 40 * 256 - 1
+    tried = 0
+    for seed in range(8):
+        rng = np.random.default_rng(8800 + seed)
+        A, pi, mu, sig = _model(n, rng, "gaussian")
+        obs = rng.normal(0, 4, T)
+        pobs = orc.pobs_gaussian(obs, mu, sig)
+        V, ptr = _viterbi_vectors(A, pobs, pi)
+        if where == "final":
+            a = int(V[T - 1].argmax())
+            vb = V[T - 1].copy()
+            vb[a] = -1.0
+            b = int(vb.argmax())
+            pobs[T - 1, b] *= V[T - 1, a] / V[T - 1, b] * (1.0 - 3e-10)
+            V, ptr = _viterbi_vectors(A, pobs, pi)
+            order = np.sort(V[T - 1])
+            planted = (order[-1] - order[-2]) / order[-1]
+        else:
+            path0 = orc.viterbi(A, pobs, pi)
+            t = T - 2                                         # a step of the last segment above its 256th
+            h = V[t - 1] * A[:, path0[t]]
+            w = int(path0[t - 1])
+            hb = h.copy()
+            hb[w] = -1.0
+            i2 = int(hb.argmax())
+            pobs[t - 1, i2] *= h[w] / h[i2] * (1.0 - 3e-10)   # v_{t-1}[i2] up to just below the winner's product
+            V, ptr = _viterbi_vectors(A, pobs, pi)
+            planted = None
+        ref = orc.viterbi(A, pobs, pi)
+        marg = _path_margins(A, V, ref)
+        if where == "middle":
+            planted = marg[T - 260:].min()
+        if not (1.5e-10 < planted < 6e-10):
+            continue                                          # (the change moved the path: next seed)
+        eng = Engine(0)
+        eng.set_option("viterbi_seg_per_simd", 1)
+        eng.set_observations("explicit", [pobs], n)
+        eng.set_option("viterbi_W", 256)
+        path = eng.viterbi(A, pi)[0]
+        assert np.array_equal(path, ref)
+        assert eng.get_option("viterbi_chunked") == 1 and eng.get_option("viterbi_segments") == 40
+        mism, far = eng.get_option("viterbi_mismatch"), eng.get_option("viterbi_far")
+        if mism > 0 and far == 0:                             # the first pass was put to the margin rule
+            tried += 1
+            assert eng.get_option("viterbi_margin_close") >= 1
+            assert eng.get_option("viterbi_margin_used") == 0 and eng.get_option("viterbi_rounds") >= 1
+        p8 = eng.viterbi_u8(A, pi)
+        assert np.array_equal(p8, ref.astype(np.uint8))
+        eng.close()
+        if tried >= 2:
+            break
+    assert tried >= 1
