@@ -586,6 +586,22 @@ def secondary_whole_iterations(rk, model, args):
     return res
 
 
+def draw_watch_rates(eng, sweep, nsweeps):
+    """Over `nsweeps` path steps with different seeds: how many draws fell within 64 x the deviation the
+    boundary check of the forward pass measured (csrc/draw_verify.hpp), how many of them were decided again on
+    the windowed serial recursion, how many calls were repeated on the exact alpha rows."""
+    ev = ck = rd = 0
+    dev = 0.0
+    for sd in range(nsweeps):
+        sweep(1000 + sd)
+        ev += int(eng.get_option("draw_events"))
+        ck += int(eng.get_option("draw_checked"))
+        rd += int(eng.get_option("draw_redone"))
+        dev = max(dev, eng.get_option("draw_alpha_dev"))
+    return {"sweeps": nsweeps, "watched": ev, "decided_again": ck, "calls_repeated_on_exact_rows": rd,
+            "largest_boundary_deviation": dev}
+
+
 def secondary_c2_paths(torch, dev, local, eng, model, K, T, args):
     """Viterbi (bit-exact, one byte per step, device-resident result) and the Gibbs hidden-path
     sweep on the headline workload's engine (configs[1] shape; configs[4] is this sweep x 100)."""
@@ -607,6 +623,7 @@ def secondary_c2_paths(torch, dev, local, eng, model, K, T, args):
     dt = timeit(lambda: eng.sample_paths_dev(*margs, sbuf.data_ptr(), seed=1), 5, eng.sync, batches=5)
     C, n0, _ = eng.unpack_path_stats(sbuf.cpu().numpy())
     assert C.sum() == K * (T - 1) and n0.sum() == K
+    watch = draw_watch_rates(eng, lambda sd: eng.sample_paths_dev(*margs, sbuf.data_ptr(), seed=sd), 100)
     b_alg = 2 * 8 + 16 * 8 + 4                           # Gibbs path sweep
     res.append({"config": "configs[4] sweep: Gibbs hidden-path step (forward + backward sampling + "
                           "path statistics), 8-state Gaussian, %d x %d, one GPU" % (K, T),
@@ -614,6 +631,7 @@ def secondary_c2_paths(torch, dev, local, eng, model, K, T, args):
                 "path_steps_100_seconds": 100 * dt,
                 "note": "the hidden-path step alone; the whole sweep incl. parameter draws is the "
                         "'WHOLE Gibbs sweep' entries below",
+                "draws_next_to_a_cumulative_sum_edge": watch,
                 "roofline": {"bound": "hbm", "alg_bytes_per_timestep": b_alg,
                              "frac": b_alg * K * T / dt / 1e9 / HBM_PEAK_GBS}})
     return res
@@ -660,8 +678,10 @@ def secondary_c4(torch, dev, local, args):
                       "over_time_segments": bool(eng.get_option("viterbi_chunked")),
                       "segments": eng.get_option("viterbi_segments"), "warmup": eng.get_option("viterbi_W"),
                       "boundaries_not_bit_identical_after_first_pass": eng.get_option("viterbi_mismatch"),
+                      "boundaries_further_than_1e-12": eng.get_option("viterbi_far"),
                       "fixup_rounds": eng.get_option("viterbi_rounds"),
                       "accepted_by_path_margins": bool(eng.get_option("viterbi_margin_used")),
+                      "close_decisions_on_the_path": eng.get_option("viterbi_margin_close"),
                       "note": "paths as one byte per step into a device buffer"}
     for _ in range(3):
         eng.sample_paths(*margs, seed=1, want_paths=False)
@@ -673,6 +693,8 @@ def secondary_c4(torch, dev, local, args):
                               "segments_drawn_again": eng.get_option("sample_mismatch"),
                               "fixup_rounds": eng.get_option("sample_rounds"),
                               "note": "forward filter + backward draw + path statistics, counts on the device"}
+    out["gibbs_path_step"]["draws_next_to_a_cumulative_sum_edge"] = draw_watch_rates(
+        eng, lambda sd: eng.sample_paths(*margs, seed=sd, want_paths=False), 20)
     eng.close()
     # whole EM iterations on this shape (E-step + native M-step, the model changes every iteration)
     import bhmm_amd
@@ -772,6 +794,8 @@ def main():
                     help="offline PMC measurements quoted as roofline.traffic (tools/profile_r05.sh)")
     ap.add_argument("--chain-sweeps", type=int, default=20, help="Gibbs sweeps timed per chain variant")
     ap.add_argument("--em-iterations", type=int, default=30, help="whole EM iterations timed")
+    ap.add_argument("--only", default="", help="profiling aid: 'c3' runs the configs[3] block alone (E-step, "
+                                               "Viterbi, Gibbs path step -- exactly the calls of the full run) and prints it")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST AID for boxes with fewer GPUs than ranks: ranks share GPUs "
                          "(local rank modulo device count) and the all-reduce runs over gloo")
@@ -814,6 +838,10 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     rk = Ranks(torch, dist, world, rank, local, dev, backend, distributed, stream)
+
+    if args.only == "c3":
+        print(json.dumps({"configs3_64_states": secondary_c4(torch, dev, local, args)}))
+        return
 
     # ---- the headline: configs[2], strong-scaled --------------------------------------------------
     # (the CPU legs run AFTER the GPU timing: tens of seconds of host work between drawing the data
@@ -884,7 +912,8 @@ def main():
         if cb is not None:
             out["cpu_baseline"] = cb
             out["speedup_vs_1core"] = value / cb["value"]
-            out["target_50x_met"] = bool(world > 1 or out["speedup_vs_1core"] >= 50.0)
+            # the target is quoted on ONE GPU (BASELINE.json north_star): checked there, not a statement elsewhere
+            out["target_50x_met"] = bool(out["speedup_vs_1core"] >= 50.0) if world == 1 else None
             if world == 1:
                 assert out["target_50x_met"], "north-star target (>= 50x the reference CPU path) missed"
     ser.close()

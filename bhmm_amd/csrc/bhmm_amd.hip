@@ -1301,10 +1301,11 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     if (!c->spec_W_fixed)
         c->spec_W = 288;
     c->vit_W = 0;
-    c->pplan[0].nseg = c->pplan[1].nseg = 0;
+    c->pplan[0].nseg = c->pplan[1].nseg = c->pplan[2].nseg = 0;
     c->smp_W = 0;
     c->tile_latched = c->tile_enabled; // (ctx.hpp: one decision per set of observations)
     c->vit_seg_given_up = false;
+    c->vit_rows_fail = 0;
     c->vit_margin_want = getenv("BHMM_AMD_VIT_MARGIN_FORCE") != nullptr; // (sweeps: the margin rule at every state count)
     c->vit_bad = 0;
     c->vit_explore = true;
@@ -1560,6 +1561,8 @@ int bhmm_ctx_set_option(bhmm_ctx *c, const char *name, double value)
         c->vit_margin = value != 0.0;
         if (value == 2.0) // (up to 64 states: from the next call on, not only after a call with two or more rounds)
             c->vit_margin_want = true;
+    } else if (n == "viterbi_mend") { // 9..64 states: segments further than 1e-12 from their predecessors run again alone
+        c->vit_mend = value != 0.0;
     } else if (n == "viterbi_seg_per_simd") { // 9..64 states: segments per SIMD of the Viterbi pass
         if (value < 1 || value > 64)
             return BHMM_ERR_INVALID;
@@ -1640,6 +1643,8 @@ int bhmm_ctx_get_option(bhmm_ctx *c, const char *name, double *value)
         *value = c->vit_seg_mismatch;
     else if (n == "viterbi_margin")
         *value = c->vit_margin ? 1.0 : 0.0;
+    else if (n == "viterbi_mended") // ... segments its last call ran again up to a kept vector of the first pass
+        *value = c->vit_mended;
     else if (n == "viterbi_far") // ... boundaries of its first pass that were not equal to 1e-12
         *value = c->vit_far;
     else if (n == "viterbi_margin_used") // ... accepted by the margins of the decisions on its path (no fix-up rounds)

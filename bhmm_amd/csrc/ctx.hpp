@@ -25,6 +25,10 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete; // (owns its allocation)
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); } // (bhmm_ctx_destroy deletes the context on its own device: nothing is left behind)
     int ensure(size_t count)
     {
         if (count <= n)
@@ -146,7 +150,8 @@ struct bhmm_ctx {
         int64_t maxlen = 0; // longest segment of the plan (boundaries are rounded to multiples of four: up to seglen + 3)
         bhmm::DevBuf<int32_t> traj, len, traj0; // traj0[k]: first segment of trajectory k, [K + 1]
         bhmm::DevBuf<int64_t> t0;
-    } pplan[2];
+    } pplan[3]; // [0] Viterbi pass, [1] backward sampler, [2] back-trace of the Viterbi pass (finer: the walk is a
+                // chain of dependent look-ups, its time is the length of a segment)
     bhmm::DevBuf<uint8_t> d_vmaps, d_vend; // back-trace over segments: maps [nseg][64], last state of each segment
     int smp_W = 0;                    // sampler: warm-up (steps above a segment) of the next call
     int smp_seg_mismatch = 0, smp_seg_rounds = 0;
@@ -173,11 +178,14 @@ struct bhmm_ctx {
     bool vit_margin_want = false;     // 9..64 states: a call on these observations needed two or more fix-up rounds (the
                                       // margin acceptance costs about one short round: it is tried from then on)
     int vit_far = 0;                  // ... boundaries of the last first pass that were not equal to 1e-12
+    bool vit_mend = true;             // option "viterbi_mend": those segments alone are run again up to a kept vector
+    int vit_mended = 0;               // ... how many the last call ran again that way
     int vit_margin_used = 0;          // ... the last call was accepted that way
     int vit_margin_close = 0;         // ... segments with a close decision on the path in the last call (then: rounds)
     bhmm::DevBuf<double> d_vckpt;  // the first pass's vector at every 64th step
     bhmm::DevBuf<uint8_t> d_vflag; // segments the next fix-up round repeats
     bool vit_seg_given_up = false;    // ... boundaries did not coalesce on these observations: serial kernel
+    int vit_rows_fail = 0;            // 129..256 states: first passes in a row that were not accepted (two: given up)
     int vit_W = 0;                    // warm-up the chunked Viterbi last verified with (0: spec_W)
     int vit_bad = 0;                  // ... a shorter one that did not verify
     bool vit_explore = true;          // ... still trying shorter ones (path_api.hip)

@@ -346,7 +346,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                 break;
             sg.W = W_try;
             if ((rc = c->d_aentry.ensure((size_t)sg.nseg * 128)) || (rc = c->d_aexit.ensure((size_t)sg.nseg * 128)) ||
-                (rc = c->d_vckpt.ensure(((size_t)(c->total >> 6) + 1) * 128)) || (rc = c->d_vflag.ensure((size_t)sg.nseg)))
+                (rc = c->d_vckpt.ensure(((size_t)(c->total >> 6) + 1) * 128)) || (rc = c->d_vflag.ensure(2 * (size_t)sg.nseg)))
                 return rc;
             const dim3 sgrid((sg.nseg + 7) / 8), sblk(512);
             int round = 0;
@@ -455,7 +455,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                            (size_t)(GVR_S - 1) * GVR_ROWS * 256 * (sizeof(double) + sizeof(int));
         if (sg.nseg > K && (rc = gen_transposed(c, m)) == BHMM_OK && c->d_gW.ensure((size_t)c->total * n) == BHMM_OK &&
             c->d_aentry.ensure((size_t)sg.nseg * 256) == BHMM_OK && c->d_aexit.ensure((size_t)sg.nseg * 256) == BHMM_OK &&
-            c->d_vflag.ensure((size_t)sg.nseg) == BHMM_OK && c->d_specres.ensure(4) == BHMM_OK &&
+            c->d_vflag.ensure(2 * (size_t)sg.nseg) == BHMM_OK && c->d_specres.ensure(4) == BHMM_OK &&
             c->d_vmaps.ensure((size_t)sg.nseg * 256) == BHMM_OK && c->d_vend.ensure((size_t)sg.nseg) == BHMM_OK) {
             if (!c->h_specres)
                 BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_specres), 4 * sizeof(unsigned int),
@@ -520,6 +520,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
             if (accepted) {
                 c->viterbi_chunked = true;
                 c->vit_W = W_try;
+                c->vit_rows_fail = 0;
                 if (out_fmt == 0)
                     BHMM_HIP(hipMemcpyAsync(paths_out, path, (size_t)c->total * sizeof(int32_t), hipMemcpyDeviceToHost,
                                             c->stream));
@@ -528,7 +529,13 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                 BHMM_HIP(hipStreamSynchronize(c->stream));
                 return BHMM_OK;
             }
-            c->vit_seg_given_up = true; // these observations: the serial kernel from now on
+            // One pass that was not accepted (a close decision under THIS model -- an early EM iterate, say) sends
+            // this call to the serial kernel; the next call tries again with twice the warm-up, and only a second
+            // failure in a row (or a warm-up that would exceed half a trajectory) gives the observations up.
+            if (++c->vit_rows_fail >= 2 || 4 * (int64_t)W_try > maxT)
+                c->vit_seg_given_up = true;
+            else
+                c->vit_W = 2 * W_try;
         } else {
             (void)hipGetLastError();
         }

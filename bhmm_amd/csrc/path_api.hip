@@ -418,14 +418,18 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     // 9..64 states over time segments, discrete: the kernel gathers from B itself (no (total, n) matrix).
     // Measured for the Gaussian kind too: the division by sigma and the exponential in every step,
     // warm-ups included, cost more than the matrix pass saves (64 states: 9.0 -> 9.7 ms, 16: 0.67 -> 0.81).
-    const bool wide_direct = c->wide && c->kind == EMIT_DISC && c->spec_enabled && !c->vit_seg_given_up;
+    // (round 6: the Gaussian density in the step too, with the reciprocal-based quotient and the one-block
+    // exponential of k_pobs_lanes -- at 64 states: 6.5 GB less written and read again per call)
+    static const bool gauss_matrix = getenv("BHMM_AMD_VIT_GAUSS_MATRIX") != nullptr; // (experiments: the round-5 way)
+    const bool wide_direct = c->wide && (c->kind == EMIT_DISC || (c->kind == EMIT_GAUSS && !gauss_matrix)) &&
+                             c->spec_enabled && !c->vit_seg_given_up;
     if (c->kind != EMIT_EXPL && !disc_direct && !wide_direct) {
         size_t freeb = 0, totb = 0;
         const size_t need = (size_t)c->total * n * sizeof(double);
         if (hipMemGetInfo(&freeb, &totb) == hipSuccess && need + ((size_t)1 << 30) < freeb + c->d_alpha_rm.n * sizeof(double) &&
             c->d_alpha_rm.ensure((size_t)c->total * n) == BHMM_OK) {
             const dim3 pg((unsigned)((c->total + 255) / 256)), pb(256);
-            const dim3 pl((unsigned)(((size_t)c->total * n + 255) / 256));
+            const dim3 pl((unsigned)(((size_t)c->total * n + 256 * POBS_LANES_R - 1) / (256 * POBS_LANES_R)));
 #define BHMM_POBS_LANES(NLV)                                                                        \
     do {                                                                                            \
         if (c->kind == EMIT_GAUSS)                                                                  \
@@ -637,9 +641,15 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
     // segment arrives at its first step with the bit pattern its predecessor left there -- then the
     // back-pointers are the serial run's, by induction from the exact first segment of each trajectory
     if (c->wide && c->spec_enabled && !c->vit_seg_given_up) {
-        // warm-up: the E-step's (the filter's forgetting length) where it has been measured; no search of
-        // its own -- every length is exact, and the time is flat over a factor of four (tools/wide_viterbi.py)
-        int W_try = c->vit_W > 0 ? c->vit_W : std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
+        // warm-up: its own, not the E-step's.  Every length is exact (bitwise check + fix-up rounds), so the length
+        // only trades warm-up steps (W / segment length of the first pass) against rounds (1.1 ms each at configs[3],
+        // whatever the number of flagged segments) -- and the E-step's length says little about that: its boundary
+        // check asks for 1e-11 on every boundary, which after a dozen EM iterations on configs[3] takes 904 steps,
+        // while the max-product vectors are within rounding noise of their predecessors' after 128 (one round
+        // either way: 17.6 ms against 23.6).  Start at 128 steps (less if the filter forgets faster); a call that
+        // needed three or more rounds doubles the length for the next call on these observations, up to the E-step's.
+        const int W_estep = std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
+        int W_try = c->vit_W > 0 ? c->vit_W : std::min(128, W_estep);
         const bool exploring = false;
         if ((rc = c->d_specres.ensure(4)))
             return rc;
@@ -664,14 +674,20 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         c->vit_margin_close = 0;
         // back-trace over the segments: maps, stitch, apply
         auto seg_walks = [&]() -> int {
-            const Segs sgw{c->pplan[0].traj.p, c->pplan[0].t0.p, c->pplan[0].len.p, c->pplan[0].nseg, 0};
+            // on a plan of its own, eight times finer than the pass's: a walk is a chain of dependent look-ups, its
+            // time the length of a segment (configs[3]: 2 x 0.49 ms on the 2048 segments of the pass)
+            Segs sgw;
             int rcw;
+            static const int walk_div = getenv("BHMM_AMD_WALK_DIV") ? atoi(getenv("BHMM_AMD_WALK_DIV")) : 8;
+            if ((rcw = wide_path_plan(c, 2, std::max<int64_t>(256, c->pplan[0].seglen / walk_div), sgw)))
+                return rcw;
+            sgw.W = 0;
             if ((rcw = c->d_vmaps.ensure((size_t)sgw.nseg * 64)) || (rcw = c->d_vend.ensure((size_t)sgw.nseg)))
                 return rcw;
             hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t>), dim3(sgw.nseg), dim3(64), 0, c->stream, off, sgw, n,
                                (const uint8_t *)ptr, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
             hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
-                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 64,
+                               (const int32_t *)c->pplan[2].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 64,
                                (const int32_t *)last, c->d_vend.p);
             if (out_fmt == 0)
                 hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t>), dim3(sgw.nseg), dim3(64), 0, c->stream, off, sgw, n,
@@ -699,7 +715,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                 return rc;
             const dim3 sgrid((sg.nseg + GP * WVS_WPB - 1) / (GP * WVS_WPB)), sblk(64 * WVS_WPB);
             if ((rc = c->d_vckpt.ensure(((size_t)(c->total >> 6) + 1) * NP)) ||
-                (rc = c->d_vflag.ensure((size_t)sg.nseg)))
+                (rc = c->d_vflag.ensure(2 * (size_t)sg.nseg))) // ([nseg] flagged | [nseg] flagged and further than vm_tol)
                 return rc;
 #define BHMM_WVS(NPV, KINDV, FIXV)                                                                    \
     hipLaunchKernelGGL((k_wide_viterbi_seg<NPV, KINDV, FIXV>), sgrid, sblk, 0, c->stream, m, off, sg,  \
@@ -726,10 +742,25 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         else                           \
             BHMM_WVS_KIND(64, FIXV);   \
     } while (0)
+#define BHMM_WVS_MEND(NPV, KINDV)                                                                      \
+    hipLaunchKernelGGL((k_wide_viterbi_seg<NPV, KINDV, true>), sgrid, sblk, 0, c->stream, m, off, sg,   \
+                       obs, ptr, last, c->d_aentry.p, c->d_aexit.p, c->d_vckpt.p,                      \
+                       (const uint8_t *)c->d_vflag.p + sg.nseg, vall, vm_tol, c->d_specres.p + 1)
+#define BHMM_WVS_MEND_KIND(NPV)                   \
+    do {                                          \
+        if (vkind == EMIT_GAUSS)                  \
+            BHMM_WVS_MEND(NPV, EMIT_GAUSS);       \
+        else if (vkind == EMIT_DISC)              \
+            BHMM_WVS_MEND(NPV, EMIT_DISC);        \
+        else                                      \
+            BHMM_WVS_MEND(NPV, EMIT_EXPL);        \
+    } while (0)
             // pass 0 with warm-ups, then fix-up rounds while any boundary is not bit-identical
             const int max_rounds = 12;
             int round = 0;
             bool margin_accepted = false;
+            bool allow_mend = c->vit_mend, mended = false;
+            c->vit_mended = 0;
             for (; round <= max_rounds; ++round) {
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
                 lds_poison(c->stream);
@@ -747,16 +778,56 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                 }
                 if (c->h_specres[3] == 0)
                     break;
+                int spliced = 0;
+                if (round == 0 && vall && c->h_specres[0] != 0 && (int64_t)c->h_specres[0] * 2 <= sg.nseg && allow_mend) {
+                    mended = true;
+                    // Some boundaries are further than vm_tol from their predecessors' vectors (the warm-up was
+                    // too short THERE; the max-product vectors of a metastable model need several times the
+                    // filter's forgetting length at a few boundaries -- configs[3]: 276 of 2048 after 256 steps,
+                    // none after 904): those segments alone are run again from the predecessor's vector until
+                    // they are within vm_tol of a kept vector of the first pass (k_wide_viterbi_seg, mend_tol)
+                    // instead of lengthening every warm-up.  If one reaches its end the rounds decide.
+                    BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                    lds_poison(c->stream);
+                    if (NP == 16)
+                        BHMM_WVS_MEND_KIND(16);
+                    else if (NP == 32)
+                        BHMM_WVS_MEND_KIND(32);
+                    else
+                        BHMM_WVS_MEND_KIND(64);
+                    BHMM_HIP(hipGetLastError());
+                    unsigned int notmet = 0;
+                    BHMM_HIP(hipMemcpyAsync(&notmet, c->d_specres.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost,
+                                            c->stream));
+                    BHMM_HIP(hipStreamSynchronize(c->stream));
+                    c->vit_mended = (int)c->h_specres[0];
+                    if (notmet == 0) {
+                        spliced = (int)c->h_specres[0];
+                        c->h_specres[0] = 0;
+                    }
+                }
                 if (round == 0 && vall && c->h_specres[0] == 0) {
-                    // every boundary within vm_tol: the path of this pass, and the margins of the decisions on it
-                    const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1;
+                    // every boundary (and splice) within vm_tol: the path of this pass, and the margins of the
+                    // decisions on it
+                    const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1 + spliced;
                     const double margin = std::max(1e-10, 16.0 * (2e-15 * (double)maxT + vm_tol * maxseg));
                     if ((rc = seg_walks()))
                         return rc;
                     BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
                     const size_t smm = (size_t)n * n * sizeof(double);
                     const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + 255) / 256)); // (the longest REAL segment)
-                    if (out_fmt == 0)
+                    static const bool vm_global = getenv("BHMM_AMD_VM_GLOBAL") != nullptr; // (experiment: A^T from L2)
+                    if (vm_global) {
+                        if ((rc = c->d_gAt.ensure((size_t)n * n)))
+                            return rc;
+                        hipLaunchKernelGGL(k_vm_transpose, dim3((n * n + 255) / 256), dim3(256), 0, c->stream, m.A, n, c->d_gAt.p);
+                        if (out_fmt == 0)
+                            hipLaunchKernelGGL((k_vit_margin<int32_t, 1, false>), mgrid, dim3(256), 0, c->stream, (const double *)c->d_gAt.p, n, off,
+                                               sg, (const double *)vall, (const int32_t *)path, margin, c->d_specres.p);
+                        else
+                            hipLaunchKernelGGL((k_vit_margin<uint8_t, 1, false>), mgrid, dim3(256), 0, c->stream, (const double *)c->d_gAt.p, n, off,
+                                               sg, (const double *)vall, (const uint8_t *)path8, margin, c->d_specres.p);
+                    } else if (out_fmt == 0)
                         hipLaunchKernelGGL((k_vit_margin<int32_t, 1>), mgrid, dim3(256), smm, c->stream, m.A, n, off,
                                            sg, (const double *)vall, (const int32_t *)path, margin, c->d_specres.p);
                     else
@@ -774,12 +845,28 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                     }
                     // (a close decision on the path: the rounds decide)
                 }
+                if (round == 0 && mended) {
+                    // The rounds compare BITWISE with the kept vectors of the first pass; a mended segment now
+                    // holds exact vectors up to its splice and first-pass vectors behind it, so a repeated run
+                    // would stop at the first kept vector and take the rest for exact.  A pass that was mended and
+                    // then not accepted is therefore run again from scratch, without mending (one first pass lost).
+                    allow_mend = false;
+                    mended = false;
+                    round = -1;
+                }
             }
 #undef BHMM_WVS_NP
 #undef BHMM_WVS_KIND
 #undef BHMM_WVS
+#undef BHMM_WVS_MEND_KIND
+#undef BHMM_WVS_MEND
             c->vit_seg_rounds = round;
-            if (round >= 2)
+            // (a round runs as long as its longest flagged segment needs to fall onto a vector of the first pass
+            // again: 1.1 ms at configs[3] on white-noise observations, 6.7 ms -- half a first pass -- on
+            // observations drawn from the model, where 1800 of 2048 boundaries carry rounding noise.  The margins
+            // cost about 1.3 ms there: wanted from the next call on when rounds were many, or the flagged
+            // segments more than a quarter)
+            if (round >= 2 || (round >= 1 && !margin_accepted && (int64_t)c->vit_seg_mismatch * 4 > sg.nseg))
                 c->vit_margin_want = true;
             const bool accepted = c->h_specres[3] == 0 || margin_accepted;
             // (How many boundaries the first pass left to the fix-up does not say whether the warm-up was
@@ -789,7 +876,10 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                 continue;
             if (accepted) {
                 done = true;
-                c->vit_W = W_try;
+                // (boundaries further than 1e-12 apart keep the margin rule from being asked: a longer warm-up for
+                // the next call, like after three or more rounds -- never beyond the E-step's)
+                const bool longer = (vall && c->vit_far > 0 && !margin_accepted) || (round >= 3 && !margin_accepted);
+                c->vit_W = (longer && W_try < W_estep) ? std::min(2 * W_try, W_estep) : W_try;
             }
         }
         if (!done && c->pplan[0].nseg > K)

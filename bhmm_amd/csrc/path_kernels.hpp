@@ -1179,13 +1179,23 @@ __device__ __forceinline__ void sum16_bcast(double &S, const double &src, const 
                  : "v"(src), "v"(one));
 }
 
+__device__ __forceinline__ double gauss_exp_block(double x, double cn); // (below: cn * exp_nonpos(x), one block)
+
 constexpr int WVS_WPB = 4;
+#ifndef WVS_LDS_ROWS
+#define WVS_LDS_ROWS 3 // 64 states: rows of 16 candidates whose v comes from LDS (0 .. 4; measured: DESIGN.md section 5)
+#endif
 template <int NP, int KIND, bool FIX>
 __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     const WideModel m, const int64_t *off, const Segs sg, const void *obs_rm, uint8_t *ptr,
     int32_t *last_state, double *v_entry, double *v_exit, double *ckpt, const uint8_t *flag,
-    double *vall = nullptr)
+    double *vall = nullptr, double mend_tol = 0.0, unsigned int *notmet = nullptr)
 {
+    // FIX with mend_tol > 0 ("mending" round, round 6): the segments whose entry vector was further than the
+    // tolerance from the predecessor's are run again from the predecessor's vector only until they are within
+    // that tolerance of a vector the first pass kept (every 64th step) -- from there on the first pass's
+    // vectors stand, a splice like a boundary that is equal to the tolerance (k_vit_margin's budget counts
+    // it).  Every vector of the repeated stretch goes to vall; a segment that reaches its end counts in notmet.
     constexpr int GP = 64 / NP;
     __shared__ __attribute__((aligned(16))) double xv[WVS_WPB][GP][NP];
     __shared__ double sA[NP * NP];
@@ -1210,7 +1220,8 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
         Acol[i] = sA[i * NP + j];
     const double mu_j = (KIND == EMIT_GAUSS && real) ? m.mu[j] : 0.0;
     const double sg_j = (KIND == EMIT_GAUSS && real) ? m.sigma[j] : 1.0;
-    const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0;
+    const double rs_j = 1.0 / sg_j; // correctly rounded: IEEE division
+    const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0; // (0 on padding lanes)
     const double pi_j = real ? m.pi[j] : 0.0;
     const int k = sg.traj[sgi];
     const int64_t o0 = off[k], T = off[k + 1] - o0;
@@ -1219,9 +1230,14 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     auto emis = [&](int64_t gt) __attribute__((always_inline)) {
         double p;
         if constexpr (KIND == EMIT_GAUSS) {
-            const double o = static_cast<const double *>(obs_rm)[gt];
-            const double d = (o - mu_j) / sg_j;
-            p = real ? cn_j * exp_nonpos(-0.5 * d * d) : 0.0; // _gaussian.c:18-20
+            // _gaussian.c:18-20 with the arithmetic of k_pobs_lanes (the same bits): the quotient by sigma from
+            // the correctly rounded reciprocal, constant and exponential as one block -- 27 instructions where
+            // the division and the statement-wise exponential took 60 (round 4 measured the in-step density
+            // slower than the emission-matrix pass with those; with these it is 0.7 ms against 1.9 at configs[3])
+            const double x = static_cast<const double *>(obs_rm)[gt] - mu_j;
+            const double q0 = x * rs_j;
+            const double d = fma(fma(-q0, sg_j, x), rs_j, q0); // == x / sigma
+            p = gauss_exp_block(-0.5 * d * d, cn_j);
             if ((__ballot(p != 0.0) & gmask) == 0ull)
                 p = real ? 1.0 : 0.0;
         } else if constexpr (KIND == EMIT_DISC) {
@@ -1234,6 +1250,8 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     };
     // (warm-up start; replaced at t = 0.  FIX: the predecessor's vector, t0 > 0 for a flagged segment)
     double v = FIX ? v_entry[(int64_t)sgi * NP + j] : (real ? 1.0 / (double)n : 0.0);
+    if constexpr (NP == 64 && WVS_LDS_ROWS > 0)
+        xv[w][gi][j] = v; // (LDS copy of v for the upper candidate rows of the next step)
     double p_next = emis(o0 + tw);
     bool met = false; // FIX: the run reproduced a vector of the first pass
     for (int64_t t = tw; t < t1; ++t) {
@@ -1261,10 +1279,23 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
                 for (int k = 0; k < NP / 16; ++k) {
                     double hh[16];
                     int ii[16];
-                    auto wk = [&](auto ic) __attribute__((always_inline)) { return Acol[16 * k + decltype(ic)::value]; };
-                    asm volatile("s_nop 1"); // (a DPP read needs two wait states after the write of its register)
-                    prod8_bcast<0>(hh, R.r[k], wk);
-                    prod8_bcast<8>(hh, R.r[k], wk);
+                    if (NP == 64 && k >= NP / 16 - WVS_LDS_ROWS) {
+                        // (round 6) the upper rows of candidates read v from its LDS copy -- every lane the same
+                        // address, 16 bytes a read: the LDS pipe idles in this kernel -- and multiply with ONE
+                        // instruction; the row-broadcast form needs a cleared accumulator per product.  Same
+                        // product, rounded once either way.
+#pragma unroll
+                        for (int q = 0; q < 16; q += 2) {
+                            const double2 y = *reinterpret_cast<const double2 *>(&xv[w][gi][16 * k + q]);
+                            hh[q] = y.x * Acol[16 * k + q];
+                            hh[q + 1] = y.y * Acol[16 * k + q + 1];
+                        }
+                    } else {
+                        auto wk = [&](auto ic) __attribute__((always_inline)) { return Acol[16 * k + decltype(ic)::value]; };
+                        asm volatile("s_nop 1"); // (a DPP read needs two wait states after the write of its register)
+                        prod8_bcast<0>(hh, R.r[k], wk);
+                        prod8_bcast<8>(hh, R.r[k], wk);
+                    }
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
                         ii[i] = 16 * k + i;
@@ -1308,16 +1339,21 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
                 sum16_bcast(S, Rn.r[k], one);
         }
         v = vn / S;
+        if constexpr (NP == 64 && WVS_LDS_ROWS > 0)
+            xv[w][gi][j] = v; // (the next step's upper candidate rows read it from here)
         if constexpr (!FIX) {
             if (t == t0 - 1)
                 v_entry[(int64_t)sgi * NP + j] = v;
-            if (vall && real && t >= t0) // (every vector of the first pass, [total][n]: k_vit_margin)
-                vall[(o0 + t) * n + j] = v;
         }
+        if (vall && real && t >= t0) // (every vector of the first pass / of a mended stretch, [total][n]: k_vit_margin)
+            vall[(o0 + t) * n + j] = v;
         if (((o0 + t) & 63) == 63 && t >= t0) {
             double *cp = ckpt + ((o0 + t) >> 6) * NP + j;
             if constexpr (FIX) {
-                const bool same = __double_as_longlong(*cp) == __double_as_longlong(v);
+                const double cv = *cp;
+                bool same = __double_as_longlong(cv) == __double_as_longlong(v);
+                if (mend_tol > 0.0) // (uniform)
+                    same = same || (fabs(cv - v) <= mend_tol * cv && (cv == 0.0) == (v == 0.0));
                 if ((__ballot(!same) & gmask) == 0ull) {
                     met = true;
                     break;
@@ -1328,6 +1364,8 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     }
     if (met)
         return;
+    if (FIX && notmet && j == 0)
+        atomicAdd(notmet, 1u);
     v_exit[(int64_t)sgi * NP + j] = v;
     if (t1 == T) { // the trajectory's final state (_hidden.c:262-267: first maximum)
         xv[w][gi][j] = v;
@@ -1348,6 +1386,7 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
 // are flagged, and their entry vector becomes the predecessor's (what the fix-up pass starts from).
 // result[0] = those of them that are not even equal to `tol` relative in every component, with the same
 // zero pattern (k_vit_margin's condition; tol = 0: not counted)
+// flag[nseg + s] (tol > 0 only): segment s is one of the latter (the mending round's list)
 template <int NP>
 __global__ void k_wide_vit_check(const Segs sg, double *v_entry, const double *v_exit, uint8_t *flag,
                                  unsigned int *result, double tol = 0.0)
@@ -1365,8 +1404,11 @@ __global__ void k_wide_vit_check(const Segs sg, double *v_entry, const double *v
             for (int j = 0; j < NP; ++j)
                 x[j] = y[j];
     }
-    if (s < sg.nseg)
+    if (s < sg.nseg) {
         flag[s] = differs ? 1 : 0;
+        if (tol > 0.0)
+            flag[sg.nseg + s] = (differs && far) ? 1 : 0;
+    }
     const unsigned long long d = __ballot(differs), f = __ballot(differs && far);
     if ((threadIdx.x & 63) == 0 && d)
         atomicAdd(&result[3], (unsigned int)__popcll(d));
@@ -1389,6 +1431,12 @@ __global__ void k_wide_vit_check(const Segs sg, double *v_entry, const double *v
 // a winner that is zero, denormal or not finite) are counted in result[2]; the host then runs the fix-up
 // rounds, which need none of this.   vall [total][n]: every vector of the first pass.
 // =========================================================================================
+[[maybe_unused]] static __global__ void k_vm_transpose(const double *A, int n, double *At)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * n)
+        At[(e % n) * n + e / n] = A[e];
+}
 // ALDS = false (more than 128 states: A^T does not fit LDS): `A` is A TRANSPOSED in global memory, read per step.
 template <typename PT, int NC, bool ALDS = true>
 __global__ __launch_bounds__(256) void k_vit_margin(const double *A, int n, const int64_t *off, const Segs sg,
@@ -2091,28 +2139,47 @@ __global__ void k_pobs_all(const WideModel m, const void *obs_rm, int64_t total,
 // thread-per-step form above writes 64 lines of which it fills an eighth each, and runs at a
 // quarter of the write rate).  NL = n must be a power of two: the outlier rule (all n
 // probabilities zero, outputmodel.py:126-130) is a ballot over the aligned group of n lanes.
+constexpr int POBS_LANES_R = 8; // rows of 256 / NL steps per workgroup
 template <int KIND, int NL>
 __global__ __launch_bounds__(256) void k_pobs_lanes(const WideModel m, const void *obs_rm,
                                                     int64_t total, double *pobs)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total * NL)
-        return;
-    const int64_t t = e / NL;
-    const int j = (int)(e % NL);
+    // thread -> state j = threadIdx.x % NL for POBS_LANES_R groups of 256 / NL consecutive steps (consecutive
+    // threads write consecutive elements).  Gaussian: the division by sigma of _gaussian.c:18 as the
+    // correctly rounded quotient from the correctly rounded reciprocal and the exponential as one block
+    // (gauss_exp_block above: the same bits as (o - mu) / sigma and cnorm * exp_nonpos(..), a third of the
+    // instructions -- at 64 states this pass was 2.8 ms of a 23 ms Viterbi call on configs[3])
+    const int j = threadIdx.x % NL;
+    [[maybe_unused]] double mu_j = 0.0, sg_j = 1.0, rs_j = 1.0, cn_j = 0.0;
     if constexpr (KIND == EMIT_GAUSS) {
-        const double o = static_cast<const double *>(obs_rm)[t];
-        const double d = (o - m.mu[j]) / m.sigma[j];
-        double p = m.cnorm[j] * exp_nonpos(-0.5 * d * d);
-        const unsigned long long nzm = __ballot(p != 0.0);
-        const int lane = threadIdx.x & 63;
-        const unsigned long long grp = (NL == 64 ? ~0ull : ((1ull << NL) - 1)) << (lane / NL * NL);
-        if ((nzm & grp) == 0ull)
-            p = 1.0;
-        pobs[e] = p;
-    } else {
-        const int sym = static_cast<const int32_t *>(obs_rm)[t];
-        pobs[e] = m.B[(int64_t)j * m.M + sym];
+        mu_j = m.mu[j];
+        sg_j = m.sigma[j];
+        rs_j = 1.0 / sg_j; // correctly rounded: IEEE division
+        cn_j = m.cnorm[j];
+    }
+    const int lane = threadIdx.x & 63;
+    [[maybe_unused]] const unsigned long long grp = (NL == 64 ? ~0ull : ((1ull << NL) - 1)) << (lane / NL * NL);
+    const int64_t e0 = (int64_t)blockIdx.x * (256 * POBS_LANES_R) + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < POBS_LANES_R; ++r) {
+        const int64_t e = e0 + (int64_t)r * 256;
+        const bool in = e < total * NL; // (uniform over a group of NL lanes: total * NL is a multiple of NL)
+        const int64_t t = in ? e / NL : 0;
+        if constexpr (KIND == EMIT_GAUSS) {
+            const double x = static_cast<const double *>(obs_rm)[t] - mu_j;
+            const double q0 = x * rs_j;
+            const double d = fma(fma(-q0, sg_j, x), rs_j, q0); // == x / sigma
+            double p = gauss_exp_block(-0.5 * d * d, cn_j);
+            const unsigned long long nzm = __ballot(p != 0.0);
+            if ((nzm & grp) == 0ull)
+                p = 1.0; // outlier rule (outputmodel.py:126-130)
+            if (in)
+                pobs[e] = p;
+        } else {
+            const int sym = static_cast<const int32_t *>(obs_rm)[t];
+            if (in)
+                pobs[e] = m.B[(int64_t)j * m.M + sym];
+        }
     }
 }
 
