@@ -266,3 +266,60 @@ def test_decision_with_a_margin_between_delta_and_16_delta_goes_to_the_rounds(n,
         if tried >= (2 if n > 64 else 1):
             break
     assert tried >= 1
+
+
+@pytest.mark.parametrize("n,kind", [(64, "gaussian"), (24, "discrete")])
+def test_mending_round_for_boundaries_further_than_the_tolerance(n, kind):
+    """A metastable model (lifetimes of 10 .. 100 steps, overlapping emissions): after a short warm-up some segments
+    start further than 1e-12 from their predecessors' vectors.  Those alone are run again up to a kept vector of the
+    first pass (k_wide_viterbi_seg, mend_tol), the rest of the pass is accepted by the margins on its path -- the
+    oracle's paths byte for byte, as with the mending switched off (fix-up rounds) and with the margins off."""
+    from bhmm_amd.engine import Engine
+    rng = np.random.default_rng(6600 + n)
+    M = 12
+    life = np.exp(np.linspace(np.log(10.0), np.log(100.0), n))
+    A = rng.random((n, n)) + 0.05
+    np.fill_diagonal(A, 0.0)
+    A = A / A.sum(axis=1)[:, None] / life[:, None]
+    A[np.arange(n), np.arange(n)] = 1.0 - 1.0 / life
+    pi = np.full(n, 1.0 / n)
+    lengths = (40000, 25000, 3, 30000)
+    if kind == "gaussian":
+        p0, p1 = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
+        states = [rng.integers(0, n, T) for T in lengths]
+        obs = [p0[s] + p1[s] * rng.normal(0, 1, len(s)) for s in states]
+        pobs = [orc.pobs_gaussian(o, p0, p1) for o in obs]
+    else:
+        p0, p1 = rng.dirichlet(np.ones(M) * 0.7, n), None
+        obs = [rng.integers(0, M, T).astype(np.int32) for T in lengths]
+        pobs = [orc.pobs_discrete(o, p0) for o in obs]
+    ref = [orc.viterbi(A, po, pi) for po in pobs]
+    eng = Engine(0)
+    eng.set_option("viterbi_seg_per_simd", 1)
+    eng.set_observations(kind, obs, n, nsymbols=M if kind == "discrete" else 0)
+    eng.set_option("viterbi_margin", 2)
+    mended = 0
+    seen = []
+    for W in (256, 128, 64):
+        eng.set_option("viterbi_W", W)
+        paths = eng.viterbi(A, pi, p0, p1)
+        for p, r in zip(paths, ref):
+            assert np.array_equal(p, r), W
+        seen.append((W, eng.get_option("viterbi_chunked"), eng.get_option("viterbi_mismatch"), eng.get_option("viterbi_far"),
+                     eng.get_option("viterbi_mended"), eng.get_option("viterbi_margin_used"), eng.get_option("viterbi_rounds")))
+        if eng.get_option("viterbi_chunked") == 0:
+            break                                 # (too short a warm-up for the rounds as well: the serial kernel from now on)
+        if eng.get_option("viterbi_mended") > 0 and eng.get_option("viterbi_margin_used") == 1:
+            mended += 1
+            assert eng.get_option("viterbi_far") == eng.get_option("viterbi_mended") and eng.get_option("viterbi_rounds") == 0
+    assert mended >= 1, seen
+    eng.set_option("viterbi_mend", 0)             # the same calls with fix-up rounds instead
+    for W in (256, 128):
+        eng.set_option("viterbi_W", W)
+        paths = eng.viterbi(A, pi, p0, p1)
+        assert eng.get_option("viterbi_mended") == 0
+        for p, r in zip(paths, ref):
+            assert np.array_equal(p, r), W
+    p8 = eng.viterbi_u8(A, pi, p0, p1)
+    assert np.array_equal(p8, np.concatenate(ref).astype(np.uint8))
+    eng.close()
