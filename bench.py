@@ -586,6 +586,69 @@ def secondary_whole_iterations(rk, model, args):
     return res
 
 
+def projected_8gpu(torch, dev, local, stream, args, n1_ms, n1_secondary, model):
+    """A PROJECTION of the 8-GPU job from ONE GPU -- not a measurement (the pool has one-GPU boxes; RCCL has
+    never run with more than one rank here).  What rank 0 of an 8-rank job does is run for real: the shard of
+    trajectories 0 .. K/8 - 1 of the SAME global set (drawn by global index), through the distributed code path
+    -- statistics into the device buffer, RCCL all-reduce (one rank: the call, its launch and its
+    synchronisation, not the xGMI hops), one copy to the host -- and timed with the contract's protocol.  The
+    8-rank all-reduce of 4.7 KB over xGMI is latency-bound; what it adds to the 1-rank call is NOT in here.
+    The distributed form of the host sums at maximum_likelihood.py:271-282."""
+    import copy
+    import socket
+    import torch.distributed as dist
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = {"what": "projection from one GPU, not a measurement: rank 0's shard of an 8-rank job run for real "
+                   "(1/8 of the trajectories, drawn by global index) with a ONE-rank RCCL all-reduce and the "
+                   "copy to the host inside every step; the latency of the 8-rank all-reduce over xGMI is not in it"}
+    try:
+        rk1 = Ranks(torch, dist, 1, 0, local, dev, "nccl", True, stream)
+        wl = workload_configs2(args.ntraj, args.length)
+        Ksh = max(1, args.ntraj // 8)
+        ser = Series(rk1, wl, Ksh, 0, chunk=args.chunk)
+        ser.run(args.warmup, args.steps, 0)
+        shard_ms = 1e3 * ser.elapsed / args.steps
+        coll_ms = ser.collective_ms()
+        out.update({"shard": "%d traj x %d steps (of %d), chunks %d of %d steps, warm-up %d"
+                             % (Ksh, wl.T, args.ntraj, ser.eng.num_chunks, ser.eng.chunk_len,
+                                int(ser.eng.get_option("spec_W"))),
+                    "shard_ms": shard_ms, "shard_kernels_ms": float(ser.kern_ms[4]),
+                    "allreduce_plus_copy_ms": coll_ms,
+                    "host_gap_ms": shard_ms - float(ser.kern_ms[4]),
+                    "n1_ms_per_step": n1_ms,
+                    "projected_speedup_vs_n1": n1_ms / shard_ms,
+                    "projected_value_timesteps_per_s": args.ntraj * wl.T / (1e-3 * shard_ms),
+                    "roofline_frac_of_the_shard": wl.b_alg * Ksh * wl.T / (1e-3 * float(ser.kern_ms[2])) / 1e9
+                                                  / HBM_PEAK_GBS})
+        ser.close()
+        del ser
+        if n1_secondary is not None:
+            # whole EM iterations / Gibbs sweeps (configs[4] chain): 1/8 of the trajectories through the sharded
+            # estimator classes, collectives forced on
+            os.environ["BHMM_AMD_FORCE_COMM"] = "1"
+            a8 = copy.copy(args)
+            a8.c1_ntraj = max(1, args.c1_ntraj // 8)
+            sh = secondary_whole_iterations(rk1, model, a8)
+            del os.environ["BHMM_AMD_FORCE_COMM"]
+            rows = []
+            for full, part in zip(n1_secondary, sh):
+                key = "ms_per_sweep" if "ms_per_sweep" in part else "ms_per_iteration"
+                rows.append({"config": full["config"].split(", 8-state")[0].split(", %d x" % args.c1_ntraj)[0],
+                             "n1_ms": full[key], "shard_ms": part[key],
+                             "projected_speedup_vs_n1": full[key] / part[key]})
+            out["whole_iterations_and_sweeps"] = rows
+    finally:
+        dist.destroy_process_group()
+    return out
+
+
 def draw_watch_rates(eng, sweep, nsweeps):
     """Over `nsweeps` path steps with different seeds: how many draws fell within 64 x the deviation the
     boundary check of the forward pass measured (csrc/draw_verify.hpp), how many of them were decided again on
@@ -794,6 +857,7 @@ def main():
                     help="offline PMC measurements quoted as roofline.traffic (tools/profile_r05.sh)")
     ap.add_argument("--chain-sweeps", type=int, default=20, help="Gibbs sweeps timed per chain variant")
     ap.add_argument("--em-iterations", type=int, default=30, help="whole EM iterations timed")
+    ap.add_argument("--no-projection", action="store_true", help="skip the labelled 8-GPU projection (N = 1 only)")
     ap.add_argument("--only", default="", help="profiling aid: 'c3' runs the configs[3] block alone (E-step, "
                                                "Viterbi, Gibbs path step -- exactly the calls of the full run) and prints it")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -949,7 +1013,10 @@ def main():
             sec.append(c4)
             gen = secondary_gen(torch, dev, local, args)
             sec.extend(gen)
-        sec.extend(secondary_whole_iterations(rk, model, args))
+        whole = secondary_whole_iterations(rk, model, args)
+        sec.extend(whole)
+        if out is not None and world == 1 and not args.no_projection:
+            out["projected_8gpu"] = projected_8gpu(torch, dev, local, stream, args, out["ms_per_step"], whole, model)
         if out is not None:
             out["secondary"] = sec
             if c1 is not None:

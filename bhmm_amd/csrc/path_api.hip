@@ -167,7 +167,13 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     // (k_smp_maps keeps within 128 VGPRs, i.e. four wavefronts per SIMD: 8 parts per chunk fill
     // them on the default plan of 32768 chunks; measured on configs[4]: P = 4 0.56, 8 0.48, 16 0.52 ms
     // for maps + stitch + apply)
-    const int P = parts_env > 0 ? parts_env : (c->Lmax >= 512 ? 8 : (c->Lmax >= 256 ? 4 : 1));
+    // Few, short chunks (the shard of one of eight ranks: 32 x 1e5 steps -> 16352 chunks of 196 steps) gave ONE
+    // part per chunk, i.e. a quarter of a wavefront per SIMD walking 196 dependent steps: k_smp_maps took 325 us
+    // of a 550 us path step.  Parts as short as 16 steps until the lanes fill the chip (round 6).
+    int Pfill = 1;
+    while (Pfill < 16 && c->Lmax / (2 * Pfill) >= 16 && (int64_t)c->G * Pfill < 262144)
+        Pfill *= 2;
+    const int P = parts_env > 0 ? parts_env : std::max(Pfill, c->Lmax >= 512 ? 8 : (c->Lmax >= 256 ? 4 : 1));
     const int nblk = (c->Gp / BLOCK) * P;
     const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)N : (c->kind == EMIT_DISC ? (size_t)c->M * N : 0);
     // scratch2: [path] | status | part maps | next-part states | lowest non-final step per part |
