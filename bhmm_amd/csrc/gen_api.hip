@@ -22,7 +22,7 @@ int tile_gen_alloc(bhmm_ctx *c);
 int tile_gen_estep(bhmm_ctx *c, const WideModel &m, double *stats_dev, int flags, bool *done);
 int tile_gen_forward_draw(bhmm_ctx *c, const WideModel &m, bool *done);
 int wide_path_plan_pub(bhmm_ctx *c, int which, int64_t seglen, Segs &sg);
-int draw_watch_prepare(bhmm_ctx *c, double tol, DrawWatch &w);
+int draw_watch_prepare(bhmm_ctx *c, double tol, DrawWatch &w, unsigned int *count_slot);
 int draw_verify_run(bhmm_ctx *c, const double *A, const double *pi, const double *par0, const double *par1,
                     unsigned int count, double thr, int64_t Wlong, bool *ok);
 
@@ -599,7 +599,7 @@ int gen_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double 
     }
     // rows of a segmented pass: draws within 64 x the deviation its boundary check measured are recorded
     DrawWatch watch;
-    if ((rc = draw_watch_prepare(c, fwd_seg ? 64.0 * std::max(c->draw_alpha_dev, 1e-16) : 0.0, watch)))
+    if ((rc = draw_watch_prepare(c, fwd_seg ? 64.0 * std::max(c->draw_alpha_dev, 1e-16) : 0.0, watch, nullptr)))
         return rc;
     const int n = c->n, K = c->K;
     const size_t nstat = (size_t)n * n + n;

@@ -47,7 +47,8 @@ static inline size_t dv_model_offset() { return 16 + (size_t)DRAW_EVENT_CAP * si
 
 // watch for one sampling call: tol <= 0 (or the option off) leaves it switched off.  The four counters are
 // cleared on the stream.
-int draw_watch_prepare(bhmm_ctx *c, double tol, DrawWatch &w)
+// count_slot: a counter the caller clears with its own fills (saves a dispatch per Gibbs sweep)
+int draw_watch_prepare(bhmm_ctx *c, double tol, DrawWatch &w, unsigned int *count_slot)
 {
     w.ev = nullptr;
     w.count = nullptr;
@@ -60,8 +61,9 @@ int draw_watch_prepare(bhmm_ctx *c, double tol, DrawWatch &w)
     int rc = c->d_dv.ensure(dv_model_offset() + msz);
     if (rc)
         return rc;
-    BHMM_HIP(hipMemsetAsync(c->d_dv.p, 0, 16, c->stream));
-    w.count = reinterpret_cast<unsigned int *>(c->d_dv.p);
+    if (!count_slot)
+        BHMM_HIP(hipMemsetAsync(c->d_dv.p, 0, 16, c->stream));
+    w.count = count_slot ? count_slot : reinterpret_cast<unsigned int *>(c->d_dv.p);
     w.ev = reinterpret_cast<DrawEvent *>(c->d_dv.p + 16);
     w.tol = c->draw_watch_tol > 0.0 ? c->draw_watch_tol : tol;
     return BHMM_OK;
@@ -88,6 +90,7 @@ int draw_verify_run(bhmm_ctx *c, const double *A, const double *pi, const double
         BHMM_HIP(hipMemcpyAsync(mp0, par0, (size_t)n * c->M * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     unsigned int *res = reinterpret_cast<unsigned int *>(c->d_dv.p);
+    BHMM_HIP(hipMemsetAsync(res + 1, 0, 12, c->stream)); // (the three result words; rare path)
     const size_t sm = (4 * (size_t)n + 8) * sizeof(double);
     hipLaunchKernelGGL(k_draw_verify, dim3(count), dim3(256), sm, c->stream,
                        reinterpret_cast<const DrawEvent *>(c->d_dv.p + 16), (int)count, (const double *)md, n, c->M,
@@ -220,7 +223,8 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
     // rows of a speculative pass: draws within 64 x the tolerance of its boundary check are recorded (the
     // measured deviation, usually far smaller, is applied when they are looked at)
     DrawWatch watch;
-    if ((rc = draw_watch_prepare(c, c->rows32_valid && !exact ? 64.0 * c->spec_tol : 0.0, watch)))
+    if ((rc = draw_watch_prepare(c, c->rows32_valid && !exact ? 64.0 * c->spec_tol : 0.0, watch,
+                                 reinterpret_cast<unsigned int *>(status) + 1))) // (second word of the cleared status slot)
         return rc;
     {
         // exact chunk-parallel sampling: maps per part, stitch, apply + statistics
@@ -291,10 +295,8 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
             BHMM_HIP(hipMemcpyAsync(he.data(), ered, esz * sizeof(double), hipMemcpyDeviceToHost,
                                     c->stream));
     }
-    BHMM_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    unsigned int nwatched = 0;
-    if (watch.count)
-        BHMM_HIP(hipMemcpyAsync(&nwatched, watch.count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    int hst[2] = {0, 0}; // [status | watched draws]
+    BHMM_HIP(hipMemcpyAsync(hst, status, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (paths)
         BHMM_HIP(hipMemcpyAsync(paths, path, (size_t)c->total * sizeof(int32_t),
                                 hipMemcpyDeviceToHost, c->stream));
@@ -308,6 +310,8 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
             return sample_run<N>(c, A, pi, par0, par1, u, seed, paths, counts, n0, emis, stats_dev,
                                  false);
     }
+    hstatus = hst[0];
+    const unsigned int nwatched = watch.count ? (unsigned int)hst[1] : 0u;
     c->draw_alpha_dev = watch.count ? (double)c->spec_last_dev : 0.0;
     if (nwatched) {
         // draws inside 64 x the deviation the boundary check measured: decided again on the serial recursion
@@ -965,7 +969,7 @@ int wide_sample_run(bhmm_ctx *c, const double *A, const double *pi, const double
     const int K = c->K, n = c->n, NP = c->N, GP = 64 / NP;
     // rows of a segmented pass: draws within 64 x the deviation its boundary check measured are recorded
     DrawWatch watch;
-    if ((rc = draw_watch_prepare(c, c->draw_fwd_segmented ? 64.0 * std::max(c->draw_alpha_dev, 1e-16) : 0.0, watch)))
+    if ((rc = draw_watch_prepare(c, c->draw_fwd_segmented ? 64.0 * std::max(c->draw_alpha_dev, 1e-16) : 0.0, watch, nullptr)))
         return rc;
     const size_t nstat = (size_t)n * n + n;
     const size_t esz = c->kind == EMIT_GAUSS ? 3 * (size_t)n
