@@ -1836,6 +1836,7 @@ int bhmm_estep(bhmm_ctx *c, const double *A, const double *pi, const double *par
     }
     double *sd = stats_dev ? stats_dev : c->d_stats.p;
     c->last_stats_internal = (stats_dev == nullptr);
+    c->last_stats_checked = false;
     c->last_stats = sd;
     c->prefetched = false;
     c->ev_lean = false;
@@ -1867,8 +1868,12 @@ int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
     bool have_logLk = true;
     if (!c->prefetched && !c->last_stats)
         return invalid("no E-step has run on these observations");
-    if (!c->last_stats_internal) {
-        // an E-step launched into the caller's buffer: this is where its result is first looked at
+    if (!c->last_stats_internal && stats && !c->last_stats_checked) {
+        // an E-step launched into the caller's buffer: this is where its result is first looked at -- once per
+        // launch, and only when the caller asks for the statistics themselves (the header's contract: they are
+        // fetched BEFORE an in-place all-reduce; a caller that reduces first and then asks for logL_k only never
+        // has the reduced buffer inspected, let alone a local E-step repeated over it)
+        c->last_stats_checked = true;
         bool retried = false;
         int rc = nonfinite_retry(c, &retried);
         if (retried) { // (what bhmm_estep does at its end)

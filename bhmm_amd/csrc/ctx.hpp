@@ -250,6 +250,7 @@ struct bhmm_ctx {
     bool prefetched = false;          // stats + logL_k of the last E-step already sit in h_pinned
     bool logLk_prefetched = true;     // ... logL_k included (not for many trajectories: on demand)
     bool last_stats_internal = true;
+    bool last_stats_checked = false;  // the caller's buffer of the last E-step has been looked at by bhmm_estep_fetch
     double *last_stats = nullptr;     // device buffer the last E-step wrote its statistics to
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_pending = false;

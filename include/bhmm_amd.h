@@ -144,7 +144,11 @@ int bhmm_estep(bhmm_ctx *ctx, const double *A, const double *pi, const double *p
  * BHMM_ERR_NONFINITE also if the log-likelihoods are finite but a count (sum gamma_0, C, sum gamma) is
  * not even after bhmm_estep's own retry on one chunk per trajectory (reducible
  * transition matrices with emission probabilities hundreds of decades apart) -- refused loudly instead
- * of handing NaN counts to an M-step. */
+ * of handing NaN counts to an M-step.
+ * ORDER when bhmm_estep wrote into the caller's stats_dev: a fetch WITH `stats` reads that buffer and is
+ * where this rank's result is inspected (once per launch; the retry above re-runs the local E-step into
+ * the same buffer) -- so fetch the statistics BEFORE reducing the buffer in place, or reduce first and
+ * fetch with stats == NULL (logL_k only: the buffer is then neither read nor inspected). */
 int bhmm_estep_fetch(bhmm_ctx *ctx, double *stats, double *logL_k);
 /* After an E-step run with BHMM_FLAG_STORE_GAMMA: copy gamma of trajectory k, (T_k,N)
  * row-major, to the host. */

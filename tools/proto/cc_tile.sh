@@ -1,6 +1,8 @@
 #!/bin/bash
 # compile wide_api.hip to ISA and list the register use of the tile kernels
-cd /root/repo/bhmm_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -S --cuda-device-only -o /tmp/wide_api.s wide_api.hip 2>&1 | grep -E "error" -A5 | head -40
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+cd $R/bhmm_amd/csrc && $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -S --cuda-device-only -o /tmp/wide_api.s wide_api.hip 2>&1 | grep -E "error" -A5 | head -40
 python3 - <<'PY'
 import re
 t=open('/tmp/wide_api.s').read()

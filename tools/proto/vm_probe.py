@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os
+import sys; sys.path.insert(0,os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))) + ''); sys.path.insert(0,os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))) + '/tests')
 import numpy as np
 from test_viterbi_margin_gpu import _model,_data
 from oracle import oracle as orc

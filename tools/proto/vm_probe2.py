@@ -1,6 +1,6 @@
-import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os, sys
 import os
-R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 import numpy as np
 from test_viterbi_margin_gpu import _model,_data
 from bhmm_amd.engine import Engine
