@@ -124,6 +124,8 @@ SIGNATURES = {
                                             c_double_p, ctypes.c_int64, ctypes.c_double,
                                             ctypes.c_double, c_int64_p]),
     "bhmm_host_is_reversible": (ctypes.c_int, [c_double_p, ctypes.c_int]),
+    "bhmm_host_sample_reversible": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int64,
+                                                   ctypes.c_uint64, ctypes.c_int]),
     "bhmm_host_partial_rev": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, c_int32_p,
                                              ctypes.c_int64, ctypes.c_double]),
     "bhmm_host_rng_draws": (ctypes.c_int, [c_double_p, ctypes.c_int64, ctypes.c_int,

@@ -81,6 +81,14 @@ extern "C" int bhmm_host_is_reversible(const double *P, int n)
     return is_reversible(P, n) ? 1 : 0;
 }
 
+extern "C" int bhmm_host_sample_reversible(double *X, const double *C, int n, int64_t nsweeps, uint64_t base, int lanes)
+{
+    if (!X || !C || n < 1 || nsweeps < 0 || (lanes != 0 && lanes != 1 && lanes != 4))
+        return -1;
+    sample_reversible_sweeps_base(C, n, nsweeps, base, X, lanes);
+    return (lanes == 1) ? 1 : reversible_sampler_lanes();
+}
+
 extern "C" int bhmm_host_rng_draws(double *out, int64_t count, int what, double param,
                                    uint64_t seed, uint64_t stream)
 {

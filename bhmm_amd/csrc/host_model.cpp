@@ -7,6 +7,7 @@
 // msmtools package in the reference ("parity unpinned"): they are restated from the publications
 // cited at each function and checked through their defining properties.
 #include "host_model.hpp"
+#include "host_rev_sampler.hpp"
 
 #include <math.h>
 
@@ -647,130 +648,40 @@ void Rng::dirichlet(const double *alpha, int n, double *out)
 }
 
 // ---- reversible posterior sampler ------------------------------------------------------------
-// One element update: target density of v = x_ij (i != j) given everything else,
-//   f(v) ~ v^(c0 - 1) (v + v1)^(-c1) (v + v2)^(-c2),
-// c0 = c_ij + c_ji, c1 = c_i, c2 = c_j (row sums of C), v1 = x_i - x_ij, v2 = x_j - x_ji.
-// An independence Metropolis step with a Gamma(k, theta) proposal matched to the maximum of
-// v f(v) and to its curvature there (Trendelkamp-Schroer et al. 2015, Sec. IV C); where no such
-// proposal exists (degenerate rows) a log-uniform random-walk step keeps the chain moving.
-static inline bool positive(double x) { return x > 1e-300 && std::isfinite(x); }
+// host_rev_sampler.hpp: the element updates of a round side by side in SIMD lanes, every update on a random
+// stream of its own -- the same chain whatever the vector width.  `lanes` = 1 / 4 picks the instantiation
+// (tests), 0 the widest the CPU runs.  The caller's generator gives the base of the streams (one draw).
+void sample_reversible_sweeps_avx2(const double *C, int n, int64_t nsweeps, uint64_t base, double *X);
 
-// log(1 + x): the arguments here are (v_new - v_old) / x_i, mostly tiny
-static inline double log1p_fast(double x)
+int reversible_sampler_lanes()
 {
-    if (fabs(x) < 1e-3)
-        return x * (1.0 - x * (0.5 - x * (1.0 / 3.0 - x * (0.25 - x * 0.2))));
-    return log1p(x);
+    static const int forced = getenv("BHMM_AMD_REV_LANES") ? atoi(getenv("BHMM_AMD_REV_LANES")) : 0;
+    if (forced == 1)
+        return 1;
+#if defined(__x86_64__)
+    static const bool avx = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    return avx ? 4 : 1;
+#else
+    return 1;
+#endif
 }
 
-static double update_offdiag(double v0, double v1, double v2, double c0, double c1, double c2,
-                             Rng &rng)
+void sample_reversible_sweeps_base(const double *C, int n, int64_t nsweeps, uint64_t base, double *X, int lanes)
 {
-    const double a = c1 + c2 - c0;
-    const double b = (c1 - c0) * v2 + (c2 - c0) * v1;
-    const double c = -c0 * v1 * v2;
-    const double vbar = 0.5 * (-b + sqrt(b * b - 4.0 * a * c)) / a;
-    if (positive(vbar)) {
-        // (reciprocals once: the divisions are what this update costs)
-        const double r0 = 1.0 / vbar, r1 = 1.0 / (vbar + v1), r2 = 1.0 / (vbar + v2);
-        const double h = c1 * r1 * r1 + c2 * r2 * r2 - c0 * r0 * r0;
-        const double k = -h * vbar * vbar, inv_theta = -h * vbar;
-        if (positive(k) && positive(inv_theta) && positive(1.0 / inv_theta)) {
-            const double vn = rng.gamma(k) / inv_theta;
-            if (!positive(vn))
-                return v0;
-            if (v0 == 0.0)
-                return vn;
-            // log [f(vn) / q(vn)] - log [f(v0) / q(v0)],  q(v) ~ v^(k-1) exp(-v / theta)
-            const double dv = vn - v0;
-            const double dl = (c0 - k) * log1p_fast(dv / v0) - c1 * log1p_fast(dv / (v0 + v1)) -
-                              c2 * log1p_fast(dv / (v0 + v2)) + dv * inv_theta;
-            return (dl >= 0.0 || rng.u01() < exp(dl)) ? vn : v0;
-        }
+    if (lanes == 0)
+        lanes = reversible_sampler_lanes();
+#if defined(__x86_64__)
+    if (lanes == 4 && reversible_sampler_lanes() == 4) {
+        sample_reversible_sweeps_avx2(C, n, nsweeps, base, X);
+        return;
     }
-    if (v0 == 0.0)
-        return v0;
-    const double step = rng.u01() - 0.5; // (random-walk step size 1)
-    const double vn = v0 * exp(step);
-    if (positive(vn)) {
-        const double dl = c0 * step - c1 * log1p((vn - v0) / (v0 + v1)) - c2 * log1p((vn - v0) / (v0 + v2));
-        if (dl >= 0.0 || rng.u01() < exp(dl))
-            v0 = vn;
-    }
-    return v0;
+#endif
+    revs::sample_reversible_sweeps_v<revs::V1>(C, n, nsweeps, base, X);
 }
 
-// Scan order of one sweep: all diagonal elements, then the off-diagonal pairs in round-robin
-// ("circle method") order -- n - 1 rounds of n / 2 pairs with pairwise disjoint indices.  Updates of
-// disjoint pairs touch disjoint rows, so consecutive updates do not depend on each other and the
-// out-of-order core overlaps their latency chains (sqrt, divisions, log, exp: ~130 ns each when
-// serialised through a shared row sum, as in lexicographic order).  Any fixed scan order is a valid
-// Gibbs sampler.
 void sample_reversible_sweeps(const double *C, int n, int64_t nsweeps, Rng &rng, double *X)
 {
-    std::vector<double> csum(n), rs(n);
-    for (int i = 0; i < n; ++i) {
-        double s = 0.0;
-        for (int j = 0; j < n; ++j)
-            s += C[(size_t)i * n + j];
-        csum[i] = s;
-    }
-    struct Pair {
-        int i, j;
-        double c0;
-    };
-    std::vector<Pair> pairs;
-    const int m = n + (n & 1); // odd n: one index sits out per round
-    for (int r = 0; r + 1 < m; ++r)
-        for (int k = 0; k < m / 2; ++k) {
-            int a = k == 0 ? m - 1 : (r + k) % (m - 1);
-            int b = k == 0 ? r : (r - k + (m - 1)) % (m - 1);
-            if (a >= n || b >= n)
-                continue;
-            if (a < b)
-                std::swap(a, b);
-            const double c0 = C[(size_t)a * n + b] + C[(size_t)b * n + a];
-            if (c0 > 0.0)
-                pairs.push_back(Pair{a, b, c0});
-        }
-    auto rowsums = [&]() {
-        for (int i = 0; i < n; ++i) {
-            double s = 0.0;
-            for (int j = 0; j < n; ++j)
-                s += X[(size_t)i * n + j];
-            rs[i] = s;
-        }
-    };
-    rowsums();
-    for (int64_t sweep = 0; sweep < nsweeps; ++sweep) {
-        for (int i = 0; i < n; ++i) {
-            // x_ii / x_i ~ Beta(c_ii, c_i - c_ii) given the rest of the row
-            const double cii = C[(size_t)i * n + i];
-            if (positive(cii) && positive(csum[i] - cii)) {
-                const double t = rng.beta(cii, csum[i] - cii);
-                const double rest = rs[i] - X[(size_t)i * n + i];
-                const double x = t / (1.0 - t) * rest;
-                if (positive(x)) {
-                    X[(size_t)i * n + i] = x;
-                    rs[i] = rest + x;
-                }
-            }
-        }
-        for (const Pair &p : pairs) {
-            const double x0 = X[(size_t)p.i * n + p.j];
-            const double v1 = rs[p.i] - x0, v2 = rs[p.j] - x0;
-            const double x = update_offdiag(x0, v1, v2, p.c0, csum[p.i], csum[p.j], rng);
-            X[(size_t)p.i * n + p.j] = X[(size_t)p.j * n + p.i] = x;
-            rs[p.i] = v1 + x;
-            rs[p.j] = v2 + x;
-        }
-        double tot = 0.0;
-        for (size_t e = 0; e < (size_t)n * n; ++e)
-            tot += X[e];
-        for (size_t e = 0; e < (size_t)n * n; ++e)
-            X[e] /= tot;
-        rowsums();
-    }
+    sample_reversible_sweeps_base(C, n, nsweeps, rng.bits(), X, 0);
 }
 
 } // namespace host

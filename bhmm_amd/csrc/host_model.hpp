@@ -66,6 +66,10 @@ struct Rng {
 // (Trendelkamp-Schroer, Wu, Paul, Noe, J. Chem. Phys. 143, 174101 (2015), Sec. IV), prior x_ij^-1.
 // X (n x n, symmetric, in/out) is advanced by `nsweeps` full sweeps over all element pairs.
 void sample_reversible_sweeps(const double *C, int n, int64_t nsweeps, Rng &rng, double *X);
+// ... with the base of the per-update random streams given; lanes: 0 = the widest instantiation the CPU runs,
+// 1 = one lane, 4 = AVX2 (falls back to one lane where the CPU has none): the same result either way
+void sample_reversible_sweeps_base(const double *C, int n, int64_t nsweeps, uint64_t base, double *X, int lanes);
+int reversible_sampler_lanes();
 
 } // namespace host
 } // namespace bhmm

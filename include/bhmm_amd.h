@@ -356,6 +356,12 @@ int bhmm_host_stationary_vector(double *pi, const double *P, int n);
 int bhmm_host_estimate_tmatrix(double *P, const double *C, int n, int reversible, const double *fixed_pi,
                          int64_t maxiter, double maxerr, double mincount, int64_t *iterations);
 int bhmm_host_is_reversible(const double *P, int n); /* 1 / 0 (-1: bad argument) */
+/* `nsweeps` full sweeps of the reversible transition-matrix posterior sampler (the draw of
+ * bayesian_sampling.py:341-360 inside bhmm_gibbs_parameters) on the symmetric flux matrix X (n x n, in/out)
+ * for the count matrix C.  base keys the per-update random streams; lanes: 0 = the widest instantiation the
+ * CPU runs, 1 = one lane, 4 = AVX2 -- the result does not depend on it (that is what the tests check).
+ * Returns the number of lanes used, negative on a bad argument. */
+int bhmm_host_sample_reversible(double *X, const double *C, int n, int64_t nsweeps, uint64_t base, int lanes);
 /* _tmatrix_disconnected.py:126-190: rows in_set != 0 of P (n x n, in/out) */
 int bhmm_host_partial_rev(double *P, const double *C, int n, const int32_t *in_set, int64_t maxiter,
                           double maxerr);

@@ -440,3 +440,37 @@ def test_reversible_sampler_properties_and_errors():
     Tb = GibbsParameters("explicit", n, 0, reversible=True, nsteps=50)(np.concatenate([big.ravel(), np.ones(n)]),
                                                                         None, None, 3, 0)[0]
     np.testing.assert_allclose(Tb, _tmatrix.mle_reversible(big, maxerr=1e-13), atol=2e-3)
+
+
+def test_reversible_sampler_is_the_same_chain_at_every_vector_width():
+    """The element updates of a round run in SIMD lanes (csrc/host_rev_sampler.hpp: four with AVX2 + FMA, one
+    without); every update draws from a stream of its own, so the chain must not depend on the width -- to the
+    bit, on dense, sparse, huge and fractional count matrices (Gamma shapes below one, degenerate rows)."""
+    import ctypes
+    rng = np.random.default_rng(0)
+
+    def run(C, nsweeps, base, lanes):
+        n = C.shape[0]
+        X = _lib.f64((C + C.T) / (2 * C.sum()))
+        r = L().bhmm_host_sample_reversible(_lib.dp(X), _lib.dp(_lib.f64(C)), n, nsweeps, ctypes.c_uint64(base), lanes)
+        return X, r
+
+    widest = None
+    for n in (2, 3, 5, 8, 13):
+        for trial in range(12):
+            C = rng.integers(0, 50, (n, n)).astype(float) + np.diag(rng.integers(10, 200, n))
+            if trial % 3 == 0:
+                C *= 1e4
+            if trial % 4 == 1 and n > 2:
+                C[0, 1] = C[1, 0] = 0
+            if trial % 5 == 2:
+                C = C * rng.random((n, n)) * 0.02
+            X1, r1 = run(C, 40, 77 + trial, 1)
+            Xw, rw = run(C, 40, 77 + trial, 0)
+            assert r1 == 1 and rw in (1, 4)
+            widest = rw
+            assert np.array_equal(X1, Xw), (n, trial)
+            assert np.allclose(X1, X1.T, rtol=0, atol=0) and abs(X1.sum() - 1) < 1e-12 and np.all(X1 >= 0)
+            assert np.array_equal(X1 == 0, (C + C.T) == 0)              # structural zeros stay
+            assert not np.array_equal(X1, run(C, 40, 78 + trial, 1)[0])  # a function of the base
+    assert widest in (1, 4)
