@@ -370,7 +370,10 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
     // The walk is a dependent chain (the column of A a step needs is known only after the previous
     // draw) and its alpha rows come straight from HBM: they are requested SMP_MPF steps ahead.
     uint32_t alive_set = (1u << n) - 1u; // the part may be entered with any real state
-    constexpr int SMP_MPF = 1;
+#ifndef SMP_MPF_VALUE
+#define SMP_MPF_VALUE 1 // steps of load-ahead of the fp32 alpha rows (measured 1 / 2 / 4: DESIGN.md section 5)
+#endif
+    constexpr int SMP_MPF = SMP_MPF_VALUE;
     constexpr int NF = N / 2; // float2 per fp32 row
     const int nst = s_hi - s_lo;
     float2 ring[SMP_MPF][NF];
