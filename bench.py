@@ -187,6 +187,26 @@ def host_cores():
 # ---------------------------------------------------------------------------------------
 # N > 1 without a launcher: start the ranks ourselves.  This parent never touches the GPU.
 # ---------------------------------------------------------------------------------------
+class OnlyTheResultOnStdout(object):
+    """The contract is ONE JSON line on stdout.  RCCL writes a version banner to the C-level stdout of every
+    process that creates a communicator (also the one-rank communicator of the 8-GPU projection), so from here
+    on file descriptor 1 is stderr; emit() flushes the C buffers there and writes the result to the real stdout."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.real = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line):
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.write(self.real, (line + "\n").encode())
+
+
 def self_launch(args, argv):
     import socket
     import subprocess
@@ -866,7 +886,8 @@ def main():
     ap.add_argument("--em-iterations", type=int, default=30, help="whole EM iterations timed")
     ap.add_argument("--no-projection", action="store_true", help="skip the labelled 8-GPU projection (N = 1 only)")
     ap.add_argument("--only", default="", help="profiling aid: 'c3' runs the configs[3] block alone (E-step, "
-                                               "Viterbi, Gibbs path step -- exactly the calls of the full run) and prints it")
+                                               "Viterbi, Gibbs path step -- exactly the calls of the full run), 'shard' the "
+                                               "E-step part of the 8-GPU projection, and prints it")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST AID for boxes with fewer GPUs than ranks: ranks share GPUs "
                          "(local rank modulo device count) and the all-reduce runs over gloo")
@@ -877,6 +898,7 @@ def main():
         # never exec / re-exec from a process that touched the GPU: this parent has not
         sys.exit(self_launch(args, sys.argv[1:]))
 
+    result = OnlyTheResultOnStdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -911,7 +933,10 @@ def main():
     rk = Ranks(torch, dist, world, rank, local, dev, backend, distributed, stream)
 
     if args.only == "c3":
-        print(json.dumps({"configs3_64_states": secondary_c4(torch, dev, local, args)}))
+        result.emit(json.dumps({"configs3_64_states": secondary_c4(torch, dev, local, args)}))
+        return
+    if args.only == "shard":   # the E-step part of the 8-GPU projection alone (rank 0's shard, 1-rank RCCL all-reduce)
+        result.emit(json.dumps({"projected_8gpu": projected_8gpu(torch, dev, local, stream, args, float("nan"), None, None)}))
         return
 
     # ---- the headline: configs[2], strong-scaled --------------------------------------------------
@@ -1037,10 +1062,10 @@ def main():
                 out["more_than_64_states"] = [{k: g[k] for k in ("config", "ms", "roofline", "tile_kernels", "self_checks_fired",
                                                                  "viterbi", "gibbs_path_step") if k in g}
                                               for g in gen]
-    if out is not None:
-        print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
+    if out is not None:
+        result.emit(json.dumps(out))
 
 
 if __name__ == "__main__":

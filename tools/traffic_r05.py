@@ -30,8 +30,8 @@ for ln in open(sys.argv[3]):
 out = {"unit": "FETCH_SIZE / WRITE_SIZE in KB per launch (mean of the last 3 launches); bytes = 1024 * (2 * FETCH_SIZE + "
                "WRITE_SIZE): on gfx950 FETCH_SIZE reports half of the bytes of a wide streaming read (MI355X_MICROARCH.md, "
                "HBM) -- checked on the 1 GiB clone below (expected FETCH 524288 KB = half, WRITE 1048576 KB)",
-       "source": "profiles/r05/%s_traffic.json (tools/profile_r05.sh %s: tools/pmc_r05.py under rocprofv3 --pmc, one "
-                 "counter per pass; SQ_INSTS_VALU from profiles/r05/%s_clock.txt)" % (tag, tag, tag),
+       "source": "profiles/%s/%s_traffic.json (tools/profile_r05.sh %s: tools/pmc_r05.py under rocprofv3 --pmc, one "
+                 "counter per pass; SQ_INSTS_VALU from profiles/%s/%s_clock.txt)" % (tag[:3], tag, tag, tag[:3], tag),
        "issue_source": "one vector instruction per SIMD and four cycles (fp64 FMA, DPP move and integer instructions alike: "
                        "tools/ubench/issue_rate.hip, profiles/r02/r02_ubench_issue_rate.txt) at the shader clock of the same "
                        "counter pass, GRBM_GUI_ACTIVE / duration / 8 XCDs",
