@@ -1868,11 +1868,11 @@ int bhmm_estep_fetch(bhmm_ctx *c, double *stats, double *logL_k)
     bool have_logLk = true;
     if (!c->prefetched && !c->last_stats)
         return invalid("no E-step has run on these observations");
-    if (!c->last_stats_internal && stats && !c->last_stats_checked) {
-        // an E-step launched into the caller's buffer: this is where its result is first looked at -- once per
-        // launch, and only when the caller asks for the statistics themselves (the header's contract: they are
-        // fetched BEFORE an in-place all-reduce; a caller that reduces first and then asks for logL_k only never
-        // has the reduced buffer inspected, let alone a local E-step repeated over it)
+    if (!c->last_stats_internal && !c->last_stats_checked) {
+        // an E-step launched into the caller's buffer: the FIRST fetch after the launch is where this rank's
+        // result is looked at (and, if the counts are not finite, repaired in place) -- once per launch, so a
+        // later fetch never inspects what an in-place all-reduce has made of the buffer since.  The header's
+        // contract: fetch (statistics or logL_k only, as the sharded estimators do) BEFORE reducing.
         c->last_stats_checked = true;
         bool retried = false;
         int rc = nonfinite_retry(c, &retried);

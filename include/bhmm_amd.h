@@ -145,10 +145,10 @@ int bhmm_estep(bhmm_ctx *ctx, const double *A, const double *pi, const double *p
  * not even after bhmm_estep's own retry on one chunk per trajectory (reducible
  * transition matrices with emission probabilities hundreds of decades apart) -- refused loudly instead
  * of handing NaN counts to an M-step.
- * ORDER when bhmm_estep wrote into the caller's stats_dev: a fetch WITH `stats` reads that buffer and is
- * where this rank's result is inspected (once per launch; the retry above re-runs the local E-step into
- * the same buffer) -- so fetch the statistics BEFORE reducing the buffer in place, or reduce first and
- * fetch with stats == NULL (logL_k only: the buffer is then neither read nor inspected). */
+ * ORDER when bhmm_estep wrote into the caller's stats_dev: the FIRST fetch after the launch (with `stats`, or
+ * with logL_k only as a sharded caller does) is where this rank's result is inspected, once per launch --
+ * the retry above re-runs the local E-step into the same buffer -- so call it BEFORE reducing the buffer in
+ * place; later fetches of the same launch do not look at the buffer's counts again. */
 int bhmm_estep_fetch(bhmm_ctx *ctx, double *stats, double *logL_k);
 /* After an E-step run with BHMM_FLAG_STORE_GAMMA: copy gamma of trajectory k, (T_k,N)
  * row-major, to the host. */
@@ -226,7 +226,19 @@ int bhmm_sample_paths_dev(bhmm_ctx *ctx, const double *A, const double *pi, cons
  *                   applies the rule per step; 9..64 states: 1 after a lazily scaled vector
  *                   left its range and the E-step was repeated with per-step normalisation
  *   "viterbi_chunked" (read-only) 1 if the last bhmm_viterbi_batch ran parallel over time
- *                   chunks (boundaries verified, no close decision), 0 if it ran serially */
+ *                   chunks (boundaries verified, no close decision), 0 if it ran serially
+ *   "viterbi_margin" 1/0/2  (9..256 states) accept a segment-parallel first pass whose boundaries equal their
+ *                   predecessors' vectors to 1e-12 by the margins of the decisions on its path (2: up to 64 states
+ *                   from the next call on, not only after a call that needed rounds); "viterbi_mend" 1/0  (9..64
+ *                   states) segments further than 1e-12 from their predecessor run again alone up to a kept
+ *                   vector of the first pass;  read-only: "viterbi_segments", "viterbi_W", "viterbi_mismatch",
+ *                   "viterbi_far", "viterbi_mended", "viterbi_rounds", "viterbi_margin_used",
+ *                   "viterbi_margin_close"
+ *   "draw_watch"    1/0  (bhmm_sample_paths*) draws whose cumulative sums lie within 64 x the deviation the
+ *                   forward pass's boundary check measured are decided again on the serial recursion over a
+ *                   long window (csrc/draw_verify.hpp); if one does not stand the call is repeated on exact
+ *                   alpha rows (default 1).  read-only: "draw_events", "draw_checked", "draw_redone",
+ *                   "draw_alpha_dev";  tests: "draw_watch_tol" (watch tolerance), "draw_test_redo" */
 int bhmm_ctx_set_option(bhmm_ctx *ctx, const char *name, double value);
 int bhmm_ctx_get_option(bhmm_ctx *ctx, const char *name, double *value);
 
