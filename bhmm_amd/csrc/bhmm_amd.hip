@@ -1084,6 +1084,12 @@ int bhmm_ctx_create(bhmm_ctx **out, int device, void *stream)
         c->tile_enabled = atoi(e) != 0;
     if (const char *e = getenv("BHMM_AMD_TILE_PER_CU"))
         c->tile_per_cu = std::max(1, std::min(4, atoi(e)));
+    // (sweeps: the watched-draw machinery of draw_verify.hpp with a wide watch / with every watched draw treated as
+    // a decision that did not stand, on whatever problems the sweep draws)
+    if (const char *e = getenv("BHMM_AMD_DRAW_WATCH_TOL"))
+        c->draw_watch_tol = std::min(0.5, std::max(0.0, atof(e)));
+    if (const char *e = getenv("BHMM_AMD_DRAW_TEST_REDO"))
+        c->draw_test_redo = atoi(e) != 0;
     if (const char *e = getenv("BHMM_AMD_SPEC_W")) {
         c->spec_W = std::max(1, atoi(e));
         c->spec_W_fixed = true;
@@ -1306,7 +1312,12 @@ int bhmm_ctx_set_observations(bhmm_ctx *c, int kind, const void *obs, const int6
     c->tile_latched = c->tile_enabled; // (ctx.hpp: one decision per set of observations)
     c->vit_seg_given_up = false;
     c->vit_rows_fail = 0;
-    c->vit_margin_want = getenv("BHMM_AMD_VIT_MARGIN_FORCE") != nullptr; // (sweeps: the margin rule at every state count)
+    // 33..64 states: the margin rule from the first call on (round 6).  On observations that follow the model --
+    // what a Viterbi pass after EM sees -- most boundaries of the first pass carry rounding noise and a fix-up round
+    // runs for half a pass (6.7 ms at configs[3]) where margins + mending take 2.6; on white-noise data the round is
+    // 0.5 ms cheaper.  Below 33 states a round is short either way: there the rule waits for a call that needed it.
+    // (BHMM_AMD_VIT_MARGIN_FORCE: the rule at every state count, for the sweeps)
+    c->vit_margin_want = getenv("BHMM_AMD_VIT_MARGIN_FORCE") != nullptr || (c->n > 32 && c->n <= 64);
     c->vit_bad = 0;
     c->vit_explore = true;
     c->wide_replans = 0;
