@@ -1048,7 +1048,10 @@ def main():
         whole = secondary_whole_iterations(rk, model, args)
         sec.extend(whole)
         if out is not None and world == 1 and not args.no_projection:
-            out["projected_8gpu"] = projected_8gpu(torch, dev, local, stream, args, out["ms_per_step"], whole, model)
+            try:
+                out["projected_8gpu"] = projected_8gpu(torch, dev, local, stream, args, out["ms_per_step"], whole, model)
+            except Exception as e:      # (a box on which a one-rank RCCL communicator cannot be made: the line stands)
+                out["projected_8gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if out is not None:
             out["secondary"] = sec
             if c1 is not None:
