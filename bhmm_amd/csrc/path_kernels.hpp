@@ -2470,7 +2470,7 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
                 // the reference's arithmetic, chain for chain
                 xs[w][gi][i] = ps;
                 double S = 0.0;
-#pragma unroll
+#pragma unroll 1 // (rare path: rolled -- fully unrolled, its 64 compare results cost the hot loop its scalar registers)
                 for (int tl = 0; tl < NP; tl += TL) {
                     double x[TL];
 #pragma unroll
@@ -2485,7 +2485,7 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
                 }
                 xp[w][gi][i] = ps / S;
                 double acc = 0.0;
-#pragma unroll
+#pragma unroll 1 // (rare path: rolled -- fully unrolled, its 64 compare results cost the hot loop its scalar registers)
                 for (int tl = 0; tl < NP; tl += TL) {
                     double x[TL];
 #pragma unroll
