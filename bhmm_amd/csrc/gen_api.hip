@@ -266,6 +266,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
     if (rc)
         return rc;
     c->viterbi_chunked = false;
+    c->vit_mended = 0;
     const double *pobs = nullptr;
     if ((rc = gen_pobs(c, m, &pobs)) ||
         (rc = c->d_scratch.ensure((size_t)c->total * n * sizeof(uint16_t))) ||
@@ -296,8 +297,11 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
         const int W0 = std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
         const int64_t fill0 = ((c->total + (int64_t)c->vit_seg_per_simd * c->num_simd - 1) /
                                ((int64_t)c->vit_seg_per_simd * c->num_simd) + 7) / 8 * 8;
-        int W_try = c->vit_W > 0 ? c->vit_W
-                    : (c->vit_margin ? (int)std::max<int64_t>(W0, std::min<int64_t>(4 * (int64_t)W0, fill0)) : W0);
+        // (round 6: with the mending round the E-step's length is where the margin route starts too -- the few
+        // boundaries that need the fourfold length are repaired alone; the length doubles for the next call, up to
+        // that fourfold, when a pass could not be mended or needed three or more rounds)
+        const int W_cap = (int)std::max<int64_t>(W0, std::min<int64_t>(4 * (int64_t)W0, fill0));
+        int W_try = c->vit_W > 0 ? c->vit_W : ((c->vit_margin && !c->vit_mend) ? W_cap : W0);
         Segs sg;
         // the path-margin acceptance of the first pass (k_vit_margin, path_kernels.hpp; see wide_viterbi_run)
         const double vm_tol = 1e-12;
@@ -351,6 +355,8 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
             const dim3 sgrid((sg.nseg + 7) / 8), sblk(512);
             int round = 0;
             bool margin_accepted = false;
+            bool allow_mend = c->vit_mend, mended = false;
+            c->vit_mended = 0;
             for (; round <= 12; ++round) {
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
                 lds_poison(c->stream);
@@ -375,9 +381,30 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                 }
                 if (c->h_specres[3] == 0)
                     break;
+                int spliced = 0;
+                if (round == 0 && vall && c->h_specres[0] != 0 && (int64_t)c->h_specres[0] * 2 <= sg.nseg && allow_mend) {
+                    // the mending round of wide_viterbi_run (path_api.hip): the segments further than vm_tol from their
+                    // predecessors' vectors alone run again up to a kept vector of the first pass
+                    mended = true;
+                    BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                    lds_poison(c->stream);
+                    hipLaunchKernelGGL(k_gen_viterbi_seg<true>, sgrid, sblk, smv, c->stream, m, (const int64_t *)c->d_offsets.p,
+                                       sg, pobs, ptr8, last, c->d_aentry.p, c->d_aexit.p, c->d_vckpt.p,
+                                       (const uint8_t *)c->d_vflag.p + sg.nseg, vall, vm_tol, c->d_specres.p + 1);
+                    BHMM_HIP(hipGetLastError());
+                    unsigned int notmet = 0;
+                    BHMM_HIP(hipMemcpyAsync(&notmet, c->d_specres.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost,
+                                            c->stream));
+                    BHMM_HIP(hipStreamSynchronize(c->stream));
+                    c->vit_mended = (int)c->h_specres[0];
+                    if (notmet == 0) {
+                        spliced = (int)c->h_specres[0];
+                        c->h_specres[0] = 0;
+                    }
+                }
                 if (round == 0 && vall && c->h_specres[0] == 0) {
-                    // every boundary within vm_tol: the path of this pass, and the margins of the decisions on it
-                    const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1;
+                    // every boundary (and splice) within vm_tol: the path of this pass, and the margins of the decisions on it
+                    const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1 + spliced;
                     const double margin = std::max(1e-10, 16.0 * (2e-15 * (double)maxT + vm_tol * maxseg));
                     if ((rc = seg_walks()))
                         return rc;
@@ -401,11 +428,21 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                     }
                     // (a close decision on the path: the rounds decide)
                 }
+                if (round == 0 && mended) {
+                    // (the rounds compare bitwise with the kept vectors: a pass that was mended and then not accepted is
+                    // run again from scratch, without mending -- see wide_viterbi_run)
+                    allow_mend = false;
+                    mended = false;
+                    round = -1;
+                }
             }
             c->vit_seg_rounds = round;
             if (c->h_specres[3] == 0 || margin_accepted) {
                 done = true;
-                c->vit_W = W_try; // (what converged is where the next call on these observations starts)
+                // (what converged is where the next call on these observations starts; longer after a pass whose far
+                // boundaries could not be mended or that needed three or more rounds)
+                const bool longer = (vall && c->vit_far > 0 && !margin_accepted) || (round >= 3 && !margin_accepted);
+                c->vit_W = (longer && W_try < W_cap) ? std::min(2 * W_try, W_cap) : W_try;
             }
         }
         if (!done && c->pplan[0].nseg > K)

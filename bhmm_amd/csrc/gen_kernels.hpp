@@ -795,8 +795,12 @@ template <bool FIX>
 __global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, const int64_t *off, const Segs sg,
                                                          const double *pobs, uint8_t *ptr, int32_t *last_state,
                                                          double *v_entry, double *v_exit, double *ckpt,
-                                                         const uint8_t *flag, double *vall = nullptr)
+                                                         const uint8_t *flag, double *vall = nullptr,
+                                                         double mend_tol = 0.0, unsigned int *notmet = nullptr)
 {
+    // FIX with mend_tol > 0: the mending round of k_wide_viterbi_seg (path_kernels.hpp) -- flagged segments run again
+    // from the predecessor's vector only until they are within mend_tol of a kept vector of the first pass; every
+    // vector of the repeated stretch goes to vall; a segment that reaches its end counts in notmet.
     extern __shared__ __attribute__((aligned(16))) double gvs_sm[];
     double *sAT = gvs_sm;                         // [128][GVS_PITCH]
     double *xv = gvs_sm + 128 * GVS_PITCH;        // [8][128]: the final-state search
@@ -925,18 +929,22 @@ __global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, cons
                 v_entry[(int64_t)sgi * 128 + j[0]] = v[0];
                 v_entry[(int64_t)sgi * 128 + j[1]] = v[1];
             }
-            if (vall && t >= t0) { // (every vector of the first pass, [total][n]: k_vit_margin)
-                if (real[0])
-                    vall[(o0 + t) * n + j[0]] = v[0];
-                if (real[1])
-                    vall[(o0 + t) * n + j[1]] = v[1];
-            }
+        }
+        if (vall && t >= t0) { // (every vector of the first pass / of a mended stretch, [total][n]: k_vit_margin)
+            if (real[0])
+                vall[(o0 + t) * n + j[0]] = v[0];
+            if (real[1])
+                vall[(o0 + t) * n + j[1]] = v[1];
         }
         if (((o0 + t) & 63) == 63 && t >= t0) {
             double *cp = ckpt + ((o0 + t) >> 6) * 128;
             if constexpr (FIX) {
-                const bool same = __double_as_longlong(cp[j[0]]) == __double_as_longlong(v[0]) &&
-                                  __double_as_longlong(cp[j[1]]) == __double_as_longlong(v[1]);
+                const double c0 = cp[j[0]], c1 = cp[j[1]];
+                bool same = __double_as_longlong(c0) == __double_as_longlong(v[0]) &&
+                            __double_as_longlong(c1) == __double_as_longlong(v[1]);
+                if (mend_tol > 0.0) // (uniform)
+                    same = same || (fabs(c0 - v[0]) <= mend_tol * c0 && (c0 == 0.0) == (v[0] == 0.0) &&
+                                    fabs(c1 - v[1]) <= mend_tol * c1 && (c1 == 0.0) == (v[1] == 0.0));
                 if (__ballot(!same) == 0ull) {
                     met = true;
                     break;
@@ -948,6 +956,8 @@ __global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, cons
     }
     if (met)
         return;
+    if (FIX && notmet && lane == 0)
+        atomicAdd(notmet, 1u);
     v_exit[(int64_t)sgi * 128 + j[0]] = v[0];
     v_exit[(int64_t)sgi * 128 + j[1]] = v[1];
     if (t1 == T) { // the trajectory's final state (_hidden.c:262-267: first maximum)

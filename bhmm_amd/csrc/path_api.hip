@@ -400,6 +400,7 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
         return rc;
     const int K = c->K, n = c->n, NP = c->wide ? c->N : 8, GP = 64 / NP;
     c->viterbi_chunked = false;
+    c->vit_mended = 0;
     const size_t gpad = c->wide ? 0 : (size_t)c->Gp;
     if ((rc = c->d_scratch.ensure((size_t)c->total * n)) ||
         (rc = c->d_scratch2.ensure(((size_t)c->total + K + 3 * gpad) * sizeof(int32_t))))

@@ -271,11 +271,11 @@ def test_decision_with_a_margin_between_delta_and_16_delta_goes_to_the_rounds(n,
     assert tried >= 1
 
 
-@pytest.mark.parametrize("n,kind", [(64, "gaussian"), (24, "discrete")])
+@pytest.mark.parametrize("n,kind", [(64, "gaussian"), (24, "discrete"), (96, "gaussian")])
 def test_mending_round_for_boundaries_further_than_the_tolerance(n, kind):
     """A metastable model (lifetimes of 10 .. 100 steps, overlapping emissions): after a short warm-up some segments
     start further than 1e-12 from their predecessors' vectors.  Those alone are run again up to a kept vector of the
-    first pass (k_wide_viterbi_seg, mend_tol), the rest of the pass is accepted by the margins on its path -- the
+    first pass (k_wide_viterbi_seg / k_gen_viterbi_seg, mend_tol), the rest of the pass is accepted by the margins on its path -- the
     oracle's paths byte for byte, as with the mending switched off (fix-up rounds) and with the margins off."""
     from bhmm_amd.engine import Engine
     rng = np.random.default_rng(6600 + n)
