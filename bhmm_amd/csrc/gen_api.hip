@@ -472,8 +472,10 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
         const int W0 = std::max(64, c->spec_W > 0 ? (c->spec_W + 7) / 8 * 8 : 128);
         // (six E-step forgetting lengths, at most one and a half fill lengths: at 256 states one boundary of 749 was
         // still 1e-12 off after 504 steps, none after 750 -- and a pass that is not accepted is lost time)
+        // (round 6: with the mending round the E-step's length; a pass that is not accepted doubles it for the next call)
         const int W_try = c->vit_W > 0 ? c->vit_W
-                                       : (int)std::max<int64_t>(W0, std::min<int64_t>(6 * (int64_t)W0, (3 * fill0 / 2 + 7) / 8 * 8));
+                          : (c->vit_mend ? W0
+                                         : (int)std::max<int64_t>(W0, std::min<int64_t>(6 * (int64_t)W0, (3 * fill0 / 2 + 7) / 8 * 8)));
         const int64_t seglen = std::max<int64_t>(fill0, W_try);
         Segs sg;
         if ((rc = wide_path_plan_pub(c, 0, seglen, sg)))
@@ -515,26 +517,60 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
             hipLaunchKernelGGL((k_wide_vit_check<256>), dim3((sg.nseg + 255) / 256), dim3(256), 0, c->stream, sg,
                                c->d_aentry.p, (const double *)c->d_aexit.p, c->d_vflag.p, c->d_specres.p, vm_tol);
             // the back-trace of this pass (needed either way)
-            hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t, 4>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
-                               (const uint8_t *)ptr8, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
-            hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
-                               (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 256,
-                               (const int32_t *)last, c->d_vend.p);
-            if (out_fmt == 0)
-                hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t, 4>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
-                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path);
-            else
-                hipLaunchKernelGGL((k_wide_vit_walk<true, uint8_t, 4>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
-                                   (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, p8);
-            BHMM_HIP(hipGetLastError());
+            auto rows_walks = [&]() -> int {
+                hipLaunchKernelGGL((k_wide_vit_walk<false, uint8_t, 4>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                   (const uint8_t *)ptr8, c->d_vmaps.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+                hipLaunchKernelGGL(k_wide_vit_stitch, dim3((K + 63) / 64), dim3(64), 0, c->stream,
+                                   (const int32_t *)c->pplan[0].traj0.p, K, (const uint8_t *)c->d_vmaps.p, 256,
+                                   (const int32_t *)last, c->d_vend.p);
+                if (out_fmt == 0)
+                    hipLaunchKernelGGL((k_wide_vit_walk<true, int32_t, 4>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                       (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, path);
+                else
+                    hipLaunchKernelGGL((k_wide_vit_walk<true, uint8_t, 4>), dim3(sg.nseg), dim3(64), 0, c->stream, off, sg, n,
+                                       (const uint8_t *)ptr8, (uint8_t *)nullptr, (const uint8_t *)c->d_vend.p, p8);
+                BHMM_HIP(hipGetLastError());
+                return BHMM_OK;
+            };
+            if ((rc = rows_walks()))
+                return rc;
             BHMM_HIP(hipMemcpyAsync(c->h_specres, c->d_specres.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost,
                                     c->stream));
             BHMM_HIP(hipStreamSynchronize(c->stream));
             c->vit_seg_mismatch = (int)c->h_specres[3];
             c->vit_far = (int)c->h_specres[0];
             bool accepted = c->h_specres[3] == 0;
+            int spliced = 0;
+            if (!accepted && c->h_specres[0] != 0 && (int64_t)c->h_specres[0] * 2 <= sg.nseg && c->vit_mend) {
+                // the mending round (see wide_viterbi_run): the rows of the segments further than vm_tol from their
+                // predecessors' vectors run again up to a vector the first pass kept; then the back-trace again
+                BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
+                lds_poison(c->stream);
+#define BHMM_GVR_MEND(SV)                                                                                                    \
+    hipLaunchKernelGGL((k_gen_viterbi_rows<GVR_ROWS, SV, true>), dim3((sg.nseg + GVR_ROWS - 1) / GVR_ROWS), dim3(256 * SV), smr, \
+                       c->stream, m, off, sg, pobs, ptr8, last, c->d_aentry.p, c->d_aexit.p, vall,                           \
+                       (const uint8_t *)c->d_vflag.p + sg.nseg, vm_tol, c->d_specres.p + 1)
+                if (GVR_S == 1)
+                    BHMM_GVR_MEND(1);
+                else if (GVR_S == 2)
+                    BHMM_GVR_MEND(2);
+                else
+                    BHMM_GVR_MEND(4);
+#undef BHMM_GVR_MEND
+                BHMM_HIP(hipGetLastError());
+                unsigned int notmet = 0;
+                BHMM_HIP(hipMemcpyAsync(&notmet, c->d_specres.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+                BHMM_HIP(hipStreamSynchronize(c->stream));
+                c->vit_mended = (int)c->h_specres[0];
+                if (notmet == 0) {
+                    spliced = (int)c->h_specres[0];
+                    c->h_specres[0] = 0;
+                    if ((rc = rows_walks()))
+                        return rc;
+                }
+            }
             if (!accepted && c->h_specres[0] == 0) {
-                const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1;
+                const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1 + spliced;
                 const double margin = std::max(1e-10, 16.0 * (2e-15 * (double)maxT + vm_tol * maxseg));
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
                 const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + 255) / 256)); // (the longest REAL segment)

@@ -989,10 +989,16 @@ __global__ __launch_bounds__(512) void k_gen_viterbi_seg(const WideModel m, cons
 //   v_entry / v_exit [nseg][256];  vall [total][n];  ptr one byte per (t, j)
 typedef double gen_d2 __attribute__((ext_vector_type(2)));
 constexpr int GVR_ROWS = 4;
-template <int R, int S>
+// MEND (round 6): the mending round -- only the rows of flagged segments run, from the predecessor's vector (v_entry, which
+// the check replaced by it) at their first step, and a row stops as soon as its vector is within mend_tol of the one
+// the first pass kept at the same step (vall, looked at on every 64th global step); every vector and back-pointer of
+// the repeated stretch replaces the first pass's.  Rows that reach their end count in notmet.
+template <int R, int S, bool MEND = false>
 __global__ __launch_bounds__(256 * S) void k_gen_viterbi_rows(const WideModel m, const int64_t *off, const Segs sg,
                                                               const double *pobs, uint8_t *ptr, int32_t *last_state,
-                                                              double *v_entry, double *v_exit, double *vall)
+                                                              double *v_entry, double *v_exit, double *vall,
+                                                              const uint8_t *flag = nullptr, double mend_tol = 0.0,
+                                                              unsigned int *notmet = nullptr)
 {
     // S threads per target state (sp = threadIdx.x / 256, uniform per wavefront): candidate range sp of S, ascending.
     // A range's winner is its FIRST maximum; ranges are merged in ascending order with a strict comparison, which is
@@ -1007,26 +1013,31 @@ __global__ __launch_bounds__(256 * S) void k_gen_viterbi_rows(const WideModel m,
     double *mh = gvr_sm + 2 * R * n + R;                              // [S - 1][R][256]: winners of the ranges 1 .. S - 1
     int *mb = reinterpret_cast<int *>(mh + (S > 1 ? (S - 1) * R * 256 : 0)); // ... and their indices
     const bool real = j < n;
+    __shared__ int sDiff[R];
     int sgi[R], k[R], nst[R];
     int64_t o0[R], T[R], t0[R], t1[R], tw[R];
+    bool rowmet[R];
     int nmax = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         sgi[r] = blockIdx.x * R + r;
-        const bool has = sgi[r] < sg.nseg && sg.len[sgi[r]] > 0;
+        const bool has = sgi[r] < sg.nseg && sg.len[sgi[r]] > 0 && (!MEND || flag[sgi[r]] != 0);
         k[r] = has ? sg.traj[sgi[r]] : 0;
         o0[r] = has ? off[k[r]] : 0;
         T[r] = has ? off[k[r] + 1] - o0[r] : 0;
         t0[r] = has ? sg.t0[sgi[r]] : 0;
         t1[r] = has ? t0[r] + sg.len[sgi[r]] : 0;
-        tw[r] = has ? ((t0[r] - sg.W > 0) ? t0[r] - sg.W : 0) : 0;
+        tw[r] = has ? (MEND ? t0[r] : ((t0[r] - sg.W > 0) ? t0[r] - sg.W : 0)) : 0;
         nst[r] = has ? (int)(t1[r] - tw[r]) : 0;
         nmax = max(nmax, nst[r]);
+        rowmet[r] = false;
     }
+    if (MEND && nmax == 0)
+        return; // (no flagged row here: uniform over the workgroup)
     if (real && sp == 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            vT[j * R + r] = 1.0 / (double)n; // (warm-up start; replaced at t = 0)
+        for (int r = 0; r < R; ++r) // (warm-up start, replaced at t = 0; MEND: the predecessor's vector)
+            vT[j * R + r] = (MEND && nst[r] > 0) ? v_entry[(int64_t)sgi[r] * 256 + j] : 1.0 / (double)n;
     }
     __syncthreads();
     const double pi_j = real ? m.pi[j] : 0.0;
@@ -1193,6 +1204,15 @@ __global__ __launch_bounds__(256 * S) void k_gen_viterbi_rows(const WideModel m,
                 s += x[i];
             sS[wid] = s;
         }
+        // MEND: rows at a kept step of the first pass compare with it (uniform: every thread knows every row's step)
+        bool cp[R], anycp = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            cp[r] = MEND && act[r] && ((o0[r] + t[r]) & 63) == 63 && t[r] >= t0[r];
+            anycp |= cp[r];
+        }
+        if (MEND && anycp && threadIdx.x < R)
+            sDiff[threadIdx.x] = 0;
         __syncthreads();
         if (sp == 0) {
 #pragma unroll
@@ -1203,6 +1223,13 @@ __global__ __launch_bounds__(256 * S) void k_gen_viterbi_rows(const WideModel m,
                         vT[j * R + r] = v;
                     if (t[r] == t0[r] - 1)
                         v_entry[(int64_t)sgi[r] * 256 + j] = v;
+                    if (cp[r] && real) {
+                        const double old = vall[(o0[r] + t[r]) * n + j];
+                        const bool same = __double_as_longlong(old) == __double_as_longlong(v) ||
+                                          (fabs(old - v) <= mend_tol * old && (old == 0.0) == (v == 0.0));
+                        if (!same)
+                            sDiff[r] = 1;
+                    }
                     if (real && t[r] >= t0[r])
                         vall[(o0[r] + t[r]) * n + j] = v;
                     if (t[r] == t1[r] - 1)
@@ -1211,9 +1238,28 @@ __global__ __launch_bounds__(256 * S) void k_gen_viterbi_rows(const WideModel m,
             }
         }
         __syncthreads();
+        if (MEND && anycp) {
+            nmax = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (cp[r] && sDiff[r] == 0) { // within the tolerance of the first pass's vector: its vectors stand from here
+                    nst[r] = u + 1;
+                    rowmet[r] = true;
+                }
+                nmax = max(nmax, nst[r]);
+            }
+        }
+    }
+    if (MEND) {
+        if (notmet && threadIdx.x == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (nst[r] > 0 && !rowmet[r])
+                    atomicAdd(notmet, 1u);
+        }
     }
     // the trajectory's final state (_hidden.c:262-267: first maximum) by the row that holds its last step
-    if (lane == 0 && wid < R && nst[wid] > 0 && t1[wid] == T[wid]) {
+    if (lane == 0 && wid < R && nst[wid] > 0 && t1[wid] == T[wid] && !rowmet[wid]) {
         double bm = vT[wid];
         int bi = 0;
         for (int i = 1; i < n; ++i)

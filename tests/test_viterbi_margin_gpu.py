@@ -271,11 +271,11 @@ def test_decision_with_a_margin_between_delta_and_16_delta_goes_to_the_rounds(n,
     assert tried >= 1
 
 
-@pytest.mark.parametrize("n,kind", [(64, "gaussian"), (24, "discrete"), (96, "gaussian")])
+@pytest.mark.parametrize("n,kind", [(64, "gaussian"), (24, "discrete"), (96, "gaussian"), (160, "gaussian")])
 def test_mending_round_for_boundaries_further_than_the_tolerance(n, kind):
     """A metastable model (lifetimes of 10 .. 100 steps, overlapping emissions): after a short warm-up some segments
     start further than 1e-12 from their predecessors' vectors.  Those alone are run again up to a kept vector of the
-    first pass (k_wide_viterbi_seg / k_gen_viterbi_seg, mend_tol), the rest of the pass is accepted by the margins on its path -- the
+    first pass (k_wide_viterbi_seg / k_gen_viterbi_seg / k_gen_viterbi_rows<.., MEND>, mend_tol), the rest of the pass is accepted by the margins on its path -- the
     oracle's paths byte for byte, as with the mending switched off (fix-up rounds) and with the margins off."""
     from bhmm_amd.engine import Engine
     rng = np.random.default_rng(6600 + n)
@@ -286,7 +286,7 @@ def test_mending_round_for_boundaries_further_than_the_tolerance(n, kind):
     A = A / A.sum(axis=1)[:, None] / life[:, None]
     A[np.arange(n), np.arange(n)] = 1.0 - 1.0 / life
     pi = np.full(n, 1.0 / n)
-    lengths = (40000, 25000, 3, 30000)
+    lengths = (40000, 25000, 3, 30000) if n <= 128 else (14000, 9000, 3)
     if kind == "gaussian":
         p0, p1 = np.linspace(-5, 5, n), np.linspace(0.5, 2.0, n)
         states = [rng.integers(0, n, T) for T in lengths]
