@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(256) void k_vit_margin(const double *A, int n, cons
     const int pj = lane < cnt ? (int)path[o0 + tb + lane] : 0;
     const int pi = (lane < cnt && tb + lane >= 1) ? (int)path[o0 + tb + lane - 1] : 0;
     bool bad = false;
-    constexpr int U = 8;
+    constexpr int U = 16;
     for (int q0 = 0; q0 < cnt; q0 += U) {
         double vr[U][NC];
 #pragma unroll
