@@ -1172,6 +1172,8 @@ int bhmm_ctx_destroy(bhmm_ctx *c)
     c->d_specres.release();
     if (c->h_specres)
         (void)hipHostFree(c->h_specres);
+    if (c->h_small)
+        (void)hipHostFree(c->h_small);
     if (c->h_raw)
         (void)hipHostFree(c->h_raw);
     c->d_tail.release();

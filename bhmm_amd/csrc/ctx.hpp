@@ -199,6 +199,7 @@ struct bhmm_ctx {
     bool tail_ready = false;          // d_tail allocated and its verdict words cleared
     bool ev_lean = false;             // last E-step recorded only ev[2..4]
     unsigned int *h_specres = nullptr; // pinned
+    double *h_small = nullptr;         // pinned, 64 KB: small results of the path calls (one copy per call)
     // two-level stitch: groups of consecutive chunks (empty when every trajectory is short)
     int nG = 0;
     bhmm::DevBuf<int32_t> d_grp_c0, d_grp_c1, d_grp_traj0; // [nG], [nG], [K+1]

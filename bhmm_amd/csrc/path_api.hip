@@ -279,8 +279,19 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
             BHMM_HIP(hipGetLastError());
         }
     }
-    std::vector<unsigned long long> hc(nstat);
-    std::vector<double> he(esz);
+    // counts | reduced emission statistics | [status, watched draws] are contiguous on the device: ONE copy, into
+    // pinned memory where it fits (a pageable destination makes every small copy a round trip of its own)
+    const size_t nres = nstat + esz + 1;
+    std::vector<double> hres_v;
+    double *hres = nullptr;
+    if (nres <= 8192) {
+        if (!c->h_small)
+            BHMM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_small), 8192 * sizeof(double), hipHostMallocDefault));
+        hres = c->h_small;
+    } else {
+        hres_v.resize(nres);
+        hres = hres_v.data();
+    }
     int hstatus = 0;
     if (stats_dev) {
         // statistics stay on the device, packed for the caller's all-reduce
@@ -288,15 +299,13 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
                            (const unsigned long long *)cnt, (const double *)ered, n, N, c->M, c->kind,
                            1, stats_dev);
         BHMM_HIP(hipGetLastError());
+        BHMM_HIP(hipMemcpyAsync(hres + nres - 1, status, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     } else {
-        BHMM_HIP(hipMemcpyAsync(hc.data(), cnt, nstat * sizeof(unsigned long long),
-                                hipMemcpyDeviceToHost, c->stream));
-        if (esz)
-            BHMM_HIP(hipMemcpyAsync(he.data(), ered, esz * sizeof(double), hipMemcpyDeviceToHost,
-                                    c->stream));
+        BHMM_HIP(hipMemcpyAsync(hres, cnt, nres * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    int hst[2] = {0, 0}; // [status | watched draws]
-    BHMM_HIP(hipMemcpyAsync(hst, status, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    const unsigned long long *hc = reinterpret_cast<const unsigned long long *>(hres);
+    const double *he = hres + nstat;
+    const int *hst = reinterpret_cast<const int *>(hres + nres - 1); // [status | watched draws]
     if (paths)
         BHMM_HIP(hipMemcpyAsync(paths, path, (size_t)c->total * sizeof(int32_t),
                                 hipMemcpyDeviceToHost, c->stream));
