@@ -152,6 +152,24 @@ inline typename V::D vlog1p(typename V::D x)
     return V::add(vlog<V>(u), c);
 }
 
+// log(1 + x) for |x| < 2^-6 by its series to x^10 (truncation < 1e-21): no division, no range reduction
+template <class V>
+inline typename V::D vlog1p_small(typename V::D x)
+{
+    typedef typename V::D D;
+    D q = V::set1(-1.0 / 10.0);
+    q = V::fma(q, x, V::set1(1.0 / 9.0));
+    q = V::fma(q, x, V::set1(-1.0 / 8.0));
+    q = V::fma(q, x, V::set1(1.0 / 7.0));
+    q = V::fma(q, x, V::set1(-1.0 / 6.0));
+    q = V::fma(q, x, V::set1(1.0 / 5.0));
+    q = V::fma(q, x, V::set1(-1.0 / 4.0));
+    q = V::fma(q, x, V::set1(1.0 / 3.0));
+    q = V::fma(q, x, V::set1(-1.0 / 2.0));
+    q = V::fma(q, x, V::set1(1.0));
+    return V::mul(q, x);
+}
+
 // exp(x) for x <= 0 (clamped at -700): x = k ln2 + r, the degree-11 polynomial of estep_sweep.hpp (exp_nonpos)
 template <class V>
 inline typename V::D vexp_nonpos(typename V::D x)
@@ -291,11 +309,19 @@ inline typename V::D voffdiag(Streams<V> &st, typename V::D v0, typename V::D v1
     typedef typename V::D D;
     typedef typename V::M M;
     const D one = V::set1(1.0);
+    // What does not depend on the proposal is taken off the chain of dependent operations (the latency of one
+    // round, seven times per sweep, is what this sampler costs): the uniform of the acceptance test and its
+    // logarithm -- the test is log u < dl --, the reciprocals of the old value's terms, 1 / (2 a).
+    const M v0z = V::eq(v0, V::set1(0.0));
+    const D v0s = V::blend(v0z, one, v0);
+    const D lu = vlog<V>(V::add(Streams<V>::to01(st.bits(act)), V::set1(0x1p-53))); // log of a uniform in (0, 1)
+    const D rv0 = V::div(one, v0s), rv1 = V::div(one, V::add(v0s, v1)), rv2 = V::div(one, V::add(v0s, v2));
     const D a = V::sub(V::add(c1, c2), c0);
+    const D inv2a = V::div(V::set1(0.5), a);
     const D b = V::fma(V::sub(c1, c0), v2, V::mul(V::sub(c2, c0), v1));
     const D c = V::mul(V::mul(V::sub(V::set1(0.0), c0), v1), v2);
     const D disc = V::sub(V::mul(b, b), V::mul(V::mul(V::set1(4.0), a), c));
-    const D vbar = V::div(V::mul(V::set1(0.5), V::sub(V::sqrt(V::max(disc, V::set1(0.0))), b)), a);
+    const D vbar = V::mul(V::sub(V::sqrt(V::max(disc, V::set1(0.0))), b), inv2a);
     M good = V::andm(V::andm(act, vpositive<V>(vbar)), V::ge(disc, V::set1(0.0)));
     const D vb = V::blend(good, vbar, one);
     const D r0 = V::div(one, vb), r1 = V::div(one, V::add(vb, v1)), r2 = V::div(one, V::add(vb, v2));
@@ -306,25 +332,31 @@ inline typename V::D voffdiag(Streams<V> &st, typename V::D v0, typename V::D v1
     D out = v0;
     if (V::any(good)) {
         const D ks = V::blend(good, k, one), is = V::blend(good, ith, one);
-        const D vn = V::div(vgamma<V>(st, ks, good), is);
+        const D theta = V::div(one, is); // (beside the Gamma draw, not behind it)
+        const D vn = V::mul(vgamma<V>(st, ks, good), theta);
         const M ok = V::andm(good, vpositive<V>(vn));
-        const M v0z = V::eq(v0, V::set1(0.0));
         // log [f(vn) / q(vn)] - log [f(v0) / q(v0)],  q(v) ~ v^(k-1) exp(-v / theta)
-        const D v0s = V::blend(V::andm(ok, V::notm(v0z)), v0, one), vns = V::blend(ok, vn, one);
-        // (the logarithms of the ratios: one division each besides the one inside vlog; the rounding of a ratio
-        // next to 1 costs 1e-16 absolute in its logarithm, times a row count of 1e6 .. 1e7: 1e-9 in dl)
+        const D vns = V::blend(ok, vn, one);
         const D dv = V::sub(vns, v0s);
-        D dl = V::mul(V::sub(c0, ks), vlog<V>(V::div(vns, v0s)));
-        dl = V::sub(dl, V::mul(c1, vlog<V>(V::div(V::add(vns, v1), V::add(v0s, v1)))));
-        dl = V::sub(dl, V::mul(c2, vlog<V>(V::div(V::add(vns, v2), V::add(v0s, v2)))));
-        dl = V::fma(dv, is, dl);
-        M accept = V::ge(dl, V::set1(0.0));
-        const M needu = V::andm(V::andm(ok, V::notm(v0z)), V::notm(accept));
-        if (V::any(needu)) {
-            const D u = Streams<V>::to01(st.bits(needu));
-            accept = V::orm(accept, V::andm(needu, V::lt(u, vexp_nonpos<V>(V::min(dl, V::set1(0.0))))));
+        // relative changes x = dv / (v0 + .): with the counts of a long trajectory the proposal sits within a per
+        // mille of the old value and log(1 + x) is its series; a lane with a larger step takes the full logarithm of
+        // the ratio -- chosen per lane by its own x, so the result does not depend on the neighbours in the vector
+        const D x0 = V::mul(dv, rv0), x1 = V::mul(dv, rv1), x2 = V::mul(dv, rv2);
+        const D lim = V::set1(0x1p-6);
+        const M small = V::andm(V::andm(V::lt(V::abs(x0), lim), V::lt(V::abs(x1), lim)), V::lt(V::abs(x2), lim));
+        D g0 = vlog1p_small<V>(x0), g1 = vlog1p_small<V>(x1), g2 = vlog1p_small<V>(x2);
+        const M large = V::andm(V::andm(ok, V::notm(v0z)), V::notm(small));
+        if (V::any(large)) {
+            g0 = V::blend(large, vlog<V>(V::mul(vns, rv0)), g0);
+            g1 = V::blend(large, vlog<V>(V::mul(V::add(vns, v1), rv1)), g1);
+            g2 = V::blend(large, vlog<V>(V::mul(V::add(vns, v2), rv2)), g2);
         }
-        accept = V::orm(accept, v0z); // (an element that was zero takes the proposal)
+        D dl = V::mul(V::sub(c0, ks), g0);
+        dl = V::sub(dl, V::mul(c1, g1));
+        dl = V::sub(dl, V::mul(c2, g2));
+        dl = V::fma(dv, is, dl);
+        // accept with probability min(1, exp(dl)): log u < dl (an element that was zero takes the proposal)
+        const M accept = V::orm(V::lt(lu, dl), v0z);
         out = V::blend(V::andm(ok, accept), vn, v0);
     }
     const M rw = V::andm(act, V::notm(good));
@@ -460,12 +492,17 @@ void sample_reversible_sweeps_v(const double *C, int n, int64_t nsweeps, uint64_
                     }
                 slot += (uint64_t)std::min<size_t>(W, rd.size() - p0);
             }
-        double tot = 0.0;
-        for (size_t e = 0; e < (size_t)n * n; ++e)
-            tot += X[e];
-        for (size_t e = 0; e < (size_t)n * n; ++e)
-            X[e] /= tot;
-        rowsums();
+        // The conditionals are covariant under a common factor of X (Beta and Gamma-proposal steps alike), so the
+        // normalisation sum X = 1 is only bookkeeping against drift: every 16th sweep and at the end (n^2 divisions and
+        // the row sums again were 4 % of a sweep at 8 states); in between the running row sums stand.
+        if ((sweep & 15) == 15 || sweep + 1 == nsweeps) {
+            double tot = 0.0;
+            for (size_t e = 0; e < (size_t)n * n; ++e)
+                tot += X[e];
+            for (size_t e = 0; e < (size_t)n * n; ++e)
+                X[e] /= tot;
+            rowsums();
+        }
     }
 }
 
