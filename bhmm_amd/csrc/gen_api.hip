@@ -307,7 +307,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
         const double vm_tol = 1e-12;
         double *vall = nullptr;
         int64_t maxT = 0;
-        const size_t smm = (size_t)n * n * sizeof(double);
+        const size_t smm = (size_t)n * (n | 1) * sizeof(double); // (odd pitch, k_vit_margin)
         if (c->vit_margin && c->d_gW.ensure((size_t)c->total * n) == BHMM_OK &&
             gen_set_smem(k_vit_margin<int32_t, 2>, smm) == BHMM_OK && gen_set_smem(k_vit_margin<uint8_t, 2>, smm) == BHMM_OK) {
             vall = c->d_gW.p;
@@ -409,7 +409,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                     if ((rc = seg_walks()))
                         return rc;
                     BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
-                    const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + 255) / 256)); // (the longest REAL segment)
+                    const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + VM_STEPS - 1) / VM_STEPS)); // (the longest REAL segment)
                     if (out_fmt == 0)
                         hipLaunchKernelGGL((k_vit_margin<int32_t, 2>), mgrid, dim3(256), smm, c->stream, m.A, n, off, sg,
                                            (const double *)vall, (const int32_t *)path, margin, c->d_specres.p);
@@ -573,7 +573,7 @@ int gen_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const double
                 const int maxseg = (int)((maxT + seglen - 1) / seglen) + 1 + spliced;
                 const double margin = std::max(1e-10, 16.0 * (2e-15 * (double)maxT + vm_tol * maxseg));
                 BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
-                const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + 255) / 256)); // (the longest REAL segment)
+                const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + VM_STEPS - 1) / VM_STEPS)); // (the longest REAL segment)
                 if (out_fmt == 0)
                     hipLaunchKernelGGL((k_vit_margin<int32_t, 4, false>), mgrid, dim3(256), 0, c->stream,
                                        (const double *)c->d_gAt.p, n, off, sg, (const double *)vall, (const int32_t *)path,

@@ -834,8 +834,8 @@ int wide_viterbi_run(bhmm_ctx *c, const double *A, const double *pi, const doubl
                     if ((rc = seg_walks()))
                         return rc;
                     BHMM_HIP(hipMemsetAsync(c->d_specres.p, 0, 4 * sizeof(unsigned int), c->stream));
-                    const size_t smm = (size_t)n * n * sizeof(double);
-                    const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + 255) / 256)); // (the longest REAL segment)
+                    const size_t smm = (size_t)n * (n | 1) * sizeof(double); // (odd pitch, k_vit_margin)
+                    const dim3 mgrid(sg.nseg, (unsigned)((c->pplan[0].maxlen + VM_STEPS - 1) / VM_STEPS)); // (the longest REAL segment)
                     static const bool vm_global = getenv("BHMM_AMD_VM_GLOBAL") != nullptr; // (experiment: A^T from L2)
                     if (vm_global) {
                         if ((rc = c->d_gAt.ensure((size_t)n * n)))

@@ -1434,6 +1434,7 @@ __global__ void k_wide_vit_check(const Segs sg, double *v_entry, const double *v
 // a winner that is zero, denormal or not finite) are counted in result[2]; the host then runs the fix-up
 // rounds, which need none of this.   vall [total][n]: every vector of the first pass.
 // =========================================================================================
+constexpr int VM_STEPS = 1024; // steps of a segment per workgroup of k_vit_margin (A^T is staged once per workgroup)
 [[maybe_unused]] static __global__ void k_vm_transpose(const double *A, int n, double *At)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1446,27 +1447,31 @@ __global__ __launch_bounds__(256) void k_vit_margin(const double *A, int n, cons
                                                     const double *vall, const PT *path, double margin,
                                                     unsigned int *result)
 {
-    // workgroup (s, c): steps [256 c, 256 c + 256) of segment s, 64 per wavefront; lane l holds the path at
-    // "its" step and the one before (one coalesced read each), the rows of v eight steps at a time
-    extern __shared__ double vm_sAT[]; // [j][i] = A[i][j]
+    // workgroup (s, c): steps [VM_STEPS c, VM_STEPS c + VM_STEPS) of segment s, 64 per wavefront and turn; lane l holds
+    // the path at "its" step and the one before (one coalesced read each), the rows of v sixteen steps at a time
+    extern __shared__ double vm_sAT[]; // [j][i] = A[i][j], rows PA apart
+    // (an odd pitch: the transposing writes of the staging -- consecutive lanes, consecutive j -- fall on different
+    // banks; with pitch n = 64 all 64 lanes of a wavefront hit one bank pair, 4 us of the LDS pipe per workgroup)
+    const int PA = ALDS ? (n | 1) : n;
     const int s = blockIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (s >= sg.nseg || sg.len[s] <= 0 || (int64_t)blockIdx.y * 256 >= sg.len[s])
+    if (s >= sg.nseg || sg.len[s] <= 0 || (int64_t)blockIdx.y * VM_STEPS >= sg.len[s])
         return;
     if constexpr (ALDS) {
         for (int e = threadIdx.x; e < n * n; e += 256)
-            vm_sAT[(e % n) * n + e / n] = A[e];
+            vm_sAT[(e % n) * PA + e / n] = A[e];
         __syncthreads();
     }
     const int k = sg.traj[s];
     const int64_t o0 = off[k], T = off[k + 1] - o0;
     const int64_t t1 = sg.t0[s] + sg.len[s];
-    const int64_t tb = sg.t0[s] + (int64_t)blockIdx.y * 256 + 64 * wid;
+    bool bad = false;
+    for (int turn = 0; turn < VM_STEPS / 256; ++turn) {
+    const int64_t tb = sg.t0[s] + (int64_t)blockIdx.y * VM_STEPS + 256 * turn + 64 * wid;
     if (tb >= t1)
-        return;
+        break;
     const int cnt = (int)(t1 - tb < 64 ? t1 - tb : 64);
     const int pj = lane < cnt ? (int)path[o0 + tb + lane] : 0;
     const int pi = (lane < cnt && tb + lane >= 1) ? (int)path[o0 + tb + lane - 1] : 0;
-    bool bad = false;
     constexpr int U = 16;
     for (int q0 = 0; q0 < cnt; q0 += U) {
         double vr[U][NC];
@@ -1482,7 +1487,7 @@ __global__ __launch_bounds__(256) void k_vit_margin(const double *A, int n, cons
             const int64_t t = tb + q0 + u;
             if (q0 + u < cnt && t >= 1) { // (uniform)
                 const int j = __shfl(pj, q0 + u, 64), ih = __shfl(pi, q0 + u, 64);
-                const double *col = (ALDS ? vm_sAT : A) + (int64_t)j * n;
+                const double *col = (ALDS ? vm_sAT : A) + (int64_t)j * PA;
                 double h[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
@@ -1509,6 +1514,7 @@ __global__ __launch_bounds__(256) void k_vit_margin(const double *A, int n, cons
         for (int i = lane; i < n; i += 64)
             bad |= i != j && !(vp[i] < lim);
     }
+    } // (turns)
     const unsigned long long b = __ballot(bad);
     if (lane == 0 && b)
         atomicAdd(&result[2], 1u);
