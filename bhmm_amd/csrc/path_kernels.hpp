@@ -1135,8 +1135,8 @@ __device__ __forceinline__ void static_for(F &&f)
 // h[i] = fma(v[16 ROW + B + i], w(B + i), 0), i = 0..7, with v given as its row copy `src`: ONE assembly
 // block per eight products (as single statements the compiler pads every one with an s_nop: its hazard
 // model cannot see which operand of an inline statement is the DPP one).
-template <int B, typename WF>
-__device__ __forceinline__ void prod8_bcast(double (&h)[16], const double &src, WF &&w)
+template <int B, int HB = B, int HN = 16, typename WF>
+__device__ __forceinline__ void prod8_bcast(double (&h)[HN], const double &src, WF &&w)
 {
 #define BHMM_W(I) "v"(w(std::integral_constant<int, B + I>{}))
     asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\t"
@@ -1149,8 +1149,8 @@ __device__ __forceinline__ void prod8_bcast(double (&h)[16], const double &src, 
                  "v_fmac_f64_dpp %5, %8, %14 row_newbcast:%22 row_mask:0xf bank_mask:0xf\n\t"
                  "v_fmac_f64_dpp %6, %8, %15 row_newbcast:%23 row_mask:0xf bank_mask:0xf\n\t"
                  "v_fmac_f64_dpp %7, %8, %16 row_newbcast:%24 row_mask:0xf bank_mask:0xf"
-                 : "=&v"(h[B + 0]), "=&v"(h[B + 1]), "=&v"(h[B + 2]), "=&v"(h[B + 3]), "=&v"(h[B + 4]),
-                   "=&v"(h[B + 5]), "=&v"(h[B + 6]), "=&v"(h[B + 7])
+                 : "=&v"(h[HB + 0]), "=&v"(h[HB + 1]), "=&v"(h[HB + 2]), "=&v"(h[HB + 3]), "=&v"(h[HB + 4]),
+                   "=&v"(h[HB + 5]), "=&v"(h[HB + 6]), "=&v"(h[HB + 7])
                  : "v"(src), BHMM_W(0), BHMM_W(1), BHMM_W(2), BHMM_W(3), BHMM_W(4), BHMM_W(5), BHMM_W(6),
                    BHMM_W(7), "n"(B + 0), "n"(B + 1), "n"(B + 2), "n"(B + 3), "n"(B + 4), "n"(B + 5),
                    "n"(B + 6), "n"(B + 7));
@@ -1183,6 +1183,76 @@ __device__ __forceinline__ void sum16_bcast(double &S, const double &src, const 
 }
 
 __device__ __forceinline__ double gauss_exp_block(double x, double cn); // (below: cn * exp_nonpos(x), one block)
+
+// First maximum of eight NaN-free non-negative candidates (`later > earlier`, strict: _hidden.c:186-200), as ONE
+// block: value in h[0], index BASE + position in iw.  Compares into scalar pairs, v_max_f64 for the values,
+// v_cndmask for the indices, ordered so that every select finds its mask two wait states old -- 22 instructions,
+// one of them an s_nop; the compiler's tree takes 21 plus seven s_nop.  h[2], h[4], h[6] are destroyed.
+template <int BASE>
+__device__ __forceinline__ void argmax_oct_const(double (&h)[8], int &iw)
+{
+    int i1, i2, i3;
+    unsigned long long s0, s1, s2, s3;
+    asm("v_cmp_gt_f64 %[s0], %[h1], %[h0]\n\t"
+        "v_cmp_gt_f64 %[s1], %[h3], %[h2]\n\t"
+        "v_cmp_gt_f64 %[s2], %[h5], %[h4]\n\t"
+        "v_cmp_gt_f64 %[s3], %[h7], %[h6]\n\t"
+        "v_max_f64 %[h0], %[h0], %[h1]\n\t"
+        "v_max_f64 %[h2], %[h2], %[h3]\n\t"
+        "v_max_f64 %[h4], %[h4], %[h5]\n\t"
+        "v_max_f64 %[h6], %[h6], %[h7]\n\t"
+        "v_cndmask_b32_e64 %[i0], %[c0], %[c1], %[s0]\n\t"
+        "v_cndmask_b32_e64 %[i1], %[c2], %[c3], %[s1]\n\t"
+        "v_cndmask_b32_e64 %[i2], %[c4], %[c5], %[s2]\n\t"
+        "v_cndmask_b32_e64 %[i3], %[c6], %[c7], %[s3]\n\t"
+        "v_cmp_gt_f64 %[s0], %[h2], %[h0]\n\t"
+        "v_cmp_gt_f64 %[s1], %[h6], %[h4]\n\t"
+        "v_max_f64 %[h0], %[h0], %[h2]\n\t"
+        "v_max_f64 %[h4], %[h4], %[h6]\n\t"
+        "v_cndmask_b32_e64 %[i0], %[i0], %[i1], %[s0]\n\t"
+        "v_cndmask_b32_e64 %[i2], %[i2], %[i3], %[s1]\n\t"
+        "v_cmp_gt_f64 %[s0], %[h4], %[h0]\n\t"
+        "v_max_f64 %[h0], %[h0], %[h4]\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_e64 %[i0], %[i0], %[i2], %[s0]"
+        : [h0] "+v"(h[0]), [h2] "+v"(h[2]), [h4] "+v"(h[4]), [h6] "+v"(h[6]), [i0] "=&v"(iw), [i1] "=&v"(i1),
+          [i2] "=&v"(i2), [i3] "=&v"(i3), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3)
+        : [h1] "v"(h[1]), [h3] "v"(h[3]), [h5] "v"(h[5]), [h7] "v"(h[7]), [c0] "n"(BASE), [c1] "n"(BASE + 1),
+          [c2] "n"(BASE + 2), [c3] "n"(BASE + 3), [c4] "n"(BASE + 4), [c5] "n"(BASE + 5), [c6] "n"(BASE + 6),
+          [c7] "n"(BASE + 7));
+}
+// the same tree over eight (value, index) pairs -- the winners of eight argmax_oct_const blocks, in index order
+__device__ __forceinline__ void argmax_oct_regs(double (&h)[8], const int (&ii)[8], int &iw)
+{
+    int i1, i2, i3;
+    unsigned long long s0, s1, s2, s3;
+    asm("v_cmp_gt_f64 %[s0], %[h1], %[h0]\n\t"
+        "v_cmp_gt_f64 %[s1], %[h3], %[h2]\n\t"
+        "v_cmp_gt_f64 %[s2], %[h5], %[h4]\n\t"
+        "v_cmp_gt_f64 %[s3], %[h7], %[h6]\n\t"
+        "v_max_f64 %[h0], %[h0], %[h1]\n\t"
+        "v_max_f64 %[h2], %[h2], %[h3]\n\t"
+        "v_max_f64 %[h4], %[h4], %[h5]\n\t"
+        "v_max_f64 %[h6], %[h6], %[h7]\n\t"
+        "v_cndmask_b32_e64 %[i0], %[c0], %[c1], %[s0]\n\t"
+        "v_cndmask_b32_e64 %[i1], %[c2], %[c3], %[s1]\n\t"
+        "v_cndmask_b32_e64 %[i2], %[c4], %[c5], %[s2]\n\t"
+        "v_cndmask_b32_e64 %[i3], %[c6], %[c7], %[s3]\n\t"
+        "v_cmp_gt_f64 %[s0], %[h2], %[h0]\n\t"
+        "v_cmp_gt_f64 %[s1], %[h6], %[h4]\n\t"
+        "v_max_f64 %[h0], %[h0], %[h2]\n\t"
+        "v_max_f64 %[h4], %[h4], %[h6]\n\t"
+        "v_cndmask_b32_e64 %[i0], %[i0], %[i1], %[s0]\n\t"
+        "v_cndmask_b32_e64 %[i2], %[i2], %[i3], %[s1]\n\t"
+        "v_cmp_gt_f64 %[s0], %[h4], %[h0]\n\t"
+        "v_max_f64 %[h0], %[h0], %[h4]\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_e64 %[i0], %[i0], %[i2], %[s0]"
+        : [h0] "+v"(h[0]), [h2] "+v"(h[2]), [h4] "+v"(h[4]), [h6] "+v"(h[6]), [i0] "=&v"(iw), [i1] "=&v"(i1),
+          [i2] "=&v"(i2), [i3] "=&v"(i3), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3)
+        : [h1] "v"(h[1]), [h3] "v"(h[3]), [h5] "v"(h[5]), [h7] "v"(h[7]), [c0] "v"(ii[0]), [c1] "v"(ii[1]),
+          [c2] "v"(ii[2]), [c3] "v"(ii[3]), [c4] "v"(ii[4]), [c5] "v"(ii[5]), [c6] "v"(ii[6]), [c7] "v"(ii[7]));
+}
 
 constexpr int WVS_WPB = 4;
 #ifndef WVS_LDS_ROWS
@@ -1322,8 +1392,48 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
                     bi = take ? ii[0] : bi;
                 }
             };
+            // (round 6) NaN-free form, eight candidates per assembly block (argmax_oct): the compiler's tree pays a
+            // wait-state s_nop between every compare and the select that reads its mask -- 63 issue slots per step
+            auto argmax_rows_blocks = [&]() __attribute__((always_inline)) {
+                double wh[8];
+                int wi[8];
+                static_for<NP / 8>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q8 = decltype(qc)::value, k = q8 / 2, o = q8 % 2;
+                    double hh[8];
+                    if constexpr (NP == 64 && k >= NP / 16 - WVS_LDS_ROWS) {
+#pragma unroll
+                        for (int q = 0; q < 8; q += 2) {
+                            const double2 y = *reinterpret_cast<const double2 *>(&xv[w][gi][8 * q8 + q]);
+                            hh[q] = y.x * Acol[8 * q8 + q];
+                            hh[q + 1] = y.y * Acol[8 * q8 + q + 1];
+                        }
+                    } else {
+                        auto wk = [&](auto ic) __attribute__((always_inline)) { return Acol[16 * k + decltype(ic)::value]; };
+                        asm volatile("s_nop 1"); // (a DPP read needs two wait states after the write of its register)
+                        prod8_bcast<8 * o, 0, 8>(hh, R.r[k], wk);
+                    }
+                    argmax_oct_const<8 * q8>(hh, wi[q8]);
+                    wh[q8] = hh[0];
+                });
+                if constexpr (NP == 16) {
+                    const bool take = wh[1] > wh[0];
+                    bh = take ? wh[1] : wh[0];
+                    bi = take ? wi[1] : wi[0];
+                } else if constexpr (NP == 32) {
+                    bh = wh[0], bi = wi[0];
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) {
+                        const bool take = wh[q] > bh;
+                        bh = take ? wh[q] : bh;
+                        bi = take ? wi[q] : bi;
+                    }
+                } else {
+                    argmax_oct_regs(wh, wi, bi);
+                    bh = wh[0];
+                }
+            };
             if (__ballot(v != v) == 0ull) // (wave-uniform; v is NaN-free, A is, so are the products)
-                argmax_rows(std::true_type{});
+                argmax_rows_blocks();
             else
                 argmax_rows(std::false_type{});
             if (real && t >= t0)
