@@ -1272,7 +1272,10 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     constexpr int GP = 64 / NP;
     __shared__ __attribute__((aligned(16))) double xv[WVS_WPB][GP][NP];
     __shared__ double sA[NP * NP];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (64 states: one segment per wavefront -- told to the compiler, so that the step counter, the segment's bounds
+    // and every test on them live in scalar registers instead of 64-bit vector compares and exec-mask branches)
+    const int w = NP == 64 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int gi = lane / NP, j = lane % NP;
     const int n = m.n;
     for (int e = threadIdx.x; e < NP * NP; e += 64 * WVS_WPB)
@@ -1296,9 +1299,16 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     const double rs_j = 1.0 / sg_j; // correctly rounded: IEEE division
     const double cn_j = (KIND == EMIT_GAUSS && real) ? m.cnorm[j] : 0.0; // (0 on padding lanes)
     const double pi_j = real ? m.pi[j] : 0.0;
-    const int k = sg.traj[sgi];
-    const int64_t o0 = off[k], T = off[k + 1] - o0;
-    const int64_t t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+    auto uni = [](int64_t x) __attribute__((always_inline)) { // (NP == 64: the same in every lane; say so)
+        if constexpr (NP == 64)
+            return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)x >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x));
+        else
+            return x;
+    };
+    const int k = (int)uni(sg.traj[sgi]);
+    const int64_t o0 = uni(off[k]), T = uni(off[k + 1]) - o0;
+    const int64_t t0 = uni(sg.t0[sgi]), t1 = t0 + uni(sg.len[sgi]);
     const int64_t tw = FIX ? t0 : ((t0 - sg.W > 0) ? t0 - sg.W : 0);
     auto emis = [&](int64_t gt) __attribute__((always_inline)) {
         double p;
@@ -1327,12 +1337,16 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
         xv[w][gi][j] = v; // (LDS copy of v for the upper candidate rows of the next step)
     double p_next = emis(o0 + tw);
     bool met = false; // FIX: the run reproduced a vector of the first pass
-    for (int64_t t = tw; t < t1; ++t) {
+    // (the step as a 32-bit count from the first one: 64-bit compares are vector instructions even on scalars)
+    const int nst = (int)(t1 - tw), r0 = (int)(t0 - tw), rz = tw == 0 ? 0 : -1;
+    const int ph = (int)((o0 + tw) & 63);
+    for (int r = 0; r < nst; ++r) {
+        const int64_t t = tw + r;
         const double p = p_next;
-        if (t + 1 < t1)
+        if (r + 1 < nst)
             p_next = emis(o0 + t + 1); // independent of the recursion
         double vn;
-        if (t == 0) {
+        if (r == rz) { // t == 0
             vn = p * pi_j; // _hidden.c:232
         } else {
             // Every lane needs every element of v: row copies (permlane swaps) and the DPP form
@@ -1436,7 +1450,7 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
                 argmax_rows_blocks();
             else
                 argmax_rows(std::false_type{});
-            if (real && t >= t0)
+            if (real && r >= r0)
                 ptr[(o0 + t) * n + j] = (uint8_t)bi;
             const double bv = __shfl(v, bi, NP), bA = sA[bi * NP + j];
             vn = p * bv * bA; // _hidden.c:253: (p v[i^]) A[i^][j]
@@ -1455,12 +1469,12 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
         if constexpr (NP == 64 && WVS_LDS_ROWS > 0)
             xv[w][gi][j] = v; // (the next step's upper candidate rows read it from here)
         if constexpr (!FIX) {
-            if (t == t0 - 1)
+            if (r == r0 - 1)
                 v_entry[(int64_t)sgi * NP + j] = v;
         }
-        if (vall && real && t >= t0) // (every vector of the first pass / of a mended stretch, [total][n]: k_vit_margin)
+        if (vall && real && r >= r0) // (every vector of the first pass / of a mended stretch, [total][n]: k_vit_margin)
             vall[(o0 + t) * n + j] = v;
-        if (((o0 + t) & 63) == 63 && t >= t0) {
+        if (((ph + r) & 63) == 63 && r >= r0) {
             double *cp = ckpt + ((o0 + t) >> 6) * NP + j;
             if constexpr (FIX) {
                 const double cv = *cp;
