@@ -1182,6 +1182,80 @@ __device__ __forceinline__ void sum16_bcast(double &S, const double &src, const 
                  : "v"(src), "v"(one));
 }
 
+// the four rows of a 64-state vector in one block (one leading wait instead of one per row and the compiler's
+// protective s_nop between the blocks)
+__device__ __forceinline__ void sum64_bcast(double &S, const double &r0, const double &r1, const double &r2,
+                                            const double &r3, const double &one)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %1, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %2, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                 : "+v"(S)
+                 : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(one));
+}
+
 __device__ __forceinline__ double gauss_exp_block(double x, double cn); // (below: cn * exp_nonpos(x), one block)
 
 // First maximum of eight NaN-free non-negative candidates (`later > earlier`, strict: _hidden.c:186-200), as ONE
@@ -1221,6 +1295,86 @@ __device__ __forceinline__ void argmax_oct_const(double (&h)[8], int &iw)
           [c2] "n"(BASE + 2), [c3] "n"(BASE + 3), [c4] "n"(BASE + 4), [c5] "n"(BASE + 5), [c6] "n"(BASE + 6),
           [c7] "n"(BASE + 7));
 }
+// The products feeding such a tree IN the block (one block = eight candidates end to end: the compiler pads the seam
+// between two blocks with s_nop, and loads consumed by one block need one s_waitcnt instead of one per load).
+#define BHMM_OCT_TREE                                                                              \
+    "v_cmp_gt_f64 %[s0], %[h1], %[h0]\n\t"                                                         \
+    "v_cmp_gt_f64 %[s1], %[h3], %[h2]\n\t"                                                         \
+    "v_max_f64 %[h0], %[h0], %[h1]\n\t"                                                            \
+    "v_max_f64 %[h2], %[h2], %[h3]\n\t"                                                            \
+    "v_cndmask_b32_e64 %[i0], %[ib], %[ib]+1, %[s0]\n\t"                                           \
+    "v_cndmask_b32_e64 %[i1], %[ib]+2, %[ib]+3, %[s1]\n\t"                                         \
+    "v_cmp_gt_f64 %[s0], %[h5], %[h4]\n\t"                                                         \
+    "v_cmp_gt_f64 %[s1], %[h7], %[h6]\n\t"                                                         \
+    "v_max_f64 %[h4], %[h4], %[h5]\n\t"                                                            \
+    "v_max_f64 %[h6], %[h6], %[h7]\n\t"                                                            \
+    "v_cndmask_b32_e64 %[i2], %[ib]+4, %[ib]+5, %[s0]\n\t"                                         \
+    "v_cndmask_b32_e64 %[i3], %[ib]+6, %[ib]+7, %[s1]\n\t"                                         \
+    "v_cmp_gt_f64 %[s0], %[h2], %[h0]\n\t"                                                         \
+    "v_cmp_gt_f64 %[s1], %[h6], %[h4]\n\t"                                                         \
+    "v_max_f64 %[h0], %[h0], %[h2]\n\t"                                                            \
+    "v_max_f64 %[h4], %[h4], %[h6]\n\t"                                                            \
+    "v_cndmask_b32_e64 %[i0], %[i0], %[i1], %[s0]\n\t"                                             \
+    "v_cndmask_b32_e64 %[i2], %[i2], %[i3], %[s1]\n\t"                                             \
+    "v_cmp_gt_f64 %[s0], %[h4], %[h0]\n\t"                                                         \
+    "v_max_f64 %[h0], %[h0], %[h4]\n\t"                                                            \
+    "s_nop 0\n\t"                                                                                  \
+    "v_cndmask_b32_e64 %[i0], %[i0], %[i2], %[s0]"
+// candidates v[i] * a[i] with v from its LDS copy (y[0..7], already loaded): value of the first maximum in hw
+template <int IB>
+__device__ __forceinline__ void argmax_oct_mul(const double (&y)[8], const double *a, double &hw, int &iw)
+{
+    double h1, h2, h3, h4, h5, h6, h7;
+    int i1, i2, i3;
+    unsigned long long s0, s1;
+    asm("v_mul_f64 %[h0], %[y0], %[a0]\n\t"
+        "v_mul_f64 %[h1], %[y1], %[a1]\n\t"
+        "v_mul_f64 %[h2], %[y2], %[a2]\n\t"
+        "v_mul_f64 %[h3], %[y3], %[a3]\n\t"
+        "v_mul_f64 %[h4], %[y4], %[a4]\n\t"
+        "v_mul_f64 %[h5], %[y5], %[a5]\n\t"
+        "v_mul_f64 %[h6], %[y6], %[a6]\n\t"
+        "v_mul_f64 %[h7], %[y7], %[a7]\n\t" BHMM_OCT_TREE
+        : [h0] "=&v"(hw), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3), [h4] "=&v"(h4), [h5] "=&v"(h5),
+          [h6] "=&v"(h6), [h7] "=&v"(h7), [i0] "=&v"(iw), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3),
+          [s0] "=&s"(s0), [s1] "=&s"(s1)
+        : [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]), [y4] "v"(y[4]), [y5] "v"(y[5]),
+          [y6] "v"(y[6]), [y7] "v"(y[7]), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]),
+          [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]), [ib] "n"(IB));
+}
+// candidates fma(v[16 ROW + LB + i] broadcast within the row, a[i], 0) with v given as its row copy `src`
+// (LEAD: `src` was written by the instruction before -- a DPP read needs two wait states)
+template <int IB, int LB, bool LEAD>
+__device__ __forceinline__ void argmax_oct_bcast(const double &src, const double *a, double &hw, int &iw)
+{
+    double h1, h2, h3, h4, h5, h6, h7;
+    int i1, i2, i3;
+    unsigned long long s0, s1;
+#define BHMM_OCT_BCAST                                                                                 \
+    "v_mov_b64 %[h0], 0\n\tv_mov_b64 %[h1], 0\n\tv_mov_b64 %[h2], 0\n\tv_mov_b64 %[h3], 0\n\t"         \
+    "v_mov_b64 %[h4], 0\n\tv_mov_b64 %[h5], 0\n\tv_mov_b64 %[h6], 0\n\tv_mov_b64 %[h7], 0\n\t"         \
+    "v_fmac_f64_dpp %[h0], %[src], %[a0] row_newbcast:%[lb] row_mask:0xf bank_mask:0xf\n\t"            \
+    "v_fmac_f64_dpp %[h1], %[src], %[a1] row_newbcast:%[lb]+1 row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_fmac_f64_dpp %[h2], %[src], %[a2] row_newbcast:%[lb]+2 row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_fmac_f64_dpp %[h3], %[src], %[a3] row_newbcast:%[lb]+3 row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_fmac_f64_dpp %[h4], %[src], %[a4] row_newbcast:%[lb]+4 row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_fmac_f64_dpp %[h5], %[src], %[a5] row_newbcast:%[lb]+5 row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_fmac_f64_dpp %[h6], %[src], %[a6] row_newbcast:%[lb]+6 row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_fmac_f64_dpp %[h7], %[src], %[a7] row_newbcast:%[lb]+7 row_mask:0xf bank_mask:0xf\n\t" BHMM_OCT_TREE
+#define BHMM_OCT_BCAST_OPS                                                                             \
+    : [h0] "=&v"(hw), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3), [h4] "=&v"(h4), [h5] "=&v"(h5),  \
+      [h6] "=&v"(h6), [h7] "=&v"(h7), [i0] "=&v"(iw), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3),  \
+      [s0] "=&s"(s0), [s1] "=&s"(s1)                                                                   \
+    : [src] "v"(src), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]),  \
+      [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]), [ib] "n"(IB), [lb] "n"(LB)
+    if constexpr (LEAD)
+        asm volatile("s_nop 1\n\t" BHMM_OCT_BCAST BHMM_OCT_BCAST_OPS);
+    else
+        asm volatile(BHMM_OCT_BCAST BHMM_OCT_BCAST_OPS);
+#undef BHMM_OCT_BCAST
+#undef BHMM_OCT_BCAST_OPS
+}
+#undef BHMM_OCT_TREE
 // the same tree over eight (value, index) pairs -- the winners of eight argmax_oct_const blocks, in index order
 __device__ __forceinline__ void argmax_oct_regs(double (&h)[8], const int (&ii)[8], int &iw)
 {
@@ -1411,23 +1565,33 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
             auto argmax_rows_blocks = [&]() __attribute__((always_inline)) {
                 double wh[8];
                 int wi[8];
+                // (the LDS copies one block of eight ahead of their products: one wait per block instead of four)
+                double2 ypre[2][4];
+                auto from_lds = [](int q8) { return NP == 64 && q8 < NP / 8 && q8 / 2 >= NP / 16 - WVS_LDS_ROWS; };
+                auto prefetch = [&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q8 = decltype(qc)::value;
+                    if constexpr (NP == 64 && q8 < NP / 8 && q8 / 2 >= NP / 16 - WVS_LDS_ROWS) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            ypre[q8 & 1][q] = *reinterpret_cast<const double2 *>(&xv[w][gi][8 * q8 + 2 * q]);
+                    }
+                };
+                (void)from_lds;
+                prefetch(std::integral_constant<int, 0>{});
                 static_for<NP / 8>([&](auto qc) __attribute__((always_inline)) {
                     constexpr int q8 = decltype(qc)::value, k = q8 / 2, o = q8 % 2;
-                    double hh[8];
+                    prefetch(std::integral_constant<int, q8 + 1>{});
+                    if constexpr (NP == 64 && q8 + 1 < NP / 8 && (q8 + 1) / 2 >= NP / 16 - WVS_LDS_ROWS)
+                        __builtin_amdgcn_sched_barrier(0); // (or the loads sink to their use, below this block)
                     if constexpr (NP == 64 && k >= NP / 16 - WVS_LDS_ROWS) {
+                        double y[8];
 #pragma unroll
-                        for (int q = 0; q < 8; q += 2) {
-                            const double2 y = *reinterpret_cast<const double2 *>(&xv[w][gi][8 * q8 + q]);
-                            hh[q] = y.x * Acol[8 * q8 + q];
-                            hh[q + 1] = y.y * Acol[8 * q8 + q + 1];
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            y[2 * q] = ypre[q8 & 1][q].x, y[2 * q + 1] = ypre[q8 & 1][q].y;
+                        argmax_oct_mul<8 * q8>(y, &Acol[8 * q8], wh[q8], wi[q8]);
                     } else {
-                        auto wk = [&](auto ic) __attribute__((always_inline)) { return Acol[16 * k + decltype(ic)::value]; };
-                        asm volatile("s_nop 1"); // (a DPP read needs two wait states after the write of its register)
-                        prod8_bcast<8 * o, 0, 8>(hh, R.r[k], wk);
+                        argmax_oct_bcast<8 * q8, 8 * o, o == 0>(R.r[k], &Acol[8 * q8], wh[q8], wi[q8]);
                     }
-                    argmax_oct_const<8 * q8>(hh, wi[q8]);
-                    wh[q8] = hh[0];
                 });
                 if constexpr (NP == 16) {
                     const bool take = wh[1] > wh[0];
@@ -1461,9 +1625,13 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
         {
             const Rows4 Rn = rows_of_group<NP>(vn);
             const double one = 1.0;
+            if constexpr (NP == 64) {
+                sum64_bcast(S, Rn.r[0], Rn.r[1], Rn.r[2], Rn.r[3], one);
+            } else {
 #pragma unroll
-            for (int k = 0; k < NP / 16; ++k)
-                sum16_bcast(S, Rn.r[k], one);
+                for (int k = 0; k < NP / 16; ++k)
+                    sum16_bcast(S, Rn.r[k], one);
+            }
         }
         v = vn / S;
         if constexpr (NP == 64 && WVS_LDS_ROWS > 0)
