@@ -1410,7 +1410,7 @@ __device__ __forceinline__ void argmax_oct_regs(double (&h)[8], const int (&ii)[
 
 constexpr int WVS_WPB = 4;
 #ifndef WVS_LDS_ROWS
-#define WVS_LDS_ROWS 3 // 64 states: rows of 16 candidates whose v comes from LDS (0 .. 4; measured: DESIGN.md section 5)
+#define WVS_LDS_ROWS 4 // 64 states: rows of 16 candidates whose v comes from LDS (0 .. 4; measured: DESIGN.md section 4)
 #endif
 template <int NP, int KIND, bool FIX>
 __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
@@ -1497,6 +1497,20 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     for (int r = 0; r < nst; ++r) {
         const int64_t t = tw + r;
         const double p = p_next;
+        // (the LDS copies of v two blocks of eight candidates ahead of their products: one wait per block)
+        double2 ypre[2][4];
+        auto prefetch = [&](auto qc) __attribute__((always_inline)) {
+            constexpr int q8 = decltype(qc)::value;
+            if constexpr (NP == 64 && q8 < NP / 8 && q8 / 2 >= NP / 16 - WVS_LDS_ROWS) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ypre[q8 & 1][q] = *reinterpret_cast<const double2 *>(&xv[w][gi][8 * q8 + 2 * q]);
+            }
+        };
+        if constexpr (NP == 64 && WVS_LDS_ROWS == 4) { // (the first block's before the density: nothing else covers them)
+            prefetch(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (r + 1 < nst)
             p_next = emis(o0 + t + 1); // independent of the recursion
         double vn;
@@ -1565,19 +1579,8 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
             auto argmax_rows_blocks = [&]() __attribute__((always_inline)) {
                 double wh[8];
                 int wi[8];
-                // (the LDS copies one block of eight ahead of their products: one wait per block instead of four)
-                double2 ypre[2][4];
-                auto from_lds = [](int q8) { return NP == 64 && q8 < NP / 8 && q8 / 2 >= NP / 16 - WVS_LDS_ROWS; };
-                auto prefetch = [&](auto qc) __attribute__((always_inline)) {
-                    constexpr int q8 = decltype(qc)::value;
-                    if constexpr (NP == 64 && q8 < NP / 8 && q8 / 2 >= NP / 16 - WVS_LDS_ROWS) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            ypre[q8 & 1][q] = *reinterpret_cast<const double2 *>(&xv[w][gi][8 * q8 + 2 * q]);
-                    }
-                };
-                (void)from_lds;
-                prefetch(std::integral_constant<int, 0>{});
+                if constexpr (WVS_LDS_ROWS < 4)
+                    prefetch(std::integral_constant<int, 0>{});
                 static_for<NP / 8>([&](auto qc) __attribute__((always_inline)) {
                     constexpr int q8 = decltype(qc)::value, k = q8 / 2, o = q8 % 2;
                     prefetch(std::integral_constant<int, q8 + 1>{});
@@ -1616,7 +1619,13 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
                 argmax_rows(std::false_type{});
             if (real && r >= r0)
                 ptr[(o0 + t) * n + j] = (uint8_t)bi;
-            const double bv = __shfl(v, bi, NP), bA = sA[bi * NP + j];
+            // (64 states: v[i^] from the LDS copy of v -- one read instead of two lane permutes and their index)
+            double bv;
+            if constexpr (NP == 64 && WVS_LDS_ROWS > 0)
+                bv = xv[w][gi][bi];
+            else
+                bv = __shfl(v, bi, NP);
+            const double bA = sA[bi * NP + j];
             vn = p * bv * bA; // _hidden.c:253: (p v[i^]) A[i^][j]
         }
         // the normalising sum in ascending order (_hidden.c:256-259), S = fma(vn[i], 1, S) = S + vn[i]
