@@ -935,6 +935,9 @@ def main():
     if args.only == "c3":
         result.emit(json.dumps({"configs3_64_states": secondary_c4(torch, dev, local, args)}))
         return
+    if args.only == "gen":
+        result.emit(json.dumps({"more_than_64_states": secondary_gen(torch, dev, local, args)}))
+        return
     if args.only == "shard":   # the E-step part of the 8-GPU projection alone (rank 0's shard, 1-rank RCCL all-reduce)
         result.emit(json.dumps({"projected_8gpu": projected_8gpu(torch, dev, local, stream, args, float("nan"), None, None)}))
         return

@@ -1340,7 +1340,9 @@ __device__ __forceinline__ void argmax_oct_mul(const double (&y)[8], const doubl
           [s0] "=&s"(s0), [s1] "=&s"(s1)
         : [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]), [y4] "v"(y[4]), [y5] "v"(y[5]),
           [y6] "v"(y[6]), [y7] "v"(y[7]), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]),
-          [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]), [ib] "n"(IB));
+          [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]), [ib] "n"(IB + 7 <= 64 ? IB : 0));
+    if constexpr (IB + 7 > 64) // (not an inline constant any more: the position, then the base)
+        iw += IB;
 }
 // candidates fma(v[16 ROW + LB + i] broadcast within the row, a[i], 0) with v given as its row copy `src`
 // (LEAD: `src` was written by the instruction before -- a DPP read needs two wait states)
@@ -1366,11 +1368,13 @@ __device__ __forceinline__ void argmax_oct_bcast(const double &src, const double
       [h6] "=&v"(h6), [h7] "=&v"(h7), [i0] "=&v"(iw), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3),  \
       [s0] "=&s"(s0), [s1] "=&s"(s1)                                                                   \
     : [src] "v"(src), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]),  \
-      [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]), [ib] "n"(IB), [lb] "n"(LB)
+      [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]), [ib] "n"(IB + 7 <= 64 ? IB : 0), [lb] "n"(LB)
     if constexpr (LEAD)
         asm volatile("s_nop 1\n\t" BHMM_OCT_BCAST BHMM_OCT_BCAST_OPS);
     else
         asm volatile(BHMM_OCT_BCAST BHMM_OCT_BCAST_OPS);
+    if constexpr (IB + 7 > 64) // (not an inline constant any more: the position, then the base)
+        iw += IB;
 #undef BHMM_OCT_BCAST
 #undef BHMM_OCT_BCAST_OPS
 }
@@ -2727,7 +2731,9 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
     __shared__ __attribute__((aligned(16))) double xs[WVS_WPB][GP][NP];
     __shared__ __attribute__((aligned(16))) double xp[WVS_WPB][GP][NP];
     __shared__ double sAT[NP * NP];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (64 states: one segment per wavefront -- bounds, step count and the step's uniform in scalar registers)
+    const int w = NP == 64 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int gi = lane / NP, i = lane % NP;
     const int n = m.n;
     for (int e = threadIdx.x; e < NP * NP; e += 64 * WVS_WPB) // sAT[nxt][i] = A[i][nxt]
@@ -2742,22 +2748,53 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
     }
     const bool real = i < n;
     const unsigned long long gmask = wgroup_mask<NP>(lane);
-    const int k = sg.traj[sgi];
-    const int64_t o0 = off[k], T = off[k + 1] - o0;
-    const int64_t s0 = soff ? soff[k] : o0; // position of this trajectory in the random stream
-    const int64_t t0 = sg.t0[sgi], t1 = t0 + sg.len[sgi];
+    auto uni = [](int64_t x) __attribute__((always_inline)) { // (NP == 64: the same in every lane; say so)
+        if constexpr (NP == 64)
+            return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)x >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x));
+        else
+            return x;
+    };
+    const int k = (int)uni(sg.traj[sgi]);
+    const int64_t o0 = uni(off[k]), T = uni(off[k + 1]) - o0;
+    const int64_t s0 = soff ? uni(soff[k]) : o0; // position of this trajectory in the random stream
+    const int64_t t0 = uni(sg.t0[sgi]), t1 = t0 + uni(sg.len[sgi]);
     const int64_t ts = FIX ? t1 - 1 : ((t1 + sg.W < T ? t1 + sg.W : T) - 1);
     int nxt = FIX ? s_entry[sgi] : 0;
-    double a_next = real ? alpha_rm[(o0 + ts) * n + i] : 0.0;
+    if constexpr (NP == 64)
+        nxt = __builtin_amdgcn_readfirstlane(nxt);
+    const int ic = real ? i : n - 1; // (padded lanes read a real entry and ignore it)
     bool met = false;
-    for (int64_t t = ts; t >= t0; --t) {
-        const double a = a_next;
-        if (t > t0)
-            a_next = real ? alpha_rm[(o0 + t - 1) * n + i] : 0.0; // independent of the draw
-        double ps = a;
-        if (t != T - 1)
-            ps = a * sAT[nxt * NP + i]; // _hidden.c:365 (padded states: 0 * 0)
-        const double r = u ? u[o0 + t] : uniform01(seed, (uint64_t)(s0 + t));
+    // NP == 64, first pass: the drawn states of 64 steps in one register (lane l: step c0 + l), one coalesced
+    // store per 64 steps -- a store per step keeps every wait of the loop waiting for it (one counter for loads and
+    // stores), which is what made the ring useless when it was tried before
+    constexpr bool PACKED_STORE = NP == 64 && !FIX;
+    int pvec = 0;
+    // (the step as a 32-bit count c = ts - t: 64-bit compares are vector instructions even on scalars)
+    const int nst = (int)(ts - t0) + 1;                     // steps of this run
+    const int cT = ts == T - 1 ? 0 : -1;                    // c of the trajectory's last step, if the run has it
+    const int c1 = (int)(ts - t1);                          // c of step t1 (the one above the segment; -1: none)
+    double rlane = 0.0; // NP == 64: lane l holds the uniform of step c0 + l, 64 steps at a time
+    auto weight = [&](const int c, const double a) __attribute__((always_inline)) {
+        return c != cT ? a * sAT[nxt * NP + i] : a; // _hidden.c:365 (padded states: 0 * 0)
+    };
+    auto step = [&](const int c, const double ps) __attribute__((always_inline)) {
+        const int64_t t = ts - c;
+        double r;
+        if constexpr (NP == 64) {
+            // (every lane computing the same counter-based uniform every step was 30 of the step's instructions)
+            if ((c & 63) == 0) {
+                const int64_t tl = t - lane;
+                rlane = tl >= t0 ? (u ? u[o0 + tl] : uniform01(seed, (uint64_t)(s0 + tl))) : 0.0;
+                // (waited for HERE, once in 64 steps: left pending, the load makes the read of rlane below a wait
+                // for everything in flight -- the ring of alpha rows included -- in every step)
+                asm volatile("" : "+v"(rlane));
+            }
+            r = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rlane), c & 63),
+                                 __builtin_amdgcn_readlane(__double2loint(rlane), c & 63));
+        } else {
+            r = u ? u[o0 + t] : uniform01(seed, (uint64_t)(s0 + t));
+        }
         int pick = NP;
         bool watched = false;
         {
@@ -2811,26 +2848,72 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_sample_seg(
             }
         }
         if (pick >= n) { // (a padded state's sum is the last real one's: it would have been drawn there)
-            if (i == 0 && t < t1)
+            if (i == 0 && c > c1)
                 status[0] = BHMM_ERR_CHOICE;
             pick = n - 1;
-        } else if (__builtin_expect(watched && i == 0 && t < t1, 0)) {
+        } else if (__builtin_expect(watched && i == 0 && c > c1, 0)) {
             draw_record(watch, k, t, nxt, r, pick, -1.0);
         }
         nxt = pick;
         if constexpr (!FIX) {
-            if (t == t1 && i == 0)
+            if (c == c1 && i == 0)
                 s_entry[sgi] = pick;
         }
-        if (t < t1) {
+        if (c > c1) { // t < t1
             if constexpr (FIX) {
                 if (path[o0 + t] == pick) {
                     met = true;
-                    break;
+                    return;
                 }
             }
-            if (i == 0)
-                path[o0 + t] = pick;
+            if constexpr (PACKED_STORE) {
+                // c - c1 - 1 = 0, 1, ... counts the segment's own steps from its last one down
+                const int cs = c - c1 - 1;
+                pvec = lane == (cs & 63) ? pick : pvec;
+                if ((cs & 63) == 63 || c == nst - 1) { // (64 collected, or the segment's first step)
+                    const int64_t tl = t + (cs & 63) - lane; // lane l holds the step l below the block's top
+                    if (lane <= (cs & 63))
+                        path[o0 + tl] = pvec;
+                }
+            } else {
+                if (i == 0)
+                    path[o0 + t] = pick;
+            }
+        }
+    };
+    if constexpr (NP == 64 && !FIX) {
+        // alpha rows four steps ahead of their draw (a row arrives from HBM after 1 - 2 us, a step takes a fifth of
+        // that): a ring of four registers, the loop unrolled by four so that every slot has a name.  Every load is
+        // issued unconditionally (beyond the run at a clamped step): with a load under a branch the compiler's wait
+        // counts must assume it was not issued, and every wait becomes a wait for the newest load.
+        constexpr int RING = 4;
+        double ar[RING];
+#pragma unroll
+        for (int q = 0; q < RING; ++q)
+            ar[q] = alpha_rm[(o0 + (ts - q > t0 ? ts - q : t0)) * n + ic];
+        int cb = 0;
+        for (; cb + RING <= nst; cb += RING) {
+#pragma unroll
+            for (int q = 0; q < RING; ++q) {
+                const int64_t t = ts - (cb + q);
+                // (the row's last use before the slot is loaded again: the same register, no copy at the loop's end
+                // that would have to wait for the load)
+                const double ps = weight(cb + q, real ? ar[q] : 0.0);
+                ar[q] = alpha_rm[(o0 + (t - RING > t0 ? t - RING : t0)) * n + ic];
+                step(cb + q, ps);
+            }
+        }
+        for (int c = cb; c < nst; ++c) // (fewer than four steps left: their rows again, from the cache)
+            step(c, weight(c, real ? alpha_rm[(o0 + ts - c) * n + ic] : 0.0));
+    } else {
+        double a_next = alpha_rm[(o0 + ts) * n + ic];
+        for (int c = 0; c < nst; ++c) {
+            const double a = real ? a_next : 0.0;
+            if (c + 1 < nst)
+                a_next = alpha_rm[(o0 + ts - c - 1) * n + ic]; // independent of the draw
+            step(c, weight(c, a));
+            if (FIX && met)
+                break;
         }
     }
     if (!met && i == 0)
