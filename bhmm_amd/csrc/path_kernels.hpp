@@ -1468,6 +1468,7 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
     const int64_t o0 = uni(off[k]), T = uni(off[k + 1]) - o0;
     const int64_t t0 = uni(sg.t0[sgi]), t1 = t0 + uni(sg.len[sgi]);
     const int64_t tw = FIX ? t0 : ((t0 - sg.W > 0) ? t0 - sg.W : 0);
+    double olane = 0.0;
     auto emis = [&](int64_t gt) __attribute__((always_inline)) {
         double p;
         if constexpr (KIND == EMIT_GAUSS) {
@@ -1475,7 +1476,22 @@ __global__ __launch_bounds__(64 * WVS_WPB) void k_wide_viterbi_seg(
             // the correctly rounded reciprocal, constant and exponential as one block -- 27 instructions where
             // the division and the statement-wise exponential took 60 (round 4 measured the in-step density
             // slower than the emission-matrix pass with those; with these it is 0.7 ms against 1.9 at configs[3])
-            const double x = static_cast<const double *>(obs_rm)[gt] - mu_j;
+            double o;
+            if constexpr (NP == 64) {
+                // (round 6) the observations of 64 steps in one register (lane l: step 64 b + l of this run), one
+                // coalesced load per 64 steps, waited for where it is issued: a load per step is waited for in that
+                // step with vmcnt(0) -- the counter the stores of the vectors and back-pointers count in, too
+                const int rr = (int)(gt - (o0 + tw));
+                if ((rr & 63) == 0) {
+                    olane = tw + rr + lane < t1 ? static_cast<const double *>(obs_rm)[gt + lane] : 0.0;
+                    asm volatile("" : "+v"(olane));
+                }
+                o = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(olane), rr & 63),
+                                     __builtin_amdgcn_readlane(__double2loint(olane), rr & 63));
+            } else {
+                o = static_cast<const double *>(obs_rm)[gt];
+            }
+            const double x = o - mu_j;
             const double q0 = x * rs_j;
             const double d = fma(fma(-q0, sg_j, x), rs_j, q0); // == x / sigma
             p = gauss_exp_block(-0.5 * d * d, cn_j);
