@@ -235,18 +235,27 @@ int sample_run(bhmm_ctx *c, const double *A, const double *pi, const double *par
         const double *wsd = c->d_ws.p, *Btd = c->d_Bt.p;
         // fp32 copies of the alpha rows, if the forward pass that just ran wrote them
         const float *r32 = c->rows32_valid ? c->d_ws32.p : nullptr;
-        if (c->kind == EMIT_GAUSS)
-            hipLaunchKernelGGL((k_smp_maps<N, EMIT_GAUSS>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
-                               chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
-                               fmap, status, dmark, nib, W8, Gp64, gw, Lp, watch);
-        else if (c->kind == EMIT_DISC)
-            hipLaunchKernelGGL((k_smp_maps<N, EMIT_DISC>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
-                               chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
-                               fmap, status, dmark, nib, W8, Gp64, gw, Lp, watch);
-        else
-            hipLaunchKernelGGL((k_smp_maps<N, EMIT_EXPL>), dim3(nblk), dim3(BLOCK), 0, c->stream, m,
-                               chs, offd, soffd, wsd, r32, obs_ci, Btd, (const double *)udev, seed, P,
-                               fmap, status, dmark, nib, W8, Gp64, gw, Lp, watch);
+#define BHMM_SMP_MAPS(KINDV, R32V)                                                                         \
+    hipLaunchKernelGGL((k_smp_maps<N, KINDV, R32V>), dim3(nblk), dim3(BLOCK), 0, c->stream, m, chs, offd, soffd, \
+                       wsd, r32, obs_ci, Btd, (const double *)udev, seed, P, fmap, status, dmark, nib, W8, Gp64, \
+                       gw, Lp, watch)
+        if (c->kind == EMIT_GAUSS) {
+            if (r32)
+                BHMM_SMP_MAPS(EMIT_GAUSS, true);
+            else
+                BHMM_SMP_MAPS(EMIT_GAUSS, false);
+        } else if (c->kind == EMIT_DISC) {
+            if (r32)
+                BHMM_SMP_MAPS(EMIT_DISC, true);
+            else
+                BHMM_SMP_MAPS(EMIT_DISC, false);
+        } else {
+            if (r32)
+                BHMM_SMP_MAPS(EMIT_EXPL, true);
+            else
+                BHMM_SMP_MAPS(EMIT_EXPL, false);
+        }
+#undef BHMM_SMP_MAPS
         BHMM_HIP(hipGetLastError());
         if ((int64_t)c->G * P >= (int64_t)32 * K) // long chains: one wavefront per trajectory
             hipLaunchKernelGGL(k_smp_stitch, dim3(K), dim3(64), 0, c->stream,

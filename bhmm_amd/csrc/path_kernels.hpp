@@ -312,7 +312,9 @@ __device__ __forceinline__ int pick_clear(const double (&a)[N], const double *co
 // i.e. as before.  rows32 == nullptr: every fp64 row is in alpha_ci (the exact fallback pass of a
 // failed speculation wrote them) and is used directly.
 constexpr double SMP_TOL32 = 1e-6;
-template <int N, int KIND>
+// R32: the forward pass left fp32 rows (rows32 != nullptr) -- a template parameter, not a run-time test: with both
+// kinds of rows in one loop the ring below is a bundle of phi registers that every load is copied into at once
+template <int N, int KIND, bool R32>
 __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chunks ch,
                                                      const int64_t *off, const int64_t *soff,
                                                      const double *alpha_ci, const float *rows32,
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
     uint32_t *mygw = gw + ((int64_t)part * Lp) * Gp + g;
     // exact fp64 row of step s: the stored row at or below it, taken forward over the steps between
     auto exact_row = [&](int s, double (&a)[N]) {
-        const int cb = rows32 ? (s & ~(FWD_CKPT - 1)) : s;
+        const int cb = R32 ? (s & ~(FWD_CKPT - 1)) : s;
         ci_load<N>(alpha_ci, ci_rec(g, cb, ch.Lmax), lane, a);
 #pragma unroll 1
         for (int q = cb + 1; q <= s; ++q) {
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
             ring[q][0] = p32[0];
         }
     };
-    if (rows32 && nst > 0) {
+    if (R32 && nst > 0) {
 #pragma unroll
         for (int q = 0; q < SMP_MPF; ++q)
             fetch32(q, q);
@@ -406,12 +408,18 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
             break;
         const int s = s_hi - 1 - j;
         double a[N];
-        if (rows32) {
+        if constexpr (R32) {
 #pragma unroll
             for (int e = 0; e < NF; ++e) {
                 a[2 * e] = ring[qq][e].x;
                 a[2 * e + 1] = ring[qq][e].y;
             }
+            // (the slot's last use BEFORE it is requested again: scheduled the other way round, the request lands in
+            // other registers and is waited for at once to be copied into the slot -- no load-ahead at all)
+#pragma unroll
+            for (int e = 0; e < N; ++e)
+                asm volatile("" : "+v"(a[e]));
+            __builtin_amdgcn_sched_barrier(0);
             fetch32(qq, j + SMP_MPF);
         } else {
             ci_load<N>(alpha_ci, ci_rec(g, s, ch.Lmax), lane, a);
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
             alive = 1u; // the draw does not depend on a next state (_hidden.c:347-355)
         const bool one = (alive & (alive - 1)) == 0;
         uint32_t G = 0;
-        bool clear = rows32 != nullptr;
+        bool clear = R32;
         if (clear) { // decide from the fp32 row where that is safe
             uint32_t todo = alive;
             while (todo) {
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
             }
         }
         if (__builtin_expect(!clear, 0)) { // the exact fp64 row, the reference's decision rule
-            if (rows32)
+            if (R32)
                 exact_row(s, a);
             G = 0;
             uint32_t todo = alive;
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(256, 4) void k_smp_maps(const Model<N> m, const Chu
                 const int y = pick_state<N, true>(a, last ? nullptr : sAt + x * N, r, n, status, &gap);
                 // a draw within reach of the deviation these alpha rows were verified to: recorded, decided
                 // again on the serial recursion afterwards (draw_verify.hpp; only rows of a speculative pass)
-                if (__builtin_expect(watch.tol > 0.0 && rows32 && y >= 0 && gap <= watch.tol, 0))
+                if (__builtin_expect(watch.tol > 0.0 && R32 && y >= 0 && gap <= watch.tol, 0))
                     draw_record(watch, ch.traj[g], t0 + s, x, r, y, gap); // (k re-read: not kept live for this)
                 // (bit 3 of a nibble: no state can precede next state x here)
                 G |= (y < 0 ? (8u | (uint32_t)(n - 1)) : (uint32_t)y) << (4 * x);
