@@ -233,6 +233,11 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
                                                                     double *a_entry, double *a_exit, unsigned int *flags,
                                                                     unsigned long long *probe = nullptr)
 {
+#ifndef BHMM_TILE_PROBE_BUILD
+    // (production build: the in-kernel cycle probe compiles away -- its run-time tests cost every wavefront some
+    // fifteen instruction slots per step even when no probe buffer is given; -DBHMM_TILE_PROBE_BUILD brings it back)
+    probe = nullptr;
+#endif
     using G = TileGeo<NT>;
     constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX, NP = G::NP;
     __shared__ __attribute__((aligned(16))) double sX[2 * 16 * PX];
@@ -268,11 +273,13 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_fwd(const WideMo
         nlast[r] = nst[r] > 0 ? nst[r] - 1 : 0;
     }
     // (every wavefront holds all 16 rows: these are uniform over the workgroup)
-    const int nmax = tile_all_max(max(max(nst[0], nst[1]), max(nst[2], nst[3])));
+    // (uniform over the workgroup by construction -- said to the compiler, so that the loop and the tests on these
+    // bounds are scalar instructions instead of vector compares and exec-mask branches)
+    const int nmax = __builtin_amdgcn_readfirstlane(tile_all_max(max(max(nst[0], nst[1]), max(nst[2], nst[3]))));
     const int g4 = (nmax + 3) & ~3;
     // steps [g2, g3): every row of the tile is inside its main part
-    const int g2 = tile_all_max(max(max(r0[0], r0[1]), max(r0[2], r0[3])));
-    const int g3 = tile_all_min(min(min(nst[0], nst[1]), min(nst[2], nst[3]))) - 1;
+    const int g2 = __builtin_amdgcn_readfirstlane(tile_all_max(max(max(r0[0], r0[1]), max(r0[2], r0[3]))));
+    const int g3 = __builtin_amdgcn_readfirstlane(tile_all_min(min(min(nst[0], nst[1]), min(nst[2], nst[3])))) - 1;
 
     for (int e = tid; e < 16 * PX; e += tile_threads<SPLIT>())
         sX[e] = (e % PX) < n ? 1.0 / (double)n : 0.0; // warm-ups start from the uniform vector
@@ -709,6 +716,11 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
                                                            double *dstat, double *b_exit, double *b_entry,
                                                            unsigned int *flags, double *Wg, unsigned long long *probe = nullptr)
 {
+#ifndef BHMM_TILE_PROBE_BUILD
+    // (production build: the in-kernel cycle probe compiles away -- its run-time tests cost every wavefront some
+    // fifteen instruction slots per step even when no probe buffer is given; -DBHMM_TILE_PROBE_BUILD brings it back)
+    probe = nullptr;
+#endif
     using G = TileGeo<NT>;
     constexpr int TPW = G::TPW, KK = G::KK, PX = G::PX, NP = G::NP;
     static_assert(!(XIG && SPLIT), "the W rows are stored by the both-role wavefronts (w_store)");
@@ -779,6 +791,9 @@ __global__ __launch_bounds__(tile_threads<SPLIT>()) void k_tile_bwd(const WideMo
     // [0, g1): both are warm-up steps of every row, and none reads alpha yet (also not four steps
     // ahead); [g2, g3): both are main-part steps of every row (entered, before the last step, t > 0
     // also for what is fetched ahead); the rest: general
+    // (read from LDS, i.e. into vector registers: uniform all the same, and said so -- scalar loop control)
+    nmax = __builtin_amdgcn_readfirstlane(nmax), nstmin = __builtin_amdgcn_readfirstlane(nstmin);
+    emin = __builtin_amdgcn_readfirstlane(emin), emax = __builtin_amdgcn_readfirstlane(emax);
     const int g4 = (nmax + 3) & ~3;
     const int g1 = min(max(emin - 2 - TILE_PF, 0) & ~3, g4);
     const int g2 = min((emax + 1 + 3) & ~3, g4);
