@@ -98,7 +98,9 @@ static int tile_launch_fwd(bhmm_ctx *c, const WideModel &m, int which)
 {
     const Segs sg = segs_of(c, which);
     const TilePlan tp{c->d_tile_seg[which].p, c->w_ntiles[which]};
-    // BHMM_AMD_TILE_PROBE=1: cycles of the phases of a step (workgroup 0), printed after the pass
+    // BHMM_AMD_TILE_PROBE=1: cycles of the phases of a step (workgroup 0), printed after the pass -- in a library
+    // built with -DBHMM_TILE_PROBE_BUILD; the production build compiles the probe out of the kernels (the phase
+    // cycles then print as zeros, the kernel time of BHMM_AMD_TILE_PROBE=2 is unaffected)
     static const bool probe_on = getenv("BHMM_AMD_TILE_PROBE") != nullptr;
     unsigned long long *probe = nullptr;
     if (probe_on) {
