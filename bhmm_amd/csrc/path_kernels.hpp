@@ -2523,13 +2523,28 @@ __global__ __launch_bounds__(256) void k_pobs_lanes(const WideModel m, const voi
 
 // back-trace: one wavefront per trajectory stages 64 steps of back-pointers in LDS
 // (coalesced), lane 0 chases them (_hidden.c:269-272)
+// `bytes` back-pointer bytes (whole rows of n) to LDS: rows of whole 16-byte pieces (e.g. 64 states) go as 16-byte
+// loads -- four per lane for 64 steps of 64 states instead of 64 byte loads
+__device__ __forceinline__ void walk_tile_load(uint8_t *tile, const uint8_t *src, int bytes, int n, int lane)
+{
+    if ((n & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(tile);
+        for (int e = lane; e < (bytes >> 4); e += 64)
+            d4[e] = s4[e];
+    } else {
+        for (int e = lane; e < bytes; e += 64)
+            tile[e] = src[e];
+    }
+}
+
 template <typename PT>
 __global__ __launch_bounds__(64) void k_wide_viterbi_trace(const int64_t *off, int K, int n,
                                                            const uint8_t *ptr,
                                                            const int32_t *last_state,
                                                            PT *path)
 {
-    __shared__ uint8_t tile[64 * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64 * 64];
     __shared__ int32_t outp[64];
     const int k = blockIdx.x;
     const int lane = threadIdx.x;
@@ -2545,8 +2560,7 @@ __global__ __launch_bounds__(64) void k_wide_viterbi_trace(const int64_t *off, i
         const int64_t lo = (hi - 63 > 1) ? hi - 63 : 1;
         const int cnt = (int)(hi - lo + 1);
         const int64_t base = (o0 + lo) * n;
-        for (int e = lane; e < cnt * n; e += 64)
-            tile[e] = ptr[base + e];
+        walk_tile_load(tile, ptr + base, cnt * n, n, lane);
         __syncthreads();
         if (lane == 0) {
             for (int q = cnt - 1; q >= 0; --q) {
@@ -2574,7 +2588,7 @@ __global__ __launch_bounds__(64) void k_wide_vit_walk(const int64_t *off, const 
                                                       const uint8_t *ptr, uint8_t *maps,
                                                       const uint8_t *end_state, PT *path)
 {
-    __shared__ uint8_t tile[64 * 64 * NC];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64 * 64 * NC];
     __shared__ int32_t outp[64];
     const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= sg.nseg || sg.len[s] <= 0)
@@ -2596,8 +2610,7 @@ __global__ __launch_bounds__(64) void k_wide_vit_walk(const int64_t *off, const 
         const int64_t lo = (hi - 63 > low) ? hi - 63 : low;
         const int cnt = (int)(hi - lo + 1);
         const int64_t base = (o0 + lo) * n;
-        for (int e = lane; e < cnt * n; e += 64)
-            tile[e] = ptr[base + e];
+        walk_tile_load(tile, ptr + base, cnt * n, n, lane);
         __syncthreads();
         if constexpr (APPLY) {
             if (lane == 0) {
