@@ -455,6 +455,73 @@ def load_traffic(args, key):
     return ent
 
 
+def live_traffic(K, T, timeout=150.0):
+    """roofline.traffic measured by THIS run (N = 1 only): two child processes, `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes, MI355X_MICROARCH.md section HBM) over tools/pmc_r05.py --only-configs2 K T --
+    this run's workload drawn and run exactly as above, plus the guide's 1 GiB calibration copy.  Bytes =
+    1024 (2 FETCH_SIZE + WRITE_SIZE) of the two sweep launches of one E-step (mean of the last three E-steps);
+    the factor 2 is checked on the copy.  Returns None when rocprofv3 is not there, a pass fails or runs out of
+    time -- the offline figures of profiles/traffic_current.json stay in the line then."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    vals = {}
+    t_all = time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bhmm_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.join(ROOT, "tools", "pmc_r05.py"), "--only-configs2", str(K), str(T)]
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return None
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                return None
+            per = collections.defaultdict(list)
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] == ctr:
+                    per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            vals[ctr] = {k: sum(v[-3:]) / len(v[-3:]) for k, v in per.items()}
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    def pick(ctr, a, b):
+        hit = [v for k, v in vals[ctr].items() if a in k and b in k]
+        return hit[0] if hit else None
+    kb = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        p1 = pick(ctr, "k_estep_light<8, 1, true", ", 2>")
+        p2 = pick(ctr, "k_estep<8, 1, true", ", 3>")
+        cp = pick(ctr, "opyBuffer", "")
+        if p1 is None or p2 is None:
+            return None
+        kb[ctr] = (p1, p2, cp)
+    traffic = 1024.0 * (2.0 * (kb["FETCH_SIZE"][0] + kb["FETCH_SIZE"][1]) + kb["WRITE_SIZE"][0] + kb["WRITE_SIZE"][1])
+    return {"traffic": traffic,
+            "source": "this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each, child processes) over "
+                      "tools/pmc_r05.py --only-configs2; bytes = 1024 (2 FETCH_SIZE + WRITE_SIZE), P1 + P2 of one E-step",
+            "kb_per_launch": {"P1": {"FETCH_SIZE": kb["FETCH_SIZE"][0], "WRITE_SIZE": kb["WRITE_SIZE"][0]},
+                              "P2": {"FETCH_SIZE": kb["FETCH_SIZE"][1], "WRITE_SIZE": kb["WRITE_SIZE"][1]}},
+            "calibration_1GiB_copy_kb": {"FETCH_SIZE": kb["FETCH_SIZE"][2], "WRITE_SIZE": kb["WRITE_SIZE"][2],
+                                         "expected": "FETCH 524288 (half of the bytes read), WRITE 1048576"},
+            "seconds": time.perf_counter() - t_all}
+
+
 def roofline_block(wl, ser, args, steps_per_s_per_gpu):
     """algorithmic bytes of this rank's launch pair over its duration by HIP events
     (recorded on the launch stream inside the library), against the 8 TB/s HBM peak."""
@@ -872,6 +939,9 @@ def main():
                     help="trajectories in the 1-core CPU baseline of the headline (~10 s at 1e6 steps each)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="keep the offline counter figures (profiles/traffic_current.json) instead of two rocprofv3 "
+                         "--pmc passes in child processes (N = 1 only, about half a minute)")
     ap.add_argument("--no-steady", action="store_true",
                     help="skip the extra steady-state window (profiling runs: the kernel statistics then "
                          "cover exactly the warm-up and timed launches)")
@@ -1017,6 +1087,16 @@ def main():
                 assert out["target_50x_met"], "north-star target (>= 50x the reference CPU path) missed"
     ser.close()
     del ser
+
+    if rank == 0 and world == 1 and out is not None and not (args.no_live_traffic or args.no_secondary or args.only):
+        # roofline.traffic of THIS run (the engine above is closed: its 20 GB are free for the child processes)
+        lt = live_traffic(K, T)
+        if lt is not None:
+            rf = out["roofline"]
+            rf["traffic_offline"] = {"traffic": rf["traffic"], "source": rf["traffic_source"]}
+            rf["traffic"], rf["traffic_is_live"], rf["traffic_source"] = lt["traffic"], True, lt["source"]
+            rf["hbm_counter_frac"] = lt["traffic"] / (rf["sweep_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            rf["traffic_live_detail"] = {k: lt[k] for k in ("kb_per_launch", "calibration_1GiB_copy_kb", "seconds")}
 
     if not args.no_secondary:
         # the secondary measurements run on ALL ranks (their collectives need everyone)

@@ -15,9 +15,13 @@ stream = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(stream)
 rk = Ranks(torch, dist, 1, 0, 0, dev, "nccl", False, stream)
 shapes = {"configs2": (1024, 1000000), "configs1": (256, 100000)}
-if len(sys.argv) > 1:                       # a smaller configs[2] for a dry run: K T
-    shapes["configs2"] = (int(sys.argv[1]), int(sys.argv[2]))
-for wl in (workload_configs2(*shapes["configs2"]), workload_configs1(*shapes["configs1"])):
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+if len(argv) > 1:                           # a smaller configs[2] for a dry run: K T
+    shapes["configs2"] = (int(argv[0]), int(argv[1]))
+wls = [workload_configs2(*shapes["configs2"])]
+if "--only-configs2" not in sys.argv:       # (bench.py's live passes: the headline workload and the calibration copy)
+    wls.append(workload_configs1(*shapes["configs1"]))
+for wl in wls:
     ser = Series(rk, wl, wl.K, 0)
     for _ in range(4):                      # the first calibrates the warm-up; the last three are read
         ser.one_step()
