@@ -512,9 +512,51 @@ def live_traffic(K, T, timeout=150.0):
             return None
         kb[ctr] = (p1, p2, cp)
     traffic = 1024.0 * (2.0 * (kb["FETCH_SIZE"][0] + kb["FETCH_SIZE"][1]) + kb["WRITE_SIZE"][0] + kb["WRITE_SIZE"][1])
-    return {"traffic": traffic,
+    # third pass: vector instructions and the shader clock of the two sweep launches (for issue_frac); optional
+    issue = None
+    d = tempfile.mkdtemp(prefix="bhmm_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.join(ROOT, "tools", "pmc_r05.py"), "--only-configs2", str(K), str(T)]
+        p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                             stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = p.wait(timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            p.wait()
+            rc = -1
+        cf = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        kf = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        if rc == 0 and cf and kf:
+            dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kf[0]))}
+            rows = collections.defaultdict(dict)
+            names = {}
+            for r in csv.DictReader(open(cf[0])):
+                rows[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+                names[r["Dispatch_Id"]] = r["Kernel_Name"]
+            ph = {}
+            for key, a, b in (("P1", "k_estep_light<8, 1, true", ", 2>"), ("P2", "k_estep<8, 1, true", ", 3>")):
+                ds = [i for i, nm in names.items() if a in nm and b in nm and i in dur][-3:]
+                if ds:
+                    ns = sum(dur[i] for i in ds) / len(ds)
+                    clk = sum(rows[i].get("GRBM_GUI_ACTIVE", 0.0) for i in ds) / len(ds) / ns
+                    ph[key] = (sum(rows[i].get("SQ_INSTS_VALU", 0.0) for i in ds) / len(ds), clk / 8.0 if clk > 4.0 else clk, ns / 1e3)
+            if len(ph) == 2 and min(ph["P1"][1], ph["P2"][1]) > 0.5:
+                i1, i2 = ph["P1"][0], ph["P2"][0]
+                issue = {"valu_wave_insts_per_launch": i1 + i2,
+                         # one vector instruction per SIMD and four cycles at the clock the counters saw
+                         "issue_ceiling_insts_per_us_per_simd": (i1 + i2) / (i1 / (250.0 * ph["P1"][1]) + i2 / (250.0 * ph["P2"][1])),
+                         "under_counters": {"P1_us": ph["P1"][2], "P2_us": ph["P2"][2],
+                                            "P1_clock_GHz": ph["P1"][1], "P2_clock_GHz": ph["P2"][1]}}
+    except Exception:
+        issue = None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return {"traffic": traffic, "issue": issue,
             "source": "this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each, child processes) over "
-                      "tools/pmc_r05.py --only-configs2; bytes = 1024 (2 FETCH_SIZE + WRITE_SIZE), P1 + P2 of one E-step",
+                      "tools/pmc_r05.py --only-configs2; bytes = 1024 (2 FETCH_SIZE + WRITE_SIZE), P1 + P2 of one E-step; "
+                      "issue_frac from a third pass (GRBM_GUI_ACTIVE, SQ_INSTS_VALU) when it succeeds",
             "kb_per_launch": {"P1": {"FETCH_SIZE": kb["FETCH_SIZE"][0], "WRITE_SIZE": kb["WRITE_SIZE"][0]},
                               "P2": {"FETCH_SIZE": kb["FETCH_SIZE"][1], "WRITE_SIZE": kb["WRITE_SIZE"][1]}},
             "calibration_1GiB_copy_kb": {"FETCH_SIZE": kb["FETCH_SIZE"][2], "WRITE_SIZE": kb["WRITE_SIZE"][2],
@@ -1097,6 +1139,12 @@ def main():
             rf["traffic"], rf["traffic_is_live"], rf["traffic_source"] = lt["traffic"], True, lt["source"]
             rf["hbm_counter_frac"] = lt["traffic"] / (rf["sweep_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             rf["traffic_live_detail"] = {k: lt[k] for k in ("kb_per_launch", "calibration_1GiB_copy_kb", "seconds")}
+            if lt.get("issue"):
+                iss = lt["issue"]
+                rf["issue_frac_offline"] = rf["issue_frac"]
+                rf["issue_frac"] = iss["valu_wave_insts_per_launch"] / (iss["issue_ceiling_insts_per_us_per_simd"] * 1024 *
+                                                                       rf["sweep_kernel_ms"] * 1e3)
+                rf["traffic_live_detail"]["issue"] = iss
 
     if not args.no_secondary:
         # the secondary measurements run on ALL ranks (their collectives need everyone)
